@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbp/s of the `match` hot path on synthetic 150 bp reads, k=31 (BASELINE.json config 2).
+
+A step = one pass of the hot path over one batch: gs_match_reset + gs_match_submit (reads already resident
+in HBM) + the per-taxid table merge (RCCL all-reduce / bitmap all-gather when N > 1) + gs_match_finish.
+Weak scaling: every rank classifies `--reads` reads of its own slice of the global read stream against a
+full replica of the store.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READ_LEN = 150
+K = 31
+BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+class _DevArray:
+    """zero-copy view of a raw device pointer for torch.as_tensor"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": typestr, "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--check-reads", type=int, default=200_000, help="reads cross-checked against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import genestrip_amd as ga
+    from genestrip_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (genestrip_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- inputs: store replica per GPU, this rank's slice of the read stream generated directly in HBM
+    db = synth.SynthDB(k=K)
+    store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, device=local_rank)
+    info = store.info
+    n = args.reads
+    first = rank * n
+    gen = torch.from_numpy(db.genomes).to(dev)
+    dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN, first=first)
+    torch.cuda.synchronize()
+
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
+    st = m.device_state()
+    nv = db.n_values
+    t_sums = torch.as_tensor(_DevArray(st["sums"], nv * ga.N_SUMS, "<i8"), device=dev)
+    t_max = torch.as_tensor(_DevArray(st["max_keys"], nv, "<i8"), device=dev)
+    t_dsum = torch.as_tensor(_DevArray(st["dsums"], nv * ga.N_DCOLS, "<f8"), device=dev)
+    t_bits = torch.as_tensor(_DevArray(st["bitmap"], st["bitmap_words"], "<i4"), device=dev)
+    t_gather = torch.empty(world * st["bitmap_words"], dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        m.reset()
+        m.submit(dseq, doff, first, n_reads=n)
+        if world > 1:
+            m.sync()
+            dist.all_reduce(t_sums, op=dist.ReduceOp.SUM)
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t_dsum, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(t_gather, t_bits)
+            torch.cuda.synchronize()
+            m.or_bitmap(t_gather.data_ptr(), world)
+        return m.finish()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    m.kernel_time()
+    launches0, ms0 = m.kernel_time()
+    barrier()
+    t0 = time.perf_counter()
+    table = None
+    for _ in range(args.steps):
+        table, _ = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches1, ms1 = m.kernel_time()
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    n_launch = max(1, launches1 - launches0)
+    kern_ms = (ms1 - ms0) / n_launch
+
+    total_bases = float(world) * n * READ_LEN * args.steps
+    gbps = total_bases / elapsed / 1e9
+    achieved = n * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9  # GB/s, algorithmic bytes of one launch / its duration
+
+    out = {
+        "metric": "Gbp/s classified (match goal), k=31, 150bp reads; bit-exact CSV counts",
+        "value": round(gbps, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "match: %d synthetic 150 bp reads per GPU, k=31, %d-k-mer / %d-taxid store resident in HBM "
+                               "(BASELINE.json configs[1])" % (n, db.n_entries, len(db.species_vi)),
+                   "reads_per_gpu": n, "read_len": READ_LEN, "k": K, "store_kmers": int(db.n_entries),
+                   "store_table_bytes": int(info.table_bytes), "parallelism": "read-sharded x%d, store replicated" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "gs_match_kernel", "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": n * BYTES_PER_READ},
+    }
+
+    # ---- parity gate + CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same reads
+    if rank == 0:
+        from oracle import gs_oracle as orc
+        cores = os.cpu_count() or 1
+        odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
+        nchk = min(args.check_reads, n)
+        seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
+        orun = orc.MatchRun(odb)
+        t1 = time.perf_counter()
+        orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+        dt_chk = time.perf_counter() - t1
+        otable, _ = orun.finish()
+        if world == 1:
+            m.reset()
+            m.submit(dseq, doff, first, n_reads=nchk)
+            gtable, _ = m.finish()
+            out["parity"] = {"reads_checked": nchk, "bit_exact": bool(np.array_equal(otable, gtable))}
+            if not out["parity"]["bit_exact"]:
+                out["value"] = None  # a throughput without parity does not count
+            if args.cpu_seconds > 0:
+                rate = nchk / dt_chk
+                ns = int(min(n, max(nchk, rate * args.cpu_seconds)))
+                seq, off = synth.reads_host(db.genomes, ns, read_len=READ_LEN, first=first)
+                orun = orc.MatchRun(odb)
+                t1 = time.perf_counter()
+                orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+                dt = time.perf_counter() - t1
+                out["cpu_baseline"] = {
+                    "value": round(ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
+                    "sample": "first %d reads of the same stream, C restatement of the Java path (sorted array + "
+                              "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,314 @@
+"""ctypes binding of include/gsgpu.h (libgsgpu.so).
+
+Host-side mirror of the reference interface for the hot path:
+
+* ``DeviceKMerStore``   <- KMerStore + SmallTaxTree as the matcher sees them (C/store/KMerStore.java:45-317)
+* ``FastqKMerMatcher``  <- C/match/FastqKMerMatcher.java (runMatcher :181-235, matchRead :327-535)
+* ``DeviceBloomFilter`` <- KMerProbFilter (C/bloom/AbstractKMerBloomFilter.java, BlockedKMerBloomFilter.java)
+* ``FastqBloomFilter``  <- C/bloom/FastqBloomFilter.java (runFilter :80-89, isAcceptRead :120-161)
+
+numpy arrays are host batches (GS_MEM_HOST); objects exposing ``data_ptr()`` (torch tensors on the GPU) are
+passed as device batches (GS_MEM_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+N_COLS, N_DCOLS, N_SUMS = 10, 4, 7
+COLS = ("reads", "kmers from reads", "kmers", "unique kmers", "contigs", "contig len sq sum", "max contig length",
+        "reads >=1 kmer", "reads bps", "max contig read no")
+MEM_HOST, MEM_DEVICE = 0, 1
+F_FOUND, F_RETURNED, F_COUNTED = 1, 2, 4
+BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
+
+# every symbol include/gsgpu.h declares (checked by the CPU test-suite against the built library)
+ABI_SYMBOLS = (
+    "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
+    "gs_db_create", "gs_db_get_info", "gs_db_destroy",
+    "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
+    "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time",
+    "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
+)
+
+
+class GsError(RuntimeError):
+    """non-zero status from the C ABI (the JNI shim turns the same codes into RuntimeException)"""
+
+    def __init__(self, code, msg):
+        super().__init__(f"gsgpu error {code}: {msg}")
+        self.code = code
+
+
+class DbInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("n_values", C.c_int32), ("n_entries", C.c_int64), ("n_stored", C.c_int64),
+                ("n_buckets", C.c_int64), ("table_bytes", C.c_int64), ("max_displacement", C.c_int32),
+                ("value_bits", C.c_int32)]
+
+
+class _MatchCfg(C.Structure):
+    _fields_ = [("classify", C.c_int32), ("count_unique", C.c_int32), ("max_paths", C.c_int32),
+                ("threshold", C.c_int32), ("max_read_tax_err", C.c_double), ("max_read_class_err", C.c_double),
+                ("profile", C.c_int32), ("reserved", C.c_int32)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libgsgpu.so")
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  libgsgpu.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel ships its own
+    copy (same SONAME) next to libtorch_hip.so.  Whichever copy is loaded first serves both, so when torch is
+    installed its copy is loaded first -- then torch (device memory, torch.distributed/RCCL in bench.py and
+    the tests) and this library share a single runtime and a single set of device contexts.  Set
+    GS_HIP_RUNTIME=system to skip this (e.g. under a JVM without torch)."""
+    if os.environ.get("GS_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
+def lib():
+    """load libgsgpu.so; raises if it was not built (no fallback implementation exists)"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GsError(-6, f"{path} is missing: build it with `make -C genestrip_amd/csrc` (hipcc, gfx950); "
+                          "genestrip_amd has no CPU fallback")
+    _preload_hip_runtime()
+    L = C.CDLL(path)
+    vp, i32, i64, dbl, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_int
+    sig = {
+        "gs_last_error": (C.c_char_p, []), "gs_strerror": (C.c_char_p, [ci]), "gs_abi_version": (ci, []),
+        "gs_device_count": (ci, [vp]),
+        "gs_db_create": (ci, [vp, ci, ci, i64, vp, vp, i32, vp]), "gs_db_get_info": (ci, [vp, vp]),
+        "gs_db_destroy": (ci, [vp]),
+        "gs_match_begin": (ci, [vp, vp, vp]), "gs_match_submit": (ci, [vp, vp, vp, i64, i64, ci, vp, vp]),
+        "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
+        "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
+        "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
+        "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
+        "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
+        "gs_filter_kernel_time": (ci, [vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise GsError(rc, (lib().gs_last_error() or b"").decode(errors="replace"))
+
+
+def abi_version():
+    return lib().gs_abi_version()
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().gs_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a):
+    """(pointer, mem kind) of a numpy array (host) or a tensor-like with data_ptr() (device)"""
+    if a is None:
+        return None, None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p), MEM_HOST
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr()), (MEM_DEVICE if getattr(a, "is_cuda", True) else MEM_HOST)
+    raise TypeError(f"unsupported buffer {type(a)}")
+
+
+class DeviceKMerStore:
+    """k-mer -> value-index store plus taxonomy, resident in HBM (gs_db)."""
+
+    def __init__(self, k, kmers_sorted, value_idx, n_values, parent_vi=None, device=0):
+        kmers = np.ascontiguousarray(kmers_sorted, dtype=np.int64)
+        vidx = np.ascontiguousarray(value_idx, dtype=np.int32)
+        if len(kmers) != len(vidx):
+            raise ValueError("kmers / value_idx length mismatch")
+        pv = None if parent_vi is None else np.ascontiguousarray(parent_vi, dtype=np.int32)
+        if pv is not None and len(pv) != n_values:
+            raise ValueError("parent_vi must have n_values entries")
+        self.h = C.c_void_p()
+        self.k, self.n_values, self.device = k, n_values, device
+        _check(lib().gs_db_create(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                  vidx.ctypes.data_as(C.c_void_p), n_values,
+                                  None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+
+    @property
+    def info(self):
+        i = DbInfo()
+        _check(lib().gs_db_get_info(self.h, C.byref(i)))
+        return i
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gs_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatchConfig:
+    """the GSConfigKey values that parameterise matchRead (C/GSConfigKey.java:302-350)"""
+
+    def __init__(self, classify=True, count_unique=True, max_paths=10, threshold=1, max_read_tax_err=-1.0,
+                 max_read_class_err=-1.0, profile=False):
+        self.classify, self.count_unique, self.max_paths, self.threshold = classify, count_unique, max_paths, threshold
+        self.max_read_tax_err, self.max_read_class_err, self.profile = max_read_tax_err, max_read_class_err, profile
+
+    def _c(self):
+        return _MatchCfg(int(self.classify), int(self.count_unique), self.max_paths, self.threshold,
+                         self.max_read_tax_err, self.max_read_class_err, int(self.profile), 0)
+
+
+class FastqKMerMatcher:
+    """one runMatcher() scope: begin -> submit batches -> finish."""
+
+    def __init__(self, store, config=None):
+        self.store = store
+        self.config = config or MatchConfig()
+        cfg = self.config._c()
+        self.h = C.c_void_p()
+        _check(lib().gs_match_begin(C.byref(self.h), store.h, C.byref(cfg)))
+
+    def submit(self, seq, offsets, first_read_no=0, class_vi=None, flags=None, n_reads=None):
+        ps, mem = _ptr(seq)
+        po, mem2 = _ptr(offsets)
+        assert mem == mem2, "seq and offsets must live in the same memory space"
+        if n_reads is None:
+            n_reads = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
+        pc, _ = _ptr(class_vi)
+        pf, _ = _ptr(flags)
+        _check(lib().gs_match_submit(self.h, ps, po, n_reads, first_read_no, mem, pc, pf))
+
+    def match_reads(self, seq, offsets, first_read_no=0):
+        """host batch -> (class_vi, flags) numpy arrays (the per-read outcome of matchRead)"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        cv = np.full(n, -1, dtype=np.int32)
+        fl = np.zeros(n, dtype=np.uint8)
+        if len(seq) == 0:
+            seq = np.zeros(1, dtype=np.uint8)
+        self.submit(seq, offsets, first_read_no, cv, fl)
+        return cv, fl
+
+    def sync(self):
+        _check(lib().gs_match_sync(self.h))
+
+    def finish(self):
+        nv = self.store.n_values
+        t = np.zeros((nv, N_COLS), dtype=np.int64)
+        d = np.zeros((nv, N_DCOLS), dtype=np.float64)
+        _check(lib().gs_match_finish(self.h, t.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p)))
+        return t, d
+
+    def reset(self):
+        _check(lib().gs_match_reset(self.h))
+
+    def device_state(self):
+        """raw device pointers of the accumulators: dict(sums, max_keys, dsums, bitmap, bitmap_words)"""
+        s, m, d, b = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        w = C.c_int64(0)
+        _check(lib().gs_match_device_state(self.h, C.byref(s), C.byref(m), C.byref(d), C.byref(b), C.byref(w)))
+        return dict(sums=s.value, max_keys=m.value, dsums=d.value, bitmap=b.value, bitmap_words=w.value)
+
+    def or_bitmap(self, parts_ptr, n_parts):
+        _check(lib().gs_match_or_bitmap(self.h, C.c_void_p(parts_ptr), n_parts))
+
+    def kernel_time(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        _check(lib().gs_match_kernel_time(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gs_match_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBloomFilter:
+    """device copy of a reference index filter (bits + hash factors replicated exactly)."""
+
+    def __init__(self, kind, bits, hash_factors, words, n_hashes=None, device=0):
+        hf = np.ascontiguousarray(hash_factors, dtype=np.int64)
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        if n_hashes is None:
+            n_hashes = len(hf)
+        self.h = C.c_void_p()
+        _check(lib().gs_bloom_create(C.byref(self.h), device, kind, bits, n_hashes, hf.ctypes.data_as(C.c_void_p),
+                                     w.ctypes.data_as(C.c_void_p), len(w)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gs_bloom_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FastqBloomFilter:
+    def __init__(self, k, bloom, min_pos_count=1, positive_ratio=0.2, profile=False):
+        self.k, self.bloom, self.min_pos_count, self.positive_ratio = k, bloom, min_pos_count, positive_ratio
+        self.profile = profile
+
+    def submit(self, seq, offsets, accept, n_reads=None):
+        ps, mem = _ptr(seq)
+        po, _ = _ptr(offsets)
+        pa, _ = _ptr(accept)
+        if n_reads is None:
+            n_reads = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
+        _check(lib().gs_filter_submit(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, ps, po, n_reads,
+                                      mem, pa, int(self.profile)))
+
+    def accept_reads(self, seq, offsets):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        acc = np.zeros(len(offsets) - 1, dtype=np.uint8)
+        if len(seq) == 0:
+            seq = np.zeros(1, dtype=np.uint8)
+        self.submit(seq, offsets, acc)
+        return acc
+
+    def sync(self):
+        _check(lib().gs_filter_sync(self.bloom.h))
+
+    def kernel_time(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        _check(lib().gs_filter_kernel_time(self.bloom.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value

@@ -1,0 +1,814 @@
+// gs_api.cpp -- C ABI (include/gsgpu.h) over the gfx950 kernels: host-side table build, HBM residency,
+// stream/event plumbing.  No CPU fallback exists: every entry point needs a HIP device and fails with
+// GS_E_NODEVICE / GS_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gs_layout.h"
+#include "gs_params.h"
+
+typedef unsigned long long u64;
+
+extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
+                                           hipStream_t stream);
+extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
+                                              int32_t n_values, u64 *unique, hipStream_t stream);
+extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
+                                           hipStream_t stream);
+extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
+extern "C" int gs_match_occupancy(int lds_stats);
+extern "C" int gs_filter_occupancy();
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP,                              \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+extern "C" const char *gs_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char *gs_strerror(int code) {
+    switch (code) {
+    case GS_OK: return "ok";
+    case GS_E_INVALID: return "invalid argument";
+    case GS_E_NOMEM: return "out of memory";
+    case GS_E_HIP: return "HIP runtime error";
+    case GS_E_UNSUPPORTED: return "unsupported";
+    case GS_E_STATE: return "invalid call order";
+    case GS_E_NODEVICE: return "no usable gfx950 device";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+extern "C" int gs_device_count(int *n) {
+    if (!n) return fail(GS_E_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *n = 0;
+        return fail(GS_E_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *n = c;
+    return GS_OK;
+}
+
+static int use_device(int device) {
+    int c = 0;
+    int rc = gs_device_count(&c);
+    if (rc) return rc;
+    if (device < 0 || device >= c) return fail(GS_E_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// store build
+// ---------------------------------------------------------------------------------------------------
+struct gs_db {
+    int device = 0;
+    gs_db_info info{};
+    GsDbDev dev{};
+    u64 *d_table = nullptr;
+    int32_t *d_tree = nullptr;  // parent | depth | tin | tout
+    int n_cu = 256;
+};
+
+// reference (interleaved, first base in the top bits) -> planar key; also reports reachability:
+// the reference only ever queries max(fwd, revcomp) (CGAT.java:145-147), so a stored key that is smaller
+// than its reverse complement can never be hit.
+static inline bool java_to_planar(u64 x, int k, u64 &key) {
+    uint32_t hi = 0, lo = 0;
+    u64 rc = 0;
+    for (int i = 0; i < k; i++) {
+        uint32_t c = (uint32_t)(x >> (2 * (k - 1 - i))) & 3u;
+        hi |= (c >> 1) << i;
+        lo |= (c & 1u) << i;
+        rc |= (u64)(c ^ 1u) << (2 * i);  // base i complemented lands at position k-1-i from the top
+    }
+    key = ((u64)hi << GS_PLANE_SHIFT) | lo;
+    return x >= rc;
+}
+
+static int bits_for(u64 v) {
+    int b = 0;
+    while (v) {
+        b++;
+        v >>= 1;
+    }
+    return b;
+}
+
+extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
+                            int32_t n_values, const int32_t *parent_vi) {
+    if (!out) return fail(GS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
+    if (n < 0 || n_values < 1 || (n > 0 && (!kmers || !vidx))) return fail(GS_E_INVALID, "bad store arrays");
+    int rc = use_device(device);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++) {
+        if (vidx[i] < 0 || vidx[i] >= n_values) return fail(GS_E_INVALID, "value_idx out of range");
+        if (i && kmers[i] <= kmers[i - 1]) return fail(GS_E_INVALID, "kmers_sorted must be strictly ascending");
+        if (kmers[i] < 0 || (k < 31 && (u64)kmers[i] >> (2 * k))) return fail(GS_E_INVALID, "k-mer exceeds 2k bits");
+    }
+    // ---- tree arrays
+    std::vector<int32_t> parent(n_values), depth(n_values, 0), tin(n_values, 0), tout(n_values, 0);
+    for (int32_t v = 0; v < n_values; v++) {
+        int32_t p = parent_vi ? parent_vi[v] : -1;
+        if (p < -2 || p >= n_values || p == v) return fail(GS_E_INVALID, "parent_vi out of range");
+        parent[v] = p;
+    }
+    {
+        std::vector<std::vector<int32_t>> kids(n_values);
+        std::vector<int32_t> roots;
+        for (int32_t v = 0; v < n_values; v++) {
+            if (parent[v] >= 0) {
+                if (parent[parent[v]] == -2) return fail(GS_E_INVALID, "parent_vi points at a value without a node");
+                kids[parent[v]].push_back(v);
+            } else if (parent[v] == -1)
+                roots.push_back(v);
+        }
+        int32_t counter = 0, visited = 0;
+        std::vector<std::pair<int32_t, size_t>> stack;
+        for (int32_t root : roots) {
+            stack.push_back({root, 0});
+            tin[root] = counter++;
+            depth[root] = 0;
+            visited++;
+            while (!stack.empty()) {
+                auto &top = stack.back();
+                if (top.second < kids[top.first].size()) {
+                    int32_t c = kids[top.first][top.second++];
+                    tin[c] = counter++;
+                    depth[c] = (int32_t)stack.size();
+                    visited++;
+                    stack.push_back({c, 0});
+                } else {
+                    tout[top.first] = counter;
+                    stack.pop_back();
+                }
+            }
+        }
+        int32_t nodes = 0;
+        for (int32_t v = 0; v < n_values; v++) nodes += parent[v] != -2;
+        if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
+    }
+    // ---- keys
+    std::vector<u64> hkey;
+    std::vector<int32_t> hval;
+    hkey.reserve((size_t)n);
+    hval.reserve((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        u64 key;
+        bool reachable = java_to_planar((u64)kmers[i], k, key);
+        if (!reachable || parent[vidx[i]] == -2) continue;
+        hkey.push_back(gs_mix62(key));
+        hval.push_back(vidx[i]);
+    }
+    const int64_t ns = (int64_t)hkey.size();
+    const int vbits = std::max(1, bits_for((u64)n_values));
+    double load = 2.0;
+    if (const char *e = getenv("GS_BUCKET_LOAD")) {
+        double v = atof(e);
+        if (v > 0.05 && v <= 6.0) load = v;
+    }
+    int b = std::max(vbits, 4);
+    while ((double)(1ULL << b) * load < (double)ns) b++;
+    std::vector<u64> table;
+    int max_disp = 0;
+    for (;; b++) {
+        if (b > 29) return fail(GS_E_UNSUPPORTED, "store too large for 32-bit slot indices");
+        const u64 nb = 1ULL << b, mask = nb - 1;
+        table.assign((size_t)nb * GS_SLOTS_PER_BUCKET, 0);
+        std::vector<uint8_t> fill((size_t)nb, 0);
+        bool ok = true;
+        max_disp = 0;
+        for (int64_t i = 0; i < ns && ok; i++) {
+            const u64 h = hkey[i], home = h & mask, rem = h >> b;
+            int d = 0;
+            for (; d <= GS_MAX_DISP; d++) {
+                const u64 bk = (home + d) & mask;
+                if (fill[bk] < GS_SLOTS_PER_BUCKET) {
+                    table[bk * GS_SLOTS_PER_BUCKET + fill[bk]++] =
+                        (rem << (vbits + 2)) | ((u64)d << vbits) | (u64)(hval[i] + 1);
+                    break;
+                }
+            }
+            if (d > GS_MAX_DISP) ok = false;
+            max_disp = std::max(max_disp, d);
+        }
+        if (ok) break;
+    }
+    gs_db *db = new gs_db();
+    db->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t tbytes = table.size() * sizeof(u64);
+    hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
+    if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(db->d_table);
+        hipFree(db->d_tree);
+        delete db;
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
+    }
+    db->info.k = k;
+    db->info.n_values = n_values;
+    db->info.n_entries = n;
+    db->info.n_stored = ns;
+    db->info.n_buckets = (int64_t)1 << b;
+    db->info.table_bytes = (int64_t)tbytes;
+    db->info.max_displacement = max_disp;
+    db->info.value_bits = vbits;
+    db->dev.table = db->d_table;
+    db->dev.bucket_bits = (uint32_t)b;
+    db->dev.vbits = (uint32_t)vbits;
+    db->dev.bucket_mask = (1ULL << b) - 1;
+    db->dev.k = k;
+    db->dev.n_values = n_values;
+    db->dev.parent = db->d_tree;
+    db->dev.depth = db->d_tree + n_values;
+    db->dev.tin = db->d_tree + 2 * (size_t)n_values;
+    db->dev.tout = db->d_tree + 3 * (size_t)n_values;
+    *out = db;
+    return GS_OK;
+}
+
+extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
+    if (!db || !info) return fail(GS_E_INVALID, "NULL argument");
+    *info = db->info;
+    return GS_OK;
+}
+
+extern "C" int gs_db_destroy(gs_db *db) {
+    if (!db) return GS_OK;
+    hipSetDevice(db->device);
+    hipFree(db->d_table);
+    hipFree(db->d_tree);
+    delete db;
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// match runs
+// ---------------------------------------------------------------------------------------------------
+struct gs_run {
+    gs_db *db = nullptr;
+    gs_match_cfg cfg{};
+    hipStream_t stream = nullptr;
+    int64_t *d_sums = nullptr;
+    int64_t *d_max = nullptr;
+    double *d_dsums = nullptr;
+    uint32_t *d_bitmap = nullptr;
+    int64_t bitmap_words = 0;
+    u64 *d_unique = nullptr;
+    unsigned int *d_long_count = nullptr;
+    uint32_t *d_long_list = nullptr;
+    int64_t long_cap = 0;
+    int32_t *d_scratch = nullptr;  // long-read kernel: per wave tag[n_values] | cnt[n_values]
+    uint32_t *d_serial = nullptr;
+    int long_grid = 0;
+    // host staging (GS_MEM_HOST)
+    uint8_t *d_seq = nullptr;
+    uint64_t *d_off = nullptr;
+    int32_t *d_class = nullptr;
+    uint8_t *d_flags = nullptr;
+    size_t seq_cap = 0, reads_cap = 0;
+    int grid = 0;
+    // profiling
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int64_t launches = 0;
+    double total_ms = 0;
+};
+
+static int run_clear(gs_run *run) {
+    const size_t nv = (size_t)run->db->info.n_values;
+    HIP_TRY(hipMemsetAsync(run->d_sums, 0, sizeof(int64_t) * nv * GS_N_SUMS, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
+    return GS_OK;
+}
+
+static void run_free(gs_run *run) {
+    if (!run) return;
+    hipSetDevice(run->db->device);
+    for (auto &p : run->pending) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    hipFree(run->d_sums);
+    hipFree(run->d_max);
+    hipFree(run->d_dsums);
+    hipFree(run->d_bitmap);
+    hipFree(run->d_unique);
+    hipFree(run->d_long_count);
+    hipFree(run->d_long_list);
+    hipFree(run->d_scratch);
+    hipFree(run->d_serial);
+    hipFree(run->d_seq);
+    hipFree(run->d_off);
+    hipFree(run->d_class);
+    hipFree(run->d_flags);
+    if (run->stream) hipStreamDestroy(run->stream);
+    delete run;
+}
+
+extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) {
+    if (!out || !db || !cfg) return fail(GS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (cfg->max_paths < 1 || cfg->max_paths > 64) return fail(GS_E_INVALID, "max_paths must be in [1,64]");
+    HIP_TRY(hipSetDevice(db->device));
+    gs_run *run = new gs_run();
+    run->db = db;
+    run->cfg = *cfg;
+    const size_t nv = (size_t)db->info.n_values;
+    run->bitmap_words = (db->info.n_buckets * GS_SLOTS_PER_BUCKET + 31) / 32;
+    hipError_t e = hipStreamCreateWithFlags(&run->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_max, sizeof(int64_t) * nv);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_dsums, sizeof(double) * nv * GS_N_DCOLS);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_bitmap, sizeof(uint32_t) * (size_t)run->bitmap_words);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, sizeof(unsigned int));
+    if (e != hipSuccess) {
+        run_free(run);
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("run alloc: ") + hipGetErrorString(e));
+    }
+    int occ = gs_match_occupancy(db->info.n_values <= GS_NV_LDS);
+    if (occ < 1) occ = 1;
+    if (const char *ev = getenv("GS_MATCH_BLOCKS_PER_CU")) {
+        int v = atoi(ev);
+        if (v >= 1 && v <= 16) occ = v;
+    }
+    run->grid = db->n_cu * occ;
+    int rc = run_clear(run);
+    if (rc) {
+        run_free(run);
+        return rc;
+    }
+    *out = run;
+    return GS_OK;
+}
+
+static int collect_events(gs_run *run) {
+    for (auto &p : run->pending) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        run->total_ms += ms;
+        run->launches++;
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    run->pending.clear();
+    return GS_OK;
+}
+
+static int ensure_long(gs_run *run, int64_t n_reads) {
+    if (run->long_cap < n_reads) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_long_list);
+        run->d_long_list = nullptr;
+        int64_t cap = std::max<int64_t>(n_reads, 1024);
+        HIP_TRY(hipMalloc((void **)&run->d_long_list, sizeof(uint32_t) * (size_t)cap));
+        run->long_cap = cap;
+    }
+    if (!run->d_scratch) {
+        // long-read kernel: a modest persistent grid, each wave owns tag[n_values] + cnt[n_values]
+        const size_t nv = (size_t)run->db->info.n_values;
+        int grid = run->db->n_cu;
+        while (grid > 8 && (size_t)grid * 4 * nv * 2 * sizeof(int32_t) > ((size_t)2 << 30)) grid /= 2;
+        run->long_grid = grid;
+        const size_t waves = (size_t)grid * (GS_BLOCK / 64);
+        HIP_TRY(hipMalloc((void **)&run->d_scratch, waves * nv * 2 * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void **)&run->d_serial, waves * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(run->d_scratch, 0, waves * nv * 2 * sizeof(int32_t), run->stream));
+        HIP_TRY(hipMemsetAsync(run->d_serial, 0, waves * sizeof(uint32_t), run->stream));
+    }
+    return GS_OK;
+}
+
+static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int64_t first_read_no,
+                        int32_t *d_class, uint8_t *d_flags) {
+    if (n_reads > (int64_t)0xffffffffLL) return fail(GS_E_INVALID, "more than 2^32-1 reads in one batch");
+    int rc = ensure_long(run, n_reads);
+    if (rc) return rc;
+    GsMatchParams P{};
+    P.db = run->db->dev;
+    P.seq = d_seq;
+    P.off = d_off;
+    P.n_reads = n_reads;
+    P.first_read_no = first_read_no;
+    P.classify = run->cfg.classify;
+    P.count_unique = run->cfg.count_unique;
+    P.max_paths = run->cfg.max_paths;
+    P.threshold = run->cfg.threshold;
+    P.max_read_tax_err = run->cfg.max_read_tax_err;
+    P.max_read_class_err = run->cfg.max_read_class_err;
+    P.sums = run->d_sums;
+    P.max_keys = run->d_max;
+    P.dsums = run->d_dsums;
+    P.bitmap = run->d_bitmap;
+    P.class_vi = d_class;
+    P.flags = d_flags;
+    P.long_count = run->d_long_count;
+    P.long_list = run->d_long_list;
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
+    int grid = (int)std::min<int64_t>(run->grid, (n_reads + (GS_BLOCK / 64) - 1) / (GS_BLOCK / 64));
+    if (grid < 1) grid = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (run->cfg.profile) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, run->stream));
+    }
+    HIP_TRY(gs_launch_match(&P, grid, run->stream));
+    if (run->cfg.profile) {
+        HIP_TRY(hipEventRecord(e1, run->stream));
+        run->pending.push_back({e0, e1});
+    }
+    // reads with more than 128 k-mer positions were queued; the long-read kernel drains the queue
+    HIP_TRY(gs_launch_match_long(&P, run->long_grid, run->d_scratch, run->d_serial, run->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                               int64_t first_read_no, int mem, int32_t *class_vi, uint8_t *flags) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (n_reads < 0 || (n_reads > 0 && (!seq || !offsets))) return fail(GS_E_INVALID, "bad batch arrays");
+    if (n_reads == 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (mem == GS_MEM_DEVICE) return launch_batch(run, seq, offsets, n_reads, first_read_no, class_vi, flags);
+    if (mem != GS_MEM_HOST) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    // host batch: stage to HBM (synchronous)
+    const size_t nbytes = (size_t)(offsets[n_reads] - offsets[0]);
+    if (run->seq_cap < nbytes + 1) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_seq);
+        run->d_seq = nullptr;
+        run->seq_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_seq, nbytes + 1));
+        run->seq_cap = nbytes + 1;
+    }
+    if (run->reads_cap < (size_t)n_reads) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_off);
+        hipFree(run->d_class);
+        hipFree(run->d_flags);
+        run->d_off = nullptr;
+        run->d_class = nullptr;
+        run->d_flags = nullptr;
+        run->reads_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+        HIP_TRY(hipMalloc((void **)&run->d_class, sizeof(int32_t) * (size_t)n_reads));
+        HIP_TRY(hipMalloc((void **)&run->d_flags, (size_t)n_reads));
+        run->reads_cap = (size_t)n_reads;
+    }
+    // offsets are rebased so that the staged slice starts at 0
+    std::vector<uint64_t> rel;
+    const uint64_t *hoff = offsets;
+    if (offsets[0] != 0) {
+        rel.resize((size_t)n_reads + 1);
+        for (int64_t i = 0; i <= n_reads; i++) rel[(size_t)i] = offsets[i] - offsets[0];
+        hoff = rel.data();
+    }
+    HIP_TRY(hipMemcpyAsync(run->d_seq, seq + offsets[0], nbytes, hipMemcpyHostToDevice, run->stream));
+    HIP_TRY(hipMemcpyAsync(run->d_off, hoff, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, run->stream));
+    int rc = launch_batch(run, run->d_seq, run->d_off, n_reads, first_read_no, class_vi ? run->d_class : nullptr,
+                          flags ? run->d_flags : nullptr);
+    if (rc) return rc;
+    if (class_vi)
+        HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
+}
+
+extern "C" int gs_match_sync(gs_run *run) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
+}
+
+extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
+    if (!run || !table) return fail(GS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    const size_t nv = (size_t)run->db->info.n_values;
+    std::vector<int64_t> sums(nv * GS_N_SUMS), maxk(nv);
+    std::vector<u64> uniq(nv, 0);
+    if (run->cfg.count_unique) {
+        HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * nv, run->stream));
+        HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET,
+                                       run->db->dev.vbits, run->db->info.n_values, run->d_unique, run->stream));
+        HIP_TRY(hipMemcpyAsync(uniq.data(), run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(sums.data(), run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipMemcpyAsync(maxk.data(), run->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToHost, run->stream));
+    if (dtable)
+        HIP_TRY(hipMemcpyAsync(dtable, run->d_dsums, sizeof(double) * nv * GS_N_DCOLS, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    int rc = collect_events(run);
+    if (rc) return rc;
+    for (size_t v = 0; v < nv; v++) {
+        int64_t *row = table + v * GS_N_COLS;
+        const int64_t *s = sums.data() + v * GS_N_SUMS;
+        row[GS_C_READS] = s[GS_S_READS];
+        row[GS_C_READS_KMERS] = s[GS_S_READS_KMERS];
+        row[GS_C_KMERS] = s[GS_S_KMERS];
+        row[GS_C_UNIQUE_KMERS] = run->cfg.count_unique ? (int64_t)uniq[v] : -1;
+        row[GS_C_CONTIGS] = s[GS_S_CONTIGS];
+        row[GS_C_CONTIG_LEN_SQ_SUM] = s[GS_S_CONTIG_LEN_SQ_SUM];
+        row[GS_C_READS_1KMER] = s[GS_S_READS_1KMER];
+        row[GS_C_READS_BPS] = s[GS_S_READS_BPS];
+        const u64 key = (u64)maxk[v];
+        row[GS_C_MAX_CONTIG_LEN] = (int64_t)(key >> 40);
+        row[GS_C_MAX_CONTIG_READ_NO] = key ? (int64_t)(((1ULL << 40) - 1) - (key & ((1ULL << 40) - 1))) : -1;
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_match_reset(gs_run *run) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    int rc = collect_events(run);
+    if (rc) return rc;
+    run->launches = 0;
+    run->total_ms = 0;
+    return run_clear(run);
+}
+
+extern "C" int gs_match_destroy(gs_run *run) {
+    if (!run) return GS_OK;
+    hipSetDevice(run->db->device);
+    hipStreamSynchronize(run->stream);
+    run_free(run);
+    return GS_OK;
+}
+
+extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsums, void **bitmap,
+                                     int64_t *bitmap_words) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    if (sums) *sums = run->d_sums;
+    if (max_keys) *max_keys = run->d_max;
+    if (dsums) *dsums = run->d_dsums;
+    if (bitmap) *bitmap = run->d_bitmap;
+    if (bitmap_words) *bitmap_words = run->bitmap_words;
+    return GS_OK;
+}
+
+extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts) {
+    if (!run || !parts || n_parts < 1) return fail(GS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(gs_launch_bitmap_or(run->d_bitmap, (const uint32_t *)parts, run->bitmap_words, n_parts, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    int rc = collect_events(run);
+    if (rc) return rc;
+    if (launches) *launches = run->launches;
+    if (total_ms) *total_ms = run->total_ms;
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter
+// ---------------------------------------------------------------------------------------------------
+struct gs_bloom {
+    int device = 0;
+    int kind = 0;
+    int64_t bits = 0;
+    int32_t n_hashes = 0;
+    int64_t n_words = 0;
+    u64 *d_words = nullptr;
+    int64_t *d_factors = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    uint8_t *d_seq = nullptr;
+    uint64_t *d_off = nullptr;
+    uint8_t *d_accept = nullptr;
+    size_t seq_cap = 0, reads_cap = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int64_t launches = 0;
+    double total_ms = 0;
+};
+
+extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bits, int32_t n_hashes,
+                               const int64_t *hash_factors, const uint64_t *words, int64_t n_words) {
+    if (!out) return fail(GS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (kind < GS_BLOOM_XOR || kind > GS_BLOOM_BLOCKED) return fail(GS_E_INVALID, "unknown bloom kind");
+    if (bits < 1 || !hash_factors || !words || n_words < 1) return fail(GS_E_INVALID, "bad bloom arrays");
+    if (kind != GS_BLOOM_BLOCKED) {
+        if (n_hashes < 1 || n_hashes > 64) return fail(GS_E_INVALID, "n_hashes must be in [1,64]");
+        if (n_words < (bits + 63) / 64) return fail(GS_E_INVALID, "words shorter than bits");
+    } else {
+        n_hashes = 1;
+        if (n_words < bits + 17) return fail(GS_E_INVALID, "blocked filter needs buckets+17 words");
+    }
+    int rc = use_device(device);
+    if (rc) return rc;
+    gs_bloom *b = new gs_bloom();
+    b->device = device;
+    b->kind = kind;
+    b->bits = bits;
+    b->n_hashes = n_hashes;
+    b->n_words = n_words;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_words, sizeof(u64) * (size_t)n_words);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_factors, sizeof(int64_t) * (size_t)n_hashes);
+    if (e == hipSuccess) e = hipMemcpy(b->d_words, words, sizeof(u64) * (size_t)n_words, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_factors, hash_factors, sizeof(int64_t) * (size_t)n_hashes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gs_bloom_destroy(b);
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("bloom upload: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return GS_OK;
+}
+
+extern "C" int gs_bloom_destroy(gs_bloom *b) {
+    if (!b) return GS_OK;
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    for (auto &p : b->pending) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    hipFree(b->d_words);
+    hipFree(b->d_factors);
+    hipFree(b->d_seq);
+    hipFree(b->d_off);
+    hipFree(b->d_accept);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return GS_OK;
+}
+
+static int bloom_collect(gs_bloom *b) {
+    for (auto &p : b->pending) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+        b->total_ms += ms;
+        b->launches++;
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    b->pending.clear();
+    return GS_OK;
+}
+
+// signed magic for floor-free truncated division by a positive 63-bit constant d:
+//   q = mulhi_u64(|v|, magic) >> shift  is exact for |v| < 2^63 when magic = ceil(2^(64+shift) / d)
+// computed with 128-bit arithmetic on the host (see gs_filter_kernel for the use).
+static void magic_u64(u64 d, u64 &magic, int &shift) {
+    // smallest l with 2^l >= d ; magic = floor(2^64 * (2^l - d) / d) + 1 ; q = (mulhi(n,magic) + ((n - mulhi)>>1)) >> (l-1)
+    int l = 0;
+    while (l < 64 && ((u64)1 << l) < d) l++;
+    unsigned __int128 num = ((unsigned __int128)((l == 64 ? 0 : ((u64)1 << l)) - d)) << 64;
+    magic = (u64)(num / d) + 1;
+    shift = l;
+}
+
+extern "C" int gs_filter_submit(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *seq,
+                                const uint64_t *offsets, int64_t n_reads, int mem, uint8_t *accept, int profile) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
+    if (n_reads < 0 || (n_reads > 0 && (!seq || !offsets || !accept))) return fail(GS_E_INVALID, "bad batch arrays");
+    if (n_reads == 0) return GS_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    const uint8_t *d_seq = seq;
+    const uint64_t *d_off = offsets;
+    uint8_t *d_acc = accept;
+    std::vector<uint64_t> rel;
+    if (mem == GS_MEM_HOST) {
+        const size_t nbytes = (size_t)(offsets[n_reads] - offsets[0]);
+        if (b->seq_cap < nbytes + 1) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            hipFree(b->d_seq);
+            b->d_seq = nullptr;
+            b->seq_cap = 0;
+            HIP_TRY(hipMalloc((void **)&b->d_seq, nbytes + 1));
+            b->seq_cap = nbytes + 1;
+        }
+        if (b->reads_cap < (size_t)n_reads) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            hipFree(b->d_off);
+            hipFree(b->d_accept);
+            b->d_off = nullptr;
+            b->d_accept = nullptr;
+            b->reads_cap = 0;
+            HIP_TRY(hipMalloc((void **)&b->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+            HIP_TRY(hipMalloc((void **)&b->d_accept, (size_t)n_reads));
+            b->reads_cap = (size_t)n_reads;
+        }
+        const uint64_t *hoff = offsets;
+        if (offsets[0] != 0) {
+            rel.resize((size_t)n_reads + 1);
+            for (int64_t i = 0; i <= n_reads; i++) rel[(size_t)i] = offsets[i] - offsets[0];
+            hoff = rel.data();
+        }
+        HIP_TRY(hipMemcpyAsync(b->d_seq, seq + offsets[0], nbytes, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_off, hoff, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, b->stream));
+        d_seq = b->d_seq;
+        d_off = b->d_off;
+        d_acc = b->d_accept;
+    } else if (mem != GS_MEM_DEVICE)
+        return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+
+    GsFilterParams P{};
+    P.kind = b->kind;
+    P.k = k;
+    P.min_pos_count = min_pos_count;
+    P.positive_ratio = positive_ratio;
+    P.bits = (u64)b->bits;
+    P.n_hashes = b->n_hashes;
+    P.words = b->d_words;
+    P.factors = b->d_factors;
+    {
+        u64 mg = 0;
+        int sh = 0;
+        magic_u64((u64)b->bits, mg, sh);
+        P.magic = mg;
+        P.magic_shift = sh;
+    }
+    P.seq = d_seq;
+    P.off = d_off;
+    P.n_reads = n_reads;
+    P.accept = d_acc;
+    int occ = gs_filter_occupancy();
+    if (occ < 1) occ = 1;
+    int grid = (int)std::min<int64_t>((int64_t)b->n_cu * occ, (n_reads + 3) / 4);
+    if (grid < 1) grid = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, b->stream));
+    }
+    HIP_TRY(gs_launch_filter(&P, grid, b->stream));
+    if (profile) {
+        HIP_TRY(hipEventRecord(e1, b->stream));
+        b->pending.push_back({e0, e1});
+    }
+    if (mem == GS_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return bloom_collect(b);
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_filter_sync(gs_bloom *b) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return bloom_collect(b);
+}
+
+extern "C" int gs_filter_kernel_time(gs_bloom *b, int64_t *launches, double *total_ms) {
+    int rc = gs_filter_sync(b);
+    if (rc) return rc;
+    if (launches) *launches = b->launches;
+    if (total_ms) *total_ms = b->total_ms;
+    return GS_OK;
+}

@@ -1,0 +1,781 @@
+// gs_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the match / filter hot path.
+//
+// match: ONE WAVE PER READ.  Lane p owns k-mer start position p; an "iteration" covers 128 positions as two
+// sub-rounds of 64, so a 150 bp read at k=31 (120 k-mers) is exactly one iteration.  Per iteration:
+//   1. coalesced byte loads of the bases, three 64-lane ballots per 64 bases (code-hi, code-lo, invalid)
+//   2. per lane: funnel-shift the ballot planes -> forward k-mer, bit-reverse -> reverse complement,
+//      reference-exact canonical choice, gs_mix62 -> bucket + remainder
+//   3. one 64-byte bucket line per k-mer (4 x dwordx4 per lane, both sub-rounds in flight together)
+//   4. per-read reduce inside the wave: contig boundaries by neighbour compare, a wave-uniform loop over
+//      the few contig "events" (flush stats / start contig / path merge), unique bitmap by test-then-
+//      atomicOr, KrakenUniq-style vote + LCA with O(1) pre-order interval ancestor tests
+//   5. per-taxid counters privatised in LDS per workgroup, flushed once with 64-bit global atomics
+// The semantics follow C/match/FastqKMerMatcher.java:327-535; the structure does
+// not: the reference's rolling/jumping state machine is replaced by its closed form
+//   node(p) = INVALID if the window [p,p+k) holds a non-CGAT byte, else store lookup,
+//   #INVALID iterations = popcount(bad bases at positions <= max-2) + (any bad base at >= max-1).
+// Reads with more than 128 k-mer positions are queued and drained by gs_match_long_kernel, the same code
+// iterating with carried state and per-wave scratch counters in HBM instead of in-register lists.
+//
+// filter: one wave per read, lanes = k-mer positions, the reference's exact Bloom hashes; accept is the
+// closed form  #(member k-mers) >= max(posThreshold, 1)  of FastqBloomFilter.isAcceptRead (:120-161).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gs_layout.h"
+#include "gs_params.h"
+
+#define GS_NODE_MISS (-1)
+#define GS_NODE_INVALID (-2)
+#define GS_NODE_NONE (-3)
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ int gs_lane() { return (int)__lane_id(); }
+__device__ __forceinline__ int gs_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int gs_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// bits [s, s+64) of the 128-bit string (b:a), s in 0..63
+__device__ __forceinline__ u64 gs_funnel(u64 a, u64 b, int s) { return (a >> s) | ((b << 1) << (63 - s)); }
+
+// ASCII base -> reference 2-bit code (C0 G1 A2 T3); valid only for upper-case ACGT (CGAT.java:66-69)
+__device__ __forceinline__ void gs_base_code(uint32_t c, uint32_t &code, bool &ok) {
+    uint32_t x = (c >> 1) & 3u;  // A->0 C->1 T->2 G->3
+    code = (0x72u >> (2 * x)) & 3u;
+    ok = c == ((0x47544341u >> (8 * x)) & 0xffu);
+}
+
+// one 64-base word of a read -> ballot planes
+__device__ __forceinline__ void gs_load_word(const uint8_t *rd, int L, int w, int lane, u64 &hi, u64 &lo, u64 &bad) {
+    const int j = 64 * w + lane;
+    uint32_t code = 0;
+    bool b = false;
+    if (j < L) {
+        bool ok;
+        gs_base_code(rd[j], code, ok);
+        b = !ok;
+    }
+    hi = __ballot((code & 2u) != 0);
+    lo = __ballot((code & 1u) != 0);
+    bad = __ballot(b);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// statistics sinks: LDS-privatised (n_values <= GS_NV_LDS) or direct global atomics
+// ---------------------------------------------------------------------------------------------------
+struct GsStats {
+    u64 *sums;      // [nv][GS_N_SUMS]
+    u64 *maxk;      // [nv]
+    double *dsums;  // [nv][GS_N_DCOLS]
+    __device__ __forceinline__ void add(int vi, int col, u64 v) const { atomicAdd(&sums[(size_t)vi * GS_N_SUMS + col], v); }
+    __device__ __forceinline__ void max(int vi, u64 key) const { atomicMax(&maxk[vi], key); }
+    __device__ __forceinline__ void dadd(int vi, int col, double v) const { atomicAdd(&dsums[(size_t)vi * GS_N_DCOLS + col], v); }
+    // contig flush (FastqKMerMatcher.java:396-411 / :457-471)
+    __device__ __forceinline__ void contig(int vi, int len, u64 key_lo) const {
+        add(vi, GS_S_KMERS, (u64)len);
+        add(vi, GS_S_CONTIGS, 1);
+        add(vi, GS_S_CONTIG_LEN_SQ_SUM, (u64)len * (u64)len);
+        max(vi, ((u64)len << 40) | key_lo);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// store probe
+// ---------------------------------------------------------------------------------------------------
+struct GsBucket {
+    ulonglong2 q[4];
+};
+
+__device__ __forceinline__ void gs_load_bucket(const u64 *table, u64 bkt, GsBucket &b) {
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(table + bkt * GS_SLOTS_PER_BUCKET);
+    b.q[0] = p[0];
+    b.q[1] = p[1];
+    b.q[2] = p[2];
+    b.q[3] = p[3];
+}
+
+// returns true when the probe is finished (hit, or miss proven by a non-full bucket)
+__device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, u64 vmask, int &vi, int &slot) {
+    const u64 s[8] = {b.q[0].x, b.q[0].y, b.q[1].x, b.q[1].y, b.q[2].x, b.q[2].y, b.q[3].x, b.q[3].y};
+    bool full = true;
+    int hit = -1, val = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u64 x = s[j] ^ want;  // equal high part  <=>  0 < x <= vmask  (value field is vi+1 >= 1)
+        if (x - 1 < vmask) {
+            hit = j;
+            val = (int)x - 1;
+        }
+        full = full && (s[j] != 0);
+    }
+    if (hit >= 0) {
+        vi = val;
+        slot = hit;
+        return true;
+    }
+    return !full;
+}
+
+// canonical planar key of the k-mer whose forward planes are (fhi, flo); reference-exact orientation choice
+__device__ __forceinline__ u64 gs_canonical_planar(uint32_t fhi, uint32_t flo, int k, uint32_t kmask) {
+    const uint32_t rhi = __brev(fhi) >> (32 - k);
+    const uint32_t rlo = (__brev(flo) >> (32 - k)) ^ kmask;
+    const uint32_t diff = (fhi ^ rhi) | (flo ^ rlo);
+    const uint32_t d = diff & (0u - diff);  // first base where the two orientations differ
+    const uint32_t cf = ((fhi & d) ? 2u : 0u) | ((flo & d) ? 1u : 0u);
+    const uint32_t cr = ((rhi & d) ? 2u : 0u) | ((rlo & d) ? 1u : 0u);
+    return cf >= cr ? (((u64)fhi << GS_PLANE_SHIFT) | flo) : (((u64)rhi << GS_PLANE_SHIFT) | rlo);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tree helpers (value index == node id; tin/tout pre-order interval)
+// ---------------------------------------------------------------------------------------------------
+// is `a` an ancestor-or-self of `x`  (SmallTaxTree.isAncestorOf(x, a), SmallTaxTree.java:242-252)
+__device__ __forceinline__ bool gs_anc_or_self(int a_tin, int a_tout, int x_tin) { return a_tin <= x_tin && x_tin < a_tout; }
+
+__device__ int gs_lca(const GsDbDev &db, int a, int b) {  // SmallTaxTree.java:263-289, -1 == null
+    if (a == b) return a;
+    if (a < 0 || b < 0) return -1;
+    const int tb = db.tin[b];
+    while (a >= 0 && !gs_anc_or_self(db.tin[a], db.tout[a], tb)) a = db.parent[a];
+    return a;
+}
+
+// per-wave scratch of the long-read kernel, always accessed at agent scope (L1 bypass)
+__device__ __forceinline__ int gs_sc_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---------------------------------------------------------------------------------------------------
+// one read on one wave.  LONG = false: max <= 128 (one iteration, distinct nodes kept in registers).
+// LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
+// ---------------------------------------------------------------------------------------------------
+template <bool LONG>
+__device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, int lane,
+                                                int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
+                                                int32_t *tag, int32_t *cnt, int serial) {
+    const GsDbDev &db = P.db;
+    const int k = db.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    const u64 vmask = (1ULL << db.vbits) - 1;
+    const int shift_rem = (int)db.vbits + 2;
+    const u64 off = P.off[r];
+    const int L = (int)(P.off[r + 1] - off);
+    const int max = L - k + 1;
+    const uint8_t *rd = P.seq + off;
+    int out_class = -1;
+    int out_flags = 0;
+
+    if (max > 0) {
+        const int64_t read_no = P.first_read_no + r;
+        const u64 key_lo = ((1ULL << 40) - 1) - ((u64)read_no & ((1ULL << 40) - 1));
+        const int n_iter = LONG ? (max + 127) >> 7 : 1;
+        // per-read state
+        bool found = false;
+        int n_miss = 0, bad_lo = 0;
+        bool bad_hi = false;
+        int carry_last = GS_NODE_NONE;  // node of the last position of the previous iteration
+        int cur_start = 0;
+        int dviA = -1, dviB = -1, dcntA = 0, dcntB = 0, nd = 0;  // !LONG: distinct hit nodes (cap 128 >= #contigs)
+        int path = -1, ptin = 0, ptout = 0, used = 0;           // candidate paths, lane i = path i
+
+        for (int it = 0; it < n_iter; it++) {
+            const int base = it << 7;  // first k-mer position of this iteration
+            // ---- 1. bases -> ballot planes (3 words cover 128 + k - 1 <= 158 bases)
+            u64 Bhi[3], Blo[3], Bbad[3];
+#pragma unroll
+            for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
+            {   // bad-base census for the INVALID-iteration closed form; word 2 belongs to the next iteration
+                const int q = max - 1;
+                const int nw = (it == n_iter - 1) ? 3 : 2;
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    if (w < nw) {
+                        const int lo_bits = q - (base + 64 * w);  // positions of this word that are < q
+                        const u64 m_lo = lo_bits >= 64 ? ~0ULL : (lo_bits <= 0 ? 0ULL : ((1ULL << lo_bits) - 1));
+                        bad_lo += __popcll(Bbad[w] & m_lo);
+                        bad_hi = bad_hi || ((Bbad[w] & ~m_lo) != 0);
+                    }
+                }
+            }
+            // ---- 2/3. k-mers + probe, both sub-rounds in flight
+            int node[2], slot[2];
+            u64 bkt[2], want[2];
+            bool act[2];
+            GsBucket bk[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int p = base + 64 * s + lane;
+                const bool valid = p < max;
+                const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+                const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+                const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
+                const u64 h = gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
+                bkt[s] = h & db.bucket_mask;
+                want[s] = (h >> db.bucket_bits) << shift_rem;
+                act[s] = valid && (wbad == 0);
+                node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
+                slot[s] = 0;
+                if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                bool pending = false;
+                if (act[s]) {
+                    int vi = -1, sl = 0;
+                    const bool done = gs_match_bucket(bk[s], want[s], vmask, vi, sl);
+                    if (vi >= 0) {
+                        node[s] = vi;
+                        slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
+                    }
+                    pending = !done;
+                }
+                // rare: home bucket full without a match -> walk the displaced buckets
+                for (int disp = 1; disp <= GS_MAX_DISP && __ballot(pending) != 0; disp++) {
+                    if (pending) {
+                        const u64 b2 = (bkt[s] + disp) & db.bucket_mask;
+                        GsBucket t;
+                        gs_load_bucket(db.table, b2, t);
+                        int vi = -1, sl = 0;
+                        const bool done = gs_match_bucket(t, want[s] | ((u64)disp << db.vbits), vmask, vi, sl);
+                        if (vi >= 0) {
+                            node[s] = vi;
+                            slot[s] = (int)(b2 * GS_SLOTS_PER_BUCKET) + sl;
+                        }
+                        pending = !done;
+                    }
+                }
+            }
+
+            // ---- 4a. unique bitmap (KMerUniqueCounterBits.putInlined): test, then atomicOr
+            const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
+            found = found || ((hit0 | hit1) != 0);
+            n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
+            if (P.count_unique) {
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    if (node[s] >= 0) {
+                        const uint32_t idx = (uint32_t)slot[s];
+                        const uint32_t bit = 1u << (idx & 31);
+                        uint32_t *w = P.bitmap + (idx >> 5);
+                        if (!(*w & bit)) atomicOr(w, bit);
+                    }
+                }
+            }
+
+            // ---- 4b. contig events
+            if ((hit0 | hit1) != 0 || carry_last >= 0) {
+                int prev[2];
+                {
+                    const int up0 = __shfl_up(node[0], 1);
+                    const int up1 = __shfl_up(node[1], 1);
+                    const int last0 = gs_readlane(node[0], 63);
+                    prev[0] = lane == 0 ? carry_last : up0;
+                    prev[1] = lane == 0 ? last0 : up1;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const bool valid = node[s] != GS_NODE_NONE;
+                    const bool head = valid && node[s] != prev[s];
+                    u64 E = __ballot(head && (node[s] >= 0 || prev[s] >= 0));
+                    while (E) {
+                        const int j = __builtin_ctzll(E);
+                        E &= E - 1;
+                        const int pj = base + 64 * s + j;
+                        const int pv = gs_readlane(prev[s], j);
+                        const int nvj = gs_readlane(node[s], j);
+                        if (pv >= 0) {  // the hit contig [cur_start, pj) of node pv ends (:391-413)
+                            const int len = pj - cur_start;
+                            if (lane == 0) {
+                                st.contig(pv, len, key_lo);
+                                if (LONG) gs_sc_store(cnt + pv, gs_sc_load(cnt + pv) + len);
+                            }
+                            if (!LONG) {
+                                dcntA += (dviA == pv) ? len : 0;
+                                dcntB += (dviB == pv) ? len : 0;
+                            }
+                        }
+                        if (nvj >= 0) {  // a hit contig starts
+                            cur_start = pj;
+                            bool seen;
+                            if (LONG) {
+                                int sn = 0;
+                                if (lane == 0) {
+                                    sn = gs_sc_load(tag + nvj) == serial;
+                                    if (!sn) {
+                                        gs_sc_store(tag + nvj, serial);
+                                        gs_sc_store(cnt + nvj, 0);
+                                    }
+                                }
+                                seen = gs_rfl(sn) != 0;
+                            } else {
+                                seen = (__ballot(dviA == nvj) | __ballot(dviB == nvj)) != 0;
+                                if (!seen) {
+                                    if (nd < 64) {
+                                        if (lane == nd) dviA = nvj;
+                                    } else {
+                                        if (lane == nd - 64) dviB = nvj;
+                                    }
+                                    nd++;
+                                }
+                            }
+                            // first k-mer of this tax id in the read (:434-439)
+                            if (!seen && lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
+                            if (P.classify) {  // mergeReadTaxidPath (:568-586)
+                                const int ntin = db.tin[nvj], ntout = db.tout[nvj];
+                                const bool mine = lane < used;
+                                const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
+                                const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
+                                const u64 m = __ballot(a || b);
+                                if (m) {
+                                    const int i = __builtin_ctzll(m);
+                                    if (lane == i && a) {
+                                        path = nvj;
+                                        ptin = ntin;
+                                        ptout = ntout;
+                                    }
+                                } else if (used < P.max_paths) {
+                                    if (lane == used) {
+                                        path = nvj;
+                                        ptin = ntin;
+                                        ptout = ntout;
+                                    }
+                                    used++;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            {   // carry: node of the last valid position of this iteration
+                const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
+                const int ls = (last_p - base) >> 6, ll = (last_p - base) & 63;
+                carry_last = gs_readlane(ls ? node[1] : node[0], ll);
+            }
+        }
+
+        if (found) {
+            out_flags = GS_F_FOUND | GS_F_RETURNED;
+            // tail flush (:455-473): the last contig if it is a hit contig
+            if (carry_last >= 0) {
+                const int len = max - cur_start;
+                if (lane == 0) {
+                    st.contig(carry_last, len, key_lo);
+                    if (LONG) gs_sc_store(cnt + carry_last, gs_sc_load(cnt + carry_last) + len);
+                }
+                if (!LONG) {
+                    dcntA += (dviA == carry_last) ? len : 0;
+                    dcntB += (dviB == carry_last) ? len : 0;
+                }
+            }
+            // ---- 4c. classification (:474-531)
+            if (P.classify) {
+                const int tax_err = n_miss + bad_lo + (bad_hi ? 1 : 0);
+                const double m = P.max_read_tax_err;
+                const bool disabled = m >= 0 && ((m >= 1 && (double)tax_err > m) || ((double)tax_err > m * (double)max));
+                if (!disabled) {
+                    // sumCounts per candidate path (SmallTaxTree.java:184-193): lanes = paths
+                    int sum = 0;
+                    if (LONG) {
+                        if (lane < used)
+                            for (int x = path; x >= 0; x = db.parent[x])
+                                if (gs_sc_load(tag + x) == serial) sum += gs_sc_load(cnt + x);
+                    } else {
+                        for (int dd = 0; dd < nd; dd++) {
+                            const int v = dd < 64 ? gs_readlane(dviA, dd) : gs_readlane(dviB, dd - 64);
+                            const int c = dd < 64 ? gs_readlane(dcntA, dd) : gs_readlane(dcntB, dd - 64);
+                            if (lane < used && gs_anc_or_self(db.tin[v], db.tout[v], ptin)) sum += c;
+                        }
+                    }
+                    // max + ties exactly as the in-place scan (:476-487); tie order = path order
+                    int best = 0;
+                    u64 tie_mask = 0;
+                    for (int i = 0; i < used; i++) {
+                        const int si = gs_readlane(sum, i);
+                        if (si > best) {
+                            best = si;
+                            tie_mask = 1ULL << i;
+                        } else if (si == best)
+                            tie_mask |= 1ULL << i;
+                    }
+                    int cand = path;  // per tied lane: the node entering the LCA fold
+                    if (P.threshold > 1) {
+                        // lowestNodeWhereSumAboveThreshold per tied path (SmallTaxTree.java:208-221)
+                        int mapped = -1;
+                        if (!LONG) {
+                            s_dvi[wave_in_block][lane] = dviA;
+                            s_dcnt[wave_in_block][lane] = dcntA;
+                            s_dvi[wave_in_block][64 + lane] = dviB;
+                            s_dcnt[wave_in_block][64 + lane] = dcntB;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
+                        if ((tie_mask >> lane) & 1ULL) {
+                            int acc = 0;
+                            for (int x = path; x >= 0 && mapped < 0; x = db.parent[x]) {
+                                if (LONG) {
+                                    if (gs_sc_load(tag + x) == serial) {
+                                        acc += gs_sc_load(cnt + x);
+                                        if (acc >= P.threshold) mapped = x;
+                                    }
+                                } else {
+                                    for (int dd = 0; dd < nd; dd++)
+                                        if (s_dvi[wave_in_block][dd] == x) {
+                                            acc += s_dcnt[wave_in_block][dd];
+                                            if (acc >= P.threshold) mapped = x;
+                                        }
+                                }
+                            }
+                        }
+                        cand = mapped;
+                    }
+                    int cn = -1, first_node = -1;
+                    {
+                        bool first = true;
+                        u64 tm = tie_mask;
+                        while (tm) {
+                            const int i = __builtin_ctzll(tm);
+                            tm &= tm - 1;
+                            const int x = gs_readlane(cand, i);
+                            if (first) {
+                                cn = x;
+                                first_node = x;
+                                first = false;
+                            } else
+                                cn = gs_lca(db, cn, x);
+                        }
+                    }
+                    out_class = cn;
+                    if (cn < 0) {
+                        out_flags &= ~GS_F_RETURNED;  // "return false" (:497-500)
+                    } else {
+                        int read_kmers = best;
+                        if (P.threshold > 1) {  // sumCounts(readTaxIdNode[0]) after the promotion (:506-507)
+                            read_kmers = 0;
+                            if (LONG) {
+                                for (int x = first_node; x >= 0; x = db.parent[x])
+                                    if (gs_sc_load(tag + x) == serial) read_kmers += gs_sc_load(cnt + x);
+                            } else {
+                                const int ft = db.tin[first_node];
+                                for (int dd = 0; dd < nd; dd++) {
+                                    const int v = dd < 64 ? gs_readlane(dviA, dd) : gs_readlane(dviB, dd - 64);
+                                    const int c = dd < 64 ? gs_readlane(dcntA, dd) : gs_readlane(dcntB, dd - 64);
+                                    if (gs_anc_or_self(db.tin[v], db.tout[v], ft)) read_kmers += c;
+                                }
+                            }
+                        }
+                        const int class_err = max - read_kmers;
+                        const double mc = P.max_read_class_err;
+                        if (mc < 0 || (mc >= 1 && (double)class_err <= mc) || ((double)class_err <= mc * (double)max)) {
+                            out_flags |= GS_F_COUNTED;
+                            if (lane == 0) {
+                                const double err = (double)tax_err / (double)max;
+                                const double cerr = (double)class_err / (double)max;
+                                st.add(cn, GS_S_READS, 1);
+                                st.add(cn, GS_S_READS_KMERS, (u64)read_kmers);
+                                st.add(cn, GS_S_READS_BPS, (u64)L);
+                                st.dadd(cn, GS_D_ERR_SUM, err);
+                                st.dadd(cn, GS_D_ERR_SQ_SUM, err * err);
+                                st.dadd(cn, GS_D_CLASS_ERR_SUM, cerr);
+                                st.dadd(cn, GS_D_CLASS_ERR_SQ_SUM, cerr * cerr);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (P.class_vi) P.class_vi[r] = out_class;
+        if (P.flags) P.flags[r] = (uint8_t)out_flags;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+#define GS_STATS_PROLOGUE()                                                                           \
+    __shared__ u64 s_sums[LDS_STATS ? GS_NV_LDS * GS_N_SUMS : 1];                                     \
+    __shared__ u64 s_max[LDS_STATS ? GS_NV_LDS : 1];                                                  \
+    __shared__ double s_d[LDS_STATS ? GS_NV_LDS * GS_N_DCOLS : 1];                                    \
+    const int nv = P.db.n_values;                                                                     \
+    if (LDS_STATS) {                                                                                  \
+        for (int i = threadIdx.x; i < nv * GS_N_SUMS; i += blockDim.x) s_sums[i] = 0;                 \
+        for (int i = threadIdx.x; i < nv; i += blockDim.x) s_max[i] = 0;                              \
+        for (int i = threadIdx.x; i < nv * GS_N_DCOLS; i += blockDim.x) s_d[i] = 0.0;                 \
+        __syncthreads();                                                                              \
+    }                                                                                                 \
+    GsStats st;                                                                                       \
+    if (LDS_STATS) {                                                                                  \
+        st.sums = s_sums;                                                                             \
+        st.maxk = s_max;                                                                              \
+        st.dsums = s_d;                                                                               \
+    } else {                                                                                          \
+        st.sums = (u64 *)P.sums;                                                                      \
+        st.maxk = (u64 *)P.max_keys;                                                                  \
+        st.dsums = P.dsums;                                                                           \
+    }
+
+#define GS_STATS_EPILOGUE()                                                                           \
+    if (LDS_STATS) {                                                                                  \
+        __syncthreads();                                                                              \
+        for (int i = threadIdx.x; i < nv * GS_N_SUMS; i += blockDim.x)                                \
+            if (s_sums[i]) atomicAdd((u64 *)P.sums + i, s_sums[i]);                                   \
+        for (int i = threadIdx.x; i < nv; i += blockDim.x)                                            \
+            if (s_max[i]) atomicMax((u64 *)P.max_keys + i, s_max[i]);                                 \
+        for (int i = threadIdx.x; i < nv * GS_N_DCOLS; i += blockDim.x)                               \
+            if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
+    }
+
+template <bool LDS_STATS>
+__global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
+    GS_STATS_PROLOGUE()
+    __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
+    __shared__ int s_dcnt[GS_BLOCK / 64][128];
+    const int lane = gs_lane();
+    const int wave_in_block = threadIdx.x >> 6;
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int k = P.db.k;
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const int L = (int)(P.off[r + 1] - P.off[r]);
+        if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
+            if (lane == 0) P.long_list[atomicAdd(P.long_count, 1u)] = (uint32_t)r;
+            continue;
+        }
+        gs_process_read<false>(P, st, r, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0);
+    }
+    GS_STATS_EPILOGUE()
+}
+
+template <bool LDS_STATS>
+__global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
+    GS_STATS_PROLOGUE()
+    const int lane = gs_lane();
+    const int wave_in_block = threadIdx.x >> 6;
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
+    int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
+    int32_t *cnt = tag + nv;
+    uint32_t serial = serials[wave_id];
+    for (int64_t i = wave_id; i < (int64_t)n_long; i += n_waves) {
+        serial++;
+        if (serial == 0) serial = 1;  // tags start zeroed; a wrap after 2^32 reads per wave may alias once
+        gs_process_read<true>(P, st, (int64_t)P.long_list[i], lane, nullptr, nullptr, wave_in_block, tag, cnt, (int)serial);
+    }
+    if (lane == 0) serials[wave_id] = serial;
+    GS_STATS_EPILOGUE()
+}
+
+// ---------------------------------------------------------------------------------------------------
+// unique k-mers per value: scan the bitmap, look the set slots up in the table
+// (KMerUniqueCounterBits.getUniqueKmerCounts, C/store/KMerUniqueCounterBits.java:146-163)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_unique_count_kernel(const u64 *table, const uint32_t *bitmap, int64_t n_slots,
+                                                             uint32_t vbits, int32_t n_values, u64 *unique) {
+    __shared__ unsigned int s_cnt[GS_NV_LDS];
+    const bool lds = n_values <= GS_NV_LDS;
+    if (lds) {
+        for (int i = threadIdx.x; i < n_values; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    const u64 vmask = (1ULL << vbits) - 1;
+    const int64_t n_words = (n_slots + 31) / 32;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = bitmap[w];
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const u64 s = table[w * 32 + b];
+            const int vi = (int)(s & vmask) - 1;
+            if (vi >= 0) {
+                if (lds)
+                    atomicAdd(&s_cnt[vi], 1u);
+                else
+                    atomicAdd(&unique[vi], 1ULL);
+            }
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_values; i += blockDim.x)
+            if (s_cnt[i]) atomicAdd(&unique[i], (u64)s_cnt[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_bitmap_or_kernel(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t v = dst[w];
+        for (int64_t p = 0; p < n_parts; p++) v |= parts[p * n_words + w];
+        dst[w] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 gs_spread32(uint32_t v) {  // bit i -> bit 2i
+    u64 x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+// canonical k-mer in the REFERENCE's interleaved encoding (the value the Bloom hashes see)
+__device__ __forceinline__ int64_t gs_canonical_java(uint32_t fhi, uint32_t flo, int k, uint32_t kmask) {
+    const uint32_t rhi = __brev(fhi) >> (32 - k);
+    const uint32_t rlo = __brev(flo) >> (32 - k);
+    const u64 fwd = (gs_spread32(rhi) << 1) | gs_spread32(rlo);                     // first base in the top bits
+    const u64 rev = (gs_spread32(fhi) << 1) | gs_spread32((flo ^ kmask) & kmask);   // complement, reversed
+    return (int64_t)(fwd > rev ? fwd : rev);
+}
+
+// |v| mod d for the reference's Math.abs(v % bits) (XORKMerBloomFilter.java:57-59); d < 2^63
+__device__ __forceinline__ u64 gs_absmod(int64_t v, u64 d, u64 magic, int shift) {
+    const u64 n = v < 0 ? (u64)0 - (u64)v : (u64)v;
+    if (shift == 0) return 0;  // d == 1
+    const u64 t = __umul64hi(magic, n);
+    const u64 q = (t + ((n - t) >> 1)) >> (shift - 1);
+    return n - q * d;
+}
+
+__device__ __forceinline__ int64_t gs_murmur64(int64_t data_, int64_t base) {  // MurmurHash3DropIn.java:60-87
+    const u64 data = (u64)data_;
+    u64 hash = (u64)base;
+    u64 kk = __builtin_bswap64(data);
+    kk *= 0x87c37b91114253d5ULL;
+    kk = (kk << 31) | (kk >> 33);
+    kk *= 0x4cf5ad432745937fULL;
+    hash ^= kk;
+    hash = ((hash << 27) | (hash >> 37)) * 5 + 0x52dce729ULL;
+    hash ^= 8;
+    hash ^= hash >> 33;
+    hash *= 0xff51afd7ed558ccdULL;
+    hash ^= hash >> 33;
+    hash *= 0xc4ceb9fe1a85ec53ULL;
+    hash ^= hash >> 33;
+    return (int64_t)(hash ^ data);
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
+    const int lane = gs_lane();
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int k = P.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const u64 off = P.off[r];
+        const int L = (int)(P.off[r + 1] - off);
+        const int max = L - k + 1;
+        const uint8_t *rd = P.seq + off;
+        int accept = 0;
+        if (max > 0) {
+            const int pos_thr = P.min_pos_count > 0 ? P.min_pos_count : (int)((double)max * P.positive_ratio);
+            const int need = pos_thr > 1 ? pos_thr : 1;
+            int members = 0;
+            u64 hi0, lo0, bad0;
+            gs_load_word(rd, L, 0, lane, hi0, lo0, bad0);
+            for (int round = 0; round * 64 < max && members < need; round++) {
+                u64 hi1, lo1, bad1;
+                gs_load_word(rd, L, round + 1, lane, hi1, lo1, bad1);
+                const int p = 64 * round + lane;
+                const uint32_t fhi = (uint32_t)gs_funnel(hi0, hi1, lane) & kmask;
+                const uint32_t flo = (uint32_t)gs_funnel(lo0, lo1, lane) & kmask;
+                const uint32_t wbad = (uint32_t)gs_funnel(bad0, bad1, lane) & kmask;
+                bool alive = p < max && wbad == 0;
+                const int64_t key = gs_canonical_java(fhi, flo, k, kmask);
+                if (P.kind == GS_BLOOM_BLOCKED) {
+                    if (alive) {  // BlockedKMerBloomFilter.containsLong :181-199
+                        const int64_t h0 = P.factors[0] ^ key;
+                        const u64 start = gs_absmod(h0, P.bits, P.magic, P.magic_shift);
+                        u64 uh = (u64)h0;
+                        uh ^= (uh << 32) | (uh >> 32);
+                        const int64_t sh = (int64_t)uh;
+                        const u64 m1 = (1ULL << (sh & 63)) | (1ULL << ((sh >> 6) & 63));
+                        const u64 m2 = (1ULL << ((sh >> 12) & 63)) | (1ULL << ((sh >> 18) & 63));
+                        const u64 a = P.words[start];
+                        const u64 b = P.words[start + 1 + (uh >> 60)];
+                        alive = ((m1 & a) == m1) && ((m2 & b) == m2);
+                    }
+                } else {
+                    // AbstractKMerBloomFilter.containsLong :209-216, early-out per lane on the first clear bit
+                    for (int i = 0; i < P.n_hashes && __ballot(alive) != 0; i++) {
+                        if (alive) {
+                            const int64_t f = P.factors[i];
+                            const int64_t h = P.kind == GS_BLOOM_XOR ? (f ^ key) : gs_murmur64(key, f);
+                            const u64 idx = gs_absmod(h, P.bits, P.magic, P.magic_shift);
+                            alive = (P.words[idx >> 6] >> (idx & 63)) & 1ULL;
+                        }
+                    }
+                }
+                members += __popcll(__ballot(alive));
+                hi0 = hi1;
+                lo0 = lo1;
+                bad0 = bad1;
+            }
+            accept = members >= need;
+        }
+        if (lane == 0) P.accept[r] = (uint8_t)accept;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers (called from gs_api.cpp)
+// ---------------------------------------------------------------------------------------------------
+extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
+    if (P->db.n_values <= GS_NV_LDS)
+        hipLaunchKernelGGL(gs_match_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    else
+        hipLaunchKernelGGL(gs_match_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
+                                           hipStream_t stream) {
+    if (P->db.n_values <= GS_NV_LDS)
+        hipLaunchKernelGGL(gs_match_long_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+    else
+        hipLaunchKernelGGL(gs_match_long_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+    return hipGetLastError();
+}
+
+extern "C" int gs_match_occupancy(int lds_stats) {
+    int n = 0;
+    hipError_t e = lds_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true>, GS_BLOCK, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false>, GS_BLOCK, 0);
+    return e == hipSuccess ? n : 0;
+}
+
+extern "C" int gs_filter_occupancy() {
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_filter_kernel, GS_BLOCK, 0);
+    return e == hipSuccess ? n : 0;
+}
+
+extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
+                                              int32_t n_values, u64 *unique, hipStream_t stream) {
+    int64_t n_words = (n_slots + 31) / 32;
+    int grid = (int)((n_words + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gs_unique_count_kernel, dim3(grid), dim3(256), 0, stream, table, bitmap, n_slots, vbits, n_values, unique);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
+                                           hipStream_t stream) {
+    int grid = (int)((n_words + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gs_bitmap_or_kernel, dim3(grid), dim3(256), 0, stream, dst, parts, n_words, n_parts);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_filter(const GsFilterParams *P, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_filter_kernel, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    return hipGetLastError();
+}

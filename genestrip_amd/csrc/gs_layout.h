@@ -1,0 +1,53 @@
+// gs_layout.h -- HBM layout of the device k-mer store, shared by the host builder and the kernels.
+//
+// Key encoding ("planar"): for a k-mer s_0..s_{k-1} with the reference's 2-bit codes (C=0 G=1 A=2 T=3,
+// C/util/CGAT.java:66-69) the key is  (hi << 31) | lo  where bit i of hi/lo is the high/low code bit of
+// base i.  A wave builds it from two 64-lane ballots; reverse complement = bit-reverse both planes and
+// flip lo (complement is code^1).  The canonical orientation is chosen exactly as the reference does
+// (numeric max of the interleaved encodings = lexicographic max from base 0, CGAT.java:145-147), so the
+// set of reachable keys is identical.
+//
+// Table: n_buckets (power of two) buckets of 8 x uint64 slots = one 64-byte line per probe.
+//   h      = gs_mix62(key)                 bijection on [0, 2^62)
+//   bucket = h & (n_buckets-1),  rem = h >> bucket_bits
+//   slot   = rem << (vbits+2) | disp << vbits | (value_index+1)        (0 = empty)
+// An entry lives in bucket (home + disp) & mask, disp in 0..3; it is displaced only past FULL buckets, so
+// a probe walks home, home+1, .. while the bucket it just read is full and holds no match.
+// The unique-k-mer bitmap has one bit per slot (bit index = bucket*8 + slot).
+#pragma once
+#include <stdint.h>
+
+#define GS_SLOTS_PER_BUCKET 8
+#define GS_MAX_DISP 3
+#define GS_KEY_BITS 62
+#define GS_PLANE_SHIFT 31
+
+#if defined(__HIPCC__)
+#define GS_HD __host__ __device__ __forceinline__
+#else
+#define GS_HD static inline
+#endif
+
+GS_HD uint64_t gs_mix62(uint64_t x) {
+    const uint64_t M = (1ULL << GS_KEY_BITS) - 1;
+    x ^= x >> 31;
+    x = (x * 0x7fb5d329728ea185ULL) & M;
+    x ^= x >> 27;
+    x = (x * 0x81dadef4bc2dd44dULL) & M;
+    x ^= x >> 33;
+    return x;
+}
+
+struct GsDbDev {
+    const unsigned long long *table;  // n_buckets * 8 slots
+    uint32_t bucket_bits;
+    uint32_t vbits;
+    uint64_t bucket_mask;
+    int32_t k;
+    int32_t n_values;
+    // per value index (tree node) arrays; tin/tout = pre-order interval, depth root = 0
+    const int32_t *parent;
+    const int32_t *depth;
+    const int32_t *tin;
+    const int32_t *tout;
+};

@@ -1,0 +1,45 @@
+// gs_params.h -- kernel parameter blocks and launch constants shared by gs_kernels.hip and gs_api.cpp
+#pragma once
+#include <stdint.h>
+
+#include "../../include/gsgpu.h"
+#include "gs_layout.h"
+
+#define GS_BLOCK 256   // 4 waves per workgroup
+#define GS_NV_LDS 256  // per-taxid counters are privatised in LDS up to this many value indices
+
+struct GsMatchParams {
+    GsDbDev db;
+    const uint8_t *seq;
+    const uint64_t *off;
+    int64_t n_reads;
+    int64_t first_read_no;
+    int32_t classify, count_unique, max_paths, threshold;
+    double max_read_tax_err, max_read_class_err;
+    int64_t *sums;         // [n_values][GS_N_SUMS]
+    int64_t *max_keys;     // [n_values]
+    double *dsums;         // [n_values][GS_N_DCOLS]
+    uint32_t *bitmap;      // one bit per table slot
+    int32_t *class_vi;     // optional per read
+    uint8_t *flags;        // optional per read
+    unsigned int *long_count;  // reads with more than 128 k-mer positions are queued for the long-read kernel
+    uint32_t *long_list;
+};
+
+struct GsFilterParams {
+    int32_t kind;           // GS_BLOOM_*
+    int32_t k;
+    int32_t min_pos_count;
+    int32_t n_hashes;
+    double positive_ratio;
+    uint64_t bits;          // XOR/Murmur: bit count ; Blocked: bucket count
+    uint64_t magic;         // unsigned division of a 64-bit value by `bits` (round-up method)
+    int32_t magic_shift;    // ceil(log2(bits))
+    int32_t pad;
+    const unsigned long long *words;
+    const int64_t *factors;
+    const uint8_t *seq;
+    const uint64_t *off;
+    int64_t n_reads;
+    uint8_t *accept;
+};

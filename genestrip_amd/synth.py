@@ -1,0 +1,151 @@
+"""Deterministic synthetic workloads shared by tests and bench.py.
+
+Not part of the hot path: it only manufactures inputs -- a k-mer store with a small taxonomy (the same
+arrays a Java host would hand over through KMerStore.visit) and fixed-length reads (libgssynth.so, the same
+bytes on the host and directly in HBM).
+
+Store recipe: tree root -> G genera -> S species each; every species gets a random genome of `genome_len`
+bases (splitmix64-seeded), 5 % of it copied from its genus core and 1 % from a root core, so that k-mers
+shared inside a genus / across genera exist; each canonical k-mer is stored with the LCA of the species
+containing it (mirrors FillDBGoal + DBGoal's LCA update, C/goals/refseq/DBGoal.java:233-256).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SYN = None
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _splitmix64(state, n):
+    """n outputs of splitmix64 starting from `state` (numpy, vectorised via the counter form)"""
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(state) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _random_dna(state, n):
+    return _ACGT[(_splitmix64(state, n) >> np.uint64(33)) & np.uint64(3)]
+
+
+def canonical_kmers(seq, k):
+    """canonical k-mers (reference encoding, CGAT.java:66-74,145-147) of every window of an ACGT byte array"""
+    lut = np.zeros(256, dtype=np.uint64)
+    for ch, v in zip(b"CGAT", range(4)):
+        lut[ch] = v
+    c = lut[seq]
+    n = len(seq) - k + 1
+    fwd = np.zeros(n, dtype=np.uint64)
+    rev = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        fwd = (fwd << np.uint64(2)) | c[j:j + n]
+        rev = rev | ((c[j:j + n] ^ np.uint64(1)) << np.uint64(2 * j))
+    return np.maximum(fwd, rev).astype(np.int64)
+
+
+class SynthDB:
+    """arrays of a synthetic store: kmers (sorted int64), value_idx, parent_vi, genomes (S_total x genome_len)"""
+
+    def __init__(self, k=31, genera=4, species_per_genus=5, genome_len=100_000, seed=42):
+        self.k, self.genome_len = k, genome_len
+        n_species = genera * species_per_genus
+        # value indices in pre-order: root 0, genus, its species, next genus ...
+        parent, genus_vi, species_vi, taxids = [-1], [], [], ["1"]
+        vi = 1
+        for g in range(genera):
+            genus_vi.append(vi)
+            parent.append(0)
+            taxids.append(str(1000 + g))
+            vi += 1
+            for s in range(species_per_genus):
+                species_vi.append(vi)
+                parent.append(genus_vi[g])
+                taxids.append(str(100000 + g * 1000 + s))
+                vi += 1
+        self.n_values = vi
+        self.parent_vi = np.array(parent, dtype=np.int32)
+        self.taxids = taxids
+        self.species_vi = np.array(species_vi, dtype=np.int32)
+        root_core = _random_dna(seed * 1000003 + 1, genome_len)
+        genomes = np.empty((n_species, genome_len), dtype=np.uint8)
+        seg = 500  # shared material is copied in 500-base segments
+        n_seg = genome_len // seg
+        # the shared segments are the same for every member of a genus (5 %) / for every species (1 %)
+        root_pick = (_splitmix64(seed * 7 + 1, n_seg) % np.uint64(100)) < np.uint64(1)
+        for g in range(genera):
+            genus_core = _random_dna(seed * 1000003 + 100 + g, genome_len)
+            genus_pick = (_splitmix64(seed * 7 + 100 + g, n_seg) % np.uint64(100)) < np.uint64(5)
+            for s in range(species_per_genus):
+                i = g * species_per_genus + s
+                gen = _random_dna(seed * 1000003 + 10000 + i, genome_len).copy()
+                for b in range(n_seg):
+                    src = root_core if root_pick[b] else genus_core if genus_pick[b] else None
+                    if src is not None:
+                        gen[b * seg:(b + 1) * seg] = src[b * seg:(b + 1) * seg]
+                genomes[i] = gen
+        self.genomes = genomes
+        # k-mer -> LCA of the species containing it
+        ks, vs = [], []
+        for i in range(n_species):
+            u = np.unique(canonical_kmers(genomes[i], k))
+            ks.append(u)
+            vs.append(np.full(len(u), species_vi[i], dtype=np.int32))
+        allk = np.concatenate(ks)
+        allv = np.concatenate(vs)
+        order = np.argsort(allk, kind="stable")
+        allk, allv = allk[order], allv[order]
+        first = np.concatenate([[True], allk[1:] != allk[:-1]])
+        grp = np.cumsum(first) - 1
+        n_groups = int(grp[-1]) + 1
+        par = self.parent_vi
+        vmin = np.full(n_groups, np.iinfo(np.int32).max, dtype=np.int32)
+        vmax = np.full(n_groups, -1, dtype=np.int32)
+        np.minimum.at(vmin, grp, allv)
+        np.maximum.at(vmax, grp, allv)
+        gmin, gmax = par[vmin], par[vmax]  # genus of the smallest / largest species (pre-order => contiguous)
+        val = np.where(vmin == vmax, vmin, np.where(gmin == gmax, gmin, 0)).astype(np.int32)
+        self.kmers = allk[first]
+        self.value_idx = val
+
+    @property
+    def n_entries(self):
+        return len(self.kmers)
+
+
+def _syn():
+    global _SYN
+    if _SYN is None:
+        path = os.path.join(_HERE, "libgssynth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: build with `make -C genestrip_amd/csrc`")
+        from .binding import _preload_hip_runtime
+        _preload_hip_runtime()
+        L = C.CDLL(path)
+        args = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.gs_synth_reads_host.restype, L.gs_synth_reads_host.argtypes = None, args
+        L.gs_synth_reads_device.restype, L.gs_synth_reads_device.argtypes = C.c_int, args
+        _SYN = L
+    return _SYN
+
+
+def reads_host(genomes, n_reads, read_len=150, seed=4242, first=0):
+    """(seq uint8[n*L], offsets uint64[n+1]) on the host"""
+    genomes = np.ascontiguousarray(genomes, dtype=np.uint8)
+    seq = np.empty(n_reads * read_len, dtype=np.uint8)
+    off = np.empty(n_reads + 1, dtype=np.uint64)
+    _syn().gs_synth_reads_host(seed, first, n_reads, read_len, genomes.ctypes.data_as(C.c_void_p), genomes.shape[0],
+                               genomes.shape[1], seq.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p))
+    return seq, off
+
+
+def reads_device(genomes_dev, n_genomes, genome_len, n_reads, seq_dev, off_dev, read_len=150, seed=4242, first=0):
+    """fill device buffers (tensor-likes with data_ptr()) with the same reads as reads_host"""
+    rc = _syn().gs_synth_reads_device(seed, first, n_reads, read_len, C.c_void_p(genomes_dev.data_ptr()), n_genomes,
+                                      genome_len, C.c_void_p(seq_dev.data_ptr()), C.c_void_p(off_dev.data_ptr()))
+    if rc != 0:
+        raise RuntimeError(f"gs_synth_reads_device failed: hip error {-rc}")

@@ -1,0 +1,185 @@
+/*
+ * gsgpu.h -- C ABI of the MI355X-native engine for Genestrip's `match` / `filter` hot path.
+ *
+ * This is the drop-in boundary.  The reference (pure Java) has no FFI for this
+ * path; its seams are Java virtual methods.  Each entry point below names the reference interface it
+ * replaces (paths relative to /root/reference, C/ = core/src/main/java/org/metagene/genestrip/).
+ * INTEGRATION.md shows the JNI stub + Java subclasses a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (GS_OK) or a negative GS_E_* code; the message of the
+ *    last failure on the calling thread is available from gs_last_error().  No exceptions cross the ABI.
+ *  - arrays passed to *_create are borrowed for the duration of the call (copied to HBM before return).
+ *  - handles are not thread safe; use one submitting thread per handle.  Handles on different devices
+ *    (one process per GPU) are independent.
+ *  - `mem` says where the batch pointers of a submit call live: GS_MEM_HOST (pageable or pinned host
+ *    memory; the library stages it to HBM) or GS_MEM_DEVICE (already resident in HBM of the handle's
+ *    device; used by bench.py and by callers that ingest on the GPU).  It applies to inputs and outputs.
+ */
+#ifndef GSGPU_H
+#define GSGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+enum {
+    GS_OK = 0,
+    GS_E_INVALID = -1,   /* bad argument                                   */
+    GS_E_NOMEM = -2,     /* host or device allocation failed               */
+    GS_E_HIP = -3,       /* a HIP runtime call failed                      */
+    GS_E_UNSUPPORTED = -4,
+    GS_E_STATE = -5,     /* call order violated                            */
+    GS_E_NODEVICE = -6   /* no usable gfx950 device                        */
+};
+
+enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1 };
+
+const char *gs_last_error(void);
+const char *gs_strerror(int code);
+int gs_abi_version(void);
+int gs_device_count(int *n);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Device-resident k-mer store + taxonomy
+ *
+ * Replaces, for lookups: KMerStore.getLong (C/store/KMerSortedArray.java:298-349,
+ * C/store/RadixKMerStore.java:369-412) and the SmallTaxTree ancestor/LCA queries
+ * (C/tax/SmallTaxTree.java:184-289).  Filled from the Java side through KMerStore.visit
+ * (C/store/KMerSortedArray.java:426-439): (kmer, valueIndex) in ascending kmer order.
+ *
+ *   kmers_sorted[n_entries]  canonical k-mers in the reference encoding (CGAT.java:66-74,145-147),
+ *                            strictly ascending
+ *   value_idx[n_entries]     store value index of each k-mer, in [0, n_values)
+ *   parent_vi[n_values]      value index of the parent tree node; -1 for the root; -2 if the value has
+ *                            no tree node (Database.convertKMerStore maps it to null => k-mer is a miss,
+ *                            C/store/Database.java:136-143).  Every tree node has a value index
+ *                            (Database.initStoreIndices, C/store/Database.java:107-128).
+ *                            NULL => no tree (classification must be off); every value is a node.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gs_db gs_db;
+
+typedef struct {
+    int32_t k;
+    int32_t n_values;
+    int64_t n_entries;      /* entries handed in                                            */
+    int64_t n_stored;       /* entries in the device table (reachable + with a tree node)   */
+    int64_t n_buckets;      /* 64-byte buckets of 8 slots                                   */
+    int64_t table_bytes;
+    int32_t max_displacement;
+    int32_t value_bits;
+} gs_db_info;
+
+int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,
+                 const int32_t *value_idx, int32_t n_values, const int32_t *parent_vi);
+int gs_db_get_info(const gs_db *db, gs_db_info *info);
+int gs_db_destroy(gs_db *db);
+
+/* ---------------------------------------------------------------------------------------------------
+ * match
+ *
+ * Replaces FastqKMerMatcher.runMatcher / matchRead (C/match/FastqKMerMatcher.java:181-235, :327-535)
+ * plus KMerUniqueCounterBits (C/store/KMerUniqueCounterBits.java:117-163).  One gs_run corresponds to
+ * one runMatcher call (one output key): stats and the unique bitmap start cleared (:192-193).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gs_run gs_run;
+
+typedef struct {
+    int32_t classify;           /* taxTree != null (MatchResultGoal.java:125-127)                */
+    int32_t count_unique;       /* GSConfigKey countUniqueKMers (C/GSConfigKey.java:305)         */
+    int32_t max_paths;          /* maxClassificationPaths (:350), 1..64                          */
+    int32_t threshold;          /* minKMersForClass (:341)                                       */
+    double max_read_tax_err;    /* maxReadTaxErrorCount (:328), -1 = off                         */
+    double max_read_class_err;  /* maxReadClassErrorCount (:337), -1 = off                       */
+    int32_t profile;            /* != 0: record HIP events around the kernels of each submit     */
+    int32_t reserved;
+} gs_match_cfg;
+
+/* integer result table: one row per value index (CountsPerTaxid fields, C/match/CountsPerTaxid.java:127-159) */
+enum {
+    GS_C_READS = 0,
+    GS_C_READS_KMERS,
+    GS_C_KMERS,
+    GS_C_UNIQUE_KMERS,       /* -1 in every row when count_unique == 0 (FastqKMerMatcher.java:226-230) */
+    GS_C_CONTIGS,            /* Java field is int; the table keeps the exact 64-bit count               */
+    GS_C_CONTIG_LEN_SQ_SUM,
+    GS_C_MAX_CONTIG_LEN,
+    GS_C_READS_1KMER,
+    GS_C_READS_BPS,
+    GS_C_MAX_CONTIG_READ_NO, /* readNo of the first read (file order) with the max contig, -1 if none   */
+    GS_N_COLS
+};
+enum { GS_D_ERR_SUM = 0, GS_D_ERR_SQ_SUM, GS_D_CLASS_ERR_SUM, GS_D_CLASS_ERR_SQ_SUM, GS_N_DCOLS };
+
+/* per-read flags (optional output) */
+enum {
+    GS_F_FOUND = 1,     /* >= 1 k-mer of the read hit the store                                   */
+    GS_F_RETURNED = 2,  /* matchRead's return value: read goes to the filtered FASTQ (:304-307)   */
+    GS_F_COUNTED = 4    /* read passed the class-error gate and was added to `reads` (:508-526)   */
+};
+
+int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg);
+
+/* One batch of reads: read i = seq[offsets[i] .. offsets[i+1]), readNo = first_read_no + i
+ * (AbstractFastqReader.java:343).  class_vi / flags may be NULL; when given they receive, per read,
+ * entry.classNode's value index (-1 = null) and GS_F_* bits.  Asynchronous for GS_MEM_DEVICE (call
+ * gs_match_sync / gs_match_finish before reading outputs); synchronous for GS_MEM_HOST. */
+int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                    int64_t first_read_no, int mem, int32_t *class_vi, uint8_t *flags);
+int gs_match_sync(gs_run *run);
+
+/* table: n_values x GS_N_COLS int64 ; dtable (may be NULL): n_values x GS_N_DCOLS double (sums of doubles
+ * accumulate in device order: not bit-reproducible, as with threads > 0 in the reference).  Host pointers. */
+int gs_match_finish(gs_run *run, int64_t *table, double *dtable);
+int gs_match_reset(gs_run *run); /* same matcher, next key: clears stats + unique bitmap */
+int gs_match_destroy(gs_run *run);
+
+/* Multi-GPU (read-sharded) merge hooks: raw device pointers of the run's accumulators so that the host
+ * can reduce them over RCCL before gs_match_finish (sum over ranks for `sums`, max for `max_keys`,
+ * all-gather + gs_match_or_bitmap for the unique bitmap).
+ *   sums      int64  [n_values][GS_N_SUMS]   additive columns
+ *   max_keys  int64  [n_values]              (maxContigLen << 40) | (2^40-1 - readNo), 0 = none
+ *   dsums     double [n_values][GS_N_DCOLS]
+ *   bitmap    uint32 [bitmap_words]          one bit per table slot                                */
+enum { GS_S_READS = 0, GS_S_READS_KMERS, GS_S_KMERS, GS_S_CONTIGS, GS_S_CONTIG_LEN_SQ_SUM, GS_S_READS_1KMER,
+       GS_S_READS_BPS, GS_N_SUMS };
+int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsums, void **bitmap,
+                          int64_t *bitmap_words);
+/* bitmap |= OR of n_parts device bitmaps laid out back to back at `parts` (each bitmap_words long) */
+int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
+
+/* accumulated device time of the match kernel launches since begin/reset (cfg.profile != 0) */
+int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);
+
+/* ---------------------------------------------------------------------------------------------------
+ * filter
+ *
+ * Replaces FastqBloomFilter.isAcceptRead (C/bloom/FastqBloomFilter.java:120-161) over a device copy of
+ * the reference's index filter: XORKMerBloomFilter / MurmurKMerBloomFilter
+ * (C/bloom/AbstractKMerBloomFilter.java:209-216, fields :52-62) or BlockedKMerBloomFilter
+ * (C/bloom/BlockedKMerBloomFilter.java:181-199).  The bit array and hash factors are replicated
+ * exactly, so false positives are identical.
+ *   kind GS_BLOOM_XOR/MURMUR: bits = number of bits, hash_factors[n_hashes]
+ *   kind GS_BLOOM_BLOCKED:    bits = number of buckets, hash_factors[0] = seed, n_hashes ignored
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gs_bloom gs_bloom;
+enum { GS_BLOOM_XOR = 0, GS_BLOOM_MURMUR = 1, GS_BLOOM_BLOCKED = 2 };
+
+int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bits, int32_t n_hashes,
+                    const int64_t *hash_factors, const uint64_t *words, int64_t n_words);
+int gs_bloom_destroy(gs_bloom *bloom);
+/* accept[i] = isAcceptRead(read i) ? 1 : 0.  profile != 0 records kernel time (gs_filter_kernel_time). */
+int gs_filter_submit(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *seq,
+                     const uint64_t *offsets, int64_t n_reads, int mem, uint8_t *accept, int profile);
+int gs_filter_sync(gs_bloom *bloom);
+int gs_filter_kernel_time(gs_bloom *bloom, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
