@@ -46,7 +46,7 @@ class GsError(RuntimeError):
 class DbInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("n_values", C.c_int32), ("n_entries", C.c_int64), ("n_stored", C.c_int64),
                 ("n_buckets", C.c_int64), ("table_bytes", C.c_int64), ("max_displacement", C.c_int32),
-                ("value_bits", C.c_int32)]
+                ("value_bits", C.c_int32), ("gate_bytes", C.c_int64)]
 
 
 class _MatchCfg(C.Structure):
@@ -56,7 +56,8 @@ class _MatchCfg(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgsgpu.so")
+    # GS_LIBGSGPU: developer override used to A/B kernel build variants on the GPU box
+    return os.environ.get("GS_LIBGSGPU") or os.path.join(_HERE, "libgsgpu.so")
 
 
 def _preload_hip_runtime():

@@ -24,7 +24,7 @@ extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *b
 extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
-extern "C" int gs_match_occupancy(int lds_stats);
+extern "C" int gs_match_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
 
 // ---------------------------------------------------------------------------------------------------
@@ -91,6 +91,7 @@ struct gs_db {
     gs_db_info info{};
     GsDbDev dev{};
     u64 *d_table = nullptr;
+    u64 *d_gate = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth | tin | tout
     int n_cu = 256;
 };
@@ -125,7 +126,8 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
     if (!out) return fail(GS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
-    if (n < 0 || n_values < 1 || (n > 0 && (!kmers || !vidx))) return fail(GS_E_INVALID, "bad store arrays");
+    if (n < 0 || n_values < 1 || n_values > (1 << 24) || (n > 0 && (!kmers || !vidx)))
+        return fail(GS_E_INVALID, "bad store arrays (n_values must be in [1, 2^24])");
     int rc = use_device(device);
     if (rc) return rc;
     for (int64_t i = 0; i < n; i++) {
@@ -221,6 +223,21 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
         }
         if (ok) break;
     }
+    // ---- L2-resident gate (see gs_layout.h): ~8-16 bits per key, only if it fits the per-XCD L2 budget
+    std::vector<u64> gate;
+    {
+        size_t max_bytes = (size_t)2 << 20;
+        if (const char *e = getenv("GS_GATE_MAX_BYTES")) max_bytes = (size_t)atoll(e);
+        size_t bits_per_key = 8;  // rounded up to a power-of-two word count: 8..16 bits per key
+        if (const char *e = getenv("GS_GATE_BITS_PER_KEY")) bits_per_key = (size_t)std::max(1, atoi(e));
+        int wbits = 3;
+        while (((size_t)64 << wbits) < (size_t)ns * bits_per_key) wbits++;
+        if (ns > 0 && ((size_t)8 << wbits) <= max_bytes && b + wbits <= GS_GATE_FIELD_SHIFT) {
+            gate.assign((size_t)1 << wbits, 0);
+            const u64 gmask = ((u64)1 << wbits) - 1;
+            for (int64_t i = 0; i < ns; i++) gate[(hkey[i] >> b) & gmask] |= gs_gate_bits(hkey[i]);
+        }
+    }
     gs_db *db = new gs_db();
     db->device = device;
     hipDeviceProp_t prop;
@@ -229,6 +246,8 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
     const size_t tbytes = table.size() * sizeof(u64);
     hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
+    if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
+    if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
@@ -236,6 +255,7 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
     if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(db->d_table);
+        hipFree(db->d_gate);
         hipFree(db->d_tree);
         delete db;
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
@@ -249,6 +269,9 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
     db->info.max_displacement = max_disp;
     db->info.value_bits = vbits;
     db->dev.table = db->d_table;
+    db->dev.gate = db->d_gate;
+    db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
+    db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
     db->dev.bucket_bits = (uint32_t)b;
     db->dev.vbits = (uint32_t)vbits;
     db->dev.bucket_mask = (1ULL << b) - 1;
@@ -272,6 +295,7 @@ extern "C" int gs_db_destroy(gs_db *db) {
     if (!db) return GS_OK;
     hipSetDevice(db->device);
     hipFree(db->d_table);
+    hipFree(db->d_gate);
     hipFree(db->d_tree);
     delete db;
     return GS_OK;
@@ -364,8 +388,9 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         run_free(run);
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("run alloc: ") + hipGetErrorString(e));
     }
-    int occ = gs_match_occupancy(db->info.n_values <= GS_NV_LDS);
+    int occ = gs_match_occupancy(db->info.n_values);
     if (occ < 1) occ = 1;
+    if (occ > 6) occ = 6;  // measured: 6 workgroups (24 waves) per CU is the optimum, 7 thrashes the caches
     if (const char *ev = getenv("GS_MATCH_BLOCKS_PER_CU")) {
         int v = atoi(ev);
         if (v >= 1 && v <= 16) occ = v;
@@ -562,9 +587,7 @@ extern "C" int gs_match_reset(gs_run *run) {
     HIP_TRY(hipSetDevice(run->db->device));
     int rc = collect_events(run);
     if (rc) return rc;
-    run->launches = 0;
-    run->total_ms = 0;
-    return run_clear(run);
+    return run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
 }
 
 extern "C" int gs_match_destroy(gs_run *run) {

@@ -82,38 +82,54 @@ struct GsStats {
 // ---------------------------------------------------------------------------------------------------
 // store probe
 // ---------------------------------------------------------------------------------------------------
+typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
+
+#ifndef GS_NT_TABLE
+// Measured on MI355X: non-temporal bucket loads stop the four dwordx4 loads of one 64-byte line from sharing a
+// single L2 request (the match kernel ran 2.2x slower), so the default is plain loads.
+#define GS_NT_TABLE 0
+#endif
+
 struct GsBucket {
-    ulonglong2 q[4];
+    gs_u64x2 q[4];
 };
 
 __device__ __forceinline__ void gs_load_bucket(const u64 *table, u64 bkt, GsBucket &b) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(table + bkt * GS_SLOTS_PER_BUCKET);
+    const gs_u64x2 *p = reinterpret_cast<const gs_u64x2 *>(table + bkt * GS_SLOTS_PER_BUCKET);
+#if GS_NT_TABLE
+    b.q[0] = __builtin_nontemporal_load(p);
+    b.q[1] = __builtin_nontemporal_load(p + 1);
+    b.q[2] = __builtin_nontemporal_load(p + 2);
+    b.q[3] = __builtin_nontemporal_load(p + 3);
+#else
     b.q[0] = p[0];
     b.q[1] = p[1];
     b.q[2] = p[2];
     b.q[3] = p[3];
+#endif
 }
 
-// returns true when the probe is finished (hit, or miss proven by a non-full bucket)
-__device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, u64 vmask, int &vi, int &slot) {
+// returns true when the probe is finished (hit, or miss proven by a non-full bucket).
+// slot = rem << (vbits+2) | disp << vbits | (vi+1) with vbits+2 < 32: a match has an equal high dword and a low
+// dword that differs from `want` (value field 0) by exactly the value field, i.e. 0 < lo ^ want_lo <= vmask.
+// Buckets fill front to back, so "full" is "slot 7 is occupied".
+__device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, uint32_t vmask, int &vi, int &slot) {
     const u64 s[8] = {b.q[0].x, b.q[0].y, b.q[1].x, b.q[1].y, b.q[2].x, b.q[2].y, b.q[3].x, b.q[3].y};
-    bool full = true;
+    const uint32_t want_hi = (uint32_t)(want >> 32), want_lo = (uint32_t)want;
     int hit = -1, val = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        u64 x = s[j] ^ want;  // equal high part  <=>  0 < x <= vmask  (value field is vi+1 >= 1)
-        if (x - 1 < vmask) {
-            hit = j;
-            val = (int)x - 1;
-        }
-        full = full && (s[j] != 0);
+        const uint32_t y = ((uint32_t)s[j] ^ want_lo) - 1u;
+        const bool m = ((uint32_t)(s[j] >> 32) == want_hi) && (y < vmask);
+        val = m ? (int)y : val;
+        hit = m ? j : hit;
     }
     if (hit >= 0) {
         vi = val;
         slot = hit;
         return true;
     }
-    return !full;
+    return s[7] == 0;
 }
 
 // canonical planar key of the k-mer whose forward planes are (fhi, flo); reference-exact orientation choice
@@ -156,7 +172,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
     const GsDbDev &db = P.db;
     const int k = db.k;
     const uint32_t kmask = (1u << k) - 1u;
-    const u64 vmask = (1ULL << db.vbits) - 1;
+    const uint32_t vmask = (1u << db.vbits) - 1u;
     const int shift_rem = (int)db.vbits + 2;
     const u64 off = P.off[r];
     const int L = (int)(P.off[r + 1] - off);
@@ -199,7 +215,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             }
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
             int node[2], slot[2];
-            u64 bkt[2], want[2];
+            u64 bkt[2], want[2], gword[2], gbits[2];
             bool act[2];
             GsBucket bk[2];
 #pragma unroll
@@ -215,6 +231,13 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 act[s] = valid && (wbad == 0);
                 node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
                 slot[s] = 0;
+                gword[s] = ~0ULL;
+                gbits[s] = gs_gate_bits(h);
+                if (db.gate != nullptr && act[s]) gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                act[s] = act[s] && ((gword[s] & gbits[s]) == gbits[s]);  // gate: no false negatives
                 if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
             }
 #pragma unroll
@@ -494,11 +517,14 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// dynamic LDS: [nv*GS_N_SUMS u64 sums][nv u64 max keys][nv*GS_N_DCOLS doubles] -- sized to the store's value count
+// so that small taxonomies do not cap the occupancy
 #define GS_STATS_PROLOGUE()                                                                           \
-    __shared__ u64 s_sums[LDS_STATS ? GS_NV_LDS * GS_N_SUMS : 1];                                     \
-    __shared__ u64 s_max[LDS_STATS ? GS_NV_LDS : 1];                                                  \
-    __shared__ double s_d[LDS_STATS ? GS_NV_LDS * GS_N_DCOLS : 1];                                    \
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_dyn_lds[];                        \
     const int nv = P.db.n_values;                                                                     \
+    u64 *s_sums = reinterpret_cast<u64 *>(gs_dyn_lds);                                                \
+    u64 *s_max = s_sums + (LDS_STATS ? nv * GS_N_SUMS : 0);                                           \
+    double *s_d = reinterpret_cast<double *>(s_max + (LDS_STATS ? nv : 0));                           \
     if (LDS_STATS) {                                                                                  \
         for (int i = threadIdx.x; i < nv * GS_N_SUMS; i += blockDim.x) s_sums[i] = 0;                 \
         for (int i = threadIdx.x; i < nv; i += blockDim.x) s_max[i] = 0;                              \
@@ -726,9 +752,14 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
 // ---------------------------------------------------------------------------------------------------
 // launchers (called from gs_api.cpp)
 // ---------------------------------------------------------------------------------------------------
+static size_t gs_stats_lds_bytes(int n_values) {
+    return n_values <= GS_NV_LDS ? (size_t)n_values * (GS_N_SUMS + 1 + GS_N_DCOLS) * 8 : 0;
+}
+
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
+    const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     if (P->db.n_values <= GS_NV_LDS)
-        hipLaunchKernelGGL(gs_match_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        hipLaunchKernelGGL(gs_match_kernel<true>, dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
     else
         hipLaunchKernelGGL(gs_match_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     return hipGetLastError();
@@ -737,16 +768,18 @@ extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStrea
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream) {
     if (P->db.n_values <= GS_NV_LDS)
-        hipLaunchKernelGGL(gs_match_long_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+        hipLaunchKernelGGL(gs_match_long_kernel<true>, dim3(grid), dim3(GS_BLOCK), gs_stats_lds_bytes(P->db.n_values), stream, *P,
+                           scratch, serial);
     else
         hipLaunchKernelGGL(gs_match_long_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
     return hipGetLastError();
 }
 
-extern "C" int gs_match_occupancy(int lds_stats) {
+extern "C" int gs_match_occupancy(int n_values) {
     int n = 0;
-    hipError_t e = lds_stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true>, GS_BLOCK, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false>, GS_BLOCK, 0);
+    hipError_t e = n_values <= GS_NV_LDS
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true>, GS_BLOCK, gs_stats_lds_bytes(n_values))
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false>, GS_BLOCK, 0);
     return e == hipSuccess ? n : 0;
 }
 

@@ -73,6 +73,7 @@ typedef struct {
     int64_t table_bytes;
     int32_t max_displacement;
     int32_t value_bits;
+    int64_t gate_bytes;     /* L2-resident pre-filter (0 = not built: store too large for it)  */
 } gs_db_info;
 
 int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,
@@ -153,7 +154,7 @@ int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsum
 /* bitmap |= OR of n_parts device bitmaps laid out back to back at `parts` (each bitmap_words long) */
 int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
 
-/* accumulated device time of the match kernel launches since begin/reset (cfg.profile != 0) */
+/* accumulated device time of the match kernel launches since gs_match_begin (cfg.profile != 0) */
 int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);
 
 /* ---------------------------------------------------------------------------------------------------
