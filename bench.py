@@ -26,6 +26,18 @@ BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence byte
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def _usable_cores():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("GS_CPU_THREADS", n))))
+
+
 class _DevArray:
     """zero-copy view of a raw device pointer for torch.as_tensor"""
 
@@ -141,8 +153,7 @@ def main():
     # ---- parity gate + CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same reads
     if rank == 0:
         from oracle import gs_oracle as orc
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = max(1, min(cores, int(os.environ.get("GS_CPU_THREADS", cores))))
+        cores = _usable_cores()
         odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
         nchk = min(args.check_reads, n)
         seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
