@@ -8,6 +8,8 @@ full replica of the store.  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+GS_BENCH_FORCE_MERGE=1 runs the RCCL merge path even at N = 1 (rehearsal of the multi-GPU code on one GPU).
 """
 import argparse
 import json
@@ -60,6 +62,7 @@ def main():
 
     import genestrip_amd as ga
     from genestrip_amd import synth
+    from genestrip_amd.distributed import merge_run_state
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,8 +73,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (genestrip_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_merge = os.environ.get("GS_BENCH_FORCE_MERGE", "") == "1"
+    use_dist = world > 1 or force_merge
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- inputs: store replica per GPU, this rank's slice of the read stream generated directly in HBM
@@ -93,23 +99,18 @@ def main():
     t_max = torch.as_tensor(_DevArray(st["max_keys"], nv, "<i8"), device=dev)
     t_dsum = torch.as_tensor(_DevArray(st["dsums"], nv * ga.N_DCOLS, "<f8"), device=dev)
     t_bits = torch.as_tensor(_DevArray(st["bitmap"], st["bitmap_words"], "<i4"), device=dev)
-    t_gather = torch.empty(world * st["bitmap_words"], dtype=torch.int32, device=dev) if world > 1 else None
 
-    def step():
+    def step(n_reads=n):
         m.reset()
-        m.submit(dseq, doff, first, n_reads=n)
-        if world > 1:
-            m.sync()
-            dist.all_reduce(t_sums, op=dist.ReduceOp.SUM)
-            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-            dist.all_reduce(t_dsum, op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(t_gather, t_bits)
-            torch.cuda.synchronize()
-            m.or_bitmap(t_gather.data_ptr(), world)
+        m.submit(dseq, doff, first, n_reads=n_reads)
+        if use_dist:
+            m.sync()  # the kernels run on the library's stream; the collectives on torch's
+            merge_run_state(t_sums, t_max, t_dsum, t_bits, force=force_merge,
+                            or_parts=lambda g, w: m.or_bitmap(g.data_ptr(), w))
         return m.finish()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +125,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launches1, ms1 = m.kernel_time()
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -143,46 +144,55 @@ def main():
         "config": {"workload": "match: %d synthetic 150 bp reads per GPU, k=31, %d-k-mer / %d-taxid store resident in HBM "
                                "(BASELINE.json configs[1])" % (n, db.n_entries, len(db.species_vi)),
                    "reads_per_gpu": n, "read_len": READ_LEN, "k": K, "store_kmers": int(db.n_entries),
-                   "store_table_bytes": int(info.table_bytes), "parallelism": "read-sharded x%d, store replicated" % world},
+                   "store_table_bytes": int(info.table_bytes), "gate_bytes": int(info.gate_bytes),
+                   "parallelism": "read-sharded x%d, store replicated" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "gs_match_kernel", "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": n * BYTES_PER_READ},
     }
 
-    # ---- parity gate + CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same reads
+    # ---- parity gate.  N = 1: the first --check-reads reads against the CPU oracle (bit-exact integer table).
+    # N > 1: every rank must hold the same merged table, and rank 0 re-checks its own slice against the oracle.
+    nchk = min(args.check_reads, n)
+    if use_dist and world > 1:
+        digest = torch.tensor([int(np.asarray(table, dtype=np.int64).sum() % (1 << 62))], dtype=torch.int64, device=dev)
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["parity"] = {"merged_table_identical_on_all_ranks": bool(lo.item() == hi.item())}
     if rank == 0:
         from oracle import gs_oracle as orc
         cores = _usable_cores()
         odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
-        nchk = min(args.check_reads, n)
         seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
         orun = orc.MatchRun(odb)
         t1 = time.perf_counter()
         orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
         dt_chk = time.perf_counter() - t1
         otable, _ = orun.finish()
-        if world == 1:
-            m.reset()
-            m.submit(dseq, doff, first, n_reads=nchk)
-            gtable, _ = m.finish()
-            out["parity"] = {"reads_checked": nchk, "bit_exact": bool(np.array_equal(otable, gtable))}
-            if not out["parity"]["bit_exact"]:
-                out["value"] = None  # a throughput without parity does not count
-            if args.cpu_seconds > 0:
-                rate = nchk / dt_chk
-                ns = int(min(n, max(nchk, rate * args.cpu_seconds)))
-                seq, off = synth.reads_host(db.genomes, ns, read_len=READ_LEN, first=first)
-                orun = orc.MatchRun(odb)
-                t1 = time.perf_counter()
-                orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
-                dt = time.perf_counter() - t1
-                out["cpu_baseline"] = {
-                    "value": round(ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
-                    "sample": "first %d reads of the same stream, C restatement of the Java path (sorted array + "
-                              "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
+        m.reset()
+        m.submit(dseq, doff, first, n_reads=nchk)
+        gtable, _ = m.finish()
+        par = out.setdefault("parity", {})
+        par["reads_checked"] = nchk
+        par["bit_exact"] = bool(np.array_equal(otable, gtable))
+        if not par["bit_exact"] or par.get("merged_table_identical_on_all_ranks") is False:
+            out["value"] = None  # a throughput without parity does not count
+        if world == 1 and args.cpu_seconds > 0:
+            rate = nchk / dt_chk
+            ns = int(min(n, max(nchk, rate * args.cpu_seconds)))
+            seq, off = synth.reads_host(db.genomes, ns, read_len=READ_LEN, first=first)
+            orun = orc.MatchRun(odb)
+            t1 = time.perf_counter()
+            orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": round(ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
+                "sample": "first %d reads of the same stream, C restatement of the Java path (sorted array + "
+                          "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -678,7 +678,43 @@ int orc_match_submit(orc_run *run, const uint8_t *seq, const uint64_t *off, int6
     return 0;
 }
 
+static void merge_consumers(orc_run *run);
+
 int orc_match_finish(orc_run *run, int64_t *table, double *dtable) {
+    const orc_db *db = run->db;
+    size_t nv = (size_t)db->n_values;
+    merge_consumers(run);
+    /* KMerUniqueCounterBits.getUniqueKmerCounts :146-163 ; -1 when counting is off (:226-230) */
+    for (size_t v = 0; v < nv; v++) run->table[v * ORC_N_COLS + ORC_C_UNIQUE_KMERS] = run->cfg.count_unique ? 0 : -1;
+    if (run->cfg.count_unique)
+        for (int64_t i = 0; i < db->n; i++)
+            if ((run->unique_bits[i >> 6] >> (i & 63)) & 1ULL) run->table[(size_t)db->vidx[i] * ORC_N_COLS + ORC_C_UNIQUE_KMERS]++;
+    memcpy(table, run->table, sizeof(int64_t) * nv * ORC_N_COLS);
+    if (dtable) memcpy(dtable, run->dtable, sizeof(double) * nv * ORC_N_DCOLS);
+    return 0;
+}
+
+/* raw accumulator state of a run, for the multi-rank merge tests: the whole table (ORC_N_COLS columns, the
+ * unique column is not meaningful here), and the unique bit vector (one bit per store rank). */
+int64_t orc_match_bitmap_words(const orc_run *run) { return (run->db->n + 63) / 64 + 1; }
+
+int orc_match_export(orc_run *run, int64_t *table, uint64_t *bitmap) {
+    size_t nv = (size_t)run->db->n_values;
+    merge_consumers(run);
+    memcpy(table, run->table, sizeof(int64_t) * nv * ORC_N_COLS);
+    memcpy(bitmap, run->unique_bits, sizeof(uint64_t) * (size_t)orc_match_bitmap_words(run));
+    return 0;
+}
+
+int orc_match_import(orc_run *run, const int64_t *table, const uint64_t *bitmap) {
+    size_t nv = (size_t)run->db->n_values;
+    merge_consumers(run);
+    memcpy(run->table, table, sizeof(int64_t) * nv * ORC_N_COLS);
+    memcpy(run->unique_bits, bitmap, sizeof(uint64_t) * (size_t)orc_match_bitmap_words(run));
+    return 0;
+}
+
+static void merge_consumers(orc_run *run) {
     const orc_db *db = run->db;
     size_t nv = (size_t)db->n_values;
     /* merge consumers into the run table */
@@ -705,14 +741,6 @@ int orc_match_finish(orc_run *run, int64_t *table, double *dtable) {
             memset(c->dtable + v * ORC_N_DCOLS, 0, sizeof(double) * ORC_N_DCOLS);
         }
     }
-    /* KMerUniqueCounterBits.getUniqueKmerCounts :146-163 ; -1 when counting is off (:226-230) */
-    for (size_t v = 0; v < nv; v++) run->table[v * ORC_N_COLS + ORC_C_UNIQUE_KMERS] = run->cfg.count_unique ? 0 : -1;
-    if (run->cfg.count_unique)
-        for (int64_t i = 0; i < db->n; i++)
-            if ((run->unique_bits[i >> 6] >> (i & 63)) & 1ULL) run->table[(size_t)db->vidx[i] * ORC_N_COLS + ORC_C_UNIQUE_KMERS]++;
-    memcpy(table, run->table, sizeof(int64_t) * nv * ORC_N_COLS);
-    if (dtable) memcpy(dtable, run->dtable, sizeof(double) * nv * ORC_N_DCOLS);
-    return 0;
 }
 
 /* Kraken-style segments: the (lastTaxid, contigLen) pairs printKrakenStyleOut receives (:391-394,:452-454) */

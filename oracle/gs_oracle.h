@@ -114,6 +114,10 @@ int orc_match_submit(orc_run *run, const uint8_t *seq, const uint64_t *offsets, 
 /* table: n_values x ORC_N_COLS int64 ; dtable: n_values x ORC_N_DCOLS double (may be NULL) */
 int orc_match_finish(orc_run *run, int64_t *table, double *dtable);
 void orc_match_destroy(orc_run *run);
+/* raw accumulator state for the multi-rank merge tests: table n_values x ORC_N_COLS, bitmap one bit per store rank */
+int64_t orc_match_bitmap_words(const orc_run *run);
+int orc_match_export(orc_run *run, int64_t *table, uint64_t *bitmap);
+int orc_match_import(orc_run *run, const int64_t *table, const uint64_t *bitmap);
 
 /* Kraken-style segments of one read (FastqKMerMatcher.java:597-611): writes up to cap (code,len)
  * pairs, code = value index, -1 (miss, "0") or -2 (INVALID, "A"); returns number of segments. */

@@ -64,6 +64,8 @@ def lib():
         "orc_match_begin": (vp, [vp, vp]),
         "orc_match_submit": (C.c_int, [vp, vp, vp, i64, i64, vp, vp, C.c_int]),
         "orc_match_finish": (C.c_int, [vp, vp, vp]), "orc_match_destroy": (None, [vp]),
+        "orc_match_bitmap_words": (i64, [vp]), "orc_match_export": (C.c_int, [vp, vp, vp]),
+        "orc_match_import": (C.c_int, [vp, vp, vp]),
         "orc_match_segments": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int]),
         "orc_parse_fastq": (C.POINTER(_Reads), [vp, C.c_size_t, C.c_int, C.c_int]),
         "orc_reads_free": (None, [C.POINTER(_Reads)]),
@@ -265,6 +267,18 @@ class MatchRun:
         d = np.zeros((self.db.n_values, N_DCOLS), dtype=np.float64)
         lib().orc_match_finish(self.h, _p(t), _p(d))
         return t, d
+
+    def export_state(self):
+        """(table int64 [nv, N_COLS], bitmap uint64[]) raw accumulators (multi-rank merge tests)"""
+        t = np.zeros((self.db.n_values, N_COLS), dtype=np.int64)
+        b = np.zeros(lib().orc_match_bitmap_words(self.h), dtype=np.uint64)
+        lib().orc_match_export(self.h, _p(t), _p(b))
+        return t, b
+
+    def import_state(self, table, bitmap):
+        t = np.ascontiguousarray(table, dtype=np.int64)
+        b = np.ascontiguousarray(bitmap, dtype=np.uint64)
+        lib().orc_match_import(self.h, _p(t), _p(b))
 
 
 def pack_reads(reads):

@@ -1,0 +1,78 @@
+"""world_size-2 gloo test of the read-sharded merge (genestrip_amd/distributed.py), on CPU.
+
+Each rank runs the oracle on its contiguous slice of the reads (global readNo kept), exports the raw
+accumulators, merges them with the same function bench.py uses over RCCL, and the merged result must equal
+a single-rank run over all reads, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+N_READS = 6000
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genestrip_amd import synth
+    from genestrip_amd.distributed import merge_run_state, shard_bounds
+    from oracle import gs_oracle as orc
+
+    db = synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=15000, seed=5)
+    seq, off = synth.reads_host(db.genomes, N_READS, read_len=150, seed=31)
+    lo, hi = shard_bounds(N_READS, rank, world)
+    odb = orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    run = orc.MatchRun(odb)
+    run.submit(seq, off[lo:hi + 1].copy(), first_read_no=lo)
+    table, bitmap = run.export_state()
+    # split the oracle table into the library's accumulator layout: additive columns + packed max key
+    add_cols = [orc.C_READS, orc.C_READS_KMERS, orc.C_KMERS, orc.C_CONTIGS, orc.C_CONTIG_LEN_SQ_SUM,
+                orc.C_READS_1KMER, orc.C_READS_BPS]
+    sums = torch.from_numpy(table[:, add_cols].copy())
+    mlen, mno = table[:, orc.C_MAX_CONTIG_LEN], table[:, orc.C_MAX_CONTIG_READ_NO]
+    keys = np.where(mlen > 0, (mlen << 40) | ((1 << 40) - 1 - np.maximum(mno, 0)), 0).astype(np.int64)
+    max_keys = torch.from_numpy(keys)
+    bits = torch.from_numpy(bitmap.view(np.int64).copy())
+    merge_run_state(sums, max_keys, None, bits)
+    merged = table.copy()
+    merged[:, add_cols] = sums.numpy()
+    k = max_keys.numpy()
+    merged[:, orc.C_MAX_CONTIG_LEN] = k >> 40
+    merged[:, orc.C_MAX_CONTIG_READ_NO] = np.where(k != 0, (1 << 40) - 1 - (k & ((1 << 40) - 1)), -1)
+    run.import_state(merged, bits.numpy().view(np.uint64))
+    final, _ = run.finish()
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), final)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_rank(tmp_path):
+    from genestrip_amd import synth
+    from oracle import gs_oracle as orc
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    db = synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=15000, seed=5)
+    seq, off = synth.reads_host(db.genomes, N_READS, read_len=150, seed=31)
+    run = orc.MatchRun(orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi))
+    run.submit(seq, off)
+    want, _ = run.finish()
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npy"))
+        assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+
+
+def test_shard_bounds_cover_everything():
+    from genestrip_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 1000):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
