@@ -1,0 +1,84 @@
+/*
+ * gsgpu_jni.c -- JNI shim between org.metagene.genestrip.gpu.GsGpuNative and the C ABI (include/gsgpu.h).
+ * SOURCE ONLY: not compiled in the build container (no JDK / jni.h).  Build on a host with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
+ *       -o libgsgpu_jni.so gsgpu_jni.c -L../../genestrip_amd -lgsgpu
+ */
+#include <jni.h>
+#include <stdint.h>
+
+#include "gsgpu.h"
+
+#define JNAME(n) Java_org_metagene_genestrip_gpu_GsGpuNative_##n
+
+static void throw_gs(JNIEnv *env, int rc) {
+    char msg[512];
+    snprintf(msg, sizeof(msg), "gsgpu error %d (%s): %s", rc, gs_strerror(rc), gs_last_error());
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg);
+}
+
+static void *addr(JNIEnv *env, jobject buf) { return buf ? (*env)->GetDirectBufferAddress(env, buf) : NULL; }
+
+JNIEXPORT jint JNICALL JNAME(deviceCount)(JNIEnv *env, jclass c) {
+    int n = 0;
+    gs_device_count(&n);
+    return n;
+}
+
+JNIEXPORT jlong JNICALL JNAME(dbCreate)(JNIEnv *env, jclass c, jint device, jint k, jlong n, jobject kmers, jobject vidx,
+                                        jint nValues, jobject parentVi) {
+    gs_db *db = NULL;
+    int rc = gs_db_create(&db, device, k, n, (const int64_t *)addr(env, kmers), (const int32_t *)addr(env, vidx), nValues,
+                          (const int32_t *)addr(env, parentVi));
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)db;
+}
+
+JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db_destroy((gs_db *)(intptr_t)db); }
+
+JNIEXPORT jlong JNICALL JNAME(matchBegin)(JNIEnv *env, jclass c, jlong db, jboolean classify, jboolean countUnique,
+                                          jint maxPaths, jint threshold, jdouble taxErr, jdouble classErr) {
+    gs_match_cfg cfg = {classify ? 1 : 0, countUnique ? 1 : 0, maxPaths, threshold, taxErr, classErr, 0, 0};
+    gs_run *run = NULL;
+    int rc = gs_match_begin(&run, (gs_db *)(intptr_t)db, &cfg);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)run;
+}
+
+JNIEXPORT void JNICALL JNAME(matchSubmit)(JNIEnv *env, jclass c, jlong run, jobject seq, jobject offsets, jlong nReads,
+                                          jlong firstReadNo, jobject classVi, jobject flags) {
+    int rc = gs_match_submit((gs_run *)(intptr_t)run, (const uint8_t *)addr(env, seq), (const uint64_t *)addr(env, offsets),
+                             nReads, firstReadNo, GS_MEM_HOST, (int32_t *)addr(env, classVi), (uint8_t *)addr(env, flags));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchFinish)(JNIEnv *env, jclass c, jlong run, jobject table, jobject dtable) {
+    int rc = gs_match_finish((gs_run *)(intptr_t)run, (int64_t *)addr(env, table), (double *)addr(env, dtable));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchReset)(JNIEnv *env, jclass c, jlong run) {
+    int rc = gs_match_reset((gs_run *)(intptr_t)run);
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchDestroy)(JNIEnv *env, jclass c, jlong run) { gs_match_destroy((gs_run *)(intptr_t)run); }
+
+JNIEXPORT jlong JNICALL JNAME(bloomCreate)(JNIEnv *env, jclass c, jint device, jint kind, jlong bits, jint nHashes,
+                                           jlongArray factors, jobject words, jlong nWords) {
+    gs_bloom *b = NULL;
+    jlong *f = (*env)->GetLongArrayElements(env, factors, NULL);
+    int rc = gs_bloom_create(&b, device, kind, bits, nHashes, (const int64_t *)f, (const uint64_t *)addr(env, words), nWords);
+    (*env)->ReleaseLongArrayElements(env, factors, f, JNI_ABORT);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)b;
+}
+
+JNIEXPORT void JNICALL JNAME(bloomDestroy)(JNIEnv *env, jclass c, jlong b) { gs_bloom_destroy((gs_bloom *)(intptr_t)b); }
+
+JNIEXPORT void JNICALL JNAME(filterSubmit)(JNIEnv *env, jclass c, jlong b, jint k, jint minPos, jdouble ratio, jobject seq,
+                                           jobject offsets, jlong nReads, jobject accept) {
+    int rc = gs_filter_submit((gs_bloom *)(intptr_t)b, k, minPos, ratio, (const uint8_t *)addr(env, seq),
+                              (const uint64_t *)addr(env, offsets), nReads, GS_MEM_HOST, (uint8_t *)addr(env, accept), 0);
+    if (rc) throw_gs(env, rc);
+}

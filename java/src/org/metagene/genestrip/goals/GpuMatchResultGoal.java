@@ -1,0 +1,34 @@
+/*
+ * The factory hook: MatchResultGoal.createMatcher (reference: core/src/main/java/org/metagene/genestrip/goals/
+ * MatchResultGoal.java:174-194) is protected and exists exactly for this kind of override -- the reference's own
+ * tests override it the same way (core/src/test/java/org/metagene/genestrip/goals/refseq/
+ * ComprehensiveFilterTest.java:114-150).  SOURCE ONLY (no JDK in the build container); see INTEGRATION.md.
+ *
+ * Wire it in by overriding GSMaker.createGoalChainForMatchResult (C/GSMaker.java:560-583) to construct this goal
+ * instead of MatchResultGoal; everything else (Database.load, CSV reporting, goal graph) stays untouched.
+ */
+package org.metagene.genestrip.goals;
+
+import org.metagene.genestrip.ExecutionContext;
+import org.metagene.genestrip.GSConfigKey;
+import org.metagene.genestrip.match.FastqKMerMatcher;
+import org.metagene.genestrip.match.GpuFastqKMerMatcher;
+import org.metagene.genestrip.store.KMerStore;
+import org.metagene.genestrip.tax.SmallTaxTree;
+import org.metagene.genestrip.tax.SmallTaxTree.SmallTaxIdNode;
+
+public abstract class GpuMatchResultGoal extends MatchResultGoal {
+	// constructors mirror MatchResultGoal's and are omitted: they only pass their arguments to super(...)
+
+	@Override
+	protected FastqKMerMatcher createMatcher(KMerStore<SmallTaxIdNode> store, SmallTaxTree taxTree,
+			ExecutionContext bundle, boolean withProbs, String dbMD5) {
+		return new GpuFastqKMerMatcher(store, intConfigValue(GSConfigKey.INITIAL_READ_SIZE_BYTES),
+				intConfigValue(GSConfigKey.THREAD_QUEUE_SIZE), bundle, withProbs,
+				intConfigValue(GSConfigKey.MAX_KMER_RES_COUNTS), taxTree,
+				intConfigValue(GSConfigKey.MAX_CLASSIFICATION_PATHS),
+				doubleConfigValue(GSConfigKey.MAX_READ_TAX_ERROR_COUNT),
+				doubleConfigValue(GSConfigKey.MAX_READ_CLASS_ERROR_COUNT), booleanConfigValue(GSConfigKey.WRITE_ALL),
+				intConfigValue(GSConfigKey.MIN_KMERS_FOR_CLASS), dbMD5, 0 /* HIP device */);
+	}
+}

@@ -1,0 +1,63 @@
+/*
+ * Reference-side binding of include/gsgpu.h.  SOURCE ONLY: the build container has no JDK (no javac, no jni.h),
+ * so this file and java/jni/gsgpu_jni.c are not compiled or tested here; see INTEGRATION.md.
+ *
+ * One static native method per C entry point.  Handles travel as long; batches as direct ByteBuffers
+ * (address + length are taken with GetDirectBufferAddress, no copies on the Java side).
+ * A non-zero status from the C ABI is turned into a RuntimeException carrying gs_last_error().
+ */
+package org.metagene.genestrip.gpu;
+
+import java.nio.ByteBuffer;
+
+public final class GsGpuNative {
+	static {
+		System.loadLibrary("gsgpu_jni"); // links against libgsgpu.so
+	}
+
+	private GsGpuNative() {
+	}
+
+	/** gs_device_count */
+	public static native int deviceCount();
+
+	/** gs_db_create: kmers = n_entries x int64 (ascending, reference encoding), valueIdx = n_entries x int32,
+	 *  parentVi = n_values x int32 (-1 root, -2 no node) or null. Returns the gs_db handle. */
+	public static native long dbCreate(int device, int k, long nEntries, ByteBuffer kmers, ByteBuffer valueIdx,
+			int nValues, ByteBuffer parentVi);
+
+	public static native void dbDestroy(long db);
+
+	/** gs_match_begin */
+	public static native long matchBegin(long db, boolean classify, boolean countUnique, int maxPaths, int threshold,
+			double maxReadTaxErr, double maxReadClassErr);
+
+	/** gs_match_submit with GS_MEM_HOST: seq = concatenated read bytes, offsets = (nReads+1) x uint64,
+	 *  classVi = nReads x int32 (or null), flags = nReads x uint8 (or null). */
+	public static native void matchSubmit(long run, ByteBuffer seq, ByteBuffer offsets, long nReads, long firstReadNo,
+			ByteBuffer classVi, ByteBuffer flags);
+
+	/** gs_match_finish: table = n_values x GS_N_COLS int64, dtable = n_values x GS_N_DCOLS double. */
+	public static native void matchFinish(long run, ByteBuffer table, ByteBuffer dtable);
+
+	public static native void matchReset(long run);
+
+	public static native void matchDestroy(long run);
+
+	/** gs_bloom_create */
+	public static native long bloomCreate(int device, int kind, long bits, int nHashes, long[] hashFactors,
+			ByteBuffer words, long nWords);
+
+	public static native void bloomDestroy(long bloom);
+
+	/** gs_filter_submit with GS_MEM_HOST: accept = nReads x uint8 */
+	public static native void filterSubmit(long bloom, int k, int minPosCount, double positiveRatio, ByteBuffer seq,
+			ByteBuffer offsets, long nReads, ByteBuffer accept);
+
+	// column indices of the integer table (include/gsgpu.h, GS_C_*)
+	public static final int C_READS = 0, C_READS_KMERS = 1, C_KMERS = 2, C_UNIQUE_KMERS = 3, C_CONTIGS = 4,
+			C_CONTIG_LEN_SQ_SUM = 5, C_MAX_CONTIG_LEN = 6, C_READS_1KMER = 7, C_READS_BPS = 8,
+			C_MAX_CONTIG_READ_NO = 9, N_COLS = 10;
+	public static final int D_ERR_SUM = 0, D_ERR_SQ_SUM = 1, D_CLASS_ERR_SUM = 2, D_CLASS_ERR_SQ_SUM = 3, N_DCOLS = 4;
+	public static final int F_FOUND = 1, F_RETURNED = 2, F_COUNTED = 4;
+}
