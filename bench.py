@@ -104,7 +104,7 @@ def main():
         m.reset()
         m.submit(dseq, doff, first, n_reads=n_reads)
         if use_dist:
-            m.sync()  # the kernels run on the library's stream; the collectives on torch's
+            m.device_state()  # syncs the library's stream and refreshes the compact unique bitmap (same pointers)
             merge_run_state(t_sums, t_max, t_dsum, t_bits, force=force_merge,
                             or_parts=lambda g, w: m.or_bitmap(g.data_ptr(), w))
         return m.finish()

@@ -21,6 +21,8 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
                                               int32_t n_values, u64 *unique, hipStream_t stream);
+extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, hipStream_t stream);
+extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, hipStream_t stream);
 extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
@@ -94,6 +96,7 @@ struct gs_db {
     u64 *d_gate = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth | tin | tout
     int n_cu = 256;
+    struct gs_run *unique_owner = nullptr;  // the slots' seen bits belong to one unique-counting run at a time
 };
 
 // reference (interleaved, first base in the top bits) -> planar key; also reports reachability:
@@ -196,7 +199,7 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
         double v = atof(e);
         if (v > 0.05 && v <= 6.0) load = v;
     }
-    int b = std::max(vbits, 4);
+    int b = std::max(vbits + 1, 4);  // slot bits: (62-b) rem + 2 disp + vbits value + 1 seen <= 64
     while ((double)(1ULL << b) * load < (double)ns) b++;
     std::vector<u64> table;
     int max_disp = 0;
@@ -214,7 +217,7 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
                 const u64 bk = (home + d) & mask;
                 if (fill[bk] < GS_SLOTS_PER_BUCKET) {
                     table[bk * GS_SLOTS_PER_BUCKET + fill[bk]++] =
-                        (rem << (vbits + 2)) | ((u64)d << vbits) | (u64)(hval[i] + 1);
+                        (rem << (vbits + 3)) | ((u64)d << (vbits + 1)) | ((u64)(hval[i] + 1) << 1);
                     break;
                 }
             }
@@ -311,8 +314,10 @@ struct gs_run {
     int64_t *d_sums = nullptr;
     int64_t *d_max = nullptr;
     double *d_dsums = nullptr;
-    uint32_t *d_bitmap = nullptr;
+    uint32_t *d_bitmap = nullptr;  // compact copy of the slots' seen bits (built on demand: finish / device_state)
     int64_t bitmap_words = 0;
+    bool seen_dirty = false;    // some slot may carry a seen bit
+    bool bitmap_merged = false; // d_bitmap holds a merged (multi-rank) bitmap: do not re-extract
     u64 *d_unique = nullptr;
     unsigned int *d_long_count = nullptr;
     uint32_t *d_long_list = nullptr;
@@ -339,6 +344,10 @@ static int run_clear(gs_run *run) {
     HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv, run->stream));
     HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS, run->stream));
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
+    if (run->seen_dirty)
+        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream));
+    run->seen_dirty = false;
+    run->bitmap_merged = false;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
     return GS_OK;
 }
@@ -372,6 +381,8 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     *out = nullptr;
     if (cfg->max_paths < 1 || cfg->max_paths > 64) return fail(GS_E_INVALID, "max_paths must be in [1,64]");
     HIP_TRY(hipSetDevice(db->device));
+    if (cfg->count_unique && db->unique_owner)
+        return fail(GS_E_STATE, "this store already has an active unique-counting run (the seen bits live in the table)");
     gs_run *run = new gs_run();
     run->db = db;
     run->cfg = *cfg;
@@ -396,11 +407,13 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         if (v >= 1 && v <= 16) occ = v;
     }
     run->grid = db->n_cu * occ;
+    run->seen_dirty = cfg->count_unique != 0;  // a previous owner may have left seen bits behind
     int rc = run_clear(run);
     if (rc) {
         run_free(run);
         return rc;
     }
+    if (cfg->count_unique) db->unique_owner = run;
     *out = run;
     return GS_OK;
 }
@@ -475,6 +488,10 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, run->stream));
+    }
+    if (run->cfg.count_unique) {
+        run->seen_dirty = true;
+        run->bitmap_merged = false;
     }
     HIP_TRY(gs_launch_match(&P, grid, run->stream));
     if (run->cfg.profile) {
@@ -552,6 +569,9 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     std::vector<int64_t> sums(nv * GS_N_SUMS), maxk(nv);
     std::vector<u64> uniq(nv, 0);
     if (run->cfg.count_unique) {
+        if (!run->bitmap_merged)
+            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->d_bitmap,
+                                             run->stream));
         HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * nv, run->stream));
         HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET,
                                        run->db->dev.vbits, run->db->info.n_values, run->d_unique, run->stream));
@@ -585,6 +605,7 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
 extern "C" int gs_match_reset(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
+    if (!run->pending.empty()) HIP_TRY(hipStreamSynchronize(run->stream));
     int rc = collect_events(run);
     if (rc) return rc;
     return run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
@@ -594,6 +615,11 @@ extern "C" int gs_match_destroy(gs_run *run) {
     if (!run) return GS_OK;
     hipSetDevice(run->db->device);
     hipStreamSynchronize(run->stream);
+    if (run->db->unique_owner == run) {
+        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream);
+        hipStreamSynchronize(run->stream);
+        run->db->unique_owner = nullptr;
+    }
     run_free(run);
     return GS_OK;
 }
@@ -602,6 +628,9 @@ extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, 
                                      int64_t *bitmap_words) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
+    if (bitmap && run->cfg.count_unique && !run->bitmap_merged)  // refresh the compact copy of the seen bits
+        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->d_bitmap,
+                                         run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     if (sums) *sums = run->d_sums;
     if (max_keys) *max_keys = run->d_max;
@@ -616,6 +645,7 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
     HIP_TRY(hipSetDevice(run->db->device));
     HIP_TRY(gs_launch_bitmap_or(run->d_bitmap, (const uint32_t *)parts, run->bitmap_words, n_parts, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
+    run->bitmap_merged = true;  // gs_match_finish counts from this merged bitmap
     return GS_OK;
 }
 

@@ -110,22 +110,22 @@ __device__ __forceinline__ void gs_load_bucket(const u64 *table, u64 bkt, GsBuck
 }
 
 // returns true when the probe is finished (hit, or miss proven by a non-full bucket).
-// slot = rem << (vbits+2) | disp << vbits | (vi+1) with vbits+2 < 32: a match has an equal high dword and a low
-// dword that differs from `want` (value field 0) by exactly the value field, i.e. 0 < lo ^ want_lo <= vmask.
-// Buckets fill front to back, so "full" is "slot 7 is occupied".
-__device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, uint32_t vmask, int &vi, int &slot) {
+// slot = rem << (vbits+3) | disp << (vbits+1) | (vi+1) << 1 | seen, with vbits+3 < 32: a match has an equal high
+// dword and a low dword that differs from `want` (value and seen fields 0) by x = 2(vi+1) + seen, i.e.
+// 0 <= x-2 < 2*vmask.  On a hit vs = 2*vi + seen.  Buckets fill front to back, so "full" is "slot 7 is occupied".
+__device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, uint32_t vmask2, int &vs, int &slot) {
     const u64 s[8] = {b.q[0].x, b.q[0].y, b.q[1].x, b.q[1].y, b.q[2].x, b.q[2].y, b.q[3].x, b.q[3].y};
     const uint32_t want_hi = (uint32_t)(want >> 32), want_lo = (uint32_t)want;
     int hit = -1, val = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t y = ((uint32_t)s[j] ^ want_lo) - 1u;
-        const bool m = ((uint32_t)(s[j] >> 32) == want_hi) && (y < vmask);
+        const uint32_t y = ((uint32_t)s[j] ^ want_lo) - 2u;
+        const bool m = ((uint32_t)(s[j] >> 32) == want_hi) && (y < vmask2);
         val = m ? (int)y : val;
         hit = m ? j : hit;
     }
     if (hit >= 0) {
-        vi = val;
+        vs = val;
         slot = hit;
         return true;
     }
@@ -172,8 +172,8 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
     const GsDbDev &db = P.db;
     const int k = db.k;
     const uint32_t kmask = (1u << k) - 1u;
-    const uint32_t vmask = (1u << db.vbits) - 1u;
-    const int shift_rem = (int)db.vbits + 2;
+    const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
+    const int shift_rem = (int)db.vbits + 3;
     const u64 off = P.off[r];
     const int L = (int)(P.off[r + 1] - off);
     const int max = L - k + 1;
@@ -215,6 +215,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             }
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
             int node[2], slot[2];
+            bool fresh[2];  // hit on a slot whose seen bit was still clear in the copy this lane read
             u64 bkt[2], want[2], gword[2], gbits[2];
             bool act[2];
             GsBucket bk[2];
@@ -231,6 +232,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 act[s] = valid && (wbad == 0);
                 node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
                 slot[s] = 0;
+                fresh[s] = false;
                 gword[s] = ~0ULL;
                 gbits[s] = gs_gate_bits(h);
                 if (db.gate != nullptr && act[s]) gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
@@ -244,10 +246,11 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
                 if (act[s]) {
-                    int vi = -1, sl = 0;
-                    const bool done = gs_match_bucket(bk[s], want[s], vmask, vi, sl);
-                    if (vi >= 0) {
-                        node[s] = vi;
+                    int vs = -1, sl = 0;
+                    const bool done = gs_match_bucket(bk[s], want[s], vmask2, vs, sl);
+                    if (vs >= 0) {
+                        node[s] = vs >> 1;
+                        fresh[s] = (vs & 1) == 0;
                         slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
                     }
                     pending = !done;
@@ -258,10 +261,11 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         const u64 b2 = (bkt[s] + disp) & db.bucket_mask;
                         GsBucket t;
                         gs_load_bucket(db.table, b2, t);
-                        int vi = -1, sl = 0;
-                        const bool done = gs_match_bucket(t, want[s] | ((u64)disp << db.vbits), vmask, vi, sl);
-                        if (vi >= 0) {
-                            node[s] = vi;
+                        int vs = -1, sl = 0;
+                        const bool done = gs_match_bucket(t, want[s] | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
+                        if (vs >= 0) {
+                            node[s] = vs >> 1;
+                            fresh[s] = (vs & 1) == 0;
                             slot[s] = (int)(b2 * GS_SLOTS_PER_BUCKET) + sl;
                         }
                         pending = !done;
@@ -269,20 +273,15 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 }
             }
 
-            // ---- 4a. unique bitmap (KMerUniqueCounterBits.putInlined): test, then atomicOr
+            // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
+            // just read, so a k-mer that is already marked costs nothing; a stale copy only repeats the atomic
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
             found = found || ((hit0 | hit1) != 0);
             n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
             if (P.count_unique) {
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    if (node[s] >= 0) {
-                        const uint32_t idx = (uint32_t)slot[s];
-                        const uint32_t bit = 1u << (idx & 31);
-                        uint32_t *w = P.bitmap + (idx >> 5);
-                        if (!(*w & bit)) atomicOr(w, bit);
-                    }
-                }
+                for (int s = 0; s < 2; s++)
+                    if (fresh[s]) atomicOr(const_cast<u64 *>(db.table) + (uint32_t)slot[s], 1ULL);
             }
 
             // ---- 4b. contig events
@@ -614,7 +613,7 @@ __global__ __launch_bounds__(256) void gs_unique_count_kernel(const u64 *table, 
             const int b = __builtin_ctz(bits);
             bits &= bits - 1;
             const u64 s = table[w * 32 + b];
-            const int vi = (int)(s & vmask) - 1;
+            const int vi = (int)((s >> 1) & vmask) - 1;
             if (vi >= 0) {
                 if (lds)
                     atomicAdd(&s_cnt[vi], 1u);
@@ -627,6 +626,25 @@ __global__ __launch_bounds__(256) void gs_unique_count_kernel(const u64 *table, 
         __syncthreads();
         for (int i = threadIdx.x; i < n_values; i += blockDim.x)
             if (s_cnt[i]) atomicAdd(&unique[i], (u64)s_cnt[i]);
+    }
+}
+
+// seen bits of the slots -> compact bitmap (bit i = slot i); one wave per 64 slots
+__global__ __launch_bounds__(256) void gs_bitmap_extract_kernel(const u64 *table, int64_t n_slots, uint32_t *bitmap) {
+    const int lane = gs_lane();
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; base < n_slots;
+         base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + lane;
+        const u64 m = __ballot(i < n_slots && (table[i] & 1ULL));
+        if (lane == 0) bitmap[base >> 5] = (uint32_t)m;
+        if (lane == 1 && base + 32 < n_slots) bitmap[(base >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_clear_seen_kernel(u64 *table, int64_t n_slots) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const u64 s = table[i];
+        if (s & 1ULL) table[i] = s & ~1ULL;
     }
 }
 
@@ -796,6 +814,16 @@ extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *b
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(gs_unique_count_kernel, dim3(grid), dim3(256), 0, stream, table, bitmap, n_slots, vbits, n_values, unique);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_bitmap_extract_kernel, dim3(4096), dim3(256), 0, stream, table, n_slots, bitmap);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_clear_seen_kernel, dim3(4096), dim3(256), 0, stream, table, n_slots);
     return hipGetLastError();
 }
 

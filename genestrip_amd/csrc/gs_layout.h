@@ -10,10 +10,12 @@
 // Table: n_buckets (power of two) buckets of 8 x uint64 slots = one 64-byte line per probe.
 //   h      = gs_mix62(key)                 bijection on [0, 2^62)
 //   bucket = h & (n_buckets-1),  rem = h >> bucket_bits
-//   slot   = rem << (vbits+2) | disp << vbits | (value_index+1)        (0 = empty)
+//   slot   = rem << (vbits+3) | disp << (vbits+1) | (value_index+1) << 1 | seen        (0 = empty)
+// `seen` is the unique-k-mer mark of the running match (KMerUniqueCounterBits): set with one atomicOr by the first
+// wave that hits the slot with a clear bit; every later probe reads it for free with the slot itself.
 // An entry lives in bucket (home + disp) & mask, disp in 0..3; it is displaced only past FULL buckets, so
 // a probe walks home, home+1, .. while the bucket it just read is full and holds no match.
-// The unique-k-mer bitmap has one bit per slot (bit index = bucket*8 + slot).
+// For the multi-GPU merge the seen bits are extracted into a compact bitmap (bit index = bucket*8 + slot).
 #pragma once
 #include <stdint.h>
 
