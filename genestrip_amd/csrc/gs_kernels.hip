@@ -60,6 +60,38 @@ __device__ __forceinline__ void gs_load_word(const uint8_t *rd, int L, int w, in
     bad = __ballot(b);
 }
 
+// the same planes from a byte that was loaded earlier (software prefetch of the next read)
+__device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64 &hi, u64 &lo, u64 &bad) {
+    uint32_t code = 0;
+    bool b = false;
+    if (in_range) {
+        bool ok;
+        gs_base_code(c, code, ok);
+        b = !ok;
+    }
+    hi = __ballot((code & 2u) != 0);
+    lo = __ballot((code & 1u) != 0);
+    bad = __ballot(b);
+}
+
+// Software pipeline across the reads of one wave: while read r waits for its bucket lines, the first 192 bases of
+// the wave's next read are already on their way (issued AFTER the bucket loads, so the in-order vmcnt wait for
+// the buckets does not cover them).
+struct GsPrefetch {
+    const uint8_t *rd;  // next read's bases (nullptr: nothing to fetch)
+    int L;
+    uint32_t c[3];
+    __device__ __forceinline__ void issue(int lane) {
+        if (rd != nullptr) {
+#pragma unroll
+            for (int w = 0; w < 3; w++) {
+                const int j = 64 * w + lane;
+                c[w] = j < L ? rd[j] : 0u;
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // statistics sinks: LDS-privatised (n_values <= GS_NV_LDS) or direct global atomics
 // ---------------------------------------------------------------------------------------------------
@@ -166,16 +198,15 @@ __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_st
 // LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
 // ---------------------------------------------------------------------------------------------------
 template <bool LONG>
-__device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, int lane,
-                                                int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
-                                                int32_t *tag, int32_t *cnt, int serial) {
+__device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
+                                                int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
+                                                int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
+                                                GsPrefetch &next) {
     const GsDbDev &db = P.db;
     const int k = db.k;
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
     const int shift_rem = (int)db.vbits + 3;
-    const u64 off = P.off[r];
-    const int L = (int)(P.off[r + 1] - off);
     const int max = L - k + 1;
     const uint8_t *rd = P.seq + off;
     int out_class = -1;
@@ -199,7 +230,12 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // ---- 1. bases -> ballot planes (3 words cover 128 + k - 1 <= 158 bases)
             u64 Bhi[3], Blo[3], Bbad[3];
 #pragma unroll
-            for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
+            for (int w = 0; w < 3; w++) {
+                if (LONG)
+                    gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
+                else
+                    gs_word_from_byte(pre[w], 64 * w + lane < L, Bhi[w], Blo[w], Bbad[w]);
+            }
             {   // bad-base census for the INVALID-iteration closed form; word 2 belongs to the next iteration
                 const int q = max - 1;
                 const int nw = (it == n_iter - 1) ? 3 : 2;
@@ -242,6 +278,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 act[s] = act[s] && ((gword[s] & gbits[s]) == gbits[s]);  // gate: no false negatives
                 if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
             }
+            if (!LONG) next.issue(lane);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
@@ -553,7 +590,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
     }
 
 template <bool LDS_STATS>
-__global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
+__global__ __launch_bounds__(GS_BLOCK, 6) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
@@ -562,13 +599,45 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = P.db.k;
-    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
-        const int L = (int)(P.off[r + 1] - P.off[r]);
+    // pipeline registers: offsets two reads ahead, bases one read ahead
+    int64_t r = wave_id;
+    u64 off_a = 0, off_b = 0, noff_a = 0, noff_b = 0;
+    GsPrefetch pf;
+    pf.rd = nullptr;
+    pf.L = 0;
+    pf.c[0] = pf.c[1] = pf.c[2] = 0;
+    if (r < P.n_reads) {
+        off_a = P.off[r];
+        off_b = P.off[r + 1];
+        pf.rd = P.seq + off_a;
+        pf.L = (int)(off_b - off_a);
+        pf.issue(lane);
+    }
+    if (r + n_waves < P.n_reads) {
+        noff_a = P.off[r + n_waves];
+        noff_b = P.off[r + n_waves + 1];
+    }
+    for (; r < P.n_reads; r += n_waves) {
+        const int L = (int)(off_b - off_a);
+        const uint32_t pre[3] = {pf.c[0], pf.c[1], pf.c[2]};
+        const u64 off = off_a;
+        // rotate the pipeline: the next read's bases are fetched inside gs_process_read, behind the bucket loads
+        const bool has_next = r + n_waves < P.n_reads;
+        off_a = noff_a;
+        off_b = noff_b;
+        pf.rd = has_next ? P.seq + off_a : nullptr;
+        pf.L = (int)(off_b - off_a);
+        if (r + 2 * n_waves < P.n_reads) {
+            noff_a = P.off[r + 2 * n_waves];
+            noff_b = P.off[r + 2 * n_waves + 1];
+        }
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
             if (lane == 0) P.long_list[atomicAdd(P.long_count, 1u)] = (uint32_t)r;
+            pf.issue(lane);
             continue;
         }
-        gs_process_read<false>(P, st, r, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0);
+        if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
+        gs_process_read<false>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
     }
     GS_STATS_EPILOGUE()
 }
@@ -587,7 +656,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     for (int64_t i = wave_id; i < (int64_t)n_long; i += n_waves) {
         serial++;
         if (serial == 0) serial = 1;  // tags start zeroed; a wrap after 2^32 reads per wave may alias once
-        gs_process_read<true>(P, st, (int64_t)P.long_list[i], lane, nullptr, nullptr, wave_in_block, tag, cnt, (int)serial);
+        const int64_t r = (int64_t)P.long_list[i];
+        const u64 off = P.off[r];
+        const uint32_t none[3] = {0, 0, 0};
+        GsPrefetch nopf;
+        nopf.rd = nullptr;
+        gs_process_read<true>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+                              (int)serial, none, nopf);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
