@@ -30,7 +30,8 @@ ABI_SYMBOLS = (
     "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
     "gs_db_create", "gs_db_get_info", "gs_db_destroy",
     "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
-    "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time",
+    "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
+    "gs_match_segments_fetch",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -101,6 +102,7 @@ def lib():
         "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
         "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
+        "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
         "gs_filter_kernel_time": (ci, [vp, vp, vp]),
@@ -221,6 +223,31 @@ class FastqKMerMatcher:
 
     def sync(self):
         _check(lib().gs_match_sync(self.h))
+
+    def segments(self, seq, offsets):
+        """Kraken-style segments of a host batch: (seg_off uint64[n+1], codes int32[], starts int32[], lens int32[])"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        if len(seq) == 0:
+            seq = np.zeros(1, dtype=np.uint8)
+        seg_off = np.zeros(n + 1, dtype=np.uint64)
+        _check(lib().gs_match_segments(self.h, seq.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n,
+                                       MEM_HOST, seg_off.ctypes.data_as(C.c_void_p)))
+        total = int(seg_off[-1])
+        codes = np.zeros(total, dtype=np.int32)
+        starts = np.zeros(total, dtype=np.int32)
+        _check(lib().gs_match_segments_fetch(self.h, codes.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p)))
+        # a run ends where the next run of the same read starts, the last one at L - k + 1
+        lens = np.zeros(total, dtype=np.int32)
+        if total:
+            nxt = np.empty(total, dtype=np.int64)
+            nxt[:-1] = starts[1:]
+            last = seg_off[1:][seg_off[1:] > seg_off[:-1]].astype(np.int64) - 1
+            rl = (offsets[1:] - offsets[:-1]).astype(np.int64)[seg_off[1:] > seg_off[:-1]]
+            nxt[last] = rl - self.store.k + 1
+            lens = (nxt - starts).astype(np.int32)
+        return seg_off, codes, starts, lens
 
     def finish(self):
         nv = self.store.n_values

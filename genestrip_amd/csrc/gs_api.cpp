@@ -25,6 +25,7 @@ extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, hipStrea
 extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, hipStream_t stream);
 extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
                                            hipStream_t stream);
+extern "C" hipError_t gs_launch_segments(const struct GsSegParams *P, int write, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
 extern "C" int gs_match_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
@@ -332,6 +333,11 @@ struct gs_run {
     uint8_t *d_flags = nullptr;
     size_t seq_cap = 0, reads_cap = 0;
     int grid = 0;
+    // Kraken-style segments of the last gs_match_segments call
+    uint32_t *d_seg_count = nullptr;
+    u64 *d_seg_off = nullptr;
+    int32_t *d_seg_code = nullptr, *d_seg_start = nullptr;
+    int64_t seg_total = 0;
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -372,6 +378,10 @@ static void run_free(gs_run *run) {
     hipFree(run->d_off);
     hipFree(run->d_class);
     hipFree(run->d_flags);
+    hipFree(run->d_seg_count);
+    hipFree(run->d_seg_off);
+    hipFree(run->d_seg_code);
+    hipFree(run->d_seg_start);
     if (run->stream) hipStreamDestroy(run->stream);
     delete run;
 }
@@ -646,6 +656,105 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
     HIP_TRY(gs_launch_bitmap_or(run->d_bitmap, (const uint32_t *)parts, run->bitmap_words, n_parts, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     run->bitmap_merged = true;  // gs_match_finish counts from this merged bitmap
+    return GS_OK;
+}
+
+// ---- Kraken-style segments (two passes: count, host prefix sum, write)
+static int stage_batch(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
+                       const uint8_t **d_seq, const uint64_t **d_off) {
+    if (mem == GS_MEM_DEVICE) {
+        *d_seq = seq;
+        *d_off = offsets;
+        return GS_OK;
+    }
+    if (mem != GS_MEM_HOST) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    const size_t nbytes = (size_t)(offsets[n_reads] - offsets[0]);
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    if (run->seq_cap < nbytes + 1) {
+        hipFree(run->d_seq);
+        run->d_seq = nullptr;
+        run->seq_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_seq, nbytes + 1));
+        run->seq_cap = nbytes + 1;
+    }
+    if (run->reads_cap < (size_t)n_reads) {
+        hipFree(run->d_off);
+        hipFree(run->d_class);
+        hipFree(run->d_flags);
+        run->d_off = nullptr;
+        run->d_class = nullptr;
+        run->d_flags = nullptr;
+        run->reads_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+        HIP_TRY(hipMalloc((void **)&run->d_class, sizeof(int32_t) * (size_t)n_reads));
+        HIP_TRY(hipMalloc((void **)&run->d_flags, (size_t)n_reads));
+        run->reads_cap = (size_t)n_reads;
+    }
+    std::vector<uint64_t> rel((size_t)n_reads + 1);
+    for (int64_t i = 0; i <= n_reads; i++) rel[(size_t)i] = offsets[i] - offsets[0];
+    HIP_TRY(hipMemcpy(run->d_seq, seq + offsets[0], nbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(run->d_off, rel.data(), sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice));
+    *d_seq = run->d_seq;
+    *d_off = run->d_off;
+    return GS_OK;
+}
+
+extern "C" int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
+                                 uint64_t *seg_off) {
+    if (!run || !seg_off) return fail(GS_E_INVALID, "NULL argument");
+    if (n_reads < 0 || (n_reads > 0 && (!seq || !offsets))) return fail(GS_E_INVALID, "bad batch arrays");
+    HIP_TRY(hipSetDevice(run->db->device));
+    seg_off[0] = 0;
+    run->seg_total = 0;
+    if (n_reads == 0) return GS_OK;
+    const uint8_t *d_seq = nullptr;
+    const uint64_t *d_off = nullptr;
+    int rc = stage_batch(run, seq, offsets, n_reads, mem, &d_seq, &d_off);
+    if (rc) return rc;
+    hipFree(run->d_seg_count);
+    hipFree(run->d_seg_off);
+    hipFree(run->d_seg_code);
+    hipFree(run->d_seg_start);
+    run->d_seg_count = nullptr;
+    run->d_seg_off = nullptr;
+    run->d_seg_code = run->d_seg_start = nullptr;
+    HIP_TRY(hipMalloc((void **)&run->d_seg_count, sizeof(uint32_t) * (size_t)n_reads));
+    HIP_TRY(hipMalloc((void **)&run->d_seg_off, sizeof(u64) * ((size_t)n_reads + 1)));
+    GsSegParams P{};
+    P.db = run->db->dev;
+    P.seq = d_seq;
+    P.off = d_off;
+    P.n_reads = n_reads;
+    P.seg_count = run->d_seg_count;
+    int grid = (int)std::min<int64_t>(run->grid, (n_reads + 3) / 4);
+    if (grid < 1) grid = 1;
+    HIP_TRY(gs_launch_segments(&P, 0, grid, run->stream));
+    std::vector<uint32_t> counts((size_t)n_reads);
+    HIP_TRY(hipMemcpyAsync(counts.data(), run->d_seg_count, sizeof(uint32_t) * (size_t)n_reads, hipMemcpyDeviceToHost,
+                           run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    for (int64_t i = 0; i < n_reads; i++) seg_off[i + 1] = seg_off[i] + counts[(size_t)i];
+    run->seg_total = (int64_t)seg_off[n_reads];
+    if (run->seg_total > 0) {
+        HIP_TRY(hipMalloc((void **)&run->d_seg_code, sizeof(int32_t) * (size_t)run->seg_total));
+        HIP_TRY(hipMalloc((void **)&run->d_seg_start, sizeof(int32_t) * (size_t)run->seg_total));
+        HIP_TRY(hipMemcpyAsync(run->d_seg_off, seg_off, sizeof(u64) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, run->stream));
+        P.seg_off = run->d_seg_off;
+        P.seg_code = run->d_seg_code;
+        P.seg_start = run->d_seg_start;
+        HIP_TRY(gs_launch_segments(&P, 1, grid, run->stream));
+        HIP_TRY(hipStreamSynchronize(run->stream));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts) {
+    if (!run || (run->seg_total > 0 && (!codes || !starts))) return fail(GS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (run->seg_total > 0) {
+        HIP_TRY(hipMemcpy(codes, run->d_seg_code, sizeof(int32_t) * (size_t)run->seg_total, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(starts, run->d_seg_start, sizeof(int32_t) * (size_t)run->seg_total, hipMemcpyDeviceToHost));
+    }
     return GS_OK;
 }
 

@@ -116,6 +116,12 @@ struct GsStats {
 // ---------------------------------------------------------------------------------------------------
 typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 
+#ifndef GS_PREFETCH
+// Software pipelining of the next read's bases behind the bucket loads (GsPrefetch).  Measured on MI355X: the
+// extra registers cost one wave per SIMD and the net effect is nil (13.3 ms either way), so it is off.
+#define GS_PREFETCH 0
+#endif
+
 #ifndef GS_NT_TABLE
 // Measured on MI355X: non-temporal bucket loads stop the four dwordx4 loads of one 64-byte line from sharing a
 // single L2 request (the match kernel ran 2.2x slower), so the default is plain loads.
@@ -194,6 +200,81 @@ __device__ __forceinline__ int gs_sc_load(const int32_t *p) { return __hip_atomi
 __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---------------------------------------------------------------------------------------------------
+// 128 k-mer positions [base, base+128) of one read: planes -> canonical keys -> gate -> bucket lines -> node codes.
+// node[s] for position base + 64 s + lane: value index (hit), GS_NODE_MISS, GS_NODE_INVALID (window holds a
+// non-CGAT byte) or GS_NODE_NONE (position >= max).  slot = global slot index of a hit, fresh = its seen bit was 0.
+// ---------------------------------------------------------------------------------------------------
+template <bool PREFETCH>
+__device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
+                                                const u64 (&Bbad)[3], int base, int max, int lane, GsPrefetch &next,
+                                                int (&node)[2], int (&slot)[2], bool (&fresh)[2]) {
+    const int k = db.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
+    const int shift_rem = (int)db.vbits + 3;
+    const uint32_t bmask = (uint32_t)db.bucket_mask;  // n_buckets <= 2^29
+    uint32_t bkt[2], gfield[2];
+    u64 want[2], gword[2];
+    bool act[2];
+    GsBucket bk[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int p = base + 64 * s + lane;
+        const bool valid = p < max;
+        const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+        const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+        const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
+        const u64 h = gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
+        bkt[s] = (uint32_t)h & bmask;
+        want[s] = (h >> db.bucket_bits) << shift_rem;
+        gfield[s] = (uint32_t)(h >> GS_GATE_FIELD_SHIFT);
+        act[s] = valid && (wbad == 0);
+        node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
+        slot[s] = 0;
+        fresh[s] = false;
+        gword[s] = ~0ULL;
+        if (db.gate != nullptr && act[s]) gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const u64 gbits = gs_gate_field_bits(gfield[s]);
+        act[s] = act[s] && ((gword[s] & gbits) == gbits);  // gate: no false negatives
+        if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
+    }
+    if (PREFETCH) next.issue(lane);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        bool pending = false;
+        if (act[s]) {
+            int vs = -1, sl = 0;
+            const bool done = gs_match_bucket(bk[s], want[s], vmask2, vs, sl);
+            if (vs >= 0) {
+                node[s] = vs >> 1;
+                fresh[s] = (vs & 1) == 0;
+                slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
+            }
+            pending = !done;
+        }
+        // rare: home bucket full without a match -> walk the displaced buckets
+        for (int disp = 1; disp <= GS_MAX_DISP && __ballot(pending) != 0; disp++) {
+            if (pending) {
+                const uint32_t b2 = (bkt[s] + (uint32_t)disp) & bmask;
+                GsBucket t;
+                gs_load_bucket(db.table, b2, t);
+                int vs = -1, sl = 0;
+                const bool done = gs_match_bucket(t, want[s] | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
+                if (vs >= 0) {
+                    node[s] = vs >> 1;
+                    fresh[s] = (vs & 1) == 0;
+                    slot[s] = (int)(b2 * GS_SLOTS_PER_BUCKET) + sl;
+                }
+                pending = !done;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // one read on one wave.  LONG = false: max <= 128 (one iteration, distinct nodes kept in registers).
 // LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
 // ---------------------------------------------------------------------------------------------------
@@ -204,9 +285,6 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                                                 GsPrefetch &next) {
     const GsDbDev &db = P.db;
     const int k = db.k;
-    const uint32_t kmask = (1u << k) - 1u;
-    const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
-    const int shift_rem = (int)db.vbits + 3;
     const int max = L - k + 1;
     const uint8_t *rd = P.seq + off;
     int out_class = -1;
@@ -252,63 +330,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
             int node[2], slot[2];
             bool fresh[2];  // hit on a slot whose seen bit was still clear in the copy this lane read
-            u64 bkt[2], want[2], gword[2], gbits[2];
-            bool act[2];
-            GsBucket bk[2];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const int p = base + 64 * s + lane;
-                const bool valid = p < max;
-                const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
-                const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
-                const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
-                const u64 h = gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
-                bkt[s] = h & db.bucket_mask;
-                want[s] = (h >> db.bucket_bits) << shift_rem;
-                act[s] = valid && (wbad == 0);
-                node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
-                slot[s] = 0;
-                fresh[s] = false;
-                gword[s] = ~0ULL;
-                gbits[s] = gs_gate_bits(h);
-                if (db.gate != nullptr && act[s]) gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
-            }
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                act[s] = act[s] && ((gword[s] & gbits[s]) == gbits[s]);  // gate: no false negatives
-                if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
-            }
-            if (!LONG) next.issue(lane);
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                bool pending = false;
-                if (act[s]) {
-                    int vs = -1, sl = 0;
-                    const bool done = gs_match_bucket(bk[s], want[s], vmask2, vs, sl);
-                    if (vs >= 0) {
-                        node[s] = vs >> 1;
-                        fresh[s] = (vs & 1) == 0;
-                        slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
-                    }
-                    pending = !done;
-                }
-                // rare: home bucket full without a match -> walk the displaced buckets
-                for (int disp = 1; disp <= GS_MAX_DISP && __ballot(pending) != 0; disp++) {
-                    if (pending) {
-                        const u64 b2 = (bkt[s] + disp) & db.bucket_mask;
-                        GsBucket t;
-                        gs_load_bucket(db.table, b2, t);
-                        int vs = -1, sl = 0;
-                        const bool done = gs_match_bucket(t, want[s] | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
-                        if (vs >= 0) {
-                            node[s] = vs >> 1;
-                            fresh[s] = (vs & 1) == 0;
-                            slot[s] = (int)(b2 * GS_SLOTS_PER_BUCKET) + sl;
-                        }
-                        pending = !done;
-                    }
-                }
-            }
+            gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh);
 
             // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
             // just read, so a k-mer that is already marked costs nothing; a stale copy only repeats the atomic
@@ -590,7 +612,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
     }
 
 template <bool LDS_STATS>
-__global__ __launch_bounds__(GS_BLOCK, 6) void gs_match_kernel(GsMatchParams P) {
+__global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
@@ -599,6 +621,7 @@ __global__ __launch_bounds__(GS_BLOCK, 6) void gs_match_kernel(GsMatchParams P) 
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = P.db.k;
+#if GS_PREFETCH
     // pipeline registers: offsets two reads ahead, bases one read ahead
     int64_t r = wave_id;
     u64 off_a = 0, off_b = 0, noff_a = 0, noff_b = 0;
@@ -639,6 +662,22 @@ __global__ __launch_bounds__(GS_BLOCK, 6) void gs_match_kernel(GsMatchParams P) 
         if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
         gs_process_read<false>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
     }
+#else
+    GsPrefetch pf;
+    pf.rd = nullptr;
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const u64 off = P.off[r];
+        const int L = (int)(P.off[r + 1] - off);
+        if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
+            if (lane == 0) P.long_list[atomicAdd(P.long_count, 1u)] = (uint32_t)r;
+            continue;
+        }
+        uint32_t pre[3];
+#pragma unroll
+        for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? P.seq[off + 64 * w + lane] : 0u;
+        gs_process_read<false>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
+    }
+#endif
     GS_STATS_EPILOGUE()
 }
 
@@ -666,6 +705,58 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kraken-style segments (FastqKMerMatcher.printKrakenStyleOut, :597-611 / :391-394 / :452-454): the maximal runs
+// of equal node over the k-mer positions of a read.  WRITE = false counts them per read; WRITE = true stores
+// (code, start) of every run at seg_off[r] + i (code = value index, -1 miss "0", -2 INVALID "A").
+// ---------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
+    const GsDbDev &db = P.db;
+    const int lane = gs_lane();
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int k = db.k;
+    GsPrefetch nopf;
+    nopf.rd = nullptr;
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const u64 off = P.off[r];
+        const int L = (int)(P.off[r + 1] - off);
+        const int max = L - k + 1;
+        const uint8_t *rd = P.seq + off;
+        const int n_iter = max > 0 ? (max + 127) >> 7 : 0;
+        int carry_last = GS_NODE_NONE;
+        uint32_t nseg = 0;
+        const u64 out_base = WRITE ? P.seg_off[r] : 0;
+        for (int it = 0; it < n_iter; it++) {
+            const int base = it << 7;
+            u64 Bhi[3], Blo[3], Bbad[3];
+#pragma unroll
+            for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
+            int node[2], slot[2];
+            bool fresh[2];
+            gs_probe_planes<false>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh);
+            const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
+            const int last0 = gs_readlane(node[0], 63);
+            const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const bool head = node[s] != GS_NODE_NONE && node[s] != prev[s];
+                const u64 H = __ballot(head);
+                if (WRITE && head) {
+                    const u64 idx = out_base + nseg + (u64)__popcll(H & ((1ULL << lane) - 1));
+                    P.seg_code[idx] = node[s];
+                    P.seg_start[idx] = base + 64 * s + lane;
+                }
+                nseg += (uint32_t)__popcll(H);
+            }
+            const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
+            carry_last = gs_readlane(((last_p - base) >> 6) ? node[1] : node[0], (last_p - base) & 63);
+        }
+        if (!WRITE && lane == 0) P.seg_count[r] = nseg;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -908,6 +999,14 @@ extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, 
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(gs_bitmap_or_kernel, dim3(grid), dim3(256), 0, stream, dst, parts, n_words, n_parts);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_segments(const GsSegParams *P, int write, int grid, hipStream_t stream) {
+    if (write)
+        hipLaunchKernelGGL(gs_segments_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    else
+        hipLaunchKernelGGL(gs_segments_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     return hipGetLastError();
 }
 

@@ -48,10 +48,11 @@ GS_HD uint64_t gs_mix62(uint64_t x) {
 //   word = gate[(h >> bucket_bits) & gate_mask],  bits = 4 x 6-bit fields of h >> 38
 #define GS_GATE_FIELD_SHIFT 38
 
-GS_HD uint64_t gs_gate_bits(uint64_t h) {
-    const uint32_t f = (uint32_t)(h >> GS_GATE_FIELD_SHIFT);
+GS_HD uint64_t gs_gate_field_bits(uint32_t f) {  // f = h >> GS_GATE_FIELD_SHIFT (24 bits)
     return (1ULL << (f & 63)) | (1ULL << ((f >> 6) & 63)) | (1ULL << ((f >> 12) & 63)) | (1ULL << ((f >> 18) & 63));
 }
+
+GS_HD uint64_t gs_gate_bits(uint64_t h) { return gs_gate_field_bits((uint32_t)(h >> GS_GATE_FIELD_SHIFT)); }
 
 struct GsDbDev {
     const unsigned long long *table;  // n_buckets * 8 slots

@@ -43,3 +43,14 @@ struct GsFilterParams {
     int64_t n_reads;
     uint8_t *accept;
 };
+
+struct GsSegParams {
+    GsDbDev db;
+    const uint8_t *seq;
+    const uint64_t *off;
+    int64_t n_reads;
+    uint32_t *seg_count;            // count pass: segments per read
+    const unsigned long long *seg_off;  // write pass: exclusive prefix of seg_count
+    int32_t *seg_code;
+    int32_t *seg_start;
+};

@@ -154,6 +154,16 @@ int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsum
 /* bitmap |= OR of n_parts device bitmaps laid out back to back at `parts` (each bitmap_words long) */
 int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
 
+/* Kraken-style per-read segments (writeKrakenStyleOut; FastqKMerMatcher.printKrakenStyleOut, :597-611): the maximal
+ * runs of equal tax node over the k-mer positions of each read, in read order.  gs_match_segments probes the batch,
+ * fills seg_off[n_reads+1] (host array, exclusive prefix of the per-read segment counts) and keeps the segments on
+ * the device; gs_match_segments_fetch copies them out: codes[i] = value index, -1 (miss, printed "0") or -2
+ * (window with a non-CGAT base, printed "A"), starts[i] = first k-mer position of the run; a run ends where the
+ * next one starts (or at L-k+1).  Does not touch the run's statistics.  Outputs are host pointers. */
+int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
+                      uint64_t *seg_off);
+int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts);
+
 /* accumulated device time of the match kernel launches since gs_match_begin (cfg.profile != 0) */
 int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);
 
