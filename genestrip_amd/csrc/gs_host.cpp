@@ -1,0 +1,759 @@
+// gs_host.cpp -- C++ host layer above the C ABI (include/gshost.h): FASTQ/FASTA ingest with the reference's
+// record semantics, the runMatcher / runFilter file pipelines (parse of batch i+1 overlaps the GPU work of batch i),
+// Kraken-style and filtered-FASTQ writers, completeResults + CSV.  Plain C++17 + zlib; all GPU work goes through
+// the C ABI of include/gsgpu.h.
+#include "../../include/gshost.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_host_err;
+int hfail(int code, const std::string &m) {
+    g_host_err = m;
+    return code;
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+bool is_gzip_name(const std::string &s) { return ends_with(s, ".gz") || ends_with(s, ".gzip"); }  // StreamProvider.java:148-150
+
+bool is_fasta_name(const std::string &s) {  // FastqMapGoal.java:64,188-201
+    static const char *suf[] = {"fasta", "fa", "fna", "fas", "fasta.gz", "fa.gz", "fna.gz", "fas.gz",
+                                "fasta.gzip", "fa.gzip", "fna.gzip", "fas.gzip"};
+    for (const char *x : suf)
+        if (ends_with(s, x)) return true;
+    return false;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------
+// byte source + line reader (BufferedLineReader.nextLine semantics: NUL bytes dropped, '\r' kept, the '\n' is part
+// of the returned line; callers take "length - 1")
+// ---------------------------------------------------------------------------------------------------
+class LineReader {
+public:
+    bool open(const std::string &path) {
+        gz_ = gzopen(path.c_str(), "rb");  // zlib reads plain files transparently, gzip by content
+        if (!gz_) return false;
+        gzbuffer(gz_, 1 << 20);
+        buf_.resize(1 << 20);
+        return true;
+    }
+    ~LineReader() {
+        if (gz_) gzclose(gz_);
+    }
+    // appends the next line (incl. '\n', NULs dropped) to out; returns the number of bytes appended (0 at EOF)
+    size_t next_line(std::vector<uint8_t> &out) {
+        const size_t start = out.size();
+        for (;;) {
+            if (pos_ == fill_) {
+                if (eof_) break;
+                const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+                if (n <= 0) {
+                    eof_ = true;
+                    break;
+                }
+                fill_ = (size_t)n;
+                pos_ = 0;
+            }
+            const uint8_t *p = buf_.data() + pos_;
+            const size_t avail = fill_ - pos_;
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', avail);
+            const size_t take = nl ? (size_t)(nl - p) + 1 : avail;
+            if (memchr(p, 0, take) == nullptr) {
+                out.insert(out.end(), p, p + take);
+            } else {
+                for (size_t i = 0; i < take; i++)
+                    if (p[i] != 0) out.push_back(p[i]);
+            }
+            pos_ += take;
+            if (nl) break;
+        }
+        return out.size() - start;
+    }
+
+private:
+    gzFile gz_ = nullptr;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0, fill_ = 0;
+    bool eof_ = false;
+};
+
+struct Batch {
+    std::vector<uint8_t> seq, desc, qual;
+    std::vector<uint64_t> seq_off{0}, desc_off{0}, qual_off{0};
+    int64_t first_read_no = 0;
+    int64_t n() const { return (int64_t)seq_off.size() - 1; }
+    void clear() {
+        seq.clear();
+        desc.clear();
+        qual.clear();
+        seq_off.assign(1, 0);
+        desc_off.assign(1, 0);
+        qual_off.assign(1, 0);
+    }
+};
+
+// AbstractFastqReader.doReadFastq (:288-368) / doReadFasta (:375-438) with unbounded buffers
+class FastqParser {
+public:
+    FastqParser(int k, bool fasta) : k_(k), fasta_(fasta) {}
+    bool open(const std::string &path) { return lr_.open(path); }
+
+    // appends up to max_reads records / max_bytes sequence bytes to b; returns false at end of file
+    bool parse(Batch &b, int64_t max_reads, int64_t max_bytes) {
+        b.clear();
+        b.first_read_no = reads_;
+        while (!done_ && b.n() < max_reads && (int64_t)b.seq.size() < max_bytes) {
+            if (!(fasta_ ? next_fasta(b) : next_fastq(b))) done_ = true;
+        }
+        return b.n() > 0;
+    }
+    int64_t reads_ = 0, kmers_ = 0, bps_ = 0;
+
+private:
+    void account(Batch &b, size_t read_size) {
+        b.seq_off.push_back(b.seq.size());
+        b.desc_off.push_back(b.desc.size());
+        b.qual_off.push_back(b.qual.size());
+        reads_++;
+        if ((int64_t)read_size >= k_) kmers_ += (int64_t)read_size - k_ + 1;
+        bps_ += (int64_t)read_size;
+    }
+
+    bool next_fastq(Batch &b) {
+        const size_t dstart = b.desc.size(), sstart = b.seq.size(), qstart = b.qual.size();
+        size_t got = lr_.next_line(b.desc);
+        if (got == 0) return false;  // readDescriptorSize == -1
+        b.desc.resize(dstart + got - 1);
+        got = lr_.next_line(b.seq);
+        if (got == 0) {  // truncated record: the reference runs into an exception here
+            b.desc.resize(dstart);
+            return false;
+        }
+        b.seq.resize(sstart + got - 1);
+        for (;;) {  // sequence lines until a line STARTING with '+' (:301-308)
+            const size_t lstart = b.seq.size();
+            got = lr_.next_line(b.seq);
+            if (got == 0) {
+                b.desc.resize(dstart);
+                b.seq.resize(sstart);
+                return false;
+            }
+            if (b.seq[lstart] == '+') {
+                b.seq.resize(lstart);
+                break;
+            }
+            b.seq.resize(lstart + got - 1);
+        }
+        const long read_size = (long)(b.seq.size() - sstart);
+        // quality lines until >= readSize characters (:320-341)
+        got = lr_.next_line(b.qual);
+        long qsize = (long)got - 1;
+        while (qsize < read_size) {
+            const long old = qsize;
+            b.qual.resize(qstart + (size_t)(qsize < 0 ? 0 : qsize));  // continue over the previous '\n'
+            got = lr_.next_line(b.qual);
+            qsize = got ? (long)(b.qual.size() - qstart) - 1 : old - 1;
+            if (qsize == old - 1) break;  // EOF
+        }
+        if (qsize < 0) qsize = 0;
+        b.qual.resize(qstart + (size_t)qsize);
+        account(b, (size_t)read_size);
+        return true;
+    }
+
+    bool next_fasta(Batch &b) {
+        if (!have_header_) {
+            header_.clear();
+            const size_t got = lr_.next_line(header_);
+            if (got == 0) return false;
+            header_.resize(got - 1);
+            have_header_ = true;
+        }
+        const size_t dstart = b.desc.size(), sstart = b.seq.size();
+        b.desc.insert(b.desc.end(), header_.begin(), header_.end());
+        if (!header_.empty()) b.desc[dstart] = '@';  // :380
+        have_header_ = false;
+        bool more = true;
+        for (;;) {
+            const size_t lstart = b.seq.size();
+            const size_t got = lr_.next_line(b.seq);
+            if (got == 0) {
+                more = false;
+                break;
+            }
+            if (b.seq[lstart] == '>') {  // next header: copied without its '\n' (:405-413)
+                header_.assign(b.seq.begin() + (long)lstart, b.seq.begin() + (long)(lstart + got - 1));
+                b.seq.resize(lstart);
+                have_header_ = true;
+                break;
+            }
+            b.seq.resize(lstart + got - 1);
+        }
+        account(b, b.seq.size() - sstart);
+        return more || have_header_;
+    }
+
+    int k_;
+    bool fasta_, done_ = false, have_header_ = false;
+    std::vector<uint8_t> header_;
+    LineReader lr_;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// output helper: plain or gzip by suffix (StreamProvider.getOutputStreamForFile)
+// ---------------------------------------------------------------------------------------------------
+class OutFile {
+public:
+    bool open(const char *path) {
+        if (!path) return true;
+        if (is_gzip_name(path)) {
+            gz_ = gzopen(path, "wb1");
+            return gz_ != nullptr;
+        }
+        f_ = fopen(path, "wb");
+        return f_ != nullptr;
+    }
+    bool active() const { return gz_ || f_; }
+    void write(const void *p, size_t n) {
+        if (gz_)
+            gzwrite(gz_, p, (unsigned)n);
+        else if (f_)
+            fwrite(p, 1, n, f_);
+    }
+    void put(char c) { write(&c, 1); }
+    ~OutFile() {
+        if (gz_) gzclose(gz_);
+        if (f_) fclose(f_);
+    }
+
+private:
+    gzFile gz_ = nullptr;
+    FILE *f_ = nullptr;
+};
+
+// ReadEntry.write (AbstractFastqReader.java:570-584); qualities are '~' x L unless with_probs and present
+void write_read(OutFile &out, const Batch &b, int64_t i, bool with_probs, std::vector<uint8_t> &tmp) {
+    tmp.clear();
+    const size_t d0 = b.desc_off[i], d1 = b.desc_off[i + 1], s0 = b.seq_off[i], s1 = b.seq_off[i + 1];
+    tmp.insert(tmp.end(), b.desc.begin() + (long)d0, b.desc.begin() + (long)d1);
+    tmp.push_back('\n');
+    tmp.insert(tmp.end(), b.seq.begin() + (long)s0, b.seq.begin() + (long)s1);
+    tmp.push_back('\n');
+    tmp.push_back('+');
+    tmp.push_back('\n');
+    const size_t q0 = b.qual_off[i], q1 = b.qual_off[i + 1];
+    if (with_probs && q1 > q0)
+        tmp.insert(tmp.end(), b.qual.begin() + (long)q0, b.qual.begin() + (long)q1);
+    else
+        tmp.insert(tmp.end(), s1 - s0, (uint8_t)'~');
+    tmp.push_back('\n');
+    out.write(tmp.data(), tmp.size());
+}
+
+// bounded producer/consumer hand-off of parsed batches (depth 2: parse i+1 while the GPU works on i)
+class BatchQueue {
+public:
+    void push(std::unique_ptr<Batch> b) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return q_.size() < 2; });
+        q_.push(std::move(b));
+        cv_.notify_all();
+    }
+    std::unique_ptr<Batch> pop() {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !q_.empty(); });
+        auto b = std::move(q_.front());
+        q_.pop();
+        cv_.notify_all();
+        return b;
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::queue<std::unique_ptr<Batch>> q_;
+};
+
+void append_int(std::string &s, long long v) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    s.append(buf, r.ptr);
+}
+
+// Double.toString: shortest round-trip digits; decimal notation for 1e-3 <= |d| < 1e7, else d.dddE[-]n
+std::string java_double(double v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), std::fabs(v), std::chars_format::scientific);
+    std::string sci(buf, r.ptr);  // d[.ddd]e[+-]XX
+    const size_t epos = sci.find('e');
+    std::string digits = sci.substr(0, epos);
+    const int exp10 = atoi(sci.c_str() + epos + 1);
+    digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+    std::string out = v < 0 ? "-" : "";
+    const double a = std::fabs(v);
+    if (a >= 1e-3 && a < 1e7) {
+        if (exp10 >= 0) {
+            std::string ip = digits.substr(0, std::min(digits.size(), (size_t)exp10 + 1));
+            while ((int)ip.size() < exp10 + 1) ip.push_back('0');
+            std::string fp = digits.size() > (size_t)exp10 + 1 ? digits.substr((size_t)exp10 + 1) : "0";
+            out += ip + "." + fp;
+        } else {
+            out += "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+        }
+    } else {
+        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E";
+        append_int(out, exp10);
+    }
+    return out;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C API
+// ---------------------------------------------------------------------------------------------------
+struct gs_fastq {
+    std::unique_ptr<FastqParser> parser;
+    Batch batch;
+};
+
+extern "C" int gs_fastq_open(gs_fastq **out, const char *path, int fasta, int k) {
+    if (!out || !path) return hfail(GS_E_INVALID, "NULL argument");
+    const bool fa = fasta < 0 ? is_fasta_name(path) : fasta != 0;
+    auto r = std::make_unique<gs_fastq>();
+    r->parser = std::make_unique<FastqParser>(k, fa);
+    if (!r->parser->open(path)) return hfail(GS_E_INVALID, std::string("cannot open ") + path);
+    *out = r.release();
+    return GS_OK;
+}
+
+extern "C" int gs_fastq_next(gs_fastq *r, int64_t max_reads, int64_t max_bytes, gs_read_batch *b) {
+    if (!r || !b) return hfail(GS_E_INVALID, "NULL argument");
+    r->parser->parse(r->batch, max_reads, max_bytes);
+    b->n_reads = r->batch.n();
+    b->seq = r->batch.seq.data();
+    b->seq_off = r->batch.seq_off.data();
+    b->desc = r->batch.desc.data();
+    b->desc_off = r->batch.desc_off.data();
+    b->qual = r->batch.qual.data();
+    b->qual_off = r->batch.qual_off.data();
+    b->first_read_no = r->batch.first_read_no;
+    return GS_OK;
+}
+
+extern "C" int gs_fastq_totals(const gs_fastq *r, int64_t *reads, int64_t *kmers, int64_t *bps) {
+    if (!r) return hfail(GS_E_INVALID, "NULL argument");
+    if (reads) *reads = r->parser->reads_;
+    if (kmers) *kmers = r->parser->kmers_;
+    if (bps) *bps = r->parser->bps_;
+    return GS_OK;
+}
+
+extern "C" int gs_fastq_close(gs_fastq *r) {
+    delete r;
+    return GS_OK;
+}
+
+extern "C" const char *gs_host_last_error(void) { return g_host_err.c_str(); }
+
+extern "C" int gs_host_java_double(double v, char *buf, int cap) {
+    const std::string s = java_double(v);
+    if (!buf || cap <= (int)s.size()) return GS_E_INVALID;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return GS_OK;
+}
+
+namespace {
+
+// parse all files on a producer thread; the consumer gets batches in file order; a null batch ends the stream
+struct Producer {
+    std::thread th;
+    BatchQueue q;
+    int64_t reads = 0, kmers = 0, bps = 0;
+    double seconds = 0;
+    std::string error;
+    void start(const std::vector<std::string> &paths, int k, int64_t batch_reads) {
+        th = std::thread([this, paths, k, batch_reads] {
+            for (const std::string &p : paths) {
+                FastqParser parser(k, is_fasta_name(p));
+                if (!parser.open(p)) {
+                    error = "cannot open " + p;
+                    break;
+                }
+                for (;;) {
+                    auto b = std::make_unique<Batch>();
+                    const double t0 = now_s();
+                    const bool ok = parser.parse(*b, batch_reads, (int64_t)1 << 30);
+                    seconds += now_s() - t0;
+                    if (!ok) break;
+                    q.push(std::move(b));
+                }
+                reads += parser.reads_;  // totalReads += reads (AbstractLoggingFastqStreamer.java:123-125)
+                kmers += parser.kmers_;
+                bps += parser.bps_;
+            }
+            q.push(nullptr);
+        });
+    }
+};
+
+}  // namespace
+
+extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
+                                   const gs_host_match_opts *opts, int64_t *table, double *dtable,
+                                   gs_host_totals *totals) {
+    if (!db || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
+    gs_db_info info;
+    int rc = gs_db_get_info(db, &info);
+    if (rc) return rc;
+    const gs_host_match_opts none{};
+    if (!opts) opts = &none;
+    if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
+    OutFile filtered, kraken;
+    if (!filtered.open(opts->filtered_path) || !kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    gs_run *run = nullptr;
+    rc = gs_match_begin(&run, db, cfg);
+    if (rc) return rc;
+    const double t_start = now_s();
+    std::vector<std::string> plist(paths, paths + n_paths);
+    Producer prod;
+    prod.start(plist, info.k, opts->batch_reads > 0 ? opts->batch_reads : (int64_t)1 << 20);
+    std::vector<int32_t> cls, seg_code, seg_start;
+    std::vector<uint8_t> flags, tmp;
+    std::vector<uint64_t> seg_off;
+    std::string line;
+    int64_t global_read_no = 0, filtered_reads = 0;
+    double t_gpu = 0;
+    int err = GS_OK;
+    for (;;) {
+        std::unique_ptr<Batch> b = prod.q.pop();
+        if (!b) break;
+        if (err) continue;  // keep draining so the producer can finish
+        const int64_t n = b->n();
+        cls.resize((size_t)n);
+        flags.resize((size_t)n);
+        if (b->seq.empty()) b->seq.push_back(0);
+        const double t0 = now_s();
+        // read numbers run over all files of this call so that "first read with the max contig" follows file order
+        err = gs_match_submit(run, b->seq.data(), b->seq_off.data(), n, global_read_no, GS_MEM_HOST, cls.data(), flags.data());
+        if (!err && kraken.active()) {
+            seg_off.resize((size_t)n + 1);
+            err = gs_match_segments(run, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST, seg_off.data());
+            if (!err) {
+                seg_code.resize((size_t)seg_off[(size_t)n]);
+                seg_start.resize((size_t)seg_off[(size_t)n]);
+                err = gs_match_segments_fetch(run, seg_code.data(), seg_start.data());
+            }
+        }
+        t_gpu += now_s() - t0;
+        if (err) continue;
+        global_read_no += n;
+        for (int64_t i = 0; i < n; i++) {
+            if (filtered.active() && (flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
+                write_read(filtered, *b, i, false, tmp);
+                filtered_reads++;
+            }
+            if (kraken.active()) {  // MatcherReadEntry.writeMatchDetails (:723-756)
+                const uint64_t s0 = seg_off[(size_t)i], s1 = seg_off[(size_t)i + 1];
+                const int32_t c = cls[(size_t)i];
+                if (s1 == s0 || !(opts->write_all || c >= 0)) continue;
+                const int64_t L = (int64_t)(b->seq_off[(size_t)i + 1] - b->seq_off[(size_t)i]);
+                const int64_t maxp = L - info.k + 1;
+                line.assign(c >= 0 ? "C\t" : "U\t");
+                const size_t d0 = b->desc_off[(size_t)i], d1 = b->desc_off[(size_t)i + 1];
+                size_t de = d1;
+                for (size_t j = d0 + 1; j < d1; j++)
+                    if (b->desc[j] == ' ') {
+                        de = j;
+                        break;
+                    }
+                if (d1 > d0 + 1) line.append((const char *)b->desc.data() + d0 + 1, de - d0 - 1);
+                line.push_back('\t');
+                line.append(c >= 0 ? opts->taxids[c] : "0");
+                line.push_back('\t');
+                append_int(line, L);
+                line.push_back('\t');
+                for (uint64_t s = s0; s < s1; s++) {
+                    if (s > s0) line.push_back(' ');
+                    const int32_t code = seg_code[(size_t)s];
+                    if (code == -2)
+                        line.push_back('A');
+                    else if (code < 0)
+                        line.push_back('0');
+                    else
+                        line.append(opts->taxids[code]);
+                    line.push_back(':');
+                    append_int(line, (s + 1 < s1 ? seg_start[(size_t)s + 1] : maxp) - seg_start[(size_t)s]);
+                }
+                line.push_back('\n');
+                kraken.write(line.data(), line.size());
+            }
+        }
+    }
+    prod.th.join();
+    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
+    if (!err) err = gs_match_finish(run, table, dtable);
+    gs_match_destroy(run);
+    if (totals) {
+        totals->reads = prod.reads;
+        totals->kmers = prod.kmers;
+        totals->bps = prod.bps;
+        totals->filtered_reads = filtered_reads;
+        totals->seconds_total = now_s() - t_start;
+        totals->seconds_parse = prod.seconds;
+        totals->seconds_gpu = t_gpu;
+    }
+    return err;
+}
+
+extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio,
+                                    const char *const *paths, int n_paths, const char *filtered_path,
+                                    const char *rest_path, gs_host_totals *totals) {
+    if (!bloom || !paths || n_paths < 0) return hfail(GS_E_INVALID, "NULL argument");
+    OutFile acc_out, rest_out;
+    if (!acc_out.open(filtered_path) || !rest_out.open(rest_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    const double t_start = now_s();
+    std::vector<std::string> plist(paths, paths + n_paths);
+    Producer prod;
+    prod.start(plist, k, (int64_t)1 << 20);
+    std::vector<uint8_t> accept, tmp;
+    int64_t accepted = 0;
+    double t_gpu = 0;
+    int err = GS_OK;
+    for (;;) {
+        std::unique_ptr<Batch> b = prod.q.pop();
+        if (!b) break;
+        if (err) continue;
+        const int64_t n = b->n();
+        accept.resize((size_t)n);
+        if (b->seq.empty()) b->seq.push_back(0);
+        const double t0 = now_s();
+        err = gs_filter_submit(bloom, k, min_pos_count, positive_ratio, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST,
+                               accept.data(), 0);
+        t_gpu += now_s() - t0;
+        if (err) continue;
+        for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+            if (accept[(size_t)i]) {
+                accepted++;
+                if (acc_out.active()) write_read(acc_out, *b, i, false, tmp);
+            } else if (rest_out.active())
+                write_read(rest_out, *b, i, false, tmp);
+        }
+    }
+    prod.th.join();
+    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
+    if (totals) {
+        totals->reads = prod.reads;
+        totals->kmers = prod.kmers;
+        totals->bps = prod.bps;
+        totals->filtered_reads = accepted;
+        totals->seconds_total = now_s() - t_start;
+        totals->seconds_parse = prod.seconds;
+        totals->seconds_gpu = t_gpu;
+    }
+    return err;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// completeResults + CSV
+// ---------------------------------------------------------------------------------------------------
+extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, const int64_t *table, const double *dtable,
+                                 const gs_host_totals *totals) {
+    if (!path || !tax || !table || !totals || !tax->parent_vi || !tax->taxids || !tax->db_kmers)
+        return hfail(GS_E_INVALID, "NULL argument");
+    const int nv = tax->n_values;
+    // rows: every value with a CountsPerTaxid (>= 1 hit k-mer or >= 1 classified read) plus all their ancestors
+    // (MatchingResult.java:88-98)
+    std::vector<char> present((size_t)nv, 0);
+    for (int v = 0; v < nv; v++) {
+        const int64_t *row = table + (size_t)v * GS_N_COLS;
+        if (tax->parent_vi[v] != -2 && (row[GS_C_READS] > 0 || row[GS_C_READS_1KMER] > 0)) present[(size_t)v] = 1;
+    }
+    for (int v = 0; v < nv; v++)
+        if (present[(size_t)v] == 1)
+            for (int a = tax->parent_vi[v]; a >= 0; a = tax->parent_vi[a])
+                if (!present[(size_t)a]) present[(size_t)a] = 2;
+    // tree order (sortTaxidsViaTree): by position; default pre-order over children in value-index order
+    std::vector<int> pos((size_t)nv, 0);
+    if (tax->position) {
+        for (int v = 0; v < nv; v++) pos[(size_t)v] = tax->position[v];
+    } else {
+        std::vector<std::vector<int>> kids((size_t)nv);
+        std::vector<int> roots, stack;
+        for (int v = 0; v < nv; v++) {
+            if (tax->parent_vi[v] >= 0)
+                kids[(size_t)tax->parent_vi[v]].push_back(v);
+            else if (tax->parent_vi[v] == -1)
+                roots.push_back(v);
+        }
+        int counter = 0;
+        for (auto it = roots.rbegin(); it != roots.rend(); ++it) stack.push_back(*it);
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            pos[(size_t)v] = counter++;
+            for (auto it = kids[(size_t)v].rbegin(); it != kids[(size_t)v].rend(); ++it) stack.push_back(*it);
+        }
+    }
+    std::vector<int> rows;
+    for (int v = 0; v < nv; v++)
+        if (present[(size_t)v]) rows.push_back(v);
+    std::sort(rows.begin(), rows.end(), [&](int a, int b) { return pos[(size_t)a] < pos[(size_t)b]; });
+    // accumulate into ancestors in tree order (:104-117); value types READS, KMERS, READS_BPS, READS_1KMER, READS_KMERS
+    static const int vcol[5] = {GS_C_READS, GS_C_KMERS, GS_C_READS_BPS, GS_C_READS_1KMER, GS_C_READS_KMERS};
+    static const char *vname[5] = {"reads", "kmers", "reads bps", "read >=1 kmer", "reads kmers"};
+    std::vector<int64_t> acc((size_t)nv * 5, 0);
+    std::vector<double> accn((size_t)nv * 5, 0.0), accd((size_t)nv * 4, 0.0);
+    auto val = [&](int v, int t) { return present[(size_t)v] == 1 ? table[(size_t)v * GS_N_COLS + vcol[t]] : (int64_t)0; };
+    auto dval = [&](int v, int j) { return (present[(size_t)v] == 1 && dtable) ? dtable[(size_t)v * GS_N_DCOLS + j] : 0.0; };
+    for (int v : rows) {
+        const int64_t dbk = tax->db_kmers[v];
+        for (int t = 0; t < 5; t++) {
+            acc[(size_t)v * 5 + t] += val(v, t);
+            accn[(size_t)v * 5 + t] += dbk > 0 ? (double)val(v, t) / (double)dbk : 0.0;
+        }
+        for (int j = 0; j < 4; j++) accd[(size_t)v * 4 + j] += dval(v, j);
+    }
+    // a descendant adds its OWN values to every ancestor, in tree order
+    for (int v : rows) {
+        const int64_t dbk = tax->db_kmers[v];
+        for (int a = tax->parent_vi[v]; a >= 0; a = tax->parent_vi[a]) {
+            for (int t = 0; t < 5; t++) {
+                acc[(size_t)a * 5 + t] += val(v, t);
+                accn[(size_t)a * 5 + t] += dbk > 0 ? (double)val(v, t) / (double)dbk : 0.0;
+            }
+            for (int j = 0; j < 4; j++) accd[(size_t)a * 4 + j] += dval(v, j);
+        }
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return hfail(GS_E_INVALID, std::string("cannot open ") + path);
+    std::string o;
+    o = "pos;level;name;rank;taxid;reads;kmers from reads;kmers;unique kmers;contigs;average contig length;max contig length;"
+        "reads >=1 kmer;reads bps;avg. read length;db coverage;exp. unique kmers;unique kmers / exp.;db kmers;parent taxid;"
+        "mean error;kmer error std. dev.;mean class error;class error std. dev.;contig len std. dev.;";
+    for (int t = 0; t < 5; t++) o += std::string("norm. ") + vname[t] + ";";
+    for (int t = 0; t < 5; t++) o += std::string("acc. ") + vname[t] + ";acc. norm. " + vname[t] + ";";
+    o += "max contig desc.;acc. mean error;acc. error std. dev.;acc. mean class error;acc. class error std. dev.;\n";
+    auto dbl = [&](double v, bool total_row, bool always = false) {  // ResultReporter.java:249-253
+        if (!std::isnan(v) && !std::isinf(v) && (!total_row || always)) o += java_double(v);
+        o.push_back(';');
+    };
+    // TOTAL row (pos 0): reads, kmers, reads bps, db kmers; everything else 0 / blank
+    o += "0;0;TOTAL;;;";
+    append_int(o, totals->reads);
+    o += ";0;";
+    append_int(o, totals->kmers);
+    o += ";0;0;";
+    dbl(0.0 / 0.0, true);  // average contig length: NaN -> blank
+    o += "0;0;";
+    append_int(o, totals->bps);
+    o.push_back(';');
+    dbl(totals->reads ? (double)totals->bps / (double)totals->reads : 0.0 / 0.0, true, true);
+    dbl(0, true);
+    dbl(0, true);
+    dbl(0, true);
+    append_int(o, tax->db_kmers_total);
+    o += ";;";
+    for (int j = 0; j < 5; j++) dbl(0, true);
+    for (int t = 0; t < 5; t++) dbl(0, true);
+    for (int t = 0; t < 10; t++) o.push_back(';');
+    o.push_back(';');
+    for (int j = 0; j < 4; j++) dbl(0, true);
+    o.push_back('\n');
+    int p = 1;
+    for (int v : rows) {
+        const int64_t *row = table + (size_t)v * GS_N_COLS;
+        const bool own = present[(size_t)v] == 1;
+        auto col = [&](int c) { return own ? row[c] : (int64_t)0; };
+        int level = 0;
+        for (int a = tax->parent_vi[v]; a >= 0; a = tax->parent_vi[a]) level++;
+        const int64_t reads = col(GS_C_READS), kmers = col(GS_C_KMERS), contigs = col(GS_C_CONTIGS);
+        const int64_t uniq = own ? row[GS_C_UNIQUE_KMERS] : 0, dbk = tax->db_kmers[v];
+        append_int(o, p++);
+        o.push_back(';');
+        append_int(o, level);
+        o.push_back(';');
+        if (tax->names && tax->names[v]) o += tax->names[v];
+        o.push_back(';');
+        if (tax->ranks && tax->ranks[v]) o += tax->ranks[v];
+        o.push_back(';');
+        o += tax->taxids[v];
+        o.push_back(';');
+        append_int(o, reads);
+        o.push_back(';');
+        append_int(o, col(GS_C_READS_KMERS));
+        o.push_back(';');
+        append_int(o, kmers);
+        o.push_back(';');
+        append_int(o, uniq);
+        o.push_back(';');
+        append_int(o, (int32_t)contigs);  // Java field is int
+        o.push_back(';');
+        dbl((double)kmers / (double)contigs, false);
+        append_int(o, col(GS_C_MAX_CONTIG_LEN));
+        o.push_back(';');
+        append_int(o, col(GS_C_READS_1KMER));
+        o.push_back(';');
+        append_int(o, col(GS_C_READS_BPS));
+        o.push_back(';');
+        dbl((double)col(GS_C_READS_BPS) / (double)reads, false);
+        dbl((double)uniq / (double)dbk, false);
+        const double expu = (1 - std::pow(1 - 1.0 / (double)dbk, (double)kmers)) * (double)dbk;
+        dbl(expu, false);
+        dbl((double)uniq / expu, false);
+        append_int(o, dbk);
+        o.push_back(';');
+        if (tax->parent_vi[v] >= 0) o += tax->taxids[tax->parent_vi[v]];
+        o.push_back(';');
+        const double es = dval(v, GS_D_ERR_SUM), es2 = dval(v, GS_D_ERR_SQ_SUM), cs = dval(v, GS_D_CLASS_ERR_SUM),
+                     cs2 = dval(v, GS_D_CLASS_ERR_SQ_SUM);
+        dbl(es / (double)reads, false);
+        dbl(std::sqrt((es2 - es * es / (double)reads) / (double)(reads - 1)), false);
+        dbl(cs / (double)reads, false);
+        dbl(std::sqrt((cs2 - cs * cs / (double)reads) / (double)(reads - 1)), false);
+        dbl(std::sqrt(((double)col(GS_C_CONTIG_LEN_SQ_SUM) - ((double)kmers * (double)kmers) / (double)contigs) / (double)(contigs - 1)), false);
+        for (int t = 0; t < 5; t++) dbl((double)val(v, t) / (double)dbk, false);
+        for (int t = 0; t < 5; t++) {
+            append_int(o, acc[(size_t)v * 5 + t]);
+            o.push_back(';');
+            o += java_double(accn[(size_t)v * 5 + t]);
+            o.push_back(';');
+        }
+        if (tax->max_contig_desc && tax->max_contig_desc[v]) o += tax->max_contig_desc[v];
+        o.push_back(';');
+        const double areads = (double)acc[(size_t)v * 5 + 0];
+        const double aes = accd[(size_t)v * 4 + 0], aes2 = accd[(size_t)v * 4 + 1], acs = accd[(size_t)v * 4 + 2],
+                     acs2 = accd[(size_t)v * 4 + 3];
+        dbl(aes / areads, false);
+        dbl(std::sqrt((aes2 - aes * aes / areads) / (areads - 1)), false);
+        dbl(acs / areads, false);
+        dbl(std::sqrt((acs2 - acs * acs / areads) / (areads - 1)), false);
+        o.push_back('\n');
+    }
+    fwrite(o.data(), 1, o.size(), f);
+    fclose(f);
+    return GS_OK;
+}

@@ -1,0 +1,116 @@
+"""End-to-end file pipelines of the C++ host layer on the GPU (gs_host_match_files / gs_host_filter_files):
+FASTQ(.gz) files -> per-taxid table, totals, Kraken-style output, filtered FASTQ -- against the oracle."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import genestrip_amd as ga
+from genestrip_amd import host, synth
+from conftest import GOLDEN
+from oracle import gs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sdb():
+    return synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=20000, seed=11)
+
+
+def _write_fastq(path, seq, off, gz, start=0):
+    n = len(off) - 1
+    recs = []
+    for i in range(n):
+        s = seq[int(off[i]):int(off[i + 1])].tobytes()
+        recs.append(b"@r%d sample=%d\n%s\n+\n%s\n" % (start + i, i % 7, s, b"F" * len(s)))
+    data = b"".join(recs)
+    with (gzip.open(path, "wb", compresslevel=1) if gz else open(path, "wb")) as f:
+        f.write(data)
+
+
+def _oracle_kraken_lines(odb, taxids, seq, off, cv, start=0, write_all=True):
+    lines = []
+    names = {-1: "0", -2: "A"}
+    for i in range(len(off) - 1):
+        r = seq[int(off[i]):int(off[i + 1])].tobytes()
+        segs = odb.segments(r)
+        if not segs or not (write_all or cv[i] >= 0):
+            continue
+        segtxt = " ".join(f"{taxids[c] if c >= 0 else names[c]}:{n}" for c, n in segs)
+        lines.append(f"{'C' if cv[i] >= 0 else 'U'}\tr{start + i}\t{taxids[cv[i]] if cv[i] >= 0 else '0'}\t{len(r)}\t{segtxt}")
+    return lines
+
+
+def test_match_files_two_inputs_table_kraken_filtered(sdb, tmp_path):
+    seq, off = synth.reads_host(sdb.genomes, 7000, read_len=150, seed=19)
+    seq = seq.copy()
+    seq[150 * 5 + 70] = ord("N")
+    seq[150 * 6:150 * 6 + 3] = ord("N")
+    f1, f2 = str(tmp_path / "a.fastq.gz"), str(tmp_path / "b.fq")
+    _write_fastq(f1, seq, off[:4001], gz=True)
+    off2 = off[4000:] - off[4000]
+    _write_fastq(f2, seq[int(off[4000]):], off2, gz=False, start=4000)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    kr, flt = str(tmp_path / "kraken.out"), str(tmp_path / "filtered.fastq.gz")
+    table, dtable, tot = host.match_files(store, [f1, f2], filtered_path=flt, kraken_out_path=kr, taxids=sdb.taxids,
+                                          batch_reads=1500)
+    # oracle: same reads, global read numbers running over both files
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    orun = orc.MatchRun(odb)
+    ocv, ofl = orun.submit(seq, off)
+    otable, _ = orun.finish()
+    assert np.array_equal(table, otable)
+    assert (tot.reads, tot.kmers, tot.bps) == (7000, 7000 * 120, 7000 * 150)
+    want = _oracle_kraken_lines(odb, sdb.taxids, seq, off, ocv)
+    got = open(kr).read().rstrip("\n").split("\n")
+    assert got == want
+    # filtered FASTQ: reads with matchRead() == true, rewritten with '~' qualities (withProbs = false)
+    flt_txt = gzip.open(flt).read().decode().split("\n")
+    exp = []
+    for i in np.flatnonzero(ofl & orc.F_RETURNED):
+        s = seq[int(off[i]):int(off[i + 1])].tobytes().decode()
+        exp += [f"@r{i} sample={(i if i < 4000 else i - 4000) % 7}", s, "+", "~" * len(s)]
+    assert flt_txt[:-1] == exp and tot.filtered_reads == int((ofl & orc.F_RETURNED != 0).sum())
+    store.close()
+
+
+def test_match_files_write_all_false_and_dengue_golden(tmp_path):
+    lines = open(os.path.join(GOLDEN, "dengue1", "dengue1.fasta")).read().split("\n")
+    genome = "".join(l.strip() for l in lines if not l.startswith(">")).upper()
+    keys = np.unique(orc.canonical_kmers(genome, 31))
+    store = ga.DeviceKMerStore(31, keys, np.zeros(len(keys), np.int32), 1, np.array([-1], np.int32))
+    junk = tmp_path / "mixed.fastq"
+    junk.write_bytes(open(os.path.join(GOLDEN, "dengue1", "test.fastq"), "rb").read() +
+                     b"@nohit\n" + b"ACGT" * 12 + b"\n+\n" + b"I" * 48 + b"\n@tiny\nACG\n+\nIII\n")
+    kr = str(tmp_path / "k.out")
+    table, _, tot = host.match_files(store, [str(junk)], kraken_out_path=kr, taxids=["1"], write_all=False)
+    assert open(kr).read() == open(os.path.join(GOLDEN, "dengue1", "test.out")).read()
+    kr2 = str(tmp_path / "k2.out")
+    host.match_files(store, [str(junk)], kraken_out_path=kr2, taxids=["1"], write_all=True)
+    assert open(kr2).read().split("\n")[:2] == ["C\ttest\t1\t41\t0:2 1:7 0:2", "U\tnohit\t0\t48\t0:18"]
+    assert tot.reads == 3 and table[0, 0] == 1
+    # the reference's own FASTA fixture goes through the FASTA path (suffix) and every k-mer is found
+    t2, _, tot2 = host.match_files(store, [os.path.join(GOLDEN, "dengue1", "dengue1.fasta")])
+    assert tot2.reads == 1 and tot2.bps == 10735 and t2[0, 2] == 10705 and t2[0, 3] == len(keys)
+    store.close()
+
+
+def test_filter_files(sdb, tmp_path):
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    seq, off = synth.reads_host(sdb.genomes, 5000, read_len=150, seed=5)
+    f1 = str(tmp_path / "in.fastq.gz")
+    _write_fastq(f1, seq, off, gz=True)
+    acc_p, rest_p = str(tmp_path / "acc.fastq"), str(tmp_path / "rest.fastq.gz")
+    tot = host.filter_files(gb, 31, [f1], filtered_path=acc_p, rest_path=rest_p)
+    want = ob.filter_batch(31, 1, 0.2, seq, off)
+    assert tot.reads == 5000 and tot.filtered_reads == int(want.sum())
+    acc_ids = [l for l in open(acc_p).read().split("\n") if l.startswith("@r")]
+    rest_ids = [l for l in gzip.open(rest_p).read().decode().split("\n") if l.startswith("@r")]
+    assert acc_ids == [f"@r{i} sample={i % 7}" for i in np.flatnonzero(want)]
+    assert rest_ids == [f"@r{i} sample={i % 7}" for i in np.flatnonzero(want == 0)]
+    gb.close()

@@ -1,0 +1,146 @@
+"""CPU tests of the C++ host layer (libgshost.so): parser semantics against the oracle's restatement and the
+reference fixtures, Double.toString formatting, completeResults + CSV integer columns."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from genestrip_amd import host
+from oracle import gs_oracle as orc
+
+
+def _read_all(path, k, fasta=None, max_reads=1 << 20):
+    r = host.FastqReader(path, k=k, fasta=fasta)
+    seqs, descs, quals = [], [], []
+    first = 0
+    while True:
+        b = r.next_batch(max_reads=max_reads)
+        if b is None:
+            break
+        assert b["first_read_no"] == first
+        first += b["n_reads"]
+        for i in range(b["n_reads"]):
+            seqs.append(b["seq"][int(b["seq_off"][i]):int(b["seq_off"][i + 1])].tobytes())
+            descs.append(b["desc"][int(b["desc_off"][i]):int(b["desc_off"][i + 1])].tobytes())
+            quals.append(b["qual"][int(b["qual_off"][i]):int(b["qual_off"][i + 1])].tobytes())
+    tot = r.totals()
+    r.close()
+    return seqs, descs, quals, tot
+
+
+def _oracle_all(data, k, fasta=False):
+    rd = orc.parse_fastq(data, fasta=fasta, k=k)
+
+    def col(name):
+        o = rd[name + "_off"]
+        return [rd[name][int(o[i]):int(o[i + 1])].tobytes() for i in range(rd["n_reads"])]
+    return col("seq"), col("desc"), col("qual"), (rd["n_reads"], rd["total_kmers"], rd["total_bps"])
+
+
+def test_k6_sample_fastq_gz_totals_and_records():
+    path = os.path.join(GOLDEN, "human_virus", "sample.fastq.gz")
+    got = _read_all(path, 31, max_reads=1000)  # several batches
+    assert got[3] == (6565, 461305, 658255)
+    want = _oracle_all(gzip.open(path).read(), 31)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and got[3] == want[3]
+
+
+def test_k7_simple_fixture():
+    seqs, descs, quals, tot = _read_all(os.path.join(GOLDEN, "fastq", "SimpleTest.fastq"), 2)
+    assert descs == [b"@S", b"@T"]
+    assert seqs == [b"GATTTGGGGTTCAAAGCAGTATCGATCAAATAGTAAATCCATTTGTTCAACTCACAGTTT", b"CGAT"]
+    assert quals == [b"!''*((((***+))%%%++)(%%%%).1***-+*''))**55CCF>>>>>>CCCCCCC65", b"!**>"]
+
+
+@pytest.mark.parametrize("name,data,fasta", [
+    ("a.fastq", b"@r1 x\nAC\0GT\r\n+\n!!!!!\n@r2\nACGT\n+\nIIII", False),
+    ("b.fastq", b"@r1\nACGT\nAC\n+r1\nII\nII\nII\n@r2\n\n+\n\n@r3\nNNNN\n+\n!!!!\n", False),
+    ("c.fasta", b">s1 d\nACGT\nAC\n>s2\nGG\n", True),
+    ("d.fa", b">only\nACGTACGT", True),
+    ("e.fastq", b"", False),
+])
+def test_parser_edge_cases_match_oracle(tmp_path, name, data, fasta):
+    p = tmp_path / name
+    p.write_bytes(data)
+    got = _read_all(str(p), 2)  # type by suffix
+    want = _oracle_all(data, 2, fasta)
+    assert got == want
+
+
+def test_gzip_by_content_and_multi_batch(tmp_path):
+    rng = np.random.default_rng(1)
+    recs = []
+    for i in range(5000):
+        L = int(rng.integers(1, 300))
+        s = bytes(rng.choice(list(b"ACGTN"), L).tolist())
+        recs.append(b"@read%d extra\n%s\n+\n%s\n" % (i, s, b"I" * L))
+    data = b"".join(recs)
+    p = tmp_path / "x.fastq.gz"
+    with gzip.open(p, "wb") as f:
+        f.write(data)
+    got = _read_all(str(p), 31, max_reads=777)
+    assert got == _oracle_all(data, 31)
+
+
+def test_java_double_to_string():
+    cases = {1.0: "1.0", 0.001: "0.001", 1e-4: "1.0E-4", 1e7: "1.0E7", 123456.789: "123456.789",
+             9999999.0: "9999999.0", 1e10: "1.0E10", 0.1 + 0.2: "0.30000000000000004", 100.0: "100.0",
+             1.5e-5: "1.5E-5", -2.5: "-2.5", 0.0: "0.0", 1234567.0: "1234567.0", 12345678.0: "1.2345678E7",
+             2.0 / 3.0: "0.6666666666666666", 150.0: "150.0"}
+    # (double columns are outside the bit-exact contract, SURVEY 8c: e.g. Double.MIN_VALUE prints 4.9E-324 in Java)
+    for v, s in cases.items():
+        assert host.java_double(v) == s, (v, host.java_double(v), s)
+    assert host.java_double(float("nan")) == "NaN"
+
+
+def test_csv_complete_results(tmp_path):
+    # tree: 0 root -> 1 genus -> {2, 3} species ; 4 = second genus without hits; 5 = value without node
+    parent = [-1, 0, 1, 1, 0, -2]
+    taxids = ["1", "10", "100", "101", "20", "999"]
+    names = ["root", "G", "S0", "S1", "H", None]
+    ranks = ["no rank", "genus", "species", "species", "genus", None]
+    dbk = [5, 50, 500, 400, 70, 0]
+    t = np.zeros((6, 10), dtype=np.int64)
+    d = np.zeros((6, 4))
+    #        reads rk   kmers uniq contigs sq   maxc r1k bps  readno
+    t[2] = [3, 300, 310, 120, 4, 30000, 100, 5, 450, 7]
+    t[3] = [1, 90, 95, 60, 2, 5000, 60, 2, 150, 9]
+    t[1] = [0, 0, 12, 10, 3, 60, 5, 3, 0, 11]
+    t[5] = [9, 9, 9, 9, 9, 9, 9, 9, 9, 9]  # no tree node: never reported
+    d[2] = [0.3, 0.05, 0.6, 0.2]
+    tot = host.Totals(1000, 120000, 150000, 0, 0, 0, 0)
+    out = tmp_path / "r.csv"
+    host.write_csv(out, parent, taxids, dbk, 1025, t, d, tot, names=names, ranks=ranks)
+    lines = out.read_text().split("\n")
+    head = lines[0].split(";")
+    assert head[:9] == ["pos", "level", "name", "rank", "taxid", "reads", "kmers from reads", "kmers", "unique kmers"]
+    assert lines[0].endswith("acc. class error std. dev.;")
+    rows = [l.split(";") for l in lines[1:] if l]
+    assert all(len(r) == len(head) for r in rows)
+    col = {n: i for i, n in enumerate(head)}
+    total = rows[0]
+    assert total[col["name"]] == "TOTAL" and total[col["reads"]] == "1000" and total[col["kmers"]] == "120000"
+    assert total[col["reads bps"]] == "150000" and total[col["db kmers"]] == "1025" and total[col["avg. read length"]] == "150.0"
+    assert total[col["taxid"]] == "" and total[col["acc. reads"]] == ""
+    # rows in tree order: root (added as missing ancestor), genus 10, species 100, 101; genus 20 and 999 absent
+    assert [r[col["taxid"]] for r in rows[1:]] == ["1", "10", "100", "101"]
+    assert [r[col["pos"]] for r in rows] == ["0", "1", "2", "3", "4"]
+    assert [r[col["level"]] for r in rows[1:]] == ["0", "1", "2", "2"]
+    root, genus, s0, s1 = rows[1:]
+    assert root[col["reads"]] == "0" and root[col["kmers"]] == "0" and root[col["parent taxid"]] == ""
+    assert genus[col["kmers"]] == "12" and genus[col["contigs"]] == "3" and genus[col["parent taxid"]] == "1"
+    assert s0[col["reads"]] == "3" and s0[col["unique kmers"]] == "120" and s0[col["max contig length"]] == "100"
+    # accumulated = own + descendants
+    assert root[col["acc. reads"]] == "4" and genus[col["acc. reads"]] == "4" and s0[col["acc. reads"]] == "3"
+    assert root[col["acc. kmers"]] == str(310 + 95 + 12) and genus[col["acc. kmers"]] == str(310 + 95 + 12)
+    assert root[col["acc. reads bps"]] == "600" and s1[col["acc. read >=1 kmer"]] == "2"
+    assert root[col["acc. reads kmers"]] == "390"
+    # doubles follow the reference formulas and Double.toString
+    assert s0[col["average contig length"]] == host.java_double(310 / 4)
+    assert s0[col["avg. read length"]] == "150.0" and s0[col["db coverage"]] == host.java_double(120 / 500)
+    assert s0[col["mean error"]] == host.java_double(0.3 / 3)
+    assert s0[col["norm. kmers"]] == host.java_double(310 / 500)
+    assert genus[col["acc. norm. kmers"]] == host.java_double(12 / 50 + 310 / 500 + 95 / 400)
+    assert root[col["average contig length"]] == "" and root[col["mean error"]] == ""  # NaN -> blank
