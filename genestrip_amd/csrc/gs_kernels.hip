@@ -912,8 +912,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
                         alive = ((m1 & a) == m1) && ((m2 & b) == m2);
                     }
                 } else {
-                    // AbstractKMerBloomFilter.containsLong :209-216, early-out per lane on the first clear bit
-                    for (int i = 0; i < P.n_hashes && __ballot(alive) != 0; i++) {
+                    // AbstractKMerBloomFilter.containsLong :209-216, early-out per lane on the first clear bit.
+                    // Only `need - members` confirmed members are required, so after a screening prefix of 4
+                    // hashes (which drops ~94 % of the non-members) the remaining hashes are evaluated for just
+                    // as many surviving lanes as are still needed; the others stay unresolved unless a candidate
+                    // fails.  The result is unchanged: accept <=> #members >= need.
+                    const int n_screen = P.n_hashes < 4 ? P.n_hashes : 4;
+                    for (int i = 0; i < n_screen && __ballot(alive) != 0; i++) {
                         if (alive) {
                             const int64_t f = P.factors[i];
                             const int64_t h = P.kind == GS_BLOOM_XOR ? (f ^ key) : gs_murmur64(key, f);
@@ -921,6 +926,27 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
                             alive = (P.words[idx >> 6] >> (idx & 63)) & 1ULL;
                         }
                     }
+                    u64 cand = __ballot(alive);  // screened candidates of this round
+                    int confirmed = 0;
+                    while (cand != 0 && members + confirmed < need) {
+                        // the lowest (need - members - confirmed) candidate lanes go through the remaining hashes
+                        const int want_n = need - members - confirmed;
+                        const int rank = __popcll(cand & ((1ULL << lane) - 1));
+                        bool chosen = ((cand >> lane) & 1ULL) && rank < want_n;
+                        const u64 chosen_mask = __ballot(chosen);
+                        for (int i = n_screen; i < P.n_hashes && __ballot(chosen) != 0; i++) {
+                            if (chosen) {
+                                const int64_t f = P.factors[i];
+                                const int64_t h = P.kind == GS_BLOOM_XOR ? (f ^ key) : gs_murmur64(key, f);
+                                const u64 idx = gs_absmod(h, P.bits, P.magic, P.magic_shift);
+                                chosen = (P.words[idx >> 6] >> (idx & 63)) & 1ULL;
+                            }
+                        }
+                        confirmed += __popcll(__ballot(chosen));
+                        cand &= ~chosen_mask;
+                    }
+                    members += confirmed;
+                    alive = false;  // already counted
                 }
                 members += __popcll(__ballot(alive));
                 hi0 = hi1;

@@ -100,13 +100,10 @@ class SynthDB:
         order = np.argsort(allk, kind="stable")
         allk, allv = allk[order], allv[order]
         first = np.concatenate([[True], allk[1:] != allk[:-1]])
-        grp = np.cumsum(first) - 1
-        n_groups = int(grp[-1]) + 1
+        starts = np.flatnonzero(first)
         par = self.parent_vi
-        vmin = np.full(n_groups, np.iinfo(np.int32).max, dtype=np.int32)
-        vmax = np.full(n_groups, -1, dtype=np.int32)
-        np.minimum.at(vmin, grp, allv)
-        np.maximum.at(vmax, grp, allv)
+        vmin = np.minimum.reduceat(allv, starts)
+        vmax = np.maximum.reduceat(allv, starts)
         gmin, gmax = par[vmin], par[vmax]  # genus of the smallest / largest species (pre-order => contiguous)
         val = np.where(vmin == vmax, vmin, np.where(gmin == gmax, gmin, 0)).astype(np.int32)
         self.kmers = allk[first]

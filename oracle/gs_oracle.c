@@ -233,6 +233,10 @@ void orc_bloom_put(orc_bloom *b, int64_t key) {
     }
 }
 
+void orc_bloom_put_many(orc_bloom *b, const int64_t *keys, int64_t n) {
+    for (int64_t i = 0; i < n; i++) orc_bloom_put(b, keys[i]);
+}
+
 int orc_bloom_contains(const orc_bloom *b, int64_t key) {
     if (b->kind == ORC_BLOOM_BLOCKED) {
         blocked_probe p = blocked_prepare(b, key);
