@@ -28,7 +28,7 @@ BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
 # every symbol include/gsgpu.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = (
     "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
-    "gs_db_create", "gs_db_get_info", "gs_db_destroy",
+    "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
     "gs_match_segments_fetch",
@@ -97,7 +97,7 @@ def lib():
         "gs_last_error": (C.c_char_p, []), "gs_strerror": (C.c_char_p, [ci]), "gs_abi_version": (ci, []),
         "gs_device_count": (ci, [vp]),
         "gs_db_create": (ci, [vp, ci, ci, i64, vp, vp, i32, vp]), "gs_db_get_info": (ci, [vp, vp]),
-        "gs_db_destroy": (ci, [vp]),
+        "gs_db_destroy": (ci, [vp]), "gs_db_save": (ci, [vp, C.c_char_p]), "gs_db_load": (ci, [vp, ci, C.c_char_p]),
         "gs_match_begin": (ci, [vp, vp, vp]), "gs_match_submit": (ci, [vp, vp, vp, i64, i64, ci, vp, vp]),
         "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
@@ -157,6 +157,20 @@ class DeviceKMerStore:
         _check(lib().gs_db_create(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
                                   vidx.ctypes.data_as(C.c_void_p), n_values,
                                   None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+
+    @classmethod
+    def load(cls, path, device=0):
+        """open a native store file written by save() (gs_db_load)"""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        _check(lib().gs_db_load(C.byref(self.h), device, str(path).encode()))
+        self.device = device
+        i = self.info
+        self.k, self.n_values = i.k, i.n_values
+        return self
+
+    def save(self, path):
+        _check(lib().gs_db_save(self.h, str(path).encode()))
 
     @property
     def info(self):

@@ -295,6 +295,96 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
     return GS_OK;
 }
 
+// ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
+// Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
+struct GsStoreFileHeader {
+    char magic[8];  // "GSSTORE1"
+    gs_db_info info;
+    uint32_t bucket_bits, vbits;
+    uint64_t gate_words;
+};
+
+extern "C" int gs_db_save(gs_db *db, const char *path) {
+    if (!db || !path) return fail(GS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(db->device));
+    if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
+    GsStoreFileHeader h{};
+    memcpy(h.magic, "GSSTORE1", 8);
+    h.info = db->info;
+    h.bucket_bits = db->dev.bucket_bits;
+    h.vbits = db->dev.vbits;
+    h.gate_words = db->d_gate ? db->dev.gate_mask + 1 : 0;
+    const size_t nv = (size_t)db->info.n_values;
+    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<int32_t> tree(4 * nv);
+    HIP_TRY(hipMemcpy(table.data(), db->d_table, table.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    if (!gate.empty()) HIP_TRY(hipMemcpy(gate.data(), db->d_gate, gate.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tree.data(), db->d_tree, tree.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
+              fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
+              fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
+    ok = (fclose(f) == 0) && ok;
+    return ok ? GS_OK : fail(GS_E_INVALID, std::string("short write to ") + path);
+}
+
+extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
+    if (!out || !path) return fail(GS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = use_device(device);
+    if (rc) return rc;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
+    GsStoreFileHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE1", 8) != 0 || h.info.n_values < 1 ||
+        h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25) {
+        fclose(f);
+        return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file");
+    }
+    const size_t nv = (size_t)h.info.n_values;
+    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<int32_t> tree(4 * nv);
+    const bool ok = fread(table.data(), sizeof(u64), table.size(), f) == table.size() &&
+                    fread(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
+                    fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
+    fclose(f);
+    if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
+    gs_db *db = new gs_db();
+    db->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (e == hipSuccess) e = hipMalloc((void **)&db->d_table, table.size() * sizeof(u64));
+    if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, tree.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), table.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree, tree.data(), tree.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(db->d_table);
+        hipFree(db->d_gate);
+        hipFree(db->d_tree);
+        delete db;
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
+    }
+    db->info = h.info;
+    db->dev.table = db->d_table;
+    db->dev.gate = db->d_gate;
+    db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
+    db->dev.bucket_bits = h.bucket_bits;
+    db->dev.vbits = h.vbits;
+    db->dev.bucket_mask = ((u64)1 << h.bucket_bits) - 1;
+    db->dev.k = h.info.k;
+    db->dev.n_values = h.info.n_values;
+    db->dev.parent = db->d_tree;
+    db->dev.depth = db->d_tree + nv;
+    db->dev.tin = db->d_tree + 2 * nv;
+    db->dev.tout = db->d_tree + 3 * nv;
+    *out = db;
+    return GS_OK;
+}
+
 extern "C" int gs_db_destroy(gs_db *db) {
     if (!db) return GS_OK;
     hipSetDevice(db->device);

@@ -81,6 +81,12 @@ int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_
 int gs_db_get_info(const gs_db *db, gs_db_info *info);
 int gs_db_destroy(gs_db *db);
 
+/* Native store file: the built device image (table, gate, taxonomy arrays), so that a later
+ * process loads it straight into HBM instead of going through Java deserialisation (Database.load,
+ * C/store/Database.java:265-314) + KMerStore.visit + gs_db_create.  Not portable across layout versions. */
+int gs_db_save(gs_db *db, const char *path);
+int gs_db_load(gs_db **out, int device, const char *path);
+
 /* ---------------------------------------------------------------------------------------------------
  * match
  *
