@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch",
+    "gs_match_segments_fetch", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -102,6 +102,9 @@ def lib():
         "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
         "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
+        "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
+        "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
+        "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
@@ -144,7 +147,7 @@ def _ptr(a):
 class DeviceKMerStore:
     """k-mer -> value-index store plus taxonomy, resident in HBM (gs_db)."""
 
-    def __init__(self, k, kmers_sorted, value_idx, n_values, parent_vi=None, device=0):
+    def __init__(self, k, kmers_sorted, value_idx, n_values, parent_vi=None, device=0, n_parts=1, part=0):
         kmers = np.ascontiguousarray(kmers_sorted, dtype=np.int64)
         vidx = np.ascontiguousarray(value_idx, dtype=np.int32)
         if len(kmers) != len(vidx):
@@ -154,9 +157,9 @@ class DeviceKMerStore:
             raise ValueError("parent_vi must have n_values entries")
         self.h = C.c_void_p()
         self.k, self.n_values, self.device = k, n_values, device
-        _check(lib().gs_db_create(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
-                                  vidx.ctypes.data_as(C.c_void_p), n_values,
-                                  None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+        _check(lib().gs_db_create_part(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                       vidx.ctypes.data_as(C.c_void_p), n_values,
+                                       None if pv is None else pv.ctypes.data_as(C.c_void_p), n_parts, part))
 
     @classmethod
     def load(cls, path, device=0):
@@ -237,6 +240,20 @@ class FastqKMerMatcher:
 
     def sync(self):
         _check(lib().gs_match_sync(self.h))
+
+    # ---- DB-partitioned mode (device tensors with data_ptr())
+    def encode(self, seq, offsets, pos_off, keys, n_reads):
+        _check(lib().gs_match_encode(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,
+                                     C.c_void_p(pos_off.data_ptr()), C.c_void_p(keys.data_ptr())))
+
+    def probe_keys(self, keys, nodes, n_keys):
+        _check(lib().gs_match_probe_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, C.c_void_p(nodes.data_ptr())))
+
+    def reduce(self, seq, offsets, pos_off, nodes, n_reads, first_read_no=0, class_vi=None, flags=None):
+        _check(lib().gs_match_reduce(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,
+                                     first_read_no, C.c_void_p(pos_off.data_ptr()), C.c_void_p(nodes.data_ptr()),
+                                     None if class_vi is None else C.c_void_p(class_vi.data_ptr()),
+                                     None if flags is None else C.c_void_p(flags.data_ptr())))
 
     def segments(self, seq, offsets):
         """Kraken-style segments of a host batch: (seg_off uint64[n+1], codes int32[], starts int32[], lens int32[])"""

@@ -26,6 +26,9 @@ extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots
 extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_segments(const struct GsSegParams *P, int write, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_encode(const struct GsEncodeParams *P, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_probe_keys(const GsDbDev *db, const u64 *keys, int64_t n, int32_t *nodes, int count_unique,
+                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
 extern "C" int gs_match_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
@@ -125,8 +128,22 @@ static int bits_for(u64 v) {
     return b;
 }
 
+static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part);
+
 extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                             int32_t n_values, const int32_t *parent_vi) {
+    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, 1, 0);
+}
+
+extern "C" int gs_db_create_part(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
+                                 int32_t n_values, const int32_t *parent_vi, int n_parts, int part) {
+    if (n_parts < 1 || part < 0 || part >= n_parts) return fail(GS_E_INVALID, "bad partition");
+    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, n_parts, part);
+}
+
+static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part) {
     if (!out) return fail(GS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
@@ -190,7 +207,9 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
         u64 key;
         bool reachable = java_to_planar((u64)kmers[i], k, key);
         if (!reachable || parent[vidx[i]] == -2) continue;
-        hkey.push_back(gs_mix62(key));
+        const u64 hk = gs_mix62(key);
+        if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
+        hkey.push_back(hk);
         hval.push_back(vidx[i]);
     }
     const int64_t ns = (int64_t)hkey.size();
@@ -556,7 +575,8 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
 }
 
 static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int64_t first_read_no,
-                        int32_t *d_class, uint8_t *d_flags) {
+                        int32_t *d_class, uint8_t *d_flags, const int32_t *d_nodes = nullptr,
+                        const uint64_t *d_pos_off = nullptr) {
     if (n_reads > (int64_t)0xffffffffLL) return fail(GS_E_INVALID, "more than 2^32-1 reads in one batch");
     int rc = ensure_long(run, n_reads);
     if (rc) return rc;
@@ -580,6 +600,8 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.flags = d_flags;
     P.long_count = run->d_long_count;
     P.long_list = run->d_long_list;
+    P.nodes = d_nodes;
+    P.pos_off = (const unsigned long long *)d_pos_off;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + (GS_BLOCK / 64) - 1) / (GS_BLOCK / 64));
     if (grid < 1) grid = 1;
@@ -589,7 +611,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, run->stream));
     }
-    if (run->cfg.count_unique) {
+    if (run->cfg.count_unique && !d_nodes) {
         run->seen_dirty = true;
         run->bitmap_merged = false;
     }
@@ -747,6 +769,46 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
     HIP_TRY(hipStreamSynchronize(run->stream));
     run->bitmap_merged = true;  // gs_match_finish counts from this merged bitmap
     return GS_OK;
+}
+
+// ---- DB-partitioned mode: encode / probe / reduce as separate steps (all pointers are device pointers)
+extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                               const uint64_t *pos_off, uint64_t *keys) {
+    if (!run || (n_reads > 0 && (!seq || !offsets || !pos_off || !keys))) return fail(GS_E_INVALID, "NULL argument");
+    if (n_reads <= 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    GsEncodeParams P{};
+    P.k = run->db->info.k;
+    P.seq = seq;
+    P.off = offsets;
+    P.n_reads = n_reads;
+    P.pos_off = (const unsigned long long *)pos_off;
+    P.keys = (unsigned long long *)keys;
+    int grid = (int)std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4);
+    if (grid < 1) grid = 1;
+    HIP_TRY(gs_launch_encode(&P, grid, run->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32_t *nodes) {
+    if (!run || (n_keys > 0 && (!keys || !nodes))) return fail(GS_E_INVALID, "NULL argument");
+    if (n_keys <= 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (run->cfg.count_unique) {
+        run->seen_dirty = true;
+        run->bitmap_merged = false;
+    }
+    HIP_TRY(gs_launch_probe_keys(&run->db->dev, (const u64 *)keys, n_keys, nodes, run->cfg.count_unique, run->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                               int64_t first_read_no, const uint64_t *pos_off, const int32_t *nodes, int32_t *class_vi,
+                               uint8_t *flags) {
+    if (!run || (n_reads > 0 && (!seq || !offsets || !pos_off || !nodes))) return fail(GS_E_INVALID, "NULL argument");
+    if (n_reads <= 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    return launch_batch(run, seq, offsets, n_reads, first_read_no, class_vi, flags, nodes, pos_off);
 }
 
 // ---- Kraken-style segments (two passes: count, host prefix sum, write)

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "gs_layout.h"
 #include "gs_params.h"
 
@@ -278,7 +280,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // one read on one wave.  LONG = false: max <= 128 (one iteration, distinct nodes kept in registers).
 // LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG>
+template <bool LONG, bool FROM_NODES>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
@@ -330,7 +332,20 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
             int node[2], slot[2];
             bool fresh[2];  // hit on a slot whose seen bit was still clear in the copy this lane read
-            gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh);
+            if (FROM_NODES) {
+                // DB-partitioned mode: the node of every position was looked up by the owner of its k-mer
+                // (gs_probe_keys_kernel on the owning rank) and routed back; INVALID windows carry GS_NODE_INVALID
+                const u64 pb = P.pos_off[r] + (u64)base;
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const int p = base + 64 * s + lane;
+                    node[s] = p < max ? P.nodes[pb + 64 * s + lane] : GS_NODE_NONE;
+                    slot[s] = 0;
+                    fresh[s] = false;
+                }
+            } else {
+                gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh);
+            }
 
             // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
             // just read, so a k-mer that is already marked costs nothing; a stale copy only repeats the atomic
@@ -340,7 +355,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             if (P.count_unique) {
 #pragma unroll
                 for (int s = 0; s < 2; s++)
-                    if (fresh[s]) atomicOr(const_cast<u64 *>(db.table) + (uint32_t)slot[s], 1ULL);
+                    if (!FROM_NODES && fresh[s]) atomicOr(const_cast<u64 *>(db.table) + (uint32_t)slot[s], 1ULL);
             }
 
             // ---- 4b. contig events
@@ -611,7 +626,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
     }
 
-template <bool LDS_STATS>
+template <bool LDS_STATS, bool FROM_NODES>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
             continue;
         }
         if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
-        gs_process_read<false>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
+        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
     }
 #else
     GsPrefetch pf;
@@ -675,13 +690,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? P.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
+        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
     }
 #endif
     GS_STATS_EPILOGUE()
 }
 
-template <bool LDS_STATS>
+template <bool LDS_STATS, bool FROM_NODES>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
@@ -700,11 +715,85 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         const uint32_t none[3] = {0, 0, 0};
         GsPrefetch nopf;
         nopf.rd = nullptr;
-        gs_process_read<true>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+        gs_process_read<true, FROM_NODES>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
                               (int)serial, none, nopf);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DB-partitioned mode: the fused kernel is split into
+//   gs_encode_kernel      reads -> mixed key h of every k-mer position (GS_KEY_INVALID for windows with a bad base)
+//   gs_probe_keys_kernel  keys -> node (value index / miss), run by the rank that OWNS the key's table partition
+//   gs_match_kernel<.., FROM_NODES = true>   per-read reduce over the routed-back node stream
+// with two all-to-all exchanges in between (genestrip_amd/distributed.py).
+// ---------------------------------------------------------------------------------------------------
+#define GS_KEY_INVALID (~0ULL)
+
+__global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
+    const int lane = gs_lane();
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int k = P.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const u64 off = P.off[r];
+        const int L = (int)(P.off[r + 1] - off);
+        const int max = L - k + 1;
+        const uint8_t *rd = P.seq + off;
+        const u64 pb = P.pos_off[r];
+        u64 hi0, lo0, bad0;
+        if (max > 0) gs_load_word(rd, L, 0, lane, hi0, lo0, bad0);
+        for (int round = 0; round * 64 < max; round++) {
+            u64 hi1, lo1, bad1;
+            gs_load_word(rd, L, round + 1, lane, hi1, lo1, bad1);
+            const int p = 64 * round + lane;
+            const uint32_t fhi = (uint32_t)gs_funnel(hi0, hi1, lane) & kmask;
+            const uint32_t flo = (uint32_t)gs_funnel(lo0, lo1, lane) & kmask;
+            const uint32_t wbad = (uint32_t)gs_funnel(bad0, bad1, lane) & kmask;
+            if (p < max) P.keys[pb + (u64)p] = wbad ? GS_KEY_INVALID : gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
+            hi0 = hi1;
+            lo0 = lo1;
+            bad0 = bad1;
+        }
+    }
+}
+
+// one lane per key; marks the slot's seen bit like the fused kernel does
+__global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u64 *keys, int64_t n, int32_t *nodes,
+                                                           int count_unique) {
+    const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
+    const int shift_rem = (int)db.vbits + 3;
+    const uint32_t bmask = (uint32_t)db.bucket_mask;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const u64 h = keys[i];
+        int node = GS_NODE_INVALID;
+        if (h != GS_KEY_INVALID) {
+            node = GS_NODE_MISS;
+            bool cand = true;
+            if (db.gate != nullptr) {
+                const u64 g = gs_gate_bits(h);
+                cand = (db.gate[(h >> db.bucket_bits) & db.gate_mask] & g) == g;
+            }
+            const uint32_t home = (uint32_t)h & bmask;
+            const u64 want = (h >> db.bucket_bits) << shift_rem;
+            for (int disp = 0; cand && disp <= GS_MAX_DISP; disp++) {
+                const uint32_t b = (home + (uint32_t)disp) & bmask;
+                GsBucket bk;
+                gs_load_bucket(db.table, b, bk);
+                int vs = -1, sl = 0;
+                const bool done = gs_match_bucket(bk, want | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
+                if (vs >= 0) {
+                    node = vs >> 1;
+                    if (count_unique && (vs & 1) == 0)
+                        atomicOr(const_cast<u64 *>(db.table) + (size_t)b * GS_SLOTS_PER_BUCKET + sl, 1ULL);
+                }
+                if (done) break;
+            }
+        }
+        nodes[i] = node;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -968,28 +1057,44 @@ static size_t gs_stats_lds_bytes(int n_values) {
 
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
-    if (P->db.n_values <= GS_NV_LDS)
-        hipLaunchKernelGGL(gs_match_kernel<true>, dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-    else
-        hipLaunchKernelGGL(gs_match_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->nodes == nullptr) {
+        if (lds_stats)
+            hipLaunchKernelGGL((gs_match_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        else
+            hipLaunchKernelGGL((gs_match_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    } else {
+        if (lds_stats)
+            hipLaunchKernelGGL((gs_match_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        else
+            hipLaunchKernelGGL((gs_match_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    }
     return hipGetLastError();
 }
 
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream) {
-    if (P->db.n_values <= GS_NV_LDS)
-        hipLaunchKernelGGL(gs_match_long_kernel<true>, dim3(grid), dim3(GS_BLOCK), gs_stats_lds_bytes(P->db.n_values), stream, *P,
-                           scratch, serial);
-    else
-        hipLaunchKernelGGL(gs_match_long_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+    const size_t lds = gs_stats_lds_bytes(P->db.n_values);
+    const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->nodes == nullptr) {
+        if (lds_stats)
+            hipLaunchKernelGGL((gs_match_long_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        else
+            hipLaunchKernelGGL((gs_match_long_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+    } else {
+        if (lds_stats)
+            hipLaunchKernelGGL((gs_match_long_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        else
+            hipLaunchKernelGGL((gs_match_long_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+    }
     return hipGetLastError();
 }
 
 extern "C" int gs_match_occupancy(int n_values) {
     int n = 0;
     hipError_t e = n_values <= GS_NV_LDS
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true>, GS_BLOCK, gs_stats_lds_bytes(n_values))
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false>, GS_BLOCK, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true, false>, GS_BLOCK, gs_stats_lds_bytes(n_values))
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false>, GS_BLOCK, 0);
     return e == hipSuccess ? n : 0;
 }
 
@@ -1025,6 +1130,19 @@ extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, 
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(gs_bitmap_or_kernel, dim3(grid), dim3(256), 0, stream, dst, parts, n_words, n_parts);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_encode(const GsEncodeParams *P, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_encode_kernel, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_probe_keys(const GsDbDev *db, const u64 *keys, int64_t n, int32_t *nodes, int count_unique,
+                                            hipStream_t stream) {
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 24);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gs_probe_keys_kernel, dim3(grid), dim3(256), 0, stream, *db, keys, n, nodes, count_unique);
     return hipGetLastError();
 }
 

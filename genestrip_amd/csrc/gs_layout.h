@@ -48,6 +48,9 @@ GS_HD uint64_t gs_mix62(uint64_t x) {
 //   word = gate[(h >> bucket_bits) & gate_mask],  bits = 4 x 6-bit fields of h >> 38
 #define GS_GATE_FIELD_SHIFT 38
 
+// DB-partitioned stores (config 5): rank (h >> GS_OWNER_SHIFT) % n_parts owns the key
+#define GS_OWNER_SHIFT 40
+
 GS_HD uint64_t gs_gate_field_bits(uint32_t f) {  // f = h >> GS_GATE_FIELD_SHIFT (24 bits)
     return (1ULL << (f & 63)) | (1ULL << ((f >> 6) & 63)) | (1ULL << ((f >> 12) & 63)) | (1ULL << ((f >> 18) & 63));
 }

@@ -24,6 +24,9 @@ struct GsMatchParams {
     uint8_t *flags;        // optional per read
     unsigned int *long_count;  // reads with more than 128 k-mer positions are queued for the long-read kernel
     uint32_t *long_list;
+    // DB-partitioned mode only: node of every k-mer position, looked up by the owning rank (nullptr: probe locally)
+    const int32_t *nodes;
+    const unsigned long long *pos_off;  // n_reads + 1: first position of read r in `nodes`
 };
 
 struct GsFilterParams {
@@ -53,4 +56,14 @@ struct GsSegParams {
     const unsigned long long *seg_off;  // write pass: exclusive prefix of seg_count
     int32_t *seg_code;
     int32_t *seg_start;
+};
+
+struct GsEncodeParams {
+    int32_t k;
+    int32_t pad;
+    const uint8_t *seq;
+    const uint64_t *off;
+    int64_t n_reads;
+    const unsigned long long *pos_off;  // n_reads + 1 (exclusive prefix of max(0, L-k+1))
+    unsigned long long *keys;           // gs_mix62(canonical planar key), ~0 for windows with a non-CGAT base
 };

@@ -49,3 +49,94 @@ def shard_bounds(n_total, rank, world):
     base, rem = divmod(n_total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DB-partitioned mode (BASELINE.json configs[4]): the store is range-split over the ranks by key
+# hash, every k-mer of a read is routed to the rank that owns it (all-to-all over xGMI), probed there, and the node
+# comes back to the read's home rank, which runs the per-read reduce.  Unique k-mers are marked in the owner's table,
+# so the per-rank unique counts are disjoint and add up.
+# ---------------------------------------------------------------------------------------------------------------
+OWNER_SHIFT = 40          # genestrip_amd/csrc/gs_layout.h: GS_OWNER_SHIFT
+KEY_INVALID = -1          # ~0 as int64: window with a non-CGAT base, never routed
+NODE_INVALID = -2
+
+
+def position_offsets(offsets, k):
+    """exclusive prefix of max(0, L - k + 1) over the reads of a batch (int64 tensor, n + 1 entries)"""
+    lens = offsets[1:] - offsets[:-1]
+    cnt = torch.clamp(lens - (k - 1), min=0)
+    out = torch.zeros(offsets.numel(), dtype=torch.int64, device=offsets.device)
+    torch.cumsum(cnt, 0, out=out[1:])
+    return out
+
+
+def plan_routing(keys, world):
+    """keys: int64 tensor of mixed keys (KEY_INVALID for invalid windows).
+    Returns (idx, send_keys, counts): idx = positions of the routed keys in owner-sorted order, send_keys =
+    keys[idx] (grouped by owner rank, ascending), counts[j] = number of keys going to rank j."""
+    valid = keys != KEY_INVALID
+    idx_valid = torch.nonzero(valid, as_tuple=False).flatten()
+    owner = (keys[idx_valid] >> OWNER_SHIFT) % world
+    order = torch.argsort(owner, stable=True)
+    idx = idx_valid[order]
+    counts = torch.bincount(owner, minlength=world)
+    return idx, keys[idx].contiguous(), counts
+
+
+def scatter_nodes(nodes_sorted, idx, n_keys):
+    """inverse of plan_routing for the returned nodes; unrouted (invalid) positions read NODE_INVALID"""
+    nodes = torch.full((n_keys,), NODE_INVALID, dtype=torch.int32, device=nodes_sorted.device)
+    nodes[idx] = nodes_sorted
+    return nodes
+
+
+def exchange_all_to_all(send, send_counts, group=None):
+    """variable-size all-to-all of a 1-D tensor: returns (recv, recv_counts)"""
+    world = dist.get_world_size(group)
+    sc = send_counts.to(torch.int64)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv = torch.empty(int(rc.sum().item()), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc.tolist(), input_split_sizes=sc.tolist(), group=group)
+    assert len(rc) == world
+    return recv, rc
+
+
+def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, group=None, class_vi=None, flags=None):
+    """One batch in DB-partitioned mode on this rank (matcher's store = this rank's partition).
+    seq / offsets: device tensors (uint8 / int64).  Collective: every rank of the group must call it."""
+    world = dist.get_world_size(group)
+    pos_off = position_offsets(offsets[:n_reads + 1], k)
+    n_keys = int(pos_off[-1].item())
+    keys = torch.empty(max(n_keys, 1), dtype=torch.int64, device=seq.device)
+    matcher.encode(seq, offsets, pos_off, keys, n_reads)
+    matcher.sync()
+    keys = keys[:n_keys]
+    idx, send_keys, counts = plan_routing(keys, world)
+    recv_keys, recv_counts = exchange_all_to_all(send_keys, counts, group)
+    recv_nodes = torch.empty(max(recv_keys.numel(), 1), dtype=torch.int32, device=seq.device)
+    torch.cuda.synchronize(seq.device)
+    matcher.probe_keys(recv_keys, recv_nodes, recv_keys.numel())
+    matcher.sync()
+    back, _ = exchange_all_to_all(recv_nodes[:recv_keys.numel()].contiguous(), recv_counts, group)
+    nodes = scatter_nodes(back, idx, max(n_keys, 1))
+    torch.cuda.synchronize(seq.device)
+    matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
+    matcher.sync()
+
+
+def partitioned_finish(matcher, sums, max_keys, dsums, group=None):
+    """merge the per-read statistics (all-reduce) and add up the disjoint per-partition unique counts.
+    Returns the global (table, dtable) as numpy arrays, identical on every rank."""
+    import numpy as np
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(max_keys, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(dsums, op=dist.ReduceOp.SUM, group=group)
+    torch.cuda.synchronize(sums.device)
+    table, dtable = matcher.finish()
+    uniq = torch.from_numpy(np.ascontiguousarray(table[:, 3])).to(sums.device)
+    if matcher.config.count_unique:
+        dist.all_reduce(uniq, op=dist.ReduceOp.SUM, group=group)
+        table[:, 3] = uniq.cpu().numpy()
+    return table, dtable

@@ -160,6 +160,24 @@ int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsum
 /* bitmap |= OR of n_parts device bitmaps laid out back to back at `parts` (each bitmap_words long) */
 int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
 
+/* ---------------------------------------------------------------------------------------------------
+ * DB-partitioned match (BASELINE.json configs[4]): the store is split over the GPUs of a node by
+ * key hash (gs_db_create_part keeps the keys with (h >> 40) % n_parts == part, h = the library's mixed key), reads stay
+ * on their home GPU.  Per batch: gs_match_encode (reads -> h of every k-mer position; ~0 marks a window with a
+ * non-CGAT base) -> all-to-all of the keys to their owners -> gs_match_probe_keys on the owner (node = value index,
+ * -1 miss, -2 invalid; marks unique k-mers in the owner's table) -> all-to-all back -> gs_match_reduce on the home
+ * GPU (the per-read state machine over the node stream).  Unique-k-mer counts of the partitions are disjoint and
+ * simply add up.  pos_off[n_reads+1] = exclusive prefix of max(0, L-k+1).  All pointers are DEVICE pointers; the
+ * calls are asynchronous on the run's stream (gs_match_sync).  No counterpart in the single-process reference.
+ * ------------------------------------------------------------------------------------------------- */
+int gs_db_create_part(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,
+                      const int32_t *value_idx, int32_t n_values, const int32_t *parent_vi, int n_parts, int part);
+int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
+                    uint64_t *keys);
+int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32_t *nodes);
+int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int64_t first_read_no,
+                    const uint64_t *pos_off, const int32_t *nodes, int32_t *class_vi, uint8_t *flags);
+
 /* Kraken-style per-read segments (writeKrakenStyleOut; FastqKMerMatcher.printKrakenStyleOut, :597-611): the maximal
  * runs of equal tax node over the k-mer positions of each read, in read order.  gs_match_segments probes the batch,
  * fills seg_off[n_reads+1] (host array, exclusive prefix of the per-read segment counts) and keeps the segments on

@@ -76,3 +76,42 @@ def test_shard_bounds_cover_everything():
             spans = [shard_bounds(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def _route_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genestrip_amd import distributed as gd
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 5000 + 37 * rank
+    keys = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, generator=g)
+    keys[torch.randint(0, n, (n // 50,), generator=g)] = gd.KEY_INVALID
+    idx, send, counts = gd.plan_routing(keys, world)
+    recv, rc = gd.exchange_all_to_all(send, counts)
+    # every key this rank received is one it owns
+    assert bool((((recv >> gd.OWNER_SHIFT) % world) == rank).all())
+    probe = (recv % 1000).to(torch.int32)  # stand-in for gs_match_probe_keys on the owner
+    back, _ = gd.exchange_all_to_all(probe, rc)
+    nodes = gd.scatter_nodes(back, idx, n)
+    want = torch.where(keys == gd.KEY_INVALID, torch.tensor(gd.NODE_INVALID, dtype=torch.int64), keys % 1000).to(torch.int32)
+    assert torch.equal(nodes, want)
+    np.save(os.path.join(out_dir, f"route{rank}.npy"), np.array([int(recv.numel())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_db_partitioned_routing_round_trip_two_ranks(tmp_path):
+    """keys -> owner ranks -> (stand-in probe) -> back to the home rank in the original order, over gloo"""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_route_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = sum(int(np.load(os.path.join(str(tmp_path), f"route{r}.npy"))[0]) for r in range(2))
+    assert 9800 < got <= 5000 + 5037
+
+
+def test_position_offsets():
+    from genestrip_amd import distributed as gd
+    off = torch.tensor([0, 10, 40, 41, 200], dtype=torch.int64)
+    assert gd.position_offsets(off, 31).tolist() == [0, 0, 0, 0, 129]
+    assert gd.position_offsets(off, 2).tolist() == [0, 9, 38, 38, 196]

@@ -1,0 +1,152 @@
+"""DB-partitioned match (SURVEY 8e / BASELINE configs[4]) on one GPU: the split pipeline
+encode -> (all-to-all) -> probe on the owner -> (all-to-all) -> reduce must give the oracle's table.
+The W-rank exchange is emulated in-process with W partitioned stores on the same GPU, using the same routing
+helpers the torch.distributed path uses; the collective path itself is exercised with a 1-rank RCCL group."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import genestrip_amd as ga
+from genestrip_amd import distributed as gd
+from genestrip_amd import synth
+from oracle import gs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ADD = [0, 1, 2, 3, 4, 5, 7, 8]  # additive columns (unique counts of the partitions are disjoint)
+
+
+@pytest.fixture(scope="module")
+def sdb():
+    return synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=20000, seed=11)
+
+
+def _reads(sdb, n):
+    seq, off = synth.reads_host(sdb.genomes, n, read_len=150, seed=61)
+    rng = np.random.default_rng(2)
+    seq = seq.copy()
+    for r in rng.choice(n, n // 40, replace=False):
+        seq[int(off[r]) + int(rng.integers(0, 150))] = ord("N")
+    # ragged tail: short, long and empty reads
+    extra = [b"", b"ACGT", bytes(sdb.genomes[1][:31]), bytes(sdb.genomes[2][100:900]), bytes(sdb.genomes[0][:40]) + b"N" * 3]
+    eseq, eoff = orc.pack_reads(extra)
+    seq = np.concatenate([seq, eseq])
+    off = np.concatenate([off, off[-1] + eoff[1:]])
+    return seq, off
+
+
+def _oracle(sdb, seq, off, **cfg):
+    run = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi), **cfg)
+    cv, fl = run.submit(seq, off)
+    t, _ = run.finish()
+    return t, cv, fl
+
+
+def _merge_tables(tables):
+    out = np.zeros_like(tables[0])
+    for c in ADD:
+        out[:, c] = sum(t[:, c] for t in tables)
+    for v in range(out.shape[0]):
+        best = (0, -1)
+        for t in tables:
+            if t[v, 6] > best[0] or (t[v, 6] == best[0] and t[v, 6] > 0 and t[v, 9] < best[1]):
+                best = (int(t[v, 6]), int(t[v, 9]))
+        out[v, 6], out[v, 9] = best
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_partitioned_pipeline_emulated(sdb, world):
+    seq, off = _reads(sdb, 6000)
+    n = len(off) - 1
+    want, wcv, wfl = _oracle(sdb, seq, off)
+    dev = torch.device("cuda")
+    stores = [ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=world, part=p)
+              for p in range(world)]
+    assert sum(s.info.n_stored for s in stores) == ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values,
+                                                                      sdb.parent_vi).info.n_stored
+    ms = [ga.FastqKMerMatcher(s) for s in stores]
+    # read shards per rank (global read numbers kept)
+    bounds = [gd.shard_bounds(n, r, world) for r in range(world)]
+    shard = []
+    for lo, hi in bounds:
+        dseq = torch.from_numpy(seq[int(off[lo]):int(off[hi])].copy()).to(dev) if hi > lo else torch.zeros(1, dtype=torch.uint8, device=dev)
+        doff = torch.from_numpy((off[lo:hi + 1] - off[lo]).astype(np.int64)).to(dev)
+        shard.append((dseq, doff, hi - lo, lo))
+    plans = []
+    for r, (dseq, doff, nr, lo) in enumerate(shard):
+        pos_off = gd.position_offsets(doff, 31)
+        nk = int(pos_off[-1].item())
+        keys = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
+        ms[r].encode(dseq, doff, pos_off, keys, nr)
+        ms[r].sync()
+        idx, send, counts = gd.plan_routing(keys[:nk], world)
+        plans.append((pos_off, nk, idx, send, counts.cpu().numpy()))
+    # all-to-all #1: keys to their owners
+    starts = [np.concatenate([[0], np.cumsum(p[4])]) for p in plans]
+    node_back = [[None] * world for _ in range(world)]
+    for j in range(world):
+        parts = [plans[i][3][starts[i][j]:starts[i][j + 1]] for i in range(world)]
+        recv = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        nodes = torch.empty(max(recv.numel(), 1), dtype=torch.int32, device=dev)
+        ms[j].probe_keys(recv, nodes, recv.numel())
+        ms[j].sync()
+        o = 0
+        for i in range(world):  # all-to-all #2: nodes back to the home ranks
+            c = int(plans[i][4][j])
+            node_back[i][j] = nodes[o:o + c]
+            o += c
+    tables, cvs, fls = [], [], []
+    for r, (dseq, doff, nr, lo) in enumerate(shard):
+        pos_off, nk, idx, _, _ = plans[r]
+        nodes = gd.scatter_nodes(torch.cat(node_back[r]), idx, max(nk, 1))
+        cv = torch.full((max(nr, 1),), -1, dtype=torch.int32, device=dev)
+        fl = torch.zeros(max(nr, 1), dtype=torch.uint8, device=dev)
+        ms[r].reduce(dseq, doff, pos_off, nodes, nr, first_read_no=lo, class_vi=cv, flags=fl)
+        t, _ = ms[r].finish()
+        tables.append(t)
+        cvs.append(cv[:nr].cpu().numpy())
+        fls.append(fl[:nr].cpu().numpy())
+    got = _merge_tables(tables)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:8]
+    assert np.array_equal(np.concatenate(cvs), wcv) and np.array_equal(np.concatenate(fls), wfl)
+    for m in ms:
+        m.close()
+    for s in stores:
+        s.close()
+
+
+def test_partitioned_collective_path_single_rank(sdb):
+    """the torch.distributed code path (all_to_all_single, all_reduce over RCCL) with a 1-rank group"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        seq, off = _reads(sdb, 3000)
+        n = len(off) - 1
+        want, wcv, wfl = _oracle(sdb, seq, off)
+        store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=1, part=0)
+        m = ga.FastqKMerMatcher(store)
+        dseq = torch.from_numpy(seq).to(dev)
+        doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+        cv = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+        gd.partitioned_match_batch(m, 31, dseq, doff, n, 0, class_vi=cv, flags=fl)
+        st = m.device_state()
+
+        class V:
+            def __init__(self, ptr, cnt, t):
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (cnt,), "typestr": t, "version": 2}
+        sums = torch.as_tensor(V(st["sums"], sdb.n_values * ga.N_SUMS, "<i8"), device=dev)
+        mx = torch.as_tensor(V(st["max_keys"], sdb.n_values, "<i8"), device=dev)
+        ds = torch.as_tensor(V(st["dsums"], sdb.n_values * ga.N_DCOLS, "<f8"), device=dev)
+        table, _ = gd.partitioned_finish(m, sums, mx, ds)
+        assert np.array_equal(table, want)
+        assert np.array_equal(cv.cpu().numpy(), wcv) and np.array_equal(fl.cpu().numpy(), wfl)
+        m.close()
+        store.close()
+    finally:
+        dist.destroy_process_group()
