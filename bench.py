@@ -148,6 +148,16 @@ def main():
     gbps = total_bases / elapsed / 1e9
     achieved = n * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9  # GB/s, algorithmic bytes of one launch / its duration
 
+    # measured memory-side traffic of one launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (profiles/r01_match_pmc_summary.csv, KiB units; 64-byte random requests are counted exactly).  Only valid for
+    # the default workload the profile was taken on.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_match_pmc_summary.csv")
+    if n == 10_000_000 and not partitioned and os.path.exists(pmc):
+        vals = dict(l.strip().split(",") for l in open(pmc) if l[0] not in "#c" and "," in l)
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            traffic = int((float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024)
+
     out = {
         "metric": "Gbp/s classified (match goal), k=31, 150bp reads; bit-exact CSV counts",
         "value": round(gbps, 3), "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,7 +170,9 @@ def main():
                    "parallelism": ("DB-partitioned x%d, k-mers routed by all-to-all" % world) if partitioned
                    else ("read-sharded x%d, store replicated" % world)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_note": "bytes per launch through the fabric (rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, "
+                                     "profiles/r01_match_pmc_summary.csv); the 64 MiB table is Infinity-Cache resident",
                      "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": n * BYTES_PER_READ},
     }

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -53,7 +53,7 @@ class DbInfo(C.Structure):
 class _MatchCfg(C.Structure):
     _fields_ = [("classify", C.c_int32), ("count_unique", C.c_int32), ("max_paths", C.c_int32),
                 ("threshold", C.c_int32), ("max_read_tax_err", C.c_double), ("max_read_class_err", C.c_double),
-                ("profile", C.c_int32), ("reserved", C.c_int32)]
+                ("profile", C.c_int32), ("max_kmer_res_counts", C.c_int32)]
 
 
 def lib_path():
@@ -105,6 +105,7 @@ def lib():
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
+        "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
@@ -197,13 +198,14 @@ class MatchConfig:
     """the GSConfigKey values that parameterise matchRead (C/GSConfigKey.java:302-350)"""
 
     def __init__(self, classify=True, count_unique=True, max_paths=10, threshold=1, max_read_tax_err=-1.0,
-                 max_read_class_err=-1.0, profile=False):
+                 max_read_class_err=-1.0, profile=False, max_kmer_res_counts=0):
         self.classify, self.count_unique, self.max_paths, self.threshold = classify, count_unique, max_paths, threshold
         self.max_read_tax_err, self.max_read_class_err, self.profile = max_read_tax_err, max_read_class_err, profile
+        self.max_kmer_res_counts = max_kmer_res_counts
 
     def _c(self):
         return _MatchCfg(int(self.classify), int(self.count_unique), self.max_paths, self.threshold,
-                         self.max_read_tax_err, self.max_read_class_err, int(self.profile), 0)
+                         self.max_read_tax_err, self.max_read_class_err, int(self.profile), int(self.max_kmer_res_counts))
 
 
 class FastqKMerMatcher:
@@ -286,6 +288,13 @@ class FastqKMerMatcher:
         d = np.zeros((nv, N_DCOLS), dtype=np.float64)
         _check(lib().gs_match_finish(self.h, t.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p)))
         return t, d
+
+    def max_counts(self):
+        """(n_values + 1) x max_kmer_res_counts int16: largest per-k-mer hit counts per value index, last row = total"""
+        n = self.config.max_kmer_res_counts
+        out = np.zeros((self.store.n_values + 1, max(n, 1)), dtype=np.int16)
+        _check(lib().gs_match_max_counts(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def reset(self):
         _check(lib().gs_match_reset(self.h))

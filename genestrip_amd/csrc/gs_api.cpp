@@ -424,6 +424,7 @@ struct gs_run {
     int64_t *d_sums = nullptr;
     int64_t *d_max = nullptr;
     double *d_dsums = nullptr;
+    uint32_t *d_hit_counts = nullptr;  // per slot, only when cfg.max_kmer_res_counts > 0
     uint32_t *d_bitmap = nullptr;  // compact copy of the slots' seen bits (built on demand: finish / device_state)
     int64_t bitmap_words = 0;
     bool seen_dirty = false;    // some slot may carry a seen bit
@@ -459,6 +460,8 @@ static int run_clear(gs_run *run) {
     HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv, run->stream));
     HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS, run->stream));
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
+    if (run->d_hit_counts)
+        HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream));
     if (run->seen_dirty)
         HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream));
     run->seen_dirty = false;
@@ -478,6 +481,7 @@ static void run_free(gs_run *run) {
     hipFree(run->d_max);
     hipFree(run->d_dsums);
     hipFree(run->d_bitmap);
+    hipFree(run->d_hit_counts);
     hipFree(run->d_unique);
     hipFree(run->d_long_count);
     hipFree(run->d_long_list);
@@ -513,6 +517,8 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_dsums, sizeof(double) * nv * GS_N_DCOLS);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_bitmap, sizeof(uint32_t) * (size_t)run->bitmap_words);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
+    if (e == hipSuccess && cfg->max_kmer_res_counts > 0)
+        e = hipMalloc((void **)&run->d_hit_counts, sizeof(uint32_t) * (size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, sizeof(unsigned int));
     if (e != hipSuccess) {
         run_free(run);
@@ -596,6 +602,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.max_keys = run->d_max;
     P.dsums = run->d_dsums;
     P.bitmap = run->d_bitmap;
+    P.hit_counts = run->d_hit_counts;
     P.class_vi = d_class;
     P.flags = d_flags;
     P.long_count = run->d_long_count;
@@ -906,6 +913,41 @@ extern "C" int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *sta
     if (run->seg_total > 0) {
         HIP_TRY(hipMemcpy(codes, run->d_seg_code, sizeof(int32_t) * (size_t)run->seg_total, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(starts, run->d_seg_start, sizeof(int32_t) * (size_t)run->seg_total, hipMemcpyDeviceToHost));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_match_max_counts(gs_run *run, int16_t *out) {
+    if (!run || !out) return fail(GS_E_INVALID, "NULL argument");
+    const int N = run->cfg.max_kmer_res_counts;
+    if (N <= 0 || !run->d_hit_counts) return fail(GS_E_STATE, "the run was not begun with max_kmer_res_counts > 0");
+    if (!run->cfg.count_unique) return fail(GS_E_STATE, "max k-mer counts need count_unique");
+    HIP_TRY(hipSetDevice(run->db->device));
+    const size_t n_slots = (size_t)run->db->info.n_buckets * GS_SLOTS_PER_BUCKET;
+    const size_t nv = (size_t)run->db->info.n_values;
+    std::vector<u64> table(n_slots);
+    std::vector<uint32_t> counts(n_slots);
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    HIP_TRY(hipMemcpy(table.data(), run->db->d_table, n_slots * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts.data(), run->d_hit_counts, n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::fill(out, out + (nv + 1) * (size_t)N, (int16_t)0);
+    const u64 vmask = ((u64)1 << run->db->dev.vbits) - 1;
+    auto update = [N](int16_t count, int16_t *target) {  // updateMaxCounts (:198-209)
+        for (int j = 0; j < N; j++)
+            if (count > target[j]) {
+                for (int kk = N - 1; kk > j; kk--) target[kk] = target[kk - 1];
+                target[j] = count;
+                return;
+            }
+    };
+    for (size_t i = 0; i < n_slots; i++) {
+        const u64 s = table[i];
+        if (!(s & 1ULL)) continue;  // bitVector.get(i)
+        const int vi = (int)((s >> 1) & vmask) - 1;
+        if (vi < 0) continue;
+        const int16_t c = (int16_t)(uint16_t)(counts[i] & 0xffffu);  // Java short arithmetic wraps
+        update(c, out + (size_t)vi * N);
+        update(c, out + nv * (size_t)N);
     }
     return GS_OK;
 }

@@ -656,7 +656,17 @@ extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, 
         "mean error;kmer error std. dev.;mean class error;class error std. dev.;contig len std. dev.;";
     for (int t = 0; t < 5; t++) o += std::string("norm. ") + vname[t] + ";";
     for (int t = 0; t < 5; t++) o += std::string("acc. ") + vname[t] + ";acc. norm. " + vname[t] + ";";
-    o += "max contig desc.;acc. mean error;acc. error std. dev.;acc. mean class error;acc. class error std. dev.;\n";
+    o += "max contig desc.;acc. mean error;acc. error std. dev.;acc. mean class error;acc. class error std. dev.;";
+    const int nmc = (tax->max_kmer_counts && tax->max_kmer_res_counts > 0) ? tax->max_kmer_res_counts : 0;
+    if (nmc) o += "max kmer counts;";  // ResultReporter.java:213, :262-271
+    o.push_back('\n');
+    auto max_counts = [&](int row) {
+        for (int i = 0; i < nmc; i++) {
+            if (i > 0) o.push_back(';');
+            append_int(o, tax->max_kmer_counts[(size_t)row * (size_t)nmc + (size_t)i]);
+        }
+        if (nmc) o.push_back(';');
+    };
     auto dbl = [&](double v, bool total_row, bool always = false) {  // ResultReporter.java:249-253
         if (!std::isnan(v) && !std::isinf(v) && (!total_row || always)) o += java_double(v);
         o.push_back(';');
@@ -682,6 +692,7 @@ extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, 
     for (int t = 0; t < 10; t++) o.push_back(';');
     o.push_back(';');
     for (int j = 0; j < 4; j++) dbl(0, true);
+    max_counts(nv);
     o.push_back('\n');
     int p = 1;
     for (int v : rows) {
@@ -751,6 +762,8 @@ extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, 
         dbl(std::sqrt((aes2 - aes * aes / areads) / (areads - 1)), false);
         dbl(acs / areads, false);
         dbl(std::sqrt((acs2 - acs * acs / areads) / (areads - 1)), false);
+        if (own) max_counts(v);
+        else if (nmc) o.push_back(';');  // maxKMerCounts == null for rows added as missing ancestors
         o.push_back('\n');
     }
     fwrite(o.data(), 1, o.size(), f);

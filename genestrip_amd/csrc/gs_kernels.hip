@@ -357,6 +357,11 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 for (int s = 0; s < 2; s++)
                     if (!FROM_NODES && fresh[s]) atomicOr(const_cast<u64 *>(db.table) + (uint32_t)slot[s], 1ULL);
             }
+            if (!FROM_NODES && P.hit_counts != nullptr) {  // maxKMerResCounts > 0: per-k-mer hit counters
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+                    if (node[s] >= 0) atomicAdd(P.hit_counts + (uint32_t)slot[s], 1u);
+            }
 
             // ---- 4b. contig events
             if ((hit0 | hit1) != 0 || carry_last >= 0) {

@@ -20,6 +20,7 @@ struct GsMatchParams {
     int64_t *max_keys;     // [n_values]
     double *dsums;         // [n_values][GS_N_DCOLS]
     uint32_t *bitmap;      // one bit per table slot
+    uint32_t *hit_counts;  // per table slot, or nullptr (maxKMerResCounts == 0)
     int32_t *class_vi;     // optional per read
     uint8_t *flags;        // optional per read
     unsigned int *long_count;  // reads with more than 128 k-mer positions are queued for the long-read kernel

@@ -29,7 +29,8 @@ class Totals(C.Structure):
 class _TaxInfo(C.Structure):
     _fields_ = [("n_values", C.c_int32), ("parent_vi", C.c_void_p), ("position", C.c_void_p),
                 ("taxids", C.POINTER(C.c_char_p)), ("names", C.POINTER(C.c_char_p)), ("ranks", C.POINTER(C.c_char_p)),
-                ("db_kmers", C.c_void_p), ("db_kmers_total", C.c_int64), ("max_contig_desc", C.POINTER(C.c_char_p))]
+                ("db_kmers", C.c_void_p), ("db_kmers_total", C.c_int64), ("max_contig_desc", C.POINTER(C.c_char_p)),
+                ("max_kmer_counts", C.c_void_p), ("max_kmer_res_counts", C.c_int32)]
 
 
 def lib():
@@ -142,14 +143,16 @@ def filter_files(bloom, k, paths, min_pos_count=1, positive_ratio=0.2, filtered_
 
 
 def write_csv(path, parent_vi, taxids, db_kmers, db_kmers_total, table, dtable, totals, names=None, ranks=None,
-              position=None, max_contig_desc=None):
+              position=None, max_contig_desc=None, max_kmer_counts=None):
     """MatchingResult.completeResults + ResultReporter.printMatchResult"""
     pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
     dk = np.ascontiguousarray(db_kmers, dtype=np.int64)
     pos = None if position is None else np.ascontiguousarray(position, dtype=np.int32)
     keep = [_cstr_array(taxids), _cstr_array(names), _cstr_array(ranks), _cstr_array(max_contig_desc)]
+    mc = None if max_kmer_counts is None else np.ascontiguousarray(max_kmer_counts, dtype=np.int16)
     info = _TaxInfo(len(pv), pv.ctypes.data_as(C.c_void_p), None if pos is None else pos.ctypes.data_as(C.c_void_p),
-                    keep[0], keep[1], keep[2], dk.ctypes.data_as(C.c_void_p), db_kmers_total, keep[3])
+                    keep[0], keep[1], keep[2], dk.ctypes.data_as(C.c_void_p), db_kmers_total, keep[3],
+                    None if mc is None else mc.ctypes.data_as(C.c_void_p), 0 if mc is None else mc.shape[1])
     t = np.ascontiguousarray(table, dtype=np.int64)
     d = np.ascontiguousarray(dtable, dtype=np.float64)
     _check(lib().gs_host_write_csv(str(path).encode(), C.byref(info), t.ctypes.data_as(C.c_void_p),

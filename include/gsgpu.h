@@ -104,7 +104,7 @@ typedef struct {
     double max_read_tax_err;    /* maxReadTaxErrorCount (:328), -1 = off                         */
     double max_read_class_err;  /* maxReadClassErrorCount (:337), -1 = off                       */
     int32_t profile;            /* != 0: record HIP events around the kernels of each submit     */
-    int32_t reserved;
+    int32_t max_kmer_res_counts; /* maxKMerResCounts (:344): > 0 keeps per-k-mer hit counters for gs_match_max_counts */
 } gs_match_cfg;
 
 /* integer result table: one row per value index (CountsPerTaxid fields, C/match/CountsPerTaxid.java:127-159) */
@@ -145,6 +145,13 @@ int gs_match_sync(gs_run *run);
 int gs_match_finish(gs_run *run, int64_t *table, double *dtable);
 int gs_match_reset(gs_run *run); /* same matcher, next key: clears stats + unique bitmap */
 int gs_match_destroy(gs_run *run);
+
+/* maxKMerResCounts > 0 (experimental CSV column "max kmer counts"; KMerUniqueCounterBits.getMaxCountsCounts,
+ * C/store/KMerUniqueCounterBits.java:173-211): the `max_kmer_res_counts` largest per-k-mer hit counts of every value
+ * index (rows 0..n_values-1) and over all values (row n_values), descending, zero padded; counts are Java shorts
+ * (they wrap at 2^15 exactly like `++countsVector.shorts[i]`).  out: (n_values + 1) x max_kmer_res_counts int16, host.
+ * Not supported in DB-partitioned mode. */
+int gs_match_max_counts(gs_run *run, int16_t *out);
 
 /* Multi-GPU (read-sharded) merge hooks: raw device pointers of the run's accumulators so that the host
  * can reduce them over RCCL before gs_match_finish (sum over ranks for `sums`, max for `max_keys`,

@@ -82,6 +82,8 @@ typedef struct {
     const int64_t *db_kmers;       /* k-mers stored per value index (Database.getStats)                 */
     int64_t db_kmers_total;
     const char *const *max_contig_desc; /* per value index, may be NULL                                 */
+    const int16_t *max_kmer_counts;     /* gs_match_max_counts output ((n_values+1) x max_kmer_res_counts) or NULL */
+    int32_t max_kmer_res_counts;        /* > 0 adds the experimental "max kmer counts" column (pos 2001)          */
 } gs_host_tax_info;
 
 int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, const int64_t *table, const double *dtable,

@@ -38,7 +38,7 @@ JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db
 
 JNIEXPORT jlong JNICALL JNAME(matchBegin)(JNIEnv *env, jclass c, jlong db, jboolean classify, jboolean countUnique,
                                           jint maxPaths, jint threshold, jdouble taxErr, jdouble classErr) {
-    gs_match_cfg cfg = {classify ? 1 : 0, countUnique ? 1 : 0, maxPaths, threshold, taxErr, classErr, 0, 0};
+    gs_match_cfg cfg = {classify ? 1 : 0, countUnique ? 1 : 0, maxPaths, threshold, taxErr, classErr, 0, 0 /* maxKMerResCounts */};
     gs_run *run = NULL;
     int rc = gs_match_begin(&run, (gs_db *)(intptr_t)db, &cfg);
     if (rc) throw_gs(env, rc);

@@ -418,6 +418,7 @@ struct orc_run {
     int64_t *table;
     double *dtable;
     uint64_t *unique_bits; /* KMerUniqueCounterBits bit vector, indexed by store rank */
+    int16_t *hit_counts;   /* countsVector (LargeShortVector), indexed by store rank; NULL unless max_kmer_res_counts > 0 */
     int n_consumers;
     consumer_t *cons;
 };
@@ -457,6 +458,7 @@ orc_run *orc_match_begin(const orc_db *db, const orc_match_cfg *cfg) {
     run->dtable = (double *)calloc(nv * ORC_N_DCOLS, sizeof(double));
     for (size_t i = 0; i < nv; i++) run->table[i * ORC_N_COLS + ORC_C_MAX_CONTIG_READ_NO] = -1;
     run->unique_bits = (uint64_t *)calloc((size_t)((db->n + 63) / 64 + 1), sizeof(uint64_t));
+    if (cfg->max_kmer_res_counts > 0) run->hit_counts = (int16_t *)calloc((size_t)(db->n > 0 ? db->n : 1), sizeof(int16_t));
     return run;
 }
 
@@ -467,6 +469,7 @@ void orc_match_destroy(orc_run *run) {
     free(run->table);
     free(run->dtable);
     free(run->unique_bits);
+    free(run->hit_counts);
     free(run);
 }
 
@@ -598,6 +601,10 @@ static int match_read(orc_run *run, consumer_t *c, const uint8_t *read, int read
             if (cfg->count_unique) { /* KMerUniqueCounterBits.putInlined :117-143 */
 #pragma omp atomic
                 run->unique_bits[pos >> 6] |= 1ULL << (pos & 63);
+                if (run->hit_counts) { /* ++countsVector.shorts[index]: Java short arithmetic wraps (:134-140) */
+#pragma omp critical(orc_hit_counts)
+                    run->hit_counts[pos] = (int16_t)(uint16_t)((uint16_t)run->hit_counts[pos] + 1u);
+                }
             }
         } else
             stats = NULL;
@@ -695,6 +702,30 @@ int orc_match_finish(orc_run *run, int64_t *table, double *dtable) {
             if ((run->unique_bits[i >> 6] >> (i & 63)) & 1ULL) run->table[(size_t)db->vidx[i] * ORC_N_COLS + ORC_C_UNIQUE_KMERS]++;
     memcpy(table, run->table, sizeof(int64_t) * nv * ORC_N_COLS);
     if (dtable) memcpy(dtable, run->dtable, sizeof(double) * nv * ORC_N_DCOLS);
+    return 0;
+}
+
+static void update_max_counts(int16_t count, int16_t *target, int n) { /* :198-209 */
+    for (int j = 0; j < n; j++)
+        if (count > target[j]) {
+            for (int k = n - 1; k > j; k--) target[k] = target[k - 1];
+            target[j] = count;
+            return;
+        }
+}
+
+int orc_match_max_counts(orc_run *run, int16_t *out) {
+    const orc_db *db = run->db;
+    const int n = run->cfg.max_kmer_res_counts;
+    if (n <= 0 || !run->hit_counts) return -1;
+    size_t nv = (size_t)db->n_values;
+    memset(out, 0, sizeof(int16_t) * (nv + 1) * (size_t)n);
+    for (int64_t i = 0; i < db->n; i++) {
+        if (!((run->unique_bits[i >> 6] >> (i & 63)) & 1ULL)) continue;
+        if (db->parent[db->vidx[i]] == -2) continue; /* taxid == null */
+        update_max_counts(run->hit_counts[i], out + (size_t)db->vidx[i] * n, n);
+        update_max_counts(run->hit_counts[i], out + nv * (size_t)n, n);
+    }
     return 0;
 }
 

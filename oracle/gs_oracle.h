@@ -89,6 +89,8 @@ typedef struct {
     int32_t threshold;           /* minKMersForClass (default 1)                      */
     double max_read_tax_err;     /* maxReadTaxErrorCount (default -1)                 */
     double max_read_class_err;   /* maxReadClassErrorCount (default -1)               */
+    int32_t max_kmer_res_counts; /* maxKMerResCounts (default 0): per-k-mer hit counters */
+    int32_t pad;
 } orc_match_cfg;
 
 /* integer table columns, one row per value index */
@@ -115,6 +117,8 @@ int orc_match_submit(orc_run *run, const uint8_t *seq, const uint64_t *offsets, 
 /* table: n_values x ORC_N_COLS int64 ; dtable: n_values x ORC_N_DCOLS double (may be NULL) */
 int orc_match_finish(orc_run *run, int64_t *table, double *dtable);
 void orc_match_destroy(orc_run *run);
+/* KMerUniqueCounterBits.getMaxCountsCounts (:173-211): (n_values + 1) x max_kmer_res_counts shorts, last row = total */
+int orc_match_max_counts(orc_run *run, int16_t *out);
 /* raw accumulator state for the multi-rank merge tests: table n_values x ORC_N_COLS, bitmap one bit per store rank */
 int64_t orc_match_bitmap_words(const orc_run *run);
 int orc_match_export(orc_run *run, int64_t *table, uint64_t *bitmap);

@@ -22,7 +22,8 @@ BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
 
 class MatchCfg(C.Structure):
     _fields_ = [("classify", C.c_int32), ("count_unique", C.c_int32), ("max_paths", C.c_int32),
-                ("threshold", C.c_int32), ("max_read_tax_err", C.c_double), ("max_read_class_err", C.c_double)]
+                ("threshold", C.c_int32), ("max_read_tax_err", C.c_double), ("max_read_class_err", C.c_double),
+                ("max_kmer_res_counts", C.c_int32), ("pad", C.c_int32)]
 
 
 class _Reads(C.Structure):
@@ -66,7 +67,7 @@ def lib():
         "orc_match_submit": (C.c_int, [vp, vp, vp, i64, i64, vp, vp, C.c_int]),
         "orc_match_finish": (C.c_int, [vp, vp, vp]), "orc_match_destroy": (None, [vp]),
         "orc_match_bitmap_words": (i64, [vp]), "orc_match_export": (C.c_int, [vp, vp, vp]),
-        "orc_match_import": (C.c_int, [vp, vp, vp]),
+        "orc_match_import": (C.c_int, [vp, vp, vp]), "orc_match_max_counts": (C.c_int, [vp, vp]),
         "orc_match_segments": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int]),
         "orc_parse_fastq": (C.POINTER(_Reads), [vp, C.c_size_t, C.c_int, C.c_int]),
         "orc_reads_free": (None, [C.POINTER(_Reads)]),
@@ -235,10 +236,10 @@ class DB:
 
 class MatchRun:
     def __init__(self, db, classify=True, count_unique=True, max_paths=10, threshold=1,
-                 max_read_tax_err=-1.0, max_read_class_err=-1.0):
+                 max_read_tax_err=-1.0, max_read_class_err=-1.0, max_kmer_res_counts=0):
         self.db = db
         self.cfg = MatchCfg(int(classify), int(count_unique), max_paths, threshold, max_read_tax_err,
-                            max_read_class_err)
+                            max_read_class_err, max_kmer_res_counts, 0)
         self.h = lib().orc_match_begin(db.h, C.byref(self.cfg))
 
     def close(self):
@@ -267,6 +268,12 @@ class MatchRun:
         d = np.zeros((self.db.n_values, N_DCOLS), dtype=np.float64)
         lib().orc_match_finish(self.h, _p(t), _p(d))
         return t, d
+
+    def max_counts(self):
+        n = self.cfg.max_kmer_res_counts
+        out = np.zeros((self.db.n_values + 1, max(n, 1)), dtype=np.int16)
+        lib().orc_match_max_counts(self.h, _p(out))
+        return out
 
     def export_state(self):
         """(table int64 [nv, N_COLS], bitmap uint64[]) raw accumulators (multi-rank merge tests)"""

@@ -22,6 +22,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.gs_strerror(-6).decode() == "no usable gfx950 device"
 
 
+def test_host_layer_exports_every_declared_symbol():
+    from genestrip_amd import host
+    L = host.lib()
+    header = open(os.path.join(ROOT, "include", "gshost.h")).read()
+    declared = set(re.findall(r"\b(gs_(?:fastq|host)_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(L, name), name
+
+
 def test_header_enums_match_binding():
     header = open(os.path.join(ROOT, "include", "gsgpu.h")).read()
     cols = re.search(r"enum \{\s*GS_C_READS = 0,(.*?)GS_N_COLS", header, re.S).group(1)

@@ -253,3 +253,30 @@ def test_full_size_properties():
     assert whole[:, 0].sum() <= n and whole[:, 7].sum() >= whole[:, 0].sum()
     m.close()
     store.close()
+
+
+def test_max_kmer_res_counts(sdb):
+    """maxKMerResCounts > 0: the largest per-k-mer hit counts per taxid and in total (experimental CSV column)"""
+    seq, off = synth.reads_host(sdb.genomes, 12000, read_len=150, seed=77)
+    # repeat one read many times so that some counters exceed a Java short and wrap
+    hot = seq[:150].copy()
+    seq = np.concatenate([seq, np.tile(hot, 40000)])
+    off = np.concatenate([off, off[-1] + 150 * np.arange(1, 40001, dtype=np.uint64)])
+    o = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi), max_kmer_res_counts=5)
+    o.submit(seq, off, threads=4)
+    ot, _ = o.finish()
+    want = o.max_counts()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(max_kmer_res_counts=5))
+    m.submit(seq, off, 0, n_reads=len(off) - 1)
+    gt, _ = m.finish()
+    got = m.max_counts()
+    assert np.array_equal(ot, gt)
+    assert np.array_equal(want, got), (want[-1], got[-1])
+    assert got[-1, 0] > 0
+    m.close()
+    m2 = ga.FastqKMerMatcher(store)
+    with pytest.raises(ga.GsError):
+        m2.max_counts()
+    m2.close()
+    store.close()

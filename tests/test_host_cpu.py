@@ -144,3 +144,12 @@ def test_csv_complete_results(tmp_path):
     assert s0[col["norm. kmers"]] == host.java_double(310 / 500)
     assert genus[col["acc. norm. kmers"]] == host.java_double(12 / 50 + 310 / 500 + 95 / 400)
     assert root[col["average contig length"]] == "" and root[col["mean error"]] == ""  # NaN -> blank
+    # experimental "max kmer counts" column (maxKMerResCounts > 0): N values per row, TOTAL row = overall
+    mc = np.zeros((7, 3), dtype=np.int16)
+    mc[2] = [9, 4, 1]
+    mc[6] = [9, 7, 4]
+    out2 = tmp_path / "r2.csv"
+    host.write_csv(out2, parent, taxids, dbk, 1025, t, d, tot, names=names, ranks=ranks, max_kmer_counts=mc)
+    l2 = out2.read_text().split("\n")
+    assert l2[0].endswith("acc. class error std. dev.;max kmer counts;")
+    assert l2[1].endswith(";9;7;4;") and l2[4].endswith(";9;4;1;") and l2[2].endswith(";;")
