@@ -74,15 +74,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (genestrip_amd has no CPU fallback)")
+    # GS_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: several ranks share GPU 0 and the merge runs over
+    # gloo on host copies, so the multi-rank control flow (barriers, collectives, rank-0-only legs) can be exercised
+    # without a multi-GPU node.  Its numbers mean nothing; the real run uses RCCL ("nccl"), one GPU per rank.
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    rehearsal = backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the small control tensors of the collectives live
     partitioned = args.mode == "partitioned"
     force_merge = os.environ.get("GS_BENCH_FORCE_MERGE", "") == "1" or partitioned
     use_dist = world > 1 or force_merge
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- inputs: store replica per GPU, this rank's slice of the read stream generated directly in HBM
     db = synth.SynthDB(k=K)
@@ -113,8 +124,15 @@ def main():
         m.submit(dseq, doff, first, n_reads=n_reads)
         if use_dist:
             m.device_state()  # syncs the library's stream and refreshes the compact unique bitmap (same pointers)
-            merge_run_state(t_sums, t_max, t_dsum, t_bits, force=force_merge,
-                            or_parts=lambda g, w: m.or_bitmap(g.data_ptr(), w))
+            if rehearsal:  # gloo: merge host copies, write them back, mark the bitmap as merged
+                hs, hm, hd, hb = t_sums.cpu(), t_max.cpu(), t_dsum.cpu(), t_bits.cpu()
+                merge_run_state(hs, hm, hd, hb, force=force_merge)
+                t_sums.copy_(hs), t_max.copy_(hm), t_dsum.copy_(hd), t_bits.copy_(hb)
+                torch.cuda.synchronize()
+                m.or_bitmap(t_bits.data_ptr(), 1)
+            else:
+                merge_run_state(t_sums, t_max, t_dsum, t_bits, force=force_merge,
+                                or_parts=lambda g, w: m.or_bitmap(g.data_ptr(), w))
         return m.finish()
 
     def barrier():
@@ -134,7 +152,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches1, ms1 = m.kernel_time()
     if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     n_launch = max(1, launches1 - launches0)
@@ -181,7 +199,7 @@ def main():
     # N > 1: every rank must hold the same merged table, and rank 0 re-checks its own slice against the oracle.
     nchk = min(args.check_reads, n)
     if use_dist and world > 1:
-        digest = torch.tensor([int(np.asarray(table, dtype=np.int64).sum() % (1 << 62))], dtype=torch.int64, device=dev)
+        digest = torch.tensor([int(np.asarray(table, dtype=np.int64).sum() % (1 << 62))], dtype=torch.int64, device=cdev)
         lo, hi = digest.clone(), digest.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -198,6 +216,11 @@ def main():
         otable, _ = orun.finish()
         if partitioned and world > 1:
             gtable = otable  # a local re-check would need the other ranks' partitions; the digest check above covers it
+        elif world > 1:
+            # rank 0 alone re-checks its own slice: no collectives here (the other ranks are already at the barrier)
+            m.reset()
+            m.submit(dseq, doff, first, n_reads=nchk)
+            gtable, _ = m.finish()
         else:
             gtable, _ = step(nchk)
         par = out.setdefault("parity", {})
