@@ -31,7 +31,8 @@ ABI_SYMBOLS = (
     "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
+    "gs_unroute_nodes",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -105,6 +106,7 @@ def lib():
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
+        "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
@@ -250,6 +252,17 @@ class FastqKMerMatcher:
 
     def probe_keys(self, keys, nodes, n_keys):
         _check(lib().gs_match_probe_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, C.c_void_p(nodes.data_ptr())))
+
+    def route_keys(self, keys, n_keys, n_parts, send_keys, idx):
+        """device counting sort of the valid keys by owner rank; returns the per-owner counts (python list)"""
+        counts = (C.c_int64 * n_parts)()
+        _check(lib().gs_route_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, n_parts, C.c_void_p(send_keys.data_ptr()),
+                                   C.c_void_p(idx.data_ptr()), counts))
+        return list(counts)
+
+    def unroute_nodes(self, idx, back, n_routed, nodes, n_keys):
+        _check(lib().gs_unroute_nodes(self.h, C.c_void_p(idx.data_ptr()), C.c_void_p(back.data_ptr()), n_routed,
+                                      C.c_void_p(nodes.data_ptr()), n_keys))
 
     def reduce(self, seq, offsets, pos_off, nodes, n_reads, first_read_no=0, class_vi=None, flags=None):
         _check(lib().gs_match_reduce(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,

@@ -818,6 +818,55 @@ extern "C" int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *
     return launch_batch(run, seq, offsets, n_reads, first_read_no, class_vi, flags, nodes, pos_off);
 }
 
+extern "C" hipError_t gs_launch_route_count(const u64 *keys, int64_t n, int n_parts, u64 *counts, hipStream_t stream);
+extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_parts, u64 *cursors, u64 *send_keys,
+                                               uint32_t *idx, hipStream_t stream);
+extern "C" hipError_t gs_launch_unroute(const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
+                                         int64_t n_keys, hipStream_t stream);
+
+// groups the valid keys by owner rank (counting sort on the device); counts[n_parts] is a HOST array
+extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int n_parts, uint64_t *send_keys,
+                             uint32_t *idx, int64_t *counts) {
+    if (!run || !counts || n_parts < 1 || n_parts > 64 || (n_keys > 0 && (!keys || !send_keys || !idx)))
+        return fail(GS_E_INVALID, "bad argument");
+    if (n_keys >= ((int64_t)1 << 32)) return fail(GS_E_INVALID, "more than 2^32-1 keys in one batch");
+    HIP_TRY(hipSetDevice(run->db->device));
+    for (int i = 0; i < n_parts; i++) counts[i] = 0;
+    if (n_keys <= 0) return GS_OK;
+    u64 *d_counts = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_counts, sizeof(u64) * 64));
+    hipError_t e = hipMemsetAsync(d_counts, 0, sizeof(u64) * 64, run->stream);
+    if (e == hipSuccess) e = gs_launch_route_count((const u64 *)keys, n_keys, n_parts, d_counts, run->stream);
+    u64 h[64];
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_counts, sizeof(u64) * 64, hipMemcpyDeviceToHost, run->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(run->stream);
+    u64 cur[64], acc = 0;
+    for (int i = 0; i < 64; i++) {
+        cur[i] = acc;
+        if (i < n_parts) {
+            counts[i] = (int64_t)h[i];
+            acc += h[i];
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_counts, cur, sizeof(u64) * 64, hipMemcpyHostToDevice, run->stream);
+    if (e == hipSuccess)
+        e = gs_launch_route_scatter((const u64 *)keys, n_keys, n_parts, d_counts, (u64 *)send_keys, idx, run->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(run->stream);
+    hipFree(d_counts);
+    if (e != hipSuccess) return fail(GS_E_HIP, std::string("gs_route_keys: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+
+// inverse of gs_route_keys for the nodes that came back: nodes[idx[i]] = back[i]; unrouted positions read -2
+extern "C" int gs_unroute_nodes(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
+                                int64_t n_keys) {
+    if (!run || (n_keys > 0 && !nodes) || (n_routed > 0 && (!idx || !back))) return fail(GS_E_INVALID, "bad argument");
+    if (n_keys <= 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(gs_launch_unroute(idx, back, n_routed, nodes, n_keys, run->stream));
+    return GS_OK;
+}
+
 // ---- Kraken-style segments (two passes: count, host prefix sum, write)
 static int stage_batch(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
                        const uint8_t **d_seq, const uint64_t **d_off) {

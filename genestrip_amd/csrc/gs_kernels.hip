@@ -765,6 +765,87 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
     }
 }
 
+// ---- routing of the keys to their owner ranks (counting sort by owner; order inside an owner group is arbitrary,
+// idx remembers where every routed key came from)
+__global__ __launch_bounds__(256) void gs_route_count_kernel(const u64 *keys, int64_t n, int n_parts, u64 *counts) {
+    __shared__ unsigned int s_cnt[64];
+    const int lane = gs_lane();
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; base < n; base += stride) {
+        const int64_t i = base + lane;
+        const u64 h = i < n ? keys[i] : GS_KEY_INVALID;
+        const int owner = h != GS_KEY_INVALID ? (int)((h >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+        u64 todo = __ballot(owner >= 0);
+        while (todo) {  // one LDS atomic per wave and distinct owner
+            const int o = gs_readlane(owner, __builtin_ctzll(todo));
+            const u64 mine = __ballot(owner == o);
+            if (lane == 0) atomicAdd(&s_cnt[o], (unsigned int)__popcll(mine));
+            todo &= ~mine;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_parts && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (u64)s_cnt[threadIdx.x]);
+}
+
+// tiles of 4096 keys per workgroup: ranks inside the tile come from LDS counters (one LDS atomic per wave and owner),
+// then ONE global atomic per owner and tile reserves the output range -- a single hot cursor would serialise the chip
+#define GS_ROUTE_T 16
+__global__ __launch_bounds__(256) void gs_route_scatter_kernel(const u64 *keys, int64_t n, int n_parts, u64 *cursors,
+                                                              u64 *send_keys, uint32_t *idx) {
+    __shared__ unsigned int s_cnt[64];
+    __shared__ u64 s_base[64];
+    const int lane = gs_lane();
+    const int64_t tile = 256 * GS_ROUTE_T;
+    for (int64_t t0 = (int64_t)blockIdx.x * tile; t0 < n; t0 += (int64_t)gridDim.x * tile) {
+        if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        u64 h[GS_ROUTE_T];
+        int owner[GS_ROUTE_T];
+        unsigned int lp[GS_ROUTE_T];
+#pragma unroll
+        for (int j = 0; j < GS_ROUTE_T; j++) {
+            const int64_t i = t0 + (int64_t)j * 256 + threadIdx.x;
+            h[j] = i < n ? keys[i] : GS_KEY_INVALID;
+            owner[j] = h[j] != GS_KEY_INVALID ? (int)((h[j] >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+            lp[j] = 0;
+            u64 todo = __ballot(owner[j] >= 0);
+            while (todo) {
+                const int first = __builtin_ctzll(todo);
+                const int o = gs_readlane(owner[j], first);
+                const u64 mine = __ballot(owner[j] == o);
+                unsigned int b = 0;
+                if (lane == first) b = atomicAdd(&s_cnt[o], (unsigned int)__popcll(mine));
+                b = (unsigned int)gs_readlane((int)b, first);
+                if (owner[j] == o) lp[j] = b + (unsigned int)__popcll(mine & ((1ULL << lane) - 1));
+                todo &= ~mine;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n_parts) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (u64)s_cnt[threadIdx.x]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < GS_ROUTE_T; j++) {
+            if (owner[j] >= 0) {
+                const u64 p = s_base[owner[j]] + lp[j];
+                send_keys[p] = h[j];
+                idx[p] = (uint32_t)(t0 + (int64_t)j * 256 + threadIdx.x);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_unroute_kernel(const uint32_t *idx, const int32_t *back, int64_t n_routed,
+                                                        int32_t *nodes, int64_t n_keys, int phase) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (phase == 0)  // every position starts as INVALID (windows with a bad base are never routed)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) nodes[i] = GS_NODE_INVALID;
+    else
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_routed; i += stride) nodes[idx[i]] = back[i];
+}
+
 // one lane per key; marks the slot's seen bit like the fused kernel does
 __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u64 *keys, int64_t n, int32_t *nodes,
                                                            int count_unique) {
@@ -1140,6 +1221,34 @@ extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, 
 
 extern "C" hipError_t gs_launch_encode(const GsEncodeParams *P, int grid, hipStream_t stream) {
     hipLaunchKernelGGL(gs_encode_kernel, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    return hipGetLastError();
+}
+
+static int gs_stream_grid(int64_t n) {
+    int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    return grid < 1 ? 1 : grid;
+}
+
+extern "C" hipError_t gs_launch_route_count(const u64 *keys, int64_t n, int n_parts, u64 *counts, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_route_count_kernel, dim3(gs_stream_grid(n)), dim3(256), 0, stream, keys, n, n_parts, counts);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_parts, u64 *cursors, u64 *send_keys,
+                                               uint32_t *idx, hipStream_t stream) {
+    int grid = (int)std::min<int64_t>((n + 256 * GS_ROUTE_T - 1) / (256 * GS_ROUTE_T), 256 * 8);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gs_route_scatter_kernel, dim3(grid), dim3(256), 0, stream, keys, n, n_parts, cursors, send_keys, idx);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_unroute(const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
+                                         int64_t n_keys, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_keys)), dim3(256), 0, stream, idx, back, n_routed, nodes,
+                       n_keys, 0);
+    if (n_routed > 0)
+        hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_routed)), dim3(256), 0, stream, idx, back, n_routed,
+                           nodes, n_keys, 1);
     return hipGetLastError();
 }
 

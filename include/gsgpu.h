@@ -184,6 +184,14 @@ int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, in
 int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32_t *nodes);
 int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int64_t first_read_no,
                     const uint64_t *pos_off, const int32_t *nodes, int32_t *class_vi, uint8_t *flags);
+/* Routing helpers around the two all-to-alls (device counting sort by owner rank, synchronous):
+ * gs_route_keys groups the valid keys by owner: send_keys[n_valid] (owner 0 first), idx[n_valid] = position of each
+ * routed key in `keys`, counts[n_parts] (HOST array) = keys per owner.  gs_unroute_nodes scatters the returned nodes
+ * back: nodes[idx[i]] = back[i], every other position (invalid windows) reads -2.  n_keys < 2^32, n_parts <= 64. */
+int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int n_parts, uint64_t *send_keys, uint32_t *idx,
+                  int64_t *counts);
+int gs_unroute_nodes(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
+                     int64_t n_keys);
 
 /* Kraken-style per-read segments (writeKrakenStyleOut; FastqKMerMatcher.printKrakenStyleOut, :597-611): the maximal
  * runs of equal tax node over the k-mer positions of each read, in read order.  gs_match_segments probes the batch,

@@ -56,8 +56,9 @@ def _merge_tables(tables):
     return out
 
 
+@pytest.mark.parametrize("device_routing", [True, False])
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_partitioned_pipeline_emulated(sdb, world):
+def test_partitioned_pipeline_emulated(sdb, world, device_routing):
     seq, off = _reads(sdb, 6000)
     n = len(off) - 1
     want, wcv, wfl = _oracle(sdb, seq, off)
@@ -81,8 +82,17 @@ def test_partitioned_pipeline_emulated(sdb, world):
         keys = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
         ms[r].encode(dseq, doff, pos_off, keys, nr)
         ms[r].sync()
-        idx, send, counts = gd.plan_routing(keys[:nk], world)
-        plans.append((pos_off, nk, idx, send, counts.cpu().numpy()))
+        if device_routing:  # gs_route_keys: counting sort on the device
+            send = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
+            idx = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
+            counts = np.array(ms[r].route_keys(keys, nk, world, send, idx), dtype=np.int64)
+            send = send[:int(counts.sum())]
+            assert bool((((send >> gd.OWNER_SHIFT) % world).cpu() == torch.repeat_interleave(
+                torch.arange(world), torch.from_numpy(counts))).all())
+        else:               # the same step with torch ops
+            idx, send, counts = gd.plan_routing(keys[:nk], world)
+            counts = counts.cpu().numpy()
+        plans.append((pos_off, nk, idx, send, counts))
     # all-to-all #1: keys to their owners
     starts = [np.concatenate([[0], np.cumsum(p[4])]) for p in plans]
     node_back = [[None] * world for _ in range(world)]
@@ -100,7 +110,12 @@ def test_partitioned_pipeline_emulated(sdb, world):
     tables, cvs, fls = [], [], []
     for r, (dseq, doff, nr, lo) in enumerate(shard):
         pos_off, nk, idx, _, _ = plans[r]
-        nodes = gd.scatter_nodes(torch.cat(node_back[r]), idx, max(nk, 1))
+        back = torch.cat(node_back[r])
+        if device_routing:
+            nodes = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
+            ms[r].unroute_nodes(idx, back, back.numel(), nodes, nk)
+        else:
+            nodes = gd.scatter_nodes(back, idx, max(nk, 1))
         cv = torch.full((max(nr, 1),), -1, dtype=torch.int32, device=dev)
         fl = torch.zeros(max(nr, 1), dtype=torch.uint8, device=dev)
         ms[r].reduce(dseq, doff, pos_off, nodes, nr, first_read_no=lo, class_vi=cv, flags=fl)
