@@ -48,7 +48,7 @@ class GsError(RuntimeError):
 class DbInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("n_values", C.c_int32), ("n_entries", C.c_int64), ("n_stored", C.c_int64),
                 ("n_buckets", C.c_int64), ("table_bytes", C.c_int64), ("max_displacement", C.c_int32),
-                ("value_bits", C.c_int32), ("gate_bytes", C.c_int64)]
+                ("value_bits", C.c_int32), ("gate_bytes", C.c_int64), ("mgate_bytes", C.c_int64)]
 
 
 class _MatchCfg(C.Structure):

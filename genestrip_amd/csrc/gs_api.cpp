@@ -98,6 +98,7 @@ struct gs_db {
     GsDbDev dev{};
     u64 *d_table = nullptr;
     u64 *d_gate = nullptr;
+    u64 *d_mgate = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth | tin | tout
     int n_cu = 256;
     struct gs_run *unique_owner = nullptr;  // the slots' seen bits belong to one unique-counting run at a time
@@ -201,8 +202,12 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- keys
     std::vector<u64> hkey;
     std::vector<int32_t> hval;
+    std::vector<uint32_t> hmin;  // minimizer order hash per stored key (k >= GS_MIN_K)
     hkey.reserve((size_t)n);
     hval.reserve((size_t)n);
+    bool want_mgate = k >= GS_MIN_K;
+    if (const char *e = getenv("GS_MGATE")) want_mgate = want_mgate && atoi(e) != 0;
+    if (want_mgate) hmin.reserve((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         u64 key;
         bool reachable = java_to_planar((u64)kmers[i], k, key);
@@ -211,6 +216,12 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
         hkey.push_back(hk);
         hval.push_back(vidx[i]);
+        if (want_mgate) {
+            const uint32_t phi = (uint32_t)(key >> GS_PLANE_SHIFT), plo = (uint32_t)(key & ((1ULL << GS_PLANE_SHIFT) - 1));
+            uint32_t m = 0xffffffffu;
+            for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
+            hmin.push_back(m);
+        }
     }
     const int64_t ns = (int64_t)hkey.size();
     const int vbits = std::max(1, bits_for((u64)n_values));
@@ -261,6 +272,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             for (int64_t i = 0; i < ns; i++) gate[(hkey[i] >> b) & gmask] |= gs_gate_bits(hkey[i]);
         }
     }
+    // ---- minimizer gate (gs_layout.h): 16 bits per DISTINCT minimizer, 3 bits set per entry
+    std::vector<u64> mgate;
+    if (want_mgate && ns > 0) {
+        std::vector<uint32_t> um(hmin);
+        std::sort(um.begin(), um.end());
+        um.erase(std::unique(um.begin(), um.end()), um.end());
+        int wb = 6;
+        while (((size_t)64 << wb) < um.size() * 16) wb++;
+        mgate.assign((size_t)1 << wb, 0);
+        const uint32_t mm = (uint32_t)mgate.size() - 1;
+        for (uint32_t m : um) mgate[(m >> 8) & mm] |= gs_mgate_bits(m);
+    }
     gs_db *db = new gs_db();
     db->device = device;
     hipDeviceProp_t prop;
@@ -271,6 +294,8 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
     if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(u64));
+    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
@@ -295,6 +320,9 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     db->dev.gate = db->d_gate;
     db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
     db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
+    db->dev.mgate = db->d_mgate;
+    db->dev.mgate_mask = mgate.empty() ? 0 : (u64)mgate.size() - 1;
+    db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(u64));
     db->dev.bucket_bits = (uint32_t)b;
     db->dev.vbits = (uint32_t)vbits;
     db->dev.bucket_mask = (1ULL << b) - 1;
@@ -321,6 +349,7 @@ struct GsStoreFileHeader {
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
+    uint64_t mgate_words;
 };
 
 extern "C" int gs_db_save(gs_db *db, const char *path) {
@@ -328,21 +357,25 @@ extern "C" int gs_db_save(gs_db *db, const char *path) {
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE1", 8);
+    memcpy(h.magic, "GSSTORE2", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
     h.gate_words = db->d_gate ? db->dev.gate_mask + 1 : 0;
+    h.mgate_words = db->d_mgate ? db->dev.mgate_mask + 1 : 0;
     const size_t nv = (size_t)db->info.n_values;
-    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words),
+        mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
     HIP_TRY(hipMemcpy(table.data(), db->d_table, table.size() * sizeof(u64), hipMemcpyDeviceToHost));
     if (!gate.empty()) HIP_TRY(hipMemcpy(gate.data(), db->d_gate, gate.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    if (!mgate.empty()) HIP_TRY(hipMemcpy(mgate.data(), db->d_mgate, mgate.size() * sizeof(u64), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tree.data(), db->d_tree, tree.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     FILE *f = fopen(path, "wb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
               fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
+              fwrite(mgate.data(), sizeof(u64), mgate.size(), f) == mgate.size() &&
               fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     ok = (fclose(f) == 0) && ok;
     return ok ? GS_OK : fail(GS_E_INVALID, std::string("short write to ") + path);
@@ -356,16 +389,18 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE1", 8) != 0 || h.info.n_values < 1 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE2", 8) != 0 || h.info.n_values < 1 ||
         h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25) {
         fclose(f);
         return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file");
     }
     const size_t nv = (size_t)h.info.n_values;
-    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words),
+        mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
     const bool ok = fread(table.data(), sizeof(u64), table.size(), f) == table.size() &&
                     fread(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
+                    fread(mgate.data(), sizeof(u64), mgate.size(), f) == mgate.size() &&
                     fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     fclose(f);
     if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
@@ -379,6 +414,8 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, tree.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), table.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(u64));
+    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, tree.data(), tree.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(db->d_table);
@@ -391,6 +428,8 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     db->dev.table = db->d_table;
     db->dev.gate = db->d_gate;
     db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
+    db->dev.mgate = db->d_mgate;
+    db->dev.mgate_mask = mgate.empty() ? 0 : (u64)mgate.size() - 1;
     db->dev.bucket_bits = h.bucket_bits;
     db->dev.vbits = h.vbits;
     db->dev.bucket_mask = ((u64)1 << h.bucket_bits) - 1;
@@ -409,6 +448,7 @@ extern "C" int gs_db_destroy(gs_db *db) {
     hipSetDevice(db->device);
     hipFree(db->d_table);
     hipFree(db->d_gate);
+    hipFree(db->d_mgate);
     hipFree(db->d_tree);
     delete db;
     return GS_OK;

@@ -209,7 +209,7 @@ __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_st
 template <bool PREFETCH>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, GsPrefetch &next,
-                                                int (&node)[2], int (&slot)[2], bool (&fresh)[2]) {
+                                                int (&node)[2], int (&slot)[2], bool (&fresh)[2], uint32_t *wave_g) {
     const int k = db.k;
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
@@ -235,12 +235,48 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         slot[s] = 0;
         fresh[s] = false;
         gword[s] = ~0ULL;
-        if (db.gate != nullptr && act[s]) gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
+        if (db.mgate != nullptr) {
+            // order hash of the 15-mer that starts at this position (positions base+64s+lane)
+            wave_g[64 * s + lane] = gs_lmer_hash(fhi & 0x7fffu, flo & 0x7fffu);
+        } else if (db.gate != nullptr && act[s]) {
+            gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
+        }
+    }
+    if (db.mgate != nullptr) {
+        // minimizer gate: min of the 15-mer hashes over the k-14 positions of each k-mer, through the wave's LDS
+        // row (positions base .. base+143); lanes that share a minimizer read the same gate word -> one request
+        if (lane < 16)
+            wave_g[128 + lane] = gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int w = k - GS_MIN_L + 1;
+        uint32_t mn[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int d = 0; d < 32 - GS_MIN_L; d++) {
+            if (d < w) {
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const uint32_t g = wave_g[64 * s + lane + d];
+                    mn[s] = g < mn[s] ? g : mn[s];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (act[s]) {
+                const u64 bits = gs_mgate_bits(mn[s]);
+                act[s] = (db.mgate[(mn[s] >> 8) & db.mgate_mask] & bits) == bits;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
     }
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const u64 gbits = gs_gate_field_bits(gfield[s]);
-        act[s] = act[s] && ((gword[s] & gbits) == gbits);  // gate: no false negatives
+        if (db.mgate == nullptr) {
+            const u64 gbits = gs_gate_field_bits(gfield[s]);
+            act[s] = act[s] && ((gword[s] & gbits) == gbits);  // gate: no false negatives
+        }
         if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
     }
     if (PREFETCH) next.issue(lane);
@@ -284,7 +320,7 @@ template <bool LONG, bool FROM_NODES>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
-                                                GsPrefetch &next) {
+                                                GsPrefetch &next, uint32_t *wave_g) {
     const GsDbDev &db = P.db;
     const int k = db.k;
     const int max = L - k + 1;
@@ -344,7 +380,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     fresh[s] = false;
                 }
             } else {
-                gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh);
+                gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh, wave_g);
             }
 
             // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
@@ -636,6 +672,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
+    __shared__ uint32_t s_g[GS_BLOCK / 64][160];  // 15-mer order hashes of the wave's current 144 positions
     const int lane = gs_lane();
     const int wave_in_block = threadIdx.x >> 6;
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
@@ -680,22 +717,34 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
             continue;
         }
         if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
-        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
+        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
+                                           s_g[wave_in_block]);
     }
 #else
     GsPrefetch pf;
     pf.rd = nullptr;
-    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
-        const u64 off = P.off[r];
-        const int L = (int)(P.off[r + 1] - off);
+    // The ~40 launch parameters do not fit the scalar register file next to the ballot planes; kept live across
+    // the loop they are spilled to VGPR lanes and read back with v_readlane on every use.  Re-reading them from
+    // the kernarg segment (scalar cache) once per read is cheaper: the empty asm hides from the compiler that the
+    // pointer is loop invariant, so the s_loads stay inside the loop.
+    typedef const __attribute__((address_space(4))) GsMatchParams *GsKernargPtr;
+    const GsKernargPtr kp0 = (GsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const int64_t n_reads = P.n_reads;
+    for (int64_t r = wave_id; r < n_reads; r += n_waves) {
+        GsKernargPtr kp = kp0;
+        asm volatile("" : "+s"(kp));
+        const GsMatchParams &Q = *(const GsMatchParams *)kp;
+        const u64 off = Q.off[r];
+        const int L = (int)(Q.off[r + 1] - off);
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
-            if (lane == 0) P.long_list[atomicAdd(P.long_count, 1u)] = (uint32_t)r;
+            if (lane == 0) Q.long_list[atomicAdd(Q.long_count, 1u)] = (uint32_t)r;
             continue;
         }
         uint32_t pre[3];
 #pragma unroll
-        for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? P.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf);
+        for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
+        gs_process_read<false, FROM_NODES>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
+                                           s_g[wave_in_block]);
     }
 #endif
     GS_STATS_EPILOGUE()
@@ -708,6 +757,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     const int wave_in_block = threadIdx.x >> 6;
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    __shared__ uint32_t s_g[GS_BLOCK / 64][160];
     const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
     int32_t *cnt = tag + nv;
@@ -721,7 +771,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         GsPrefetch nopf;
         nopf.rd = nullptr;
         gs_process_read<true, FROM_NODES>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
-                              (int)serial, none, nopf);
+                              (int)serial, none, nopf, s_g[wave_in_block]);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
@@ -889,6 +939,7 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
 // ---------------------------------------------------------------------------------------------------
 template <bool WRITE>
 __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
+    __shared__ uint32_t s_g[GS_BLOCK / 64][160];
     const GsDbDev &db = P.db;
     const int lane = gs_lane();
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
@@ -912,7 +963,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
             for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
             int node[2], slot[2];
             bool fresh[2];
-            gs_probe_planes<false>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh);
+            gs_probe_planes<false>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh, s_g[threadIdx.x >> 6]);
             const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
             const int last0 = gs_readlane(node[0], 63);
             const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};

@@ -57,10 +57,40 @@ GS_HD uint64_t gs_gate_field_bits(uint32_t f) {  // f = h >> GS_GATE_FIELD_SHIFT
 
 GS_HD uint64_t gs_gate_bits(uint64_t h) { return gs_gate_field_bits((uint32_t)(h >> GS_GATE_FIELD_SHIFT)); }
 
+// Minimizer gate: a second, much smaller filter over the MINIMIZERS of the stored k-mers.  The minimizer of a k-mer
+// is the canonical 15-mer with the smallest hash among its k-14 15-mers (strand symmetric).  A k-mer can only be in
+// the store if its minimizer is in this set, and consecutive k-mers of a read share their minimizer for ~(k-13)/2
+// positions, so the 64 lanes of a wave ask for only ~8 distinct words: the lookups coalesce to a handful of requests
+// instead of one per k-mer.  Used by the fused kernels when k >= GS_MIN_K; the word gate above stays for the
+// key-only probe of the DB-partitioned mode.
+#define GS_MIN_L 15
+#define GS_MIN_K 19
+
+GS_HD uint32_t gs_lmer_hash(uint32_t fh, uint32_t fl) {  // 15-bit planes of a 15-mer (base 0 in bit 0) -> order hash
+    const uint32_t M = (1u << GS_MIN_L) - 1u;
+    const uint32_t rh = __builtin_bitreverse32(fh) >> (32 - GS_MIN_L);
+    const uint32_t rl = (__builtin_bitreverse32(fl) >> (32 - GS_MIN_L)) ^ M;
+    const uint32_t f = (fh << GS_MIN_L) | fl, r = (rh << GS_MIN_L) | rl;
+    uint32_t g = f < r ? f : r;  // canonical 15-mer (30 bits); the mix below is a bijection on 32 bits
+    g *= 0x9E3779B1u;
+    g ^= g >> 15;
+    g *= 0x85EBCA77u;
+    g ^= g >> 13;
+    return g;
+}
+
+GS_HD uint64_t gs_mgate_bits(uint32_t m) {  // 3 bits inside one 64-bit word
+    uint32_t x = m * 0xC2B2AE35u;
+    x ^= x >> 16;
+    return (1ULL << (x & 63)) | (1ULL << ((x >> 6) & 63)) | (1ULL << ((x >> 12) & 63));
+}
+
 struct GsDbDev {
     const unsigned long long *table;  // n_buckets * 8 slots
     const unsigned long long *gate;   // gate_mask+1 words, or nullptr
     uint64_t gate_mask;
+    const unsigned long long *mgate;  // minimizer gate: mgate_mask+1 words, or nullptr
+    uint64_t mgate_mask;
     uint32_t bucket_bits;
     uint32_t vbits;
     uint64_t bucket_mask;

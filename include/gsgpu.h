@@ -74,6 +74,7 @@ typedef struct {
     int32_t max_displacement;
     int32_t value_bits;
     int64_t gate_bytes;     /* L2-resident pre-filter (0 = not built: store too large for it)  */
+    int64_t mgate_bytes;    /* minimizer gate (0 = not built: k < 19)                           */
 } gs_db_info;
 
 int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,
