@@ -12,6 +12,7 @@ passed as device batches (GS_MEM_DEVICE).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -147,6 +148,18 @@ def _ptr(a):
     raise TypeError(f"unsupported buffer {type(a)}")
 
 
+def _ready(*bufs):
+    """The library works on its own HIP stream and takes device buffers as complete (include/gsgpu.h): wait for the
+    producer's stream (torch's current one) before handing tensors over."""
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    for b in bufs:
+        if b is not None and getattr(b, "is_cuda", False):
+            torch.cuda.current_stream(b.device).synchronize()
+            return
+
+
 class DeviceKMerStore:
     """k-mer -> value-index store plus taxonomy, resident in HBM (gs_db)."""
 
@@ -228,6 +241,7 @@ class FastqKMerMatcher:
             n_reads = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
         pc, _ = _ptr(class_vi)
         pf, _ = _ptr(flags)
+        _ready(seq, offsets, class_vi, flags)
         _check(lib().gs_match_submit(self.h, ps, po, n_reads, first_read_no, mem, pc, pf))
 
     def match_reads(self, seq, offsets, first_read_no=0):
@@ -247,24 +261,29 @@ class FastqKMerMatcher:
 
     # ---- DB-partitioned mode (device tensors with data_ptr())
     def encode(self, seq, offsets, pos_off, keys, n_reads):
+        _ready(seq, offsets, pos_off, keys)
         _check(lib().gs_match_encode(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,
                                      C.c_void_p(pos_off.data_ptr()), C.c_void_p(keys.data_ptr())))
 
     def probe_keys(self, keys, nodes, n_keys):
+        _ready(keys, nodes)
         _check(lib().gs_match_probe_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, C.c_void_p(nodes.data_ptr())))
 
     def route_keys(self, keys, n_keys, n_parts, send_keys, idx):
         """device counting sort of the valid keys by owner rank; returns the per-owner counts (python list)"""
         counts = (C.c_int64 * n_parts)()
+        _ready(keys, send_keys, idx)
         _check(lib().gs_route_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, n_parts, C.c_void_p(send_keys.data_ptr()),
                                    C.c_void_p(idx.data_ptr()), counts))
         return list(counts)
 
     def unroute_nodes(self, idx, back, n_routed, nodes, n_keys):
+        _ready(idx, back, nodes)
         _check(lib().gs_unroute_nodes(self.h, C.c_void_p(idx.data_ptr()), C.c_void_p(back.data_ptr()), n_routed,
                                       C.c_void_p(nodes.data_ptr()), n_keys))
 
     def reduce(self, seq, offsets, pos_off, nodes, n_reads, first_read_no=0, class_vi=None, flags=None):
+        _ready(seq, offsets, pos_off, nodes, class_vi, flags)
         _check(lib().gs_match_reduce(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,
                                      first_read_no, C.c_void_p(pos_off.data_ptr()), C.c_void_p(nodes.data_ptr()),
                                      None if class_vi is None else C.c_void_p(class_vi.data_ptr()),
@@ -374,6 +393,7 @@ class FastqBloomFilter:
         pa, _ = _ptr(accept)
         if n_reads is None:
             n_reads = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
+        _ready(seq, offsets, accept)
         _check(lib().gs_filter_submit(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, ps, po, n_reads,
                                       mem, pa, int(self.profile)))
 

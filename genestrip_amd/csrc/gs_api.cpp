@@ -98,17 +98,17 @@ struct gs_db {
     GsDbDev dev{};
     u64 *d_table = nullptr;
     u64 *d_gate = nullptr;
-    u64 *d_mgate = nullptr;
+    uint32_t *d_mgate = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth | tin | tout
     int n_cu = 256;
     struct gs_run *unique_owner = nullptr;  // the slots' seen bits belong to one unique-counting run at a time
 };
 
-// reference (interleaved, first base in the top bits) -> planar key; also reports reachability:
+// reference (interleaved, first base in the top bits) -> forward planes; also reports reachability:
 // the reference only ever queries max(fwd, revcomp) (CGAT.java:145-147), so a stored key that is smaller
 // than its reverse complement can never be hit.
-static inline bool java_to_planar(u64 x, int k, u64 &key) {
-    uint32_t hi = 0, lo = 0;
+static inline bool java_to_planes(u64 x, int k, uint32_t &hi, uint32_t &lo) {
+    hi = lo = 0;
     u64 rc = 0;
     for (int i = 0; i < k; i++) {
         uint32_t c = (uint32_t)(x >> (2 * (k - 1 - i))) & 3u;
@@ -116,7 +116,6 @@ static inline bool java_to_planar(u64 x, int k, u64 &key) {
         lo |= (c & 1u) << i;
         rc |= (u64)(c ^ 1u) << (2 * i);  // base i complemented lands at position k-1-i from the top
     }
-    key = ((u64)hi << GS_PLANE_SHIFT) | lo;
     return x >= rc;
 }
 
@@ -208,16 +207,17 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     bool want_mgate = k >= GS_MIN_K;
     if (const char *e = getenv("GS_MGATE")) want_mgate = want_mgate && atoi(e) != 0;
     if (want_mgate) hmin.reserve((size_t)n);
+    const uint32_t kmask = (1u << k) - 1u;
     for (int64_t i = 0; i < n; i++) {
-        u64 key;
-        bool reachable = java_to_planar((u64)kmers[i], k, key);
+        uint32_t fhi, flo, phi, plo;
+        bool reachable = java_to_planes((u64)kmers[i], k, fhi, flo);
         if (!reachable || parent[vidx[i]] == -2) continue;
-        const u64 hk = gs_mix62(key);
+        gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
+        const u64 hk = gs_mix_planes(phi, plo);
         if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
         hkey.push_back(hk);
         hval.push_back(vidx[i]);
-        if (want_mgate) {
-            const uint32_t phi = (uint32_t)(key >> GS_PLANE_SHIFT), plo = (uint32_t)(key & ((1ULL << GS_PLANE_SHIFT) - 1));
+        if (want_mgate) {  // strand symmetric: either orientation gives the same minimizer
             uint32_t m = 0xffffffffu;
             for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
             hmin.push_back(m);
@@ -272,17 +272,17 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             for (int64_t i = 0; i < ns; i++) gate[(hkey[i] >> b) & gmask] |= gs_gate_bits(hkey[i]);
         }
     }
-    // ---- minimizer gate (gs_layout.h): 16 bits per DISTINCT minimizer, 3 bits set per entry
-    std::vector<u64> mgate;
+    // ---- minimizer gate (gs_layout.h): 16-32 bits per DISTINCT minimizer, 2 bits set per entry, 32-bit words
+    std::vector<uint32_t> mgate;
+    int mgate_bits = 0;
     if (want_mgate && ns > 0) {
         std::vector<uint32_t> um(hmin);
         std::sort(um.begin(), um.end());
         um.erase(std::unique(um.begin(), um.end()), um.end());
-        int wb = 6;
-        while (((size_t)64 << wb) < um.size() * 16) wb++;
-        mgate.assign((size_t)1 << wb, 0);
-        const uint32_t mm = (uint32_t)mgate.size() - 1;
-        for (uint32_t m : um) mgate[(m >> 8) & mm] |= gs_mgate_bits(m);
+        mgate_bits = 6;
+        while (mgate_bits < 30 && ((size_t)32 << mgate_bits) < um.size() * 16) mgate_bits++;
+        mgate.assign((size_t)1 << mgate_bits, 0);
+        for (uint32_t m : um) mgate[gs_mgate_word(m, (uint32_t)mgate_bits)] |= gs_mgate_bits(m);
     }
     gs_db *db = new gs_db();
     db->device = device;
@@ -294,8 +294,8 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
     if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(u64));
-    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
+    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
@@ -321,8 +321,9 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
     db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
     db->dev.mgate = db->d_mgate;
-    db->dev.mgate_mask = mgate.empty() ? 0 : (u64)mgate.size() - 1;
-    db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(u64));
+    db->dev.mgate_bits = 0;
+    while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
+    db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(uint32_t));
     db->dev.bucket_bits = (uint32_t)b;
     db->dev.vbits = (uint32_t)vbits;
     db->dev.bucket_mask = (1ULL << b) - 1;
@@ -345,11 +346,11 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE1"
+    char magic[8];  // "GSSTORE3"
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
-    uint64_t mgate_words;
+    uint64_t mgate_words;  // 32-bit words, a power of two
 };
 
 extern "C" int gs_db_save(gs_db *db, const char *path) {
@@ -357,25 +358,25 @@ extern "C" int gs_db_save(gs_db *db, const char *path) {
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE2", 8);
+    memcpy(h.magic, "GSSTORE3", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
     h.gate_words = db->d_gate ? db->dev.gate_mask + 1 : 0;
-    h.mgate_words = db->d_mgate ? db->dev.mgate_mask + 1 : 0;
+    h.mgate_words = db->d_mgate ? (uint64_t)1 << db->dev.mgate_bits : 0;
     const size_t nv = (size_t)db->info.n_values;
-    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words),
-        mgate((size_t)h.mgate_words);
+    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<uint32_t> mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
     HIP_TRY(hipMemcpy(table.data(), db->d_table, table.size() * sizeof(u64), hipMemcpyDeviceToHost));
     if (!gate.empty()) HIP_TRY(hipMemcpy(gate.data(), db->d_gate, gate.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    if (!mgate.empty()) HIP_TRY(hipMemcpy(mgate.data(), db->d_mgate, mgate.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    if (!mgate.empty()) HIP_TRY(hipMemcpy(mgate.data(), db->d_mgate, mgate.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tree.data(), db->d_tree, tree.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     FILE *f = fopen(path, "wb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
               fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
-              fwrite(mgate.data(), sizeof(u64), mgate.size(), f) == mgate.size() &&
+              fwrite(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
               fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     ok = (fclose(f) == 0) && ok;
     return ok ? GS_OK : fail(GS_E_INVALID, std::string("short write to ") + path);
@@ -389,18 +390,19 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE2", 8) != 0 || h.info.n_values < 1 ||
-        h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE3", 8) != 0 || h.info.n_values < 1 ||
+        h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25 ||
+        (h.mgate_words & (h.mgate_words - 1)) != 0 || h.mgate_words > ((uint64_t)1 << 30)) {
         fclose(f);
         return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file");
     }
     const size_t nv = (size_t)h.info.n_values;
-    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words),
-        mgate((size_t)h.mgate_words);
+    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<uint32_t> mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
     const bool ok = fread(table.data(), sizeof(u64), table.size(), f) == table.size() &&
                     fread(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
-                    fread(mgate.data(), sizeof(u64), mgate.size(), f) == mgate.size() &&
+                    fread(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
                     fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     fclose(f);
     if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
@@ -414,8 +416,8 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, tree.size() * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), table.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(u64));
-    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
+    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, tree.data(), tree.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(db->d_table);
@@ -429,7 +431,8 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     db->dev.gate = db->d_gate;
     db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
     db->dev.mgate = db->d_mgate;
-    db->dev.mgate_mask = mgate.empty() ? 0 : (u64)mgate.size() - 1;
+    db->dev.mgate_bits = 0;
+    while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
     db->dev.bucket_bits = h.bucket_bits;
     db->dev.vbits = h.vbits;
     db->dev.bucket_mask = ((u64)1 << h.bucket_bits) - 1;

@@ -4,7 +4,7 @@
 // sub-rounds of 64, so a 150 bp read at k=31 (120 k-mers) is exactly one iteration.  Per iteration:
 //   1. coalesced byte loads of the bases, three 64-lane ballots per 64 bases (code-hi, code-lo, invalid)
 //   2. per lane: funnel-shift the ballot planes -> forward k-mer, bit-reverse -> reverse complement,
-//      reference-exact canonical choice, gs_mix62 -> bucket + remainder
+//      representative orientation (gs_rep_planes), gs_mix_planes -> bucket + remainder
 //   3. one 64-byte bucket line per k-mer (4 x dwordx4 per lane, both sub-rounds in flight together)
 //   4. per-read reduce inside the wave: contig boundaries by neighbour compare, a wave-uniform loop over
 //      the few contig "events" (flush stats / start contig / path merge), unique bitmap by test-then-
@@ -155,32 +155,31 @@ __device__ __forceinline__ void gs_load_bucket(const u64 *table, u64 bkt, GsBuck
 // 0 <= x-2 < 2*vmask.  On a hit vs = 2*vi + seen.  Buckets fill front to back, so "full" is "slot 7 is occupied".
 __device__ __forceinline__ bool gs_match_bucket(const GsBucket &b, u64 want, uint32_t vmask2, int &vs, int &slot) {
     const u64 s[8] = {b.q[0].x, b.q[0].y, b.q[1].x, b.q[1].y, b.q[2].x, b.q[2].y, b.q[3].x, b.q[3].y};
-    const uint32_t want_hi = (uint32_t)(want >> 32), want_lo = (uint32_t)want;
-    int hit = -1, val = 0;
+    // two instructions per slot: mask the value/seen field away and compare all 64 bits.  An empty slot (0) can only
+    // "match" want == 0 and is told apart afterwards by its zero value field.
+    const u64 keep = ~(u64)(vmask2 + 1u);  // vmask2 + 1 = 2^(vbits+1) - 1: the (vi+1, seen) field
+    int hit = -1;
+    uint32_t low = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t y = ((uint32_t)s[j] ^ want_lo) - 2u;
-        const bool m = ((uint32_t)(s[j] >> 32) == want_hi) && (y < vmask2);
-        val = m ? (int)y : val;
+    for (int j = 7; j >= 0; j--) {  // buckets fill front to back: the lowest match is the real entry
+        const bool m = (s[j] & keep) == want;
+        low = m ? (uint32_t)s[j] : low;
         hit = m ? j : hit;
     }
-    if (hit >= 0) {
-        vs = val;
+    const int x = (int)(low & (vmask2 + 1u)) - 2;  // 2 vi + seen, or < 0 for the empty slot
+    if (hit >= 0 && x >= 0) {
+        vs = x;
         slot = hit;
         return true;
     }
     return s[7] == 0;
 }
 
-// canonical planar key of the k-mer whose forward planes are (fhi, flo); reference-exact orientation choice
-__device__ __forceinline__ u64 gs_canonical_planar(uint32_t fhi, uint32_t flo, int k, uint32_t kmask) {
-    const uint32_t rhi = __brev(fhi) >> (32 - k);
-    const uint32_t rlo = (__brev(flo) >> (32 - k)) ^ kmask;
-    const uint32_t diff = (fhi ^ rhi) | (flo ^ rlo);
-    const uint32_t d = diff & (0u - diff);  // first base where the two orientations differ
-    const uint32_t cf = ((fhi & d) ? 2u : 0u) | ((flo & d) ? 1u : 0u);
-    const uint32_t cr = ((rhi & d) ? 2u : 0u) | ((rlo & d) ? 1u : 0u);
-    return cf >= cr ? (((u64)fhi << GS_PLANE_SHIFT) | flo) : (((u64)rhi << GS_PLANE_SHIFT) | rlo);
+// table hash of the k-mer whose forward planes are (fhi, flo): representative orientation, then the Feistel mix
+__device__ __forceinline__ u64 gs_kmer_hash(uint32_t fhi, uint32_t flo, int k, uint32_t kmask) {
+    uint32_t a, b;
+    gs_rep_planes(fhi, flo, k, kmask, a, b);
+    return gs_mix_planes(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -206,15 +205,16 @@ __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_st
 // node[s] for position base + 64 s + lane: value index (hit), GS_NODE_MISS, GS_NODE_INVALID (window holds a
 // non-CGAT byte) or GS_NODE_NONE (position >= max).  slot = global slot index of a hit, fresh = its seen bit was 0.
 // ---------------------------------------------------------------------------------------------------
-template <bool PREFETCH>
+template <bool PREFETCH, int KC>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, GsPrefetch &next,
                                                 int (&node)[2], int (&slot)[2], bool (&fresh)[2], uint32_t *wave_g) {
-    const int k = db.k;
+    const int k = KC ? KC : db.k;  // KC = compile-time k of the specialised kernels (0: any k)
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
     const int shift_rem = (int)db.vbits + 3;
     const uint32_t bmask = (uint32_t)db.bucket_mask;  // n_buckets <= 2^29
+    const bool any_bad = (Bbad[0] | Bbad[1] | Bbad[2]) != 0;
     uint32_t bkt[2], gfield[2];
     u64 want[2], gword[2];
     bool act[2];
@@ -225,8 +225,9 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         const bool valid = p < max;
         const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
         const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
-        const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
-        const u64 h = gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
+        // almost every read is clean: the per-lane window test is skipped on a wave-uniform branch
+        const uint32_t wbad = any_bad ? (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask : 0u;
+        const u64 h = gs_kmer_hash(fhi, flo, k, kmask);
         bkt[s] = (uint32_t)h & bmask;
         want[s] = (h >> db.bucket_bits) << shift_rem;
         gfield[s] = (uint32_t)(h >> GS_GATE_FIELD_SHIFT);
@@ -253,10 +254,10 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         const int w = k - GS_MIN_L + 1;
         uint32_t mn[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll
-        for (int d = 0; d < 32 - GS_MIN_L; d++) {
-            if (d < w) {
+        for (int s = 0; s < 2; s++) {
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
+            for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
+                if (KC || d < w) {
                     const uint32_t g = wave_g[64 * s + lane + d];
                     mn[s] = g < mn[s] ? g : mn[s];
                 }
@@ -265,8 +266,8 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             if (act[s]) {
-                const u64 bits = gs_mgate_bits(mn[s]);
-                act[s] = (db.mgate[(mn[s] >> 8) & db.mgate_mask] & bits) == bits;
+                const uint32_t bits = gs_mgate_bits(mn[s]);
+                act[s] = (db.mgate[gs_mgate_word(mn[s], db.mgate_bits)] & bits) == bits;
             }
         }
         __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
@@ -316,13 +317,13 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // one read on one wave.  LONG = false: max <= 128 (one iteration, distinct nodes kept in registers).
 // LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG, bool FROM_NODES>
+template <bool LONG, bool FROM_NODES, int KC>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
                                                 GsPrefetch &next, uint32_t *wave_g) {
     const GsDbDev &db = P.db;
-    const int k = db.k;
+    const int k = KC ? KC : db.k;
     const int max = L - k + 1;
     const uint8_t *rd = P.seq + off;
     int out_class = -1;
@@ -375,12 +376,15 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     const int p = base + 64 * s + lane;
-                    node[s] = p < max ? P.nodes[pb + 64 * s + lane] : GS_NODE_NONE;
+                    int v = p < max ? P.nodes[pb + 64 * s + lane] : GS_NODE_NONE;
+                    // the stream comes from other ranks: a value outside the store's range must not index anything
+                    if (p < max && (v >= db.n_values || v < GS_NODE_INVALID)) v = GS_NODE_MISS;
+                    node[s] = v;
                     slot[s] = 0;
                     fresh[s] = false;
                 }
             } else {
-                gs_probe_planes<!LONG>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh, wave_g);
+                gs_probe_planes<!LONG, KC>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh, wave_g);
             }
 
             // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
@@ -667,8 +671,8 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
     }
 
-template <bool LDS_STATS, bool FROM_NODES>
-__global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
+template <bool LDS_STATS, bool FROM_NODES, int KC>
+__global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
     const int wave_in_block = threadIdx.x >> 6;
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
-    const int k = P.db.k;
+    const int k = KC ? KC : P.db.k;
 #if GS_PREFETCH
     // pipeline registers: offsets two reads ahead, bases one read ahead
     int64_t r = wave_id;
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
             continue;
         }
         if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
-        gs_process_read<false, FROM_NODES>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
+        gs_process_read<false, FROM_NODES, KC>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
                                            s_g[wave_in_block]);
     }
 #else
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_kernel(GsMatchParams P) {
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
+        gs_process_read<false, FROM_NODES, KC>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
                                            s_g[wave_in_block]);
     }
 #endif
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         const uint32_t none[3] = {0, 0, 0};
         GsPrefetch nopf;
         nopf.rd = nullptr;
-        gs_process_read<true, FROM_NODES>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+        gs_process_read<true, FROM_NODES, 0>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
                               (int)serial, none, nopf, s_g[wave_in_block]);
     }
     if (lane == 0) serials[wave_id] = serial;
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
             const uint32_t fhi = (uint32_t)gs_funnel(hi0, hi1, lane) & kmask;
             const uint32_t flo = (uint32_t)gs_funnel(lo0, lo1, lane) & kmask;
             const uint32_t wbad = (uint32_t)gs_funnel(bad0, bad1, lane) & kmask;
-            if (p < max) P.keys[pb + (u64)p] = wbad ? GS_KEY_INVALID : gs_mix62(gs_canonical_planar(fhi, flo, k, kmask));
+            if (p < max) P.keys[pb + (u64)p] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi, flo, k, kmask);
             hi0 = hi1;
             lo0 = lo1;
             bad0 = bad1;
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
             for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
             int node[2], slot[2];
             bool fresh[2];
-            gs_probe_planes<false>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh, s_g[threadIdx.x >> 6]);
+            gs_probe_planes<false, 0>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh, s_g[threadIdx.x >> 6]);
             const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
             const int last0 = gs_readlane(node[0], 63);
             const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
@@ -1195,16 +1199,24 @@ static size_t gs_stats_lds_bytes(int n_values) {
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    // k = 31 (the reference's default and maximum) runs a kernel with k folded in at compile time
     if (P->nodes == nullptr) {
-        if (lds_stats)
-            hipLaunchKernelGGL((gs_match_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        else
-            hipLaunchKernelGGL((gs_match_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        if (P->db.k == 31) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 31>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        } else {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 0>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        }
     } else {
         if (lds_stats)
-            hipLaunchKernelGGL((gs_match_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            hipLaunchKernelGGL((gs_match_kernel<true, true, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         else
-            hipLaunchKernelGGL((gs_match_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+            hipLaunchKernelGGL((gs_match_kernel<false, true, 0>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     }
     return hipGetLastError();
 }
@@ -1230,8 +1242,8 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
 extern "C" int gs_match_occupancy(int n_values) {
     int n = 0;
     hipError_t e = n_values <= GS_NV_LDS
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true, false>, GS_BLOCK, gs_stats_lds_bytes(n_values))
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false>, GS_BLOCK, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true, false, 31>, GS_BLOCK, gs_stats_lds_bytes(n_values))
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false, 31>, GS_BLOCK, 0);
     return e == hipSuccess ? n : 0;
 }
 

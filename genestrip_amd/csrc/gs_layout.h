@@ -3,12 +3,14 @@
 // Key encoding ("planar"): for a k-mer s_0..s_{k-1} with the reference's 2-bit codes (C=0 G=1 A=2 T=3,
 // C/util/CGAT.java:66-69) the key is  (hi << 31) | lo  where bit i of hi/lo is the high/low code bit of
 // base i.  A wave builds it from two 64-lane ballots; reverse complement = bit-reverse both planes and
-// flip lo (complement is code^1).  The canonical orientation is chosen exactly as the reference does
-// (numeric max of the interleaved encodings = lexicographic max from base 0, CGAT.java:145-147), so the
-// set of reachable keys is identical.
+// flip lo (complement is code^1).  The reference looks a k-mer up under max(fwd, revcomp) of its interleaved
+// encoding (CGAT.java:145-147); the table files the same k-mer under the orientation whose (hi, lo) plane pair is
+// the larger one (gs_rep_planes: one 64-bit compare on the register pair).  Both rules pick one representative
+// per {k-mer, reverse complement} class, and the builder converts every reachable stored k-mer to that
+// representative, so hit/miss and values are identical.
 //
 // Table: n_buckets (power of two) buckets of 8 x uint64 slots = one 64-byte line per probe.
-//   h      = gs_mix62(key)                 bijection on [0, 2^62)
+//   h      = gs_mix_planes(hi, lo)         bijection on [0, 2^62)
 //   bucket = h & (n_buckets-1),  rem = h >> bucket_bits
 //   slot   = rem << (vbits+3) | disp << (vbits+1) | (value_index+1) << 1 | seen        (0 = empty)
 // `seen` is the unique-k-mer mark of the running match (KMerUniqueCounterBits): set with one atomicOr by the first
@@ -30,14 +32,31 @@
 #define GS_HD static inline
 #endif
 
-GS_HD uint64_t gs_mix62(uint64_t x) {
-    const uint64_t M = (1ULL << GS_KEY_BITS) - 1;
-    x ^= x >> 31;
-    x = (x * 0x7fb5d329728ea185ULL) & M;
-    x ^= x >> 27;
-    x = (x * 0x81dadef4bc2dd44dULL) & M;
-    x ^= x >> 33;
-    return x;
+GS_HD uint32_t gs_brev32(uint32_t x) { return __builtin_bitreverse32(x); }
+
+// representative orientation of the k-mer with forward planes (fhi, flo): planes of the larger (hi:lo) pair
+GS_HD void gs_rep_planes(uint32_t fhi, uint32_t flo, int k, uint32_t kmask, uint32_t &a, uint32_t &b) {
+    const uint32_t rhi = gs_brev32(fhi) >> (32 - k);
+    const uint32_t rlo = (gs_brev32(flo) >> (32 - k)) ^ kmask;
+    const bool fwd = (((uint64_t)fhi << 32) | flo) >= (((uint64_t)rhi << 32) | rlo);
+    a = fwd ? fhi : rhi;
+    b = fwd ? flo : rlo;
+}
+
+// 31-bit round function of the Feistel network below: both halves of the 32x32 -> 64-bit product folded together,
+// so every output bit depends on every input bit (one v_mad_u64_u32 + xor + shift)
+GS_HD uint32_t gs_fold31(uint32_t x, uint32_t c) {
+    const uint64_t p = (uint64_t)x * c;
+    return ((uint32_t)p ^ (uint32_t)(p >> 32)) >> 1;
+}
+
+// (hi, lo) planes, 31 bits each -> h in [0, 2^62).  A three-round Feistel network is a bijection whatever the round
+// function is, so (bucket, remainder) identifies the key exactly and the slots need no full key.
+GS_HD uint64_t gs_mix_planes(uint32_t a, uint32_t b) {
+    a ^= gs_fold31(b, 0x9E3779B1u);
+    b ^= gs_fold31(a, 0x85EBCA77u);
+    a ^= gs_fold31(b, 0xC2B2AE3Du);
+    return ((uint64_t)a << GS_PLANE_SHIFT) | b;
 }
 
 // Gate ("is this k-mer possibly in the store?"): a word-blocked Bloom filter, 4 bits per key inside one 64-bit
@@ -61,36 +80,34 @@ GS_HD uint64_t gs_gate_bits(uint64_t h) { return gs_gate_field_bits((uint32_t)(h
 // is the canonical 15-mer with the smallest hash among its k-14 15-mers (strand symmetric).  A k-mer can only be in
 // the store if its minimizer is in this set, and consecutive k-mers of a read share their minimizer for ~(k-13)/2
 // positions, so the 64 lanes of a wave ask for only ~8 distinct words: the lookups coalesce to a handful of requests
-// instead of one per k-mer.  Used by the fused kernels when k >= GS_MIN_K; the word gate above stays for the
-// key-only probe of the DB-partitioned mode.
+// instead of one per k-mer.  32-bit words, two bits per entry, 16-32 bits per distinct minimizer.  Used by the fused
+// kernels when k >= GS_MIN_K; the word gate above stays for the key-only probe of the DB-partitioned mode.
 #define GS_MIN_L 15
 #define GS_MIN_K 19
 
 GS_HD uint32_t gs_lmer_hash(uint32_t fh, uint32_t fl) {  // 15-bit planes of a 15-mer (base 0 in bit 0) -> order hash
     const uint32_t M = (1u << GS_MIN_L) - 1u;
-    const uint32_t rh = __builtin_bitreverse32(fh) >> (32 - GS_MIN_L);
-    const uint32_t rl = (__builtin_bitreverse32(fl) >> (32 - GS_MIN_L)) ^ M;
+    const uint32_t rh = gs_brev32(fh) >> (32 - GS_MIN_L);
+    const uint32_t rl = (gs_brev32(fl) >> (32 - GS_MIN_L)) ^ M;
     const uint32_t f = (fh << GS_MIN_L) | fl, r = (rh << GS_MIN_L) | rl;
-    uint32_t g = f < r ? f : r;  // canonical 15-mer (30 bits); the mix below is a bijection on 32 bits
-    g *= 0x9E3779B1u;
-    g ^= g >> 15;
-    g *= 0x85EBCA77u;
-    g ^= g >> 13;
-    return g;
+    const uint32_t g = f < r ? f : r;  // canonical 15-mer (30 bits)
+    return g * 0x9E3779B1u;            // odd multiplier: a bijection on 32 bits; the order is set by the well-mixed top bits
 }
 
-GS_HD uint64_t gs_mgate_bits(uint32_t m) {  // 3 bits inside one 64-bit word
-    uint32_t x = m * 0xC2B2AE35u;
-    x ^= x >> 16;
-    return (1ULL << (x & 63)) | (1ULL << ((x >> 6) & 63)) | (1ULL << ((x >> 12) & 63));
+// minimizer gate word (32 bits) and the two bits an entry sets in it
+GS_HD uint32_t gs_mgate_word(uint32_t m, uint32_t word_bits) { return (m * 0x85EBCA77u) >> (32 - word_bits); }
+GS_HD uint32_t gs_mgate_bits(uint32_t m) {
+    const uint32_t y = m * 0xC2B2AE3Du;  // a second product: independent of the word index at any gate size
+    return (1u << (y >> 27)) | (1u << ((y >> 22) & 31));
 }
 
 struct GsDbDev {
     const unsigned long long *table;  // n_buckets * 8 slots
     const unsigned long long *gate;   // gate_mask+1 words, or nullptr
     uint64_t gate_mask;
-    const unsigned long long *mgate;  // minimizer gate: mgate_mask+1 words, or nullptr
-    uint64_t mgate_mask;
+    const uint32_t *mgate;  // minimizer gate: 2^mgate_bits 32-bit words, or nullptr
+    uint32_t mgate_bits;
+    uint32_t pad0;
     uint32_t bucket_bits;
     uint32_t vbits;
     uint64_t bucket_mask;

@@ -15,6 +15,9 @@
  *  - `mem` says where the batch pointers of a submit call live: GS_MEM_HOST (pageable or pinned host
  *    memory; the library stages it to HBM) or GS_MEM_DEVICE (already resident in HBM of the handle's
  *    device; used by bench.py and by callers that ingest on the GPU).  It applies to inputs and outputs.
+ *  - every handle works on its own HIP stream.  Device buffers handed to a call must be COMPLETE: the
+ *    caller synchronises the stream that produced them first; outputs are complete after the matching
+ *    *_sync / *_finish call.  (genestrip_amd/binding.py waits for torch's current stream for you.)
  */
 #ifndef GSGPU_H
 #define GSGPU_H
