@@ -403,7 +403,12 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     if (node[s] >= 0) atomicAdd(P.hit_counts + (uint32_t)slot[s], 1u);
             }
 
-            // ---- 4b. contig events
+            // ---- 4b. contigs and distinct nodes.  Contig statistics are lane parallel: every lane that starts a hit
+            // contig finds the next node change in the ballot masks and books the contig itself (:391-413).  Only
+            // the DISTINCT hit nodes are walked one by one, in order of first appearance: reads1KMer counts a
+            // (read, tax id) pair once (:434-439) and mergeReadTaxidPath (:568-586) is idempotent for a node it
+            // has already seen (paths only ever move down the tree), so repeats need no work.  The per-node vote
+            // count of the read (incCount, :380-388) is the number of positions holding that node.
             if ((hit0 | hit1) != 0 || carry_last >= 0) {
                 int prev[2];
                 {
@@ -413,75 +418,79 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     prev[0] = lane == 0 ? carry_last : up0;
                     prev[1] = lane == 0 ? last0 : up1;
                 }
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const bool valid = node[s] != GS_NODE_NONE;
-                    const bool head = valid && node[s] != prev[s];
-                    u64 E = __ballot(head && (node[s] >= 0 || prev[s] >= 0));
-                    while (E) {
-                        const int j = __builtin_ctzll(E);
-                        E &= E - 1;
-                        const int pj = base + 64 * s + j;
-                        const int pv = gs_readlane(prev[s], j);
-                        const int nvj = gs_readlane(node[s], j);
-                        if (pv >= 0) {  // the hit contig [cur_start, pj) of node pv ends (:391-413)
-                            const int len = pj - cur_start;
-                            if (lane == 0) {
-                                st.contig(pv, len, key_lo);
-                                if (LONG) gs_sc_store(cnt + pv, gs_sc_load(cnt + pv) + len);
-                            }
-                            if (!LONG) {
-                                dcntA += (dviA == pv) ? len : 0;
-                                dcntB += (dviB == pv) ? len : 0;
-                            }
+                const u64 chg0 = __ballot(node[0] != GS_NODE_NONE && node[0] != prev[0]);
+                const u64 chg1 = __ballot(node[1] != GS_NODE_NONE && node[1] != prev[1]);
+                // a hit contig left open by the previous iteration ends at the first change of this one
+                if (LONG && carry_last >= 0 && (chg0 | chg1) != 0) {
+                    const int q = chg0 ? __builtin_ctzll(chg0) : 64 + __builtin_ctzll(chg1);
+                    if (lane == 0) st.contig(carry_last, base + q - cur_start, key_lo);
+                }
+                {   // hit contigs that start here and end before the iteration does
+                    const u64 a0 = (chg0 >> 1) >> lane, a1 = (chg1 >> 1) >> lane;  // changes above this lane
+                    const int e1 = chg1 ? 64 + __builtin_ctzll(chg1) : -1;
+                    const int end0 = a0 ? lane + 1 + __builtin_ctzll(a0) : e1;
+                    const int end1 = a1 ? 64 + lane + 1 + __builtin_ctzll(a1) : -1;
+                    if (node[0] >= 0 && node[0] != prev[0] && end0 >= 0) st.contig(node[0], end0 - lane, key_lo);
+                    if (node[1] >= 0 && node[1] != prev[1] && end1 >= 0) st.contig(node[1], end1 - 64 - lane, key_lo);
+                }
+                // start of the contig that is still open at the end of this iteration
+                if (chg1)
+                    cur_start = base + 127 - __builtin_clzll(chg1);
+                else if (chg0)
+                    cur_start = base + 63 - __builtin_clzll(chg0);
+                // distinct hit nodes of this iteration, in order of first appearance
+                u64 m0 = hit0, m1 = hit1;
+                while ((m0 | m1) != 0) {
+                    const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+                    const int nvj = j < 64 ? gs_readlane(node[0], j) : gs_readlane(node[1], j - 64);
+                    const u64 e0 = __ballot(node[0] == nvj), e1 = __ballot(node[1] == nvj);
+                    const int c = __popcll(e0) + __popcll(e1);
+                    m0 &= ~e0;
+                    m1 &= ~e1;
+                    bool first = true;
+                    if (LONG) {
+                        int f = 0;
+                        if (lane == 0) {
+                            f = gs_sc_load(tag + nvj) != serial;
+                            if (f) gs_sc_store(tag + nvj, serial);
+                            gs_sc_store(cnt + nvj, f ? c : gs_sc_load(cnt + nvj) + c);
                         }
-                        if (nvj >= 0) {  // a hit contig starts
-                            cur_start = pj;
-                            bool seen;
-                            if (LONG) {
-                                int sn = 0;
-                                if (lane == 0) {
-                                    sn = gs_sc_load(tag + nvj) == serial;
-                                    if (!sn) {
-                                        gs_sc_store(tag + nvj, serial);
-                                        gs_sc_store(cnt + nvj, 0);
-                                    }
-                                }
-                                seen = gs_rfl(sn) != 0;
-                            } else {
-                                seen = (__ballot(dviA == nvj) | __ballot(dviB == nvj)) != 0;
-                                if (!seen) {
-                                    if (nd < 64) {
-                                        if (lane == nd) dviA = nvj;
-                                    } else {
-                                        if (lane == nd - 64) dviB = nvj;
-                                    }
-                                    nd++;
-                                }
+                        first = gs_rfl(f) != 0;
+                    } else {  // one iteration per read: every node of the walk is new
+                        if (nd < 64) {
+                            if (lane == nd) {
+                                dviA = nvj;
+                                dcntA = c;
                             }
-                            // first k-mer of this tax id in the read (:434-439)
-                            if (!seen && lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
-                            if (P.classify) {  // mergeReadTaxidPath (:568-586)
-                                const int ntin = db.tin[nvj], ntout = db.tout[nvj];
-                                const bool mine = lane < used;
-                                const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
-                                const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
-                                const u64 m = __ballot(a || b);
-                                if (m) {
-                                    const int i = __builtin_ctzll(m);
-                                    if (lane == i && a) {
-                                        path = nvj;
-                                        ptin = ntin;
-                                        ptout = ntout;
-                                    }
-                                } else if (used < P.max_paths) {
-                                    if (lane == used) {
-                                        path = nvj;
-                                        ptin = ntin;
-                                        ptout = ntout;
-                                    }
-                                    used++;
+                        } else if (lane == nd - 64) {
+                            dviB = nvj;
+                            dcntB = c;
+                        }
+                        nd++;
+                    }
+                    if (first) {
+                        // first k-mer of this tax id in the read (:434-439)
+                        if (lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
+                        if (P.classify) {  // mergeReadTaxidPath (:568-586)
+                            const int ntin = db.tin[nvj], ntout = db.tout[nvj];
+                            const bool mine = lane < used;
+                            const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
+                            const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
+                            const u64 m = __ballot(a || b);
+                            if (m) {
+                                const int i = __builtin_ctzll(m);
+                                if (lane == i && a) {
+                                    path = nvj;
+                                    ptin = ntin;
+                                    ptout = ntout;
                                 }
+                            } else if (used < P.max_paths) {
+                                if (lane == used) {
+                                    path = nvj;
+                                    ptin = ntin;
+                                    ptout = ntout;
+                                }
+                                used++;
                             }
                         }
                     }
@@ -499,14 +508,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // tail flush (:455-473): the last contig if it is a hit contig
             if (carry_last >= 0) {
                 const int len = max - cur_start;
-                if (lane == 0) {
-                    st.contig(carry_last, len, key_lo);
-                    if (LONG) gs_sc_store(cnt + carry_last, gs_sc_load(cnt + carry_last) + len);
-                }
-                if (!LONG) {
-                    dcntA += (dviA == carry_last) ? len : 0;
-                    dcntB += (dviB == carry_last) ? len : 0;
-                }
+                if (lane == 0) st.contig(carry_last, len, key_lo);
             }
             // ---- 4c. classification (:474-531)
             if (P.classify) {
@@ -678,9 +680,9 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
     __shared__ uint32_t s_g[GS_BLOCK / 64][160];  // 15-mer order hashes of the wave's current 144 positions
     const int lane = gs_lane();
-    const int wave_in_block = threadIdx.x >> 6;
+    const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
-    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
     const int k = KC ? KC : P.db.k;
 #if GS_PREFETCH
     // pipeline registers: offsets two reads ahead, bases one read ahead
@@ -758,9 +760,9 @@ template <bool LDS_STATS, bool FROM_NODES>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
-    const int wave_in_block = threadIdx.x >> 6;
+    const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
-    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
     __shared__ uint32_t s_g[GS_BLOCK / 64][160];
     const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;

@@ -1,0 +1,40 @@
+#!/bin/bash
+# PMC passes over the match kernel (developer tool; run on the GPU box from the repo root):
+#   tools/pmc_passes.sh <tag> [python script + args ...]
+# One rocprofv3 --pmc run per counter group (never combined with trace domains), then a per-kernel summary
+# (mean over the full-size launches) in gpurun_out/pmc_<tag>.csv.
+set -u
+tag=${1:-x}
+shift
+if [ $# -eq 0 ]; then set -- tools/kernel_one.py; fi
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+out=gpurun_out/pmc_$tag
+mkdir -p "$out"
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
+           "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
+           "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i + 1))
+    timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d "$out/g$i" -o run -- python3 "$@" > "$out/g$i.log" 2>&1 || echo "pass $i failed" >> "$out/fail.log"
+    echo "pass $i done: $grp"
+done
+python3 - "$out" <<'EOF'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(list)
+for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "gs_match_kernel" in row["Kernel_Name"]:
+            acc[row["Counter_Name"]].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+with open(out + ".csv", "w") as o:
+    o.write("counter,value_per_launch,launches\n")
+    for name in sorted(acc):
+        g = max(x[0] for x in acc[name])
+        vals = [v for gs, v in acc[name] if gs == g]
+        o.write(f"{name},{sum(vals) / len(vals):.6g},{len(vals)}\n")
+print(open(out + ".csv").read())
+EOF
