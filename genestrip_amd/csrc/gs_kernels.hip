@@ -101,6 +101,9 @@ struct GsStats {
     u64 *sums;      // [nv][GS_N_SUMS]
     u64 *maxk;      // [nv]
     double *dsums;  // [nv][GS_N_DCOLS]
+    // the taxonomy next to the counters: LDS copies when the counters are in LDS (a tree walk is a chain of dependent
+    // loads; from HBM/L2 each link costs the better part of a microsecond), the store's arrays otherwise
+    const int32_t *parent, *tin, *tout;
     __device__ __forceinline__ void add(int vi, int col, u64 v) const { atomicAdd(&sums[(size_t)vi * GS_N_SUMS + col], v); }
     __device__ __forceinline__ void max(int vi, u64 key) const { atomicMax(&maxk[vi], key); }
     __device__ __forceinline__ void dadd(int vi, int col, double v) const { atomicAdd(&dsums[(size_t)vi * GS_N_DCOLS + col], v); }
@@ -188,11 +191,12 @@ __device__ __forceinline__ u64 gs_kmer_hash(uint32_t fhi, uint32_t flo, int k, u
 // is `a` an ancestor-or-self of `x`  (SmallTaxTree.isAncestorOf(x, a), SmallTaxTree.java:242-252)
 __device__ __forceinline__ bool gs_anc_or_self(int a_tin, int a_tout, int x_tin) { return a_tin <= x_tin && x_tin < a_tout; }
 
-__device__ int gs_lca(const GsDbDev &db, int a, int b) {  // SmallTaxTree.java:263-289, -1 == null
+template <typename Tree>
+__device__ __forceinline__ int gs_lca(const Tree &t, int a, int b) {  // SmallTaxTree.java:263-289, -1 == null
     if (a == b) return a;
     if (a < 0 || b < 0) return -1;
-    const int tb = db.tin[b];
-    while (a >= 0 && !gs_anc_or_self(db.tin[a], db.tout[a], tb)) a = db.parent[a];
+    const int tb = t.tin[b];
+    while (a >= 0 && !gs_anc_or_self(t.tin[a], t.tout[a], tb)) a = t.parent[a];
     return a;
 }
 
@@ -472,7 +476,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         // first k-mer of this tax id in the read (:434-439)
                         if (lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
                         if (P.classify) {  // mergeReadTaxidPath (:568-586)
-                            const int ntin = db.tin[nvj], ntout = db.tout[nvj];
+                            const int ntin = st.tin[nvj], ntout = st.tout[nvj];
                             const bool mine = lane < used;
                             const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
                             const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
@@ -520,13 +524,13 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     int sum = 0;
                     if (LONG) {
                         if (lane < used)
-                            for (int x = path; x >= 0; x = db.parent[x])
+                            for (int x = path; x >= 0; x = st.parent[x])
                                 if (gs_sc_load(tag + x) == serial) sum += gs_sc_load(cnt + x);
                     } else {
                         for (int dd = 0; dd < nd; dd++) {
                             const int v = dd < 64 ? gs_readlane(dviA, dd) : gs_readlane(dviB, dd - 64);
                             const int c = dd < 64 ? gs_readlane(dcntA, dd) : gs_readlane(dcntB, dd - 64);
-                            if (lane < used && gs_anc_or_self(db.tin[v], db.tout[v], ptin)) sum += c;
+                            if (lane < used && gs_anc_or_self(st.tin[v], st.tout[v], ptin)) sum += c;
                         }
                     }
                     // max + ties exactly as the in-place scan (:476-487); tie order = path order
@@ -555,7 +559,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         }
                         if ((tie_mask >> lane) & 1ULL) {
                             int acc = 0;
-                            for (int x = path; x >= 0 && mapped < 0; x = db.parent[x]) {
+                            for (int x = path; x >= 0 && mapped < 0; x = st.parent[x]) {
                                 if (LONG) {
                                     if (gs_sc_load(tag + x) == serial) {
                                         acc += gs_sc_load(cnt + x);
@@ -585,7 +589,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                                 first_node = x;
                                 first = false;
                             } else
-                                cn = gs_lca(db, cn, x);
+                                cn = gs_lca(st, cn, x);
                         }
                     }
                     out_class = cn;
@@ -596,14 +600,14 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         if (P.threshold > 1) {  // sumCounts(readTaxIdNode[0]) after the promotion (:506-507)
                             read_kmers = 0;
                             if (LONG) {
-                                for (int x = first_node; x >= 0; x = db.parent[x])
+                                for (int x = first_node; x >= 0; x = st.parent[x])
                                     if (gs_sc_load(tag + x) == serial) read_kmers += gs_sc_load(cnt + x);
                             } else {
-                                const int ft = db.tin[first_node];
+                                const int ft = st.tin[first_node];
                                 for (int dd = 0; dd < nd; dd++) {
                                     const int v = dd < 64 ? gs_readlane(dviA, dd) : gs_readlane(dviB, dd - 64);
                                     const int c = dd < 64 ? gs_readlane(dcntA, dd) : gs_readlane(dcntB, dd - 64);
-                                    if (gs_anc_or_self(db.tin[v], db.tout[v], ft)) read_kmers += c;
+                                    if (gs_anc_or_self(st.tin[v], st.tout[v], ft)) read_kmers += c;
                                 }
                             }
                         }
@@ -637,7 +641,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
-// dynamic LDS: [nv*GS_N_SUMS u64 sums][nv u64 max keys][nv*GS_N_DCOLS doubles] -- sized to the store's value count
+// dynamic LDS: [nv*GS_N_SUMS u64 sums][nv u64 max keys][nv*GS_N_DCOLS doubles][3*nv int32 tree] -- sized to the store's value count
 // so that small taxonomies do not cap the occupancy
 #define GS_STATS_PROLOGUE()                                                                           \
     extern __shared__ __attribute__((aligned(16))) unsigned char gs_dyn_lds[];                        \
@@ -645,10 +649,16 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
     u64 *s_sums = reinterpret_cast<u64 *>(gs_dyn_lds);                                                \
     u64 *s_max = s_sums + (LDS_STATS ? nv * GS_N_SUMS : 0);                                           \
     double *s_d = reinterpret_cast<double *>(s_max + (LDS_STATS ? nv : 0));                           \
+    int32_t *s_tree = reinterpret_cast<int32_t *>(s_d + (LDS_STATS ? nv * GS_N_DCOLS : 0));           \
     if (LDS_STATS) {                                                                                  \
         for (int i = threadIdx.x; i < nv * GS_N_SUMS; i += blockDim.x) s_sums[i] = 0;                 \
         for (int i = threadIdx.x; i < nv; i += blockDim.x) s_max[i] = 0;                              \
         for (int i = threadIdx.x; i < nv * GS_N_DCOLS; i += blockDim.x) s_d[i] = 0.0;                 \
+        for (int i = threadIdx.x; i < nv; i += blockDim.x) {                                          \
+            s_tree[i] = P.db.parent[i];                                                               \
+            s_tree[nv + i] = P.db.tin[i];                                                             \
+            s_tree[2 * nv + i] = P.db.tout[i];                                                        \
+        }                                                                                             \
         __syncthreads();                                                                              \
     }                                                                                                 \
     GsStats st;                                                                                       \
@@ -656,10 +666,16 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         st.sums = s_sums;                                                                             \
         st.maxk = s_max;                                                                              \
         st.dsums = s_d;                                                                               \
+        st.parent = s_tree;                                                                           \
+        st.tin = s_tree + nv;                                                                         \
+        st.tout = s_tree + 2 * nv;                                                                    \
     } else {                                                                                          \
         st.sums = (u64 *)P.sums;                                                                      \
         st.maxk = (u64 *)P.max_keys;                                                                  \
         st.dsums = P.dsums;                                                                           \
+        st.parent = P.db.parent;                                                                      \
+        st.tin = P.db.tin;                                                                            \
+        st.tout = P.db.tout;                                                                          \
     }
 
 #define GS_STATS_EPILOGUE()                                                                           \
@@ -1195,7 +1211,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
 // launchers (called from gs_api.cpp)
 // ---------------------------------------------------------------------------------------------------
 static size_t gs_stats_lds_bytes(int n_values) {
-    return n_values <= GS_NV_LDS ? (size_t)n_values * (GS_N_SUMS + 1 + GS_N_DCOLS) * 8 : 0;
+    return n_values <= GS_NV_LDS ? (size_t)n_values * ((GS_N_SUMS + 1 + GS_N_DCOLS) * 8 + 3 * 4) : 0;
 }
 
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
