@@ -22,19 +22,4 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
     timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d "$out/g$i" -o run -- python3 "$@" > "$out/g$i.log" 2>&1 || echo "pass $i failed" >> "$out/fail.log"
     echo "pass $i done: $grp"
 done
-python3 - "$out" <<'EOF'
-import csv, glob, sys, collections
-out = sys.argv[1]
-acc = collections.defaultdict(list)
-for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "gs_match_kernel" in row["Kernel_Name"]:
-            acc[row["Counter_Name"]].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
-with open(out + ".csv", "w") as o:
-    o.write("counter,value_per_launch,launches\n")
-    for name in sorted(acc):
-        g = max(x[0] for x in acc[name])
-        vals = [v for gs, v in acc[name] if gs == g]
-        o.write(f"{name},{sum(vals) / len(vals):.6g},{len(vals)}\n")
-print(open(out + ".csv").read())
-EOF
+python3 tools/pmc_summary.py "$out"
