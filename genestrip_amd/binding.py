@@ -34,6 +34,8 @@ ABI_SYMBOLS = (
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
+    "gs_match_submit_text", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
+    "gs_pinned_alloc", "gs_pinned_free",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -109,6 +111,10 @@ def lib():
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
         "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
+        "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
+        "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
+        "gs_match_text_clear_error": (ci, [vp]),
+        "gs_pinned_alloc": (ci, [vp, C.c_size_t]), "gs_pinned_free": (ci, [vp]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
@@ -255,6 +261,36 @@ class FastqKMerMatcher:
             seq = np.zeros(1, dtype=np.uint8)
         self.submit(seq, offsets, first_read_no, cv, fl)
         return cv, fl
+
+    def submit_text(self, text, n_lines=None, first_read_no=0, class_vi=None, flags=None):
+        """raw FASTQ text of whole 4-line records (numpy uint8 / bytes on the host, or a device tensor): the records
+        are found on the device (gs_match_submit_text).  Returns the ticket."""
+        if isinstance(text, (bytes, bytearray)):
+            text = np.frombuffer(bytes(text), dtype=np.uint8)
+        if n_lines is None:
+            n_lines = int((text == 10).sum())
+        n_bytes = int(text.shape[0])
+        pt, mem = _ptr(text) if n_bytes else (None, MEM_HOST)
+        pc, _ = _ptr(class_vi)
+        pf, _ = _ptr(flags)
+        _ready(text, class_vi, flags)
+        ticket = C.c_int64(-1)
+        self._text_keep = text  # the copy is asynchronous
+        _check(lib().gs_match_submit_text(self.h, pt, n_bytes, int(n_lines), mem, first_read_no, pc, pf, C.byref(ticket)))
+        return ticket.value
+
+    def text_wait_copy(self, ticket):
+        _check(lib().gs_match_text_wait_copy(self.h, ticket))
+
+    def text_status(self):
+        """(failed_ticket or -1, first_bad_record or -1, (reads, kmers, bases) accepted so far); synchronises"""
+        ft, fb = C.c_int64(-1), C.c_int64(-1)
+        tot = (C.c_int64 * 3)()
+        _check(lib().gs_match_text_status(self.h, C.byref(ft), C.byref(fb), tot))
+        return ft.value, fb.value, tuple(tot)
+
+    def text_clear_error(self):
+        _check(lib().gs_match_text_clear_error(self.h))
 
     def sync(self):
         _check(lib().gs_match_sync(self.h))

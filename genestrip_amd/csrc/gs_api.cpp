@@ -491,6 +491,17 @@ struct gs_run {
     u64 *d_seg_off = nullptr;
     int32_t *d_seg_code = nullptr, *d_seg_start = nullptr;
     int64_t seg_total = 0;
+    // text mode (gs_match_submit_text): raw FASTQ chunk, newline offsets, (start, end) pairs, scan state
+    uint8_t *d_text = nullptr;
+    size_t text_cap = 0;
+    uint32_t *d_tile = nullptr, *d_nl = nullptr;
+    size_t tile_cap = 0, nl_cap = 0;
+    u64 *d_off2 = nullptr;
+    size_t off2_cap = 0;
+    uint32_t *d_tstatus = nullptr;  // GS_TS_WORDS
+    u64 *d_ttotals = nullptr;       // [3] chunk scratch | [3] run totals
+    hipEvent_t copied[8] = {};      // H2D of ticket t has completed: copied[t % 8]
+    int64_t tickets = 0;
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
@@ -538,6 +549,14 @@ static void run_free(gs_run *run) {
     hipFree(run->d_seg_off);
     hipFree(run->d_seg_code);
     hipFree(run->d_seg_start);
+    hipFree(run->d_text);
+    hipFree(run->d_tile);
+    hipFree(run->d_nl);
+    hipFree(run->d_off2);
+    hipFree(run->d_tstatus);
+    hipFree(run->d_ttotals);
+    for (hipEvent_t ev : run->copied)
+        if (ev) hipEventDestroy(ev);
     if (run->stream) hipStreamDestroy(run->stream);
     delete run;
 }
@@ -625,7 +644,7 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
 
 static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int64_t first_read_no,
                         int32_t *d_class, uint8_t *d_flags, const int32_t *d_nodes = nullptr,
-                        const uint64_t *d_pos_off = nullptr) {
+                        const uint64_t *d_pos_off = nullptr, int off_stride = 1, const uint32_t *d_skip = nullptr) {
     if (n_reads > (int64_t)0xffffffffLL) return fail(GS_E_INVALID, "more than 2^32-1 reads in one batch");
     int rc = ensure_long(run, n_reads);
     if (rc) return rc;
@@ -652,6 +671,8 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.long_list = run->d_long_list;
     P.nodes = d_nodes;
     P.pos_off = (const unsigned long long *)d_pos_off;
+    P.off_stride = off_stride;
+    P.skip = d_skip;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + (GS_BLOCK / 64) - 1) / (GS_BLOCK / 64));
     if (grid < 1) grid = 1;
@@ -727,6 +748,157 @@ extern "C" int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *
     return collect_events(run);
 }
 
+// ---- text mode: raw 4-line FASTQ chunks, records found on the device (gs_text.hip) ------------------------------
+extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket, hipStream_t stream);
+
+extern "C" int gs_pinned_alloc(void **p, size_t bytes) {
+    if (!p) return fail(GS_E_INVALID, "NULL argument");
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+
+extern "C" int gs_pinned_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return GS_OK;
+}
+
+template <typename T>
+static int grow(T **p, size_t *cap, size_t need, hipStream_t stream) {
+    if (*cap >= need) return GS_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 4;
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return GS_OK;
+}
+
+static int text_reset(gs_run *run, bool totals) {
+    if (!run->d_tstatus) return GS_OK;
+    HIP_TRY(hipMemsetAsync(run->d_tstatus, 0, sizeof(uint32_t) * GS_TS_WORDS, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_tstatus + GS_TS_FIRST_BAD, 0xff, sizeof(uint32_t), run->stream));
+    if (totals) HIP_TRY(hipMemsetAsync(run->d_ttotals, 0, sizeof(u64) * 6, run->stream));
+    return GS_OK;
+}
+
+static int text_init(gs_run *run) {
+    if (run->d_tstatus) return GS_OK;
+    HIP_TRY(hipMalloc((void **)&run->d_tstatus, sizeof(uint32_t) * GS_TS_WORDS));
+    HIP_TRY(hipMalloc((void **)&run->d_ttotals, sizeof(u64) * 6));
+    int rc = text_reset(run, true);
+    if (rc) return rc;
+    for (hipEvent_t &ev : run->copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return GS_OK;
+}
+
+extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
+                                    int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (n_bytes < 0 || n_lines < 0 || (n_lines & 3) != 0 || (n_bytes > 0 && !text) || n_lines > n_bytes)
+        return fail(GS_E_INVALID, "bad text chunk (n_lines must be a multiple of 4)");
+    if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    HIP_TRY(hipSetDevice(run->db->device));
+    int rc = text_init(run);
+    if (rc) return rc;
+    const int64_t n_reads = n_lines >> 2;
+    const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
+    if ((rc = grow(&run->d_text, &run->text_cap, padded + 4096, run->stream))) return rc;
+    if ((rc = grow(&run->d_tile, &run->tile_cap, padded / 4096 + 1, run->stream))) return rc;
+    if ((rc = grow(&run->d_nl, &run->nl_cap, (size_t)n_lines + 4, run->stream))) return rc;
+    if ((rc = grow(&run->d_off2, &run->off2_cap, 2 * (size_t)n_reads + 2, run->stream))) return rc;
+    if ((class_vi || flags) && run->reads_cap < (size_t)n_reads) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_off);
+        hipFree(run->d_class);
+        hipFree(run->d_flags);
+        run->d_off = nullptr;
+        run->d_class = nullptr;
+        run->d_flags = nullptr;
+        run->reads_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+        HIP_TRY(hipMalloc((void **)&run->d_class, sizeof(int32_t) * (size_t)n_reads));
+        HIP_TRY(hipMalloc((void **)&run->d_flags, (size_t)n_reads));
+        run->reads_cap = (size_t)n_reads;
+    }
+    const int64_t t = run->tickets;
+    hipEvent_t ev = run->copied[t & 7];
+    if (n_bytes > 0)
+        HIP_TRY(hipMemcpyAsync(run->d_text, text, (size_t)n_bytes, mem == GS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                               run->stream));
+    HIP_TRY(hipEventRecord(ev, run->stream));
+    if (padded > (size_t)n_bytes) HIP_TRY(hipMemsetAsync(run->d_text + n_bytes, ' ', padded - (size_t)n_bytes, run->stream));
+    GsTextParams T{};
+    T.text = run->d_text;
+    T.n_bytes = n_bytes;
+    T.n_lines = n_lines;
+    T.tile_count = run->d_tile;
+    T.nl = run->d_nl;
+    T.off2 = (unsigned long long *)run->d_off2;
+    T.chunk_totals = (unsigned long long *)run->d_ttotals;
+    T.run_totals = (unsigned long long *)run->d_ttotals + 3;
+    T.status = run->d_tstatus;
+    T.k = run->db->info.k;
+    HIP_TRY(gs_launch_text_scan(&T, (uint32_t)t, run->stream));
+    run->tickets = t + 1;
+    if (ticket) *ticket = t;
+    if (n_reads == 0) return GS_OK;
+    const bool dev_out = mem == GS_MEM_DEVICE;
+    int32_t *dc = class_vi ? (dev_out ? class_vi : run->d_class) : nullptr;
+    uint8_t *df = flags ? (dev_out ? flags : run->d_flags) : nullptr;
+    rc = launch_batch(run, run->d_text, (const uint64_t *)run->d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
+                      run->d_tstatus + GS_TS_SKIP);
+    if (rc) return rc;
+    if (!dev_out) {  // complete after gs_match_sync
+        if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_match_text_wait_copy(gs_run *run, int64_t ticket) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (ticket < 0 || ticket >= run->tickets) return fail(GS_E_INVALID, "unknown ticket");
+    if (ticket + 8 <= run->tickets) return GS_OK;  // its event has been re-recorded by a later submit: long done
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(hipEventSynchronize(run->copied[ticket & 7]));
+    return GS_OK;
+}
+
+extern "C" int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (failed_ticket) *failed_ticket = -1;
+    if (first_bad_record) *first_bad_record = -1;
+    if (totals) totals[0] = totals[1] = totals[2] = 0;
+    if (!run->d_tstatus) return GS_OK;
+    uint32_t st[GS_TS_WORDS];
+    u64 tt[6];
+    HIP_TRY(hipMemcpyAsync(st, run->d_tstatus, sizeof(st), hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipMemcpyAsync(tt, run->d_ttotals, sizeof(tt), hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    int rc = collect_events(run);
+    if (rc) return rc;
+    if (st[GS_TS_STICKY]) {
+        if (failed_ticket) *failed_ticket = (int64_t)st[GS_TS_FAILED_TICKET];
+        if (first_bad_record && st[GS_TS_FIRST_BAD] != 0xffffffffu) *first_bad_record = (int64_t)st[GS_TS_FIRST_BAD];
+    }
+    if (totals)
+        for (int i = 0; i < 3; i++) totals[i] = (int64_t)tt[3 + i];
+    return GS_OK;
+}
+
+extern "C" int gs_match_text_clear_error(gs_run *run) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (!run->d_tstatus) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    return text_reset(run, false);
+}
+
 extern "C" int gs_match_sync(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
@@ -780,7 +952,9 @@ extern "C" int gs_match_reset(gs_run *run) {
     if (!run->pending.empty()) HIP_TRY(hipStreamSynchronize(run->stream));
     int rc = collect_events(run);
     if (rc) return rc;
-    return run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
+    rc = run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
+    if (rc) return rc;
+    return text_reset(run, true);
 }
 
 extern "C" int gs_match_destroy(gs_run *run) {

@@ -121,11 +121,8 @@ struct GsStats {
 // ---------------------------------------------------------------------------------------------------
 typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 
-#ifndef GS_PREFETCH
-// Software pipelining of the next read's bases behind the bucket loads (GsPrefetch).  Measured on MI355X: the
-// extra registers cost one wave per SIMD and the net effect is nil (13.3 ms either way), so it is off.
-#define GS_PREFETCH 0
-#endif
+// (Software pipelining of the next read's bases behind the bucket loads was measured on MI355X: the extra registers
+// cost one wave per SIMD and the net effect was nil, so GsPrefetch::issue is never armed.)
 
 #ifndef GS_NT_TABLE
 // Measured on MI355X: non-temporal bucket loads stop the four dwordx4 loads of one 64-byte line from sharing a
@@ -700,49 +697,6 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
     const int k = KC ? KC : P.db.k;
-#if GS_PREFETCH
-    // pipeline registers: offsets two reads ahead, bases one read ahead
-    int64_t r = wave_id;
-    u64 off_a = 0, off_b = 0, noff_a = 0, noff_b = 0;
-    GsPrefetch pf;
-    pf.rd = nullptr;
-    pf.L = 0;
-    pf.c[0] = pf.c[1] = pf.c[2] = 0;
-    if (r < P.n_reads) {
-        off_a = P.off[r];
-        off_b = P.off[r + 1];
-        pf.rd = P.seq + off_a;
-        pf.L = (int)(off_b - off_a);
-        pf.issue(lane);
-    }
-    if (r + n_waves < P.n_reads) {
-        noff_a = P.off[r + n_waves];
-        noff_b = P.off[r + n_waves + 1];
-    }
-    for (; r < P.n_reads; r += n_waves) {
-        const int L = (int)(off_b - off_a);
-        const uint32_t pre[3] = {pf.c[0], pf.c[1], pf.c[2]};
-        const u64 off = off_a;
-        // rotate the pipeline: the next read's bases are fetched inside gs_process_read, behind the bucket loads
-        const bool has_next = r + n_waves < P.n_reads;
-        off_a = noff_a;
-        off_b = noff_b;
-        pf.rd = has_next ? P.seq + off_a : nullptr;
-        pf.L = (int)(off_b - off_a);
-        if (r + 2 * n_waves < P.n_reads) {
-            noff_a = P.off[r + 2 * n_waves];
-            noff_b = P.off[r + 2 * n_waves + 1];
-        }
-        if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
-            if (lane == 0) P.long_list[atomicAdd(P.long_count, 1u)] = (uint32_t)r;
-            pf.issue(lane);
-            continue;
-        }
-        if (L - k + 1 <= 0) pf.issue(lane);  // gs_process_read skips its body (and the prefetch) for such reads
-        gs_process_read<false, FROM_NODES, KC>(P, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
-                                           s_g[wave_in_block]);
-    }
-#else
     GsPrefetch pf;
     pf.rd = nullptr;
     // The ~40 launch parameters do not fit the scalar register file next to the ballot planes; kept live across
@@ -751,13 +705,15 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))
     // pointer is loop invariant, so the s_loads stay inside the loop.
     typedef const __attribute__((address_space(4))) GsMatchParams *GsKernargPtr;
     const GsKernargPtr kp0 = (GsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    const int64_t n_reads = P.n_reads;
+    // text mode: a chunk that the device-side record scan refused is skipped as a whole (gs_text.hip)
+    const int64_t n_reads = (P.skip != nullptr && *P.skip != 0) ? 0 : P.n_reads;
     for (int64_t r = wave_id; r < n_reads; r += n_waves) {
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
         const GsMatchParams &Q = *(const GsMatchParams *)kp;
-        const u64 off = Q.off[r];
-        const int L = (int)(Q.off[r + 1] - off);
+        const uint64_t *po = Q.off + r * Q.off_stride;  // stride 1: running offsets; 2: (start, end) pairs
+        const u64 off = po[0];
+        const int L = (int)(po[1] - off);
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
             if (lane == 0) Q.long_list[atomicAdd(Q.long_count, 1u)] = (uint32_t)r;
             continue;
@@ -768,7 +724,6 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))
         gs_process_read<false, FROM_NODES, KC>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
                                            s_g[wave_in_block]);
     }
-#endif
     GS_STATS_EPILOGUE()
 }
 
@@ -788,11 +743,12 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         serial++;
         if (serial == 0) serial = 1;  // tags start zeroed; a wrap after 2^32 reads per wave may alias once
         const int64_t r = (int64_t)P.long_list[i];
-        const u64 off = P.off[r];
+        const uint64_t *po = P.off + r * P.off_stride;
+        const u64 off = po[0];
         const uint32_t none[3] = {0, 0, 0};
         GsPrefetch nopf;
         nopf.rd = nullptr;
-        gs_process_read<true, FROM_NODES, 0>(P, st, r, off, (int)(P.off[r + 1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+        gs_process_read<true, FROM_NODES, 0>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
                               (int)serial, none, nopf, s_g[wave_in_block]);
     }
     if (lane == 0) serials[wave_id] = serial;

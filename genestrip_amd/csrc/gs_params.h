@@ -28,6 +28,30 @@ struct GsMatchParams {
     // DB-partitioned mode only: node of every k-mer position, looked up by the owning rank (nullptr: probe locally)
     const int32_t *nodes;
     const unsigned long long *pos_off;  // n_reads + 1: first position of read r in `nodes`
+    // text mode (gs_match_submit_text): `off` holds (start, end) PAIRS of the in-place sequence lines (off_stride 2,
+    // else 1: n_reads + 1 running offsets), and the whole launch is skipped when *skip != 0 (chunk refused by the
+    // device-side record scan, gs_text.hip)
+    int32_t off_stride;
+    int32_t pad1;
+    const uint32_t *skip;
+};
+
+// device-side FASTQ record scan (gs_text.hip)
+enum { GS_TS_STICKY = 0, GS_TS_CHUNK_ERR = 1, GS_TS_FIRST_BAD = 2, GS_TS_SKIP = 3, GS_TS_FAILED_TICKET = 4, GS_TS_WORDS = 8 };
+enum { GS_TE_NUL = 1, GS_TE_COUNT = 2, GS_TE_SHAPE = 4 };
+
+struct GsTextParams {
+    const uint8_t *text;   // n_bytes, padded with blanks to a multiple of 4096
+    int64_t n_bytes;
+    int64_t n_lines;       // newlines the host counted (a multiple of 4)
+    uint32_t *tile_count;  // one per 4096-byte tile
+    uint32_t *nl;          // n_lines newline offsets
+    unsigned long long *off2;          // 2 * (n_lines / 4): (start, end) of every record's sequence line
+    unsigned long long *chunk_totals;  // [3] scratch: -, k-mers, bases of this chunk
+    unsigned long long *run_totals;    // [3] reads, k-mers, bases accepted so far
+    uint32_t *status;      // GS_TS_WORDS words
+    int32_t k;
+    int32_t pad;
 };
 
 struct GsFilterParams {

@@ -144,6 +144,29 @@ int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *offsets, in
                     int64_t first_read_no, int mem, int32_t *class_vi, uint8_t *flags);
 int gs_match_sync(gs_run *run);
 
+/* Text mode: a chunk of RAW FASTQ text made of whole four-line records; the device finds the records itself
+ * (replaces the producer-thread parse of AbstractFastqReader.doReadFastq, C/fastq/AbstractFastqReader.java:288-368,
+ * for the common file shape; read i of the chunk is its (4i+2)-th line, '\r' kept, readNo = first_read_no + i).
+ * n_lines = number of '\n' in the chunk as counted by the caller: a multiple of 4, the chunk ends with one.
+ * The chunk is REFUSED on the device -- nothing of it, nor of any later text chunk, reaches the run's state -- if
+ * it is not exactly what the reference would split into one record per four lines: a NUL byte (the reference drops
+ * those, B/io/BufferedLineReader.java:176-178), a third line that does not start with '+' (multi-line sequence,
+ * :301-308), a quality line shorter than its sequence (:320-341), or a newline count other than n_lines.
+ * gs_match_text_status reports the ticket of the first refused chunk (-1: none); the caller re-parses from there
+ * with the general parser, calls gs_match_text_clear_error and goes on.  Asynchronous: with GS_MEM_HOST the text
+ * must stay untouched until gs_match_text_wait_copy(ticket) returns (use gs_pinned_alloc for overlap); class_vi /
+ * flags (n_lines / 4 entries, same memory kind as text, may be NULL) are complete after gs_match_sync.
+ * totals[3] = reads, k-mers (sum of max(0, L-k+1)) and bases of all ACCEPTED chunks since begin/reset
+ * (AbstractFastqReader.java:343-349).  Chunks are limited to 1 GiB. */
+int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
+                         int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket);
+int gs_match_text_wait_copy(gs_run *run, int64_t ticket);
+int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
+int gs_match_text_clear_error(gs_run *run);
+/* page-locked host memory for the text blocks (so that the H2D copy overlaps the caller's file reads) */
+int gs_pinned_alloc(void **p, size_t bytes);
+int gs_pinned_free(void *p);
+
 /* table: n_values x GS_N_COLS int64 ; dtable (may be NULL): n_values x GS_N_DCOLS double (sums of doubles
  * accumulate in device order: not bit-reproducible, as with threads > 0 in the reference).  Host pointers. */
 int gs_match_finish(gs_run *run, int64_t *table, double *dtable);
