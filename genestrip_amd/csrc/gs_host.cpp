@@ -4,6 +4,9 @@
 // the C ABI of include/gsgpu.h.
 #include "../../include/gshost.h"
 
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -50,12 +53,18 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // ---------------------------------------------------------------------------------------------------
 class LineReader {
 public:
-    bool open(const std::string &path) {
+    bool open(const std::string &path, int64_t offset = 0) {
         gz_ = gzopen(path.c_str(), "rb");  // zlib reads plain files transparently, gzip by content
         if (!gz_) return false;
         gzbuffer(gz_, 1 << 20);
         buf_.resize(1 << 20);
-        return true;
+        return offset == 0 || gzseek(gz_, (z_off_t)offset, SEEK_SET) == (z_off_t)offset;
+    }
+    void open_mem(const uint8_t *p, size_t n) {  // a byte range that is already in memory
+        buf_.assign(p, p + n);
+        fill_ = n;
+        pos_ = 0;
+        eof_ = true;
     }
     ~LineReader() {
         if (gz_) gzclose(gz_);
@@ -116,7 +125,8 @@ struct Batch {
 class FastqParser {
 public:
     FastqParser(int k, bool fasta) : k_(k), fasta_(fasta) {}
-    bool open(const std::string &path) { return lr_.open(path); }
+    bool open(const std::string &path, int64_t offset = 0) { return lr_.open(path, offset); }
+    void open_mem(const uint8_t *p, size_t n) { lr_.open_mem(p, n); }
 
     // appends up to max_reads records / max_bytes sequence bytes to b; returns false at end of file
     bool parse(Batch &b, int64_t max_reads, int64_t max_bytes) {
@@ -388,21 +398,25 @@ extern "C" int gs_host_java_double(double v, char *buf, int cap) {
 
 namespace {
 
-// parse all files on a producer thread; the consumer gets batches in file order; a null batch ends the stream
+// parse one source on a producer thread; the consumer gets batches in order; a null batch ends the stream
 struct Producer {
     std::thread th;
     BatchQueue q;
     int64_t reads = 0, kmers = 0, bps = 0;
     double seconds = 0;
     std::string error;
-    void start(const std::vector<std::string> &paths, int k, int64_t batch_reads) {
-        th = std::thread([this, paths, k, batch_reads] {
-            for (const std::string &p : paths) {
-                FastqParser parser(k, is_fasta_name(p));
-                if (!parser.open(p)) {
-                    error = "cannot open " + p;
-                    break;
-                }
+    // path from byte `offset` on, or the memory range [mem, mem + mem_n) when path is empty
+    void start(const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int k, int64_t batch_reads) {
+        th = std::thread([this, path, offset, mem, mem_n, k, batch_reads] {
+            FastqParser parser(k, !path.empty() && is_fasta_name(path));
+            bool ok_open = true;
+            if (path.empty())
+                parser.open_mem(mem, mem_n);
+            else
+                ok_open = parser.open(path, offset);
+            if (!ok_open) {
+                error = "cannot open " + path;
+            } else {
                 for (;;) {
                     auto b = std::make_unique<Batch>();
                     const double t0 = now_s();
@@ -411,14 +425,363 @@ struct Producer {
                     if (!ok) break;
                     q.push(std::move(b));
                 }
-                reads += parser.reads_;  // totalReads += reads (AbstractLoggingFastqStreamer.java:123-125)
-                kmers += parser.kmers_;
-                bps += parser.bps_;
+                reads = parser.reads_;  // totalReads += reads (AbstractLoggingFastqStreamer.java:123-125)
+                kmers = parser.kmers_;
+                bps = parser.bps_;
             }
             q.push(nullptr);
         });
     }
 };
+
+// ---- fast path for plain four-line FASTQ: reader threads fill pinned blocks, the device finds the records -----------
+// (gs_match_submit_text).  The host only counts newlines to cut the stream at record boundaries.
+size_t count_newlines(const uint8_t *p, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; i++) c += p[i] == '\n';  // vectorised by the compiler
+    return c;
+}
+
+struct TextSlot {
+    uint8_t *buf = nullptr;  // pinned: headroom (for the carried partial record) + block
+    size_t n = 0;            // bytes read into the block
+    int64_t newlines = 0;
+    int64_t last4[4] = {-1, -1, -1, -1};  // offsets of the last four newlines of the block, last first
+    int state = 0;           // 0 empty, 1 full
+    bool eof = false, io_error = false;
+};
+
+struct TextReader {
+    int fd = -1;
+    size_t block = 0, headroom = 0;
+    int n_slots = 0, n_threads = 0;
+    std::vector<TextSlot> slots;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    int64_t start_off = 0;
+
+    int open(const std::string &path, size_t block_bytes, int readers) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
+#ifdef POSIX_FADV_SEQUENTIAL
+        posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+#endif
+        block = block_bytes;
+        headroom = block_bytes;
+        n_threads = readers;
+        n_slots = 2 * readers;
+        slots.resize((size_t)n_slots);
+        for (auto &sl : slots) {
+            void *p = nullptr;
+            int rc = gs_pinned_alloc(&p, headroom + block);
+            if (rc) return rc;
+            sl.buf = (uint8_t *)p;
+        }
+        return GS_OK;
+    }
+    void start() {
+        for (int t = 0; t < n_threads; t++)
+            threads.emplace_back([this, t] {
+                for (int64_t i = t;; i += n_threads) {
+                    TextSlot &sl = slots[(size_t)(i % n_slots)];
+                    {
+                        std::unique_lock<std::mutex> l(m);
+                        cv.wait(l, [&] { return stop || sl.state == 0; });
+                        if (stop) return;
+                    }
+                    uint8_t *dst = sl.buf + headroom;
+                    size_t got = 0;
+                    bool err = false;
+                    while (got < block) {
+                        const ssize_t r = pread(fd, dst + got, block - got, (off_t)(start_off + i * (int64_t)block + (int64_t)got));
+                        if (r < 0) {
+                            if (errno == EINTR) continue;
+                            err = true;
+                            break;
+                        }
+                        if (r == 0) break;
+                        got += (size_t)r;
+                    }
+                    sl.n = got;
+                    sl.eof = got < block;
+                    sl.io_error = err;
+                    sl.newlines = (int64_t)count_newlines(dst, got);
+                    size_t end = got;
+                    for (int j = 0; j < 4; j++) {
+                        const void *q = end ? memrchr(dst, '\n', end) : nullptr;
+                        sl.last4[j] = q ? (int64_t)((const uint8_t *)q - dst) : -1;
+                        end = q ? (size_t)((const uint8_t *)q - dst) : 0;
+                    }
+                    {
+                        std::lock_guard<std::mutex> l(m);
+                        sl.state = 1;
+                    }
+                    cv.notify_all();
+                    if (sl.eof || err) return;  // later blocks are past the end: the consumer stops at this one
+                }
+            });
+    }
+    TextSlot &wait_full(int64_t i) {
+        TextSlot &sl = slots[(size_t)(i % n_slots)];
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return sl.state == 1; });
+        return sl;
+    }
+    void release(int64_t i) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            slots[(size_t)(i % n_slots)].state = 0;
+        }
+        cv.notify_all();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+        for (auto &sl : slots) gs_pinned_free(sl.buf);
+        slots.clear();
+        if (fd >= 0) ::close(fd);
+        fd = -1;
+    }
+};
+
+bool plain_fastq_file(const std::string &path) {
+    if (is_fasta_name(path) || is_gzip_name(path)) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char mg[2] = {0, 0};
+    const size_t n = fread(mg, 1, 2, f);
+    fclose(f);
+    return !(n == 2 && mg[0] == 0x1f && mg[1] == 0x8b);  // gzip content under another name: zlib path
+}
+
+}  // namespace
+
+namespace {
+
+// everything one runMatcher call carries from batch to batch
+struct MatchCtx {
+    gs_run *run = nullptr;
+    gs_db_info info{};
+    const gs_host_match_opts *opts = nullptr;
+    OutFile filtered, kraken;
+    std::vector<int32_t> cls, seg_code, seg_start;
+    std::vector<uint8_t> flags, tmp;
+    std::vector<uint64_t> seg_off;
+    std::string line;
+    int64_t global_read_no = 0, filtered_reads = 0;  // read numbers run over all files of the call (file order)
+    int64_t reads = 0, kmers = 0, bps = 0;
+    double t_gpu = 0, t_parse = 0;
+};
+
+// one parsed batch through the GPU and the per-read writers
+int consume_batch(MatchCtx &c, Batch &b) {
+    const int64_t n = b.n();
+    c.cls.resize((size_t)n);
+    c.flags.resize((size_t)n);
+    if (b.seq.empty()) b.seq.push_back(0);
+    const double t0 = now_s();
+    int err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, c.global_read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
+    if (!err && c.kraken.active()) {
+        c.seg_off.resize((size_t)n + 1);
+        err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, c.seg_off.data());
+        if (!err) {
+            c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
+            c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
+            err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
+        }
+    }
+    c.t_gpu += now_s() - t0;
+    if (err) return err;
+    c.global_read_no += n;
+    const gs_host_match_opts *opts = c.opts;
+    for (int64_t i = 0; i < n; i++) {
+        if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
+            write_read(c.filtered, b, i, false, c.tmp);
+            c.filtered_reads++;
+        }
+        if (c.kraken.active()) {  // MatcherReadEntry.writeMatchDetails (:723-756)
+            const uint64_t s0 = c.seg_off[(size_t)i], s1 = c.seg_off[(size_t)i + 1];
+            const int32_t cl = c.cls[(size_t)i];
+            if (s1 == s0 || !(opts->write_all || cl >= 0)) continue;
+            const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
+            const int64_t maxp = L - c.info.k + 1;
+            std::string &line = c.line;
+            line.assign(cl >= 0 ? "C\t" : "U\t");
+            const size_t d0 = b.desc_off[(size_t)i], d1 = b.desc_off[(size_t)i + 1];
+            size_t de = d1;
+            for (size_t j = d0 + 1; j < d1; j++)
+                if (b.desc[j] == ' ') {
+                    de = j;
+                    break;
+                }
+            if (d1 > d0 + 1) line.append((const char *)b.desc.data() + d0 + 1, de - d0 - 1);
+            line.push_back('\t');
+            line.append(cl >= 0 ? opts->taxids[cl] : "0");
+            line.push_back('\t');
+            append_int(line, L);
+            line.push_back('\t');
+            for (uint64_t sg = s0; sg < s1; sg++) {
+                if (sg > s0) line.push_back(' ');
+                const int32_t code = c.seg_code[(size_t)sg];
+                if (code == -2)
+                    line.push_back('A');
+                else if (code < 0)
+                    line.push_back('0');
+                else
+                    line.append(opts->taxids[code]);
+                line.push_back(':');
+                append_int(line, (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg]);
+            }
+            line.push_back('\n');
+            c.kraken.write(line.data(), line.size());
+        }
+    }
+    return GS_OK;
+}
+
+// the general path: the reference's record parser on a producer thread (file from `offset`, or a memory range)
+int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n) {
+    Producer prod;
+    prod.start(path, offset, mem, mem_n, c.info.k, c.opts->batch_reads > 0 ? c.opts->batch_reads : (int64_t)1 << 20);
+    int err = GS_OK;
+    for (;;) {
+        std::unique_ptr<Batch> b = prod.q.pop();
+        if (!b) break;
+        if (err) continue;  // keep draining so the producer can finish
+        err = consume_batch(c, *b);
+    }
+    prod.th.join();
+    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
+    c.reads += prod.reads;
+    c.kmers += prod.kmers;
+    c.bps += prod.bps;
+    c.t_parse += prod.seconds;
+    return err;
+}
+
+struct TextChunk {
+    int64_t file_off;  // of the chunk's first byte
+    int64_t reads_before;  // reads of this file in earlier chunks
+};
+
+// plain FASTQ without per-read outputs: blocks of raw text to the device.  Falls back to parsed_source() from the
+// first chunk the device refuses (gs_match_text_status), so any file the general path accepts gives the same result.
+int text_file(MatchCtx &c, const std::string &path) {
+    // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
+    // 24.8 GB/s of file, 4 x 32 MiB 10.6 GB/s, 8 x 128 MiB 9.1 GB/s -- blocks that stay in the CPU caches between
+    // pread and the newline count win
+    size_t block = (size_t)8 << 20;
+    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
+    }
+    int readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("GS_HOST_READERS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) readers = v;
+    }
+    TextReader tr;
+    int err = tr.open(path, block, readers);
+    if (err) {
+        tr.close();
+        return err;
+    }
+    int64_t base_tot[3] = {0, 0, 0}, tot[3] = {0, 0, 0}, failed = -1, bad = -1;
+    err = gs_match_text_status(c.run, &failed, &bad, base_tot);  // totals of earlier files of this run
+    std::vector<uint8_t> carry;
+    int64_t carry_lines = 0, reads_in_file = 0, carry_file_off = 0;
+    std::vector<TextChunk> chunks;
+    int64_t first_ticket = -1;
+    bool fell_back = false, too_long = false;
+    const double t0 = now_s();
+    if (!err) tr.start();
+    for (int64_t i = 0; !err; i++) {
+        TextSlot &sl = tr.wait_full(i);
+        if (sl.io_error) {
+            err = hfail(GS_E_INVALID, "read error on " + path);
+            break;
+        }
+        uint8_t *blk = sl.buf + tr.headroom;
+        const int64_t total = carry_lines + sl.newlines;
+        const int64_t rem = total & 3, usable = total - rem;
+        const bool eof = sl.eof;
+        if (usable == 0) {  // not one whole record yet: keep everything
+            carry.insert(carry.end(), blk, blk + sl.n);
+            carry_lines = total;
+            if (carry.size() > tr.headroom && !eof) {
+                too_long = true;
+                tr.release(i);
+                break;
+            }
+        } else {
+            const int64_t cut = sl.last4[rem];  // the newline with `rem` newlines behind it ends the last whole record
+            if (carry.size() > tr.headroom) {  // a record longer than a block: the general parser takes over here
+                too_long = true;
+                tr.release(i);
+                break;
+            }
+            uint8_t *start = blk - carry.size();
+            if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+            int64_t ticket = -1;
+            err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST,
+                                       c.global_read_no + reads_in_file, nullptr, nullptr, &ticket);
+            if (err) break;
+            if (first_ticket < 0) first_ticket = ticket;
+            chunks.push_back({carry_file_off, reads_in_file});
+            reads_in_file += usable >> 2;
+            carry_file_off = i * (int64_t)tr.block + cut + 1;
+            carry.assign(blk + cut + 1, blk + sl.n);
+            carry_lines = rem;
+            err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
+            if (err) break;
+            // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
+            if (chunks.size() == 1 || (chunks.size() & 15) == 0 || eof) {
+                err = gs_match_text_status(c.run, &failed, &bad, tot);
+                if (err) break;
+                if (failed >= 0) {
+                    fell_back = true;
+                    tr.release(i);
+                    break;
+                }
+            }
+        }
+        tr.release(i);
+        if (eof) break;
+    }
+    tr.close();
+    c.t_parse += now_s() - t0;
+    if (err) return err;
+    if (!fell_back) {
+        err = gs_match_text_status(c.run, &failed, &bad, tot);
+        if (err) return err;
+        fell_back = failed >= 0;
+    }
+    c.reads += tot[0] - base_tot[0];
+    c.kmers += tot[1] - base_tot[1];
+    c.bps += tot[2] - base_tot[2];
+    if (fell_back) {
+        const TextChunk &ch = chunks[(size_t)(failed - first_ticket)];
+        c.global_read_no += ch.reads_before;
+        err = gs_match_text_clear_error(c.run);
+        if (err) return err;
+        return parsed_source(c, path, ch.file_off, nullptr, 0);
+    }
+    if (too_long) {
+        c.global_read_no += reads_in_file;
+        return parsed_source(c, path, carry_file_off, nullptr, 0);
+    }
+    c.global_read_no += reads_in_file;
+    // what is left after the last whole four-line group (no final newline, truncated record): the general parser
+    if (!carry.empty()) return parsed_source(c, std::string(), 0, carry.data(), carry.size());
+    return GS_OK;
+}
 
 }  // namespace
 
@@ -426,105 +789,37 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
                                    const gs_host_match_opts *opts, int64_t *table, double *dtable,
                                    gs_host_totals *totals) {
     if (!db || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
-    gs_db_info info;
-    int rc = gs_db_get_info(db, &info);
+    MatchCtx c;
+    int rc = gs_db_get_info(db, &c.info);
     if (rc) return rc;
     const gs_host_match_opts none{};
     if (!opts) opts = &none;
+    c.opts = opts;
     if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
-    OutFile filtered, kraken;
-    if (!filtered.open(opts->filtered_path) || !kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
-    gs_run *run = nullptr;
-    rc = gs_match_begin(&run, db, cfg);
+    if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    rc = gs_match_begin(&c.run, db, cfg);
     if (rc) return rc;
     const double t_start = now_s();
-    std::vector<std::string> plist(paths, paths + n_paths);
-    Producer prod;
-    prod.start(plist, info.k, opts->batch_reads > 0 ? opts->batch_reads : (int64_t)1 << 20);
-    std::vector<int32_t> cls, seg_code, seg_start;
-    std::vector<uint8_t> flags, tmp;
-    std::vector<uint64_t> seg_off;
-    std::string line;
-    int64_t global_read_no = 0, filtered_reads = 0;
-    double t_gpu = 0;
+    bool fast = !c.filtered.active() && !c.kraken.active();  // the text path has no per-read writers yet
+    if (const char *e = getenv("GS_HOST_FAST")) fast = fast && atoi(e) != 0;
     int err = GS_OK;
-    for (;;) {
-        std::unique_ptr<Batch> b = prod.q.pop();
-        if (!b) break;
-        if (err) continue;  // keep draining so the producer can finish
-        const int64_t n = b->n();
-        cls.resize((size_t)n);
-        flags.resize((size_t)n);
-        if (b->seq.empty()) b->seq.push_back(0);
-        const double t0 = now_s();
-        // read numbers run over all files of this call so that "first read with the max contig" follows file order
-        err = gs_match_submit(run, b->seq.data(), b->seq_off.data(), n, global_read_no, GS_MEM_HOST, cls.data(), flags.data());
-        if (!err && kraken.active()) {
-            seg_off.resize((size_t)n + 1);
-            err = gs_match_segments(run, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST, seg_off.data());
-            if (!err) {
-                seg_code.resize((size_t)seg_off[(size_t)n]);
-                seg_start.resize((size_t)seg_off[(size_t)n]);
-                err = gs_match_segments_fetch(run, seg_code.data(), seg_start.data());
-            }
-        }
-        t_gpu += now_s() - t0;
-        if (err) continue;
-        global_read_no += n;
-        for (int64_t i = 0; i < n; i++) {
-            if (filtered.active() && (flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
-                write_read(filtered, *b, i, false, tmp);
-                filtered_reads++;
-            }
-            if (kraken.active()) {  // MatcherReadEntry.writeMatchDetails (:723-756)
-                const uint64_t s0 = seg_off[(size_t)i], s1 = seg_off[(size_t)i + 1];
-                const int32_t c = cls[(size_t)i];
-                if (s1 == s0 || !(opts->write_all || c >= 0)) continue;
-                const int64_t L = (int64_t)(b->seq_off[(size_t)i + 1] - b->seq_off[(size_t)i]);
-                const int64_t maxp = L - info.k + 1;
-                line.assign(c >= 0 ? "C\t" : "U\t");
-                const size_t d0 = b->desc_off[(size_t)i], d1 = b->desc_off[(size_t)i + 1];
-                size_t de = d1;
-                for (size_t j = d0 + 1; j < d1; j++)
-                    if (b->desc[j] == ' ') {
-                        de = j;
-                        break;
-                    }
-                if (d1 > d0 + 1) line.append((const char *)b->desc.data() + d0 + 1, de - d0 - 1);
-                line.push_back('\t');
-                line.append(c >= 0 ? opts->taxids[c] : "0");
-                line.push_back('\t');
-                append_int(line, L);
-                line.push_back('\t');
-                for (uint64_t s = s0; s < s1; s++) {
-                    if (s > s0) line.push_back(' ');
-                    const int32_t code = seg_code[(size_t)s];
-                    if (code == -2)
-                        line.push_back('A');
-                    else if (code < 0)
-                        line.push_back('0');
-                    else
-                        line.append(opts->taxids[code]);
-                    line.push_back(':');
-                    append_int(line, (s + 1 < s1 ? seg_start[(size_t)s + 1] : maxp) - seg_start[(size_t)s]);
-                }
-                line.push_back('\n');
-                kraken.write(line.data(), line.size());
-            }
-        }
+    for (int i = 0; i < n_paths && !err; i++) {
+        const std::string path(paths[i]);
+        if (fast && plain_fastq_file(path))
+            err = text_file(c, path);
+        else
+            err = parsed_source(c, path, 0, nullptr, 0);
     }
-    prod.th.join();
-    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
-    if (!err) err = gs_match_finish(run, table, dtable);
-    gs_match_destroy(run);
+    if (!err) err = gs_match_finish(c.run, table, dtable);
+    gs_match_destroy(c.run);
     if (totals) {
-        totals->reads = prod.reads;
-        totals->kmers = prod.kmers;
-        totals->bps = prod.bps;
-        totals->filtered_reads = filtered_reads;
+        totals->reads = c.reads;
+        totals->kmers = c.kmers;
+        totals->bps = c.bps;
+        totals->filtered_reads = c.filtered_reads;
         totals->seconds_total = now_s() - t_start;
-        totals->seconds_parse = prod.seconds;
-        totals->seconds_gpu = t_gpu;
+        totals->seconds_parse = c.t_parse;
+        totals->seconds_gpu = c.t_gpu;
     }
     return err;
 }
@@ -536,42 +831,47 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     OutFile acc_out, rest_out;
     if (!acc_out.open(filtered_path) || !rest_out.open(rest_path)) return hfail(GS_E_INVALID, "cannot open output file");
     const double t_start = now_s();
-    std::vector<std::string> plist(paths, paths + n_paths);
-    Producer prod;
-    prod.start(plist, k, (int64_t)1 << 20);
     std::vector<uint8_t> accept, tmp;
-    int64_t accepted = 0;
-    double t_gpu = 0;
+    int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
+    double t_gpu = 0, t_parse = 0;
     int err = GS_OK;
-    for (;;) {
-        std::unique_ptr<Batch> b = prod.q.pop();
-        if (!b) break;
-        if (err) continue;
-        const int64_t n = b->n();
-        accept.resize((size_t)n);
-        if (b->seq.empty()) b->seq.push_back(0);
-        const double t0 = now_s();
-        err = gs_filter_submit(bloom, k, min_pos_count, positive_ratio, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST,
-                               accept.data(), 0);
-        t_gpu += now_s() - t0;
-        if (err) continue;
-        for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-            if (accept[(size_t)i]) {
-                accepted++;
-                if (acc_out.active()) write_read(acc_out, *b, i, false, tmp);
-            } else if (rest_out.active())
-                write_read(rest_out, *b, i, false, tmp);
+    for (int f = 0; f < n_paths && !err; f++) {
+        Producer prod;
+        prod.start(std::string(paths[f]), 0, nullptr, 0, k, (int64_t)1 << 20);
+        for (;;) {
+            std::unique_ptr<Batch> b = prod.q.pop();
+            if (!b) break;
+            if (err) continue;
+            const int64_t n = b->n();
+            accept.resize((size_t)n);
+            if (b->seq.empty()) b->seq.push_back(0);
+            const double t0 = now_s();
+            err = gs_filter_submit(bloom, k, min_pos_count, positive_ratio, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST,
+                                   accept.data(), 0);
+            t_gpu += now_s() - t0;
+            if (err) continue;
+            for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                if (accept[(size_t)i]) {
+                    accepted++;
+                    if (acc_out.active()) write_read(acc_out, *b, i, false, tmp);
+                } else if (rest_out.active())
+                    write_read(rest_out, *b, i, false, tmp);
+            }
         }
+        prod.th.join();
+        if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
+        reads += prod.reads;
+        kmers += prod.kmers;
+        bps += prod.bps;
+        t_parse += prod.seconds;
     }
-    prod.th.join();
-    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
     if (totals) {
-        totals->reads = prod.reads;
-        totals->kmers = prod.kmers;
-        totals->bps = prod.bps;
+        totals->reads = reads;
+        totals->kmers = kmers;
+        totals->bps = bps;
         totals->filtered_reads = accepted;
         totals->seconds_total = now_s() - t_start;
-        totals->seconds_parse = prod.seconds;
+        totals->seconds_parse = t_parse;
         totals->seconds_gpu = t_gpu;
     }
     return err;

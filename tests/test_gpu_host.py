@@ -114,3 +114,88 @@ def test_filter_files(sdb, tmp_path):
     assert acc_ids == [f"@r{i} sample={i % 7}" for i in np.flatnonzero(want)]
     assert rest_ids == [f"@r{i} sample={i % 7}" for i in np.flatnonzero(want == 0)]
     gb.close()
+
+
+# ------------------------------------------------------------------ text fast path (device-side record scan)
+def _oracle_file(sdb, data):
+    p = orc.parse_fastq(data, k=31)
+    seq = p["seq"] if len(p["seq"]) else np.zeros(1, dtype=np.uint8)
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    run = orc.MatchRun(odb)
+    run.submit(seq, p["seq_off"])
+    t, _ = run.finish()
+    return t, (int(p["n_reads"]), int(p["total_kmers"]), int(p["total_bps"]))
+
+
+def _fastq_bytes(sdb, n, seed, nl=b"\n"):
+    seq, off = synth.reads_host(sdb.genomes, n, read_len=150, seed=seed)
+    recs = []
+    for i in range(n):
+        s = seq[int(off[i]):int(off[i + 1])].tobytes()
+        if i % 11 == 3:
+            s = s[:i % 40]                    # short / empty reads
+        if i % 13 == 5:
+            s = s[:60] + b"N" + s[61:]
+        if i % 17 == 7:
+            s = s * 3                         # long reads
+        recs.append(b"@r%d x\n".replace(b"\n", nl) % i + s + nl + b"+" + nl + b"F" * len(s) + nl)
+    return recs
+
+
+@pytest.mark.parametrize("block", [0, 64, 1000, 4096])
+@pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "truncated", "nul", "tiny"])
+def test_match_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypatch, block, shape):
+    """every file shape must give the general parser's result; the device path may only be faster (block = 0: default
+    32 MiB blocks, else tiny blocks so that records straddle block boundaries and carries pile up)"""
+    recs = _fastq_bytes(sdb, 600, seed=23, nl=b"\r\n" if shape == "crlf" else b"\n")
+    if shape == "multi-line record":
+        s = recs[400].split(b"\n")
+        recs[400] = s[0] + b"\n" + s[1][:50] + b"\n" + s[1][50:] + b"\n+\n" + s[3] + b"\n"
+    data = b"".join(recs)
+    if shape == "no final newline":
+        data = data[:-1]
+    elif shape == "truncated":
+        data = data[:-200]
+    elif shape == "nul":
+        data = data[:30000] + b"\0" + data[30000:]
+    elif shape == "tiny":
+        data = b"".join(recs[:1])
+    path = str(tmp_path / "in.fastq")
+    open(path, "wb").write(data)
+    want_t, want_tot = _oracle_file(sdb, data)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    if block:
+        monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+    table, _, tot = host.match_files(store, [path])
+    assert (tot.reads, tot.kmers, tot.bps) == want_tot
+    assert np.array_equal(table, want_t), np.argwhere(table != want_t)[:8]
+    monkeypatch.setenv("GS_HOST_FAST", "0")
+    table2, _, tot2 = host.match_files(store, [path])
+    assert np.array_equal(table2, want_t) and (tot2.reads, tot2.kmers, tot2.bps) == want_tot
+    store.close()
+
+
+def test_match_files_text_path_several_files_and_max_contig_order(sdb, tmp_path):
+    """read numbers run over all files of a call, also when text chunks and parsed batches alternate"""
+    recs = _fastq_bytes(sdb, 900, seed=29)
+    parts = [b"".join(recs[:300]), b"".join(recs[300:600]), b"".join(recs[600:])]
+    paths = [str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq.gz"), str(tmp_path / "c.fq")]
+    open(paths[0], "wb").write(parts[0])
+    with gzip.open(paths[1], "wb") as f:
+        f.write(parts[1])
+    open(paths[2], "wb").write(parts[2])
+    want_t, want_tot = _oracle_file(sdb, b"".join(parts))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    table, _, tot = host.match_files(store, paths)
+    assert np.array_equal(table, want_t)
+    assert (tot.reads, tot.kmers, tot.bps) == want_tot
+    store.close()
+
+
+def test_match_files_empty_file(sdb, tmp_path):
+    path = str(tmp_path / "empty.fastq")
+    open(path, "wb").close()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    table, _, tot = host.match_files(store, [path])
+    assert tot.reads == 0 and not table[:, :9].any()
+    store.close()
