@@ -52,6 +52,32 @@ JNIEXPORT void JNICALL JNAME(matchSubmit)(JNIEnv *env, jclass c, jlong run, jobj
     if (rc) throw_gs(env, rc);
 }
 
+JNIEXPORT jlong JNICALL JNAME(matchSubmitText)(JNIEnv *env, jclass c, jlong run, jobject text, jlong nBytes, jlong nLines,
+                                               jlong firstReadNo) {
+    int64_t ticket = -1;
+    int rc = gs_match_submit_text((gs_run *)(intptr_t)run, (const uint8_t *)addr(env, text), nBytes, nLines, GS_MEM_HOST,
+                                  firstReadNo, NULL, NULL, &ticket);
+    if (rc) throw_gs(env, rc);
+    return (jlong)ticket;
+}
+
+JNIEXPORT void JNICALL JNAME(matchTextWaitCopy)(JNIEnv *env, jclass c, jlong run, jlong ticket) {
+    int rc = gs_match_text_wait_copy((gs_run *)(intptr_t)run, ticket);
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchTextStatus)(JNIEnv *env, jclass c, jlong run, jlongArray out) {
+    int64_t v[5] = {-1, -1, 0, 0, 0};
+    int rc = gs_match_text_status((gs_run *)(intptr_t)run, &v[0], &v[1], &v[2]);
+    if (rc) throw_gs(env, rc);
+    (*env)->SetLongArrayRegion(env, out, 0, 5, (const jlong *)v);
+}
+
+JNIEXPORT void JNICALL JNAME(matchTextClearError)(JNIEnv *env, jclass c, jlong run) {
+    int rc = gs_match_text_clear_error((gs_run *)(intptr_t)run);
+    if (rc) throw_gs(env, rc);
+}
+
 JNIEXPORT void JNICALL JNAME(matchFinish)(JNIEnv *env, jclass c, jlong run, jobject table, jobject dtable) {
     int rc = gs_match_finish((gs_run *)(intptr_t)run, (int64_t *)addr(env, table), (double *)addr(env, dtable));
     if (rc) throw_gs(env, rc);

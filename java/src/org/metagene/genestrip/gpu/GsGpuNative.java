@@ -37,6 +37,18 @@ public final class GsGpuNative {
 	public static native void matchSubmit(long run, ByteBuffer seq, ByteBuffer offsets, long nReads, long firstReadNo,
 			ByteBuffer classVi, ByteBuffer flags);
 
+	/** gs_match_submit_text with GS_MEM_HOST: text = a direct buffer holding whole four-line FASTQ records, nLines =
+	 *  number of '\n' in it (a multiple of 4).  Returns the ticket; the buffer may be refilled after matchTextWaitCopy. */
+	public static native long matchSubmitText(long run, ByteBuffer text, long nBytes, long nLines, long firstReadNo);
+
+	public static native void matchTextWaitCopy(long run, long ticket);
+
+	/** gs_match_text_status: out[0] = ticket of the first refused chunk or -1, out[1] = first bad record or -1,
+	 *  out[2..4] = reads, k-mers, bases of the accepted chunks. */
+	public static native void matchTextStatus(long run, long[] out);
+
+	public static native void matchTextClearError(long run);
+
 	/** gs_match_finish: table = n_values x GS_N_COLS int64, dtable = n_values x GS_N_DCOLS double. */
 	public static native void matchFinish(long run, ByteBuffer table, ByteBuffer dtable);
 
