@@ -1260,6 +1260,7 @@ extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bit
     if (kind != GS_BLOOM_BLOCKED) {
         if (n_hashes < 1 || n_hashes > 64) return fail(GS_E_INVALID, "n_hashes must be in [1,64]");
         if (n_words < (bits + 63) / 64) return fail(GS_E_INVALID, "words shorter than bits");
+        if (bits > ((int64_t)1 << 37)) return fail(GS_E_UNSUPPORTED, "filters above 2^37 bits (16 GiB) are not supported");
     } else {
         n_hashes = 1;
         if (n_words < bits + 17) return fail(GS_E_INVALID, "blocked filter needs buckets+17 words");
@@ -1399,6 +1400,10 @@ extern "C" int gs_filter_submit(gs_bloom *b, int k, int min_pos_count, double po
     P.accept = d_acc;
     int occ = gs_filter_occupancy();
     if (occ < 1) occ = 1;
+    if (const char *ev = getenv("GS_FILTER_BLOCKS_PER_CU")) {
+        const int v = atoi(ev);
+        if (v >= 1 && v <= 16) occ = v;
+    }
     int grid = (int)std::min<int64_t>((int64_t)b->n_cu * occ, (n_reads + 3) / 4);
     if (grid < 1) grid = 1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
