@@ -658,6 +658,15 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         }                                                                                             \
         __syncthreads();                                                                              \
     }                                                                                                 \
+    const bool tree_lds = !LDS_STATS && nv <= GS_NV_TREE_LDS; /* counters too big for LDS, the tree is not */ \
+    if (tree_lds) {                                                                                   \
+        for (int i = threadIdx.x; i < nv; i += blockDim.x) {                                          \
+            s_tree[i] = P.db.parent[i];                                                               \
+            s_tree[nv + i] = P.db.tin[i];                                                             \
+            s_tree[2 * nv + i] = P.db.tout[i];                                                        \
+        }                                                                                             \
+        __syncthreads();                                                                              \
+    }                                                                                                 \
     GsStats st;                                                                                       \
     if (LDS_STATS) {                                                                                  \
         st.sums = s_sums;                                                                             \
@@ -670,9 +679,9 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         st.sums = (u64 *)P.sums;                                                                      \
         st.maxk = (u64 *)P.max_keys;                                                                  \
         st.dsums = P.dsums;                                                                           \
-        st.parent = P.db.parent;                                                                      \
-        st.tin = P.db.tin;                                                                            \
-        st.tout = P.db.tout;                                                                          \
+        st.parent = tree_lds ? s_tree : P.db.parent;                                                  \
+        st.tin = tree_lds ? s_tree + nv : P.db.tin;                                                   \
+        st.tout = tree_lds ? s_tree + 2 * nv : P.db.tout;                                             \
     }
 
 #define GS_STATS_EPILOGUE()                                                                           \
@@ -1229,7 +1238,8 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
 // launchers (called from gs_api.cpp)
 // ---------------------------------------------------------------------------------------------------
 static size_t gs_stats_lds_bytes(int n_values) {
-    return n_values <= GS_NV_LDS ? (size_t)n_values * ((GS_N_SUMS + 1 + GS_N_DCOLS) * 8 + 3 * 4) : 0;
+    if (n_values <= GS_NV_LDS) return (size_t)n_values * ((GS_N_SUMS + 1 + GS_N_DCOLS) * 8 + 3 * 4);
+    return n_values <= GS_NV_TREE_LDS ? (size_t)n_values * 3 * 4 : 0;  // the tree alone
 }
 
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
@@ -1241,18 +1251,18 @@ extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStrea
             if (lds_stats)
                 hipLaunchKernelGGL((gs_match_kernel<true, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
             else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 31>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         } else {
             if (lds_stats)
                 hipLaunchKernelGGL((gs_match_kernel<true, false, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
             else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 0>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         }
     } else {
         if (lds_stats)
             hipLaunchKernelGGL((gs_match_kernel<true, true, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         else
-            hipLaunchKernelGGL((gs_match_kernel<false, true, 0>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+            hipLaunchKernelGGL((gs_match_kernel<false, true, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
     }
     return hipGetLastError();
 }
@@ -1265,12 +1275,12 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
         if (lds_stats)
             hipLaunchKernelGGL((gs_match_long_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
         else
-            hipLaunchKernelGGL((gs_match_long_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+            hipLaunchKernelGGL((gs_match_long_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
     } else {
         if (lds_stats)
             hipLaunchKernelGGL((gs_match_long_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
         else
-            hipLaunchKernelGGL((gs_match_long_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P, scratch, serial);
+            hipLaunchKernelGGL((gs_match_long_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
     }
     return hipGetLastError();
 }
@@ -1279,7 +1289,7 @@ extern "C" int gs_match_occupancy(int n_values) {
     int n = 0;
     hipError_t e = n_values <= GS_NV_LDS
                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true, false, 31>, GS_BLOCK, gs_stats_lds_bytes(n_values))
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false, 31>, GS_BLOCK, 0);
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false, 31>, GS_BLOCK, gs_stats_lds_bytes(n_values));
     return e == hipSuccess ? n : 0;
 }
 

@@ -6,7 +6,8 @@
 #include "gs_layout.h"
 
 #define GS_BLOCK 256   // 4 waves per workgroup
-#define GS_NV_LDS 256  // per-taxid counters are privatised in LDS up to this many value indices
+#define GS_NV_LDS 256         // per-taxid counters are privatised in LDS up to this many value indices
+#define GS_NV_TREE_LDS 2048   // up to here the taxonomy arrays (12 B per value) still travel in LDS
 
 struct GsMatchParams {
     GsDbDev db;
