@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_pinned_alloc", "gs_pinned_free",
+    "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
     "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -115,6 +116,9 @@ def lib():
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
         "gs_match_text_clear_error": (ci, [vp]),
         "gs_pinned_alloc": (ci, [vp, C.c_size_t]), "gs_pinned_free": (ci, [vp]),
+        "gs_filter_submit_text": (ci, [vp, ci, ci, dbl, vp, i64, i64, ci, vp, vp, ci, vp]),
+        "gs_filter_text_wait_copy": (ci, [vp, i64]), "gs_filter_text_status": (ci, [vp, vp, vp, vp]),
+        "gs_filter_text_reset": (ci, [vp, ci]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
@@ -432,6 +436,32 @@ class FastqBloomFilter:
         _ready(seq, offsets, accept)
         _check(lib().gs_filter_submit(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, ps, po, n_reads,
                                       mem, pa, int(self.profile)))
+
+    def submit_text(self, text, accept, n_lines=None, newlines=None):
+        """raw FASTQ text of whole 4-line records (gs_filter_submit_text); returns the ticket"""
+        if isinstance(text, (bytes, bytearray)):
+            text = np.frombuffer(bytes(text), dtype=np.uint8)
+        if n_lines is None:
+            n_lines = int((text == 10).sum())
+        n_bytes = int(text.shape[0])
+        pt, mem = _ptr(text) if n_bytes else (None, MEM_HOST)
+        pa, _ = _ptr(accept)
+        pn, _ = _ptr(newlines)
+        _ready(text, accept, newlines)
+        ticket = C.c_int64(-1)
+        self._text_keep = text
+        _check(lib().gs_filter_submit_text(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, pt, n_bytes,
+                                           int(n_lines), mem, pa, pn, int(self.profile), C.byref(ticket)))
+        return ticket.value
+
+    def text_status(self):
+        ft, fb = C.c_int64(-1), C.c_int64(-1)
+        tot = (C.c_int64 * 3)()
+        _check(lib().gs_filter_text_status(self.bloom.h, C.byref(ft), C.byref(fb), tot))
+        return ft.value, fb.value, tuple(tot)
+
+    def text_reset(self, clear_totals=False):
+        _check(lib().gs_filter_text_reset(self.bloom.h, int(clear_totals)))
 
     def accept_reads(self, seq, offsets):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)

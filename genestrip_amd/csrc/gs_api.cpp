@@ -460,6 +460,20 @@ extern "C" int gs_db_destroy(gs_db *db) {
 // ---------------------------------------------------------------------------------------------------
 // match runs
 // ---------------------------------------------------------------------------------------------------
+// device state of the text mode (raw FASTQ chunk -> records, gs_text.hip); one per run / per filter handle
+struct TextScan {
+    uint8_t *d_text = nullptr;
+    size_t text_cap = 0;
+    uint32_t *d_tile = nullptr, *d_nl = nullptr;
+    size_t tile_cap = 0, nl_cap = 0;
+    u64 *d_off2 = nullptr;
+    size_t off2_cap = 0;
+    uint32_t *d_status = nullptr;  // GS_TS_WORDS
+    u64 *d_totals = nullptr;       // [3] chunk scratch | [3] totals of the accepted chunks
+    hipEvent_t copied[8] = {};     // H2D of ticket t has completed: copied[t % 8]
+    int64_t tickets = 0;
+};
+
 struct gs_run {
     gs_db *db = nullptr;
     gs_match_cfg cfg{};
@@ -491,22 +505,119 @@ struct gs_run {
     u64 *d_seg_off = nullptr;
     int32_t *d_seg_code = nullptr, *d_seg_start = nullptr;
     int64_t seg_total = 0;
-    // text mode (gs_match_submit_text): raw FASTQ chunk, newline offsets, (start, end) pairs, scan state
-    uint8_t *d_text = nullptr;
-    size_t text_cap = 0;
-    uint32_t *d_tile = nullptr, *d_nl = nullptr;
-    size_t tile_cap = 0, nl_cap = 0;
-    u64 *d_off2 = nullptr;
-    size_t off2_cap = 0;
-    uint32_t *d_tstatus = nullptr;  // GS_TS_WORDS
-    u64 *d_ttotals = nullptr;       // [3] chunk scratch | [3] run totals
-    hipEvent_t copied[8] = {};      // H2D of ticket t has completed: copied[t % 8]
-    int64_t tickets = 0;
+    TextScan text;  // text mode (gs_match_submit_text)
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
     double total_ms = 0;
 };
+
+
+static void text_free(TextScan &t) {
+    hipFree(t.d_text);
+    hipFree(t.d_tile);
+    hipFree(t.d_nl);
+    hipFree(t.d_off2);
+    hipFree(t.d_status);
+    hipFree(t.d_totals);
+    for (hipEvent_t ev : t.copied)
+        if (ev) hipEventDestroy(ev);
+    t = TextScan();
+}
+
+template <typename T>
+static int grow(T **p, size_t *cap, size_t need, hipStream_t stream) {
+    if (*cap >= need) return GS_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 4;
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return GS_OK;
+}
+
+static int text_reset(TextScan &t, bool totals, hipStream_t stream) {
+    if (!t.d_status) return GS_OK;
+    HIP_TRY(hipMemsetAsync(t.d_status, 0, sizeof(uint32_t) * GS_TS_WORDS, stream));
+    HIP_TRY(hipMemsetAsync(t.d_status + GS_TS_FIRST_BAD, 0xff, sizeof(uint32_t), stream));
+    if (totals) HIP_TRY(hipMemsetAsync(t.d_totals, 0, sizeof(u64) * 6, stream));
+    return GS_OK;
+}
+
+extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket, hipStream_t stream);
+
+// copies the chunk to the device and runs the record scan; *ticket identifies the chunk.  After it the (start, end)
+// pairs of the sequence lines are in t.d_off2, the newline offsets in t.d_nl and the skip flag in t.d_status.
+static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int k,
+                       int64_t *ticket) {
+    if (n_bytes < 0 || n_lines < 0 || (n_lines & 3) != 0 || (n_bytes > 0 && !text) || n_lines > n_bytes)
+        return fail(GS_E_INVALID, "bad text chunk (n_lines must be a multiple of 4)");
+    if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    if (!t.d_status) {
+        HIP_TRY(hipMalloc((void **)&t.d_status, sizeof(uint32_t) * GS_TS_WORDS));
+        HIP_TRY(hipMalloc((void **)&t.d_totals, sizeof(u64) * 6));
+        int rc = text_reset(t, true, stream);
+        if (rc) return rc;
+        for (hipEvent_t &ev : t.copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int64_t n_reads = n_lines >> 2;
+    const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
+    int rc;
+    if ((rc = grow(&t.d_text, &t.text_cap, padded + 4096, stream))) return rc;
+    if ((rc = grow(&t.d_tile, &t.tile_cap, padded / 4096 + 1, stream))) return rc;
+    if ((rc = grow(&t.d_nl, &t.nl_cap, (size_t)n_lines + 4, stream))) return rc;
+    if ((rc = grow(&t.d_off2, &t.off2_cap, 2 * (size_t)n_reads + 2, stream))) return rc;
+    const int64_t tk = t.tickets;
+    if (n_bytes > 0)
+        HIP_TRY(hipMemcpyAsync(t.d_text, text, (size_t)n_bytes, mem == GS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipEventRecord(t.copied[tk & 7], stream));
+    if (padded > (size_t)n_bytes) HIP_TRY(hipMemsetAsync(t.d_text + n_bytes, ' ', padded - (size_t)n_bytes, stream));
+    GsTextParams T{};
+    T.text = t.d_text;
+    T.n_bytes = n_bytes;
+    T.n_lines = n_lines;
+    T.tile_count = t.d_tile;
+    T.nl = t.d_nl;
+    T.off2 = (unsigned long long *)t.d_off2;
+    T.chunk_totals = (unsigned long long *)t.d_totals;
+    T.run_totals = (unsigned long long *)t.d_totals + 3;
+    T.status = t.d_status;
+    T.k = k;
+    HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
+    t.tickets = tk + 1;
+    if (ticket) *ticket = tk;
+    return GS_OK;
+}
+
+static int text_wait_copy(TextScan &t, int64_t ticket) {
+    if (ticket < 0 || ticket >= t.tickets) return fail(GS_E_INVALID, "unknown ticket");
+    if (ticket + 8 <= t.tickets) return GS_OK;  // its event has been re-recorded by a later submit: long done
+    HIP_TRY(hipEventSynchronize(t.copied[ticket & 7]));
+    return GS_OK;
+}
+
+// synchronises the stream
+static int text_status(TextScan &t, hipStream_t stream, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]) {
+    if (failed_ticket) *failed_ticket = -1;
+    if (first_bad_record) *first_bad_record = -1;
+    if (totals) totals[0] = totals[1] = totals[2] = 0;
+    if (!t.d_status) return GS_OK;
+    uint32_t st[GS_TS_WORDS];
+    u64 tt[6];
+    HIP_TRY(hipMemcpyAsync(st, t.d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(tt, t.d_totals, sizeof(tt), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (st[GS_TS_STICKY]) {
+        if (failed_ticket) *failed_ticket = (int64_t)st[GS_TS_FAILED_TICKET];
+        if (first_bad_record && st[GS_TS_FIRST_BAD] != 0xffffffffu) *first_bad_record = (int64_t)st[GS_TS_FIRST_BAD];
+    }
+    if (totals)
+        for (int i = 0; i < 3; i++) totals[i] = (int64_t)tt[3 + i];
+    return GS_OK;
+}
 
 static int run_clear(gs_run *run) {
     const size_t nv = (size_t)run->db->info.n_values;
@@ -549,14 +660,7 @@ static void run_free(gs_run *run) {
     hipFree(run->d_seg_off);
     hipFree(run->d_seg_code);
     hipFree(run->d_seg_start);
-    hipFree(run->d_text);
-    hipFree(run->d_tile);
-    hipFree(run->d_nl);
-    hipFree(run->d_off2);
-    hipFree(run->d_tstatus);
-    hipFree(run->d_ttotals);
-    for (hipEvent_t ev : run->copied)
-        if (ev) hipEventDestroy(ev);
+    text_free(run->text);
     if (run->stream) hipStreamDestroy(run->stream);
     delete run;
 }
@@ -749,8 +853,6 @@ extern "C" int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *
 }
 
 // ---- text mode: raw 4-line FASTQ chunks, records found on the device (gs_text.hip) ------------------------------
-extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket, hipStream_t stream);
-
 extern "C" int gs_pinned_alloc(void **p, size_t bytes) {
     if (!p) return fail(GS_E_INVALID, "NULL argument");
     *p = nullptr;
@@ -764,54 +866,16 @@ extern "C" int gs_pinned_free(void *p) {
     return GS_OK;
 }
 
-template <typename T>
-static int grow(T **p, size_t *cap, size_t need, hipStream_t stream) {
-    if (*cap >= need) return GS_OK;
-    HIP_TRY(hipStreamSynchronize(stream));
-    hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t n = need + need / 4;
-    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
-    *cap = n;
-    return GS_OK;
-}
-
-static int text_reset(gs_run *run, bool totals) {
-    if (!run->d_tstatus) return GS_OK;
-    HIP_TRY(hipMemsetAsync(run->d_tstatus, 0, sizeof(uint32_t) * GS_TS_WORDS, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_tstatus + GS_TS_FIRST_BAD, 0xff, sizeof(uint32_t), run->stream));
-    if (totals) HIP_TRY(hipMemsetAsync(run->d_ttotals, 0, sizeof(u64) * 6, run->stream));
-    return GS_OK;
-}
-
-static int text_init(gs_run *run) {
-    if (run->d_tstatus) return GS_OK;
-    HIP_TRY(hipMalloc((void **)&run->d_tstatus, sizeof(uint32_t) * GS_TS_WORDS));
-    HIP_TRY(hipMalloc((void **)&run->d_ttotals, sizeof(u64) * 6));
-    int rc = text_reset(run, true);
-    if (rc) return rc;
-    for (hipEvent_t &ev : run->copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    return GS_OK;
-}
-
 extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
                                     int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
-    if (n_bytes < 0 || n_lines < 0 || (n_lines & 3) != 0 || (n_bytes > 0 && !text) || n_lines > n_bytes)
-        return fail(GS_E_INVALID, "bad text chunk (n_lines must be a multiple of 4)");
-    if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
-    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
     HIP_TRY(hipSetDevice(run->db->device));
-    int rc = text_init(run);
-    if (rc) return rc;
     const int64_t n_reads = n_lines >> 2;
-    const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
-    if ((rc = grow(&run->d_text, &run->text_cap, padded + 4096, run->stream))) return rc;
-    if ((rc = grow(&run->d_tile, &run->tile_cap, padded / 4096 + 1, run->stream))) return rc;
-    if ((rc = grow(&run->d_nl, &run->nl_cap, (size_t)n_lines + 4, run->stream))) return rc;
-    if ((rc = grow(&run->d_off2, &run->off2_cap, 2 * (size_t)n_reads + 2, run->stream))) return rc;
-    if ((class_vi || flags) && run->reads_cap < (size_t)n_reads) {
+    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket);
+    if (rc) return rc;
+    if (n_reads == 0) return GS_OK;
+    const bool dev_out = mem == GS_MEM_DEVICE;
+    if ((class_vi || flags) && !dev_out && run->reads_cap < (size_t)n_reads) {
         HIP_TRY(hipStreamSynchronize(run->stream));
         hipFree(run->d_off);
         hipFree(run->d_class);
@@ -825,33 +889,10 @@ extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_
         HIP_TRY(hipMalloc((void **)&run->d_flags, (size_t)n_reads));
         run->reads_cap = (size_t)n_reads;
     }
-    const int64_t t = run->tickets;
-    hipEvent_t ev = run->copied[t & 7];
-    if (n_bytes > 0)
-        HIP_TRY(hipMemcpyAsync(run->d_text, text, (size_t)n_bytes, mem == GS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                               run->stream));
-    HIP_TRY(hipEventRecord(ev, run->stream));
-    if (padded > (size_t)n_bytes) HIP_TRY(hipMemsetAsync(run->d_text + n_bytes, ' ', padded - (size_t)n_bytes, run->stream));
-    GsTextParams T{};
-    T.text = run->d_text;
-    T.n_bytes = n_bytes;
-    T.n_lines = n_lines;
-    T.tile_count = run->d_tile;
-    T.nl = run->d_nl;
-    T.off2 = (unsigned long long *)run->d_off2;
-    T.chunk_totals = (unsigned long long *)run->d_ttotals;
-    T.run_totals = (unsigned long long *)run->d_ttotals + 3;
-    T.status = run->d_tstatus;
-    T.k = run->db->info.k;
-    HIP_TRY(gs_launch_text_scan(&T, (uint32_t)t, run->stream));
-    run->tickets = t + 1;
-    if (ticket) *ticket = t;
-    if (n_reads == 0) return GS_OK;
-    const bool dev_out = mem == GS_MEM_DEVICE;
     int32_t *dc = class_vi ? (dev_out ? class_vi : run->d_class) : nullptr;
     uint8_t *df = flags ? (dev_out ? flags : run->d_flags) : nullptr;
-    rc = launch_batch(run, run->d_text, (const uint64_t *)run->d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
-                      run->d_tstatus + GS_TS_SKIP);
+    rc = launch_batch(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
+                      run->text.d_status + GS_TS_SKIP);
     if (rc) return rc;
     if (!dev_out) {  // complete after gs_match_sync
         if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
@@ -862,41 +903,22 @@ extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_
 
 extern "C" int gs_match_text_wait_copy(gs_run *run, int64_t ticket) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
-    if (ticket < 0 || ticket >= run->tickets) return fail(GS_E_INVALID, "unknown ticket");
-    if (ticket + 8 <= run->tickets) return GS_OK;  // its event has been re-recorded by a later submit: long done
     HIP_TRY(hipSetDevice(run->db->device));
-    HIP_TRY(hipEventSynchronize(run->copied[ticket & 7]));
-    return GS_OK;
+    return text_wait_copy(run->text, ticket);
 }
 
 extern "C" int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
-    if (failed_ticket) *failed_ticket = -1;
-    if (first_bad_record) *first_bad_record = -1;
-    if (totals) totals[0] = totals[1] = totals[2] = 0;
-    if (!run->d_tstatus) return GS_OK;
-    uint32_t st[GS_TS_WORDS];
-    u64 tt[6];
-    HIP_TRY(hipMemcpyAsync(st, run->d_tstatus, sizeof(st), hipMemcpyDeviceToHost, run->stream));
-    HIP_TRY(hipMemcpyAsync(tt, run->d_ttotals, sizeof(tt), hipMemcpyDeviceToHost, run->stream));
-    HIP_TRY(hipStreamSynchronize(run->stream));
-    int rc = collect_events(run);
+    int rc = text_status(run->text, run->stream, failed_ticket, first_bad_record, totals);
     if (rc) return rc;
-    if (st[GS_TS_STICKY]) {
-        if (failed_ticket) *failed_ticket = (int64_t)st[GS_TS_FAILED_TICKET];
-        if (first_bad_record && st[GS_TS_FIRST_BAD] != 0xffffffffu) *first_bad_record = (int64_t)st[GS_TS_FIRST_BAD];
-    }
-    if (totals)
-        for (int i = 0; i < 3; i++) totals[i] = (int64_t)tt[3 + i];
-    return GS_OK;
+    return collect_events(run);
 }
 
 extern "C" int gs_match_text_clear_error(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
-    if (!run->d_tstatus) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
-    return text_reset(run, false);
+    return text_reset(run->text, false, run->stream);
 }
 
 extern "C" int gs_match_sync(gs_run *run) {
@@ -954,7 +976,7 @@ extern "C" int gs_match_reset(gs_run *run) {
     if (rc) return rc;
     rc = run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
     if (rc) return rc;
-    return text_reset(run, true);
+    return text_reset(run->text, true, run->stream);
 }
 
 extern "C" int gs_match_destroy(gs_run *run) {
@@ -1246,6 +1268,7 @@ struct gs_bloom {
     uint64_t *d_off = nullptr;
     uint8_t *d_accept = nullptr;
     size_t seq_cap = 0, reads_cap = 0;
+    TextScan text;  // text mode (gs_filter_submit_text)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int64_t launches = 0;
     double total_ms = 0;
@@ -1302,6 +1325,7 @@ extern "C" int gs_bloom_destroy(gs_bloom *b) {
     hipFree(b->d_seq);
     hipFree(b->d_off);
     hipFree(b->d_accept);
+    text_free(b->text);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
     return GS_OK;
@@ -1330,6 +1354,53 @@ static void magic_u64(u64 d, u64 &magic, int &shift) {
     unsigned __int128 num = ((unsigned __int128)((l == 64 ? 0 : ((u64)1 << l)) - d)) << 64;
     magic = (u64)(num / d) + 1;
     shift = l;
+}
+
+static int filter_launch(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *d_seq,
+                         const uint64_t *d_off, int64_t n_reads, uint8_t *d_acc, int off_stride, const uint32_t *d_skip,
+                         int profile) {
+    GsFilterParams P{};
+    P.kind = b->kind;
+    P.k = k;
+    P.min_pos_count = min_pos_count;
+    P.positive_ratio = positive_ratio;
+    P.bits = (u64)b->bits;
+    P.n_hashes = b->n_hashes;
+    P.words = b->d_words;
+    P.factors = b->d_factors;
+    {
+        u64 mg = 0;
+        int sh = 0;
+        magic_u64((u64)b->bits, mg, sh);
+        P.magic = mg;
+        P.magic_shift = sh;
+    }
+    P.seq = d_seq;
+    P.off = d_off;
+    P.n_reads = n_reads;
+    P.accept = d_acc;
+    P.off_stride = off_stride;
+    P.skip = d_skip;
+    int occ = gs_filter_occupancy();
+    if (occ < 1) occ = 1;
+    if (const char *ev = getenv("GS_FILTER_BLOCKS_PER_CU")) {
+        const int v = atoi(ev);
+        if (v >= 1 && v <= 16) occ = v;
+    }
+    int grid = (int)std::min<int64_t>((int64_t)b->n_cu * occ, (n_reads + 3) / 4);
+    if (grid < 1) grid = 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, b->stream));
+    }
+    HIP_TRY(gs_launch_filter(&P, grid, b->stream));
+    if (profile) {
+        HIP_TRY(hipEventRecord(e1, b->stream));
+        b->pending.push_back({e0, e1});
+    }
+    return GS_OK;
 }
 
 extern "C" int gs_filter_submit(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *seq,
@@ -1378,45 +1449,8 @@ extern "C" int gs_filter_submit(gs_bloom *b, int k, int min_pos_count, double po
     } else if (mem != GS_MEM_DEVICE)
         return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
 
-    GsFilterParams P{};
-    P.kind = b->kind;
-    P.k = k;
-    P.min_pos_count = min_pos_count;
-    P.positive_ratio = positive_ratio;
-    P.bits = (u64)b->bits;
-    P.n_hashes = b->n_hashes;
-    P.words = b->d_words;
-    P.factors = b->d_factors;
-    {
-        u64 mg = 0;
-        int sh = 0;
-        magic_u64((u64)b->bits, mg, sh);
-        P.magic = mg;
-        P.magic_shift = sh;
-    }
-    P.seq = d_seq;
-    P.off = d_off;
-    P.n_reads = n_reads;
-    P.accept = d_acc;
-    int occ = gs_filter_occupancy();
-    if (occ < 1) occ = 1;
-    if (const char *ev = getenv("GS_FILTER_BLOCKS_PER_CU")) {
-        const int v = atoi(ev);
-        if (v >= 1 && v <= 16) occ = v;
-    }
-    int grid = (int)std::min<int64_t>((int64_t)b->n_cu * occ, (n_reads + 3) / 4);
-    if (grid < 1) grid = 1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, b->stream));
-    }
-    HIP_TRY(gs_launch_filter(&P, grid, b->stream));
-    if (profile) {
-        HIP_TRY(hipEventRecord(e1, b->stream));
-        b->pending.push_back({e0, e1});
-    }
+    int rc = filter_launch(b, k, min_pos_count, positive_ratio, d_seq, d_off, n_reads, d_acc, 1, nullptr, profile);
+    if (rc) return rc;
     if (mem == GS_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1430,6 +1464,62 @@ extern "C" int gs_filter_sync(gs_bloom *b) {
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return bloom_collect(b);
+}
+
+// ---- text mode of the filter (see gs_match_submit_text) ----
+extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                                     int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines,
+                                     int profile, int64_t *ticket) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
+    if (n_lines > 0 && !accept) return fail(GS_E_INVALID, "accept is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    const int64_t n_reads = n_lines >> 2;
+    int rc = text_submit(b->text, b->stream, text, n_bytes, n_lines, mem, k, ticket);
+    if (rc) return rc;
+    if (n_reads == 0) return GS_OK;
+    const bool dev_out = mem == GS_MEM_DEVICE;
+    if (!dev_out && b->reads_cap < (size_t)n_reads) {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        hipFree(b->d_off);
+        hipFree(b->d_accept);
+        b->d_off = nullptr;
+        b->d_accept = nullptr;
+        b->reads_cap = 0;
+        HIP_TRY(hipMalloc((void **)&b->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+        HIP_TRY(hipMalloc((void **)&b->d_accept, (size_t)n_reads));
+        b->reads_cap = (size_t)n_reads;
+    }
+    uint8_t *d_acc = dev_out ? accept : b->d_accept;
+    // a refused chunk leaves `accept` untouched: zero it so that stale flags never look like results
+    HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_reads, b->stream));
+    rc = filter_launch(b, k, min_pos_count, positive_ratio, b->text.d_text, (const uint64_t *)b->text.d_off2, n_reads, d_acc, 2,
+                       b->text.d_status + GS_TS_SKIP, profile);
+    if (rc) return rc;
+    const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!dev_out) HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, kind, b->stream));
+    if (newlines) HIP_TRY(hipMemcpyAsync(newlines, b->text.d_nl, sizeof(uint32_t) * (size_t)n_lines, kind, b->stream));
+    return GS_OK;
+}
+
+extern "C" int gs_filter_text_wait_copy(gs_bloom *b, int64_t ticket) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    return text_wait_copy(b->text, ticket);
+}
+
+extern "C" int gs_filter_text_status(gs_bloom *b, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = text_status(b->text, b->stream, failed_ticket, first_bad_record, totals);
+    if (rc) return rc;
+    return bloom_collect(b);
+}
+
+extern "C" int gs_filter_text_reset(gs_bloom *b, int clear_totals) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    return text_reset(b->text, clear_totals != 0, b->stream);
 }
 
 extern "C" int gs_filter_kernel_time(gs_bloom *b, int64_t *launches, double *total_ms) {

@@ -1110,9 +1110,11 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
     // bit i of the filter = bit (i & 31) of 32-bit word i >> 5 (little endian): a dword load with a scalar base and a
     // 32-bit lane offset is the cheapest scattered load there is (XOR / Murmur filters are limited to 2^37 bits)
     const uint32_t *words32 = reinterpret_cast<const uint32_t *>(P.words);
-    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
-        const u64 off = P.off[r];
-        const int L = (int)(P.off[r + 1] - off);
+    const int64_t n_reads = (P.skip != nullptr && *P.skip != 0) ? 0 : P.n_reads;
+    for (int64_t r = wave_id; r < n_reads; r += n_waves) {
+        const uint64_t *po = P.off + r * P.off_stride;
+        const u64 off = po[0];
+        const int L = (int)(po[1] - off);
         const int max = L - k + 1;
         const uint8_t *rd = P.seq + off;
         int accept = 0;

@@ -71,6 +71,9 @@ struct GsFilterParams {
     const uint64_t *off;
     int64_t n_reads;
     uint8_t *accept;
+    int32_t off_stride;     // 1: running offsets; 2: (start, end) pairs (text mode, gs_text.hip)
+    int32_t pad2;
+    const uint32_t *skip;   // text mode: the launch does nothing when *skip != 0
 };
 
 struct GsSegParams {

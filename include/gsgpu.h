@@ -254,6 +254,18 @@ int gs_bloom_destroy(gs_bloom *bloom);
 int gs_filter_submit(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *seq,
                      const uint64_t *offsets, int64_t n_reads, int mem, uint8_t *accept, int profile);
 int gs_filter_sync(gs_bloom *bloom);
+/* Text mode of the filter, as gs_match_submit_text: a chunk of raw four-line FASTQ, records found (and checked) on the
+ * device.  accept[n_lines / 4] as gs_filter_submit; newlines (may be NULL) receives the byte offset of every '\n' of
+ * the chunk, i.e. the record geometry the caller needs to rewrite the accepted reads (FastqBloomFilter.java:92-105).
+ * Both live in the same memory kind as text and are complete after gs_filter_sync; a refused chunk yields all-zero
+ * accept flags and shows up in gs_filter_text_status.  gs_filter_text_reset clears the refusal (and, if asked, the
+ * totals of the accepted chunks). */
+int gs_filter_submit_text(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                          int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines, int profile,
+                          int64_t *ticket);
+int gs_filter_text_wait_copy(gs_bloom *bloom, int64_t ticket);
+int gs_filter_text_status(gs_bloom *bloom, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
+int gs_filter_text_reset(gs_bloom *bloom, int clear_totals);
 int gs_filter_kernel_time(gs_bloom *bloom, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

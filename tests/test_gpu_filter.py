@@ -88,3 +88,60 @@ def test_filter_consistent_with_match(sdb):
     m.close()
     store.close()
     gb.close()
+
+
+# ------------------------------------------------------------------ text mode (records found on the device)
+def _fastq(seq, off, nl=b"\n"):
+    recs = []
+    for i in range(len(off) - 1):
+        s = seq[int(off[i]):int(off[i + 1])].tobytes()
+        if i % 9 == 4:
+            s = s[:i % 37]  # short and empty reads
+        recs.append(b"@q%d" % i + nl + s + nl + b"+" + nl + b"#" * len(s) + nl)
+    return recs
+
+
+@pytest.mark.parametrize("kind,fpp,min_pos,ratio", [(ga.BLOOM_XOR, 1e-8, 1, 0.2), (ga.BLOOM_XOR, 0.05, 0, 0.5),
+                                                   (ga.BLOOM_MURMUR, 1e-4, 3, 0.2), (ga.BLOOM_BLOCKED, 0.01, 1, 0.2)])
+def test_filter_text_mode_matches_oracle(sdb, kind, fpp, min_pos, ratio):
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:5])]
+    ob, gb = _filters(keys, kind, fpp)
+    seq, off = _reads(sdb, 3000)
+    for nl in (b"\n", b"\r\n"):
+        text = b"".join(_fastq(seq, off, nl))
+        p = orc.parse_fastq(text, k=31)  # what the reference parser makes of it ('\r' stays in the read)
+        pseq = p["seq"] if len(p["seq"]) else np.zeros(1, dtype=np.uint8)
+        want = ob.filter_batch(31, min_pos, ratio, pseq, p["seq_off"], threads=4)
+        f = ga.FastqBloomFilter(31, gb, min_pos, ratio)
+        acc = np.full(3000, 7, dtype=np.uint8)
+        nls = np.zeros(12000, dtype=np.uint32)
+        f.submit_text(text, acc, newlines=nls)
+        f.sync()
+        assert f.text_status()[0] == -1
+        assert np.array_equal(acc, want), np.flatnonzero(acc != want)[:10]
+        assert np.array_equal(nls, np.flatnonzero(np.frombuffer(text, dtype=np.uint8) == 10).astype(np.uint32))
+        f.text_reset(True)
+    gb.close()
+
+
+def test_filter_text_mode_refusal(sdb):
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:5])]
+    ob, gb = _filters(keys, ga.BLOOM_XOR, 1e-8)
+    seq, off = _reads(sdb, 40)
+    recs = _fastq(seq, off)
+    bad = b"".join(recs[:3]) + b"@x\nACGT\nACGT\n+\nIIIIIIII\n@y\nAC\n+\n"  # multi-line record: 12 + 8 lines
+    f = ga.FastqBloomFilter(31, gb, 1, 0.2)
+    acc = np.full(5, 9, dtype=np.uint8)
+    f.submit_text(bad, acc)
+    f.sync()
+    failed, first_bad, tot = f.text_status()
+    assert failed == 0 and first_bad == 3 and tot == (0, 0, 0)
+    assert not acc.any()  # a refused chunk never reports stale flags
+    f.text_reset()
+    acc2 = np.zeros(40, dtype=np.uint8)
+    f.submit_text(b"".join(recs), acc2)
+    f.sync()
+    assert f.text_status()[0] == -1
+    p = orc.parse_fastq(b"".join(recs), k=31)
+    assert np.array_equal(acc2, ob.filter_batch(31, 1, 0.2, p["seq"], p["seq_off"], threads=1))
+    gb.close()
