@@ -824,55 +824,205 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     return err;
 }
 
+namespace {
+
+struct FilterCtx {
+    gs_bloom *bloom = nullptr;
+    int k = 31, min_pos_count = 1;
+    double positive_ratio = 0.2;
+    OutFile acc_out, rest_out;
+    std::vector<uint8_t> accept, tmp;
+    int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
+    double t_gpu = 0, t_parse = 0;
+};
+
+// the general path for one source (file from `offset`, or a memory range): reference parser -> batches -> GPU -> writers
+int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n) {
+    Producer prod;
+    prod.start(path, offset, mem, mem_n, c.k, (int64_t)1 << 20);
+    int err = GS_OK;
+    for (;;) {
+        std::unique_ptr<Batch> b = prod.q.pop();
+        if (!b) break;
+        if (err) continue;
+        const int64_t n = b->n();
+        c.accept.resize((size_t)n);
+        if (b->seq.empty()) b->seq.push_back(0);
+        const double t0 = now_s();
+        err = gs_filter_submit(c.bloom, c.k, c.min_pos_count, c.positive_ratio, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST,
+                               c.accept.data(), 0);
+        c.t_gpu += now_s() - t0;
+        if (err) continue;
+        for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+            if (c.accept[(size_t)i]) {
+                c.accepted++;
+                if (c.acc_out.active()) write_read(c.acc_out, *b, i, false, c.tmp);
+            } else if (c.rest_out.active())
+                write_read(c.rest_out, *b, i, false, c.tmp);
+        }
+    }
+    prod.th.join();
+    if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
+    c.reads += prod.reads;
+    c.kmers += prod.kmers;
+    c.bps += prod.bps;
+    c.t_parse += prod.seconds;
+    return err;
+}
+
+// ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", '~' x length
+void write_text_record(OutFile &out, const uint8_t *text, const uint32_t *nl, int64_t i, std::vector<uint8_t> &tmp) {
+    const size_t d0 = i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1, d1 = nl[4 * i], s0 = d1 + 1, s1 = nl[4 * i + 1];
+    tmp.clear();
+    tmp.insert(tmp.end(), text + d0, text + d1);
+    tmp.push_back('\n');
+    tmp.insert(tmp.end(), text + s0, text + s1);
+    tmp.push_back('\n');
+    tmp.push_back('+');
+    tmp.push_back('\n');
+    tmp.insert(tmp.end(), s1 - s0, (uint8_t)'~');
+    tmp.push_back('\n');
+    out.write(tmp.data(), tmp.size());
+}
+
+// plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
+int filter_text_file(FilterCtx &c, const std::string &path) {
+    size_t block = (size_t)8 << 20;
+    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
+    }
+    int readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("GS_HOST_READERS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) readers = v;
+    }
+    TextReader tr;
+    int err = tr.open(path, block, readers);
+    if (err) {
+        tr.close();
+        return err;
+    }
+    err = gs_filter_text_reset(c.bloom, 1);
+    // results of a chunk land in pinned memory: accept flags + newline offsets
+    uint8_t *h_acc = nullptr;
+    uint32_t *h_nl = nullptr;
+    size_t acc_cap = 0, nl_cap = 0;
+    std::vector<uint8_t> carry;
+    int64_t carry_lines = 0, carry_file_off = 0, fallback_off = -1;
+    int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
+    const double t0 = now_s();
+    if (!err) tr.start();
+    for (int64_t i = 0; !err; i++) {
+        TextSlot &sl = tr.wait_full(i);
+        if (sl.io_error) {
+            err = hfail(GS_E_INVALID, "read error on " + path);
+            break;
+        }
+        uint8_t *blk = sl.buf + tr.headroom;
+        const int64_t total = carry_lines + sl.newlines;
+        const int64_t rem = total & 3, usable = total - rem;
+        const bool eof = sl.eof;
+        if (usable == 0) {
+            carry.insert(carry.end(), blk, blk + sl.n);
+            carry_lines = total;
+            if (carry.size() > tr.headroom && !eof) fallback_off = carry_file_off;
+        } else if (carry.size() > tr.headroom) {
+            fallback_off = carry_file_off;
+        } else {
+            const int64_t cut = sl.last4[rem];
+            uint8_t *start = blk - carry.size();
+            if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+            const int64_t n_reads = usable >> 2;
+            if (acc_cap < (size_t)n_reads) {
+                gs_pinned_free(h_acc);
+                h_acc = nullptr;
+                acc_cap = (size_t)n_reads + (size_t)n_reads / 4;
+                void *p = nullptr;
+                if ((err = gs_pinned_alloc(&p, acc_cap))) break;
+                h_acc = (uint8_t *)p;
+            }
+            if (nl_cap < (size_t)usable) {
+                gs_pinned_free(h_nl);
+                h_nl = nullptr;
+                nl_cap = (size_t)usable + (size_t)usable / 4;
+                void *p = nullptr;
+                if ((err = gs_pinned_alloc(&p, nl_cap * sizeof(uint32_t)))) break;
+                h_nl = (uint32_t *)p;
+            }
+            int64_t ticket = -1;
+            const double tg = now_s();
+            err = gs_filter_submit_text(c.bloom, c.k, c.min_pos_count, c.positive_ratio, start, (int64_t)carry.size() + cut + 1,
+                                        usable, GS_MEM_HOST, h_acc, h_nl, 0, &ticket);
+            if (!err) err = gs_filter_text_status(c.bloom, &failed, &bad, tot);  // synchronises: results are needed now
+            c.t_gpu += now_s() - tg;
+            if (err) break;
+            if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
+                fallback_off = carry_file_off;
+            } else {
+                for (int64_t r = 0; r < n_reads; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                    if (h_acc[r]) {
+                        c.accepted++;
+                        if (c.acc_out.active()) write_text_record(c.acc_out, start, h_nl, r, c.tmp);
+                    } else if (c.rest_out.active())
+                        write_text_record(c.rest_out, start, h_nl, r, c.tmp);
+                }
+                carry_file_off = i * (int64_t)tr.block + cut + 1;
+                carry.assign(blk + cut + 1, blk + sl.n);
+                carry_lines = rem;
+            }
+        }
+        tr.release(i);
+        if (eof || fallback_off >= 0) break;
+    }
+    tr.close();
+    gs_pinned_free(h_acc);
+    gs_pinned_free(h_nl);
+    c.t_parse += now_s() - t0;
+    if (err) return err;
+    c.reads += tot[0];
+    c.kmers += tot[1];
+    c.bps += tot[2];
+    if (fallback_off >= 0) {
+        err = gs_filter_text_reset(c.bloom, 1);
+        if (err) return err;
+        return filter_parsed_source(c, path, fallback_off, nullptr, 0);
+    }
+    if (!carry.empty()) return filter_parsed_source(c, std::string(), 0, carry.data(), carry.size());
+    return GS_OK;
+}
+
+}  // namespace
+
 extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio,
                                     const char *const *paths, int n_paths, const char *filtered_path,
                                     const char *rest_path, gs_host_totals *totals) {
     if (!bloom || !paths || n_paths < 0) return hfail(GS_E_INVALID, "NULL argument");
-    OutFile acc_out, rest_out;
-    if (!acc_out.open(filtered_path) || !rest_out.open(rest_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    FilterCtx c;
+    c.bloom = bloom;
+    c.k = k;
+    c.min_pos_count = min_pos_count;
+    c.positive_ratio = positive_ratio;
+    if (!c.acc_out.open(filtered_path) || !c.rest_out.open(rest_path)) return hfail(GS_E_INVALID, "cannot open output file");
     const double t_start = now_s();
-    std::vector<uint8_t> accept, tmp;
-    int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
-    double t_gpu = 0, t_parse = 0;
+    bool fast = true;
+    if (const char *e = getenv("GS_HOST_FAST")) fast = atoi(e) != 0;
     int err = GS_OK;
     for (int f = 0; f < n_paths && !err; f++) {
-        Producer prod;
-        prod.start(std::string(paths[f]), 0, nullptr, 0, k, (int64_t)1 << 20);
-        for (;;) {
-            std::unique_ptr<Batch> b = prod.q.pop();
-            if (!b) break;
-            if (err) continue;
-            const int64_t n = b->n();
-            accept.resize((size_t)n);
-            if (b->seq.empty()) b->seq.push_back(0);
-            const double t0 = now_s();
-            err = gs_filter_submit(bloom, k, min_pos_count, positive_ratio, b->seq.data(), b->seq_off.data(), n, GS_MEM_HOST,
-                                   accept.data(), 0);
-            t_gpu += now_s() - t0;
-            if (err) continue;
-            for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-                if (accept[(size_t)i]) {
-                    accepted++;
-                    if (acc_out.active()) write_read(acc_out, *b, i, false, tmp);
-                } else if (rest_out.active())
-                    write_read(rest_out, *b, i, false, tmp);
-            }
-        }
-        prod.th.join();
-        if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
-        reads += prod.reads;
-        kmers += prod.kmers;
-        bps += prod.bps;
-        t_parse += prod.seconds;
+        const std::string path(paths[f]);
+        if (fast && plain_fastq_file(path))
+            err = filter_text_file(c, path);
+        else
+            err = filter_parsed_source(c, path, 0, nullptr, 0);
     }
     if (totals) {
-        totals->reads = reads;
-        totals->kmers = kmers;
-        totals->bps = bps;
-        totals->filtered_reads = accepted;
+        totals->reads = c.reads;
+        totals->kmers = c.kmers;
+        totals->bps = c.bps;
+        totals->filtered_reads = c.accepted;
         totals->seconds_total = now_s() - t_start;
-        totals->seconds_parse = t_parse;
-        totals->seconds_gpu = t_gpu;
+        totals->seconds_parse = c.t_parse;
+        totals->seconds_gpu = c.t_gpu;
     }
     return err;
 }

@@ -199,3 +199,47 @@ def test_match_files_empty_file(sdb, tmp_path):
     table, _, tot = host.match_files(store, [path])
     assert tot.reads == 0 and not table[:, :9].any()
     store.close()
+
+
+@pytest.mark.parametrize("block", [0, 100, 5000])
+@pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "nul"])
+def test_filter_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypatch, block, shape):
+    """gs_host_filter_files over plain FASTQ: the device-side record scan must give byte-identical output files
+    and totals to the reference-exact parser path, whatever the file shape and the block size"""
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    recs = _fastq_bytes(sdb, 500, seed=31, nl=b"\r\n" if shape == "crlf" else b"\n")
+    if shape == "multi-line record":
+        s = recs[300].split(b"\n")
+        recs[300] = s[0] + b"\n" + s[1][:50] + b"\n" + s[1][50:] + b"\n+\n" + s[3] + b"\n"
+    data = b"".join(recs)
+    if shape == "no final newline":
+        data = data[:-1]
+    elif shape == "nul":
+        data = data[:20000] + b"\0" + data[20000:]
+    path = str(tmp_path / "in.fq")
+    open(path, "wb").write(data)
+    p = orc.parse_fastq(data, k=31)
+    pseq = p["seq"] if len(p["seq"]) else np.zeros(1, dtype=np.uint8)
+    want = ob.filter_batch(31, 1, 0.2, pseq, p["seq_off"])
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_FAST", fast)
+        if block:
+            monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+        a, r = str(tmp_path / f"acc{fast}.fastq"), str(tmp_path / f"rest{fast}.fastq")
+        tot = host.filter_files(gb, 31, [path], filtered_path=a, rest_path=r)
+        assert (tot.reads, tot.kmers, tot.bps) == (int(p["n_reads"]), int(p["total_kmers"]), int(p["total_bps"]))
+        assert tot.filtered_reads == int(want.sum())
+        outs[fast] = (open(a, "rb").read(), open(r, "rb").read())
+    assert outs["1"] == outs["0"]
+    # and the accepted file holds exactly the oracle's accepted reads, rewritten like ReadEntry.write
+    exp = b""
+    for i in np.flatnonzero(want):
+        d = bytes(p["desc"][int(p["desc_off"][i]):int(p["desc_off"][i + 1])])
+        s = bytes(p["seq"][int(p["seq_off"][i]):int(p["seq_off"][i + 1])])
+        exp += d + b"\n" + s + b"\n+\n" + b"~" * len(s) + b"\n"
+    assert outs["1"][0] == exp
+    gb.close()
