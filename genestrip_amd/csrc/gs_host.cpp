@@ -871,18 +871,23 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
 }
 
 // ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", '~' x length
-void write_text_record(OutFile &out, const uint8_t *text, const uint32_t *nl, int64_t i, std::vector<uint8_t> &tmp) {
+// (appended to `buf`; the caller writes one buffer per chunk)
+void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const uint32_t *nl, int64_t i) {
     const size_t d0 = i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1, d1 = nl[4 * i], s0 = d1 + 1, s1 = nl[4 * i + 1];
-    tmp.clear();
-    tmp.insert(tmp.end(), text + d0, text + d1);
-    tmp.push_back('\n');
-    tmp.insert(tmp.end(), text + s0, text + s1);
-    tmp.push_back('\n');
-    tmp.push_back('+');
-    tmp.push_back('\n');
-    tmp.insert(tmp.end(), s1 - s0, (uint8_t)'~');
-    tmp.push_back('\n');
-    out.write(tmp.data(), tmp.size());
+    const size_t at = buf.size(), dl = d1 - d0, sl = s1 - s0;
+    buf.resize(at + dl + 2 * sl + 5);
+    uint8_t *o = buf.data() + at;
+    memcpy(o, text + d0, dl);
+    o += dl;
+    *o++ = '\n';
+    memcpy(o, text + s0, sl);
+    o += sl;
+    *o++ = '\n';
+    *o++ = '+';
+    *o++ = '\n';
+    memset(o, '~', sl);
+    o += sl;
+    *o = '\n';
 }
 
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
@@ -908,7 +913,7 @@ int filter_text_file(FilterCtx &c, const std::string &path) {
     uint8_t *h_acc = nullptr;
     uint32_t *h_nl = nullptr;
     size_t acc_cap = 0, nl_cap = 0;
-    std::vector<uint8_t> carry;
+    std::vector<uint8_t> carry, acc_buf, rest_buf;
     int64_t carry_lines = 0, carry_file_off = 0, fallback_off = -1;
     int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
     const double t0 = now_s();
@@ -960,13 +965,17 @@ int filter_text_file(FilterCtx &c, const std::string &path) {
             if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
                 fallback_off = carry_file_off;
             } else {
+                acc_buf.clear();
+                rest_buf.clear();
                 for (int64_t r = 0; r < n_reads; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
                     if (h_acc[r]) {
                         c.accepted++;
-                        if (c.acc_out.active()) write_text_record(c.acc_out, start, h_nl, r, c.tmp);
+                        if (c.acc_out.active()) append_text_record(acc_buf, start, h_nl, r);
                     } else if (c.rest_out.active())
-                        write_text_record(c.rest_out, start, h_nl, r, c.tmp);
+                        append_text_record(rest_buf, start, h_nl, r);
                 }
+                if (!acc_buf.empty()) c.acc_out.write(acc_buf.data(), acc_buf.size());
+                if (!rest_buf.empty()) c.rest_out.write(rest_buf.data(), rest_buf.size());
                 carry_file_off = i * (int64_t)tr.block + cut + 1;
                 carry.assign(blk + cut + 1, blk + sl.n);
                 carry_lines = rem;
