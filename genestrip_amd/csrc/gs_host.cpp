@@ -451,6 +451,47 @@ struct TextSlot {
     bool eof = false, io_error = false;
 };
 
+// page-locked blocks are expensive to create (the driver pins every page): the pipelines of one process reuse them
+// from file to file.  At most 64 idle blocks are kept; they are deliberately not released at exit (the HIP runtime
+// may already be gone when static destructors run).
+class PinnedPool {
+public:
+    int get(size_t bytes, uint8_t **out) {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t i = 0; i < idle_.size(); i++)
+                if (idle_[i].second == bytes) {
+                    *out = idle_[i].first;
+                    idle_.erase(idle_.begin() + (long)i);
+                    return GS_OK;
+                }
+        }
+        void *p = nullptr;
+        const int rc = gs_pinned_alloc(&p, bytes);
+        *out = (uint8_t *)p;
+        return rc;
+    }
+    void put(uint8_t *p, size_t bytes) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (idle_.size() < 64) {
+                idle_.push_back({p, bytes});
+                return;
+            }
+        }
+        gs_pinned_free(p);
+    }
+
+private:
+    std::mutex m_;
+    std::vector<std::pair<uint8_t *, size_t>> idle_;
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *pool = new PinnedPool();
+    return *pool;
+}
+
 struct TextReader {
     int fd = -1;
     size_t block = 0, headroom = 0;
@@ -474,10 +515,8 @@ struct TextReader {
         n_slots = 2 * readers;
         slots.resize((size_t)n_slots);
         for (auto &sl : slots) {
-            void *p = nullptr;
-            int rc = gs_pinned_alloc(&p, headroom + block);
+            int rc = pinned_pool().get(headroom + block, &sl.buf);
             if (rc) return rc;
-            sl.buf = (uint8_t *)p;
         }
         return GS_OK;
     }
@@ -544,7 +583,7 @@ struct TextReader {
         cv.notify_all();
         for (auto &t : threads) t.join();
         threads.clear();
-        for (auto &sl : slots) gs_pinned_free(sl.buf);
+        for (auto &sl : slots) pinned_pool().put(sl.buf, headroom + block);
         slots.clear();
         if (fd >= 0) ::close(fd);
         fd = -1;
