@@ -3,9 +3,12 @@
 // Kraken-style and filtered-FASTQ writers, completeResults + CSV.  Plain C++17 + zlib; all GPU work goes through
 // the C ABI of include/gsgpu.h.
 #include "../../include/gshost.h"
+#include "gs_inflate.h"
 
 #include <errno.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -389,6 +392,30 @@ extern "C" int gs_fastq_close(gs_fastq *r) {
 
 extern "C" const char *gs_host_last_error(void) { return g_host_err.c_str(); }
 
+// the ingest path's gzip decoder on a memory range, delivering `block` bytes per decode call (test hook)
+extern "C" int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, size_t block) {
+    if ((!in && n_in) || !out || !n_out || block == 0) return hfail(GS_E_INVALID, "bad argument");
+    std::unique_ptr<GsInflate> inf(new GsInflate());
+    inf->init(in, n_in, true);
+    size_t total = 0;
+    for (;;) {
+        size_t room = out_cap - total;
+        if (room > block) room = block;
+        size_t p = 0;
+        const GsInflate::Status st = inf->decode(out + total, room, total, &p);
+        total += p;
+        if (st == GsInflate::CORRUPT) return hfail(GS_E_INVALID, "corrupt gzip stream");
+        if (st == GsInflate::DONE) break;
+        if (total == out_cap) {  // the stream may just have ended: one more call without room tells
+            const GsInflate::Status st2 = inf->decode(out + total, 0, total, &p);
+            if (st2 == GsInflate::DONE) break;
+            return hfail(st2 == GsInflate::CORRUPT ? GS_E_INVALID : GS_E_NOMEM, st2 == GsInflate::CORRUPT ? "corrupt gzip stream" : "output buffer too small");
+        }
+    }
+    *n_out = total;
+    return GS_OK;
+}
+
 extern "C" int gs_host_java_double(double v, char *buf, int cap) {
     const std::string s = java_double(v);
     if (!buf || cap <= (int)s.size()) return GS_E_INVALID;
@@ -449,6 +476,7 @@ struct TextSlot {
     int64_t last4[4] = {-1, -1, -1, -1};  // offsets of the last four newlines of the block, last first
     int state = 0;           // 0 empty, 1 full
     bool eof = false, io_error = false;
+    std::vector<std::pair<uint32_t, uint32_t>> member_ends;  // gzip input: (offset in the block, CRC-32 of the trailer)
 };
 
 // page-locked blocks are expensive to create (the driver pins every page): the pipelines of one process reuse them
@@ -503,16 +531,40 @@ struct TextReader {
     bool stop = false;
     int64_t start_off = 0;
 
-    int open(const std::string &path, size_t block_bytes, int readers) {
-        fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
+    // gzip input: the file is mapped and ONE thread inflates it into the blocks, in order (a gzip stream is serial);
+    // the CRC-32 of the members is left to the consumer of the blocks (verify_gzip), which has the time
+    bool gz = false;
+    const uint8_t *map = nullptr;
+    size_t map_len = 0;
+    uint32_t run_crc = 0;
+
+    int open(const std::string &path, size_t block_bytes, int readers, bool gzip) {
+        if (gzip) {
+            gz = true;
+            fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
+            struct stat sb;
+            if (fstat(fd, &sb) != 0) return hfail(GS_E_INVALID, "cannot stat " + path);
+            map_len = (size_t)sb.st_size;
+            if (map_len) {
+                void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) return hfail(GS_E_INVALID, "cannot map " + path);
+                map = (const uint8_t *)m;
+                madvise(m, map_len, MADV_SEQUENTIAL);
+            }
+            if (block_bytes < ((size_t)64 << 10)) block_bytes = (size_t)64 << 10;  // the 32 KiB window lives in the headroom
+            readers = 1;
+        } else {
+            fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
 #ifdef POSIX_FADV_SEQUENTIAL
-        posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+            posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
 #endif
+        }
         block = block_bytes;
         headroom = block_bytes;
         n_threads = readers;
-        n_slots = 2 * readers;
+        n_slots = gzip ? 4 : 2 * readers;
         slots.resize((size_t)n_slots);
         for (auto &sl : slots) {
             int rc = pinned_pool().get(headroom + block, &sl.buf);
@@ -520,7 +572,81 @@ struct TextReader {
         }
         return GS_OK;
     }
+    void fill_newlines(TextSlot &sl, const uint8_t *dst, size_t got) {
+        sl.newlines = (int64_t)count_newlines(dst, got);
+        size_t end = got;
+        for (int j = 0; j < 4; j++) {
+            const void *q = end ? memrchr(dst, '\n', end) : nullptr;
+            sl.last4[j] = q ? (int64_t)((const uint8_t *)q - dst) : -1;
+            end = q ? (size_t)((const uint8_t *)q - dst) : 0;
+        }
+    }
+    void start_gzip() {
+        threads.emplace_back([this] {
+            std::unique_ptr<GsInflate> inf(new GsInflate());
+            inf->init(map, map_len, false);
+            std::vector<uint8_t> window(32768);
+            size_t hist = 0;
+            bool done = map_len == 0;
+            for (int64_t i = 0;; i++) {
+                TextSlot &sl = slots[(size_t)(i % n_slots)];
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return stop || sl.state == 0; });
+                    if (stop) return;
+                }
+                uint8_t *dst = sl.buf + headroom;
+                memcpy(dst - hist, window.data() + (32768 - hist), hist);
+                size_t got = 0;
+                bool err = false;
+                sl.member_ends.clear();
+                while (!done && got < block) {
+                    size_t p = 0;
+                    const GsInflate::Status st = inf->decode(dst + got, block - got, hist + got, &p);
+                    const uint64_t block_start = (uint64_t)i * block;
+                    for (int e = 0; e < inf->n_member_ends(); e++)
+                        sl.member_ends.push_back({(uint32_t)(inf->member_ends()[e].out_offset - block_start), inf->member_ends()[e].crc});
+                    inf->clear_member_ends();
+                    got += p;
+                    if (st == GsInflate::CORRUPT) err = true;
+                    if (st != GsInflate::NEED_OUTPUT) done = true;
+                }
+                const size_t keep = got < 32768 ? got : 32768;  // (a short block is the last one)
+                if (keep == 32768)
+                    memcpy(window.data(), dst + got - 32768, 32768);
+                hist = keep == 32768 ? 32768 : hist;
+                sl.n = got;
+                sl.eof = got < block || done;
+                sl.io_error = err;
+                fill_newlines(sl, dst, got);
+                {
+                    std::lock_guard<std::mutex> l(m);
+                    sl.state = 1;
+                }
+                cv.notify_all();
+                if (sl.eof || err) return;
+            }
+        });
+    }
+    // consumer side: CRC-32 of the gzip members over the delivered block (GZIPInputStream checks it while reading)
+    bool verify_gzip(const TextSlot &sl) {
+        if (!gz) return true;
+        const uint8_t *p = sl.buf + headroom;
+        size_t at = 0;
+        for (const auto &me : sl.member_ends) {
+            run_crc = GsCrc32::update(run_crc, p + at, me.first - at);
+            if (run_crc != me.second) return false;
+            run_crc = 0;
+            at = me.first;
+        }
+        run_crc = GsCrc32::update(run_crc, p + at, sl.n - at);
+        return true;
+    }
     void start() {
+        if (gz) {
+            start_gzip();
+            return;
+        }
         for (int t = 0; t < n_threads; t++)
             threads.emplace_back([this, t] {
                 for (int64_t i = t;; i += n_threads) {
@@ -546,13 +672,7 @@ struct TextReader {
                     sl.n = got;
                     sl.eof = got < block;
                     sl.io_error = err;
-                    sl.newlines = (int64_t)count_newlines(dst, got);
-                    size_t end = got;
-                    for (int j = 0; j < 4; j++) {
-                        const void *q = end ? memrchr(dst, '\n', end) : nullptr;
-                        sl.last4[j] = q ? (int64_t)((const uint8_t *)q - dst) : -1;
-                        end = q ? (size_t)((const uint8_t *)q - dst) : 0;
-                    }
+                    fill_newlines(sl, dst, got);
                     {
                         std::lock_guard<std::mutex> l(m);
                         sl.state = 1;
@@ -585,19 +705,23 @@ struct TextReader {
         threads.clear();
         for (auto &sl : slots) pinned_pool().put(sl.buf, headroom + block);
         slots.clear();
+        if (map) munmap((void *)map, map_len);
+        map = nullptr;
         if (fd >= 0) ::close(fd);
         fd = -1;
     }
 };
 
-bool plain_fastq_file(const std::string &path) {
-    if (is_fasta_name(path) || is_gzip_name(path)) return false;
+// 0: not for the text path (FASTA), 1: plain FASTQ (parallel pread), 2: gzip FASTQ (one inflating thread)
+int text_path_kind(const std::string &path) {
+    if (is_fasta_name(path)) return 0;
     FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
+    if (!f) return 0;
     unsigned char mg[2] = {0, 0};
     const size_t n = fread(mg, 1, 2, f);
     fclose(f);
-    return !(n == 2 && mg[0] == 0x1f && mg[1] == 0x8b);  // gzip content under another name: zlib path
+    const bool gzip_content = n == 2 && mg[0] == 0x1f && mg[1] == 0x8b;  // zlib decides by content, so do we
+    return gzip_content ? 2 : 1;
 }
 
 }  // namespace
@@ -712,7 +836,7 @@ struct TextChunk {
 
 // plain FASTQ without per-read outputs: blocks of raw text to the device.  Falls back to parsed_source() from the
 // first chunk the device refuses (gs_match_text_status), so any file the general path accepts gives the same result.
-int text_file(MatchCtx &c, const std::string &path) {
+int text_file(MatchCtx &c, const std::string &path, bool gzip) {
     // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
     // 24.8 GB/s of file, 4 x 32 MiB 10.6 GB/s, 8 x 128 MiB 9.1 GB/s -- blocks that stay in the CPU caches between
     // pread and the newline count win
@@ -727,7 +851,7 @@ int text_file(MatchCtx &c, const std::string &path) {
         if (v >= 1 && v <= 32) readers = v;
     }
     TextReader tr;
-    int err = tr.open(path, block, readers);
+    int err = tr.open(path, block, readers, gzip);
     if (err) {
         tr.close();
         return err;
@@ -743,8 +867,8 @@ int text_file(MatchCtx &c, const std::string &path) {
     if (!err) tr.start();
     for (int64_t i = 0; !err; i++) {
         TextSlot &sl = tr.wait_full(i);
-        if (sl.io_error) {
-            err = hfail(GS_E_INVALID, "read error on " + path);
+        if (sl.io_error || !tr.verify_gzip(sl)) {
+            err = hfail(GS_E_INVALID, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
             break;
         }
         uint8_t *blk = sl.buf + tr.headroom;
@@ -844,8 +968,9 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     int err = GS_OK;
     for (int i = 0; i < n_paths && !err; i++) {
         const std::string path(paths[i]);
-        if (fast && plain_fastq_file(path))
-            err = text_file(c, path);
+        const int kind = fast ? text_path_kind(path) : 0;
+        if (kind)
+            err = text_file(c, path, kind == 2);
         else
             err = parsed_source(c, path, 0, nullptr, 0);
     }
@@ -930,7 +1055,7 @@ void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const ui
 }
 
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
-int filter_text_file(FilterCtx &c, const std::string &path) {
+int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     size_t block = (size_t)8 << 20;
     if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
         const long long v = atoll(e);
@@ -942,7 +1067,7 @@ int filter_text_file(FilterCtx &c, const std::string &path) {
         if (v >= 1 && v <= 32) readers = v;
     }
     TextReader tr;
-    int err = tr.open(path, block, readers);
+    int err = tr.open(path, block, readers, gzip);
     if (err) {
         tr.close();
         return err;
@@ -959,8 +1084,8 @@ int filter_text_file(FilterCtx &c, const std::string &path) {
     if (!err) tr.start();
     for (int64_t i = 0; !err; i++) {
         TextSlot &sl = tr.wait_full(i);
-        if (sl.io_error) {
-            err = hfail(GS_E_INVALID, "read error on " + path);
+        if (sl.io_error || !tr.verify_gzip(sl)) {
+            err = hfail(GS_E_INVALID, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
             break;
         }
         uint8_t *blk = sl.buf + tr.headroom;
@@ -1058,8 +1183,9 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     int err = GS_OK;
     for (int f = 0; f < n_paths && !err; f++) {
         const std::string path(paths[f]);
-        if (fast && plain_fastq_file(path))
-            err = filter_text_file(c, path);
+        const int kind = fast ? text_path_kind(path) : 0;
+        if (kind)
+            err = filter_text_file(c, path, kind == 2);
         else
             err = filter_parsed_source(c, path, 0, nullptr, 0);
     }

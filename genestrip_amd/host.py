@@ -50,6 +50,7 @@ def lib():
         "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
+        "gs_host_gunzip": (ci, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -157,6 +158,16 @@ def write_csv(path, parent_vi, taxids, db_kmers, db_kmers_total, table, dtable, 
     d = np.ascontiguousarray(dtable, dtype=np.float64)
     _check(lib().gs_host_write_csv(str(path).encode(), C.byref(info), t.ctypes.data_as(C.c_void_p),
                                    d.ctypes.data_as(C.c_void_p), C.byref(totals)))
+
+
+def gunzip(data, expected_size, block=1 << 20):
+    """the ingest path's gzip decoder on bytes (test hook): returns the decoded bytes"""
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.empty(max(int(expected_size), 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(lib().gs_host_gunzip(src.ctypes.data_as(C.c_void_p) if len(src) else None, len(src), out.ctypes.data_as(C.c_void_p),
+                                int(expected_size), C.byref(n), int(block)))
+    return out[:n.value].tobytes()
 
 
 def java_double(v):

@@ -92,6 +92,11 @@ int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, const int64
 /* message of the last failure raised inside the host layer itself (failures of the C ABI: gs_last_error) */
 const char *gs_host_last_error(void);
 
+/* The ingest path's own gzip decoder (genestrip_amd/csrc/gs_inflate.h; replaces java.util.zip.GZIPInputStream,
+ * B/io/StreamProvider.java:92-100) on a memory range, `block` output bytes per decode call -- exposed for the tests:
+ * out receives the concatenated members; GS_E_INVALID for a corrupt stream (CRC-32 and ISIZE are checked). */
+int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, size_t block);
+
 /* Double.toString(double) -- exposed for the tests of the CSV writer */
 int gs_host_java_double(double v, char *buf, int cap);
 

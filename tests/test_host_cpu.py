@@ -153,3 +153,60 @@ def test_csv_complete_results(tmp_path):
     l2 = out2.read_text().split("\n")
     assert l2[0].endswith("acc. class error std. dev.;max kmer counts;")
     assert l2[1].endswith(";9;7;4;") and l2[4].endswith(";9;4;1;") and l2[2].endswith(";;")
+
+
+# ------------------------------------------------------------------ the ingest path's gzip decoder (gs_inflate.h)
+def _gz(data, level=6, strategy=0, wbits=31):
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def _gz_inputs():
+    import random
+    rnd = random.Random(7)
+    fastq = b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, bytes(rnd.choice(b"ACGT") for _ in range(150)),
+                                                bytes(rnd.choice(b"F:,#") for _ in range(150))) for i in range(1500))
+    return {
+        "empty": b"", "one byte": b"A", "fastq": fastq, "random": bytes(rnd.getrandbits(8) for _ in range(100_000)),
+        "run": b"A" * 300_000, "period 7": (b"ACGTTGC" * 50_000), "mixed": fastq[:50_000] + bytes(rnd.getrandbits(8) for _ in range(70_000)) + fastq[:90_000],
+    }
+
+
+@pytest.mark.parametrize("block", [1, 7, 4096, 1 << 20])
+def test_gunzip_equals_zlib_on_all_block_types(block):
+    """stored / fixed / dynamic blocks, every compression level, output cut into blocks of any size (the decoder must
+    resume inside a DEFLATE block and inside a match)"""
+    import zlib
+    for name, data in _gz_inputs().items():
+        if block < 4096 and len(data) > 120_000:
+            data = data[:120_000]
+        for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (4, zlib.Z_RLE)):
+            got = host.gunzip(_gz(data, level, strategy), len(data), block)
+            assert got == data, (name, level, strategy, block)
+
+
+def test_gunzip_members_header_fields_and_corruption():
+    import gzip
+    import io
+    d = _gz_inputs()
+    a, b = d["fastq"], d["mixed"]
+    assert host.gunzip(_gz(a, 6) + _gz(b, 1) + _gz(b"", 9), len(a) + len(b), 5000) == a + b  # concatenated members
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="reads.fastq", mode="wb", fileobj=buf, mtime=123) as f:  # FNAME header field
+        f.write(a)
+    assert host.gunzip(buf.getvalue(), len(a), 333) == a
+    raw = bytearray(_gz(a, 6))
+    for cut in (len(raw) // 2, len(raw) - 3, 5):
+        with pytest.raises(RuntimeError):
+            host.gunzip(bytes(raw[:cut]), len(a))       # truncated
+    flip = bytearray(raw)
+    flip[len(flip) // 2] ^= 0x10
+    with pytest.raises(RuntimeError):
+        host.gunzip(bytes(flip), len(a) + 1000)          # damaged data: bad code or CRC mismatch
+    crc = bytearray(raw)
+    crc[-6] ^= 1
+    with pytest.raises(RuntimeError):
+        host.gunzip(bytes(crc), len(a))                  # trailer CRC
+    with pytest.raises(RuntimeError):
+        host.gunzip(b"not a gzip stream at all", 100)
