@@ -468,11 +468,15 @@ struct TextScan {
     size_t tile_cap = 0, nl_cap = 0;
     u64 *d_off2 = nullptr;
     size_t off2_cap = 0;
-    uint32_t *d_status = nullptr;  // GS_TS_WORDS
-    u64 *d_totals = nullptr;       // [3] chunk scratch | [3] totals of the accepted chunks
+    // GS_TEXT_BANKS independent streams of chunks (files read side by side): a refusal in one must not silence the
+    // others, so the status words and totals exist once per bank; `bank` is the one the next calls work on
+    uint32_t *d_status = nullptr;  // GS_TEXT_BANKS x GS_TS_WORDS
+    u64 *d_totals = nullptr;       // GS_TEXT_BANKS x ([3] chunk scratch | [3] totals of the accepted chunks)
+    int bank = 0;
     hipEvent_t copied[8] = {};     // H2D of ticket t has completed: copied[t % 8]
     int64_t tickets = 0;
 };
+enum { GS_TEXT_BANKS = 16 };
 
 struct gs_run {
     gs_db *db = nullptr;
@@ -538,11 +542,22 @@ static int grow(T **p, size_t *cap, size_t need, hipStream_t stream) {
     return GS_OK;
 }
 
-static int text_reset(TextScan &t, bool totals, hipStream_t stream) {
+static int text_reset_bank(TextScan &t, int bank, bool totals, hipStream_t stream) {
+    uint32_t *st = t.d_status + (size_t)bank * GS_TS_WORDS;
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(uint32_t) * GS_TS_WORDS, stream));
+    HIP_TRY(hipMemsetAsync(st + GS_TS_FIRST_BAD, 0xff, sizeof(uint32_t), stream));
+    if (totals) HIP_TRY(hipMemsetAsync(t.d_totals + (size_t)bank * 6, 0, sizeof(u64) * 6, stream));
+    return GS_OK;
+}
+
+// the selected bank, or (all = true: begin / reset of the handle) every bank
+static int text_reset(TextScan &t, bool totals, hipStream_t stream, bool all = false) {
     if (!t.d_status) return GS_OK;
-    HIP_TRY(hipMemsetAsync(t.d_status, 0, sizeof(uint32_t) * GS_TS_WORDS, stream));
-    HIP_TRY(hipMemsetAsync(t.d_status + GS_TS_FIRST_BAD, 0xff, sizeof(uint32_t), stream));
-    if (totals) HIP_TRY(hipMemsetAsync(t.d_totals, 0, sizeof(u64) * 6, stream));
+    if (!all) return text_reset_bank(t, t.bank, totals, stream);
+    for (int b = 0; b < GS_TEXT_BANKS; b++) {
+        int rc = text_reset_bank(t, b, totals, stream);
+        if (rc) return rc;
+    }
     return GS_OK;
 }
 
@@ -557,9 +572,9 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
     if (!t.d_status) {
-        HIP_TRY(hipMalloc((void **)&t.d_status, sizeof(uint32_t) * GS_TS_WORDS));
-        HIP_TRY(hipMalloc((void **)&t.d_totals, sizeof(u64) * 6));
-        int rc = text_reset(t, true, stream);
+        HIP_TRY(hipMalloc((void **)&t.d_status, sizeof(uint32_t) * GS_TS_WORDS * GS_TEXT_BANKS));
+        HIP_TRY(hipMalloc((void **)&t.d_totals, sizeof(u64) * 6 * GS_TEXT_BANKS));
+        int rc = text_reset(t, true, stream, true);
         if (rc) return rc;
         for (hipEvent_t &ev : t.copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
@@ -582,9 +597,9 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     T.tile_count = t.d_tile;
     T.nl = t.d_nl;
     T.off2 = (unsigned long long *)t.d_off2;
-    T.chunk_totals = (unsigned long long *)t.d_totals;
-    T.run_totals = (unsigned long long *)t.d_totals + 3;
-    T.status = t.d_status;
+    T.chunk_totals = (unsigned long long *)t.d_totals + (size_t)t.bank * 6;
+    T.run_totals = T.chunk_totals + 3;
+    T.status = t.d_status + (size_t)t.bank * GS_TS_WORDS;
     T.k = k;
     HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
     t.tickets = tk + 1;
@@ -607,8 +622,8 @@ static int text_status(TextScan &t, hipStream_t stream, int64_t *failed_ticket, 
     if (!t.d_status) return GS_OK;
     uint32_t st[GS_TS_WORDS];
     u64 tt[6];
-    HIP_TRY(hipMemcpyAsync(st, t.d_status, sizeof(st), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(tt, t.d_totals, sizeof(tt), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(st, t.d_status + (size_t)t.bank * GS_TS_WORDS, sizeof(st), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(tt, t.d_totals + (size_t)t.bank * 6, sizeof(tt), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (st[GS_TS_STICKY]) {
         if (failed_ticket) *failed_ticket = (int64_t)st[GS_TS_FAILED_TICKET];
@@ -892,7 +907,7 @@ extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_
     int32_t *dc = class_vi ? (dev_out ? class_vi : run->d_class) : nullptr;
     uint8_t *df = flags ? (dev_out ? flags : run->d_flags) : nullptr;
     rc = launch_batch(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
-                      run->text.d_status + GS_TS_SKIP);
+                      run->text.d_status + (size_t)run->text.bank * GS_TS_WORDS + GS_TS_SKIP);
     if (rc) return rc;
     if (!dev_out) {  // complete after gs_match_sync
         if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
@@ -913,6 +928,13 @@ extern "C" int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t
     int rc = text_status(run->text, run->stream, failed_ticket, first_bad_record, totals);
     if (rc) return rc;
     return collect_events(run);
+}
+
+extern "C" int gs_match_text_select(gs_run *run, int bank) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (bank < 0 || bank >= GS_TEXT_BANKS) return fail(GS_E_INVALID, "text bank out of range");
+    run->text.bank = bank;
+    return GS_OK;
 }
 
 extern "C" int gs_match_text_clear_error(gs_run *run) {
@@ -976,7 +998,7 @@ extern "C" int gs_match_reset(gs_run *run) {
     if (rc) return rc;
     rc = run_clear(run);  // kernel-time counters stay cumulative over the life of the handle
     if (rc) return rc;
-    return text_reset(run->text, true, run->stream);
+    return text_reset(run->text, true, run->stream, true);
 }
 
 extern "C" int gs_match_destroy(gs_run *run) {
@@ -1494,7 +1516,7 @@ extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, doub
     // a refused chunk leaves `accept` untouched: zero it so that stale flags never look like results
     HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_reads, b->stream));
     rc = filter_launch(b, k, min_pos_count, positive_ratio, b->text.d_text, (const uint64_t *)b->text.d_off2, n_reads, d_acc, 2,
-                       b->text.d_status + GS_TS_SKIP, profile);
+                       b->text.d_status + (size_t)b->text.bank * GS_TS_WORDS + GS_TS_SKIP, profile);
     if (rc) return rc;
     const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (!dev_out) HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, kind, b->stream));

@@ -682,6 +682,10 @@ struct TextReader {
                 }
             });
     }
+    bool is_full(int64_t i) {
+        std::lock_guard<std::mutex> l(m);
+        return slots[(size_t)(i % n_slots)].state == 1;
+    }
     TextSlot &wait_full(int64_t i) {
         TextSlot &sl = slots[(size_t)(i % n_slots)];
         std::unique_lock<std::mutex> l(m);
@@ -744,13 +748,13 @@ struct MatchCtx {
 };
 
 // one parsed batch through the GPU and the per-read writers
-int consume_batch(MatchCtx &c, Batch &b) {
+int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
     const int64_t n = b.n();
     c.cls.resize((size_t)n);
     c.flags.resize((size_t)n);
     if (b.seq.empty()) b.seq.push_back(0);
     const double t0 = now_s();
-    int err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, c.global_read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
+    int err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
     if (!err && c.kraken.active()) {
         c.seg_off.resize((size_t)n + 1);
         err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, c.seg_off.data());
@@ -762,7 +766,7 @@ int consume_batch(MatchCtx &c, Batch &b) {
     }
     c.t_gpu += now_s() - t0;
     if (err) return err;
-    c.global_read_no += n;
+    read_no += n;
     const gs_host_match_opts *opts = c.opts;
     for (int64_t i = 0; i < n; i++) {
         if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
@@ -810,7 +814,7 @@ int consume_batch(MatchCtx &c, Batch &b) {
 }
 
 // the general path: the reference's record parser on a producer thread (file from `offset`, or a memory range)
-int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n) {
+int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int64_t &read_no) {
     Producer prod;
     prod.start(path, offset, mem, mem_n, c.info.k, c.opts->batch_reads > 0 ? c.opts->batch_reads : (int64_t)1 << 20);
     int err = GS_OK;
@@ -818,7 +822,7 @@ int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const ui
         std::unique_ptr<Batch> b = prod.q.pop();
         if (!b) break;
         if (err) continue;  // keep draining so the producer can finish
-        err = consume_batch(c, *b);
+        err = consume_batch(c, *b, read_no);
     }
     prod.th.join();
     if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
@@ -832,119 +836,143 @@ int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const ui
 struct TextChunk {
     int64_t file_off;  // of the chunk's first byte
     int64_t reads_before;  // reads of this file in earlier chunks
+    int64_t ticket;
 };
 
-// plain FASTQ without per-read outputs: blocks of raw text to the device.  Falls back to parsed_source() from the
-// first chunk the device refuses (gs_match_text_status), so any file the general path accepts gives the same result.
-int text_file(MatchCtx &c, const std::string &path, bool gzip) {
-    // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
-    // 24.8 GB/s of file, 4 x 32 MiB 10.6 GB/s, 8 x 128 MiB 9.1 GB/s -- blocks that stay in the CPU caches between
-    // pread and the newline count win
-    size_t block = (size_t)8 << 20;
-    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
-        const long long v = atoll(e);
-        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
-    }
-    int readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
-    if (const char *e = getenv("GS_HOST_READERS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 32) readers = v;
-    }
+// One FASTQ file (plain or gzip) going to the device as raw text blocks (no per-read outputs).  Falls back to
+// parsed_source() from the first chunk the device refuses (gs_match_text_status), so any file the general path accepts
+// gives the same result.  step() handles one block; several jobs can be stepped in turn (files read side by side),
+// each with its own status bank on the device and its own range of read numbers.
+struct TextJob {
+    MatchCtx &c;
+    std::string path;
+    int bank;
+    int64_t read_no;  // number of the next read of this file
     TextReader tr;
-    int err = tr.open(path, block, readers, gzip);
-    if (err) {
-        tr.close();
+    std::vector<uint8_t> carry;
+    std::vector<TextChunk> chunks;
+    int64_t carry_lines = 0, reads_in_file = 0, carry_file_off = 0, first_ticket = -1, next_block = 0;
+    int64_t base_tot[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+    bool done = false;
+    double t0 = 0;
+
+    TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no) : c(ctx), path(p), bank(bank_), read_no(first_read_no) {}
+
+    int open(bool gzip, int readers) {
+        // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
+        // 24.8 GB/s of file, 4 x 32 MiB 10.6 GB/s, 8 x 128 MiB 9.1 GB/s -- blocks that stay in the CPU caches between
+        // pread and the newline count win
+        size_t block = (size_t)8 << 20;
+        if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
+            const long long v = atoll(e);
+            if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
+        }
+        if (const char *e = getenv("GS_HOST_READERS")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 32) readers = v;
+        }
+        t0 = now_s();
+        int err = tr.open(path, block, readers, gzip);
+        if (!err) err = gs_match_text_select(c.run, bank);
+        int64_t failed = -1, bad = -1;
+        if (!err) err = gs_match_text_status(c.run, &failed, &bad, base_tot);  // totals this bank has seen before
+        if (!err) tr.start();
         return err;
     }
-    int64_t base_tot[3] = {0, 0, 0}, tot[3] = {0, 0, 0}, failed = -1, bad = -1;
-    err = gs_match_text_status(c.run, &failed, &bad, base_tot);  // totals of earlier files of this run
-    std::vector<uint8_t> carry;
-    int64_t carry_lines = 0, reads_in_file = 0, carry_file_off = 0;
-    std::vector<TextChunk> chunks;
-    int64_t first_ticket = -1;
-    bool fell_back = false, too_long = false;
-    const double t0 = now_s();
-    if (!err) tr.start();
-    for (int64_t i = 0; !err; i++) {
+
+    // 1: a block was handled, 0: none ready (blocking = false only); `done` is set when the file is through
+    int step(bool blocking, int *err_out) {
+        int err = GS_OK;
+        const int64_t i = next_block;
+        if (!blocking && !tr.is_full(i)) return 0;
         TextSlot &sl = tr.wait_full(i);
+        int64_t fallback_off = -1, fallback_reads = 0;
+        bool last = false;
         if (sl.io_error || !tr.verify_gzip(sl)) {
             err = hfail(GS_E_INVALID, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
-            break;
-        }
-        uint8_t *blk = sl.buf + tr.headroom;
-        const int64_t total = carry_lines + sl.newlines;
-        const int64_t rem = total & 3, usable = total - rem;
-        const bool eof = sl.eof;
-        if (usable == 0) {  // not one whole record yet: keep everything
-            carry.insert(carry.end(), blk, blk + sl.n);
-            carry_lines = total;
-            if (carry.size() > tr.headroom && !eof) {
-                too_long = true;
-                tr.release(i);
-                break;
-            }
         } else {
-            const int64_t cut = sl.last4[rem];  // the newline with `rem` newlines behind it ends the last whole record
-            if (carry.size() > tr.headroom) {  // a record longer than a block: the general parser takes over here
-                too_long = true;
-                tr.release(i);
-                break;
-            }
-            uint8_t *start = blk - carry.size();
-            if (!carry.empty()) memcpy(start, carry.data(), carry.size());
-            int64_t ticket = -1;
-            err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST,
-                                       c.global_read_no + reads_in_file, nullptr, nullptr, &ticket);
-            if (err) break;
-            if (first_ticket < 0) first_ticket = ticket;
-            chunks.push_back({carry_file_off, reads_in_file});
-            reads_in_file += usable >> 2;
-            carry_file_off = i * (int64_t)tr.block + cut + 1;
-            carry.assign(blk + cut + 1, blk + sl.n);
-            carry_lines = rem;
-            err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
-            if (err) break;
-            // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
-            if (chunks.size() == 1 || (chunks.size() & 15) == 0 || eof) {
-                err = gs_match_text_status(c.run, &failed, &bad, tot);
-                if (err) break;
-                if (failed >= 0) {
-                    fell_back = true;
-                    tr.release(i);
-                    break;
+            err = gs_match_text_select(c.run, bank);
+            uint8_t *blk = sl.buf + tr.headroom;
+            const int64_t total = carry_lines + sl.newlines;
+            const int64_t rem = total & 3, usable = total - rem;
+            last = sl.eof;
+            if (err) {
+            } else if (usable == 0) {  // not one whole record yet: keep everything
+                carry.insert(carry.end(), blk, blk + sl.n);
+                carry_lines = total;
+                if (carry.size() > tr.headroom && !last) {  // a record longer than a block: the general parser takes over
+                    fallback_off = carry_file_off;
+                    fallback_reads = reads_in_file;
                 }
+            } else if (carry.size() > tr.headroom) {
+                fallback_off = carry_file_off;
+                fallback_reads = reads_in_file;
+            } else {
+                const int64_t cut = sl.last4[rem];  // the newline with `rem` newlines behind it ends the last whole record
+                uint8_t *start = blk - carry.size();
+                if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+                int64_t ticket = -1;
+                err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
+                                           nullptr, nullptr, &ticket);
+                if (!err) {
+                    if (first_ticket < 0) first_ticket = ticket;
+                    chunks.push_back({carry_file_off, reads_in_file, ticket});
+                    reads_in_file += usable >> 2;
+                    carry_file_off = i * (int64_t)tr.block + cut + 1;
+                    carry.assign(blk + cut + 1, blk + sl.n);
+                    carry_lines = rem;
+                    err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
+                }
+                // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
+                if (!err && (chunks.size() == 1 || (chunks.size() & 15) == 0)) err = check_refusal(&fallback_off, &fallback_reads);
             }
         }
         tr.release(i);
-        if (eof) break;
+        next_block = i + 1;
+        if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
+        *err_out = err;
+        return 1;
     }
-    tr.close();
-    c.t_parse += now_s() - t0;
-    if (err) return err;
-    if (!fell_back) {
-        err = gs_match_text_status(c.run, &failed, &bad, tot);
+
+private:
+    int check_refusal(int64_t *fallback_off, int64_t *fallback_reads) {
+        int64_t failed = -1, bad = -1;
+        int err = gs_match_text_status(c.run, &failed, &bad, tot);
+        if (err || failed < 0) return err;
+        for (const TextChunk &ch : chunks)
+            if (ch.ticket == failed) {
+                *fallback_off = ch.file_off;
+                *fallback_reads = ch.reads_before;
+            }
+        return gs_match_text_clear_error(c.run);
+    }
+
+    int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
+        done = true;
+        tr.close();
+        c.t_parse += now_s() - t0;
         if (err) return err;
-        fell_back = failed >= 0;
-    }
-    c.reads += tot[0] - base_tot[0];
-    c.kmers += tot[1] - base_tot[1];
-    c.bps += tot[2] - base_tot[2];
-    if (fell_back) {
-        const TextChunk &ch = chunks[(size_t)(failed - first_ticket)];
-        c.global_read_no += ch.reads_before;
-        err = gs_match_text_clear_error(c.run);
+        err = gs_match_text_select(c.run, bank);
+        if (!err && fallback_off < 0) err = check_refusal(&fallback_off, &fallback_reads);  // also fetches the final totals
         if (err) return err;
-        return parsed_source(c, path, ch.file_off, nullptr, 0);
+        if (fallback_off >= 0) {  // `tot` was read after the refusal: it holds exactly the accepted chunks
+            int64_t failed = -1, bad = -1;
+            err = gs_match_text_status(c.run, &failed, &bad, tot);
+            if (err) return err;
+        }
+        c.reads += tot[0] - base_tot[0];
+        c.kmers += tot[1] - base_tot[1];
+        c.bps += tot[2] - base_tot[2];
+        if (fallback_off >= 0) {
+            read_no += fallback_reads;
+            return parsed_source(c, path, fallback_off, nullptr, 0, read_no);
+        }
+        read_no += reads_in_file;
+        // what is left after the last whole four-line group (no final newline, truncated record): the general parser
+        if (!carry.empty()) return parsed_source(c, std::string(), 0, carry.data(), carry.size(), read_no);
+        return GS_OK;
     }
-    if (too_long) {
-        c.global_read_no += reads_in_file;
-        return parsed_source(c, path, carry_file_off, nullptr, 0);
-    }
-    c.global_read_no += reads_in_file;
-    // what is left after the last whole four-line group (no final newline, truncated record): the general parser
-    if (!carry.empty()) return parsed_source(c, std::string(), 0, carry.data(), carry.size());
-    return GS_OK;
-}
+};
 
 }  // namespace
 
@@ -966,15 +994,83 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     bool fast = !c.filtered.active() && !c.kraken.active();  // the text path has no per-read writers yet
     if (const char *e = getenv("GS_HOST_FAST")) fast = fast && atoi(e) != 0;
     int err = GS_OK;
-    for (int i = 0; i < n_paths && !err; i++) {
-        const std::string path(paths[i]);
-        const int kind = fast ? text_path_kind(path) : 0;
-        if (kind)
-            err = text_file(c, path, kind == 2);
-        else
-            err = parsed_source(c, path, 0, nullptr, 0);
+    std::vector<int> kind((size_t)n_paths, 0);
+    int n_gzip = 0;
+    for (int i = 0; i < n_paths; i++) {
+        kind[(size_t)i] = fast ? text_path_kind(paths[i]) : 0;
+        n_gzip += kind[(size_t)i] == 2;
+    }
+    const int default_readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    // Several gzip files: each is bound by its single inflating thread, so they are read side by side (up to 8 at a
+    // time).  The read numbers of file f then start at f << 32, which keeps "first read in file order" (the max-contig
+    // tie-break) intact; the column is converted back to running read numbers at the end.
+    bool side_by_side = n_gzip >= 2 && n_paths <= 256;
+    if (const char *e = getenv("GS_HOST_PARALLEL_FILES")) side_by_side = side_by_side && atoi(e) != 0;
+    std::vector<int64_t> reads_of_file((size_t)n_paths, 0);
+    if (!side_by_side) {
+        int64_t read_no = 0;
+        for (int i = 0; i < n_paths && !err; i++) {
+            const std::string path(paths[i]);
+            if (kind[(size_t)i]) {
+                TextJob job(c, path, 0, read_no);
+                err = job.open(kind[(size_t)i] == 2, default_readers);
+                while (!err && !job.done) job.step(true, &err);
+                if (!job.done) job.tr.close();
+                read_no = job.read_no;
+            } else {
+                err = parsed_source(c, path, 0, nullptr, 0, read_no);
+            }
+        }
+    } else {
+        std::vector<std::unique_ptr<TextJob>> active;
+        std::vector<int> file_of;
+        int next = 0;
+        while (!err && (next < n_paths || !active.empty())) {
+            while (!err && next < n_paths && (int)active.size() < 8) {
+                const int64_t base = (int64_t)next << 32;
+                if (kind[(size_t)next]) {
+                    int bank = 0;  // a free bank
+                    for (;; bank++) {
+                        bool used = false;
+                        for (auto &j : active) used = used || j->bank == bank;
+                        if (!used) break;
+                    }
+                    auto job = std::make_unique<TextJob>(c, std::string(paths[next]), bank, base);
+                    err = job->open(kind[(size_t)next] == 2, 2);
+                    active.push_back(std::move(job));
+                    file_of.push_back(next);
+                } else {  // FASTA etc.: the general parser, on its own
+                    int64_t read_no = base;
+                    err = parsed_source(c, std::string(paths[next]), 0, nullptr, 0, read_no);
+                    reads_of_file[(size_t)next] = read_no - base;
+                }
+                next++;
+            }
+            bool progressed = false;
+            for (size_t j = 0; j < active.size() && !err; j++) progressed = active[j]->step(false, &err) > 0 || progressed;
+            for (size_t j = 0; j < active.size();) {
+                if (active[j]->done) {
+                    reads_of_file[(size_t)file_of[j]] = active[j]->read_no - ((int64_t)file_of[j] << 32);
+                    if (reads_of_file[(size_t)file_of[j]] >= ((int64_t)1 << 32) && !err)
+                        err = hfail(GS_E_UNSUPPORTED, "more than 2^32 reads in one of several files read side by side (set GS_HOST_PARALLEL_FILES=0)");
+                    active.erase(active.begin() + (long)j);
+                    file_of.erase(file_of.begin() + (long)j);
+                } else
+                    j++;
+            }
+            if (!progressed && !active.empty()) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        for (auto &j : active) j->tr.close();
     }
     if (!err) err = gs_match_finish(c.run, table, dtable);
+    if (!err && side_by_side) {  // (file << 32 | read in file) -> running read number over the files in order
+        std::vector<int64_t> before((size_t)n_paths + 1, 0);
+        for (int i = 0; i < n_paths; i++) before[(size_t)i + 1] = before[(size_t)i] + reads_of_file[(size_t)i];
+        for (int32_t v = 0; v < c.info.n_values; v++) {
+            int64_t &x = table[(size_t)v * GS_N_COLS + GS_C_MAX_CONTIG_READ_NO];
+            if (x >= 0) x = before[(size_t)(x >> 32)] + (x & 0xffffffffLL);
+        }
+    }
     gs_match_destroy(c.run);
     if (totals) {
         totals->reads = c.reads;

@@ -163,6 +163,10 @@ int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int6
 int gs_match_text_wait_copy(gs_run *run, int64_t ticket);
 int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_match_text_clear_error(gs_run *run);
+/* Files that are read side by side are independent streams of chunks: a refusal in one must not silence the others.
+ * The refusal state and the totals exist in 16 banks; submit / status / clear_error work on the selected one (0 at
+ * begin).  Use first_read_no to keep the read numbers of the files apart. */
+int gs_match_text_select(gs_run *run, int bank);
 /* page-locked host memory for the text blocks (so that the H2D copy overlaps the caller's file reads) */
 int gs_pinned_alloc(void **p, size_t bytes);
 int gs_pinned_free(void *p);

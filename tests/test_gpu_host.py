@@ -243,3 +243,37 @@ def test_filter_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypat
         exp += d + b"\n" + s + b"\n+\n" + b"~" * len(s) + b"\n"
     assert outs["1"][0] == exp
     gb.close()
+
+
+@pytest.mark.parametrize("odd", [False, True])
+def test_match_files_gzip_files_side_by_side(sdb, tmp_path, monkeypatch, odd):
+    """two or more gzip files are inflated side by side (each behind its own thread, own status bank on the device,
+    read numbers file << 32 | read); the table -- including the max-contig read numbers -- must equal the sequential run"""
+    recs = _fastq_bytes(sdb, 1200, seed=37)
+    if odd:  # one file needs the general parser from its middle on, one has no final newline
+        s = recs[700].split(b"\n")
+        recs[700] = s[0] + b"\n" + s[1][:40] + b"\n" + s[1][40:] + b"\n+\n" + s[3] + b"\n"
+    cuts = [0, 250, 251, 600, 900, 1200]
+    parts = [b"".join(recs[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    if odd:
+        parts[1] = parts[1][:-1]
+    paths = []
+    for i, part in enumerate(parts):
+        p = str(tmp_path / f"part{i}.fastq.gz")
+        if i == 2:
+            p = str(tmp_path / "part2.fastq")  # a plain file among the gzip files
+            open(p, "wb").write(part)
+        else:
+            with gzip.open(p, "wb", compresslevel=1 + i) as f:
+                f.write(part)
+        paths.append(p)
+    want_t, want_tot = _oracle_file(sdb, b"".join(p + (b"\n" if odd and i == 1 else b"") for i, p in enumerate(parts)))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(70000))
+    t1, _, tot1 = host.match_files(store, paths)
+    monkeypatch.setenv("GS_HOST_PARALLEL_FILES", "0")
+    t0, _, tot0 = host.match_files(store, paths)
+    assert np.array_equal(t1, t0), np.argwhere(t1 != t0)[:8]
+    assert (tot1.reads, tot1.kmers, tot1.bps) == (tot0.reads, tot0.kmers, tot0.bps) == want_tot
+    assert np.array_equal(t0, want_t), np.argwhere(t0 != want_t)[:8]
+    store.close()
