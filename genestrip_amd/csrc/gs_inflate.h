@@ -213,6 +213,7 @@ private:
     // smaller roots); build() refuses a table that would not fit rather than overrun
     Entry ll_[(1 << LL_BITS) + 2048], dd_[(1 << D_BITS) + 1024];
     uint8_t pmax_[1 << LL_BITS];
+    Entry pair_[1 << LL_BITS];
 
     size_t avail_bytes() const { return (size_t)(in_end_ - in_) + (size_t)(bitcnt_ >> 3); }
 
@@ -300,7 +301,8 @@ private:
 
     // canonical Huffman decode table: `n` code lengths -> primary table of `tbits` bits + sub-tables
     // is_dist selects the symbol -> entry mapping.  Returns false for an over-subscribed or (non-trivially) incomplete code.
-    bool build(const uint8_t *lens, int n, Entry *tab, int tbits, int tab_cap, bool is_dist) {
+    bool build(const uint8_t *lens, int n, Entry *tab, int tbits, int tab_cap, bool is_dist, bool pair_literals = false) {
+        if (pair_literals) memset(pair_, 0, sizeof(pair_));
         static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
         static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
         static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -380,6 +382,23 @@ private:
                 for (uint32_t i = rev >> tbits; i < (1u << sbits); i += 1u << (l - tbits)) tab[base + i] = e;
             }
         }
+        if (pair_literals) {
+            // two literals in one look-up where both codes fit the primary index (FASTQ text: bases and the common
+            // quality values have 2-4 bit codes): kind 5, value = first | second << 8, length = both code lengths
+            const uint32_t n_prim = 1u << tbits;
+            for (uint32_t i = 0; i < n_prim; i++) {
+                const Entry e1 = tab[i];
+                if ((e1 & 0xf0u) != 0) continue;
+                const uint32_t l1 = e1 & 15;
+                const Entry e2 = tab[(i >> l1) & (n_prim - 1)];  // valid only if its code lies inside the known bits
+                if ((e2 & 0xf0u) != 0) continue;
+                const uint32_t l2 = e2 & 15;
+                if (l1 + l2 > (uint32_t)tbits) continue;
+                pair_[i] = mk(l1 + l2, 5, l1, (e1 >> 16) | ((e2 >> 16) << 8));  // (extra field: length of the first code)
+            }
+            for (uint32_t i = 0; i < n_prim; i++)
+                if (((pair_[i] >> 4) & 15) == 5) tab[i] = pair_[i];
+        }
         return true;
     }
 
@@ -390,7 +409,7 @@ private:
         for (; i < 256; i++) lens[i] = 9;
         for (; i < 280; i++) lens[i] = 7;
         for (; i < 288; i++) lens[i] = 8;
-        build(lens, 288, ll_, LL_BITS, (int)(sizeof(ll_) / sizeof(ll_[0])), false);
+        build(lens, 288, ll_, LL_BITS, (int)(sizeof(ll_) / sizeof(ll_[0])), false, true);
         for (i = 0; i < 32; i++) lens[i] = 5;
         build(lens, 32, dd_, D_BITS, (int)(sizeof(dd_) / sizeof(dd_[0])), true);
     }
@@ -438,7 +457,7 @@ private:
             }
         }
         if (lens[256] == 0) return false;  // no end-of-block code
-        if (!build(lens, hlit, ll_, LL_BITS, (int)(sizeof(ll_) / sizeof(ll_[0])), false)) return false;
+        if (!build(lens, hlit, ll_, LL_BITS, (int)(sizeof(ll_) / sizeof(ll_[0])), false, true)) return false;
         if (!build(lens + hlit, hdist, dd_, D_BITS, (int)(sizeof(dd_) / sizeof(dd_[0])), true)) return false;
         return true;
     }
@@ -464,20 +483,24 @@ private:
             while (o_end - o >= 258 + 16 && in_end_ - in_ >= 16) {
                 refill();  // >= 56 bits: litlen (15) + extra (5) + dist (15) + extra (13) = 48
                 Entry e = ll_[bitbuf_ & ((1u << LL_BITS) - 1)];
-                if ((e & 0xf0u) == 0) {  // literal: up to three per refill (3 x 15 bits <= 56)
-                    bitbuf_ >>= (e & 15);
-                    bitcnt_ -= (int)(e & 15);
-                    *o++ = (uint8_t)(e >> 16);
+                if ((e & 0xf0u) == 0 || (e & 0xf0u) == 0x50u) {  // literal or literal pair: three look-ups per refill (<= 45 bits)
+#define GS_INF_LITERALS()                                   \
+    bitbuf_ >>= (e & 15);                                   \
+    bitcnt_ -= (int)(e & 15);                               \
+    if ((e & 0xf0u) == 0x50u) {                             \
+        const uint16_t two = (uint16_t)(e >> 16);           \
+        memcpy(o, &two, 2);                                 \
+        o += 2;                                             \
+    } else                                                  \
+        *o++ = (uint8_t)(e >> 16);
+                    GS_INF_LITERALS()
                     e = ll_[bitbuf_ & ((1u << LL_BITS) - 1)];
-                    if ((e & 0xf0u) != 0) goto not_literal;
-                    bitbuf_ >>= (e & 15);
-                    bitcnt_ -= (int)(e & 15);
-                    *o++ = (uint8_t)(e >> 16);
+                    if ((e & 0xf0u) != 0 && (e & 0xf0u) != 0x50u) goto not_literal;
+                    GS_INF_LITERALS()
                     e = ll_[bitbuf_ & ((1u << LL_BITS) - 1)];
-                    if ((e & 0xf0u) != 0) goto not_literal;
-                    bitbuf_ >>= (e & 15);
-                    bitcnt_ -= (int)(e & 15);
-                    *o++ = (uint8_t)(e >> 16);
+                    if ((e & 0xf0u) != 0 && (e & 0xf0u) != 0x50u) goto not_literal;
+                    GS_INF_LITERALS()
+#undef GS_INF_LITERALS
                     continue;
                 }
             not_literal:
@@ -546,7 +569,11 @@ private:
                 used = LL_BITS;
                 e = ll_[(e >> 16) + ((bitbuf_ >> LL_BITS) & ((1u << ((e >> 8) & 31)) - 1))];
             }
-            const uint32_t kind = (e >> 4) & 15;
+            uint32_t kind = (e >> 4) & 15;
+            if (kind == 5) {  // a literal pair: take only its first literal here
+                e = mk((e >> 8) & 31, 0, 0, (e >> 16) & 0xffu);
+                kind = 0;
+            }
             used += (int)(e & 15);
             if (kind == 15 || used > bitcnt_) return -1;
             if (kind == 0) {
