@@ -976,21 +976,14 @@ private:
 
 }  // namespace
 
-extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
-                                   const gs_host_match_opts *opts, int64_t *table, double *dtable,
-                                   gs_host_totals *totals) {
-    if (!db || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
-    MatchCtx c;
-    int rc = gs_db_get_info(db, &c.info);
-    if (rc) return rc;
-    const gs_host_match_opts none{};
-    if (!opts) opts = &none;
-    c.opts = opts;
-    if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
-    if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
-    rc = gs_match_begin(&c.run, db, cfg);
-    if (rc) return rc;
-    const double t_start = now_s();
+namespace {
+
+// the files of one runMatcher call into c.run (begin and finish are the caller's).  file_index (may be NULL): the
+// position of each file in the global file order when several processes share the files of a run; read numbers are then
+// (file_index << 32 | read in file).  reads_of_file[n_paths] receives the read counts, *composite says whether the
+// max-contig read numbers of the run are in that (file, read) form.
+int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t *file_index, std::vector<int64_t> &reads_of_file_out,
+              bool *composite) {
     bool fast = !c.filtered.active() && !c.kraken.active();  // the text path has no per-read writers yet
     if (const char *e = getenv("GS_HOST_FAST")) fast = fast && atoi(e) != 0;
     int err = GS_OK;
@@ -1006,6 +999,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     // tie-break) intact; the column is converted back to running read numbers at the end.
     bool side_by_side = n_gzip >= 2 && n_paths <= 256;
     if (const char *e = getenv("GS_HOST_PARALLEL_FILES")) side_by_side = side_by_side && atoi(e) != 0;
+    if (file_index) side_by_side = true;  // read numbers are (file << 32 | read): the files are independent anyway
     std::vector<int64_t> reads_of_file((size_t)n_paths, 0);
     if (!side_by_side) {
         int64_t read_no = 0;
@@ -1027,7 +1021,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         int next = 0;
         while (!err && (next < n_paths || !active.empty())) {
             while (!err && next < n_paths && (int)active.size() < 8) {
-                const int64_t base = (int64_t)next << 32;
+                const int64_t base = (int64_t)(file_index ? file_index[next] : next) << 32;
                 if (kind[(size_t)next]) {
                     int bank = 0;  // a free bank
                     for (;; bank++) {
@@ -1050,7 +1044,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
             for (size_t j = 0; j < active.size() && !err; j++) progressed = active[j]->step(false, &err) > 0 || progressed;
             for (size_t j = 0; j < active.size();) {
                 if (active[j]->done) {
-                    reads_of_file[(size_t)file_of[j]] = active[j]->read_no - ((int64_t)file_of[j] << 32);
+                    reads_of_file[(size_t)file_of[j]] = active[j]->read_no - ((int64_t)(file_index ? file_index[file_of[j]] : file_of[j]) << 32);
                     if (reads_of_file[(size_t)file_of[j]] >= ((int64_t)1 << 32) && !err)
                         err = hfail(GS_E_UNSUPPORTED, "more than 2^32 reads in one of several files read side by side (set GS_HOST_PARALLEL_FILES=0)");
                     active.erase(active.begin() + (long)j);
@@ -1062,6 +1056,31 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         }
         for (auto &j : active) j->tr.close();
     }
+    reads_of_file_out = reads_of_file;
+    *composite = side_by_side;
+    return err;
+}
+
+}  // namespace
+
+extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
+                                   const gs_host_match_opts *opts, int64_t *table, double *dtable,
+                                   gs_host_totals *totals) {
+    if (!db || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
+    MatchCtx c;
+    int rc = gs_db_get_info(db, &c.info);
+    if (rc) return rc;
+    const gs_host_match_opts none{};
+    if (!opts) opts = &none;
+    c.opts = opts;
+    if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
+    if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    rc = gs_match_begin(&c.run, db, cfg);
+    if (rc) return rc;
+    const double t_start = now_s();
+    std::vector<int64_t> reads_of_file;
+    bool side_by_side = false;
+    int err = run_files(c, paths, n_paths, nullptr, reads_of_file, &side_by_side);
     if (!err) err = gs_match_finish(c.run, table, dtable);
     if (!err && side_by_side) {  // (file << 32 | read in file) -> running read number over the files in order
         std::vector<int64_t> before((size_t)n_paths + 1, 0);
@@ -1077,6 +1096,38 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         totals->kmers = c.kmers;
         totals->bps = c.bps;
         totals->filtered_reads = c.filtered_reads;
+        totals->seconds_total = now_s() - t_start;
+        totals->seconds_parse = c.t_parse;
+        totals->seconds_gpu = c.t_gpu;
+    }
+    return err;
+}
+
+
+// The same, into a run the caller began and will finish: for one-process-per-GPU runs that share the files of a sample
+// (genestrip_amd/distributed.py: match_files_sharded) -- every process takes some of the files, merges the device state
+// of its run with the others (gs_match_device_state) and finishes.  file_index[n_paths] = position of each file in the
+// global file order; the read numbers handed to the device are (file_index << 32 | read in file), reads_of_file[n_paths]
+// receives the read counts (needed to turn the max-contig read numbers into running ones after the merge).
+extern "C" int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
+                                  int64_t *reads_of_file, gs_host_totals *totals) {
+    if (!run || !db || !paths || n_paths < 0 || !file_index || !reads_of_file) return hfail(GS_E_INVALID, "NULL argument");
+    MatchCtx c;
+    int rc = gs_db_get_info(db, &c.info);
+    if (rc) return rc;
+    const gs_host_match_opts none{};
+    c.opts = &none;
+    c.run = run;
+    const double t_start = now_s();
+    std::vector<int64_t> rof;
+    bool composite = false;
+    const int err = run_files(c, paths, n_paths, file_index, rof, &composite);
+    for (int i = 0; i < n_paths && (size_t)i < rof.size(); i++) reads_of_file[i] = rof[(size_t)i];
+    if (totals) {
+        totals->reads = c.reads;
+        totals->kmers = c.kmers;
+        totals->bps = c.bps;
+        totals->filtered_reads = 0;
         totals->seconds_total = now_s() - t_start;
         totals->seconds_parse = c.t_parse;
         totals->seconds_gpu = c.t_gpu;

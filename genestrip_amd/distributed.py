@@ -44,6 +44,58 @@ def merge_run_state(sums, max_keys, dsums, bitmap, group=None, or_parts=None, fo
         bitmap.copy_(acc)
 
 
+class _DevArray:
+    """device memory of the library as a torch tensor (no copy)"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": typestr, "version": 2}
+
+
+def match_files_sharded(matcher, paths, group=None, device=None, via_host=False):
+    """runMatcher over the files of a sample with one process per GPU: rank r takes files r, r + world, ...
+    (gs_host_match_into: raw text blocks to its own GPU), then the runs are merged (merge_run_state) and finished.
+    Returns (table, dtable, (reads, kmers, bps)) -- identical on every rank and identical to a single-process run over
+    the same files in the same order.  via_host: merge host copies (gloo groups); default: the device buffers over RCCL."""
+    import numpy as np
+    from . import binding as _b
+    from . import host as _h
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    paths = list(paths)
+    mine = list(range(rank, len(paths), world))
+    counts_mine, tot = _h.match_files_into(matcher, [paths[i] for i in mine], mine)
+    st = matcher.device_state()  # syncs the run's stream and refreshes the compact unique bitmap
+    nv = matcher.store.n_values
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    t_sums = torch.as_tensor(_DevArray(st["sums"], nv * _b.N_SUMS, "<i8"), device=dev)
+    t_max = torch.as_tensor(_DevArray(st["max_keys"], nv, "<i8"), device=dev)
+    t_dsum = torch.as_tensor(_DevArray(st["dsums"], nv * _b.N_DCOLS, "<f8"), device=dev)
+    t_bits = torch.as_tensor(_DevArray(st["bitmap"], st["bitmap_words"], "<i4"), device=dev)
+    counts = torch.zeros(len(paths) + 3, dtype=torch.int64)
+    for i, c in zip(mine, counts_mine):
+        counts[i] = int(c)
+    counts[len(paths):] = torch.tensor([tot.reads, tot.kmers, tot.bps])
+    if via_host:
+        hs, hm, hd, hb = t_sums.cpu(), t_max.cpu(), t_dsum.cpu(), t_bits.cpu()
+        merge_run_state(hs, hm, hd, hb, group=group)
+        t_sums.copy_(hs), t_max.copy_(hm), t_dsum.copy_(hd), t_bits.copy_(hb)
+        torch.cuda.synchronize(dev)
+        matcher.or_bitmap(t_bits.data_ptr(), 1)
+        dist.all_reduce(counts, group=group)
+    else:
+        merge_run_state(t_sums, t_max, t_dsum, t_bits, group=group, or_parts=lambda g, w: matcher.or_bitmap(g.data_ptr(), w))
+        cd = counts.to(dev)
+        dist.all_reduce(cd, group=group)
+        counts = cd.cpu()
+    table, dtable = matcher.finish()
+    # (file << 32 | read in file) -> running read number over the files in order
+    before = np.concatenate([[0], np.cumsum(counts[:len(paths)].numpy())])
+    col = table[:, _b.N_COLS - 1]
+    has = col >= 0
+    col[has] = before[col[has] >> 32] + (col[has] & 0xFFFFFFFF)
+    return table, dtable, tuple(int(x) for x in counts[len(paths):])
+
+
 def shard_bounds(n_total, rank, world):
     """contiguous read range [lo, hi) of `rank` (global readNo is kept)"""
     base, rem = divmod(n_total, world)

@@ -47,6 +47,7 @@ def lib():
         "gs_fastq_open": (ci, [vp, C.c_char_p, ci, ci]), "gs_fastq_next": (ci, [vp, i64, i64, vp]),
         "gs_fastq_totals": (ci, [vp, vp, vp, vp]), "gs_fastq_close": (ci, [vp]),
         "gs_host_match_files": (ci, [vp, vp, vp, ci, vp, vp, vp, vp]),
+        "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
         "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
@@ -132,6 +133,18 @@ def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=N
     _check(lib().gs_host_match_files(store.h, C.byref(cfg), parr, len(paths), C.byref(opts),
                                      table.ctypes.data_as(C.c_void_p), dtable.ctypes.data_as(C.c_void_p), C.byref(tot)))
     return table, dtable, tot
+
+
+def match_files_into(matcher, paths, file_index):
+    """the given files into `matcher`'s run (no finish): returns (reads per file, Totals); file_index = position of each
+    file in the global file order (read numbers are file_index << 32 | read in file)"""
+    parr = _cstr_array(list(paths))
+    fi = np.ascontiguousarray(file_index, dtype=np.int32)
+    counts = np.zeros(max(len(fi), 1), dtype=np.int64)
+    tot = Totals()
+    _check(lib().gs_host_match_into(matcher.h, matcher.store.h, parr, len(fi), fi.ctypes.data_as(C.c_void_p),
+                                    counts.ctypes.data_as(C.c_void_p), C.byref(tot)))
+    return counts[:len(fi)], tot
 
 
 def filter_files(bloom, k, paths, min_pos_count=1, positive_ratio=0.2, filtered_path=None, rest_path=None):

@@ -67,6 +67,15 @@ typedef struct {
 int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
                         const gs_host_match_opts *opts, int64_t *table, double *dtable, gs_host_totals *totals);
 
+/* The files of a run into a gs_run that the caller began and will finish -- for one-process-per-GPU runs that share
+ * the files of a sample (genestrip_amd/distributed.py: match_files_sharded): every process takes some of the files,
+ * merges its run's device state with the others (gs_match_device_state) and finishes.  file_index[n_paths] = position
+ * of each file in the global file order; read numbers on the device are (file_index << 32 | read in file), so the
+ * max-contig tie-break keeps the global file order; reads_of_file[n_paths] receives the read counts, which turn those
+ * numbers into running ones after the merge.  No per-read outputs. */
+int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
+                       int64_t *reads_of_file, gs_host_totals *totals);
+
 /* ---- runFilter: accepted reads -> filtered_path, the rest -> rest_path (either may be NULL) ---- */
 int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const char *const *paths,
                          int n_paths, const char *filtered_path, const char *rest_path, gs_host_totals *totals);
