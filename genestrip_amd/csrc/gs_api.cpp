@@ -473,6 +473,7 @@ struct TextScan {
     uint32_t *d_status = nullptr;  // GS_TEXT_BANKS x GS_TS_WORDS
     u64 *d_totals = nullptr;       // GS_TEXT_BANKS x ([3] chunk scratch | [3] totals of the accepted chunks)
     int bank = 0;
+    int64_t last_reads = 0, last_lines = 0;  // of the most recent chunk (per-read follow-up calls refer to it)
     hipEvent_t copied[8] = {};     // H2D of ticket t has completed: copied[t % 8]
     int64_t tickets = 0;
 };
@@ -603,6 +604,8 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     T.k = k;
     HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
     t.tickets = tk + 1;
+    t.last_reads = n_reads;
+    t.last_lines = n_lines;
     if (ticket) *ticket = tk;
     return GS_OK;
 }
@@ -1168,18 +1171,7 @@ static int stage_batch(gs_run *run, const uint8_t *seq, const uint64_t *offsets,
     return GS_OK;
 }
 
-extern "C" int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
-                                 uint64_t *seg_off) {
-    if (!run || !seg_off) return fail(GS_E_INVALID, "NULL argument");
-    if (n_reads < 0 || (n_reads > 0 && (!seq || !offsets))) return fail(GS_E_INVALID, "bad batch arrays");
-    HIP_TRY(hipSetDevice(run->db->device));
-    seg_off[0] = 0;
-    run->seg_total = 0;
-    if (n_reads == 0) return GS_OK;
-    const uint8_t *d_seq = nullptr;
-    const uint64_t *d_off = nullptr;
-    int rc = stage_batch(run, seq, offsets, n_reads, mem, &d_seq, &d_off);
-    if (rc) return rc;
+static int segments_core(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int off_stride, uint64_t *seg_off) {
     hipFree(run->d_seg_count);
     hipFree(run->d_seg_off);
     hipFree(run->d_seg_code);
@@ -1193,6 +1185,7 @@ extern "C" int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t
     P.db = run->db->dev;
     P.seq = d_seq;
     P.off = d_off;
+    P.off_stride = off_stride;
     P.n_reads = n_reads;
     P.seg_count = run->d_seg_count;
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + 3) / 4);
@@ -1215,6 +1208,44 @@ extern "C" int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t
         HIP_TRY(hipStreamSynchronize(run->stream));
     }
     return GS_OK;
+}
+
+extern "C" int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
+                                 uint64_t *seg_off) {
+    if (!run || !seg_off) return fail(GS_E_INVALID, "NULL argument");
+    if (n_reads < 0 || (n_reads > 0 && (!seq || !offsets))) return fail(GS_E_INVALID, "bad batch arrays");
+    HIP_TRY(hipSetDevice(run->db->device));
+    seg_off[0] = 0;
+    run->seg_total = 0;
+    if (n_reads == 0) return GS_OK;
+    const uint8_t *d_seq = nullptr;
+    const uint64_t *d_off = nullptr;
+    int rc = stage_batch(run, seq, offsets, n_reads, mem, &d_seq, &d_off);
+    if (rc) return rc;
+    return segments_core(run, d_seq, d_off, n_reads, 1, seg_off);
+}
+
+// the same for the reads of the most recent text chunk (which must not have been refused: gs_match_text_status)
+extern "C" int gs_match_segments_text(gs_run *run, uint64_t *seg_off) {
+    if (!run || !seg_off) return fail(GS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    seg_off[0] = 0;
+    run->seg_total = 0;
+    const int64_t n_reads = run->text.last_reads;
+    if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
+    if (n_reads == 0) return GS_OK;
+    return segments_core(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, 2, seg_off);
+}
+
+// newline offsets of the most recent text chunk (the record geometry for per-read writers); synchronises
+extern "C" int gs_match_text_newlines(gs_run *run, uint32_t *newlines) {
+    if (!run || !newlines) return fail(GS_E_INVALID, "NULL argument");
+    if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (run->text.last_lines > 0)
+        HIP_TRY(hipMemcpyAsync(newlines, run->text.d_nl, sizeof(uint32_t) * (size_t)run->text.last_lines, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
 }
 
 extern "C" int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts) {

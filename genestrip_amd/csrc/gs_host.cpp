@@ -742,10 +742,49 @@ struct MatchCtx {
     std::vector<uint8_t> flags, tmp;
     std::vector<uint64_t> seg_off;
     std::string line;
+    std::vector<uint8_t> out_buf, flt_buf, nl_bytes;  // Kraken lines / filtered records of one batch, written in one go
     int64_t global_read_no = 0, filtered_reads = 0;  // read numbers run over all files of the call (file order)
     int64_t reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
 };
+
+// MatcherReadEntry.writeMatchDetails (:723-756) for read i of the current batch / chunk (c.cls, c.seg_*): descriptor
+// up to the first blank without its '@', class taxid, length, runs "taxid:n"
+void kraken_line(MatchCtx &c, const uint8_t *desc, size_t dlen, int64_t L, int64_t i) {
+    const gs_host_match_opts *opts = c.opts;
+    const uint64_t s0 = c.seg_off[(size_t)i], s1 = c.seg_off[(size_t)i + 1];
+    const int32_t cl = c.cls[(size_t)i];
+    if (s1 == s0 || !(opts->write_all || cl >= 0)) return;
+    const int64_t maxp = L - c.info.k + 1;
+    std::string &line = c.line;
+    line.assign(cl >= 0 ? "C\t" : "U\t");
+    size_t de = dlen;
+    for (size_t j = 1; j < dlen; j++)
+        if (desc[j] == ' ') {
+            de = j;
+            break;
+        }
+    if (dlen > 1) line.append((const char *)desc + 1, de - 1);
+    line.push_back('\t');
+    line.append(cl >= 0 ? opts->taxids[cl] : "0");
+    line.push_back('\t');
+    append_int(line, L);
+    line.push_back('\t');
+    for (uint64_t sg = s0; sg < s1; sg++) {
+        if (sg > s0) line.push_back(' ');
+        const int32_t code = c.seg_code[(size_t)sg];
+        if (code == -2)
+            line.push_back('A');
+        else if (code < 0)
+            line.push_back('0');
+        else
+            line.append(opts->taxids[code]);
+        line.push_back(':');
+        append_int(line, (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg]);
+    }
+    line.push_back('\n');
+    c.out_buf.insert(c.out_buf.end(), line.begin(), line.end());
+}
 
 // one parsed batch through the GPU and the per-read writers
 int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
@@ -767,49 +806,19 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
     c.t_gpu += now_s() - t0;
     if (err) return err;
     read_no += n;
-    const gs_host_match_opts *opts = c.opts;
+    c.out_buf.clear();
     for (int64_t i = 0; i < n; i++) {
         if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
             write_read(c.filtered, b, i, false, c.tmp);
             c.filtered_reads++;
         }
-        if (c.kraken.active()) {  // MatcherReadEntry.writeMatchDetails (:723-756)
-            const uint64_t s0 = c.seg_off[(size_t)i], s1 = c.seg_off[(size_t)i + 1];
-            const int32_t cl = c.cls[(size_t)i];
-            if (s1 == s0 || !(opts->write_all || cl >= 0)) continue;
-            const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
-            const int64_t maxp = L - c.info.k + 1;
-            std::string &line = c.line;
-            line.assign(cl >= 0 ? "C\t" : "U\t");
+        if (c.kraken.active()) {
             const size_t d0 = b.desc_off[(size_t)i], d1 = b.desc_off[(size_t)i + 1];
-            size_t de = d1;
-            for (size_t j = d0 + 1; j < d1; j++)
-                if (b.desc[j] == ' ') {
-                    de = j;
-                    break;
-                }
-            if (d1 > d0 + 1) line.append((const char *)b.desc.data() + d0 + 1, de - d0 - 1);
-            line.push_back('\t');
-            line.append(cl >= 0 ? opts->taxids[cl] : "0");
-            line.push_back('\t');
-            append_int(line, L);
-            line.push_back('\t');
-            for (uint64_t sg = s0; sg < s1; sg++) {
-                if (sg > s0) line.push_back(' ');
-                const int32_t code = c.seg_code[(size_t)sg];
-                if (code == -2)
-                    line.push_back('A');
-                else if (code < 0)
-                    line.push_back('0');
-                else
-                    line.append(opts->taxids[code]);
-                line.push_back(':');
-                append_int(line, (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg]);
-            }
-            line.push_back('\n');
-            c.kraken.write(line.data(), line.size());
+            const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
+            kraken_line(c, b.desc.data() + d0, d1 - d0, L, i);
         }
     }
+    if (!c.out_buf.empty()) c.kraken.write(c.out_buf.data(), c.out_buf.size());
     return GS_OK;
 }
 
@@ -839,7 +848,27 @@ struct TextChunk {
     int64_t ticket;
 };
 
-// One FASTQ file (plain or gzip) going to the device as raw text blocks (no per-read outputs).  Falls back to
+// ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", '~' x length
+// (appended to `buf`; the caller writes one buffer per chunk)
+void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const uint32_t *nl, int64_t i) {
+    const size_t d0 = i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1, d1 = nl[4 * i], s0 = d1 + 1, s1 = nl[4 * i + 1];
+    const size_t at = buf.size(), dl = d1 - d0, sl = s1 - s0;
+    buf.resize(at + dl + 2 * sl + 5);
+    uint8_t *o = buf.data() + at;
+    memcpy(o, text + d0, dl);
+    o += dl;
+    *o++ = '\n';
+    memcpy(o, text + s0, sl);
+    o += sl;
+    *o++ = '\n';
+    *o++ = '+';
+    *o++ = '\n';
+    memset(o, '~', sl);
+    o += sl;
+    *o = '\n';
+}
+
+// One FASTQ file (plain or gzip) going to the device as raw text blocks.  Falls back to
 // parsed_source() from the first chunk the device refuses (gs_match_text_status), so any file the general path accepts
 // gives the same result.  step() handles one block; several jobs can be stepped in turn (files read side by side),
 // each with its own status bank on the device and its own range of read numbers.
@@ -912,9 +941,21 @@ struct TextJob {
                 uint8_t *start = blk - carry.size();
                 if (!carry.empty()) memcpy(start, carry.data(), carry.size());
                 int64_t ticket = -1;
+                const bool per_read = c.filtered.active() || c.kraken.active();
+                const int64_t n_chunk = usable >> 2;
+                if (per_read) {
+                    c.cls.resize((size_t)n_chunk);
+                    c.flags.resize((size_t)n_chunk);
+                }
                 err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
-                                           nullptr, nullptr, &ticket);
-                if (!err) {
+                                           per_read ? c.cls.data() : nullptr, per_read ? c.flags.data() : nullptr, &ticket);
+                if (!err && per_read) {  // the writers need this chunk's results now
+                    chunks.push_back({carry_file_off, reads_in_file, ticket});
+                    err = check_refusal(&fallback_off, &fallback_reads);
+                    chunks.pop_back();
+                    if (!err && fallback_off < 0) err = write_chunk_outputs(start, n_chunk);
+                }
+                if (!err && fallback_off < 0) {
                     if (first_ticket < 0) first_ticket = ticket;
                     chunks.push_back({carry_file_off, reads_in_file, ticket});
                     reads_in_file += usable >> 2;
@@ -924,7 +965,8 @@ struct TextJob {
                     err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
                 }
                 // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
-                if (!err && (chunks.size() == 1 || (chunks.size() & 15) == 0)) err = check_refusal(&fallback_off, &fallback_reads);
+                if (!err && fallback_off < 0 && !per_read && (chunks.size() == 1 || (chunks.size() & 15) == 0))
+                    err = check_refusal(&fallback_off, &fallback_reads);
             }
         }
         tr.release(i);
@@ -935,6 +977,39 @@ struct TextJob {
     }
 
 private:
+    // filtered FASTQ (afterMatch, :304-307) and Kraken-style lines (:723-756) of the chunk that was just matched, from
+    // the raw block: the device returns the record geometry (newline offsets) and the segments
+    int write_chunk_outputs(const uint8_t *text, int64_t n) {
+        c.nl_bytes.resize((size_t)n * 4 * sizeof(uint32_t));
+        uint32_t *nl = reinterpret_cast<uint32_t *>(c.nl_bytes.data());
+        int err = gs_match_text_newlines(c.run, nl);
+        if (!err && c.kraken.active()) {
+            c.seg_off.resize((size_t)n + 1);
+            err = gs_match_segments_text(c.run, c.seg_off.data());
+            if (!err) {
+                c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
+                c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
+                err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
+            }
+        }
+        if (err) return err;
+        c.out_buf.clear();
+        c.flt_buf.clear();
+        for (int64_t r = 0; r < n; r++) {
+            if (c.filtered.active() && (c.flags[(size_t)r] & GS_F_RETURNED)) {
+                append_text_record(c.flt_buf, text, nl, r);
+                c.filtered_reads++;
+            }
+            if (c.kraken.active()) {
+                const size_t d0 = r == 0 ? 0 : (size_t)nl[4 * r - 1] + 1, d1 = nl[4 * r];
+                kraken_line(c, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
+            }
+        }
+        if (!c.flt_buf.empty()) c.filtered.write(c.flt_buf.data(), c.flt_buf.size());
+        if (!c.out_buf.empty()) c.kraken.write(c.out_buf.data(), c.out_buf.size());
+        return GS_OK;
+    }
+
     int check_refusal(int64_t *fallback_off, int64_t *fallback_reads) {
         int64_t failed = -1, bad = -1;
         int err = gs_match_text_status(c.run, &failed, &bad, tot);
@@ -984,8 +1059,8 @@ namespace {
 // max-contig read numbers of the run are in that (file, read) form.
 int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t *file_index, std::vector<int64_t> &reads_of_file_out,
               bool *composite) {
-    bool fast = !c.filtered.active() && !c.kraken.active();  // the text path has no per-read writers yet
-    if (const char *e = getenv("GS_HOST_FAST")) fast = fast && atoi(e) != 0;
+    bool fast = true;
+    if (const char *e = getenv("GS_HOST_FAST")) fast = atoi(e) != 0;
     int err = GS_OK;
     std::vector<int> kind((size_t)n_paths, 0);
     int n_gzip = 0;
@@ -997,7 +1072,8 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
     // Several gzip files: each is bound by its single inflating thread, so they are read side by side (up to 8 at a
     // time).  The read numbers of file f then start at f << 32, which keeps "first read in file order" (the max-contig
     // tie-break) intact; the column is converted back to running read numbers at the end.
-    bool side_by_side = n_gzip >= 2 && n_paths <= 256;
+    // (per-read outputs follow the read order: one file after the other)
+    bool side_by_side = n_gzip >= 2 && n_paths <= 256 && !c.filtered.active() && !c.kraken.active();
     if (const char *e = getenv("GS_HOST_PARALLEL_FILES")) side_by_side = side_by_side && atoi(e) != 0;
     if (file_index) side_by_side = true;  // read numbers are (file << 32 | read): the files are independent anyway
     std::vector<int64_t> reads_of_file((size_t)n_paths, 0);
@@ -1179,26 +1255,6 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
     c.bps += prod.bps;
     c.t_parse += prod.seconds;
     return err;
-}
-
-// ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", '~' x length
-// (appended to `buf`; the caller writes one buffer per chunk)
-void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const uint32_t *nl, int64_t i) {
-    const size_t d0 = i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1, d1 = nl[4 * i], s0 = d1 + 1, s1 = nl[4 * i + 1];
-    const size_t at = buf.size(), dl = d1 - d0, sl = s1 - s0;
-    buf.resize(at + dl + 2 * sl + 5);
-    uint8_t *o = buf.data() + at;
-    memcpy(o, text + d0, dl);
-    o += dl;
-    *o++ = '\n';
-    memcpy(o, text + s0, sl);
-    o += sl;
-    *o++ = '\n';
-    *o++ = '+';
-    *o++ = '\n';
-    memset(o, '~', sl);
-    o += sl;
-    *o = '\n';
 }
 
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back

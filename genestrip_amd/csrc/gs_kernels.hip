@@ -935,8 +935,9 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
     GsPrefetch nopf;
     nopf.rd = nullptr;
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
-        const u64 off = P.off[r];
-        const int L = (int)(P.off[r + 1] - off);
+        const uint64_t *po = P.off + r * P.off_stride;
+        const u64 off = po[0];
+        const int L = (int)(po[1] - off);
         const int max = L - k + 1;
         const uint8_t *rd = P.seq + off;
         const int n_iter = max > 0 ? (max + 127) >> 7 : 0;

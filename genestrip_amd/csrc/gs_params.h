@@ -85,6 +85,8 @@ struct GsSegParams {
     const unsigned long long *seg_off;  // write pass: exclusive prefix of seg_count
     int32_t *seg_code;
     int32_t *seg_start;
+    int32_t off_stride;  // 1: running offsets; 2: (start, end) pairs (text mode)
+    int32_t pad3;
 };
 
 struct GsEncodeParams {

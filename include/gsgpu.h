@@ -233,6 +233,11 @@ int gs_unroute_nodes(gs_run *run, const uint32_t *idx, const int32_t *back, int6
 int gs_match_segments(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int mem,
                       uint64_t *seg_off);
 int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts);
+/* the same for the reads of the most recent text chunk (gs_match_submit_text; it must not have been refused), and the
+ * byte offsets of that chunk's newlines (n_lines entries, host memory) -- the record geometry a caller needs to write
+ * the filtered FASTQ and the Kraken-style lines from its copy of the raw text.  Both synchronise. */
+int gs_match_segments_text(gs_run *run, uint64_t *seg_off);
+int gs_match_text_newlines(gs_run *run, uint32_t *newlines);
 
 /* accumulated device time of the match kernel launches since gs_match_begin (cfg.profile != 0) */
 int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);

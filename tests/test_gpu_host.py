@@ -277,3 +277,34 @@ def test_match_files_gzip_files_side_by_side(sdb, tmp_path, monkeypatch, odd):
     assert (tot1.reads, tot1.kmers, tot1.bps) == (tot0.reads, tot0.kmers, tot0.bps) == want_tot
     assert np.array_equal(t0, want_t), np.argwhere(t0 != want_t)[:8]
     store.close()
+
+
+@pytest.mark.parametrize("block", [0, 3000])
+@pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "gzip"])
+def test_match_files_text_path_per_read_outputs(sdb, tmp_path, monkeypatch, block, shape):
+    """filtered FASTQ and Kraken-style lines written from the raw blocks (record geometry and segments come from the
+    device) must be byte-identical to what the reference-exact parser path writes"""
+    recs = _fastq_bytes(sdb, 700, seed=41, nl=b"\r\n" if shape == "crlf" else b"\n")
+    if shape == "multi-line record":
+        s = recs[500].split(b"\n")
+        recs[500] = s[0] + b"\n" + s[1][:50] + b"\n" + s[1][50:] + b"\n+\n" + s[3] + b"\n"
+    data = b"".join(recs)
+    if shape == "no final newline":
+        data = data[:-1]
+    path = str(tmp_path / ("in.fastq.gz" if shape == "gzip" else "in.fastq"))
+    with (gzip.open(path, "wb") if shape == "gzip" else open(path, "wb")) as f:
+        f.write(data)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_FAST", fast)
+        if block:
+            monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+        kr, fl = str(tmp_path / f"k{fast}.out"), str(tmp_path / f"f{fast}.fastq")
+        t, _, tot = host.match_files(store, [path], filtered_path=fl, kraken_out_path=kr, taxids=sdb.taxids, write_all=(block == 0))
+        outs[fast] = (t, (tot.reads, tot.kmers, tot.bps, tot.filtered_reads), open(kr, "rb").read(), open(fl, "rb").read())
+    assert np.array_equal(outs["1"][0], outs["0"][0])
+    assert outs["1"][1] == outs["0"][1]
+    assert outs["1"][2] == outs["0"][2] and len(outs["1"][2]) > 1000
+    assert outs["1"][3] == outs["0"][3] and len(outs["1"][3]) > 1000
+    store.close()
