@@ -308,3 +308,23 @@ def test_match_files_text_path_per_read_outputs(sdb, tmp_path, monkeypatch, bloc
     assert outs["1"][2] == outs["0"][2] and len(outs["1"][2]) > 1000
     assert outs["1"][3] == outs["0"][3] and len(outs["1"][3]) > 1000
     store.close()
+
+
+def test_match_files_corrupt_gzip_is_an_error(sdb, tmp_path):
+    """a damaged or truncated gzip file must fail the call (GZIPInputStream throws), not yield a silently shorter run"""
+    data = b"".join(_fastq_bytes(sdb, 3000, seed=43))
+    good = str(tmp_path / "good.fastq.gz")
+    with gzip.open(good, "wb") as f:
+        f.write(data)
+    raw = open(good, "rb").read()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    t, _, tot = host.match_files(store, [good])
+    assert tot.reads == 3000
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x20
+    for name, blob in (("flip", bytes(flipped)), ("cut", raw[:len(raw) // 2]), ("crc", raw[:-8] + bytes([raw[-8] ^ 1]) + raw[-7:])):
+        p = str(tmp_path / f"{name}.fastq.gz")
+        open(p, "wb").write(blob)
+        with pytest.raises(RuntimeError):
+            host.match_files(store, [p])
+    store.close()
