@@ -1,0 +1,542 @@
+// gs_ingest.h -- the byte-level side of the host layer (include/gshost.h): file names, the line reader and record
+// parser with the reference's exact semantics (C/fastq/AbstractFastqReader.java:288-438 over
+// B/io/BufferedLineReader.java:114-182), and the block readers of the text path (parallel pread / one inflating thread
+// into pooled pinned blocks).  Header-only, included by gs_host.cpp and gs_report.cpp.
+#pragma once
+#include "../../include/gshost.h"
+#include "gs_inflate.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace gs_host {
+
+
+inline thread_local std::string g_host_err;
+inline int hfail(int code, const std::string &m) {
+    g_host_err = m;
+    return code;
+}
+
+inline bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+inline bool is_gzip_name(const std::string &s) { return ends_with(s, ".gz") || ends_with(s, ".gzip"); }  // StreamProvider.java:148-150
+
+inline bool is_fasta_name(const std::string &s) {  // FastqMapGoal.java:64,188-201
+    static const char *suf[] = {"fasta", "fa", "fna", "fas", "fasta.gz", "fa.gz", "fna.gz", "fas.gz",
+                                "fasta.gzip", "fa.gzip", "fna.gzip", "fas.gzip"};
+    for (const char *x : suf)
+        if (ends_with(s, x)) return true;
+    return false;
+}
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------
+// byte source + line reader (BufferedLineReader.nextLine semantics: NUL bytes dropped, '\r' kept, the '\n' is part
+// of the returned line; callers take "length - 1")
+// ---------------------------------------------------------------------------------------------------
+class LineReader {
+public:
+    bool open(const std::string &path, int64_t offset = 0) {
+        gz_ = gzopen(path.c_str(), "rb");  // zlib reads plain files transparently, gzip by content
+        if (!gz_) return false;
+        gzbuffer(gz_, 1 << 20);
+        buf_.resize(1 << 20);
+        return offset == 0 || gzseek(gz_, (z_off_t)offset, SEEK_SET) == (z_off_t)offset;
+    }
+    void open_mem(const uint8_t *p, size_t n) {  // a byte range that is already in memory
+        buf_.assign(p, p + n);
+        fill_ = n;
+        pos_ = 0;
+        eof_ = true;
+    }
+    ~LineReader() {
+        if (gz_) gzclose(gz_);
+    }
+    // appends the next line (incl. '\n', NULs dropped) to out; returns the number of bytes appended (0 at EOF)
+    size_t next_line(std::vector<uint8_t> &out) {
+        const size_t start = out.size();
+        for (;;) {
+            if (pos_ == fill_) {
+                if (eof_) break;
+                const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+                if (n <= 0) {
+                    eof_ = true;
+                    break;
+                }
+                fill_ = (size_t)n;
+                pos_ = 0;
+            }
+            const uint8_t *p = buf_.data() + pos_;
+            const size_t avail = fill_ - pos_;
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', avail);
+            const size_t take = nl ? (size_t)(nl - p) + 1 : avail;
+            if (memchr(p, 0, take) == nullptr) {
+                out.insert(out.end(), p, p + take);
+            } else {
+                for (size_t i = 0; i < take; i++)
+                    if (p[i] != 0) out.push_back(p[i]);
+            }
+            pos_ += take;
+            if (nl) break;
+        }
+        return out.size() - start;
+    }
+
+private:
+    gzFile gz_ = nullptr;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0, fill_ = 0;
+    bool eof_ = false;
+};
+
+struct Batch {
+    std::vector<uint8_t> seq, desc, qual;
+    std::vector<uint64_t> seq_off{0}, desc_off{0}, qual_off{0};
+    int64_t first_read_no = 0;
+    int64_t n() const { return (int64_t)seq_off.size() - 1; }
+    void clear() {
+        seq.clear();
+        desc.clear();
+        qual.clear();
+        seq_off.assign(1, 0);
+        desc_off.assign(1, 0);
+        qual_off.assign(1, 0);
+    }
+};
+
+// AbstractFastqReader.doReadFastq (:288-368) / doReadFasta (:375-438) with unbounded buffers
+class FastqParser {
+public:
+    FastqParser(int k, bool fasta) : k_(k), fasta_(fasta) {}
+    bool open(const std::string &path, int64_t offset = 0) { return lr_.open(path, offset); }
+    void open_mem(const uint8_t *p, size_t n) { lr_.open_mem(p, n); }
+
+    // appends up to max_reads records / max_bytes sequence bytes to b; returns false at end of file
+    bool parse(Batch &b, int64_t max_reads, int64_t max_bytes) {
+        b.clear();
+        b.first_read_no = reads_;
+        while (!done_ && b.n() < max_reads && (int64_t)b.seq.size() < max_bytes) {
+            if (!(fasta_ ? next_fasta(b) : next_fastq(b))) done_ = true;
+        }
+        return b.n() > 0;
+    }
+    int64_t reads_ = 0, kmers_ = 0, bps_ = 0;
+
+private:
+    void account(Batch &b, size_t read_size) {
+        b.seq_off.push_back(b.seq.size());
+        b.desc_off.push_back(b.desc.size());
+        b.qual_off.push_back(b.qual.size());
+        reads_++;
+        if ((int64_t)read_size >= k_) kmers_ += (int64_t)read_size - k_ + 1;
+        bps_ += (int64_t)read_size;
+    }
+
+    bool next_fastq(Batch &b) {
+        const size_t dstart = b.desc.size(), sstart = b.seq.size(), qstart = b.qual.size();
+        size_t got = lr_.next_line(b.desc);
+        if (got == 0) return false;  // readDescriptorSize == -1
+        b.desc.resize(dstart + got - 1);
+        got = lr_.next_line(b.seq);
+        if (got == 0) {  // truncated record: the reference runs into an exception here
+            b.desc.resize(dstart);
+            return false;
+        }
+        b.seq.resize(sstart + got - 1);
+        for (;;) {  // sequence lines until a line STARTING with '+' (:301-308)
+            const size_t lstart = b.seq.size();
+            got = lr_.next_line(b.seq);
+            if (got == 0) {
+                b.desc.resize(dstart);
+                b.seq.resize(sstart);
+                return false;
+            }
+            if (b.seq[lstart] == '+') {
+                b.seq.resize(lstart);
+                break;
+            }
+            b.seq.resize(lstart + got - 1);
+        }
+        const long read_size = (long)(b.seq.size() - sstart);
+        // quality lines until >= readSize characters (:320-341)
+        got = lr_.next_line(b.qual);
+        long qsize = (long)got - 1;
+        while (qsize < read_size) {
+            const long old = qsize;
+            b.qual.resize(qstart + (size_t)(qsize < 0 ? 0 : qsize));  // continue over the previous '\n'
+            got = lr_.next_line(b.qual);
+            qsize = got ? (long)(b.qual.size() - qstart) - 1 : old - 1;
+            if (qsize == old - 1) break;  // EOF
+        }
+        if (qsize < 0) qsize = 0;
+        b.qual.resize(qstart + (size_t)qsize);
+        account(b, (size_t)read_size);
+        return true;
+    }
+
+    bool next_fasta(Batch &b) {
+        if (!have_header_) {
+            header_.clear();
+            const size_t got = lr_.next_line(header_);
+            if (got == 0) return false;
+            header_.resize(got - 1);
+            have_header_ = true;
+        }
+        const size_t dstart = b.desc.size(), sstart = b.seq.size();
+        b.desc.insert(b.desc.end(), header_.begin(), header_.end());
+        if (!header_.empty()) b.desc[dstart] = '@';  // :380
+        have_header_ = false;
+        bool more = true;
+        for (;;) {
+            const size_t lstart = b.seq.size();
+            const size_t got = lr_.next_line(b.seq);
+            if (got == 0) {
+                more = false;
+                break;
+            }
+            if (b.seq[lstart] == '>') {  // next header: copied without its '\n' (:405-413)
+                header_.assign(b.seq.begin() + (long)lstart, b.seq.begin() + (long)(lstart + got - 1));
+                b.seq.resize(lstart);
+                have_header_ = true;
+                break;
+            }
+            b.seq.resize(lstart + got - 1);
+        }
+        account(b, b.seq.size() - sstart);
+        return more || have_header_;
+    }
+
+    int k_;
+    bool fasta_, done_ = false, have_header_ = false;
+    std::vector<uint8_t> header_;
+    LineReader lr_;
+};
+
+inline void append_int(std::string &s, long long v) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    s.append(buf, r.ptr);
+}
+
+// Double.toString: shortest round-trip digits; decimal notation for 1e-3 <= |d| < 1e7, else d.dddE[-]n
+inline std::string java_double(double v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), std::fabs(v), std::chars_format::scientific);
+    std::string sci(buf, r.ptr);  // d[.ddd]e[+-]XX
+    const size_t epos = sci.find('e');
+    std::string digits = sci.substr(0, epos);
+    const int exp10 = atoi(sci.c_str() + epos + 1);
+    digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+    std::string out = v < 0 ? "-" : "";
+    const double a = std::fabs(v);
+    if (a >= 1e-3 && a < 1e7) {
+        if (exp10 >= 0) {
+            std::string ip = digits.substr(0, std::min(digits.size(), (size_t)exp10 + 1));
+            while ((int)ip.size() < exp10 + 1) ip.push_back('0');
+            std::string fp = digits.size() > (size_t)exp10 + 1 ? digits.substr((size_t)exp10 + 1) : "0";
+            out += ip + "." + fp;
+        } else {
+            out += "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
+        }
+    } else {
+        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E";
+        append_int(out, exp10);
+    }
+    return out;
+}
+
+
+// ---- fast path for plain four-line FASTQ: reader threads fill pinned blocks, the device finds the records -----------
+// (gs_match_submit_text).  The host only counts newlines to cut the stream at record boundaries.
+inline size_t count_newlines(const uint8_t *p, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; i++) c += p[i] == '\n';  // vectorised by the compiler
+    return c;
+}
+
+struct TextSlot {
+    uint8_t *buf = nullptr;  // pinned: headroom (for the carried partial record) + block
+    size_t n = 0;            // bytes read into the block
+    int64_t newlines = 0;
+    int64_t last4[4] = {-1, -1, -1, -1};  // offsets of the last four newlines of the block, last first
+    int state = 0;           // 0 empty, 1 full
+    bool eof = false, io_error = false;
+    std::vector<std::pair<uint32_t, uint32_t>> member_ends;  // gzip input: (offset in the block, CRC-32 of the trailer)
+};
+
+// page-locked blocks are expensive to create (the driver pins every page): the pipelines of one process reuse them
+// from file to file.  At most 64 idle blocks are kept; they are deliberately not released at exit (the HIP runtime
+// may already be gone when static destructors run).
+class PinnedPool {
+public:
+    int get(size_t bytes, uint8_t **out) {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            for (size_t i = 0; i < idle_.size(); i++)
+                if (idle_[i].second == bytes) {
+                    *out = idle_[i].first;
+                    idle_.erase(idle_.begin() + (long)i);
+                    return GS_OK;
+                }
+        }
+        void *p = nullptr;
+        const int rc = gs_pinned_alloc(&p, bytes);
+        *out = (uint8_t *)p;
+        return rc;
+    }
+    void put(uint8_t *p, size_t bytes) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (idle_.size() < 64) {
+                idle_.push_back({p, bytes});
+                return;
+            }
+        }
+        gs_pinned_free(p);
+    }
+
+private:
+    std::mutex m_;
+    std::vector<std::pair<uint8_t *, size_t>> idle_;
+};
+inline PinnedPool &pinned_pool() {
+    static PinnedPool *pool = new PinnedPool();
+    return *pool;
+}
+
+struct TextReader {
+    int fd = -1;
+    size_t block = 0, headroom = 0;
+    int n_slots = 0, n_threads = 0;
+    std::vector<TextSlot> slots;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    int64_t start_off = 0;
+
+    // gzip input: the file is mapped and ONE thread inflates it into the blocks, in order (a gzip stream is serial);
+    // the CRC-32 of the members is left to the consumer of the blocks (verify_gzip), which has the time
+    bool gz = false;
+    const uint8_t *map = nullptr;
+    size_t map_len = 0;
+    uint32_t run_crc = 0;
+
+    int open(const std::string &path, size_t block_bytes, int readers, bool gzip) {
+        if (gzip) {
+            gz = true;
+            fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
+            struct stat sb;
+            if (fstat(fd, &sb) != 0) return hfail(GS_E_INVALID, "cannot stat " + path);
+            map_len = (size_t)sb.st_size;
+            if (map_len) {
+                void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) return hfail(GS_E_INVALID, "cannot map " + path);
+                map = (const uint8_t *)m;
+                madvise(m, map_len, MADV_SEQUENTIAL);
+            }
+            if (block_bytes < ((size_t)64 << 10)) block_bytes = (size_t)64 << 10;  // the 32 KiB window lives in the headroom
+            readers = 1;
+        } else {
+            fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) return hfail(GS_E_INVALID, "cannot open " + path);
+#ifdef POSIX_FADV_SEQUENTIAL
+            posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+#endif
+        }
+        block = block_bytes;
+        headroom = block_bytes;
+        n_threads = readers;
+        n_slots = gzip ? 4 : 2 * readers;
+        slots.resize((size_t)n_slots);
+        for (auto &sl : slots) {
+            int rc = pinned_pool().get(headroom + block, &sl.buf);
+            if (rc) return rc;
+        }
+        return GS_OK;
+    }
+    void fill_newlines(TextSlot &sl, const uint8_t *dst, size_t got) {
+        sl.newlines = (int64_t)count_newlines(dst, got);
+        size_t end = got;
+        for (int j = 0; j < 4; j++) {
+            const void *q = end ? memrchr(dst, '\n', end) : nullptr;
+            sl.last4[j] = q ? (int64_t)((const uint8_t *)q - dst) : -1;
+            end = q ? (size_t)((const uint8_t *)q - dst) : 0;
+        }
+    }
+    void start_gzip() {
+        threads.emplace_back([this] {
+            std::unique_ptr<GsInflate> inf(new GsInflate());
+            inf->init(map, map_len, false);
+            std::vector<uint8_t> window(32768);
+            size_t hist = 0;
+            bool done = map_len == 0;
+            for (int64_t i = 0;; i++) {
+                TextSlot &sl = slots[(size_t)(i % n_slots)];
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return stop || sl.state == 0; });
+                    if (stop) return;
+                }
+                uint8_t *dst = sl.buf + headroom;
+                memcpy(dst - hist, window.data() + (32768 - hist), hist);
+                size_t got = 0;
+                bool err = false;
+                sl.member_ends.clear();
+                while (!done && got < block) {
+                    size_t p = 0;
+                    const GsInflate::Status st = inf->decode(dst + got, block - got, hist + got, &p);
+                    const uint64_t block_start = (uint64_t)i * block;
+                    for (int e = 0; e < inf->n_member_ends(); e++)
+                        sl.member_ends.push_back({(uint32_t)(inf->member_ends()[e].out_offset - block_start), inf->member_ends()[e].crc});
+                    inf->clear_member_ends();
+                    got += p;
+                    if (st == GsInflate::CORRUPT) err = true;
+                    if (st != GsInflate::NEED_OUTPUT) done = true;
+                }
+                const size_t keep = got < 32768 ? got : 32768;  // (a short block is the last one)
+                if (keep == 32768)
+                    memcpy(window.data(), dst + got - 32768, 32768);
+                hist = keep == 32768 ? 32768 : hist;
+                sl.n = got;
+                sl.eof = got < block || done;
+                sl.io_error = err;
+                fill_newlines(sl, dst, got);
+                {
+                    std::lock_guard<std::mutex> l(m);
+                    sl.state = 1;
+                }
+                cv.notify_all();
+                if (sl.eof || err) return;
+            }
+        });
+    }
+    // consumer side: CRC-32 of the gzip members over the delivered block (GZIPInputStream checks it while reading)
+    bool verify_gzip(const TextSlot &sl) {
+        if (!gz) return true;
+        const uint8_t *p = sl.buf + headroom;
+        size_t at = 0;
+        for (const auto &me : sl.member_ends) {
+            run_crc = GsCrc32::update(run_crc, p + at, me.first - at);
+            if (run_crc != me.second) return false;
+            run_crc = 0;
+            at = me.first;
+        }
+        run_crc = GsCrc32::update(run_crc, p + at, sl.n - at);
+        return true;
+    }
+    void start() {
+        if (gz) {
+            start_gzip();
+            return;
+        }
+        for (int t = 0; t < n_threads; t++)
+            threads.emplace_back([this, t] {
+                for (int64_t i = t;; i += n_threads) {
+                    TextSlot &sl = slots[(size_t)(i % n_slots)];
+                    {
+                        std::unique_lock<std::mutex> l(m);
+                        cv.wait(l, [&] { return stop || sl.state == 0; });
+                        if (stop) return;
+                    }
+                    uint8_t *dst = sl.buf + headroom;
+                    size_t got = 0;
+                    bool err = false;
+                    while (got < block) {
+                        const ssize_t r = pread(fd, dst + got, block - got, (off_t)(start_off + i * (int64_t)block + (int64_t)got));
+                        if (r < 0) {
+                            if (errno == EINTR) continue;
+                            err = true;
+                            break;
+                        }
+                        if (r == 0) break;
+                        got += (size_t)r;
+                    }
+                    sl.n = got;
+                    sl.eof = got < block;
+                    sl.io_error = err;
+                    fill_newlines(sl, dst, got);
+                    {
+                        std::lock_guard<std::mutex> l(m);
+                        sl.state = 1;
+                    }
+                    cv.notify_all();
+                    if (sl.eof || err) return;  // later blocks are past the end: the consumer stops at this one
+                }
+            });
+    }
+    bool is_full(int64_t i) {
+        std::lock_guard<std::mutex> l(m);
+        return slots[(size_t)(i % n_slots)].state == 1;
+    }
+    TextSlot &wait_full(int64_t i) {
+        TextSlot &sl = slots[(size_t)(i % n_slots)];
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return sl.state == 1; });
+        return sl;
+    }
+    void release(int64_t i) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            slots[(size_t)(i % n_slots)].state = 0;
+        }
+        cv.notify_all();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+        threads.clear();
+        for (auto &sl : slots) pinned_pool().put(sl.buf, headroom + block);
+        slots.clear();
+        if (map) munmap((void *)map, map_len);
+        map = nullptr;
+        if (fd >= 0) ::close(fd);
+        fd = -1;
+    }
+};
+
+// 0: not for the text path (FASTA), 1: plain FASTQ (parallel pread), 2: gzip FASTQ (one inflating thread)
+inline int text_path_kind(const std::string &path) {
+    if (is_fasta_name(path)) return 0;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    unsigned char mg[2] = {0, 0};
+    const size_t n = fread(mg, 1, 2, f);
+    fclose(f);
+    const bool gzip_content = n == 2 && mg[0] == 0x1f && mg[1] == 0x8b;  // zlib decides by content, so do we
+    return gzip_content ? 2 : 1;
+}
+
+
+}  // namespace gs_host
