@@ -712,7 +712,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     }
     int occ = gs_match_occupancy(db->info.n_values);
     if (occ < 1) occ = 1;
-    if (occ > 6) occ = 6;  // measured: 6 workgroups (24 waves) per CU is the optimum, 7 thrashes the caches
+    if (occ > 8) occ = 8;  // 8 workgroups (32 waves) per CU: the kernel is built for 64 VGPRs
     if (const char *ev = getenv("GS_MATCH_BLOCKS_PER_CU")) {
         int v = atoi(ev);
         if (v >= 1 && v <= 16) occ = v;
