@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gs_layout.h"
@@ -208,19 +209,52 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (const char *e = getenv("GS_MGATE")) want_mgate = want_mgate && atoi(e) != 0;
     if (want_mgate) hmin.reserve((size_t)n);
     const uint32_t kmask = (1u << k) - 1u;
-    for (int64_t i = 0; i < n; i++) {
-        uint32_t fhi, flo, phi, plo;
-        bool reachable = java_to_planes((u64)kmers[i], k, fhi, flo);
-        if (!reachable || parent[vidx[i]] == -2) continue;
-        gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
-        const u64 hk = gs_mix_planes(phi, plo);
-        if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
-        hkey.push_back(hk);
-        hval.push_back(vidx[i]);
-        if (want_mgate) {  // strand symmetric: either orientation gives the same minimizer
-            uint32_t m = 0xffffffffu;
-            for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
-            hmin.push_back(m);
+    {
+        // per-key work (planes, representative, hash, minimizer) on all host cores: slices are converted independently
+        // and concatenated in order, so the result does not depend on the thread count
+        int n_thr = (int)std::min<int64_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 32);
+        if (const char *e = getenv("GS_BUILD_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+        if (n < 200000) n_thr = 1;
+        struct Slice {
+            std::vector<u64> h;
+            std::vector<int32_t> v;
+            std::vector<uint32_t> m;
+        };
+        std::vector<Slice> sl((size_t)n_thr);
+        auto work = [&](int t) {
+            const int64_t lo = n * t / n_thr, hi = n * (t + 1) / n_thr;
+            Slice &o = sl[(size_t)t];
+            o.h.reserve((size_t)(hi - lo));
+            o.v.reserve((size_t)(hi - lo));
+            if (want_mgate) o.m.reserve((size_t)(hi - lo));
+            for (int64_t i = lo; i < hi; i++) {
+                uint32_t fhi, flo, phi, plo;
+                bool reachable = java_to_planes((u64)kmers[i], k, fhi, flo);
+                if (!reachable || parent[vidx[i]] == -2) continue;
+                gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
+                const u64 hk = gs_mix_planes(phi, plo);
+                if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
+                o.h.push_back(hk);
+                o.v.push_back(vidx[i]);
+                if (want_mgate) {  // strand symmetric: either orientation gives the same minimizer
+                    uint32_t m = 0xffffffffu;
+                    for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
+                    o.m.push_back(m);
+                }
+            }
+        };
+        if (n_thr == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        for (Slice &o : sl) {
+            hkey.insert(hkey.end(), o.h.begin(), o.h.end());
+            hval.insert(hval.end(), o.v.begin(), o.v.end());
+            hmin.insert(hmin.end(), o.m.begin(), o.m.end());
+            Slice().h.swap(o.h);
         }
     }
     const int64_t ns = (int64_t)hkey.size();
@@ -278,13 +312,22 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     std::vector<uint32_t> mgate;
     int mgate_bits = 0;
     if (want_mgate && ns > 0) {
-        std::vector<uint32_t> um(hmin);
-        std::sort(um.begin(), um.end());
-        um.erase(std::unique(um.begin(), um.end()), um.end());
+        // size by the number of DISTINCT minimizers, estimated by linear counting on a 2^26-bit sketch (a sort of
+        // the 32-bit hashes costs seconds for tens of millions of keys; +-1 % is plenty for a power-of-two size)
+        const size_t sketch_bits = (size_t)1 << 26;
+        std::vector<u64> sketch(sketch_bits / 64, 0);
+        for (int64_t i = 0; i < ns; i++) {
+            const uint32_t x = hmin[(size_t)i] * 0x9E3779B1u;  // (the hash is a bijection of the 15-mer: no extra collisions)
+            sketch[(x >> 6) & (sketch.size() - 1)] |= 1ULL << (x & 63);
+        }
+        size_t ones = 0;
+        for (u64 w : sketch) ones += (size_t)__builtin_popcountll(w);
+        const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
+        const double distinct = std::min((double)ns, -(double)sketch_bits * std::log(zero_frac));
         mgate_bits = 6;
-        while (mgate_bits < 30 && ((size_t)32 << mgate_bits) < um.size() * 16) mgate_bits++;
+        while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < distinct * 16.0) mgate_bits++;
         mgate.assign((size_t)1 << mgate_bits, 0);
-        for (uint32_t m : um) mgate[gs_mgate_word(m, (uint32_t)mgate_bits)] |= gs_mgate_bits(m);
+        for (int64_t i = 0; i < ns; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }
     gs_db *db = new gs_db();
     db->device = device;
