@@ -57,15 +57,43 @@ private:
     };
 };
 
-class GsInflate {
+// OutT = uint8_t: the decoded bytes.  OutT = uint16_t: "marker mode" for decoding that starts in the middle of a stream
+// (GsParallelGunzip below): values < 256 are bytes, values >= 0x8000 stand for byte (v - 0x8000) of the 32 KiB of output
+// that precede the start and are not known yet -- the caller puts these 32768 marker values in front of the buffer, so
+// that back-references into the unknown window simply copy them.
+template <typename OutT>
+class GsInflateT {
 public:
-    enum Status { NEED_OUTPUT = 0, DONE = 1, CORRUPT = -1 };
+    enum Status { NEED_OUTPUT = 0, DONE = 1, AT_BOUNDARY = 2, CORRUPT = -1 };
     struct MemberEnd {
         uint64_t out_offset;  // total output bytes when the member ended
         uint32_t crc;         // CRC-32 of the member's data according to its trailer
+        uint32_t isize;       // ... and its length mod 2^32
     };
 
+    // start INSIDE a stream, at the first bit of a DEFLATE block header (GsParallelGunzip): no gzip header is read, the
+    // size of the member that is in progress cannot be checked here (its end is reported with the others)
+    void init_at(const uint8_t *in, size_t n_in, uint64_t bit_offset) {
+        init(in, n_in, false);
+        in_ = in + (bit_offset >> 3);
+        refill();
+        const int r = (int)(bit_offset & 7);
+        bitbuf_ >>= r;
+        bitcnt_ -= r;
+        state_ = S_BLOCK_HEADER;
+        partial_member_ = true;
+        any_member_ = true;
+    }
+    // bits of the input consumed so far
+    uint64_t bit_position() const { return (uint64_t)(in_ - in_begin_) * 8 - (uint64_t)bitcnt_; }
+    // decode() returns AT_BOUNDARY when it stands in front of a non-final dynamic-Huffman block at or behind this bit
+    // (the kind of block start a decoder that begins mid-stream can recognise)
+    void stop_at_boundary_from(uint64_t bit_limit) { stop_limit_ = bit_limit; }
+
     void init(const uint8_t *in, size_t n_in, bool check_crc = true) {
+        in_begin_ = in;
+        stop_limit_ = ~0ULL;
+        partial_member_ = false;
         check_crc_ = check_crc;
         total_out_ = 0;
         n_ends_ = 0;
@@ -91,10 +119,10 @@ public:
 
     // fills out[0, cap) as far as the stream goes; *produced bytes were written.  `history` = number of valid bytes
     // directly in front of `out` (the tail of the previous block, at least min(32768, total output so far)).
-    Status decode(uint8_t *out, size_t cap, size_t history, size_t *produced) {
-        uint8_t *o = out, *const o_end = out + cap;
-        uint8_t *const out0 = out;
-        const uint8_t *const o_min = out - history;
+    Status decode(OutT *out, size_t cap, size_t history, size_t *produced) {
+        OutT *o = out, *const o_end = out + cap;
+        OutT *const out0 = out;
+        const OutT *const o_min = out - history;
         Status st = NEED_OUTPUT;
         for (;;) {
             if (state_ == S_HEADER) {
@@ -118,6 +146,10 @@ public:
                     continue;
                 }
                 if (!need_bits(3)) return fail_corrupt(out0, o, produced);
+                if (bit_position() >= stop_limit_ && (bitbuf_ & 7u) == 4u) {  // BFINAL = 0, BTYPE = 2
+                    st = AT_BOUNDARY;
+                    break;
+                }
                 final_ = take(1) != 0;
                 const uint32_t type = take(2);
                 if (type == 0) {
@@ -141,7 +173,7 @@ public:
                 size_t n = stored_left_;
                 if (n > (size_t)(o_end - o)) n = (size_t)(o_end - o);
                 if (n > (size_t)(in_end_ - in_)) return fail_corrupt(out0, o, produced);
-                memcpy(o, in_, n);
+                for (size_t q = 0; q < n; q++) o[q] = (OutT)in_[q];  // (uint8_t: a plain copy)
                 o += n;
                 in_ += n;
                 stored_left_ -= (uint32_t)n;
@@ -156,7 +188,7 @@ public:
                 state_ = S_BLOCK_HEADER;
             } else if (state_ == S_TRAILER_PENDING) {
                 if (n_ends_ == MAX_ENDS) break;
-                ends_[n_ends_++] = {total_out_ + (uint64_t)(o - out0), pend_crc_};
+                ends_[n_ends_++] = {total_out_ + (uint64_t)(o - out0), pend_crc_, pend_isize_};
                 any_member_ = true;
                 state_ = S_HEADER;
             } else {  // S_TRAILER
@@ -168,7 +200,9 @@ public:
                 const uint32_t crc = take(32);
                 if (!need_bits(32)) return fail_corrupt(out0, o, produced);
                 const uint32_t isz = take(32);
-                if ((check_crc_ && crc != crc_) || isz != isize_) return fail_corrupt(out0, o, produced);
+                if ((check_crc_ && crc != crc_) || (!partial_member_ && isz != isize_)) return fail_corrupt(out0, o, produced);
+                partial_member_ = false;
+                pend_isize_ = isz;
                 if (!check_crc_) {
                     if (n_ends_ == MAX_ENDS) {  // the caller has to drain the list first: stop at this member boundary
                         // put the trailer back and report the block as full
@@ -176,7 +210,7 @@ public:
                         pend_crc_ = crc;
                         break;
                     }
-                    ends_[n_ends_++] = {total_out_ + (uint64_t)(o - out0), crc};
+                    ends_[n_ends_++] = {total_out_ + (uint64_t)(o - out0), crc, isz};
                 }
                 any_member_ = true;
                 state_ = S_HEADER;
@@ -204,7 +238,10 @@ private:
     int state_ = S_HEADER;
     bool final_ = false, any_member_ = false, header_started_ = false;
     uint32_t pend_len_ = 0, pend_dist_ = 0, stored_left_ = 0;
-    uint32_t crc_ = 0, isize_ = 0, pend_crc_ = 0;
+    uint32_t crc_ = 0, isize_ = 0, pend_crc_ = 0, pend_isize_ = 0;
+    const uint8_t *in_begin_ = nullptr;
+    uint64_t stop_limit_ = ~0ULL;
+    bool partial_member_ = false;
     bool check_crc_ = true;
     uint64_t total_out_ = 0;
     int n_ends_ = 0;
@@ -252,10 +289,11 @@ private:
         bitbuf_ = 0;
         bitcnt_ = 0;
     }
-    void flush_crc(const uint8_t *from, const uint8_t *to) {
-        size_t n = (size_t)(to - from);
+    void flush_crc(const OutT *from_t, const OutT *to_t) {
+        size_t n = (size_t)(to_t - from_t);
         isize_ += (uint32_t)n;
-        if (!check_crc_) return;
+        if (!check_crc_ || sizeof(OutT) != 1) return;
+        const uint8_t *from = reinterpret_cast<const uint8_t *>(from_t);
         while (n) {
             const uInt c = n > 0x40000000u ? 0x40000000u : (uInt)n;
             crc_ = (uint32_t)crc32(crc_, from, c);
@@ -263,7 +301,7 @@ private:
             n -= c;
         }
     }
-    Status fail_corrupt(uint8_t *out, uint8_t *o, size_t *produced) {
+    Status fail_corrupt(OutT *out, OutT *o, size_t *produced) {
         *produced = (size_t)(o - out);
         return CORRUPT;
     }
@@ -463,8 +501,8 @@ private:
     }
 
     // 1: end of block, 0: output full (state saved), -1: corrupt
-    __attribute__((optimize("O3"))) int decode_codes(uint8_t *&o_ref, uint8_t *o_end, const uint8_t *o_min) {
-        uint8_t *o = o_ref;
+    __attribute__((optimize("O3"))) int decode_codes(OutT *&o_ref, OutT *o_end, const OutT *o_min) {
+        OutT *o = o_ref;
         // a match that did not fit the previous block
         if (pend_len_) {
             if ((size_t)(o - o_min) < pend_dist_) return -1;
@@ -488,11 +526,11 @@ private:
     bitbuf_ >>= (e & 15);                                   \
     bitcnt_ -= (int)(e & 15);                               \
     if ((e & 0xf0u) == 0x50u) {                             \
-        const uint16_t two = (uint16_t)(e >> 16);           \
-        memcpy(o, &two, 2);                                 \
+        o[0] = (OutT)((e >> 16) & 0xffu);                   \
+        o[1] = (OutT)(e >> 24);                             \
         o += 2;                                             \
     } else                                                  \
-        *o++ = (uint8_t)(e >> 16);
+        *o++ = (OutT)(e >> 16);
                     GS_INF_LITERALS()
                     e = ll_[bitbuf_ & ((1u << LL_BITS) - 1)];
                     if ((e & 0xf0u) != 0 && (e & 0xf0u) != 0x50u) goto not_literal;
@@ -514,7 +552,7 @@ private:
                 bitbuf_ >>= (e & 15);
                 bitcnt_ -= (int)(e & 15);
                 if (kind == 0) {
-                    *o++ = (uint8_t)(e >> 16);
+                    *o++ = (OutT)(e >> 16);
                     continue;
                 }
                 if (kind == 2) {
@@ -540,18 +578,20 @@ private:
                 bitbuf_ >>= db;
                 bitcnt_ -= db;
                 if ((size_t)(o - o_min) < dist) return -1;
-                const uint8_t *s = o - dist;
-                uint8_t *const e_out = o + len;
-                if (dist >= 8) {  // word-wise; may write up to 7 bytes past the match (room is guaranteed)
+                const OutT *s = o - dist;
+                OutT *const e_out = o + len;
+                constexpr uint32_t W = 8 / sizeof(OutT);  // elements per 8-byte word
+                if (dist >= W) {  // word-wise; may write up to 7 bytes past the match (room is guaranteed)
                     do {
                         uint64_t w;
                         memcpy(&w, s, 8);
                         memcpy(o, &w, 8);
-                        s += 8;
-                        o += 8;
+                        s += W;
+                        o += W;
                     } while (o < e_out);
                 } else if (dist == 1) {
-                    memset(o, *s, len);
+                    const OutT c = *s;
+                    for (uint32_t q = 0; q < len; q++) o[q] = c;
                 } else {
                     do {
                         *o++ = *s++;
@@ -583,7 +623,7 @@ private:
                 }
                 bitbuf_ >>= used;
                 bitcnt_ -= used;
-                *o++ = (uint8_t)(e >> 16);
+                *o++ = (OutT)(e >> 16);
                 continue;
             }
             bitbuf_ >>= used;
@@ -624,6 +664,400 @@ private:
                 o_ref = o;
                 return 0;
             }
+        }
+    }
+};
+
+typedef GsInflateT<uint8_t> GsInflate;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GsParallelGunzip -- one gzip stream inflated by several threads.
+//
+// A DEFLATE stream can only be decoded from its start: every block may copy from the 32 KiB before it.  But it can be
+// decoded SPECULATIVELY from the middle: a worker looks for something that parses as the header of a non-final
+// dynamic-Huffman block (complete code-length, literal and distance codes, an end-of-block code, and 64 Ki symbols that
+// decode without an error), starts there and writes 16-bit symbols -- bytes, or "marker" values that stand for a byte of
+// the unknown 32 KiB window.  When the chunk before it is complete, the window is known and the markers are replaced.
+// A guess is never trusted: the resolver checks that every chunk starts exactly at the bit where the previous one
+// stopped (a decoder stops at the first recognisable block start behind its chunk's end) and otherwise decodes the gap
+// itself, so a wrong or missing guess costs time, not correctness.  (The scheme is the one of pugz / rapidgzip.)
+// ---------------------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+class GsParallelGunzip {
+public:
+    typedef GsInflateT<uint16_t> Dec;
+    typedef Dec::MemberEnd MemberEnd;
+
+    ~GsParallelGunzip() { stop(); }
+    // diagnostics: chunks the resolver had to decode itself / worker chunks it could not use
+    size_t n_decoded_here = 0, n_dropped = 0, n_used = 0;
+    std::atomic<uint64_t> ns_find{0}, ns_run{0}, n_candidates{0};
+    uint64_t ns_wait = 0, ns_resolve = 0;
+
+    void start(const uint8_t *in, size_t n_in, int n_threads, size_t chunk_bytes = (size_t)4 << 20) {
+        in_ = in;
+        n_in_ = n_in;
+        chunk_ = chunk_bytes < 65536 ? 65536 : chunk_bytes;
+        n_chunks_ = n_in ? (n_in + chunk_ - 1) / chunk_ : 1;
+        chunks_.resize(n_chunks_);
+        for (auto &c : chunks_) c.reset(new Chunk());
+        next_claim_ = 0;
+        consumed_ = 0;
+        max_ahead_ = (size_t)n_threads * 2 + 2;
+        stop_ = false;
+        for (int t = 0; t < n_threads; t++) workers_.emplace_back([this] { worker(); });
+    }
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+        workers_.clear();
+        for (auto &b : pool_) free(b.first);
+        pool_.clear();
+    }
+
+    // the next bytes of the decoded stream, in order: up to cap bytes into out; member ends that fall into them are
+    // appended to `ends` with out_offset relative to `out`.  *done: the stream is complete; returns false on corruption.
+    bool read(uint8_t *out, size_t cap, size_t *produced, std::vector<MemberEnd> *ends, bool *done) {
+        size_t got = 0;
+        *done = false;
+        while (got < cap) {
+            if (!cur_) {
+                if (finished_) break;
+                if (!next_chunk()) return false;
+                if (!cur_) {
+                    finished_ = true;
+                    break;
+                }
+            }
+            const size_t avail = cur_->size - cur_off_;
+            const size_t n = avail < cap - got ? avail : cap - got;
+            const auto r0 = std::chrono::steady_clock::now();
+            resolve(cur_->data + 32768 + cur_off_, n, out + got);
+            ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r0).count();
+            while (cur_end_ < cur_->ends.size() && cur_->ends[cur_end_].out_offset <= cur_off_ + n) {
+                MemberEnd e = cur_->ends[cur_end_++];
+                e.out_offset = got + (e.out_offset - cur_off_);
+                ends->push_back(e);
+            }
+            push_tail(out + got, n);
+            got += n;
+            cur_off_ += n;
+            if (cur_off_ == cur_->size) {
+                pos_bit_ = cur_->end_bit;
+                if (cur_->last) finished_ = true;
+                release_current();
+            }
+        }
+        *produced = got;
+        *done = finished_ && !cur_;
+        return true;
+    }
+
+private:
+    struct Chunk {
+        std::mutex m;
+        std::condition_variable cv;
+        bool ready = false, found = false, corrupt = false, last = false;
+        uint64_t start_bit = 0, end_bit = 0;
+        uint16_t *data = nullptr;  // 32768 markers, then `size` symbols (malloc: grown without being cleared)
+        size_t cap = 0, size = 0;
+        std::vector<MemberEnd> ends;
+        ~Chunk() { free(data); }
+        void reserve(size_t n) {
+            if (n <= cap) return;
+            data = (uint16_t *)realloc(data, n * sizeof(uint16_t));
+            cap = n;
+        }
+    };
+    // symbol buffers go back to a pool instead of to the OS: fresh pages cost a fault and a clear each
+    std::mutex pool_m_;
+    std::vector<std::pair<uint16_t *, size_t>> pool_;
+    void take_buffer(Chunk &c) {
+        std::lock_guard<std::mutex> l(pool_m_);
+        if (!pool_.empty()) {
+            c.data = pool_.back().first;
+            c.cap = pool_.back().second;
+            pool_.pop_back();
+        }
+    }
+    void give_buffer(Chunk &c) {
+        if (!c.data) return;
+        std::lock_guard<std::mutex> l(pool_m_);
+        pool_.push_back({c.data, c.cap});
+        c.data = nullptr;
+        c.cap = 0;
+    }
+
+    const uint8_t *in_ = nullptr;
+    size_t n_in_ = 0, chunk_ = 0, n_chunks_ = 0;
+    std::vector<std::unique_ptr<Chunk>> chunks_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    size_t next_claim_ = 0, consumed_ = 0, max_ahead_ = 4;
+    bool stop_ = false;
+    // resolver state
+    std::unique_ptr<Chunk> own_;  // a chunk the resolver decoded itself (gap or wrong guess)
+    Chunk *cur_ = nullptr;
+    size_t cur_idx_ = 0, cur_off_ = 0, cur_end_ = 0, next_idx_ = 0;
+    uint64_t pos_bit_ = 0;
+    bool finished_ = false, first_ = true;
+    uint8_t tail_[32768];
+    size_t tail_n_ = 0;
+    uint8_t window_[32768];  // the 32 KiB in front of the current chunk
+    uint8_t lut_[65536];
+
+    static void fill_markers(uint16_t *v) {
+        for (int i = 0; i < 32768; i++) v[i] = (uint16_t)(0x8000 + i);
+    }
+
+    // decode from where `d` stands until it stops by itself (boundary behind stop_bit, end of stream, corruption)
+    void run(Dec &d, Chunk &c, uint64_t stop_bit) {
+        take_buffer(c);
+        c.reserve(32768 + ((size_t)4 << 20));
+        fill_markers(c.data);
+        d.stop_at_boundary_from(stop_bit);
+        size_t size = 0;
+        for (;;) {
+            if (c.cap - 32768 - size < ((size_t)1 << 20)) c.reserve(32768 + 2 * size + ((size_t)4 << 20));  // grow geometrically
+            const size_t room = c.cap - 32768 - size;
+            size_t p = 0;
+            const Dec::Status st = d.decode(c.data + 32768 + size, room, 32768 + size, &p);
+            for (int e = 0; e < d.n_member_ends(); e++) c.ends.push_back(d.member_ends()[e]);
+            d.clear_member_ends();
+            size += p;
+            if (st == Dec::NEED_OUTPUT) continue;
+            c.corrupt = st == Dec::CORRUPT;
+            c.last = st == Dec::DONE;
+            break;
+        }
+        c.size = size;
+        c.end_bit = d.bit_position();
+    }
+
+    // first position >= from_bit that looks like the start of a non-final dynamic block
+    bool find_start(uint64_t from_bit, uint64_t *found) const {
+        std::unique_ptr<Dec> d(new Dec());
+        std::vector<uint16_t> scratch(32768 + 65536);
+        fill_markers(scratch.data());
+        const uint64_t end_bit = (uint64_t)n_in_ * 8;
+        for (uint64_t p = from_bit; p + 160 < end_bit; p++) {
+            // cheap tests first (a candidate costs a full header parse otherwise): BFINAL = 0 and BTYPE = 2, at most 286
+            // literal/length and 30 distance codes, and a COMPLETE code-length code (Kraft sum exactly 1)
+            const size_t byte = (size_t)(p >> 3);
+            uint64_t w;
+            memcpy(&w, in_ + byte, 8);
+            w >>= (p & 7);  // >= 56 valid bits
+            if ((w & 7u) != 4u) continue;
+            if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+            const int hclen = (int)((w >> 13) & 15u) + 4;
+            {
+                // 3 bits per code length, hclen <= 19 of them from bit 17 on: 57 bits; the window has >= 56 - 17 = 39,
+                // so read them from a second load
+                uint64_t v[2];
+                memcpy(v, in_ + byte + 2, 16);
+                const int sh = (int)(p & 7) + 1;  // bit 17 of the header = bit 1 of byte + 2
+                const uint64_t lo = sh ? ((v[0] >> sh) | (v[1] << (64 - sh))) : v[0];
+                uint32_t kraft = 0;
+                int used = 0;
+                for (int q = 0; q < hclen; q++) {
+                    const uint32_t len = (uint32_t)(lo >> (3 * q)) & 7u;
+                    if (len) {
+                        kraft += 128u >> len;
+                        used++;
+                    }
+                }
+                if (kraft != 128u && !(used == 1)) continue;
+            }
+            const_cast<GsParallelGunzip *>(this)->n_candidates++;
+            d->init_at(in_, n_in_, p);
+            size_t prod = 0;
+            const Dec::Status st = d->decode(scratch.data() + 32768, 65536, 32768, &prod);
+            if (st == Dec::CORRUPT) continue;
+            *found = p;
+            return true;
+        }
+        return false;
+    }
+
+    void worker() {
+        std::unique_ptr<Dec> d(new Dec());
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || (next_claim_ < n_chunks_ && next_claim_ < consumed_ + max_ahead_); });
+                if (stop_ || next_claim_ >= n_chunks_) {
+                    if (stop_ || next_claim_ >= n_chunks_) {
+                        if (stop_) return;
+                        if (next_claim_ >= n_chunks_) return;
+                    }
+                }
+                i = next_claim_++;
+            }
+            Chunk &c = *chunks_[i];
+            const uint64_t stop_bit = (uint64_t)(i + 1) * chunk_ * 8;
+            if (i == 0) {
+                d->init(in_, n_in_, false);
+                c.found = true;
+                c.start_bit = 0;
+                run(*d, c, stop_bit);
+            } else {
+                uint64_t s = 0;
+                const auto t0 = std::chrono::steady_clock::now();
+                const bool ok = find_start((uint64_t)i * chunk_ * 8, &s);
+                const auto t1 = std::chrono::steady_clock::now();
+                ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+                if (ok) {
+                    c.found = true;
+                    c.start_bit = s;
+                    d->init_at(in_, n_in_, s);
+                    run(*d, c, stop_bit > s ? stop_bit : s + 1);
+                    ns_run += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+                }
+            }
+            {
+                std::lock_guard<std::mutex> l(c.m);
+                c.ready = true;
+            }
+            c.cv.notify_all();
+        }
+    }
+
+    // makes cur_ the chunk that continues at pos_bit_ (a worker's, if its guess fits, else one decoded here)
+    bool next_chunk() {
+        for (;;) {
+            if (next_idx_ >= n_chunks_) {
+                if (first_ && n_in_ == 0) return false;
+                // every worker chunk is used up or skipped but the stream has not ended: finish it here
+                return decode_here(~0ULL);
+            }
+            Chunk &c = *chunks_[next_idx_];
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                std::unique_lock<std::mutex> l(c.m);
+                c.cv.wait(l, [&] { return c.ready; });
+                ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+            }
+            if (!c.found || c.start_bit < pos_bit_ || (first_ && next_idx_ != 0)) {  // nothing usable in this chunk
+                n_dropped++;
+                drop(next_idx_++);
+                continue;
+            }
+            if (c.start_bit > pos_bit_) {  // a gap in front of it: decode up to its start here
+                if (!decode_here(c.start_bit)) return false;
+                return true;  // (cur_ is the gap chunk; the worker's chunk is looked at again afterwards)
+            }
+            if (c.corrupt) return false;
+            n_used++;
+            first_ = false;
+            cur_ = &c;
+            cur_idx_ = next_idx_++;
+            cur_off_ = cur_end_ = 0;
+            memcpy(window_, tail_, 32768);
+            build_lut();
+            if (cur_->size == 0) {  // nothing decoded (cannot happen for a valid start): treat as used up
+                pos_bit_ = cur_->end_bit;
+                const bool last = cur_->last;
+                release_current();
+                if (last) {
+                    finished_ = true;
+                    return true;
+                }
+                continue;
+            }
+            return true;
+        }
+    }
+
+    bool decode_here(uint64_t stop_bit) {
+        n_decoded_here++;
+        own_.reset(new Chunk());
+        std::unique_ptr<Dec> d(new Dec());
+        if (first_ && pos_bit_ == 0)
+            d->init(in_, n_in_, false);
+        else
+            d->init_at(in_, n_in_, pos_bit_);
+        run(*d, *own_, stop_bit);
+        if (own_->corrupt) return false;
+        first_ = false;
+        cur_ = own_.get();
+        cur_idx_ = (size_t)-1;
+        cur_off_ = cur_end_ = 0;
+        memcpy(window_, tail_, 32768);
+        build_lut();
+        if (cur_->size == 0) {
+            pos_bit_ = cur_->end_bit;
+            if (cur_->last) finished_ = true;
+            cur_ = nullptr;
+            own_.reset();
+        }
+        return true;
+    }
+
+    void drop(size_t idx) {
+        give_buffer(*chunks_[idx]);
+        {
+            std::lock_guard<std::mutex> l(m_);
+            consumed_ = idx + 1;
+        }
+        cv_.notify_all();
+    }
+
+    void release_current() {
+        if (cur_idx_ != (size_t)-1)
+            drop(cur_idx_);
+        else {
+            give_buffer(*own_);
+            own_.reset();
+        }
+        cur_ = nullptr;
+    }
+
+    // 16-bit symbols -> bytes.  In FASTQ nearly every record copies its header from the one before, so markers do not
+    // fade with the distance from the chunk start: every symbol goes through a 64 Ki-entry table built per chunk
+    // (bytes map to themselves, marker 0x8000 + i to byte i of the window in front of the chunk).
+    void build_lut() {
+        for (int i = 0; i < 256; i++) lut_[i] = (uint8_t)i;
+        memset(lut_ + 256, 0, 0x8000 - 256);
+        memcpy(lut_ + 0x8000, window_, 32768);
+    }
+    void resolve(const uint16_t *src, size_t n, uint8_t *dst) const {
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            dst[i] = lut_[src[i]];
+            dst[i + 1] = lut_[src[i + 1]];
+            dst[i + 2] = lut_[src[i + 2]];
+            dst[i + 3] = lut_[src[i + 3]];
+            dst[i + 4] = lut_[src[i + 4]];
+            dst[i + 5] = lut_[src[i + 5]];
+            dst[i + 6] = lut_[src[i + 6]];
+            dst[i + 7] = lut_[src[i + 7]];
+        }
+        for (; i < n; i++) dst[i] = lut_[src[i]];
+    }
+
+    // the window in front of the NEXT chunk: the last 32 KiB of everything delivered so far
+    void push_tail(const uint8_t *p, size_t n) {
+        if (n >= 32768) {
+            memcpy(tail_, p + n - 32768, 32768);
+            tail_n_ = 32768;
+        } else {
+            memmove(tail_, tail_ + n, 32768 - n);
+            memcpy(tail_ + 32768 - n, p, n);
+            tail_n_ = tail_n_ + n > 32768 ? 32768 : tail_n_ + n;
         }
     }
 };

@@ -286,7 +286,10 @@ struct TextSlot {
     int64_t last4[4] = {-1, -1, -1, -1};  // offsets of the last four newlines of the block, last first
     int state = 0;           // 0 empty, 1 full
     bool eof = false, io_error = false;
-    std::vector<std::pair<uint32_t, uint32_t>> member_ends;  // gzip input: (offset in the block, CRC-32 of the trailer)
+    struct GzEnd {
+        uint32_t offset, crc, isize;  // gzip input: a member ended at this offset of the block; CRC-32 / ISIZE of its trailer
+    };
+    std::vector<GzEnd> member_ends;
 };
 
 // page-locked blocks are expensive to create (the driver pins every page): the pipelines of one process reuse them
@@ -347,6 +350,8 @@ struct TextReader {
     const uint8_t *map = nullptr;
     size_t map_len = 0;
     uint32_t run_crc = 0;
+    uint64_t run_size = 0;
+    int gz_threads_hint = 0;
 
     int open(const std::string &path, size_t block_bytes, int readers, bool gzip) {
         if (gzip) {
@@ -363,6 +368,7 @@ struct TextReader {
                 madvise(m, map_len, MADV_SEQUENTIAL);
             }
             if (block_bytes < ((size_t)64 << 10)) block_bytes = (size_t)64 << 10;  // the 32 KiB window lives in the headroom
+            gz_threads_hint = readers;  // inflating threads behind the ONE thread that fills the blocks
             readers = 1;
         } else {
             fd = ::open(path.c_str(), O_RDONLY);
@@ -391,10 +397,23 @@ struct TextReader {
             end = q ? (size_t)((const uint8_t *)q - dst) : 0;
         }
     }
+    // gzip input: the stream is inflated by GsParallelGunzip (several threads, speculative starts inside the stream)
+    // when the machine has the cores, by one GsInflate otherwise; either way ONE thread hands the decoded bytes to
+    // the blocks in order.  member_ends carry (offset in the block, CRC-32, ISIZE) for the consumer's check.
     void start_gzip() {
-        threads.emplace_back([this] {
-            std::unique_ptr<GsInflate> inf(new GsInflate());
-            inf->init(map, map_len, false);
+        int gz_threads = gz_threads_hint > 0 ? gz_threads_hint : (int)std::min<unsigned>(8, std::thread::hardware_concurrency() / 2);
+        if (const char *e = getenv("GS_GZ_THREADS")) gz_threads = std::max(1, std::min(32, atoi(e)));
+        threads.emplace_back([this, gz_threads] {
+            std::unique_ptr<GsInflate> inf;
+            std::unique_ptr<GsParallelGunzip> par;
+            std::vector<GsParallelGunzip::MemberEnd> ends;
+            if (gz_threads >= 2 && map_len >= ((size_t)1 << 20)) {
+                par.reset(new GsParallelGunzip());
+                par->start(map, map_len, gz_threads, (size_t)1 << 20);
+            } else {
+                inf.reset(new GsInflate());
+                inf->init(map, map_len, false);
+            }
             std::vector<uint8_t> window(32768);
             size_t hist = 0;
             bool done = map_len == 0;
@@ -403,28 +422,41 @@ struct TextReader {
                 {
                     std::unique_lock<std::mutex> l(m);
                     cv.wait(l, [&] { return stop || sl.state == 0; });
-                    if (stop) return;
+                    if (stop) break;
                 }
                 uint8_t *dst = sl.buf + headroom;
-                memcpy(dst - hist, window.data() + (32768 - hist), hist);
                 size_t got = 0;
                 bool err = false;
                 sl.member_ends.clear();
-                while (!done && got < block) {
-                    size_t p = 0;
-                    const GsInflate::Status st = inf->decode(dst + got, block - got, hist + got, &p);
-                    const uint64_t block_start = (uint64_t)i * block;
-                    for (int e = 0; e < inf->n_member_ends(); e++)
-                        sl.member_ends.push_back({(uint32_t)(inf->member_ends()[e].out_offset - block_start), inf->member_ends()[e].crc});
-                    inf->clear_member_ends();
-                    got += p;
-                    if (st == GsInflate::CORRUPT) err = true;
-                    if (st != GsInflate::NEED_OUTPUT) done = true;
+                if (par) {
+                    while (!done && !err && got < block) {
+                        size_t p = 0;
+                        ends.clear();
+                        bool fin = false;
+                        if (!par->read(dst + got, block - got, &p, &ends, &fin)) err = true;
+                        for (const auto &e : ends) sl.member_ends.push_back({(uint32_t)(got + e.out_offset), e.crc, e.isize});
+                        got += p;
+                        if (fin) done = true;
+                        if (p == 0 && !fin && !err) err = true;  // (cannot happen: read() blocks until it has bytes)
+                    }
+                } else {
+                    memcpy(dst - hist, window.data() + (32768 - hist), hist);
+                    while (!done && got < block) {
+                        size_t p = 0;
+                        const GsInflate::Status st = inf->decode(dst + got, block - got, hist + got, &p);
+                        const uint64_t block_start = (uint64_t)i * block;
+                        for (int e = 0; e < inf->n_member_ends(); e++)
+                            sl.member_ends.push_back({(uint32_t)(inf->member_ends()[e].out_offset - block_start), inf->member_ends()[e].crc,
+                                                      inf->member_ends()[e].isize});
+                        inf->clear_member_ends();
+                        got += p;
+                        if (st == GsInflate::CORRUPT) err = true;
+                        if (st != GsInflate::NEED_OUTPUT) done = true;
+                    }
+                    const size_t keep = got < 32768 ? got : 32768;  // (a short block is the last one)
+                    if (keep == 32768) memcpy(window.data(), dst + got - 32768, 32768);
+                    hist = keep == 32768 ? 32768 : hist;
                 }
-                const size_t keep = got < 32768 ? got : 32768;  // (a short block is the last one)
-                if (keep == 32768)
-                    memcpy(window.data(), dst + got - 32768, 32768);
-                hist = keep == 32768 ? 32768 : hist;
                 sl.n = got;
                 sl.eof = got < block || done;
                 sl.io_error = err;
@@ -434,8 +466,9 @@ struct TextReader {
                     sl.state = 1;
                 }
                 cv.notify_all();
-                if (sl.eof || err) return;
+                if (sl.eof || err) break;
             }
+            if (par) par->stop();
         });
     }
     // consumer side: CRC-32 of the gzip members over the delivered block (GZIPInputStream checks it while reading)
@@ -444,12 +477,15 @@ struct TextReader {
         const uint8_t *p = sl.buf + headroom;
         size_t at = 0;
         for (const auto &me : sl.member_ends) {
-            run_crc = GsCrc32::update(run_crc, p + at, me.first - at);
-            if (run_crc != me.second) return false;
+            run_crc = GsCrc32::update(run_crc, p + at, me.offset - at);
+            run_size += me.offset - at;
+            if (run_crc != me.crc || (uint32_t)run_size != me.isize) return false;
             run_crc = 0;
-            at = me.first;
+            run_size = 0;
+            at = me.offset;
         }
         run_crc = GsCrc32::update(run_crc, p + at, sl.n - at);
+        run_size += sl.n - at;
         return true;
     }
     void start() {

@@ -52,6 +52,7 @@ def lib():
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
         "gs_host_gunzip": (ci, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]),
+        "gs_host_gunzip_parallel": (ci, [vp, C.c_size_t, vp, C.c_size_t, vp, ci, C.c_size_t, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -180,6 +181,16 @@ def gunzip(data, expected_size, block=1 << 20):
     n = C.c_size_t(0)
     _check(lib().gs_host_gunzip(src.ctypes.data_as(C.c_void_p) if len(src) else None, len(src), out.ctypes.data_as(C.c_void_p),
                                 int(expected_size), C.byref(n), int(block)))
+    return out[:n.value].tobytes()
+
+
+def gunzip_parallel(data, expected_size, threads=4, chunk=1 << 20, block=1 << 20):
+    """the multi-threaded gzip decoder of the text path on bytes (test hook)"""
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.empty(max(int(expected_size), 1), dtype=np.uint8)
+    n = C.c_size_t(0)
+    _check(lib().gs_host_gunzip_parallel(src.ctypes.data_as(C.c_void_p) if len(src) else None, len(src),
+                                         out.ctypes.data_as(C.c_void_p), int(expected_size), C.byref(n), int(threads), int(chunk), int(block)))
     return out[:n.value].tobytes()
 
 

@@ -105,6 +105,10 @@ const char *gs_host_last_error(void);
  * B/io/StreamProvider.java:92-100) on a memory range, `block` output bytes per decode call -- exposed for the tests:
  * out receives the concatenated members; GS_E_INVALID for a corrupt stream (CRC-32 and ISIZE are checked). */
 int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, size_t block);
+/* ... and through the multi-threaded decoder of the gzip text path (speculative starts inside the stream, checked and
+ * repaired by the in-order resolver): `threads` workers on compressed chunks of `chunk` bytes */
+int gs_host_gunzip_parallel(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, int threads,
+                            size_t chunk, size_t block);
 
 /* Double.toString(double) -- exposed for the tests of the CSV writer */
 int gs_host_java_double(double v, char *buf, int cap);

@@ -210,3 +210,22 @@ def test_gunzip_members_header_fields_and_corruption():
         host.gunzip(bytes(crc), len(a))                  # trailer CRC
     with pytest.raises(RuntimeError):
         host.gunzip(b"not a gzip stream at all", 100)
+
+
+@pytest.mark.parametrize("threads,chunk", [(1, 65536), (3, 65536), (4, 200_000), (8, 1 << 20)])
+def test_parallel_gunzip_equals_zlib(threads, chunk):
+    """speculative mid-stream starts, marker resolution and the in-order repair of wrong or missing guesses: the
+    multi-threaded decoder must deliver exactly zlib's bytes (and check CRC-32 / ISIZE) whatever the chunking"""
+    import zlib
+    d = _gz_inputs()
+    big = d["fastq"] * 6 + d["random"] * 3 + d["run"] + d["mixed"] * 4 + d["period 7"]
+    for level, strategy in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (0, 0), (6, zlib.Z_HUFFMAN_ONLY)):
+        assert host.gunzip_parallel(_gz(big, level, strategy), len(big), threads, chunk, 77_777) == big, (level, strategy)
+    members = _gz(d["fastq"] * 3, 6) + _gz(d["mixed"], 1) + _gz(b"", 6) + _gz(d["fastq"], 9)
+    assert host.gunzip_parallel(members, len(d["fastq"]) * 4 + len(d["mixed"]), threads, chunk) == d["fastq"] * 3 + d["mixed"] + d["fastq"]
+    raw = bytearray(_gz(big, 6))
+    raw[len(raw) // 3] ^= 4
+    with pytest.raises(RuntimeError):
+        host.gunzip_parallel(bytes(raw), len(big) + 100_000, threads, chunk)
+    with pytest.raises(RuntimeError):
+        host.gunzip_parallel(bytes(_gz(big, 6)[:-20]), len(big) + 100_000, threads, chunk)
