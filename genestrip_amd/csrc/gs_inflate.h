@@ -807,6 +807,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     size_t next_claim_ = 0, consumed_ = 0, max_ahead_ = 4;
+    size_t inflight_bytes_ = 0;  // symbol buffers of chunks that are decoded but not yet consumed (under m_)
     bool stop_ = false;
     // resolver state
     std::unique_ptr<Chunk> own_;  // a chunk the resolver decoded itself (gap or wrong guess)
@@ -898,13 +899,13 @@ private:
             size_t i;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return stop_ || (next_claim_ < n_chunks_ && next_claim_ < consumed_ + max_ahead_); });
-                if (stop_ || next_claim_ >= n_chunks_) {
-                    if (stop_ || next_claim_ >= n_chunks_) {
-                        if (stop_) return;
-                        if (next_claim_ >= n_chunks_) return;
-                    }
-                }
+                // not too far ahead of the resolver, neither in chunks nor in bytes (a chunk of highly compressible data
+                // can inflate a thousandfold: DEFLATE tops out at 1032:1)
+                cv_.wait(l, [&] {
+                    return stop_ || next_claim_ >= n_chunks_ ||
+                           (next_claim_ < consumed_ + max_ahead_ && (inflight_bytes_ < ((size_t)2 << 30) || next_claim_ == consumed_));
+                });
+                if (stop_ || next_claim_ >= n_chunks_) return;
                 i = next_claim_++;
             }
             Chunk &c = *chunks_[i];
@@ -927,6 +928,10 @@ private:
                     run(*d, c, stop_bit > s ? stop_bit : s + 1);
                     ns_run += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
                 }
+            }
+            {
+                std::lock_guard<std::mutex> l(m_);
+                inflight_bytes_ += c.size * sizeof(uint16_t);
             }
             {
                 std::lock_guard<std::mutex> l(c.m);
@@ -1012,6 +1017,8 @@ private:
         {
             std::lock_guard<std::mutex> l(m_);
             consumed_ = idx + 1;
+            const size_t b = chunks_[idx]->size * sizeof(uint16_t);
+            inflight_bytes_ = inflight_bytes_ > b ? inflight_bytes_ - b : 0;
         }
         cv_.notify_all();
     }
