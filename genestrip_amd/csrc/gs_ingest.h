@@ -379,8 +379,18 @@ struct TextReader {
         }
         block = block_bytes;
         headroom = block_bytes;
-        n_threads = readers;
-        n_slots = gzip ? 4 : 2 * readers;
+        // small files: no more readers and pinned blocks than the file has blocks (pinning memory is not free)
+        {
+            struct stat sb2;
+            const size_t fsize = fstat(fd, &sb2) == 0 ? (size_t)sb2.st_size : ~(size_t)0;
+            const size_t est = gzip ? fsize * 8 : fsize;  // (gzip: a generous guess of the text size)
+            const size_t n_blocks = est / block + 1;
+            if (!gzip && (size_t)readers > n_blocks) readers = (int)n_blocks;
+            n_threads = readers;
+            // block i lives in slot i % n_slots and is read by thread i % n_threads: n_slots must stay a multiple of
+            // n_threads, so that the blocks sharing a slot are filled by ONE thread, in order
+            n_slots = gzip ? 4 : 2 * readers;
+        }
         slots.resize((size_t)n_slots);
         for (auto &sl : slots) {
             int rc = pinned_pool().get(headroom + block, &sl.buf);

@@ -328,3 +328,22 @@ def test_match_files_corrupt_gzip_is_an_error(sdb, tmp_path):
         with pytest.raises(RuntimeError):
             host.match_files(store, [p])
     store.close()
+
+
+@pytest.mark.parametrize("readers", [1, 3, 4, 7])
+def test_match_files_few_blocks_many_readers(sdb, tmp_path, monkeypatch, readers):
+    """files with fewer blocks than reader threads, processed repeatedly (pinned blocks come back from the pool): block i
+    must always be the one the consumer gets for index i"""
+    data = b"".join(_fastq_bytes(sdb, 600, seed=47))
+    path = str(tmp_path / "few.fastq")
+    open(path, "wb").write(data)
+    want_t, want_tot = _oracle_file(sdb, data)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    monkeypatch.setenv("GS_HOST_READERS", str(readers))
+    for block in (len(data) // 5 + 7, len(data) // 2 + 3, len(data) + 100):
+        monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+        for _ in range(3):
+            t, _, tot = host.match_files(store, [path])
+            assert (tot.reads, tot.kmers, tot.bps) == want_tot
+            assert np.array_equal(t, want_t)
+    store.close()
