@@ -229,3 +229,31 @@ def test_parallel_gunzip_equals_zlib(threads, chunk):
         host.gunzip_parallel(bytes(raw), len(big) + 100_000, threads, chunk)
     with pytest.raises(RuntimeError):
         host.gunzip_parallel(bytes(_gz(big, 6)[:-20]), len(big) + 100_000, threads, chunk)
+
+
+def test_gunzip_survives_random_damage():
+    """random damage to the compressed bytes must end in an error (or, for bytes that do not matter such as the header's
+    timestamp, in the exact data) -- never in a crash, a hang or silently different data"""
+    import random
+    d = _gz_inputs()
+    data = d["fastq"][:200_000] + d["random"][:20_000] + d["fastq"][:100_000]
+    good = _gz(data, 6)
+    rnd = random.Random(99)
+    outcomes = {"error": 0, "same": 0}
+    for case in range(400):
+        raw = bytearray(good)
+        for _ in range(rnd.choice([1, 1, 1, 2, 5])):
+            pos = rnd.randrange(len(raw))
+            raw[pos] ^= 1 << rnd.randrange(8)
+        if rnd.random() < 0.1:
+            raw = raw[:rnd.randrange(len(raw))]
+        for fn in ((lambda b: host.gunzip(b, len(data) + 65536, 10_000)),
+                   (lambda b: host.gunzip_parallel(b, len(data) + 65536, 3, 65536, 50_000))):
+            try:
+                out = fn(bytes(raw))
+            except RuntimeError:
+                outcomes["error"] += 1
+                continue
+            assert out == data, case
+            outcomes["same"] += 1
+    assert outcomes["error"] > 600
