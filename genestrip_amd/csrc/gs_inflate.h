@@ -682,9 +682,10 @@ typedef GsInflateT<uint8_t> GsInflate;
 // stopped (a decoder stops at the first recognisable block start behind its chunk's end) and otherwise decodes the gap
 // itself, so a wrong or missing guess costs time, not correctness.  (The scheme is the one of pugz / rapidgzip.)
 // ---------------------------------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -696,12 +697,10 @@ public:
     typedef Dec::MemberEnd MemberEnd;
 
     ~GsParallelGunzip() { stop(); }
-    // diagnostics: chunks the resolver had to decode itself / worker chunks it could not use
+    // diagnostics: chunks the sequencer had to decode itself / worker chunks it could not use
     size_t n_decoded_here = 0, n_dropped = 0, n_used = 0;
-    std::atomic<uint64_t> ns_find{0}, ns_run{0}, n_candidates{0};
-    uint64_t ns_wait = 0, ns_resolve = 0;
 
-    void start(const uint8_t *in, size_t n_in, int n_threads, size_t chunk_bytes = (size_t)4 << 20) {
+    void start(const uint8_t *in, size_t n_in, int n_threads, size_t chunk_bytes = (size_t)1 << 20) {
         in_ = in;
         n_in_ = n_in;
         chunk_ = chunk_bytes < 65536 ? 65536 : chunk_bytes;
@@ -712,7 +711,8 @@ public:
         consumed_ = 0;
         max_ahead_ = (size_t)n_threads * 2 + 2;
         stop_ = false;
-        for (int t = 0; t < n_threads; t++) workers_.emplace_back([this] { worker(); });
+        for (int t = 0; t < n_threads; t++) threads_.emplace_back([this] { worker(); });
+        threads_.emplace_back([this] { sequencer(); });
     }
 
     void stop() {
@@ -721,47 +721,77 @@ public:
             stop_ = true;
         }
         cv_.notify_all();
-        for (auto &t : workers_) t.join();
-        workers_.clear();
+        q_cv_.notify_all();
+        for (auto &c : chunks_) c->cv.notify_all();
+        for (auto &t : threads_) t.join();
+        threads_.clear();
+        order_.clear();
         for (auto &b : pool_) free(b.first);
         pool_.clear();
     }
 
-    // the next bytes of the decoded stream, in order: up to cap bytes into out; member ends that fall into them are
-    // appended to `ends` with out_offset relative to `out`.  *done: the stream is complete; returns false on corruption.
+    // the next bytes of the decoded stream, in order: up to cap bytes into out.  CRC-32 and ISIZE of every member are
+    // checked here (from per-chunk checksums the workers computed, combined in stream order).  *done: the stream is
+    // complete; returns false on corruption.  ends (may be NULL): member ends inside these bytes, offsets relative to out.
     bool read(uint8_t *out, size_t cap, size_t *produced, std::vector<MemberEnd> *ends, bool *done) {
         size_t got = 0;
         *done = false;
+        *produced = 0;
         while (got < cap) {
             if (!cur_) {
-                if (finished_) break;
-                if (!next_chunk()) return false;
-                if (!cur_) {
-                    finished_ = true;
-                    break;
+                std::unique_lock<std::mutex> l(q_m_);
+                q_cv_.wait(l, [&] { return stop_flag() || !order_.empty() || seq_done_ || seq_error_; });
+                if (order_.empty()) {
+                    if (seq_error_) return false;
+                    if (seq_done_) {
+                        *done = true;
+                        break;
+                    }
+                    return false;  // stopped
+                }
+                cur_item_ = std::move(order_.front());
+                order_.pop_front();
+                l.unlock();
+                cur_ = cur_item_.c;
+                {
+                    std::unique_lock<std::mutex> lc(cur_->m);
+                    cur_->cv.wait(lc, [&] { return cur_->bytes_ready || stop_flag(); });
+                    if (!cur_->bytes_ready) return false;
+                }
+                cur_off_ = cur_end_ = 0;
+                // member checks: the chunk's segment checksums, combined with what earlier chunks left open
+                for (size_t k = 0; k < cur_->seg.size(); k++) {
+                    run_crc_ = (uint32_t)crc32_combine(run_crc_, cur_->seg[k].second, (z_off_t)cur_->seg[k].first);
+                    run_len_ += cur_->seg[k].first;
+                    if (k < cur_->ends.size()) {
+                        if (run_crc_ != cur_->ends[k].crc || (uint32_t)run_len_ != cur_->ends[k].isize) return false;
+                        run_crc_ = 0;
+                        run_len_ = 0;
+                    }
                 }
             }
-            const size_t avail = cur_->size - cur_off_;
-            const size_t n = avail < cap - got ? avail : cap - got;
-            const auto r0 = std::chrono::steady_clock::now();
-            resolve(cur_->data + 32768 + cur_off_, n, out + got);
-            ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r0).count();
+            const size_t n = std::min(cur_->size - cur_off_, cap - got);
+            memcpy(out + got, reinterpret_cast<const uint8_t *>(cur_->data + 32768) + cur_off_, n);
             while (cur_end_ < cur_->ends.size() && cur_->ends[cur_end_].out_offset <= cur_off_ + n) {
-                MemberEnd e = cur_->ends[cur_end_++];
-                e.out_offset = got + (e.out_offset - cur_off_);
-                ends->push_back(e);
+                if (ends) {
+                    MemberEnd e = cur_->ends[cur_end_];
+                    e.out_offset = got + (e.out_offset - cur_off_);
+                    ends->push_back(e);
+                }
+                cur_end_++;
             }
-            push_tail(out + got, n);
             got += n;
             cur_off_ += n;
             if (cur_off_ == cur_->size) {
-                pos_bit_ = cur_->end_bit;
-                if (cur_->last) finished_ = true;
-                release_current();
+                release(cur_item_);
+                cur_ = nullptr;
             }
         }
         *produced = got;
-        *done = finished_ && !cur_;
+        if (!cur_ && !*done) {  // the stream may just have ended
+            std::lock_guard<std::mutex> l(q_m_);
+            if (order_.empty() && seq_done_ && !seq_error_) *done = true;
+        }
         return true;
     }
 
@@ -769,11 +799,14 @@ private:
     struct Chunk {
         std::mutex m;
         std::condition_variable cv;
-        bool ready = false, found = false, corrupt = false, last = false;
+        bool ready = false, bytes_ready = false, found = false, corrupt = false, last = false;
         uint64_t start_bit = 0, end_bit = 0;
-        uint16_t *data = nullptr;  // 32768 markers, then `size` symbols (malloc: grown without being cleared)
+        uint16_t *data = nullptr;  // 32768 markers, then `size` symbols (malloc: grown without being cleared); after the
+                                   // resolve task the `size` BYTES of the chunk sit at the start of the symbol area
         size_t cap = 0, size = 0;
         std::vector<MemberEnd> ends;
+        std::vector<std::pair<uint64_t, uint32_t>> seg;  // (length, CRC-32) of the byte ranges between member ends
+        uint8_t window[32768];                           // the 32 KiB in front of the chunk
         ~Chunk() { free(data); }
         void reserve(size_t n) {
             if (n <= cap) return;
@@ -781,9 +814,41 @@ private:
             cap = n;
         }
     };
+    struct Item {
+        Chunk *c = nullptr;
+        std::unique_ptr<Chunk> own;  // a chunk the sequencer decoded itself (gap or wrong guess)
+        size_t idx = (size_t)-1;     // index in chunks_ (worker chunk)
+    };
+
+    const uint8_t *in_ = nullptr;
+    size_t n_in_ = 0, chunk_ = 0, n_chunks_ = 0;
+    std::vector<std::unique_ptr<Chunk>> chunks_;
+    std::vector<std::thread> threads_;
+    std::mutex m_;  // claims, tasks, in-flight accounting
+    std::condition_variable cv_;
+    size_t next_claim_ = 0, consumed_ = 0, max_ahead_ = 4;
+    size_t inflight_bytes_ = 0;  // symbol buffers of chunks that are decoded but not yet consumed
+    std::deque<Chunk *> tasks_;  // chunks whose window is known: symbols -> bytes + checksums
+    bool stop_ = false;
     // symbol buffers go back to a pool instead of to the OS: fresh pages cost a fault and a clear each
     std::mutex pool_m_;
     std::vector<std::pair<uint16_t *, size_t>> pool_;
+    // sequencer -> reader
+    std::mutex q_m_;
+    std::condition_variable q_cv_;
+    std::deque<Item> order_;
+    bool seq_done_ = false, seq_error_ = false;
+    // reader state
+    Item cur_item_;
+    Chunk *cur_ = nullptr;
+    size_t cur_off_ = 0, cur_end_ = 0;
+    uint32_t run_crc_ = 0;
+    uint64_t run_len_ = 0;
+
+    bool stop_flag() {
+        std::lock_guard<std::mutex> l(m_);
+        return stop_;
+    }
     void take_buffer(Chunk &c) {
         std::lock_guard<std::mutex> l(pool_m_);
         if (!pool_.empty()) {
@@ -799,27 +864,6 @@ private:
         c.data = nullptr;
         c.cap = 0;
     }
-
-    const uint8_t *in_ = nullptr;
-    size_t n_in_ = 0, chunk_ = 0, n_chunks_ = 0;
-    std::vector<std::unique_ptr<Chunk>> chunks_;
-    std::vector<std::thread> workers_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    size_t next_claim_ = 0, consumed_ = 0, max_ahead_ = 4;
-    size_t inflight_bytes_ = 0;  // symbol buffers of chunks that are decoded but not yet consumed (under m_)
-    bool stop_ = false;
-    // resolver state
-    std::unique_ptr<Chunk> own_;  // a chunk the resolver decoded itself (gap or wrong guess)
-    Chunk *cur_ = nullptr;
-    size_t cur_idx_ = 0, cur_off_ = 0, cur_end_ = 0, next_idx_ = 0;
-    uint64_t pos_bit_ = 0;
-    bool finished_ = false, first_ = true;
-    uint8_t tail_[32768];
-    size_t tail_n_ = 0;
-    uint8_t window_[32768];  // the 32 KiB in front of the current chunk
-    uint8_t lut_[65536];
-
     static void fill_markers(uint16_t *v) {
         for (int i = 0; i < 32768; i++) v[i] = (uint16_t)(0x8000 + i);
     }
@@ -865,12 +909,11 @@ private:
             if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
             const int hclen = (int)((w >> 13) & 15u) + 4;
             {
-                // 3 bits per code length, hclen <= 19 of them from bit 17 on: 57 bits; the window has >= 56 - 17 = 39,
-                // so read them from a second load
+                // 3 bits per code length, hclen <= 19 of them from bit 17 of the header on = bit (p & 7) + 1 of byte + 2
                 uint64_t v[2];
                 memcpy(v, in_ + byte + 2, 16);
-                const int sh = (int)(p & 7) + 1;  // bit 17 of the header = bit 1 of byte + 2
-                const uint64_t lo = sh ? ((v[0] >> sh) | (v[1] << (64 - sh))) : v[0];
+                const int sh = (int)(p & 7) + 1;
+                const uint64_t lo = (v[0] >> sh) | (v[1] << (64 - sh));
                 uint32_t kraft = 0;
                 int used = 0;
                 for (int q = 0; q < hclen; q++) {
@@ -882,7 +925,6 @@ private:
                 }
                 if (kraft != 128u && !(used == 1)) continue;
             }
-            const_cast<GsParallelGunzip *>(this)->n_candidates++;
             d->init_at(in_, n_in_, p);
             size_t prod = 0;
             const Dec::Status st = d->decode(scratch.data() + 32768, 65536, 32768, &prod);
@@ -893,20 +935,66 @@ private:
         return false;
     }
 
+    static void build_lut(const uint8_t *window, uint8_t *lut) {
+        for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+        memset(lut + 256, 0, 0x8000 - 256);
+        memcpy(lut + 0x8000, window, 32768);
+    }
+
+    // 16-bit symbols -> bytes, in place, plus the checksums of the ranges between member ends.  In FASTQ nearly every
+    // record copies its header from the one before, so markers do not fade with the distance from the chunk start:
+    // every symbol goes through a 64 Ki-entry table (bytes map to themselves, marker 0x8000 + i to byte i of the window).
+    void resolve_task(Chunk &c) {
+        std::unique_ptr<uint8_t[]> lut(new uint8_t[65536]);
+        build_lut(c.window, lut.get());
+        const uint16_t *src = c.data + 32768;
+        uint8_t *dst = reinterpret_cast<uint8_t *>(c.data + 32768);  // dst[i] is written after src[i] was read
+        const size_t n = c.size;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            const uint8_t b0 = lut[src[i]], b1 = lut[src[i + 1]], b2 = lut[src[i + 2]], b3 = lut[src[i + 3]];
+            const uint8_t b4 = lut[src[i + 4]], b5 = lut[src[i + 5]], b6 = lut[src[i + 6]], b7 = lut[src[i + 7]];
+            dst[i] = b0, dst[i + 1] = b1, dst[i + 2] = b2, dst[i + 3] = b3;
+            dst[i + 4] = b4, dst[i + 5] = b5, dst[i + 6] = b6, dst[i + 7] = b7;
+        }
+        for (; i < n; i++) dst[i] = lut[src[i]];
+        size_t at = 0;
+        for (const MemberEnd &e : c.ends) {
+            c.seg.push_back({e.out_offset - at, GsCrc32::update(0, dst + at, (size_t)e.out_offset - at)});
+            at = (size_t)e.out_offset;
+        }
+        c.seg.push_back({n - at, GsCrc32::update(0, dst + at, n - at)});
+        {
+            std::lock_guard<std::mutex> l(c.m);
+            c.bytes_ready = true;
+        }
+        c.cv.notify_all();
+    }
+
     void worker() {
         std::unique_ptr<Dec> d(new Dec());
         for (;;) {
-            size_t i;
+            Chunk *task = nullptr;
+            size_t i = 0;
             {
                 std::unique_lock<std::mutex> l(m_);
-                // not too far ahead of the resolver, neither in chunks nor in bytes (a chunk of highly compressible data
-                // can inflate a thousandfold: DEFLATE tops out at 1032:1)
+                // resolve tasks first; else decode a new chunk -- not too far ahead of the reader, neither in chunks
+                // nor in bytes (highly compressible data can inflate a thousandfold: DEFLATE tops out at 1032:1)
                 cv_.wait(l, [&] {
-                    return stop_ || next_claim_ >= n_chunks_ ||
-                           (next_claim_ < consumed_ + max_ahead_ && (inflight_bytes_ < ((size_t)2 << 30) || next_claim_ == consumed_));
+                    return stop_ || !tasks_.empty() ||
+                           (next_claim_ < n_chunks_ && next_claim_ < consumed_ + max_ahead_ &&
+                            (inflight_bytes_ < ((size_t)2 << 30) || next_claim_ == consumed_));
                 });
-                if (stop_ || next_claim_ >= n_chunks_) return;
-                i = next_claim_++;
+                if (stop_) return;
+                if (!tasks_.empty()) {
+                    task = tasks_.front();
+                    tasks_.pop_front();
+                } else
+                    i = next_claim_++;
+            }
+            if (task) {
+                resolve_task(*task);
+                continue;
             }
             Chunk &c = *chunks_[i];
             const uint64_t stop_bit = (uint64_t)(i + 1) * chunk_ * 8;
@@ -917,16 +1005,11 @@ private:
                 run(*d, c, stop_bit);
             } else {
                 uint64_t s = 0;
-                const auto t0 = std::chrono::steady_clock::now();
-                const bool ok = find_start((uint64_t)i * chunk_ * 8, &s);
-                const auto t1 = std::chrono::steady_clock::now();
-                ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-                if (ok) {
+                if (find_start((uint64_t)i * chunk_ * 8, &s)) {
                     c.found = true;
                     c.start_bit = s;
                     d->init_at(in_, n_in_, s);
                     run(*d, c, stop_bit > s ? stop_bit : s + 1);
-                    ns_run += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
                 }
             }
             {
@@ -941,130 +1024,127 @@ private:
         }
     }
 
-    // makes cur_ the chunk that continues at pos_bit_ (a worker's, if its guess fits, else one decoded here)
-    bool next_chunk() {
-        for (;;) {
-            if (next_idx_ >= n_chunks_) {
-                if (first_ && n_in_ == 0) return false;
-                // every worker chunk is used up or skipped but the stream has not ended: finish it here
-                return decode_here(~0ULL);
-            }
-            Chunk &c = *chunks_[next_idx_];
+    // puts the chunks into stream order: a worker's chunk is used if it starts exactly at the bit where the stream
+    // stands, gaps and wrong guesses are decoded here; hands every chunk its window and queues its resolve task
+    void sequencer() {
+        uint64_t pos_bit = 0;
+        bool first = true, finished = false, error = false;
+        std::vector<uint8_t> tail(32768, 0), lut(65536);
+        std::unique_ptr<Dec> d(new Dec());
+        auto accept = [&](Item item) {
+            Chunk &c = *item.c;
+            memcpy(c.window, tail.data(), 32768);
+            // the window of the NEXT chunk: the last 32 KiB of (window + this chunk's bytes)
+            const size_t t = c.size < 32768 ? c.size : 32768;
+            build_lut(c.window, lut.data());
+            if (t < 32768) memmove(tail.data(), tail.data() + t, 32768 - t);
+            const uint16_t *src = c.data + 32768 + (c.size - t);
+            uint8_t *dst = tail.data() + (32768 - t);
+            for (size_t q = 0; q < t; q++) dst[q] = lut[src[q]];
+            pos_bit = c.end_bit;
+            if (c.last) finished = true;
+            Chunk *cp = item.c;
             {
-                const auto w0 = std::chrono::steady_clock::now();
-                std::unique_lock<std::mutex> l(c.m);
-                c.cv.wait(l, [&] { return c.ready; });
-                ns_wait += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+                std::lock_guard<std::mutex> l(q_m_);
+                order_.push_back(std::move(item));
             }
-            if (!c.found || c.start_bit < pos_bit_ || (first_ && next_idx_ != 0)) {  // nothing usable in this chunk
-                n_dropped++;
-                drop(next_idx_++);
-                continue;
+            q_cv_.notify_all();
+            {
+                std::lock_guard<std::mutex> l(m_);
+                tasks_.push_back(cp);
             }
-            if (c.start_bit > pos_bit_) {  // a gap in front of it: decode up to its start here
-                if (!decode_here(c.start_bit)) return false;
-                return true;  // (cur_ is the gap chunk; the worker's chunk is looked at again afterwards)
+            cv_.notify_all();
+        };
+        auto decode_here = [&](uint64_t stop_bit) {
+            n_decoded_here++;
+            Item item;
+            item.own.reset(new Chunk());
+            item.c = item.own.get();
+            if (first && pos_bit == 0)
+                d->init(in_, n_in_, false);
+            else
+                d->init_at(in_, n_in_, pos_bit);
+            run(*d, *item.c, stop_bit);
+            first = false;
+            if (item.c->corrupt) {
+                error = true;
+                return;
             }
-            if (c.corrupt) return false;
-            n_used++;
-            first_ = false;
-            cur_ = &c;
-            cur_idx_ = next_idx_++;
-            cur_off_ = cur_end_ = 0;
-            memcpy(window_, tail_, 32768);
-            build_lut();
-            if (cur_->size == 0) {  // nothing decoded (cannot happen for a valid start): treat as used up
-                pos_bit_ = cur_->end_bit;
-                const bool last = cur_->last;
-                release_current();
-                if (last) {
-                    finished_ = true;
-                    return true;
+            if (item.c->size == 0 && !item.c->last) {  // (cannot happen: a decoder that does not stop makes progress)
+                pos_bit = item.c->end_bit;
+                give_buffer(*item.c);
+                return;
+            }
+            accept(std::move(item));
+        };
+        size_t idx = 0;
+        while (!finished && !error) {
+            if (stop_flag()) return;
+            if (idx >= n_chunks_) {
+                if (first && n_in_ == 0) {
+                    error = true;
+                    break;
                 }
+                decode_here(~0ULL);  // the worker chunks are used up but the stream has not ended
                 continue;
             }
-            return true;
+            Chunk &c = *chunks_[idx];
+            {
+                std::unique_lock<std::mutex> l(c.m);
+                c.cv.wait(l, [&] { return c.ready || stop_flag_unlocked(); });
+                if (!c.ready) return;
+            }
+            if (!c.found || c.start_bit < pos_bit || (first && idx != 0)) {  // nothing usable in this chunk
+                n_dropped++;
+                drop(idx++);
+                continue;
+            }
+            if (c.start_bit > pos_bit) {  // a gap in front of it: decode up to its start here, then look again
+                decode_here(c.start_bit);
+                continue;
+            }
+            if (c.corrupt) {
+                error = true;
+                break;
+            }
+            n_used++;
+            first = false;
+            Item item;
+            item.c = &c;
+            item.idx = idx++;
+            accept(std::move(item));
         }
+        {
+            std::lock_guard<std::mutex> l(q_m_);
+            seq_done_ = true;
+            seq_error_ = error;
+        }
+        q_cv_.notify_all();
     }
 
-    bool decode_here(uint64_t stop_bit) {
-        n_decoded_here++;
-        own_.reset(new Chunk());
-        std::unique_ptr<Dec> d(new Dec());
-        if (first_ && pos_bit_ == 0)
-            d->init(in_, n_in_, false);
-        else
-            d->init_at(in_, n_in_, pos_bit_);
-        run(*d, *own_, stop_bit);
-        if (own_->corrupt) return false;
-        first_ = false;
-        cur_ = own_.get();
-        cur_idx_ = (size_t)-1;
-        cur_off_ = cur_end_ = 0;
-        memcpy(window_, tail_, 32768);
-        build_lut();
-        if (cur_->size == 0) {
-            pos_bit_ = cur_->end_bit;
-            if (cur_->last) finished_ = true;
-            cur_ = nullptr;
-            own_.reset();
-        }
-        return true;
+    bool stop_flag_unlocked() {  // (called with a chunk's mutex held: m_ is a different lock)
+        std::lock_guard<std::mutex> l(m_);
+        return stop_;
     }
 
     void drop(size_t idx) {
         give_buffer(*chunks_[idx]);
         {
             std::lock_guard<std::mutex> l(m_);
-            consumed_ = idx + 1;
+            if (idx + 1 > consumed_) consumed_ = idx + 1;
             const size_t b = chunks_[idx]->size * sizeof(uint16_t);
             inflight_bytes_ = inflight_bytes_ > b ? inflight_bytes_ - b : 0;
         }
         cv_.notify_all();
     }
 
-    void release_current() {
-        if (cur_idx_ != (size_t)-1)
-            drop(cur_idx_);
-        else {
-            give_buffer(*own_);
-            own_.reset();
+    void release(Item &item) {
+        if (item.idx != (size_t)-1)
+            drop(item.idx);
+        else if (item.own) {
+            give_buffer(*item.own);
+            item.own.reset();
         }
-        cur_ = nullptr;
-    }
-
-    // 16-bit symbols -> bytes.  In FASTQ nearly every record copies its header from the one before, so markers do not
-    // fade with the distance from the chunk start: every symbol goes through a 64 Ki-entry table built per chunk
-    // (bytes map to themselves, marker 0x8000 + i to byte i of the window in front of the chunk).
-    void build_lut() {
-        for (int i = 0; i < 256; i++) lut_[i] = (uint8_t)i;
-        memset(lut_ + 256, 0, 0x8000 - 256);
-        memcpy(lut_ + 0x8000, window_, 32768);
-    }
-    void resolve(const uint16_t *src, size_t n, uint8_t *dst) const {
-        size_t i = 0;
-        for (; i + 8 <= n; i += 8) {
-            dst[i] = lut_[src[i]];
-            dst[i + 1] = lut_[src[i + 1]];
-            dst[i + 2] = lut_[src[i + 2]];
-            dst[i + 3] = lut_[src[i + 3]];
-            dst[i + 4] = lut_[src[i + 4]];
-            dst[i + 5] = lut_[src[i + 5]];
-            dst[i + 6] = lut_[src[i + 6]];
-            dst[i + 7] = lut_[src[i + 7]];
-        }
-        for (; i < n; i++) dst[i] = lut_[src[i]];
-    }
-
-    // the window in front of the NEXT chunk: the last 32 KiB of everything delivered so far
-    void push_tail(const uint8_t *p, size_t n) {
-        if (n >= 32768) {
-            memcpy(tail_, p + n - 32768, 32768);
-            tail_n_ = 32768;
-        } else {
-            memmove(tail_, tail_ + n, 32768 - n);
-            memcpy(tail_ + 32768 - n, p, n);
-            tail_n_ = tail_n_ + n > 32768 ? 32768 : tail_n_ + n;
-        }
+        item.c = nullptr;
     }
 };

@@ -443,8 +443,7 @@ struct TextReader {
                         size_t p = 0;
                         ends.clear();
                         bool fin = false;
-                        if (!par->read(dst + got, block - got, &p, &ends, &fin)) err = true;
-                        for (const auto &e : ends) sl.member_ends.push_back({(uint32_t)(got + e.out_offset), e.crc, e.isize});
+                        if (!par->read(dst + got, block - got, &p, nullptr, &fin)) err = true;  // (checks CRC-32 / ISIZE itself)
                         got += p;
                         if (fin) done = true;
                         if (p == 0 && !fin && !err) err = true;  // (cannot happen: read() blocks until it has bytes)
