@@ -329,10 +329,10 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         mgate.assign((size_t)1 << mgate_bits, 0);
         for (int64_t i = 0; i < ns; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }
-    gs_db *db = new gs_db();
-    db->device = device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    gs_db *db = new gs_db();
+    db->device = device;
     db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t tbytes = table.size() * sizeof(u64);
     hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
@@ -349,6 +349,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (e != hipSuccess) {
         hipFree(db->d_table);
         hipFree(db->d_gate);
+        hipFree(db->d_mgate);
         hipFree(db->d_tree);
         delete db;
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
@@ -467,6 +468,7 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     if (e != hipSuccess) {
         hipFree(db->d_table);
         hipFree(db->d_gate);
+        hipFree(db->d_mgate);
         hipFree(db->d_tree);
         delete db;
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));

@@ -417,6 +417,7 @@ struct TextJob {
             const int64_t rem = total & 3, usable = total - rem;
             last = sl.eof;
             if (err) {
+                // (the bank could not be selected: reported below)
             } else if (usable == 0) {  // not one whole record yet: keep everything
                 carry.insert(carry.end(), blk, blk + sl.n);
                 carry_lines = total;
