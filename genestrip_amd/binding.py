@@ -111,7 +111,7 @@ def lib():
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
-        "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, i64, vp, i64]),
+        "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
@@ -323,10 +323,10 @@ class FastqKMerMatcher:
                                    C.c_void_p(idx.data_ptr()), counts))
         return list(counts)
 
-    def unroute_nodes(self, idx, back, n_routed, nodes, n_keys):
-        _ready(idx, back, nodes)
-        _check(lib().gs_unroute_nodes(self.h, C.c_void_p(idx.data_ptr()), C.c_void_p(back.data_ptr()), n_routed,
-                                      C.c_void_p(nodes.data_ptr()), n_keys))
+    def unroute_nodes(self, keys, idx, back, n_routed, nodes, n_keys):
+        _ready(keys, idx, back, nodes)
+        _check(lib().gs_unroute_nodes(self.h, C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
+                                      C.c_void_p(back.data_ptr()), n_routed, C.c_void_p(nodes.data_ptr()), n_keys))
 
     def reduce(self, seq, offsets, pos_off, nodes, n_reads, first_read_no=0, class_vi=None, flags=None):
         _ready(seq, offsets, pos_off, nodes, class_vi, flags)

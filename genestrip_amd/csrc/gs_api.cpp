@@ -202,7 +202,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- keys
     std::vector<u64> hkey;
     std::vector<int32_t> hval;
-    std::vector<uint32_t> hmin;  // minimizer order hash per stored key (k >= GS_MIN_K)
+    std::vector<uint32_t> hmin;  // minimizer order hash per reachable key of ANY partition (k >= GS_MIN_K)
     hkey.reserve((size_t)n);
     hval.reserve((size_t)n);
     bool want_mgate = k >= GS_MIN_K;
@@ -233,14 +233,16 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 if (!reachable || parent[vidx[i]] == -2) continue;
                 gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
                 const u64 hk = gs_mix_planes(phi, plo);
-                if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
-                o.h.push_back(hk);
-                o.v.push_back(vidx[i]);
+                // the minimizer gate of a partition covers the keys of ALL partitions: the rank that encodes a read
+                // (gs_match_encode) uses it to decide which k-mers are worth routing to their owner at all
                 if (want_mgate) {  // strand symmetric: either orientation gives the same minimizer
                     uint32_t m = 0xffffffffu;
                     for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
                     o.m.push_back(m);
                 }
+                if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
+                o.h.push_back(hk);
+                o.v.push_back(vidx[i]);
             }
         };
         if (n_thr == 1) {
@@ -311,23 +313,24 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- minimizer gate (gs_layout.h): 16-32 bits per DISTINCT minimizer, 2 bits set per entry, 32-bit words
     std::vector<uint32_t> mgate;
     int mgate_bits = 0;
-    if (want_mgate && ns > 0) {
+    const int64_t nm = (int64_t)hmin.size();
+    if (want_mgate && nm > 0) {
         // size by the number of DISTINCT minimizers, estimated by linear counting on a 2^26-bit sketch (a sort of
         // the 32-bit hashes costs seconds for tens of millions of keys; +-1 % is plenty for a power-of-two size)
         const size_t sketch_bits = (size_t)1 << 26;
         std::vector<u64> sketch(sketch_bits / 64, 0);
-        for (int64_t i = 0; i < ns; i++) {
+        for (int64_t i = 0; i < nm; i++) {
             const uint32_t x = hmin[(size_t)i] * 0x9E3779B1u;  // (the hash is a bijection of the 15-mer: no extra collisions)
             sketch[(x >> 6) & (sketch.size() - 1)] |= 1ULL << (x & 63);
         }
         size_t ones = 0;
         for (u64 w : sketch) ones += (size_t)__builtin_popcountll(w);
         const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
-        const double distinct = std::min((double)ns, -(double)sketch_bits * std::log(zero_frac));
+        const double distinct = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
         mgate_bits = 6;
         while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < distinct * 16.0) mgate_bits++;
         mgate.assign((size_t)1 << mgate_bits, 0);
-        for (int64_t i = 0; i < ns; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
+        for (int64_t i = 0; i < nm; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -392,7 +395,7 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE3"
+    char magic[8];  // "GSSTORE4"
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
@@ -404,7 +407,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) {
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE3", 8);
+    memcpy(h.magic, "GSSTORE4", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
@@ -436,7 +439,7 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE3", 8) != 0 || h.info.n_values < 1 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE4", 8) != 0 || h.info.n_values < 1 ||
         h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25 ||
         (h.mgate_words & (h.mgate_words - 1)) != 0 || h.mgate_words > ((uint64_t)1 << 30)) {
         fclose(f);
@@ -1102,6 +1105,8 @@ extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *
     P.n_reads = n_reads;
     P.pos_off = (const unsigned long long *)pos_off;
     P.keys = (unsigned long long *)keys;
+    P.mgate = run->db->dev.mgate;
+    P.mgate_bits = run->db->dev.mgate_bits;
     int grid = (int)std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4);
     if (grid < 1) grid = 1;
     HIP_TRY(gs_launch_encode(&P, grid, run->stream));
@@ -1132,7 +1137,7 @@ extern "C" int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *
 extern "C" hipError_t gs_launch_route_count(const u64 *keys, int64_t n, int n_parts, u64 *counts, hipStream_t stream);
 extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_parts, u64 *cursors, u64 *send_keys,
                                                uint32_t *idx, hipStream_t stream);
-extern "C" hipError_t gs_launch_unroute(const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
+extern "C" hipError_t gs_launch_unroute(const u64 *keys, const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
                                          int64_t n_keys, hipStream_t stream);
 
 // groups the valid keys by owner rank (counting sort on the device); counts[n_parts] is a HOST array
@@ -1169,12 +1174,13 @@ extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, 
 }
 
 // inverse of gs_route_keys for the nodes that came back: nodes[idx[i]] = back[i]; unrouted positions read -2
-extern "C" int gs_unroute_nodes(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
-                                int64_t n_keys) {
-    if (!run || (n_keys > 0 && !nodes) || (n_routed > 0 && (!idx || !back))) return fail(GS_E_INVALID, "bad argument");
+extern "C" int gs_unroute_nodes(gs_run *run, const uint64_t *keys, const uint32_t *idx, const int32_t *back,
+                                int64_t n_routed, int32_t *nodes, int64_t n_keys) {
+    if (!run || (n_keys > 0 && (!nodes || !keys)) || (n_routed > 0 && (!idx || !back)))
+        return fail(GS_E_INVALID, "bad argument");
     if (n_keys <= 0) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
-    HIP_TRY(gs_launch_unroute(idx, back, n_routed, nodes, n_keys, run->stream));
+    HIP_TRY(gs_launch_unroute((const u64 *)keys, idx, back, n_routed, nodes, n_keys, run->stream));
     return GS_OK;
 }
 

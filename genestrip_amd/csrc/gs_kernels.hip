@@ -845,39 +845,109 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
 
 // ---------------------------------------------------------------------------------------------------
 // DB-partitioned mode: the fused kernel is split into
-//   gs_encode_kernel      reads -> mixed key h of every k-mer position (GS_KEY_INVALID for windows with a bad base)
+//   gs_encode_kernel      reads -> mixed key h of every k-mer position (GS_KEY_INVALID for windows with a bad base,
+//                         GS_KEY_MISS for k-mers the store-wide minimizer gate rules out)
 //   gs_probe_keys_kernel  keys -> node (value index / miss), run by the rank that OWNS the key's table partition
 //   gs_match_kernel<.., FROM_NODES = true>   per-read reduce over the routed-back node stream
 // with two all-to-all exchanges in between (genestrip_amd/distributed.py).
 // ---------------------------------------------------------------------------------------------------
 #define GS_KEY_INVALID (~0ULL)
+#define GS_KEY_MISS (~0ULL - 1)  // the minimizer gate already says "not stored": never routed, node = MISS
+#define GS_KEY_ROUTED(h) ((h) < GS_KEY_MISS)
 
+template <int KC>
 __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
+    __shared__ uint32_t s_g[GS_BLOCK / 64][160];  // 15-mer order hashes of the wave's current 128 + 16 positions
     const int lane = gs_lane();
+    uint32_t *wave_g = s_g[threadIdx.x >> 6];
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
-    const int k = P.k;
+    const int k = KC ? KC : P.k;  // KC = compile-time k (0: any k)
     const uint32_t kmask = (1u << k) - 1u;
+    const int w = k - GS_MIN_L + 1;
+    // software pipeline over the wave's reads: the first 192 bases of the next read are loaded while the current
+    // one is hashed (a read is a chain of dependent loads: offsets -> bases -> gate word)
+    u64 off = 0, pb = 0;
+    int L = 0;
+    uint32_t c[3] = {0, 0, 0};
+    if (wave_id < P.n_reads) {
+        off = P.off[wave_id];
+        L = (int)(P.off[wave_id + 1] - off);
+        pb = P.pos_off[wave_id];
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] = 64 * i + lane < L ? P.seq[off + 64 * i + lane] : 0u;
+    }
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
-        const u64 off = P.off[r];
-        const int L = (int)(P.off[r + 1] - off);
         const int max = L - k + 1;
         const uint8_t *rd = P.seq + off;
-        const u64 pb = P.pos_off[r];
-        u64 hi0, lo0, bad0;
-        if (max > 0) gs_load_word(rd, L, 0, lane, hi0, lo0, bad0);
-        for (int round = 0; round * 64 < max; round++) {
-            u64 hi1, lo1, bad1;
-            gs_load_word(rd, L, round + 1, lane, hi1, lo1, bad1);
-            const int p = 64 * round + lane;
-            const uint32_t fhi = (uint32_t)gs_funnel(hi0, hi1, lane) & kmask;
-            const uint32_t flo = (uint32_t)gs_funnel(lo0, lo1, lane) & kmask;
-            const uint32_t wbad = (uint32_t)gs_funnel(bad0, bad1, lane) & kmask;
-            if (p < max) P.keys[pb + (u64)p] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi, flo, k, kmask);
-            hi0 = hi1;
-            lo0 = lo1;
-            bad0 = bad1;
+        const int64_t rn = r + n_waves;
+        u64 offN = 0, pbN = 0;
+        int LN = 0;
+        if (rn < P.n_reads) {
+            offN = P.off[rn];
+            LN = (int)(P.off[rn + 1] - offN);
+            pbN = P.pos_off[rn];
         }
+        uint32_t cN[3] = {0, 0, 0};
+        for (int base = 0; base < max || base == 0; base += 128) {
+            u64 Bhi[3], Blo[3], Bbad[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                if (base == 0)
+                    gs_word_from_byte(c[i], 64 * i + lane < L, Bhi[i], Blo[i], Bbad[i]);
+                else
+                    gs_load_word(rd, L, (base >> 6) + i, lane, Bhi[i], Blo[i], Bbad[i]);
+            }
+            if (base == 0 && rn < P.n_reads) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) cN[i] = 64 * i + lane < LN ? P.seq[offN + 64 * i + lane] : 0u;
+            }
+            if (max <= 0) break;
+            u64 key[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+                const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+                const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
+                key[s] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi, flo, k, kmask);
+                if (P.mgate != nullptr) wave_g[64 * s + lane] = gs_lmer_hash(fhi & 0x7fffu, flo & 0x7fffu);
+            }
+            if (P.mgate != nullptr) {
+                // the store's minimizer gate (which covers the keys of every partition) as in gs_probe_planes: k-mers
+                // it rules out are not routed at all
+                if (lane < 16)
+                    wave_g[128 + lane] = gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    uint32_t mn = 0xffffffffu;
+#pragma unroll
+                    for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
+                        if (KC || d < w) {
+                            const uint32_t g = wave_g[64 * s + lane + d];
+                            mn = g < mn ? g : mn;
+                        }
+                    }
+                    if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
+                        const uint32_t bits = gs_mgate_bits(mn);
+                        if ((P.mgate[gs_mgate_word(mn, P.mgate_bits)] & bits) != bits) key[s] = GS_KEY_MISS;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int p = base + 64 * s + lane;
+                if (p < max) P.keys[pb + (u64)p] = key[s];
+            }
+        }
+        off = offN;
+        L = LN;
+        pb = pbN;
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] = cN[i];
     }
 }
 
@@ -892,7 +962,7 @@ __global__ __launch_bounds__(256) void gs_route_count_kernel(const u64 *keys, in
     for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; base < n; base += stride) {
         const int64_t i = base + lane;
         const u64 h = i < n ? keys[i] : GS_KEY_INVALID;
-        const int owner = h != GS_KEY_INVALID ? (int)((h >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+        const int owner = GS_KEY_ROUTED(h) ? (int)((h >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
         u64 todo = __ballot(owner >= 0);
         while (todo) {  // one LDS atomic per wave and distinct owner
             const int o = gs_readlane(owner, __builtin_ctzll(todo));
@@ -924,7 +994,7 @@ __global__ __launch_bounds__(256) void gs_route_scatter_kernel(const u64 *keys, 
         for (int j = 0; j < GS_ROUTE_T; j++) {
             const int64_t i = t0 + (int64_t)j * 256 + threadIdx.x;
             h[j] = i < n ? keys[i] : GS_KEY_INVALID;
-            owner[j] = h[j] != GS_KEY_INVALID ? (int)((h[j] >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+            owner[j] = GS_KEY_ROUTED(h[j]) ? (int)((h[j] >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
             lp[j] = 0;
             u64 todo = __ballot(owner[j] >= 0);
             while (todo) {
@@ -953,11 +1023,12 @@ __global__ __launch_bounds__(256) void gs_route_scatter_kernel(const u64 *keys, 
     }
 }
 
-__global__ __launch_bounds__(256) void gs_unroute_kernel(const uint32_t *idx, const int32_t *back, int64_t n_routed,
-                                                        int32_t *nodes, int64_t n_keys, int phase) {
+__global__ __launch_bounds__(256) void gs_unroute_kernel(const u64 *keys, const uint32_t *idx, const int32_t *back,
+                                                        int64_t n_routed, int32_t *nodes, int64_t n_keys, int phase) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (phase == 0)  // every position starts as INVALID (windows with a bad base are never routed)
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) nodes[i] = GS_NODE_INVALID;
+    if (phase == 0)  // positions that were never routed: windows with a bad base, k-mers the gate ruled out
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride)
+            nodes[i] = keys[i] == GS_KEY_MISS ? GS_NODE_MISS : GS_NODE_INVALID;
     else
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_routed; i += stride) nodes[idx[i]] = back[i];
 }
@@ -970,8 +1041,8 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
     const uint32_t bmask = (uint32_t)db.bucket_mask;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const u64 h = keys[i];
-        int node = GS_NODE_INVALID;
-        if (h != GS_KEY_INVALID) {
+        int node = h == GS_KEY_MISS ? GS_NODE_MISS : GS_NODE_INVALID;
+        if (GS_KEY_ROUTED(h)) {
             node = GS_NODE_MISS;
             bool cand = true;
             if (db.gate != nullptr) {
@@ -1411,7 +1482,10 @@ extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, 
 }
 
 extern "C" hipError_t gs_launch_encode(const GsEncodeParams *P, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(gs_encode_kernel, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    if (P->k == 31)
+        hipLaunchKernelGGL(gs_encode_kernel<31>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    else
+        hipLaunchKernelGGL(gs_encode_kernel<0>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     return hipGetLastError();
 }
 
@@ -1433,13 +1507,13 @@ extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_
     return hipGetLastError();
 }
 
-extern "C" hipError_t gs_launch_unroute(const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
-                                         int64_t n_keys, hipStream_t stream) {
-    hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_keys)), dim3(256), 0, stream, idx, back, n_routed, nodes,
-                       n_keys, 0);
+extern "C" hipError_t gs_launch_unroute(const u64 *keys, const uint32_t *idx, const int32_t *back, int64_t n_routed,
+                                         int32_t *nodes, int64_t n_keys, hipStream_t stream) {
+    hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_keys)), dim3(256), 0, stream, keys, idx, back, n_routed,
+                       nodes, n_keys, 0);
     if (n_routed > 0)
-        hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_routed)), dim3(256), 0, stream, idx, back, n_routed,
-                           nodes, n_keys, 1);
+        hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_routed)), dim3(256), 0, stream, keys, idx, back,
+                           n_routed, nodes, n_keys, 1);
     return hipGetLastError();
 }
 

@@ -98,5 +98,9 @@ struct GsEncodeParams {
     const uint64_t *off;
     int64_t n_reads;
     const unsigned long long *pos_off;  // n_reads + 1 (exclusive prefix of max(0, L-k+1))
-    unsigned long long *keys;           // gs_mix62(canonical planar key), ~0 for windows with a non-CGAT base
+    unsigned long long *keys;           // gs_mix62(canonical planar key), ~0 for windows with a non-CGAT base,
+                                        // ~0 - 1 for k-mers the minimizer gate rules out
+    const uint32_t *mgate;              // the store's minimizer gate (covers every partition's keys) or NULL
+    uint32_t mgate_bits;
+    uint32_t pad2;
 };

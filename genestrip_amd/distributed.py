@@ -111,6 +111,8 @@ def shard_bounds(n_total, rank, world):
 # ---------------------------------------------------------------------------------------------------------------
 OWNER_SHIFT = 40          # genestrip_amd/csrc/gs_layout.h: GS_OWNER_SHIFT
 KEY_INVALID = -1          # ~0 as int64: window with a non-CGAT base, never routed
+KEY_MISS = -2             # ~0 - 1: the store-wide minimizer gate rules the k-mer out, never routed (node = miss)
+NODE_MISS = -1
 NODE_INVALID = -2
 
 
@@ -124,10 +126,11 @@ def position_offsets(offsets, k):
 
 
 def plan_routing(keys, world):
-    """keys: int64 tensor of mixed keys (KEY_INVALID for invalid windows).
+    """keys: int64 tensor of mixed keys (KEY_INVALID for invalid windows, KEY_MISS for gate-rejected k-mers; real
+    keys are < 2^62, i.e. non-negative).
     Returns (idx, send_keys, counts): idx = positions of the routed keys in owner-sorted order, send_keys =
     keys[idx] (grouped by owner rank, ascending), counts[j] = number of keys going to rank j."""
-    valid = keys != KEY_INVALID
+    valid = keys >= 0
     idx_valid = torch.nonzero(valid, as_tuple=False).flatten()
     owner = (keys[idx_valid] >> OWNER_SHIFT) % world
     order = torch.argsort(owner, stable=True)
@@ -136,9 +139,12 @@ def plan_routing(keys, world):
     return idx, keys[idx].contiguous(), counts
 
 
-def scatter_nodes(nodes_sorted, idx, n_keys):
-    """inverse of plan_routing for the returned nodes; unrouted (invalid) positions read NODE_INVALID"""
+def scatter_nodes(nodes_sorted, idx, n_keys, keys=None):
+    """inverse of plan_routing for the returned nodes; unrouted positions read NODE_INVALID, or NODE_MISS where
+    keys (the tensor plan_routing saw) holds KEY_MISS"""
     nodes = torch.full((n_keys,), NODE_INVALID, dtype=torch.int32, device=nodes_sorted.device)
+    if keys is not None:
+        nodes[keys[:n_keys] == KEY_MISS] = NODE_MISS
     nodes[idx] = nodes_sorted
     return nodes
 
@@ -179,7 +185,7 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
     back, _ = exchange_all_to_all(recv_nodes[:recv_keys.numel()].contiguous(), recv_counts, group)
     nodes = torch.empty(max(n_keys, 1), dtype=torch.int32, device=seq.device)
     torch.cuda.synchronize(seq.device)
-    matcher.unroute_nodes(idx, back, n_routed, nodes, n_keys)
+    matcher.unroute_nodes(keys, idx, back, n_routed, nodes, n_keys)
     matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
     matcher.sync()
 

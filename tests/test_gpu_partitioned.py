@@ -30,6 +30,8 @@ def _reads(sdb, n):
         seq[int(off[r]) + int(rng.integers(0, 150))] = ord("N")
     # ragged tail: short, long and empty reads
     extra = [b"", b"ACGT", bytes(sdb.genomes[1][:31]), bytes(sdb.genomes[2][100:900]), bytes(sdb.genomes[0][:40]) + b"N" * 3]
+    # reads from elsewhere: almost all of their k-mers are ruled out by the minimizer gate and never routed
+    extra += [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(ln))) for ln in rng.integers(31, 400, 300)]
     eseq, eoff = orc.pack_reads(extra)
     seq = np.concatenate([seq, eseq])
     off = np.concatenate([off, off[-1] + eoff[1:]])
@@ -76,12 +78,14 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
         doff = torch.from_numpy((off[lo:hi + 1] - off[lo]).astype(np.int64)).to(dev)
         shard.append((dseq, doff, hi - lo, lo))
     plans = []
+    n_gated = 0
     for r, (dseq, doff, nr, lo) in enumerate(shard):
         pos_off = gd.position_offsets(doff, 31)
         nk = int(pos_off[-1].item())
         keys = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
         ms[r].encode(dseq, doff, pos_off, keys, nr)
         ms[r].sync()
+        n_gated += int((keys[:nk] == gd.KEY_MISS).sum().item())
         if device_routing:  # gs_route_keys: counting sort on the device
             send = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
             idx = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
@@ -92,7 +96,8 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
         else:               # the same step with torch ops
             idx, send, counts = gd.plan_routing(keys[:nk], world)
             counts = counts.cpu().numpy()
-        plans.append((pos_off, nk, idx, send, counts))
+        plans.append((pos_off, nk, idx, send, counts, keys))
+    assert n_gated > 30000  # the foreign reads' k-mers (about 55 k) stop at the gate of the encoding rank
     # all-to-all #1: keys to their owners
     starts = [np.concatenate([[0], np.cumsum(p[4])]) for p in plans]
     node_back = [[None] * world for _ in range(world)]
@@ -109,13 +114,13 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
             o += c
     tables, cvs, fls = [], [], []
     for r, (dseq, doff, nr, lo) in enumerate(shard):
-        pos_off, nk, idx, _, _ = plans[r]
+        pos_off, nk, idx, _, _, keys = plans[r]
         back = torch.cat(node_back[r])
         if device_routing:
             nodes = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
-            ms[r].unroute_nodes(idx, back, back.numel(), nodes, nk)
+            ms[r].unroute_nodes(keys, idx, back, back.numel(), nodes, nk)
         else:
-            nodes = gd.scatter_nodes(back, idx, max(nk, 1))
+            nodes = gd.scatter_nodes(back, idx, max(nk, 1), keys)
         cv = torch.full((max(nr, 1),), -1, dtype=torch.int32, device=dev)
         fl = torch.zeros(max(nr, 1), dtype=torch.uint8, device=dev)
         ms[r].reduce(dseq, doff, pos_off, nodes, nr, first_read_no=lo, class_vi=cv, flags=fl)
