@@ -9,55 +9,22 @@ using namespace gs_host;
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------------
-// output helper: plain or gzip by suffix (StreamProvider.getOutputStreamForFile)
-// ---------------------------------------------------------------------------------------------------
-class OutFile {
-public:
-    bool open(const char *path) {
-        if (!path) return true;
-        if (is_gzip_name(path)) {
-            gz_ = gzopen(path, "wb1");
-            return gz_ != nullptr;
-        }
-        f_ = fopen(path, "wb");
-        return f_ != nullptr;
-    }
-    bool active() const { return gz_ || f_; }
-    void write(const void *p, size_t n) {
-        if (gz_)
-            gzwrite(gz_, p, (unsigned)n);
-        else if (f_)
-            fwrite(p, 1, n, f_);
-    }
-    void put(char c) { write(&c, 1); }
-    ~OutFile() {
-        if (gz_) gzclose(gz_);
-        if (f_) fclose(f_);
-    }
-
-private:
-    gzFile gz_ = nullptr;
-    FILE *f_ = nullptr;
-};
-
-// ReadEntry.write (AbstractFastqReader.java:570-584); qualities are '~' x L unless with_probs and present
-void write_read(OutFile &out, const Batch &b, int64_t i, bool with_probs, std::vector<uint8_t> &tmp) {
-    tmp.clear();
+// ReadEntry.write (AbstractFastqReader.java:570-584) appended to `buf`; qualities are '~' x L unless with_probs and
+// present
+void append_read(std::vector<uint8_t> &buf, const Batch &b, int64_t i, bool with_probs) {
     const size_t d0 = b.desc_off[i], d1 = b.desc_off[i + 1], s0 = b.seq_off[i], s1 = b.seq_off[i + 1];
-    tmp.insert(tmp.end(), b.desc.begin() + (long)d0, b.desc.begin() + (long)d1);
-    tmp.push_back('\n');
-    tmp.insert(tmp.end(), b.seq.begin() + (long)s0, b.seq.begin() + (long)s1);
-    tmp.push_back('\n');
-    tmp.push_back('+');
-    tmp.push_back('\n');
+    buf.insert(buf.end(), b.desc.begin() + (long)d0, b.desc.begin() + (long)d1);
+    buf.push_back('\n');
+    buf.insert(buf.end(), b.seq.begin() + (long)s0, b.seq.begin() + (long)s1);
+    buf.push_back('\n');
+    buf.push_back('+');
+    buf.push_back('\n');
     const size_t q0 = b.qual_off[i], q1 = b.qual_off[i + 1];
     if (with_probs && q1 > q0)
-        tmp.insert(tmp.end(), b.qual.begin() + (long)q0, b.qual.begin() + (long)q1);
+        buf.insert(buf.end(), b.qual.begin() + (long)q0, b.qual.begin() + (long)q1);
     else
-        tmp.insert(tmp.end(), s1 - s0, (uint8_t)'~');
-    tmp.push_back('\n');
-    out.write(tmp.data(), tmp.size());
+        buf.insert(buf.end(), s1 - s0, (uint8_t)'~');
+    buf.push_back('\n');
 }
 
 // bounded producer/consumer hand-off of parsed batches (depth 2: parse i+1 while the GPU works on i)
@@ -230,10 +197,12 @@ struct MatchCtx {
     const gs_host_match_opts *opts = nullptr;
     OutFile filtered, kraken;
     std::vector<int32_t> cls, seg_code, seg_start;
-    std::vector<uint8_t> flags, tmp;
+    std::vector<uint8_t> flags;
     std::vector<uint64_t> seg_off;
-    std::string line;
-    std::vector<uint8_t> out_buf, flt_buf, nl_bytes;  // Kraken lines / filtered records of one batch, written in one go
+    std::vector<uint8_t> nl_bytes;
+    FormatPool pool{format_threads()};  // the per-read writers format a batch on these threads
+    std::vector<uint32_t> taxid_len;    // strlen of opts->taxids[vi] (Kraken-style lines)
+    size_t taxid_max = 1;
     int64_t global_read_no = 0, filtered_reads = 0;  // read numbers run over all files of the call (file order)
     int64_t reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
@@ -241,40 +210,79 @@ struct MatchCtx {
 
 // MatcherReadEntry.writeMatchDetails (:723-756) for read i of the current batch / chunk (c.cls, c.seg_*): descriptor
 // up to the first blank without its '@', class taxid, length, runs "taxid:n"
-void kraken_line(MatchCtx &c, const uint8_t *desc, size_t dlen, int64_t L, int64_t i) {
+inline uint8_t *put_uint(uint8_t *o, uint64_t v) {
+    char tmp[20];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *o++ = (uint8_t)tmp[--n];
+    return o;
+}
+
+void kraken_line(const MatchCtx &c, std::vector<uint8_t> &out, const uint8_t *desc, size_t dlen, int64_t L, int64_t i) {
     const gs_host_match_opts *opts = c.opts;
     const uint64_t s0 = c.seg_off[(size_t)i], s1 = c.seg_off[(size_t)i + 1];
     const int32_t cl = c.cls[(size_t)i];
     if (s1 == s0 || !(opts->write_all || cl >= 0)) return;
     const int64_t maxp = L - c.info.k + 1;
-    std::string &line = c.line;
-    line.assign(cl >= 0 ? "C\t" : "U\t");
-    size_t de = dlen;
-    for (size_t j = 1; j < dlen; j++)
-        if (desc[j] == ' ') {
-            de = j;
-            break;
-        }
-    if (dlen > 1) line.append((const char *)desc + 1, de - 1);
-    line.push_back('\t');
-    line.append(cl >= 0 ? opts->taxids[cl] : "0");
-    line.push_back('\t');
-    append_int(line, L);
-    line.push_back('\t');
+    // written in place: make room for the longest this line can get, cut back to what it took
+    const size_t at = out.size();
+    const size_t room = 2 + dlen + 1 + c.taxid_max + 1 + 20 + 1 + (size_t)(s1 - s0) * (c.taxid_max + 23) + 1;
+    if (out.capacity() < at + room) out.reserve(std::max(2 * out.capacity(), at + room + ((size_t)1 << 16)));
+    out.resize(at + room);
+    uint8_t *o = out.data() + at;
+    *o++ = cl >= 0 ? 'C' : 'U';
+    *o++ = '\t';
+    if (dlen > 1) {
+        const void *sp = memchr(desc + 1, ' ', dlen - 1);
+        const size_t n = sp ? (size_t)((const uint8_t *)sp - desc) - 1 : dlen - 1;
+        memcpy(o, desc + 1, n);
+        o += n;
+    }
+    *o++ = '\t';
+    if (cl >= 0) {
+        memcpy(o, opts->taxids[cl], c.taxid_len[(size_t)cl]);
+        o += c.taxid_len[(size_t)cl];
+    } else
+        *o++ = '0';
+    *o++ = '\t';
+    o = put_uint(o, (uint64_t)L);
+    *o++ = '\t';
     for (uint64_t sg = s0; sg < s1; sg++) {
-        if (sg > s0) line.push_back(' ');
+        if (sg > s0) *o++ = ' ';
         const int32_t code = c.seg_code[(size_t)sg];
         if (code == -2)
-            line.push_back('A');
+            *o++ = 'A';
         else if (code < 0)
-            line.push_back('0');
-        else
-            line.append(opts->taxids[code]);
-        line.push_back(':');
-        append_int(line, (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg]);
+            *o++ = '0';
+        else {
+            memcpy(o, opts->taxids[code], c.taxid_len[(size_t)code]);
+            o += c.taxid_len[(size_t)code];
+        }
+        *o++ = ':';
+        const int64_t cnt = (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg];
+        if (cnt < 0) *o++ = '-';  // (cannot happen for segments the device produced; printed like the reference's int)
+        o = put_uint(o, (uint64_t)(cnt < 0 ? -cnt : cnt));
     }
-    line.push_back('\n');
-    c.out_buf.insert(c.out_buf.end(), line.begin(), line.end());
+    *o++ = '\n';
+    out.resize((size_t)(o - out.data()));
+}
+
+// per-thread output of one batch: Kraken lines and filtered records of a contiguous range of reads
+struct FormatPart {
+    std::vector<uint8_t> kraken, filtered;
+    int64_t n_filtered = 0;
+};
+
+// hands the parts to the writers in read order
+void write_parts(MatchCtx &c, std::vector<FormatPart> &parts) {
+    for (FormatPart &p : parts) {
+        c.filtered_reads += p.n_filtered;
+        c.filtered.write(std::move(p.filtered));
+        c.kraken.write(std::move(p.kraken));
+    }
 }
 
 // one parsed batch through the GPU and the per-read writers
@@ -297,19 +305,25 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
     c.t_gpu += now_s() - t0;
     if (err) return err;
     read_no += n;
-    c.out_buf.clear();
-    for (int64_t i = 0; i < n; i++) {
-        if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
-            write_read(c.filtered, b, i, false, c.tmp);
-            c.filtered_reads++;
+    if (!c.filtered.active() && !c.kraken.active()) return GS_OK;
+    std::vector<FormatPart> parts((size_t)c.pool.threads());
+    c.pool.run(n, [&](int t, int64_t lo, int64_t hi) {
+        FormatPart &p = parts[(size_t)t];
+        p.filtered = c.filtered.take();
+        p.kraken = c.kraken.take();
+        for (int64_t i = lo; i < hi; i++) {
+            if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
+                append_read(p.filtered, b, i, false);
+                p.n_filtered++;
+            }
+            if (c.kraken.active()) {
+                const size_t d0 = b.desc_off[(size_t)i], d1 = b.desc_off[(size_t)i + 1];
+                const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
+                kraken_line(c, p.kraken, b.desc.data() + d0, d1 - d0, L, i);
+            }
         }
-        if (c.kraken.active()) {
-            const size_t d0 = b.desc_off[(size_t)i], d1 = b.desc_off[(size_t)i + 1];
-            const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
-            kraken_line(c, b.desc.data() + d0, d1 - d0, L, i);
-        }
-    }
-    if (!c.out_buf.empty()) c.kraken.write(c.out_buf.data(), c.out_buf.size());
+    });
+    write_parts(c, parts);
     return GS_OK;
 }
 
@@ -485,20 +499,24 @@ private:
             }
         }
         if (err) return err;
-        c.out_buf.clear();
-        c.flt_buf.clear();
-        for (int64_t r = 0; r < n; r++) {
-            if (c.filtered.active() && (c.flags[(size_t)r] & GS_F_RETURNED)) {
-                append_text_record(c.flt_buf, text, nl, r);
-                c.filtered_reads++;
+        std::vector<FormatPart> parts((size_t)c.pool.threads());
+        MatchCtx &cc = c;
+        c.pool.run(n, [&cc, &parts, text, nl](int t, int64_t lo, int64_t hi) {
+            FormatPart &p = parts[(size_t)t];
+            p.filtered = cc.filtered.take();
+            p.kraken = cc.kraken.take();
+            for (int64_t r = lo; r < hi; r++) {
+                if (cc.filtered.active() && (cc.flags[(size_t)r] & GS_F_RETURNED)) {
+                    append_text_record(p.filtered, text, nl, r);
+                    p.n_filtered++;
+                }
+                if (cc.kraken.active()) {
+                    const size_t d0 = r == 0 ? 0 : (size_t)nl[4 * r - 1] + 1, d1 = nl[4 * r];
+                    kraken_line(cc, p.kraken, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
+                }
             }
-            if (c.kraken.active()) {
-                const size_t d0 = r == 0 ? 0 : (size_t)nl[4 * r - 1] + 1, d1 = nl[4 * r];
-                kraken_line(c, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
-            }
-        }
-        if (!c.flt_buf.empty()) c.filtered.write(c.flt_buf.data(), c.flt_buf.size());
-        if (!c.out_buf.empty()) c.kraken.write(c.out_buf.data(), c.out_buf.size());
+        });
+        write_parts(c, parts);
         return GS_OK;
     }
 
@@ -642,6 +660,14 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     if (!opts) opts = &none;
     c.opts = opts;
     if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
+    if (opts->kraken_out_path) {
+        c.taxid_len.resize((size_t)c.info.n_values);
+        for (int32_t v = 0; v < c.info.n_values; v++) {
+            if (!opts->taxids[v]) return hfail(GS_E_INVALID, "Kraken-style output: a taxid string is NULL");
+            c.taxid_len[(size_t)v] = (uint32_t)strlen(opts->taxids[v]);
+            c.taxid_max = std::max(c.taxid_max, (size_t)c.taxid_len[(size_t)v]);
+        }
+    }
     if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
     rc = gs_match_begin(&c.run, db, cfg);
     if (rc) return rc;
@@ -659,6 +685,8 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         }
     }
     gs_match_destroy(c.run);
+    const bool wrote = c.filtered.close() & c.kraken.close();  // (both are flushed before the clock stops)
+    if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {
         totals->reads = c.reads;
         totals->kmers = c.kmers;
@@ -710,10 +738,24 @@ struct FilterCtx {
     int k = 31, min_pos_count = 1;
     double positive_ratio = 0.2;
     OutFile acc_out, rest_out;
-    std::vector<uint8_t> accept, tmp;
+    std::vector<uint8_t> accept;
     int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
+    FormatPool pool{format_threads()};
 };
+
+struct FilterPart {
+    std::vector<uint8_t> acc, rest;
+    int64_t n_accepted = 0;
+};
+
+void write_filter_parts(FilterCtx &c, std::vector<FilterPart> &parts) {
+    for (FilterPart &p : parts) {
+        c.accepted += p.n_accepted;
+        c.acc_out.write(std::move(p.acc));
+        c.rest_out.write(std::move(p.rest));
+    }
+}
 
 // the general path for one source (file from `offset`, or a memory range): reference parser -> batches -> GPU -> writers
 int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n) {
@@ -732,13 +774,21 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
                                c.accept.data(), 0);
         c.t_gpu += now_s() - t0;
         if (err) continue;
-        for (int64_t i = 0; i < n; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-            if (c.accept[(size_t)i]) {
-                c.accepted++;
-                if (c.acc_out.active()) write_read(c.acc_out, *b, i, false, c.tmp);
-            } else if (c.rest_out.active())
-                write_read(c.rest_out, *b, i, false, c.tmp);
-        }
+        std::vector<FilterPart> parts((size_t)c.pool.threads());
+        const Batch &bb = *b;
+        c.pool.run(n, [&](int t, int64_t lo, int64_t hi) {
+            FilterPart &p = parts[(size_t)t];
+            p.acc = c.acc_out.take();
+            p.rest = c.rest_out.take();
+            for (int64_t i = lo; i < hi; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                if (c.accept[(size_t)i]) {
+                    p.n_accepted++;
+                    if (c.acc_out.active()) append_read(p.acc, bb, i, false);
+                } else if (c.rest_out.active())
+                    append_read(p.rest, bb, i, false);
+            }
+        });
+        write_filter_parts(c, parts);
     }
     prod.th.join();
     if (!err && !prod.error.empty()) err = hfail(GS_E_INVALID, prod.error);
@@ -772,7 +822,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     uint8_t *h_acc = nullptr;
     uint32_t *h_nl = nullptr;
     size_t acc_cap = 0, nl_cap = 0;
-    std::vector<uint8_t> carry, acc_buf, rest_buf;
+    std::vector<uint8_t> carry;
     int64_t carry_lines = 0, carry_file_off = 0, fallback_off = -1;
     int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
     const double t0 = now_s();
@@ -824,17 +874,20 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
             if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
                 fallback_off = carry_file_off;
             } else {
-                acc_buf.clear();
-                rest_buf.clear();
-                for (int64_t r = 0; r < n_reads; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-                    if (h_acc[r]) {
-                        c.accepted++;
-                        if (c.acc_out.active()) append_text_record(acc_buf, start, h_nl, r);
-                    } else if (c.rest_out.active())
-                        append_text_record(rest_buf, start, h_nl, r);
-                }
-                if (!acc_buf.empty()) c.acc_out.write(acc_buf.data(), acc_buf.size());
-                if (!rest_buf.empty()) c.rest_out.write(rest_buf.data(), rest_buf.size());
+                std::vector<FilterPart> parts((size_t)c.pool.threads());
+                c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
+                    FilterPart &p = parts[(size_t)t];
+                    p.acc = c.acc_out.take();
+                    p.rest = c.rest_out.take();
+                    for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                        if (h_acc[r]) {
+                            p.n_accepted++;
+                            if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r);
+                        } else if (c.rest_out.active())
+                            append_text_record(p.rest, start, h_nl, r);
+                    }
+                });
+                write_filter_parts(c, parts);
                 carry_file_off = i * (int64_t)tr.block + cut + 1;
                 carry.assign(blk + cut + 1, blk + sl.n);
                 carry_lines = rem;
@@ -884,6 +937,8 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
         else
             err = filter_parsed_source(c, path, 0, nullptr, 0);
     }
+    const bool wrote = c.acc_out.close() & c.rest_out.close();
+    if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {
         totals->reads = c.reads;
         totals->kmers = c.kmers;

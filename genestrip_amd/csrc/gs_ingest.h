@@ -14,12 +14,14 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <queue>
@@ -583,5 +585,167 @@ inline int text_path_kind(const std::string &path) {
     return gzip_content ? 2 : 1;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// output helper: plain or gzip by suffix (StreamProvider.getOutputStreamForFile)
+// ---------------------------------------------------------------------------------------------------
+// Writes happen on a thread of the file's own (started with the first buffer): the pipeline hands over whole buffers
+// (one or a few per chunk, in order) and goes on with the next chunk while the previous one is on its way to the page
+// cache or through deflate.  At most 64 buffers (a few chunks' worth) wait; close() reports a failed or short write.
+class OutFile {
+public:
+    bool open(const char *path) {
+        if (!path) return true;
+        if (is_gzip_name(path)) {
+            gz_ = gzopen(path, "wb1");
+            return gz_ != nullptr;
+        }
+        f_ = fopen(path, "wb");
+        return f_ != nullptr;
+    }
+    bool active() const { return gz_ || f_; }
+    void write(std::vector<uint8_t> &&buf) {
+        if (!active() || buf.empty()) return;
+        std::unique_lock<std::mutex> l(m_);
+        if (!th_.joinable()) th_ = std::thread([this] { drain(); });
+        cv_.wait(l, [&] { return q_.size() < 64; });
+        q_.push(std::move(buf));
+        cv_.notify_all();
+    }
+    void write(const void *p, size_t n) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        write(std::vector<uint8_t>(b, b + n));
+    }
+    // an empty buffer that keeps the capacity of one written earlier (fresh memory costs page faults)
+    std::vector<uint8_t> take() {
+        std::lock_guard<std::mutex> l(m_);
+        if (free_.empty()) return {};
+        std::vector<uint8_t> b = std::move(free_.back());
+        free_.pop_back();
+        return b;
+    }
+    // flushes and closes; false if any write failed
+    bool close() {
+        if (th_.joinable()) {
+            {
+                std::lock_guard<std::mutex> l(m_);
+                done_ = true;
+            }
+            cv_.notify_all();
+            th_.join();
+        }
+        if (gz_ && gzclose(gz_) != Z_OK) failed_ = true;
+        if (f_ && fclose(f_) != 0) failed_ = true;
+        gz_ = nullptr;
+        f_ = nullptr;
+        return !failed_;
+    }
+    ~OutFile() { close(); }
+
+private:
+    void drain() {
+        for (;;) {
+            std::vector<uint8_t> buf;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return done_ || !q_.empty(); });
+                if (q_.empty()) return;
+                buf = std::move(q_.front());
+                q_.pop();
+            }
+            cv_.notify_all();
+            // (a dead file keeps taking buffers so that the producer never blocks on it)
+            for (size_t at = 0; at < buf.size() && !failed_;) {
+                const size_t n = std::min(buf.size() - at, (size_t)1 << 30);
+                const size_t w = gz_ ? (size_t)std::max(0, gzwrite(gz_, buf.data() + at, (unsigned)n)) : fwrite(buf.data() + at, 1, n, f_);
+                if (w != n) failed_ = true;
+                at += n;
+            }
+            buf.clear();
+            std::lock_guard<std::mutex> l(m_);
+            if (free_.size() < 64) free_.push_back(std::move(buf));
+        }
+    }
+    gzFile gz_ = nullptr;
+    FILE *f_ = nullptr;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::queue<std::vector<uint8_t>> q_;
+    std::vector<std::vector<uint8_t>> free_;
+    bool done_ = false;
+    std::atomic<bool> failed_{false};
+};
+
+// A few threads that format the per-read outputs of a batch: run(n, f) calls f(t, lo, hi) for contiguous ranges of
+// [0, n), range t on worker t, the last one on the caller's thread, and returns when all are done.  Small inputs run
+// inline.  (Threads are kept: a chunk is formatted in well under a millisecond, less than starting them would take.)
+class FormatPool {
+public:
+    explicit FormatPool(int threads) : n_(std::max(1, threads)) {}
+    int threads() const { return n_; }
+    template <class F>
+    void run(int64_t n, F f) {
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_, n / 1024));
+        if (T == 1) {
+            f(0, (int64_t)0, n);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (th_.empty())
+                for (int t = 0; t + 1 < n_; t++) th_.emplace_back([this, t] { worker(t); });
+            job_ = [&f, n, T](int t) { f(t, n * t / T, n * (t + 1) / T); };
+            active_ = T - 1;
+            pending_ = T - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        f(T - 1, n * (T - 1) / T, n);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return pending_ == 0; });
+    }
+    ~FormatPool() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &x : th_) x.join();
+    }
+
+private:
+    void worker(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> l(m_);
+            cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            if (t >= active_) continue;
+            l.unlock();
+            job_(t);
+            l.lock();
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    const int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void(int)> job_;
+    uint64_t gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+inline int format_threads() {
+    int t = (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("GS_HOST_FORMAT_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) t = v;
+    }
+    return t;
+}
 
 }  // namespace gs_host

@@ -38,7 +38,8 @@ enum {
     GS_E_HIP = -3,       /* a HIP runtime call failed                      */
     GS_E_UNSUPPORTED = -4,
     GS_E_STATE = -5,     /* call order violated                            */
-    GS_E_NODEVICE = -6   /* no usable gfx950 device                        */
+    GS_E_NODEVICE = -6,  /* no usable gfx950 device                        */
+    GS_E_IO = -7         /* reading or writing a file failed (host layer)  */
 };
 
 enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1 };

@@ -330,6 +330,21 @@ def test_match_files_corrupt_gzip_is_an_error(sdb, tmp_path):
     store.close()
 
 
+@pytest.mark.skipif(not os.path.exists("/dev/full"), reason="needs /dev/full")
+def test_output_write_failure_is_reported(sdb, tmp_path):
+    """the writers run on their own threads: a write that fails (disk full) must still fail the call"""
+    path = str(tmp_path / "in.fastq")
+    open(path, "wb").write(b"".join(_fastq_bytes(sdb, 5000, seed=47)))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    with pytest.raises(RuntimeError, match="write"):
+        host.match_files(store, [path], kraken_out_path="/dev/full", taxids=sdb.taxids, write_all=True)
+    with pytest.raises(RuntimeError, match="write"):
+        host.match_files(store, [path], filtered_path="/dev/full")
+    t, _, tot = host.match_files(store, [path])  # the store and the library are fine afterwards
+    assert tot.reads == 5000
+    store.close()
+
+
 @pytest.mark.parametrize("readers", [1, 3, 4, 7])
 def test_match_files_few_blocks_many_readers(sdb, tmp_path, monkeypatch, readers):
     """files with fewer blocks than reader threads, processed repeatedly (pinned blocks come back from the pool): block i

@@ -276,3 +276,22 @@ def test_gunzip_under_sanitizers(tmp_path, sanitizer):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fails 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_writers_under_sanitizers(tmp_path, sanitizer):
+    """the output side of the host layer (formatting pool + writer threads) under ThreadSanitizer / AddressSanitizer"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(__file__), "native", "writers_sanitize.cpp")
+    exe = str(tmp_path / "writers_sanitize")
+    flags = ["-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize=alignment", "-std=c++17", "-pthread"]
+    b = subprocess.run(["g++", *flags, "-o", exe, src, "-lz"], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fails 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
