@@ -63,6 +63,7 @@ extern "C" const char *gs_strerror(int code) {
     case GS_E_UNSUPPORTED: return "unsupported";
     case GS_E_STATE: return "invalid call order";
     case GS_E_NODEVICE: return "no usable gfx950 device";
+    case GS_E_IO: return "file input/output failed";
     default: return "unknown error";
     }
 }
@@ -1173,7 +1174,8 @@ extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, 
     return GS_OK;
 }
 
-// inverse of gs_route_keys for the nodes that came back: nodes[idx[i]] = back[i]; unrouted positions read -2
+// inverse of gs_route_keys for the nodes that came back: nodes[idx[i]] = back[i]; unrouted positions read -2 (key ~0)
+// or -1 (key ~0 - 1: ruled out by the gate of the encoding rank)
 extern "C" int gs_unroute_nodes(gs_run *run, const uint64_t *keys, const uint32_t *idx, const int32_t *back,
                                 int64_t n_routed, int32_t *nodes, int64_t n_keys) {
     if (!run || (n_keys > 0 && (!nodes || !keys)) || (n_routed > 0 && (!idx || !back)))
