@@ -158,7 +158,10 @@ class Bloom:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may be gone already
+            pass
 
     def put(self, key):
         lib().orc_bloom_put(self.h, int(key))
@@ -216,7 +219,10 @@ class DB:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may be gone already
+            pass
 
     def get(self, kmer):
         pos = C.c_int64(-1)
@@ -248,7 +254,10 @@ class MatchRun:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may be gone already
+            pass
 
     def submit(self, seq, offsets, first_read_no=0, threads=1, per_read=True):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
