@@ -273,15 +273,22 @@ void kraken_line(const MatchCtx &c, std::vector<uint8_t> &out, const uint8_t *de
 // per-thread output of one batch: Kraken lines and filtered records of a contiguous range of reads
 struct FormatPart {
     std::vector<uint8_t> kraken, filtered;
+    bool kraken_packed = false, filtered_packed = false;  // already a gzip member (OutFile::pack)
     int64_t n_filtered = 0;
+    // a part that is big enough is compressed by the thread that made it
+    void pack(OutFile &kr, OutFile &flt) {
+        const size_t worth_it = (size_t)64 << 10;
+        kraken_packed = kr.gzip() && kraken.size() >= worth_it && kr.pack(kraken);
+        filtered_packed = flt.gzip() && filtered.size() >= worth_it && flt.pack(filtered);
+    }
 };
 
 // hands the parts to the writers in read order
 void write_parts(MatchCtx &c, std::vector<FormatPart> &parts) {
     for (FormatPart &p : parts) {
         c.filtered_reads += p.n_filtered;
-        c.filtered.write(std::move(p.filtered));
-        c.kraken.write(std::move(p.kraken));
+        c.filtered.write(std::move(p.filtered), p.filtered_packed);
+        c.kraken.write(std::move(p.kraken), p.kraken_packed);
     }
 }
 
@@ -322,6 +329,7 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
                 kraken_line(c, p.kraken, b.desc.data() + d0, d1 - d0, L, i);
             }
         }
+        p.pack(c.kraken, c.filtered);
     });
     write_parts(c, parts);
     return GS_OK;
@@ -515,6 +523,7 @@ private:
                     kraken_line(cc, p.kraken, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
                 }
             }
+            p.pack(cc.kraken, cc.filtered);
         });
         write_parts(c, parts);
         return GS_OK;
@@ -746,14 +755,20 @@ struct FilterCtx {
 
 struct FilterPart {
     std::vector<uint8_t> acc, rest;
+    bool acc_packed = false, rest_packed = false;
     int64_t n_accepted = 0;
+    void pack(OutFile &a, OutFile &r) {
+        const size_t worth_it = (size_t)64 << 10;
+        acc_packed = a.gzip() && acc.size() >= worth_it && a.pack(acc);
+        rest_packed = r.gzip() && rest.size() >= worth_it && r.pack(rest);
+    }
 };
 
 void write_filter_parts(FilterCtx &c, std::vector<FilterPart> &parts) {
     for (FilterPart &p : parts) {
         c.accepted += p.n_accepted;
-        c.acc_out.write(std::move(p.acc));
-        c.rest_out.write(std::move(p.rest));
+        c.acc_out.write(std::move(p.acc), p.acc_packed);
+        c.rest_out.write(std::move(p.rest), p.rest_packed);
     }
 }
 
@@ -787,6 +802,7 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
                 } else if (c.rest_out.active())
                     append_read(p.rest, bb, i, false);
             }
+            p.pack(c.acc_out, c.rest_out);
         });
         write_filter_parts(c, parts);
     }
@@ -886,6 +902,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
                         } else if (c.rest_out.active())
                             append_text_record(p.rest, start, h_nl, r);
                     }
+                    p.pack(c.acc_out, c.rest_out);
                 });
                 write_filter_parts(c, parts);
                 carry_file_off = i * (int64_t)tr.block + cut + 1;

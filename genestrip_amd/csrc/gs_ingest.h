@@ -596,20 +596,54 @@ class OutFile {
 public:
     bool open(const char *path) {
         if (!path) return true;
-        if (is_gzip_name(path)) {
-            gz_ = gzopen(path, "wb1");
-            return gz_ != nullptr;
-        }
+        gzip_ = is_gzip_name(path);
         f_ = fopen(path, "wb");
         return f_ != nullptr;
     }
-    bool active() const { return gz_ || f_; }
-    void write(std::vector<uint8_t> &&buf) {
+    bool active() const { return f_ != nullptr; }
+    // A gzip file is written as a sequence of gzip members (RFC 1952 2.2; gunzip, zcat and java.util.zip.GZIPInputStream
+    // read them as one stream), so that the threads that format a chunk can also compress their part of it: pack()
+    // turns a buffer into one member (level 1, like the "wb1" stream it replaces) and write(.., true) passes it
+    // through.  Small buffers are better left to the writer thread, which collects them into members of >= 1 MiB.
+    bool gzip() const { return gzip_; }
+    bool pack(std::vector<uint8_t> &buf) {
+        if (!gzip_ || !active()) return false;
+        const size_t piece = (size_t)1 << 30;  // zlib counts in 32 bits: one member per GiB of input
+        const size_t n_pieces = buf.empty() ? 1 : (buf.size() + piece - 1) / piece;
+        std::vector<uint8_t> out = take();
+        out.resize(buf.size() + buf.size() / 8 + n_pieces * 1024);
+        size_t produced = 0;
+        bool ok = true;
+        for (size_t i = 0; i < n_pieces && ok; i++) {
+            const size_t at = i * piece, n = std::min(piece, buf.size() - at);
+            z_stream z{};
+            ok = deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+            if (!ok) break;
+            ok = deflateBound(&z, (uLong)n) <= out.size() - produced;
+            z.next_in = buf.data() + at;
+            z.avail_in = (uInt)n;
+            z.next_out = out.data() + produced;
+            z.avail_out = (uInt)std::min<size_t>(out.size() - produced, 0xffffffffu);
+            ok = ok && deflate(&z, Z_FINISH) == Z_STREAM_END;
+            produced += (size_t)z.total_out;
+            deflateEnd(&z);
+        }
+        if (!ok) {
+            failed_ = true;
+            give_back(std::move(out));
+            return false;
+        }
+        out.resize(produced);
+        buf.swap(out);
+        give_back(std::move(out));
+        return true;
+    }
+    void write(std::vector<uint8_t> &&buf, bool packed = false) {
         if (!active() || buf.empty()) return;
         std::unique_lock<std::mutex> l(m_);
         if (!th_.joinable()) th_ = std::thread([this] { drain(); });
         cv_.wait(l, [&] { return q_.size() < 64; });
-        q_.push(std::move(buf));
+        q_.push(Item{std::move(buf), packed});
         cv_.notify_all();
     }
     void write(const void *p, size_t n) {
@@ -634,45 +668,69 @@ public:
             cv_.notify_all();
             th_.join();
         }
-        if (gz_ && gzclose(gz_) != Z_OK) failed_ = true;
-        if (f_ && fclose(f_) != 0) failed_ = true;
-        gz_ = nullptr;
+        if (f_) {
+            if (gzip_ && !wrote_member_) {  // an empty gzip file is one empty member, not zero bytes
+                std::vector<uint8_t> none;
+                if (pack(none)) put(none);
+            }
+            if (fclose(f_) != 0) failed_ = true;
+        }
         f_ = nullptr;
         return !failed_;
     }
     ~OutFile() { close(); }
 
 private:
+    struct Item {
+        std::vector<uint8_t> buf;
+        bool packed;
+    };
+    void give_back(std::vector<uint8_t> &&b) {
+        b.clear();
+        std::lock_guard<std::mutex> l(m_);
+        if (free_.size() < 64) free_.push_back(std::move(b));
+    }
+    void put(const std::vector<uint8_t> &b) {
+        if (failed_ || b.empty()) return;
+        if (fwrite(b.data(), 1, b.size(), f_) != b.size()) failed_ = true;
+        wrote_member_ = true;
+    }
+    void flush_pending() {
+        if (pending_.empty()) return;
+        if (pack(pending_)) put(pending_);
+        pending_.clear();
+    }
     void drain() {
         for (;;) {
-            std::vector<uint8_t> buf;
+            Item it;
             {
                 std::unique_lock<std::mutex> l(m_);
                 cv_.wait(l, [&] { return done_ || !q_.empty(); });
-                if (q_.empty()) return;
-                buf = std::move(q_.front());
+                if (q_.empty()) break;
+                it = std::move(q_.front());
                 q_.pop();
             }
             cv_.notify_all();
             // (a dead file keeps taking buffers so that the producer never blocks on it)
-            for (size_t at = 0; at < buf.size() && !failed_;) {
-                const size_t n = std::min(buf.size() - at, (size_t)1 << 30);
-                const size_t w = gz_ ? (size_t)std::max(0, gzwrite(gz_, buf.data() + at, (unsigned)n)) : fwrite(buf.data() + at, 1, n, f_);
-                if (w != n) failed_ = true;
-                at += n;
+            if (!gzip_ || it.packed) {
+                if (gzip_) flush_pending();  // order
+                put(it.buf);
+            } else {
+                pending_.insert(pending_.end(), it.buf.begin(), it.buf.end());
+                if (pending_.size() >= ((size_t)1 << 20)) flush_pending();
             }
-            buf.clear();
-            std::lock_guard<std::mutex> l(m_);
-            if (free_.size() < 64) free_.push_back(std::move(buf));
+            give_back(std::move(it.buf));
         }
+        if (gzip_) flush_pending();
     }
-    gzFile gz_ = nullptr;
+    bool gzip_ = false, wrote_member_ = false;
     FILE *f_ = nullptr;
     std::thread th_;
     std::mutex m_;
     std::condition_variable cv_;
-    std::queue<std::vector<uint8_t>> q_;
+    std::queue<Item> q_;
     std::vector<std::vector<uint8_t>> free_;
+    std::vector<uint8_t> pending_;  // writer thread only
     bool done_ = false;
     std::atomic<bool> failed_{false};
 };

@@ -53,7 +53,9 @@ int main(int argc, char **argv) {
                 line_no += n;
                 for (auto &p : parts) {
                     want.insert(want.end(), p.begin(), p.end());
-                    b.write(p.data(), p.size());
+                    std::vector<uint8_t> copy = p;  // big parts become gzip members on this side, small ones in the writer
+                    const bool packed = copy.size() >= 65536 && b.pack(copy);
+                    b.write(std::move(copy), packed);
                     a.write(std::move(p));
                     unused.write(std::vector<uint8_t>(3, 'x'));  // an inactive file swallows its buffers
                 }
@@ -62,6 +64,20 @@ int main(int argc, char **argv) {
         }
         if (slurp(plain, false) != want) fails++;
         if (slurp(packed, true) != want) fails++;
+    }
+    {   // a gzip file nothing was written to is still a gzip file
+        const std::string empty = dir + "/e.gz";
+        {
+            OutFile e;
+            if (!e.open(empty.c_str()) || !e.close()) fails++;
+        }
+        gzFile f = gzopen(empty.c_str(), "rb");
+        char c;
+        if (!f || gzread(f, &c, 1) != 0 || !gzeof(f)) fails++;
+        if (f) gzclose(f);
+        FILE *raw = fopen(empty.c_str(), "rb");
+        if (!raw || fgetc(raw) != 0x1f) fails++;
+        if (raw) fclose(raw);
     }
     {   // a file that cannot take the data reports it at close()
         OutFile full;

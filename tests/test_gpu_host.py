@@ -330,6 +330,32 @@ def test_match_files_corrupt_gzip_is_an_error(sdb, tmp_path):
     store.close()
 
 
+def test_gzip_outputs_are_multi_member_and_round_trip(sdb, tmp_path):
+    """.gz outputs are compressed by the formatting threads, one gzip member per part: the content must equal the
+    plain outputs, and the library's own gzip reader must take the file back"""
+    path = str(tmp_path / "in.fastq")
+    open(path, "wb").write(b"".join(_fastq_bytes(sdb, 40000, seed=53)))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    plain = dict(filtered_path=str(tmp_path / "f.fastq"), kraken_out_path=str(tmp_path / "k.out"))
+    packed = dict(filtered_path=str(tmp_path / "f.fastq.gz"), kraken_out_path=str(tmp_path / "k.out.gz"))
+    t1, _, tot1 = host.match_files(store, [path], taxids=sdb.taxids, write_all=True, **plain)
+    t2, _, tot2 = host.match_files(store, [path], taxids=sdb.taxids, write_all=True, **packed)
+    assert np.array_equal(t1, t2) and tot1.filtered_reads == tot2.filtered_reads > 1000
+    for a, b in zip(plain.values(), packed.values()):
+        raw = open(b, "rb").read()
+        assert raw.count(b"\x1f\x8b\x08\x00\x00\x00\x00\x00") > 1  # several members (threads packed their parts)
+        assert gzip.decompress(raw) == open(a, "rb").read()
+    t3, _, tot3 = host.match_files(store, [packed["filtered_path"]])
+    assert tot3.reads == tot1.filtered_reads
+    # nothing to write: still a valid (empty) gzip file
+    junk = str(tmp_path / "junk.fastq")
+    open(junk, "wb").write(b"@r\n" + b"ACGT" * 20 + b"\n+\n" + b"I" * 80 + b"\n")
+    none = str(tmp_path / "none.fastq.gz")
+    host.match_files(store, [junk], filtered_path=none)
+    assert gzip.decompress(open(none, "rb").read()) == b""
+    store.close()
+
+
 @pytest.mark.skipif(not os.path.exists("/dev/full"), reason="needs /dev/full")
 def test_output_write_failure_is_reported(sdb, tmp_path):
     """the writers run on their own threads: a write that fails (disk full) must still fail the call"""

@@ -10,6 +10,7 @@ import genestrip_amd as ga  # noqa: E402
 from genestrip_amd import host, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+gz = ".gz" if len(sys.argv) > 2 and sys.argv[2] == "gz" else ""  # compressed outputs (multi-member gzip)
 db = synth.SynthDB()
 store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
 seq, off = synth.reads_host(db.genomes, n)
@@ -19,9 +20,9 @@ L = 150
 blk = seq.tobytes()
 with open(path, "wb") as f:
     f.write(b"".join(b"@r%d\n" % i + blk[i * L:(i + 1) * L] + b"\n+\n" + b"I" * L + b"\n" for i in range(n)))
-for label, kw in (("table only", {}), ("kraken out", dict(kraken_out_path=os.path.join(d, "k.out"), taxids=db.taxids)),
-                  ("filtered fastq", dict(filtered_path=os.path.join(d, "f.fastq"))),
-                  ("both", dict(kraken_out_path=os.path.join(d, "k.out"), taxids=db.taxids, filtered_path=os.path.join(d, "f.fastq")))):
+for label, kw in (("table only", {}), ("kraken out", dict(kraken_out_path=os.path.join(d, "k.out" + gz), taxids=db.taxids)),
+                  ("filtered fastq", dict(filtered_path=os.path.join(d, "f.fastq" + gz))),
+                  ("both", dict(kraken_out_path=os.path.join(d, "k.out" + gz), taxids=db.taxids, filtered_path=os.path.join(d, "f.fastq" + gz)))):
     t0 = time.perf_counter()
     _, _, tot = host.match_files(store, [path], **kw)
     dt = time.perf_counter() - t0
