@@ -328,8 +328,10 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         for (u64 w : sketch) ones += (size_t)__builtin_popcountll(w);
         const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
         const double distinct = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
+        double bits_per_min = 16.0;  // rounded up to a power-of-two word count: 16..32 bits per distinct minimizer
+        if (const char *e = getenv("GS_MGATE_BITS_PER_MIN")) bits_per_min = std::max(1.0, atof(e));
         mgate_bits = 6;
-        while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < distinct * 16.0) mgate_bits++;
+        while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < distinct * bits_per_min) mgate_bits++;
         mgate.assign((size_t)1 << mgate_bits, 0);
         for (int64_t i = 0; i < nm; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }

@@ -362,7 +362,6 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             }
         }
 #else
-        bool pending = false;
         if (act[s]) {
             int vs = -1, sl = 0;
             const bool done = gs_match_bucket(bk[s], want[s], vmask2, vs, sl);
