@@ -20,7 +20,7 @@ void append_read(std::vector<uint8_t> &buf, const Batch &b, int64_t i, bool with
     buf.push_back('+');
     buf.push_back('\n');
     const size_t q0 = b.qual_off[i], q1 = b.qual_off[i + 1];
-    if (with_probs && q1 > q0)
+    if (with_probs && b.has_qual)
         buf.insert(buf.end(), b.qual.begin() + (long)q0, b.qual.begin() + (long)q1);
     else
         buf.insert(buf.end(), s1 - s0, (uint8_t)'~');
@@ -320,7 +320,7 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
         p.kraken = c.kraken.take();
         for (int64_t i = lo; i < hi; i++) {
             if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
-                append_read(p.filtered, b, i, false);
+                append_read(p.filtered, b, i, c.opts->with_probs != 0);
                 p.n_filtered++;
             }
             if (c.kraken.active()) {
@@ -361,11 +361,23 @@ struct TextChunk {
     int64_t ticket;
 };
 
-// ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", '~' x length
+// ReadEntry.write of record i of a raw chunk (newline offsets nl[]): descriptor, read, "+", then '~' x length or
+// (with_probs) the record's quality line -- in a chunk the device accepted that is ONE line at least as long as the read
 // (appended to `buf`; the caller writes one buffer per chunk)
-void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const uint32_t *nl, int64_t i) {
+void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const uint32_t *nl, int64_t i, bool with_probs) {
     const size_t d0 = i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1, d1 = nl[4 * i], s0 = d1 + 1, s1 = nl[4 * i + 1];
     const size_t at = buf.size(), dl = d1 - d0, sl = s1 - s0;
+    if (with_probs) {
+        const size_t q0 = (size_t)nl[4 * i + 2] + 1, ql = (size_t)nl[4 * i + 3] - q0;
+        buf.resize(at + dl + sl + ql + 5);
+        uint8_t *o = buf.data() + at;
+        memcpy(o, text + d0, dl + 1 + sl + 1);  // descriptor and read lines as they stand, newlines included
+        o += dl + sl + 2;
+        *o++ = '+';
+        *o++ = '\n';
+        memcpy(o, text + q0, ql + 1);
+        return;
+    }
     buf.resize(at + dl + 2 * sl + 5);
     uint8_t *o = buf.data() + at;
     memcpy(o, text + d0, dl);
@@ -515,7 +527,7 @@ private:
             p.kraken = cc.kraken.take();
             for (int64_t r = lo; r < hi; r++) {
                 if (cc.filtered.active() && (cc.flags[(size_t)r] & GS_F_RETURNED)) {
-                    append_text_record(p.filtered, text, nl, r);
+                    append_text_record(p.filtered, text, nl, r, cc.opts->with_probs != 0);
                     p.n_filtered++;
                 }
                 if (cc.kraken.active()) {
@@ -746,6 +758,7 @@ struct FilterCtx {
     gs_bloom *bloom = nullptr;
     int k = 31, min_pos_count = 1;
     double positive_ratio = 0.2;
+    bool with_probs = false;
     OutFile acc_out, rest_out;
     std::vector<uint8_t> accept;
     int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
@@ -798,9 +811,9 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
             for (int64_t i = lo; i < hi; i++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
                 if (c.accept[(size_t)i]) {
                     p.n_accepted++;
-                    if (c.acc_out.active()) append_read(p.acc, bb, i, false);
+                    if (c.acc_out.active()) append_read(p.acc, bb, i, c.with_probs);
                 } else if (c.rest_out.active())
-                    append_read(p.rest, bb, i, false);
+                    append_read(p.rest, bb, i, c.with_probs);
             }
             p.pack(c.acc_out, c.rest_out);
         });
@@ -898,9 +911,9 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
                     for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
                         if (h_acc[r]) {
                             p.n_accepted++;
-                            if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r);
+                            if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r, c.with_probs);
                         } else if (c.rest_out.active())
-                            append_text_record(p.rest, start, h_nl, r);
+                            append_text_record(p.rest, start, h_nl, r, c.with_probs);
                     }
                     p.pack(c.acc_out, c.rest_out);
                 });
@@ -934,9 +947,10 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
 
 extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio,
                                     const char *const *paths, int n_paths, const char *filtered_path,
-                                    const char *rest_path, gs_host_totals *totals) {
+                                    const char *rest_path, int with_probs, gs_host_totals *totals) {
     if (!bloom || !paths || n_paths < 0) return hfail(GS_E_INVALID, "NULL argument");
     FilterCtx c;
+    c.with_probs = with_probs != 0;
     c.bloom = bloom;
     c.k = k;
     c.min_pos_count = min_pos_count;

@@ -117,6 +117,7 @@ struct Batch {
     std::vector<uint8_t> seq, desc, qual;
     std::vector<uint64_t> seq_off{0}, desc_off{0}, qual_off{0};
     int64_t first_read_no = 0;
+    bool has_qual = true;  // false for FASTA records (readProbsSize = -1, AbstractFastqReader.java:417)
     int64_t n() const { return (int64_t)seq_off.size() - 1; }
     void clear() {
         seq.clear();
@@ -125,6 +126,7 @@ struct Batch {
         seq_off.assign(1, 0);
         desc_off.assign(1, 0);
         qual_off.assign(1, 0);
+        has_qual = true;
     }
 };
 
@@ -199,6 +201,7 @@ private:
     }
 
     bool next_fasta(Batch &b) {
+        b.has_qual = false;
         if (!have_header_) {
             header_.clear();
             const size_t got = lr_.next_line(header_);

@@ -18,7 +18,7 @@ class _ReadBatch(C.Structure):
 
 class _MatchOpts(C.Structure):
     _fields_ = [("filtered_path", C.c_char_p), ("kraken_out_path", C.c_char_p), ("write_all", C.c_int32),
-                ("taxids", C.POINTER(C.c_char_p)), ("batch_reads", C.c_int64)]
+                ("taxids", C.POINTER(C.c_char_p)), ("batch_reads", C.c_int64), ("with_probs", C.c_int32)]
 
 
 class Totals(C.Structure):
@@ -48,7 +48,7 @@ def lib():
         "gs_fastq_totals": (ci, [vp, vp, vp, vp]), "gs_fastq_close": (ci, [vp]),
         "gs_host_match_files": (ci, [vp, vp, vp, ci, vp, vp, vp, vp]),
         "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
-        "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, vp]),
+        "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, ci, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
         "gs_host_gunzip": (ci, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]),
@@ -119,14 +119,15 @@ class FastqReader:
 
 
 def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=None, write_all=True, taxids=None,
-                batch_reads=0):
-    """FastqKMerMatcher.runMatcher over files: returns (table, dtable, Totals)"""
+                batch_reads=0, with_probs=False):
+    """FastqKMerMatcher.runMatcher over files: returns (table, dtable, Totals); with_probs = the reference's withProbs
+    (written reads keep their quality lines)"""
     cfg = (config or _b.MatchConfig())._c()
     parr = _cstr_array(list(paths))
     tarr = _cstr_array(taxids)
     opts = _MatchOpts(None if filtered_path is None else str(filtered_path).encode(),
                       None if kraken_out_path is None else str(kraken_out_path).encode(), int(write_all),
-                      tarr, batch_reads)
+                      tarr, batch_reads, int(with_probs))
     nv = store.n_values
     table = np.zeros((nv, _b.N_COLS), dtype=np.int64)
     dtable = np.zeros((nv, _b.N_DCOLS), dtype=np.float64)
@@ -148,12 +149,14 @@ def match_files_into(matcher, paths, file_index):
     return counts[:len(fi)], tot
 
 
-def filter_files(bloom, k, paths, min_pos_count=1, positive_ratio=0.2, filtered_path=None, rest_path=None):
+def filter_files(bloom, k, paths, min_pos_count=1, positive_ratio=0.2, filtered_path=None, rest_path=None,
+                 with_probs=False):
     parr = _cstr_array(list(paths))
     tot = Totals()
     _check(lib().gs_host_filter_files(bloom.h, k, min_pos_count, positive_ratio, parr, len(paths),
                                       None if filtered_path is None else str(filtered_path).encode(),
-                                      None if rest_path is None else str(rest_path).encode(), C.byref(tot)))
+                                      None if rest_path is None else str(rest_path).encode(), int(with_probs),
+                                      C.byref(tot)))
     return tot
 
 

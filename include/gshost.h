@@ -55,6 +55,8 @@ typedef struct {
     int32_t write_all;             /* writeAll: also lines of unclassified reads (C/GSConfigKey.java:315)      */
     const char *const *taxids;     /* taxid string per value index (needed for the Kraken-style output)        */
     int64_t batch_reads;           /* 0 = default (1 Mi reads)                                                 */
+    int32_t with_probs;            /* withProbs (C/GSConfigKey.java:364): written reads keep their quality line(s)
+                                      (ReadEntry.write, AbstractFastqReader.java:570-584) instead of '~' x length */
 } gs_host_match_opts;
 
 typedef struct {
@@ -76,9 +78,10 @@ int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *p
 int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
                        int64_t *reads_of_file, gs_host_totals *totals);
 
-/* ---- runFilter: accepted reads -> filtered_path, the rest -> rest_path (either may be NULL) ---- */
+/* ---- runFilter: accepted reads -> filtered_path, the rest -> rest_path (either may be NULL); with_probs as above ---- */
 int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const char *const *paths,
-                         int n_paths, const char *filtered_path, const char *rest_path, gs_host_totals *totals);
+                         int n_paths, const char *filtered_path, const char *rest_path, int with_probs,
+                         gs_host_totals *totals);
 
 /* ---- completeResults + CSV ---- */
 typedef struct {

@@ -330,6 +330,55 @@ def test_match_files_corrupt_gzip_is_an_error(sdb, tmp_path):
     store.close()
 
 
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_with_probs_keeps_the_quality_lines(sdb, tmp_path, monkeypatch, fast):
+    """withProbs (GSConfigKey WITH_PROBS): ReadEntry.write puts out the quality characters it read -- the whole line
+    when it is longer than the read, several lines joined when the record has them -- instead of '~' x length.
+    The file starts as plain four-line FASTQ (device text path) and turns multi-line later (reference parser)."""
+    monkeypatch.setenv("GS_HOST_FAST", fast)
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", "65536")
+    seq, off = synth.reads_host(sdb.genomes, 3000, read_len=150, seed=59)
+    rng = np.random.default_rng(4)
+    recs, reads, quals = [], [], []
+    for i in range(3000):
+        r = seq[int(off[i]):int(off[i + 1])].tobytes()
+        q = bytes(rng.integers(33, 74, len(r) + (3 if i % 9 == 0 else 0), dtype=np.uint8))  # some longer than the read
+        if i >= 2000 and i % 5 == 0:   # sequence and quality split over two lines each
+            recs.append(b"@r%d\n" % i + r[:70] + b"\n" + r[70:] + b"\n+\n" + q[:50] + b"\n" + q[50:] + b"\n")
+        else:
+            recs.append(b"@r%d\n" % i + r + b"\n+\n" + q + b"\n")
+        reads.append(r)
+        quals.append(q)
+    path = str(tmp_path / "in.fastq")
+    open(path, "wb").write(b"".join(recs))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    orun = orc.MatchRun(odb)
+    _, ofl = orun.submit(seq, off)
+    orun.finish()
+    keep = np.flatnonzero(ofl & orc.F_RETURNED)
+    assert 500 < len(keep)
+    flt = str(tmp_path / "f.fastq")
+    _, _, tot = host.match_files(store, [path], filtered_path=flt, with_probs=True)
+    want = b"".join(b"@r%d\n" % i + reads[i] + b"\n+\n" + quals[i] + b"\n" for i in keep)
+    assert open(flt, "rb").read() == want and tot.filtered_reads == len(keep)
+    _, _, tot = host.match_files(store, [path], filtered_path=flt)  # the default stays '~' x length
+    want = b"".join(b"@r%d\n" % i + reads[i] + b"\n+\n" + b"~" * len(reads[i]) + b"\n" for i in keep)
+    assert open(flt, "rb").read() == want
+    # the filter goal has the same switch
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    bloom = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    acc, rest = str(tmp_path / "acc.fastq"), str(tmp_path / "rest.fastq")
+    host.filter_files(bloom, 31, [path], filtered_path=acc, rest_path=rest, with_probs=True)
+    ok = ob.filter_batch(31, 1, 0.2, seq, off)
+    for out, sel in ((acc, np.flatnonzero(ok)), (rest, np.flatnonzero(ok == 0))):
+        assert open(out, "rb").read() == b"".join(b"@r%d\n" % i + reads[i] + b"\n+\n" + quals[i] + b"\n" for i in sel)
+    bloom.close()
+    store.close()
+
+
 def test_gzip_outputs_are_multi_member_and_round_trip(sdb, tmp_path):
     """.gz outputs are compressed by the formatting threads, one gzip member per part: the content must equal the
     plain outputs, and the library's own gzip reader must take the file back"""
