@@ -191,15 +191,45 @@ struct Producer {
 namespace {
 
 // everything one runMatcher call carries from batch to batch
+// grow-only array in pinned host memory: per-read results come back from the device into these (a copy into pageable
+// memory is staged by the runtime and several times slower); resize() does not keep the contents
+template <class T>
+struct PinnedVec {
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    int resize(size_t m) {
+        if (m > cap) {
+            gs_pinned_free(p);
+            p = nullptr;
+            cap = 0;
+            void *q = nullptr;
+            const size_t want = m + m / 4 + 64;
+            const int err = gs_pinned_alloc(&q, want * sizeof(T));
+            if (err) return err;
+            p = static_cast<T *>(q);
+            cap = want;
+        }
+        n = m;
+        return GS_OK;
+    }
+    T *data() { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    PinnedVec() = default;
+    PinnedVec(const PinnedVec &) = delete;
+    PinnedVec &operator=(const PinnedVec &) = delete;
+    ~PinnedVec() { gs_pinned_free(p); }
+};
+
 struct MatchCtx {
     gs_run *run = nullptr;
     gs_db_info info{};
     const gs_host_match_opts *opts = nullptr;
     OutFile filtered, kraken;
-    std::vector<int32_t> cls, seg_code, seg_start;
-    std::vector<uint8_t> flags;
-    std::vector<uint64_t> seg_off;
-    std::vector<uint8_t> nl_bytes;
+    PinnedVec<int32_t> cls, seg_code, seg_start;
+    PinnedVec<uint8_t> flags;
+    PinnedVec<uint64_t> seg_off;
+    PinnedVec<uint32_t> nl;
     FormatPool pool{format_threads()};  // the per-read writers format a batch on these threads
     std::vector<uint32_t> taxid_len;    // strlen of opts->taxids[vi] (Kraken-style lines)
     size_t taxid_max = 1;
@@ -295,19 +325,18 @@ void write_parts(MatchCtx &c, std::vector<FormatPart> &parts) {
 // one parsed batch through the GPU and the per-read writers
 int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
     const int64_t n = b.n();
-    c.cls.resize((size_t)n);
-    c.flags.resize((size_t)n);
+    int err = c.cls.resize((size_t)n);
+    if (!err) err = c.flags.resize((size_t)n);
+    if (err) return err;
     if (b.seq.empty()) b.seq.push_back(0);
     const double t0 = now_s();
-    int err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
+    err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
     if (!err && c.kraken.active()) {
-        c.seg_off.resize((size_t)n + 1);
-        err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, c.seg_off.data());
-        if (!err) {
-            c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
-            c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
-            err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
-        }
+        err = c.seg_off.resize((size_t)n + 1);
+        if (!err) err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, c.seg_off.data());
+        if (!err) err = c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
+        if (!err) err = c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
+        if (!err) err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
     }
     c.t_gpu += now_s() - t0;
     if (err) return err;
@@ -470,10 +499,11 @@ struct TextJob {
                 const bool per_read = c.filtered.active() || c.kraken.active();
                 const int64_t n_chunk = usable >> 2;
                 if (per_read) {
-                    c.cls.resize((size_t)n_chunk);
-                    c.flags.resize((size_t)n_chunk);
+                    err = c.cls.resize((size_t)n_chunk);
+                    if (!err) err = c.flags.resize((size_t)n_chunk);
                 }
-                err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
+                if (!err)
+                    err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
                                            per_read ? c.cls.data() : nullptr, per_read ? c.flags.data() : nullptr, &ticket);
                 if (!err && per_read) {  // the writers need this chunk's results now
                     chunks.push_back({carry_file_off, reads_in_file, ticket});
@@ -506,17 +536,15 @@ private:
     // filtered FASTQ (afterMatch, :304-307) and Kraken-style lines (:723-756) of the chunk that was just matched, from
     // the raw block: the device returns the record geometry (newline offsets) and the segments
     int write_chunk_outputs(const uint8_t *text, int64_t n) {
-        c.nl_bytes.resize((size_t)n * 4 * sizeof(uint32_t));
-        uint32_t *nl = reinterpret_cast<uint32_t *>(c.nl_bytes.data());
-        int err = gs_match_text_newlines(c.run, nl);
+        int err = c.nl.resize((size_t)n * 4);
+        const uint32_t *nl = c.nl.data();
+        if (!err) err = gs_match_text_newlines(c.run, c.nl.data());
         if (!err && c.kraken.active()) {
-            c.seg_off.resize((size_t)n + 1);
-            err = gs_match_segments_text(c.run, c.seg_off.data());
-            if (!err) {
-                c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
-                c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
-                err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
-            }
+            err = c.seg_off.resize((size_t)n + 1);
+            if (!err) err = gs_match_segments_text(c.run, c.seg_off.data());
+            if (!err) err = c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
+            if (!err) err = c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
+            if (!err) err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
         }
         if (err) return err;
         std::vector<FormatPart> parts((size_t)c.pool.threads());
