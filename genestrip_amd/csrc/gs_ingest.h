@@ -367,10 +367,10 @@ struct TextReader {
             if (fstat(fd, &sb) != 0) return hfail(GS_E_INVALID, "cannot stat " + path);
             map_len = (size_t)sb.st_size;
             if (map_len) {
-                void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m == MAP_FAILED) return hfail(GS_E_INVALID, "cannot map " + path);
-                map = (const uint8_t *)m;
-                madvise(m, map_len, MADV_SEQUENTIAL);
+                void *mapped = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (mapped == MAP_FAILED) return hfail(GS_E_INVALID, "cannot map " + path);
+                map = (const uint8_t *)mapped;
+                madvise(mapped, map_len, MADV_SEQUENTIAL);
             }
             if (block_bytes < ((size_t)64 << 10)) block_bytes = (size_t)64 << 10;  // the 32 KiB window lives in the headroom
             gz_threads_hint = readers;  // inflating threads behind the ONE thread that fills the blocks
