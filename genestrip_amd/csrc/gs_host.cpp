@@ -226,10 +226,14 @@ struct MatchCtx {
     gs_db_info info{};
     const gs_host_match_opts *opts = nullptr;
     OutFile filtered, kraken;
-    PinnedVec<int32_t> cls, seg_code, seg_start;
-    PinnedVec<uint8_t> flags;
-    PinnedVec<uint64_t> seg_off;
-    PinnedVec<uint32_t> nl;
+    // per-read results of a batch; two sets, so that the writers can work on one chunk while the device fills the
+    // other (TextJob)
+    struct Results {
+        PinnedVec<int32_t> cls, seg_code, seg_start;
+        PinnedVec<uint8_t> flags;
+        PinnedVec<uint64_t> seg_off;
+        PinnedVec<uint32_t> nl;
+    } res[2];
     FormatPool pool{format_threads()};  // the per-read writers format a batch on these threads
     std::vector<uint32_t> taxid_len;    // strlen of opts->taxids[vi] (Kraken-style lines)
     size_t taxid_max = 1;
@@ -251,10 +255,11 @@ inline uint8_t *put_uint(uint8_t *o, uint64_t v) {
     return o;
 }
 
-void kraken_line(const MatchCtx &c, std::vector<uint8_t> &out, const uint8_t *desc, size_t dlen, int64_t L, int64_t i) {
+void kraken_line(const MatchCtx &c, const MatchCtx::Results &rs, std::vector<uint8_t> &out, const uint8_t *desc, size_t dlen,
+                 int64_t L, int64_t i) {
     const gs_host_match_opts *opts = c.opts;
-    const uint64_t s0 = c.seg_off[(size_t)i], s1 = c.seg_off[(size_t)i + 1];
-    const int32_t cl = c.cls[(size_t)i];
+    const uint64_t s0 = rs.seg_off[(size_t)i], s1 = rs.seg_off[(size_t)i + 1];
+    const int32_t cl = rs.cls[(size_t)i];
     if (s1 == s0 || !(opts->write_all || cl >= 0)) return;
     const int64_t maxp = L - c.info.k + 1;
     // written in place: make room for the longest this line can get, cut back to what it took
@@ -282,7 +287,7 @@ void kraken_line(const MatchCtx &c, std::vector<uint8_t> &out, const uint8_t *de
     *o++ = '\t';
     for (uint64_t sg = s0; sg < s1; sg++) {
         if (sg > s0) *o++ = ' ';
-        const int32_t code = c.seg_code[(size_t)sg];
+        const int32_t code = rs.seg_code[(size_t)sg];
         if (code == -2)
             *o++ = 'A';
         else if (code < 0)
@@ -292,7 +297,7 @@ void kraken_line(const MatchCtx &c, std::vector<uint8_t> &out, const uint8_t *de
             o += c.taxid_len[(size_t)code];
         }
         *o++ = ':';
-        const int64_t cnt = (sg + 1 < s1 ? c.seg_start[(size_t)sg + 1] : maxp) - c.seg_start[(size_t)sg];
+        const int64_t cnt = (sg + 1 < s1 ? rs.seg_start[(size_t)sg + 1] : maxp) - rs.seg_start[(size_t)sg];
         if (cnt < 0) *o++ = '-';  // (cannot happen for segments the device produced; printed like the reference's int)
         o = put_uint(o, (uint64_t)(cnt < 0 ? -cnt : cnt));
     }
@@ -325,18 +330,19 @@ void write_parts(MatchCtx &c, std::vector<FormatPart> &parts) {
 // one parsed batch through the GPU and the per-read writers
 int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
     const int64_t n = b.n();
-    int err = c.cls.resize((size_t)n);
-    if (!err) err = c.flags.resize((size_t)n);
+    MatchCtx::Results &rs = c.res[0];
+    int err = rs.cls.resize((size_t)n);
+    if (!err) err = rs.flags.resize((size_t)n);
     if (err) return err;
     if (b.seq.empty()) b.seq.push_back(0);
     const double t0 = now_s();
-    err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, read_no, GS_MEM_HOST, c.cls.data(), c.flags.data());
+    err = gs_match_submit(c.run, b.seq.data(), b.seq_off.data(), n, read_no, GS_MEM_HOST, rs.cls.data(), rs.flags.data());
     if (!err && c.kraken.active()) {
-        err = c.seg_off.resize((size_t)n + 1);
-        if (!err) err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, c.seg_off.data());
-        if (!err) err = c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
-        if (!err) err = c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
-        if (!err) err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
+        err = rs.seg_off.resize((size_t)n + 1);
+        if (!err) err = gs_match_segments(c.run, b.seq.data(), b.seq_off.data(), n, GS_MEM_HOST, rs.seg_off.data());
+        if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n]);
+        if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n]);
+        if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
     }
     c.t_gpu += now_s() - t0;
     if (err) return err;
@@ -348,14 +354,14 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
         p.filtered = c.filtered.take();
         p.kraken = c.kraken.take();
         for (int64_t i = lo; i < hi; i++) {
-            if (c.filtered.active() && (c.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
+            if (c.filtered.active() && (rs.flags[(size_t)i] & GS_F_RETURNED)) {  // afterMatch (:304-307)
                 append_read(p.filtered, b, i, c.opts->with_probs != 0);
                 p.n_filtered++;
             }
             if (c.kraken.active()) {
                 const size_t d0 = b.desc_off[(size_t)i], d1 = b.desc_off[(size_t)i + 1];
                 const int64_t L = (int64_t)(b.seq_off[(size_t)i + 1] - b.seq_off[(size_t)i]);
-                kraken_line(c, p.kraken, b.desc.data() + d0, d1 - d0, L, i);
+                kraken_line(c, rs, p.kraken, b.desc.data() + d0, d1 - d0, L, i);
             }
         }
         p.pack(c.kraken, c.filtered);
@@ -438,8 +444,16 @@ struct TextJob {
     int64_t base_tot[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
     bool done = false;
     double t0 = 0;
+    std::future<void> formatting;  // per-read outputs of the previous chunk on their way to the writers
+    int64_t n_formatted = 0;
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no) : c(ctx), path(p), bank(bank_), read_no(first_read_no) {}
+    ~TextJob() { abort(); }
+    // stops the readers (after the writers of the last chunk are through with its block)
+    void abort() {
+        drain();
+        tr.close();
+    }
 
     int open(bool gzip, int readers) {
         // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
@@ -467,6 +481,7 @@ struct TextJob {
     int step(bool blocking, int *err_out) {
         int err = GS_OK;
         const int64_t i = next_block;
+        bool keep_block = false;
         if (!blocking && !tr.is_full(i)) return 0;
         TextSlot &sl = tr.wait_full(i);
         int64_t fallback_off = -1, fallback_reads = 0;
@@ -496,20 +511,23 @@ struct TextJob {
                 uint8_t *start = blk - carry.size();
                 if (!carry.empty()) memcpy(start, carry.data(), carry.size());
                 int64_t ticket = -1;
+                bool format_it = false;
                 const bool per_read = c.filtered.active() || c.kraken.active();
                 const int64_t n_chunk = usable >> 2;
+                MatchCtx::Results &rs = c.res[n_formatted & 1];  // (the set of the chunk before last: its writers are done)
                 if (per_read) {
-                    err = c.cls.resize((size_t)n_chunk);
-                    if (!err) err = c.flags.resize((size_t)n_chunk);
+                    err = rs.cls.resize((size_t)n_chunk);
+                    if (!err) err = rs.flags.resize((size_t)n_chunk);
                 }
                 if (!err)
                     err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
-                                           per_read ? c.cls.data() : nullptr, per_read ? c.flags.data() : nullptr, &ticket);
-                if (!err && per_read) {  // the writers need this chunk's results now
+                                               per_read ? rs.cls.data() : nullptr, per_read ? rs.flags.data() : nullptr, &ticket);
+                if (!err && per_read) {  // the writers need this chunk's results
                     chunks.push_back({carry_file_off, reads_in_file, ticket});
                     err = check_refusal(&fallback_off, &fallback_reads);
                     chunks.pop_back();
-                    if (!err && fallback_off < 0) err = write_chunk_outputs(start, n_chunk);
+                    if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
+                    format_it = !err && fallback_off < 0;
                 }
                 if (!err && fallback_off < 0) {
                     if (first_ticket < 0) first_ticket = ticket;
@@ -520,12 +538,20 @@ struct TextJob {
                     carry_lines = rem;
                     err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
                 }
+                if (format_it && !err) {
+                    // (only now: the block returns to its reader when the writers are through with it, and the
+                    // carry above had to be taken out first)
+                    drain();  // one chunk at a time: output order, and the other result set becomes free
+                    n_formatted++;
+                    keep_block = true;
+                    formatting = std::async(std::launch::async, [this, &rs, start, n_chunk, i] { format_chunk(rs, start, n_chunk, i); });
+                }
                 // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
                 if (!err && fallback_off < 0 && !per_read && (chunks.size() == 1 || (chunks.size() & 15) == 0))
                     err = check_refusal(&fallback_off, &fallback_reads);
             }
         }
-        tr.release(i);
+        if (!keep_block) tr.release(i);  // (else: format_chunk releases it)
         next_block = i + 1;
         if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
         *err_out = err;
@@ -534,39 +560,49 @@ struct TextJob {
 
 private:
     // filtered FASTQ (afterMatch, :304-307) and Kraken-style lines (:723-756) of the chunk that was just matched, from
-    // the raw block: the device returns the record geometry (newline offsets) and the segments
-    int write_chunk_outputs(const uint8_t *text, int64_t n) {
-        int err = c.nl.resize((size_t)n * 4);
-        const uint32_t *nl = c.nl.data();
-        if (!err) err = gs_match_text_newlines(c.run, c.nl.data());
+    // the raw block: the device returns the record geometry (newline offsets) and the segments (fetch_chunk_results,
+    // on the submitting thread), the lines are formatted and handed to the writers on a thread of their own
+    // (format_chunk) while the next chunk is on the device; the chunk's block goes back to its reader afterwards
+    int fetch_chunk_results(MatchCtx::Results &rs, int64_t n) {
+        int err = rs.nl.resize((size_t)n * 4);
+        if (!err) err = gs_match_text_newlines(c.run, rs.nl.data());
         if (!err && c.kraken.active()) {
-            err = c.seg_off.resize((size_t)n + 1);
-            if (!err) err = gs_match_segments_text(c.run, c.seg_off.data());
-            if (!err) err = c.seg_code.resize((size_t)c.seg_off[(size_t)n]);
-            if (!err) err = c.seg_start.resize((size_t)c.seg_off[(size_t)n]);
-            if (!err) err = gs_match_segments_fetch(c.run, c.seg_code.data(), c.seg_start.data());
+            err = rs.seg_off.resize((size_t)n + 1);
+            if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
+            if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n]);
+            if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n]);
+            if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
         }
-        if (err) return err;
+        return err;
+    }
+
+    void format_chunk(const MatchCtx::Results &rs, const uint8_t *text, int64_t n, int64_t block) {
         std::vector<FormatPart> parts((size_t)c.pool.threads());
         MatchCtx &cc = c;
-        c.pool.run(n, [&cc, &parts, text, nl](int t, int64_t lo, int64_t hi) {
+        const uint32_t *nl = rs.nl.p;
+        c.pool.run(n, [&cc, &rs, &parts, text, nl](int t, int64_t lo, int64_t hi) {
             FormatPart &p = parts[(size_t)t];
             p.filtered = cc.filtered.take();
             p.kraken = cc.kraken.take();
             for (int64_t r = lo; r < hi; r++) {
-                if (cc.filtered.active() && (cc.flags[(size_t)r] & GS_F_RETURNED)) {
+                if (cc.filtered.active() && (rs.flags[(size_t)r] & GS_F_RETURNED)) {
                     append_text_record(p.filtered, text, nl, r, cc.opts->with_probs != 0);
                     p.n_filtered++;
                 }
                 if (cc.kraken.active()) {
                     const size_t d0 = r == 0 ? 0 : (size_t)nl[4 * r - 1] + 1, d1 = nl[4 * r];
-                    kraken_line(cc, p.kraken, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
+                    kraken_line(cc, rs, p.kraken, text + d0, d1 - d0, (int64_t)nl[4 * r + 1] - (int64_t)d1 - 1, r);
                 }
             }
             p.pack(cc.kraken, cc.filtered);
         });
         write_parts(c, parts);
-        return GS_OK;
+        tr.release(block);
+    }
+
+    // waits for the chunk that is being formatted (its result set and its block are free afterwards)
+    void drain() {
+        if (formatting.valid()) formatting.get();
     }
 
     int check_refusal(int64_t *fallback_off, int64_t *fallback_reads) {
@@ -583,6 +619,7 @@ private:
 
     int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
         done = true;
+        drain();
         tr.close();
         c.t_parse += now_s() - t0;
         if (err) return err;
@@ -644,7 +681,7 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
                 TextJob job(c, path, 0, read_no);
                 err = job.open(kind[(size_t)i] == 2, default_readers);
                 while (!err && !job.done) job.step(true, &err);
-                if (!job.done) job.tr.close();
+                if (!job.done) job.abort();
                 read_no = job.read_no;
             } else {
                 err = parsed_source(c, path, 0, nullptr, 0, read_no);
@@ -689,7 +726,7 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
             }
             if (!progressed && !active.empty()) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
-        for (auto &j : active) j->tr.close();
+        for (auto &j : active) j->abort();
     }
     reads_of_file_out = reads_of_file;
     *composite = side_by_side;
@@ -875,10 +912,12 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
         return err;
     }
     err = gs_filter_text_reset(c.bloom, 1);
-    // results of a chunk land in pinned memory: accept flags + newline offsets
-    uint8_t *h_acc = nullptr;
-    uint32_t *h_nl = nullptr;
-    size_t acc_cap = 0, nl_cap = 0;
+    // results of a chunk land in pinned memory: accept flags + newline offsets; two sets, so that the writers can work
+    // on one chunk (on a thread of their own) while the device is busy with the next
+    PinnedVec<uint8_t> acc_sets[2];
+    PinnedVec<uint32_t> nl_sets[2];
+    std::future<void> formatting;
+    int64_t n_formatted = 0;
     std::vector<uint8_t> carry;
     int64_t carry_lines = 0, carry_file_off = 0, fallback_off = -1;
     int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
@@ -894,6 +933,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
         const int64_t total = carry_lines + sl.newlines;
         const int64_t rem = total & 3, usable = total - rem;
         const bool eof = sl.eof;
+        bool keep_block = false;
         if (usable == 0) {
             carry.insert(carry.end(), blk, blk + sl.n);
             carry_lines = total;
@@ -905,22 +945,10 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
             uint8_t *start = blk - carry.size();
             if (!carry.empty()) memcpy(start, carry.data(), carry.size());
             const int64_t n_reads = usable >> 2;
-            if (acc_cap < (size_t)n_reads) {
-                gs_pinned_free(h_acc);
-                h_acc = nullptr;
-                acc_cap = (size_t)n_reads + (size_t)n_reads / 4;
-                void *p = nullptr;
-                if ((err = gs_pinned_alloc(&p, acc_cap))) break;
-                h_acc = (uint8_t *)p;
-            }
-            if (nl_cap < (size_t)usable) {
-                gs_pinned_free(h_nl);
-                h_nl = nullptr;
-                nl_cap = (size_t)usable + (size_t)usable / 4;
-                void *p = nullptr;
-                if ((err = gs_pinned_alloc(&p, nl_cap * sizeof(uint32_t)))) break;
-                h_nl = (uint32_t *)p;
-            }
+            if ((err = acc_sets[n_formatted & 1].resize((size_t)n_reads))) break;  // (the set of the chunk before last)
+            if ((err = nl_sets[n_formatted & 1].resize((size_t)usable))) break;
+            uint8_t *h_acc = acc_sets[n_formatted & 1].data();
+            uint32_t *h_nl = nl_sets[n_formatted & 1].data();
             int64_t ticket = -1;
             const double tg = now_s();
             err = gs_filter_submit_text(c.bloom, c.k, c.min_pos_count, c.positive_ratio, start, (int64_t)carry.size() + cut + 1,
@@ -931,32 +959,38 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
             if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
                 fallback_off = carry_file_off;
             } else {
-                std::vector<FilterPart> parts((size_t)c.pool.threads());
-                c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
-                    FilterPart &p = parts[(size_t)t];
-                    p.acc = c.acc_out.take();
-                    p.rest = c.rest_out.take();
-                    for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-                        if (h_acc[r]) {
-                            p.n_accepted++;
-                            if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r, c.with_probs);
-                        } else if (c.rest_out.active())
-                            append_text_record(p.rest, start, h_nl, r, c.with_probs);
-                    }
-                    p.pack(c.acc_out, c.rest_out);
-                });
-                write_filter_parts(c, parts);
+                // (the carry is taken out first: the block returns to its reader when the writers are through with it)
                 carry_file_off = i * (int64_t)tr.block + cut + 1;
                 carry.assign(blk + cut + 1, blk + sl.n);
                 carry_lines = rem;
+                if (formatting.valid()) formatting.get();  // one chunk at a time: output order, the other set is free
+                n_formatted++;
+                keep_block = true;
+                formatting = std::async(std::launch::async, [&c, &tr, h_acc, h_nl, start, n_reads, i] {
+                    std::vector<FilterPart> parts((size_t)c.pool.threads());
+                    c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
+                        FilterPart &p = parts[(size_t)t];
+                        p.acc = c.acc_out.take();
+                        p.rest = c.rest_out.take();
+                        for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                            if (h_acc[r]) {
+                                p.n_accepted++;
+                                if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r, c.with_probs);
+                            } else if (c.rest_out.active())
+                                append_text_record(p.rest, start, h_nl, r, c.with_probs);
+                        }
+                        p.pack(c.acc_out, c.rest_out);
+                    });
+                    write_filter_parts(c, parts);
+                    tr.release(i);  // the block goes back to its reader
+                });
             }
         }
-        tr.release(i);
+        if (!keep_block) tr.release(i);
         if (eof || fallback_off >= 0) break;
     }
+    if (formatting.valid()) formatting.get();
     tr.close();
-    gs_pinned_free(h_acc);
-    gs_pinned_free(h_nl);
     c.t_parse += now_s() - t0;
     if (err) return err;
     c.reads += tot[0];
