@@ -131,11 +131,32 @@ extern "C" int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size
 extern "C" int gs_host_gunzip_parallel(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, int threads,
                                        size_t chunk, size_t block) {
     if ((!in && n_in) || !out || !n_out || threads < 1 || block == 0) return hfail(GS_E_INVALID, "bad argument");
-    GsParallelGunzip pg;
-    pg.start(in, n_in, threads, chunk);
     size_t total = 0;
-    bool done = false;
     std::vector<uint8_t> spill(block);
+    // BGZF blocks are inflated side by side (GsBgzfReader); ordinary members (behind them, or the whole file) go
+    // through the speculative decoder -- the same hand-over as in the file pipeline (TextReader::start_gzip)
+    size_t from = 0;
+    if (GsBgzfReader::looks_like(in, n_in)) {
+        GsBgzfReader bg(in, n_in, threads);
+        bool done = false;
+        while (!done) {
+            uint8_t *dst = total < out_cap ? out + total : spill.data();
+            const size_t room = total < out_cap ? std::min(block, out_cap - total) : block;
+            size_t p = 0;
+            if (!bg.read(dst, room, &p, &done)) return hfail(GS_E_INVALID, "corrupt gzip stream");
+            if (dst == spill.data() && p > 0) return hfail(GS_E_NOMEM, "output buffer too small");
+            total += p;
+        }
+        from = bg.rest_offset();
+        if (!(from < n_in && n_in - from >= 10 && in[from] == 0x1f && in[from + 1] == 0x8b)) from = n_in;  // trailing garbage
+        if (from >= n_in) {
+            *n_out = total;
+            return GS_OK;
+        }
+    }
+    GsParallelGunzip pg;
+    pg.start(in + from, n_in - from, threads, chunk);
+    bool done = false;
     while (!done) {
         uint8_t *dst = total < out_cap ? out + total : spill.data();
         const size_t room = total < out_cap ? std::min(block, out_cap - total) : block;
@@ -665,6 +686,9 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
         n_gzip += kind[(size_t)i] == 2;
     }
     const int default_readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    // one gzip file at a time: its inflating threads are all the parallelism there is (measured on the MI355X box,
+    // tools/gz_threads_sweep.py: 8 threads 1.7 Gbp/s, 12 2.3, 16 2.9, 24 3.3)
+    const int gzip_threads = (int)std::min<unsigned>(16, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
     // Several gzip files: each is bound by its single inflating thread, so they are read side by side (up to 8 at a
     // time).  The read numbers of file f then start at f << 32, which keeps "first read in file order" (the max-contig
     // tie-break) intact; the column is converted back to running read numbers at the end.
@@ -679,7 +703,7 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
             const std::string path(paths[i]);
             if (kind[(size_t)i]) {
                 TextJob job(c, path, 0, read_no);
-                err = job.open(kind[(size_t)i] == 2, default_readers);
+                err = job.open(kind[(size_t)i] == 2, kind[(size_t)i] == 2 ? gzip_threads : default_readers);
                 while (!err && !job.done) job.step(true, &err);
                 if (!job.done) job.abort();
                 read_no = job.read_no;
@@ -900,7 +924,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
         const long long v = atoll(e);
         if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
     }
-    int readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    int readers = (int)std::min<unsigned>(gzip ? 16 : 8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
     if (const char *e = getenv("GS_HOST_READERS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 32) readers = v;

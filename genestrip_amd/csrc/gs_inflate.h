@@ -1148,3 +1148,133 @@ private:
         item.c = nullptr;
     }
 };
+
+// ---------------------------------------------------------------------------------------------------
+// BGZF (SAM/BAM spec 4.1; bgzip, htslib, many sequencing pipelines): a gzip file whose members are blocks of at most
+// 64 KiB of text and say how long they are -- an extra subfield 'B' 'C' holds the compressed size of the member --
+// so the blocks of a buffer can be found without decoding and inflated independently: no speculative starts, no
+// marker symbols, no second pass.  read() delivers the next bytes of the stream like GsParallelGunzip::read(), with
+// the CRC-32 and ISIZE of every block checked by the thread that inflates it.  A member that is not a BGZF block ends
+// this reader's part of the file: *done is set and rest_offset() says where the general decoder has to go on.
+// ---------------------------------------------------------------------------------------------------
+#include "gs_pool.h"
+
+class GsBgzfReader {
+public:
+    // a BGZF block at in[o .. o + *block_len): gzip member with FEXTRA and a 'BC' subfield of two bytes (BSIZE)
+    static bool block_at(const uint8_t *in, size_t n, size_t o, size_t *block_len, uint32_t *isize) {
+        if (o > n || n - o < 28) return false;  // the empty block (end-of-file marker) has 28 bytes
+        const uint8_t *p = in + o;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 4) == 0) return false;
+        const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+        if (n - o < 12 + xlen + 10) return false;
+        size_t bsize = 0;
+        bool found = false;
+        for (size_t q = 12; q + 4 <= 12 + xlen;) {
+            const size_t slen = (size_t)p[q + 2] | ((size_t)p[q + 3] << 8);
+            if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+                bsize = (size_t)p[q + 4] | ((size_t)p[q + 5] << 8);
+                found = true;
+            }
+            q += 4 + slen;
+        }
+        if (!found) return false;
+        const size_t len = bsize + 1;
+        if (len < 12 + xlen + 10 || len > n - o) return false;
+        const uint8_t *t = p + len - 4;
+        const uint32_t sz = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (sz > 65536) return false;
+        *block_len = len;
+        *isize = sz;
+        return true;
+    }
+    static bool looks_like(const uint8_t *in, size_t n) {
+        size_t len;
+        uint32_t isize;
+        return block_at(in, n, 0, &len, &isize);
+    }
+
+    GsBgzfReader(const uint8_t *in, size_t n_in, int threads) : in_(in), n_(n_in), pool_(threads), dec_((size_t)std::max(1, threads)) {}
+
+    // first byte of the input this reader did not take (== n_in when the whole file was BGZF)
+    size_t rest_offset() const { return pos_; }
+
+    // up to cap bytes of the decoded stream into out; *done: this reader's part of the file is through (see
+    // rest_offset()).  Returns false on corruption (a block that does not inflate to its ISIZE / CRC-32).
+    bool read(uint8_t *out, size_t cap, size_t *produced, bool *done) {
+        size_t got = 0;
+        *done = false;
+        if (spill_at_ < spill_.size()) {  // the rest of a block that did not fit the previous buffer
+            const size_t m = std::min(cap, spill_.size() - spill_at_);
+            memcpy(out, spill_.data() + spill_at_, m);
+            spill_at_ += m;
+            got = m;
+        }
+        tasks_.clear();
+        size_t off = got;
+        bool spilled = false;
+        while (off < cap && !ended_) {
+            size_t len;
+            uint32_t isize;
+            if (pos_ >= n_ || !block_at(in_, n_, pos_, &len, &isize)) {
+                ended_ = true;
+                break;
+            }
+            if (isize <= cap - off) {
+                tasks_.push_back({pos_, len, out + off, isize});
+                off += isize;
+                pos_ += len;
+            } else {  // does not fit any more: decoded on the side, handed out in two parts
+                spill_.resize(isize);
+                spill_at_ = 0;
+                tasks_.push_back({pos_, len, spill_.data(), isize});
+                pos_ += len;
+                spilled = true;
+                break;
+            }
+        }
+        std::atomic<bool> ok{true};
+        pool_.run((int64_t)tasks_.size(), [&](int t, int64_t lo, int64_t hi) {
+            GsInflate &d = dec_[(size_t)t];
+            for (int64_t i = lo; i < hi && ok.load(std::memory_order_relaxed); i++) {
+                const Task &k = tasks_[(size_t)i];
+                uint8_t dummy;
+                size_t p = 0;
+                d.init(in_ + k.pos, k.len, true);
+                GsInflate::Status st = d.decode(k.isize ? k.out : &dummy, k.isize ? k.isize : 1, 0, &p);
+                if (st == GsInflate::NEED_OUTPUT && p == k.isize && k.isize) {
+                    // the text is complete, the end-of-block symbol and the trailer are still to come
+                    size_t more = 0;
+                    st = d.decode(&dummy, 1, 0, &more);
+                    p += more;
+                }
+                if (st != GsInflate::DONE || p != k.isize) ok = false;
+            }
+        }, 4);
+        if (!ok) return false;
+        if (spilled) {
+            const size_t m = std::min(cap - off, spill_.size());
+            memcpy(out + off, spill_.data(), m);
+            spill_at_ = m;
+            off += m;
+        }
+        *produced = off;
+        *done = ended_ && spill_at_ >= spill_.size();
+        return true;
+    }
+
+private:
+    struct Task {
+        size_t pos, len;
+        uint8_t *out;
+        uint32_t isize;
+    };
+    const uint8_t *in_;
+    size_t n_, pos_ = 0;
+    GsRangePool pool_;
+    std::vector<GsInflate> dec_;
+    std::vector<Task> tasks_;
+    std::vector<uint8_t> spill_;
+    size_t spill_at_ = 0;
+    bool ended_ = false;
+};

@@ -5,6 +5,7 @@
 #pragma once
 #include "../../include/gshost.h"
 #include "gs_inflate.h"
+#include "gs_pool.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -12,6 +13,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -279,9 +283,31 @@ inline std::string java_double(double v) {
 
 // ---- fast path for plain four-line FASTQ: reader threads fill pinned blocks, the device finds the records -----------
 // (gs_match_submit_text).  The host only counts newlines to cut the stream at record boundaries.
+// newlines in p[0, n): 16 bytes per step where SSE2 is there (every x86-64); the readers of the file pipelines run this
+// over everything they read, so a byte-at-a-time loop (3 GB/s) would be what bounds them
 inline size_t count_newlines(const uint8_t *p, size_t n) {
-    size_t c = 0;
-    for (size_t i = 0; i < n; i++) c += p[i] == '\n';  // vectorised by the compiler
+    size_t c = 0, i = 0;
+#if defined(__SSE2__)
+    const __m128i nl = _mm_set1_epi8('\n'), zero = _mm_setzero_si128();
+    __m128i total = zero;
+    while (n - i >= 16) {
+        // byte counters take 255 steps before they could overflow; two independent chains
+        size_t steps = (n - i) / 32;
+        if (steps > 255) steps = 255;
+        __m128i a = zero, b = zero;
+        for (size_t s = 0; s < steps; s++, i += 32) {
+            a = _mm_sub_epi8(a, _mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl));
+            b = _mm_sub_epi8(b, _mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 16)), nl));
+        }
+        if (steps == 0) {
+            a = _mm_sub_epi8(a, _mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl));
+            i += 16;
+        }
+        total = _mm_add_epi64(total, _mm_add_epi64(_mm_sad_epu8(a, zero), _mm_sad_epu8(b, zero)));
+    }
+    c = (size_t)_mm_cvtsi128_si64(total) + (size_t)_mm_cvtsi128_si64(_mm_unpackhi_epi64(total, total));
+#endif
+    for (; i < n; i++) c += p[i] == '\n';
     return c;
 }
 
@@ -290,7 +316,7 @@ struct TextSlot {
     size_t n = 0;            // bytes read into the block
     int64_t newlines = 0;
     int64_t last4[4] = {-1, -1, -1, -1};  // offsets of the last four newlines of the block, last first
-    int state = 0;           // 0 empty, 1 full
+    int state = 0;           // 0 empty, 1 full, 2 decoded (gzip input: its newlines are still to be counted)
     bool eof = false, io_error = false;
     struct GzEnd {
         uint32_t offset, crc, isize;  // gzip input: a member ended at this offset of the block; CRC-32 / ISIZE of its trailer
@@ -356,6 +382,7 @@ struct TextReader {
     const uint8_t *map = nullptr;
     size_t map_len = 0;
     uint32_t run_crc = 0;
+    bool consumer_checks_crc = false;  // gzip input: verify_gzip() runs the CRC-32 over the delivered blocks
     uint64_t run_size = 0;
     int gz_threads_hint = 0;
 
@@ -419,17 +446,33 @@ struct TextReader {
     void start_gzip() {
         int gz_threads = gz_threads_hint > 0 ? gz_threads_hint : (int)std::min<unsigned>(8, std::thread::hardware_concurrency() / 2);
         if (const char *e = getenv("GS_GZ_THREADS")) gz_threads = std::max(1, std::min(32, atoi(e)));
-        threads.emplace_back([this, gz_threads] {
+        bool use_bgzf = GsBgzfReader::looks_like(map, map_len);
+        if (const char *e = getenv("GS_BGZF")) use_bgzf = use_bgzf && atoi(e) != 0;
+        // only the one-thread decoder leaves the CRC-32 to the consumer of the blocks (verify_gzip); the multi-threaded
+        // readers check it themselves, and running it again there would bound the whole pipeline by one core's CRC rate
+        consumer_checks_crc = !use_bgzf && !(gz_threads >= 2 && map_len >= ((size_t)1 << 20));
+        threads.emplace_back([this, gz_threads, use_bgzf] {
             std::unique_ptr<GsInflate> inf;
             std::unique_ptr<GsParallelGunzip> par;
+            std::unique_ptr<GsBgzfReader> bgzf;  // blocks that say how long they are: inflated side by side
             std::vector<GsParallelGunzip::MemberEnd> ends;
-            if (gz_threads >= 2 && map_len >= ((size_t)1 << 20)) {
-                par.reset(new GsParallelGunzip());
-                par->start(map, map_len, gz_threads, (size_t)1 << 20);
-            } else {
-                inf.reset(new GsInflate());
-                inf->init(map, map_len, false);
-            }
+            // the general decoders, for the file from `from` on
+            auto start_general = [&](size_t from) {
+                if (gz_threads >= 2 && map_len - from >= ((size_t)1 << 20)) {
+                    par.reset(new GsParallelGunzip());
+                    par->start(map + from, map_len - from, gz_threads, (size_t)1 << 20);
+                } else {
+                    // (from the start of the file the consumer of the blocks runs the CRC-32, verify_gzip; behind
+                    // BGZF blocks the decoder checks it itself)
+                    inf.reset(new GsInflate());
+                    inf->init(map + from, map_len - from, from != 0);
+                }
+            };
+            if (use_bgzf)
+                bgzf.reset(new GsBgzfReader(map, map_len, gz_threads));
+            else
+                start_general(0);
+
             std::vector<uint8_t> window(32768);
             size_t hist = 0;
             bool done = map_len == 0;
@@ -444,6 +487,26 @@ struct TextReader {
                 size_t got = 0;
                 bool err = false;
                 sl.member_ends.clear();
+                if (bgzf) {
+                    while (!done && !err && got < block) {
+                        size_t p = 0;
+                        bool fin = false;
+                        if (!bgzf->read(dst + got, block - got, &p, &fin)) err = true;  // (checks CRC-32 / ISIZE itself)
+                        got += p;
+                        if (fin) {
+                            const size_t rest = bgzf->rest_offset();
+                            bgzf.reset();
+                            // ordinary gzip members may follow the BGZF blocks; anything that does not even start like
+                            // a member is trailing garbage, which the general decoder ignores as well
+                            if (rest < map_len && map_len - rest >= 10 && map[rest] == 0x1f && map[rest + 1] == 0x8b)
+                                start_general(rest);
+                            else
+                                done = true;
+                            break;
+                        }
+                        if (p == 0 && !err) err = true;
+                    }
+                }
                 if (par) {
                     while (!done && !err && got < block) {
                         size_t p = 0;
@@ -454,7 +517,7 @@ struct TextReader {
                         if (fin) done = true;
                         if (p == 0 && !fin && !err) err = true;  // (cannot happen: read() blocks until it has bytes)
                     }
-                } else {
+                } else if (inf) {
                     memcpy(dst - hist, window.data() + (32768 - hist), hist);
                     while (!done && got < block) {
                         size_t p = 0;
@@ -475,20 +538,37 @@ struct TextReader {
                 sl.n = got;
                 sl.eof = got < block || done;
                 sl.io_error = err;
-                fill_newlines(sl, dst, got);
                 {
                     std::lock_guard<std::mutex> l(m);
-                    sl.state = 1;
+                    sl.state = 2;  // the thread below counts the newlines while this one goes on decoding
                 }
                 cv.notify_all();
                 if (sl.eof || err) break;
             }
             if (par) par->stop();
         });
+        threads.emplace_back([this] {
+            for (int64_t i = 0;; i++) {
+                TextSlot &sl = slots[(size_t)(i % n_slots)];
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return stop || sl.state == 2; });
+                    if (stop) break;
+                }
+                fill_newlines(sl, sl.buf + headroom, sl.n);
+                const bool last = sl.eof || sl.io_error;
+                {
+                    std::lock_guard<std::mutex> l(m);
+                    sl.state = 1;
+                }
+                cv.notify_all();
+                if (last) break;
+            }
+        });
     }
     // consumer side: CRC-32 of the gzip members over the delivered block (GZIPInputStream checks it while reading)
     bool verify_gzip(const TextSlot &sl) {
-        if (!gz) return true;
+        if (!gz || !consumer_checks_crc) return true;
         const uint8_t *p = sl.buf + headroom;
         size_t at = 0;
         for (const auto &me : sl.member_ends) {
@@ -739,67 +819,7 @@ private:
     std::atomic<bool> failed_{false};
 };
 
-// A few threads that format the per-read outputs of a batch: run(n, f) calls f(t, lo, hi) for contiguous ranges of
-// [0, n), range t on worker t, the last one on the caller's thread, and returns when all are done.  Small inputs run
-// inline.  (Threads are kept: a chunk is formatted in well under a millisecond, less than starting them would take.)
-class FormatPool {
-public:
-    explicit FormatPool(int threads) : n_(std::max(1, threads)) {}
-    int threads() const { return n_; }
-    template <class F>
-    void run(int64_t n, F f) {
-        const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_, n / 1024));
-        if (T == 1) {
-            f(0, (int64_t)0, n);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> l(m_);
-            if (th_.empty())
-                for (int t = 0; t + 1 < n_; t++) th_.emplace_back([this, t] { worker(t); });
-            job_ = [&f, n, T](int t) { f(t, n * t / T, n * (t + 1) / T); };
-            active_ = T - 1;
-            pending_ = T - 1;
-            gen_++;
-        }
-        cv_.notify_all();
-        f(T - 1, n * (T - 1) / T, n);
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [&] { return pending_ == 0; });
-    }
-    ~FormatPool() {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &x : th_) x.join();
-    }
-
-private:
-    void worker(int t) {
-        uint64_t seen = 0;
-        for (;;) {
-            std::unique_lock<std::mutex> l(m_);
-            cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-            if (stop_) return;
-            seen = gen_;
-            if (t >= active_) continue;
-            l.unlock();
-            job_(t);
-            l.lock();
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    const int n_;
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    std::function<void(int)> job_;
-    uint64_t gen_ = 0;
-    int active_ = 0, pending_ = 0;
-    bool stop_ = false;
-};
+typedef GsRangePool FormatPool;
 
 inline int format_threads() {
     int t = (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));

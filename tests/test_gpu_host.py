@@ -379,6 +379,33 @@ def test_with_probs_keeps_the_quality_lines(sdb, tmp_path, monkeypatch, fast):
     store.close()
 
 
+def test_bgzf_input_equals_plain_input(sdb, tmp_path):
+    """a BGZF file (bgzip) is inflated block-parallel; table, totals and per-read outputs equal those of the plain file,
+    also when ordinary gzip members follow the blocks"""
+    from conftest import bgzf
+    data = b"".join(_fastq_bytes(sdb, 30000, seed=61))
+    more = b"".join(_fastq_bytes(sdb, 2000, seed=62))
+    plain, packed, mixed = str(tmp_path / "a.fastq"), str(tmp_path / "a.fastq.gz"), str(tmp_path / "m.fastq.gz")
+    open(plain, "wb").write(data)
+    open(packed, "wb").write(bgzf(data))
+    open(mixed, "wb").write(bgzf(data, eof_marker=False) + gzip.compress(more))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    t0, _, tot0 = host.match_files(store, [plain], kraken_out_path=str(tmp_path / "k0"), taxids=sdb.taxids)
+    t1, _, tot1 = host.match_files(store, [packed], kraken_out_path=str(tmp_path / "k1"), taxids=sdb.taxids)
+    assert np.array_equal(t0, t1) and (tot0.reads, tot0.kmers, tot0.bps) == (tot1.reads, tot1.kmers, tot1.bps)
+    assert open(str(tmp_path / "k0"), "rb").read() == open(str(tmp_path / "k1"), "rb").read()
+    open(plain, "wb").write(data + more)
+    t2, _, tot2 = host.match_files(store, [plain])
+    t3, _, tot3 = host.match_files(store, [mixed])
+    assert np.array_equal(t2, t3) and tot2.reads == tot3.reads == 32000
+    bad = bytearray(bgzf(data))
+    bad[len(bad) // 2] ^= 0x20
+    open(packed, "wb").write(bytes(bad))
+    with pytest.raises(RuntimeError):
+        host.match_files(store, [packed])
+    store.close()
+
+
 def test_gzip_outputs_are_multi_member_and_round_trip(sdb, tmp_path):
     """.gz outputs are compressed by the formatting threads, one gzip member per part: the content must equal the
     plain outputs, and the library's own gzip reader must take the file back"""

@@ -231,6 +231,45 @@ def test_parallel_gunzip_equals_zlib(threads, chunk):
         host.gunzip_parallel(bytes(_gz(big, 6)[:-20]), len(big) + 100_000, threads, chunk)
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+def test_bgzf_blocks_are_inflated_side_by_side(threads):
+    from conftest import bgzf as _bgzf
+    """BGZF input (blocks that say how long they are) takes the block-parallel reader; ordinary members behind the blocks,
+    trailing garbage, odd buffer sizes and damage must behave exactly as with the general decoder"""
+    import gzip as gz
+    d = _gz_inputs()
+    data = d["fastq"] * 5 + d["random"] + d["mixed"] * 2
+    for kw in (dict(), dict(block=4000, level=1), dict(eof_marker=False), dict(extra_subfield=True), dict(block=60000, level=0)):
+        raw = _bgzf(data, **kw)
+        assert gz.decompress(raw) == data
+        for room in (1 << 20, 77_777, 65_536, 10_007):
+            assert host.gunzip_parallel(raw, len(data), threads, 1 << 16, room) == data, (kw, room)
+    assert host.gunzip_parallel(_bgzf(b""), 10, threads) == b""
+    # ordinary members behind the blocks (the general decoder takes over), then trailing garbage
+    tail = d["mixed"] * 30
+    mixed = _bgzf(data, eof_marker=False) + _gz(tail, 6) + _bgzf(d["fastq"])
+    assert host.gunzip_parallel(mixed, len(data) + len(tail) + len(d["fastq"]), threads, 1 << 16, 50_000) == data + tail + d["fastq"]
+    assert host.gunzip_parallel(_bgzf(data) + b"\0" * 100, len(data), threads) == data
+    # damage: a flipped bit in the text of a block, a wrong CRC, a wrong ISIZE, a truncated last block
+    raw = bytearray(_bgzf(data))
+    for pos in (len(raw) // 2, 40):
+        bad = bytearray(raw)
+        bad[pos] ^= 0x10
+        with pytest.raises(RuntimeError):
+            host.gunzip_parallel(bytes(bad), len(data) + 70_000, threads)
+    first_len = int.from_bytes(raw[16:18], "little") + 1
+    bad = bytearray(raw)
+    bad[first_len - 8] ^= 1       # CRC-32 of the first block
+    with pytest.raises(RuntimeError):
+        host.gunzip_parallel(bytes(bad), len(data) + 70_000, threads)
+    bad = bytearray(raw)
+    bad[first_len - 4] ^= 1       # its ISIZE
+    with pytest.raises(RuntimeError):
+        host.gunzip_parallel(bytes(bad), len(data) + 70_000, threads)
+    with pytest.raises(RuntimeError):
+        host.gunzip_parallel(bytes(raw[:len(raw) - 40]), len(data) + 70_000, threads)
+
+
 def test_gunzip_survives_random_damage():
     """random damage to the compressed bytes must end in an error (or, for bytes that do not matter such as the header's
     timestamp, in the exact data) -- never in a crash, a hang or silently different data"""

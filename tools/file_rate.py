@@ -57,4 +57,21 @@ if len(sys.argv) > 2 and sys.argv[2] == "gz":
         shutil.copyfileobj(fi, fo, 1 << 24)
     print(f"gzip -1: {time.perf_counter() - t0:.1f} s, {os.path.getsize(gz) / 1e9:.2f} GB", flush=True)
     run(gz, "gzip FASTQ")
+if len(sys.argv) > 2 and sys.argv[2] == "bgzf":  # what bgzip writes: members of <= 64 KiB that say how long they are
+    import struct
+    import zlib
+    bz = path + ".bgzf.gz"
+    t0 = time.perf_counter()
+    with open(path, "rb") as fi, open(bz, "wb") as fo:
+        while True:
+            c = fi.read(65280)
+            z = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = z.compress(c) + z.flush()
+            fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(body) + 8 - 1) + body +
+                     struct.pack("<II", zlib.crc32(c), len(c)))
+            if not c:
+                break
+    print(f"bgzf -1: {time.perf_counter() - t0:.1f} s, {os.path.getsize(bz) / 1e9:.2f} GB", flush=True)
+    run(bz, "BGZF FASTQ")
+    run(bz, "BGZF FASTQ (again)")
 shutil.rmtree(d)
