@@ -515,8 +515,14 @@ extern "C" int gs_db_destroy(gs_db *db) {
 // ---------------------------------------------------------------------------------------------------
 // device state of the text mode (raw FASTQ chunk -> records, gs_text.hip); one per run / per filter handle
 struct TextScan {
+    // the chunk's bytes on the device: two buffers, filled by turns on a stream of their own, so that the copy of chunk
+    // i+1 runs while the kernels of chunk i work on the other buffer.  d_text = the buffer of the latest chunk.
     uint8_t *d_text = nullptr;
-    size_t text_cap = 0;
+    uint8_t *d_buf[2] = {nullptr, nullptr};
+    size_t buf_cap[2] = {0, 0};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t done[2] = {};       // the kernels that read d_buf[b] have been issued up to here (on the owner's stream)
+    bool done_valid[2] = {false, false};
     uint32_t *d_tile = nullptr, *d_nl = nullptr;
     size_t tile_cap = 0, nl_cap = 0;
     u64 *d_off2 = nullptr;
@@ -572,7 +578,14 @@ struct gs_run {
 
 
 static void text_free(TextScan &t) {
-    hipFree(t.d_text);
+    if (t.copy_stream) {
+        hipStreamSynchronize(t.copy_stream);
+        hipStreamDestroy(t.copy_stream);
+    }
+    for (hipEvent_t ev : t.done)
+        if (ev) hipEventDestroy(ev);
+    hipFree(t.d_buf[0]);
+    hipFree(t.d_buf[1]);
     hipFree(t.d_tile);
     hipFree(t.d_nl);
     hipFree(t.d_off2);
@@ -631,18 +644,27 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
         int rc = text_reset(t, true, stream, true);
         if (rc) return rc;
         for (hipEvent_t &ev : t.copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (hipEvent_t &ev : t.done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
     }
     const int64_t n_reads = n_lines >> 2;
     const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
+    const int64_t tk = t.tickets;
+    const int b = (int)(tk & 1);
     int rc;
-    if ((rc = grow(&t.d_text, &t.text_cap, padded + 4096, stream))) return rc;
+    if (t.buf_cap[b] < padded + 4096) HIP_TRY(hipStreamSynchronize(t.copy_stream));  // (grow() waits for `stream` itself)
+    if ((rc = grow(&t.d_buf[b], &t.buf_cap[b], padded + 4096, stream))) return rc;
     if ((rc = grow(&t.d_tile, &t.tile_cap, padded / 4096 + 1, stream))) return rc;
     if ((rc = grow(&t.d_nl, &t.nl_cap, (size_t)n_lines + 4, stream))) return rc;
     if ((rc = grow(&t.d_off2, &t.off2_cap, 2 * (size_t)n_reads + 2, stream))) return rc;
-    const int64_t tk = t.tickets;
+    t.d_text = t.d_buf[b];
+    // the copy waits for the kernels of the chunk before last (they read this buffer), the scan for the copy
+    if (t.done_valid[b]) HIP_TRY(hipStreamWaitEvent(t.copy_stream, t.done[b], 0));
     if (n_bytes > 0)
-        HIP_TRY(hipMemcpyAsync(t.d_text, text, (size_t)n_bytes, mem == GS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipEventRecord(t.copied[tk & 7], stream));
+        HIP_TRY(hipMemcpyAsync(t.d_text, text, (size_t)n_bytes, mem == GS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                               t.copy_stream));
+    HIP_TRY(hipEventRecord(t.copied[tk & 7], t.copy_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, t.copied[tk & 7], 0));
     if (padded > (size_t)n_bytes) HIP_TRY(hipMemsetAsync(t.d_text + n_bytes, ' ', padded - (size_t)n_bytes, stream));
     GsTextParams T{};
     T.text = t.d_text;
@@ -656,10 +678,20 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     T.status = t.d_status + (size_t)t.bank * GS_TS_WORDS;
     T.k = k;
     HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
+    HIP_TRY(hipEventRecord(t.done[b], stream));
+    t.done_valid[b] = true;
     t.tickets = tk + 1;
     t.last_reads = n_reads;
     t.last_lines = n_lines;
     if (ticket) *ticket = tk;
+    return GS_OK;
+}
+
+// to be called after every launch on `stream` that reads the latest chunk's bytes (match / filter / segment kernels):
+// the buffer may be overwritten by the chunk after next only when these are through
+static int text_touched(TextScan &t, hipStream_t stream) {
+    if (t.tickets == 0) return GS_OK;
+    HIP_TRY(hipEventRecord(t.done[(t.tickets - 1) & 1], stream));
     return GS_OK;
 }
 
@@ -965,6 +997,7 @@ extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_
     rc = launch_batch(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
                       run->text.d_status + (size_t)run->text.bank * GS_TS_WORDS + GS_TS_SKIP);
     if (rc) return rc;
+    if ((rc = text_touched(run->text, run->stream))) return rc;
     if (!dev_out) {  // complete after gs_match_sync
         if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
@@ -1291,7 +1324,9 @@ extern "C" int gs_match_segments_text(gs_run *run, uint64_t *seg_off) {
     const int64_t n_reads = run->text.last_reads;
     if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
     if (n_reads == 0) return GS_OK;
-    return segments_core(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, 2, seg_off);
+    const int rc = segments_core(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, 2, seg_off);
+    if (rc) return rc;
+    return text_touched(run->text, run->stream);
 }
 
 // newline offsets of the most recent text chunk (the record geometry for per-read writers); synchronises
@@ -1606,6 +1641,7 @@ extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, doub
     rc = filter_launch(b, k, min_pos_count, positive_ratio, b->text.d_text, (const uint64_t *)b->text.d_off2, n_reads, d_acc, 2,
                        b->text.d_status + (size_t)b->text.bank * GS_TS_WORDS + GS_TS_SKIP, profile);
     if (rc) return rc;
+    if ((rc = text_touched(b->text, b->stream))) return rc;
     const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (!dev_out) HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, kind, b->stream));
     if (newlines) HIP_TRY(hipMemcpyAsync(newlines, b->text.d_nl, sizeof(uint32_t) * (size_t)n_lines, kind, b->stream));

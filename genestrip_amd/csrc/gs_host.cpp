@@ -467,12 +467,14 @@ struct TextJob {
     double t0 = 0;
     std::future<void> formatting;  // per-read outputs of the previous chunk on their way to the writers
     int64_t n_formatted = 0;
+    int64_t held_ticket = -1, held_block = -1;
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no) : c(ctx), path(p), bank(bank_), read_no(first_read_no) {}
     ~TextJob() { abort(); }
     // stops the readers (after the writers of the last chunk are through with its block)
     void abort() {
         drain();
+        release_held();
         tr.close();
     }
 
@@ -557,7 +559,16 @@ struct TextJob {
                     carry_file_off = i * (int64_t)tr.block + cut + 1;
                     carry.assign(blk + cut + 1, blk + sl.n);
                     carry_lines = rem;
-                    err = gs_match_text_wait_copy(c.run, ticket);  // the pinned block goes back to its reader
+                    if (format_it) {
+                        err = gs_match_text_wait_copy(c.run, ticket);  // (the writers hand the block back, below)
+                    } else {
+                        // the pinned block goes back to its reader when its copy is through: looked at one chunk later,
+                        // so that this thread is already submitting the next copy while this one runs
+                        err = release_held();
+                        held_ticket = ticket;
+                        held_block = i;
+                        keep_block = true;
+                    }
                 }
                 if (format_it && !err) {
                     // (only now: the block returns to its reader when the writers are through with it, and the
@@ -625,6 +636,14 @@ private:
     void drain() {
         if (formatting.valid()) formatting.get();
     }
+    // the block whose copy to the device was still running when the thread went on
+    int release_held() {
+        if (held_ticket < 0) return GS_OK;
+        const int err = gs_match_text_wait_copy(c.run, held_ticket);
+        tr.release(held_block);
+        held_ticket = -1;
+        return err;
+    }
 
     int check_refusal(int64_t *fallback_off, int64_t *fallback_reads) {
         int64_t failed = -1, bad = -1;
@@ -641,6 +660,8 @@ private:
     int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
         done = true;
         drain();
+        const int held_err = release_held();  // (the blocks return to the pool in close(): no copy may still read them)
+        if (!err) err = held_err;
         tr.close();
         c.t_parse += now_s() - t0;
         if (err) return err;
