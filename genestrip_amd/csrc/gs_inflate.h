@@ -897,7 +897,9 @@ private:
         std::unique_ptr<Dec> d(new Dec());
         std::vector<uint16_t> scratch(32768 + 65536);
         fill_markers(scratch.data());
-        const uint64_t end_bit = (uint64_t)n_in_ * 8;
+        // inside the chunk only: a stretch without the start of a non-final dynamic block (stored data, or members that
+        // are one final block each) is left to the sequencer instead of being searched to the end of the file
+        const uint64_t end_bit = std::min((uint64_t)n_in_ * 8, from_bit + (uint64_t)chunk_ * 8 + 160);
         for (uint64_t p = from_bit; p + 160 < end_bit; p++) {
             // cheap tests first (a candidate costs a full header parse otherwise): BFINAL = 0 and BTYPE = 2, at most 286
             // literal/length and 30 distance codes, and a COMPLETE code-length code (Kraft sum exactly 1)
