@@ -424,12 +424,13 @@ struct TextReader {
             // n_threads, so that the blocks sharing a slot are filled by ONE thread, in order
             n_slots = gzip ? 4 : 2 * readers;
         }
-        slots.resize((size_t)n_slots);
-        for (auto &sl : slots) {
-            int rc = pinned_pool().get(headroom + block, &sl.buf);
-            if (rc) return rc;
-        }
+        slots.resize((size_t)n_slots);  // (each filling thread pins its own blocks when it first needs them: in parallel)
         return GS_OK;
+    }
+    // the pinned block of a slot, allocated by the thread that fills it; false: out of (pinnable) memory
+    bool slot_buffer(TextSlot &sl) {
+        if (sl.buf) return true;
+        return pinned_pool().get(headroom + block, &sl.buf) == GS_OK && sl.buf != nullptr;
     }
     void fill_newlines(TextSlot &sl, const uint8_t *dst, size_t got) {
         sl.newlines = (int64_t)count_newlines(dst, got);
@@ -483,9 +484,9 @@ struct TextReader {
                     cv.wait(l, [&] { return stop || sl.state == 0; });
                     if (stop) break;
                 }
-                uint8_t *dst = sl.buf + headroom;
+                bool err = !slot_buffer(sl);
+                uint8_t *dst = err ? nullptr : sl.buf + headroom;
                 size_t got = 0;
-                bool err = false;
                 sl.member_ends.clear();
                 if (bgzf) {
                     while (!done && !err && got < block) {
@@ -517,7 +518,7 @@ struct TextReader {
                         if (fin) done = true;
                         if (p == 0 && !fin && !err) err = true;  // (cannot happen: read() blocks until it has bytes)
                     }
-                } else if (inf) {
+                } else if (inf && !err) {
                     memcpy(dst - hist, window.data() + (32768 - hist), hist);
                     while (!done && got < block) {
                         size_t p = 0;
@@ -555,7 +556,7 @@ struct TextReader {
                     cv.wait(l, [&] { return stop || sl.state == 2; });
                     if (stop) break;
                 }
-                fill_newlines(sl, sl.buf + headroom, sl.n);
+                fill_newlines(sl, sl.buf ? sl.buf + headroom : nullptr, sl.buf ? sl.n : 0);
                 const bool last = sl.eof || sl.io_error;
                 {
                     std::lock_guard<std::mutex> l(m);
@@ -597,10 +598,10 @@ struct TextReader {
                         cv.wait(l, [&] { return stop || sl.state == 0; });
                         if (stop) return;
                     }
-                    uint8_t *dst = sl.buf + headroom;
+                    bool err = !slot_buffer(sl);
+                    uint8_t *dst = err ? nullptr : sl.buf + headroom;
                     size_t got = 0;
-                    bool err = false;
-                    while (got < block) {
+                    while (!err && got < block) {
                         const ssize_t r = pread(fd, dst + got, block - got, (off_t)(start_off + i * (int64_t)block + (int64_t)got));
                         if (r < 0) {
                             if (errno == EINTR) continue;
