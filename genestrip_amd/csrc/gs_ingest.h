@@ -432,8 +432,17 @@ struct TextReader {
         if (sl.buf) return true;
         return pinned_pool().get(headroom + block, &sl.buf) == GS_OK && sl.buf != nullptr;
     }
-    void fill_newlines(TextSlot &sl, const uint8_t *dst, size_t got) {
-        sl.newlines = (int64_t)count_newlines(dst, got);
+    void fill_newlines(TextSlot &sl, const uint8_t *dst, size_t got, GsRangePool *pool = nullptr) {
+        if (pool && got >= ((size_t)1 << 20)) {  // (gzip input: ONE thread counts for all the inflating threads)
+            std::atomic<int64_t> total{0};
+            const int64_t pieces = (int64_t)((got + 262143) >> 18);
+            pool->run(pieces, [&](int, int64_t lo, int64_t hi) {
+                const size_t a = (size_t)lo << 18, b = std::min(got, (size_t)hi << 18);
+                total += (int64_t)count_newlines(dst + a, b - a);
+            }, 1);
+            sl.newlines = total.load();
+        } else
+            sl.newlines = (int64_t)count_newlines(dst, got);
         size_t end = got;
         for (int j = 0; j < 4; j++) {
             const void *q = end ? memrchr(dst, '\n', end) : nullptr;
@@ -549,6 +558,7 @@ struct TextReader {
             if (par) par->stop();
         });
         threads.emplace_back([this] {
+            GsRangePool counters(4);
             for (int64_t i = 0;; i++) {
                 TextSlot &sl = slots[(size_t)(i % n_slots)];
                 {
@@ -556,7 +566,7 @@ struct TextReader {
                     cv.wait(l, [&] { return stop || sl.state == 2; });
                     if (stop) break;
                 }
-                fill_newlines(sl, sl.buf ? sl.buf + headroom : nullptr, sl.buf ? sl.n : 0);
+                fill_newlines(sl, sl.buf ? sl.buf + headroom : nullptr, sl.buf ? sl.n : 0, &counters);
                 const bool last = sl.eof || sl.io_error;
                 {
                     std::lock_guard<std::mutex> l(m);
