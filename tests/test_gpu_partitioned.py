@@ -170,3 +170,25 @@ def test_partitioned_collective_path_single_rank(sdb):
         store.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["partitioned", "sharded"])
+def test_two_rank_bench_flow_over_gloo(mode):
+    """bench.py's multi-rank control flow (barriers, routing all-to-alls or state merge, rank-0-only legs) with two
+    processes on this one GPU; the collectives run over gloo on host copies (GS_BENCH_BACKEND=gloo, a rehearsal mode:
+    the numbers mean nothing).  Both ranks must end with the same merged table, bit-exact against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo")
+    port = 29800 + (os.getpid() % 1500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--reads", "300000", "--check-reads", "50000", "--cpu-seconds", "0", "--mode", mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["parity"]["bit_exact"] is True
+    assert out["parity"]["merged_table_identical_on_all_ranks"] is True
