@@ -111,7 +111,7 @@ def lib():
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
-        "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
+        "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
@@ -315,17 +315,19 @@ class FastqKMerMatcher:
         _ready(keys, nodes)
         _check(lib().gs_match_probe_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, C.c_void_p(nodes.data_ptr())))
 
-    def route_keys(self, keys, n_keys, n_parts, send_keys, idx):
-        """device counting sort of the valid keys by owner rank; returns the per-owner counts (python list)"""
+    def route_keys(self, keys, n_keys, n_parts, send_keys, idx, nodes=None):
+        """device counting sort of the valid keys by owner rank; returns the per-owner counts (python list).
+        nodes (int32 tensor, optional): the unrouted positions get their node (miss / invalid) here already"""
         counts = (C.c_int64 * n_parts)()
-        _ready(keys, send_keys, idx)
+        _ready(keys, send_keys, idx, nodes)
         _check(lib().gs_route_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, n_parts, C.c_void_p(send_keys.data_ptr()),
-                                   C.c_void_p(idx.data_ptr()), counts))
+                                   C.c_void_p(idx.data_ptr()), counts, None if nodes is None else C.c_void_p(nodes.data_ptr())))
         return list(counts)
 
     def unroute_nodes(self, keys, idx, back, n_routed, nodes, n_keys):
+        """keys = None: route_keys(..., nodes) has written the unrouted positions already"""
         _ready(keys, idx, back, nodes)
-        _check(lib().gs_unroute_nodes(self.h, C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
+        _check(lib().gs_unroute_nodes(self.h, None if keys is None else C.c_void_p(keys.data_ptr()), C.c_void_p(idx.data_ptr()),
                                       C.c_void_p(back.data_ptr()), n_routed, C.c_void_p(nodes.data_ptr()), n_keys))
 
     def reduce(self, seq, offsets, pos_off, nodes, n_reads, first_read_no=0, class_vi=None, flags=None):

@@ -1172,13 +1172,13 @@ extern "C" int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *
 
 extern "C" hipError_t gs_launch_route_count(const u64 *keys, int64_t n, int n_parts, u64 *counts, hipStream_t stream);
 extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_parts, u64 *cursors, u64 *send_keys,
-                                               uint32_t *idx, hipStream_t stream);
+                                               uint32_t *idx, int32_t *nodes, hipStream_t stream);
 extern "C" hipError_t gs_launch_unroute(const u64 *keys, const uint32_t *idx, const int32_t *back, int64_t n_routed, int32_t *nodes,
                                          int64_t n_keys, hipStream_t stream);
 
 // groups the valid keys by owner rank (counting sort on the device); counts[n_parts] is a HOST array
 extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int n_parts, uint64_t *send_keys,
-                             uint32_t *idx, int64_t *counts) {
+                             uint32_t *idx, int64_t *counts, int32_t *nodes) {
     if (!run || !counts || n_parts < 1 || n_parts > 64 || (n_keys > 0 && (!keys || !send_keys || !idx)))
         return fail(GS_E_INVALID, "bad argument");
     if (n_keys >= ((int64_t)1 << 32)) return fail(GS_E_INVALID, "more than 2^32-1 keys in one batch");
@@ -1202,7 +1202,7 @@ extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_counts, cur, sizeof(u64) * 64, hipMemcpyHostToDevice, run->stream);
     if (e == hipSuccess)
-        e = gs_launch_route_scatter((const u64 *)keys, n_keys, n_parts, d_counts, (u64 *)send_keys, idx, run->stream);
+        e = gs_launch_route_scatter((const u64 *)keys, n_keys, n_parts, d_counts, (u64 *)send_keys, idx, nodes, run->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(run->stream);
     hipFree(d_counts);
     if (e != hipSuccess) return fail(GS_E_HIP, std::string("gs_route_keys: ") + hipGetErrorString(e));
@@ -1213,8 +1213,7 @@ extern "C" int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, 
 // or -1 (key ~0 - 1: ruled out by the gate of the encoding rank)
 extern "C" int gs_unroute_nodes(gs_run *run, const uint64_t *keys, const uint32_t *idx, const int32_t *back,
                                 int64_t n_routed, int32_t *nodes, int64_t n_keys) {
-    if (!run || (n_keys > 0 && (!nodes || !keys)) || (n_routed > 0 && (!idx || !back)))
-        return fail(GS_E_INVALID, "bad argument");
+    if (!run || (n_keys > 0 && !nodes) || (n_routed > 0 && (!idx || !back))) return fail(GS_E_INVALID, "bad argument");
     if (n_keys <= 0) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
     HIP_TRY(gs_launch_unroute((const u64 *)keys, idx, back, n_routed, nodes, n_keys, run->stream));

@@ -977,8 +977,10 @@ __global__ __launch_bounds__(256) void gs_route_count_kernel(const u64 *keys, in
 // tiles of 4096 keys per workgroup: ranks inside the tile come from LDS counters (one LDS atomic per wave and owner),
 // then ONE global atomic per owner and tile reserves the output range -- a single hot cursor would serialise the chip
 #define GS_ROUTE_T 16
+// nodes (may be NULL): the positions that are not routed get their node here already (miss / invalid window), so that
+// gs_unroute_kernel only has to scatter what comes back
 __global__ __launch_bounds__(256) void gs_route_scatter_kernel(const u64 *keys, int64_t n, int n_parts, u64 *cursors,
-                                                              u64 *send_keys, uint32_t *idx) {
+                                                              u64 *send_keys, uint32_t *idx, int32_t *nodes) {
     __shared__ unsigned int s_cnt[64];
     __shared__ u64 s_base[64];
     const int lane = gs_lane();
@@ -994,6 +996,7 @@ __global__ __launch_bounds__(256) void gs_route_scatter_kernel(const u64 *keys, 
             const int64_t i = t0 + (int64_t)j * 256 + threadIdx.x;
             h[j] = i < n ? keys[i] : GS_KEY_INVALID;
             owner[j] = GS_KEY_ROUTED(h[j]) ? (int)((h[j] >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+            if (nodes != nullptr && i < n && owner[j] < 0) nodes[i] = h[j] == GS_KEY_MISS ? GS_NODE_MISS : GS_NODE_INVALID;
             lp[j] = 0;
             u64 todo = __ballot(owner[j] >= 0);
             while (todo) {
@@ -1026,6 +1029,7 @@ __global__ __launch_bounds__(256) void gs_unroute_kernel(const u64 *keys, const 
                                                         int64_t n_routed, int32_t *nodes, int64_t n_keys, int phase) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (phase == 0)  // positions that were never routed: windows with a bad base, k-mers the gate ruled out
+                     // (only when gs_route_scatter_kernel has not written them already)
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride)
             nodes[i] = keys[i] == GS_KEY_MISS ? GS_NODE_MISS : GS_NODE_INVALID;
     else
@@ -1499,17 +1503,19 @@ extern "C" hipError_t gs_launch_route_count(const u64 *keys, int64_t n, int n_pa
 }
 
 extern "C" hipError_t gs_launch_route_scatter(const u64 *keys, int64_t n, int n_parts, u64 *cursors, u64 *send_keys,
-                                               uint32_t *idx, hipStream_t stream) {
+                                               uint32_t *idx, int32_t *nodes, hipStream_t stream) {
     int grid = (int)std::min<int64_t>((n + 256 * GS_ROUTE_T - 1) / (256 * GS_ROUTE_T), 256 * 8);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(gs_route_scatter_kernel, dim3(grid), dim3(256), 0, stream, keys, n, n_parts, cursors, send_keys, idx);
+    hipLaunchKernelGGL(gs_route_scatter_kernel, dim3(grid), dim3(256), 0, stream, keys, n, n_parts, cursors, send_keys, idx,
+                       nodes);
     return hipGetLastError();
 }
 
 extern "C" hipError_t gs_launch_unroute(const u64 *keys, const uint32_t *idx, const int32_t *back, int64_t n_routed,
                                          int32_t *nodes, int64_t n_keys, hipStream_t stream) {
-    hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_keys)), dim3(256), 0, stream, keys, idx, back, n_routed,
-                       nodes, n_keys, 0);
+    if (keys != nullptr)  // (NULL: gs_route_scatter_kernel has filled in the unrouted positions)
+        hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_keys)), dim3(256), 0, stream, keys, idx, back, n_routed,
+                           nodes, n_keys, 0);
     if (n_routed > 0)
         hipLaunchKernelGGL(gs_unroute_kernel, dim3(gs_stream_grid(n_routed)), dim3(256), 0, stream, keys, idx, back,
                            n_routed, nodes, n_keys, 1);

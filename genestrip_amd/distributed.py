@@ -175,7 +175,8 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
     # are the same steps written with torch ops (used by the CPU/gloo tests)
     send_buf = torch.empty(max(n_keys, 1), dtype=torch.int64, device=seq.device)
     idx = torch.empty(max(n_keys, 1), dtype=torch.int32, device=seq.device)
-    counts = torch.tensor(matcher.route_keys(keys, n_keys, world, send_buf, idx), dtype=torch.int64, device=seq.device)
+    nodes = torch.empty(max(n_keys, 1), dtype=torch.int32, device=seq.device)
+    counts = torch.tensor(matcher.route_keys(keys, n_keys, world, send_buf, idx, nodes), dtype=torch.int64, device=seq.device)
     n_routed = int(counts.sum().item())
     recv_keys, recv_counts = exchange_all_to_all(send_buf[:n_routed], counts, group)
     recv_nodes = torch.empty(max(recv_keys.numel(), 1), dtype=torch.int32, device=seq.device)
@@ -183,9 +184,8 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
     matcher.probe_keys(recv_keys, recv_nodes, recv_keys.numel())
     matcher.sync()
     back, _ = exchange_all_to_all(recv_nodes[:recv_keys.numel()].contiguous(), recv_counts, group)
-    nodes = torch.empty(max(n_keys, 1), dtype=torch.int32, device=seq.device)
     torch.cuda.synchronize(seq.device)
-    matcher.unroute_nodes(keys, idx, back, n_routed, nodes, n_keys)
+    matcher.unroute_nodes(None, idx, back, n_routed, nodes, n_keys)  # (route_keys wrote the unrouted positions)
     matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
     matcher.sync()
 

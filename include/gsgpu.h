@@ -218,12 +218,14 @@ int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, in
                     const uint64_t *pos_off, const int32_t *nodes, int32_t *class_vi, uint8_t *flags);
 /* Routing helpers around the two all-to-alls (device counting sort by owner rank, synchronous):
  * gs_route_keys groups the valid keys by owner: send_keys[n_valid] (owner 0 first), idx[n_valid] = position of each
- * routed key in `keys`, counts[n_parts] (HOST array) = keys per owner.  gs_unroute_nodes scatters the returned nodes
- * back: nodes[idx[i]] = back[i]; a position that was not routed reads -2 (invalid window, key ~0) or -1 (key ~0 - 1:
- * gs_match_encode found that the store's minimizer gate, which every partition builds over the keys of ALL
- * partitions, rules the k-mer out, so it is a miss without asking its owner).  n_keys < 2^32, n_parts <= 64. */
+ * routed key in `keys`, counts[n_parts] (HOST array) = keys per owner; nodes (may be NULL): the positions that are
+ * NOT routed get their node right here -- -2 (invalid window, key ~0) or -1 (key ~0 - 1: gs_match_encode found that
+ * the store's minimizer gate, which every partition builds over the keys of ALL partitions, rules the k-mer out, so it
+ * is a miss without asking its owner).  gs_unroute_nodes scatters the returned nodes back: nodes[idx[i]] = back[i];
+ * with keys != NULL it first writes the unrouted positions as above (keys = NULL: gs_route_keys has done it).
+ * n_keys < 2^32, n_parts <= 64. */
 int gs_route_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int n_parts, uint64_t *send_keys, uint32_t *idx,
-                  int64_t *counts);
+                  int64_t *counts, int32_t *nodes);
 int gs_unroute_nodes(gs_run *run, const uint64_t *keys, const uint32_t *idx, const int32_t *back, int64_t n_routed,
                      int32_t *nodes, int64_t n_keys);
 

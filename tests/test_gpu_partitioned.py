@@ -89,14 +89,15 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
         if device_routing:  # gs_route_keys: counting sort on the device
             send = torch.empty(max(nk, 1), dtype=torch.int64, device=dev)
             idx = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
-            counts = np.array(ms[r].route_keys(keys, nk, world, send, idx), dtype=np.int64)
+            early = torch.full((max(nk, 1),), -9, dtype=torch.int32, device=dev) if r % 2 == 0 else None
+            counts = np.array(ms[r].route_keys(keys, nk, world, send, idx, early), dtype=np.int64)
             send = send[:int(counts.sum())]
             assert bool((((send >> gd.OWNER_SHIFT) % world).cpu() == torch.repeat_interleave(
                 torch.arange(world), torch.from_numpy(counts))).all())
         else:               # the same step with torch ops
             idx, send, counts = gd.plan_routing(keys[:nk], world)
             counts = counts.cpu().numpy()
-        plans.append((pos_off, nk, idx, send, counts, keys))
+        plans.append((pos_off, nk, idx, send, counts, keys, early if device_routing else None))
     assert n_gated > 30000  # the foreign reads' k-mers (about 55 k) stop at the gate of the encoding rank
     # all-to-all #1: keys to their owners
     starts = [np.concatenate([[0], np.cumsum(p[4])]) for p in plans]
@@ -114,11 +115,12 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
             o += c
     tables, cvs, fls = [], [], []
     for r, (dseq, doff, nr, lo) in enumerate(shard):
-        pos_off, nk, idx, _, _, keys = plans[r]
+        pos_off, nk, idx, _, _, keys, early = plans[r]
         back = torch.cat(node_back[r])
         if device_routing:
-            nodes = torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
-            ms[r].unroute_nodes(keys, idx, back, back.numel(), nodes, nk)
+            # both ways of filling in the unrouted positions: by gs_route_keys already, or by gs_unroute_nodes
+            nodes = early if early is not None else torch.empty(max(nk, 1), dtype=torch.int32, device=dev)
+            ms[r].unroute_nodes(None if early is not None else keys, idx, back, back.numel(), nodes, nk)
         else:
             nodes = gd.scatter_nodes(back, idx, max(nk, 1), keys)
         cv = torch.full((max(nr, 1),), -1, dtype=torch.int32, device=dev)
