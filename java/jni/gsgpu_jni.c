@@ -78,6 +78,23 @@ JNIEXPORT void JNICALL JNAME(matchTextClearError)(JNIEnv *env, jclass c, jlong r
     if (rc) throw_gs(env, rc);
 }
 
+/* page-locked staging memory as a direct ByteBuffer: copies from it run at the full host-to-device rate and
+ * asynchronously, copies from ordinary (pageable) direct buffers are staged by the runtime */
+JNIEXPORT jobject JNICALL JNAME(pinnedAlloc)(JNIEnv *env, jclass c, jlong bytes) {
+    void *p = NULL;
+    int rc = gs_pinned_alloc(&p, (size_t)bytes);
+    if (rc) {
+        throw_gs(env, rc);
+        return NULL;
+    }
+    return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+
+JNIEXPORT void JNICALL JNAME(pinnedFree)(JNIEnv *env, jclass c, jobject buf) {
+    int rc = gs_pinned_free(addr(env, buf));
+    if (rc) throw_gs(env, rc);
+}
+
 JNIEXPORT void JNICALL JNAME(matchFinish)(JNIEnv *env, jclass c, jlong run, jobject table, jobject dtable) {
     int rc = gs_match_finish((gs_run *)(intptr_t)run, (int64_t *)addr(env, table), (double *)addr(env, dtable));
     if (rc) throw_gs(env, rc);

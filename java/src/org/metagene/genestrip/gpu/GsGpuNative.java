@@ -49,6 +49,13 @@ public final class GsGpuNative {
 
 	public static native void matchTextClearError(long run);
 
+	/** gs_pinned_alloc as a direct buffer (native byte order is up to the caller): the place to stage batches and text
+	 *  chunks -- copies from page-locked memory run at the full host-to-device rate.  Free it with pinnedFree, never
+	 *  let it be garbage collected while a submit may still read it. */
+	public static native ByteBuffer pinnedAlloc(long bytes);
+
+	public static native void pinnedFree(ByteBuffer buf);
+
 	/** gs_match_finish: table = n_values x GS_N_COLS int64, dtable = n_values x GS_N_DCOLS double. */
 	public static native void matchFinish(long run, ByteBuffer table, ByteBuffer dtable);
 
