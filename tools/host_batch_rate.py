@@ -1,5 +1,5 @@
-"""PCIe-inclusive rate of the host-batch path (gs_match_submit with GS_MEM_HOST): reads in pageable host
-memory, staged to HBM by the library.  Reported in DESIGN.md next to the HBM-resident number of bench.py."""
+"""PCIe-inclusive rate of the host-batch path (gs_match_submit with GS_MEM_HOST): reads in pageable and in page-locked
+host memory, staged to HBM by the library.  Reported in DESIGN.md next to the HBM-resident number of bench.py."""
 import os
 import sys
 import time
@@ -17,12 +17,21 @@ seq, off = synth.reads_host(db.genomes, n)
 m = ga.FastqKMerMatcher(store)
 m.submit(seq, off, 0, n_reads=n)  # warm-up (allocates the staging buffers)
 m.reset()
-for with_per_read in (False, True):
-    cv = np.empty(n, np.int32) if with_per_read else None
-    fl = np.empty(n, np.uint8) if with_per_read else None
-    t0 = time.perf_counter()
-    for _ in range(3):
-        m.submit(seq, off, 0, cv, fl, n_reads=n)
-    dt = (time.perf_counter() - t0) / 3
-    print(f"host batch of {n} reads, per-read outputs={with_per_read}: {dt*1e3:.1f} ms -> {n*150/dt/1e9:.2f} Gbp/s "
-          f"({n*150/dt/1e9:.2f} GB/s of sequence over PCIe)")
+import torch  # noqa: E402  (page-locked arrays: what gs_pinned_alloc gives a C or Java host)
+
+pseq = torch.from_numpy(seq).pin_memory().numpy()
+poff = torch.from_numpy(off.astype(np.int64)).pin_memory().numpy().view(off.dtype)
+for label, s_, o_ in (("pageable", seq, off), ("page-locked", pseq, poff)):
+    for with_per_read in (False, True):
+        if with_per_read:
+            cv = torch.empty(n, dtype=torch.int32).pin_memory().numpy() if label == "page-locked" else np.empty(n, np.int32)
+            fl = torch.empty(n, dtype=torch.uint8).pin_memory().numpy() if label == "page-locked" else np.empty(n, np.uint8)
+        else:
+            cv = fl = None
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.submit(s_, o_, 0, cv, fl, n_reads=n)
+        m.sync()
+        dt = (time.perf_counter() - t0) / 3
+        print(f"{label} host batch of {n} reads, per-read outputs={with_per_read}: {dt*1e3:.1f} ms -> {n*150/dt/1e9:.2f} Gbp/s "
+              f"({n*150/dt/1e9:.2f} GB/s of sequence over PCIe)")
