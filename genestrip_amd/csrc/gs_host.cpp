@@ -576,7 +576,11 @@ struct TextJob {
                     drain();  // one chunk at a time: output order, and the other result set becomes free
                     n_formatted++;
                     keep_block = true;
-                    formatting = std::async(std::launch::async, [this, &rs, start, n_chunk, i] { format_chunk(rs, start, n_chunk, i); });
+                    try {
+                        formatting = std::async(std::launch::async, [this, &rs, start, n_chunk, i] { format_chunk(rs, start, n_chunk, i); });
+                    } catch (const std::system_error &) {  // no thread to be had: on this one
+                        format_chunk(rs, start, n_chunk, i);
+                    }
                 }
                 // a file that is not four-line FASTQ fails in its first chunk: look early, then now and again
                 if (!err && fallback_off < 0 && !per_read && (chunks.size() == 1 || (chunks.size() & 15) == 0))
@@ -1011,7 +1015,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
                 if (formatting.valid()) formatting.get();  // one chunk at a time: output order, the other set is free
                 n_formatted++;
                 keep_block = true;
-                formatting = std::async(std::launch::async, [&c, &tr, h_acc, h_nl, start, n_reads, i] {
+                auto write_chunk = [&c, &tr, h_acc, h_nl, start, n_reads, i] {
                     std::vector<FilterPart> parts((size_t)c.pool.threads());
                     c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
                         FilterPart &p = parts[(size_t)t];
@@ -1028,7 +1032,12 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
                     });
                     write_filter_parts(c, parts);
                     tr.release(i);  // the block goes back to its reader
-                });
+                };
+                try {
+                    formatting = std::async(std::launch::async, write_chunk);
+                } catch (const std::system_error &) {  // no thread to be had: on this one
+                    write_chunk();
+                }
             }
         }
         if (!keep_block) tr.release(i);

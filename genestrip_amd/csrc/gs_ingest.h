@@ -31,6 +31,7 @@
 #include <mutex>
 #include <queue>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
