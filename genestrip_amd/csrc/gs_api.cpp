@@ -134,14 +134,22 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                           int32_t n_values, const int32_t *parent_vi, int n_parts, int part);
 
 extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                            int32_t n_values, const int32_t *parent_vi) {
+                            int32_t n_values, const int32_t *parent_vi) try {
     return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, 1, 0);
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 extern "C" int gs_db_create_part(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                                 int32_t n_values, const int32_t *parent_vi, int n_parts, int part) {
+                                 int32_t n_values, const int32_t *parent_vi, int n_parts, int part) try {
     if (n_parts < 1 || part < 0 || part >= n_parts) return fail(GS_E_INVALID, "bad partition");
     return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, n_parts, part);
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
@@ -405,7 +413,7 @@ struct GsStoreFileHeader {
     uint64_t mgate_words;  // 32-bit words, a power of two
 };
 
-extern "C" int gs_db_save(gs_db *db, const char *path) {
+extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (!db || !path) return fail(GS_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
@@ -432,9 +440,13 @@ extern "C" int gs_db_save(gs_db *db, const char *path) {
               fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     ok = (fclose(f) == 0) && ok;
     return ok ? GS_OK : fail(GS_E_INVALID, std::string("short write to ") + path);
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
-extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
+extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     if (!out || !path) return fail(GS_E_INVALID, "NULL argument");
     *out = nullptr;
     int rc = use_device(device);
@@ -497,6 +509,10 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) {
     db->dev.tout = db->d_tree + 3 * nv;
     *out = db;
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 extern "C" int gs_db_destroy(gs_db *db) {
@@ -1419,7 +1435,7 @@ struct gs_bloom {
 };
 
 extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bits, int32_t n_hashes,
-                               const int64_t *hash_factors, const uint64_t *words, int64_t n_words) {
+                               const int64_t *hash_factors, const uint64_t *words, int64_t n_words) try {
     if (!out) return fail(GS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (kind < GS_BLOOM_XOR || kind > GS_BLOOM_BLOCKED) return fail(GS_E_INVALID, "unknown bloom kind");
@@ -1454,6 +1470,10 @@ extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bit
     }
     *out = b;
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 extern "C" int gs_bloom_destroy(gs_bloom *b) {

@@ -62,7 +62,7 @@ struct gs_fastq {
     Batch batch;
 };
 
-extern "C" int gs_fastq_open(gs_fastq **out, const char *path, int fasta, int k) {
+extern "C" int gs_fastq_open(gs_fastq **out, const char *path, int fasta, int k) try {
     if (!out || !path) return hfail(GS_E_INVALID, "NULL argument");
     const bool fa = fasta < 0 ? is_fasta_name(path) : fasta != 0;
     auto r = std::make_unique<gs_fastq>();
@@ -70,9 +70,13 @@ extern "C" int gs_fastq_open(gs_fastq **out, const char *path, int fasta, int k)
     if (!r->parser->open(path)) return hfail(GS_E_INVALID, std::string("cannot open ") + path);
     *out = r.release();
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
-extern "C" int gs_fastq_next(gs_fastq *r, int64_t max_reads, int64_t max_bytes, gs_read_batch *b) {
+extern "C" int gs_fastq_next(gs_fastq *r, int64_t max_reads, int64_t max_bytes, gs_read_batch *b) try {
     if (!r || !b) return hfail(GS_E_INVALID, "NULL argument");
     r->parser->parse(r->batch, max_reads, max_bytes);
     b->n_reads = r->batch.n();
@@ -84,6 +88,10 @@ extern "C" int gs_fastq_next(gs_fastq *r, int64_t max_reads, int64_t max_bytes, 
     b->qual_off = r->batch.qual_off.data();
     b->first_read_no = r->batch.first_read_no;
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 extern "C" int gs_fastq_totals(const gs_fastq *r, int64_t *reads, int64_t *kmers, int64_t *bps) {
@@ -102,7 +110,7 @@ extern "C" int gs_fastq_close(gs_fastq *r) {
 extern "C" const char *gs_host_last_error(void) { return g_host_err.c_str(); }
 
 // the ingest path's gzip decoder on a memory range, delivering `block` bytes per decode call (test hook)
-extern "C" int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, size_t block) {
+extern "C" int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, size_t block) try {
     if ((!in && n_in) || !out || !n_out || block == 0) return hfail(GS_E_INVALID, "bad argument");
     std::unique_ptr<GsInflate> inf(new GsInflate());
     inf->init(in, n_in, true);
@@ -123,13 +131,17 @@ extern "C" int gs_host_gunzip(const uint8_t *in, size_t n_in, uint8_t *out, size
     }
     *n_out = total;
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 
 // the same stream through GsParallelGunzip (test hook): `threads` workers, compressed chunks of `chunk` bytes;
 // CRC-32 and ISIZE of every member are checked inside read()
 extern "C" int gs_host_gunzip_parallel(const uint8_t *in, size_t n_in, uint8_t *out, size_t out_cap, size_t *n_out, int threads,
-                                       size_t chunk, size_t block) {
+                                       size_t chunk, size_t block) try {
     if ((!in && n_in) || !out || !n_out || threads < 1 || block == 0) return hfail(GS_E_INVALID, "bad argument");
     size_t total = 0;
     std::vector<uint8_t> spill(block);
@@ -167,6 +179,10 @@ extern "C" int gs_host_gunzip_parallel(const uint8_t *in, size_t n_in, uint8_t *
     }
     *n_out = total;
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 namespace {
@@ -786,7 +802,7 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
 
 extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
                                    const gs_host_match_opts *opts, int64_t *table, double *dtable,
-                                   gs_host_totals *totals) {
+                                   gs_host_totals *totals) try {
     if (!db || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
     MatchCtx c;
     int rc = gs_db_get_info(db, &c.info);
@@ -832,6 +848,10 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         totals->seconds_gpu = c.t_gpu;
     }
     return err;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 
@@ -841,7 +861,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
 // global file order; the read numbers handed to the device are (file_index << 32 | read in file), reads_of_file[n_paths]
 // receives the read counts (needed to turn the max-contig read numbers into running ones after the merge).
 extern "C" int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
-                                  int64_t *reads_of_file, gs_host_totals *totals) {
+                                  int64_t *reads_of_file, gs_host_totals *totals) try {
     if (!run || !db || !paths || n_paths < 0 || !file_index || !reads_of_file) return hfail(GS_E_INVALID, "NULL argument");
     MatchCtx c;
     int rc = gs_db_get_info(db, &c.info);
@@ -864,6 +884,10 @@ extern "C" int gs_host_match_into(gs_run *run, gs_db *db, const char *const *pat
         totals->seconds_gpu = c.t_gpu;
     }
     return err;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
 namespace {
@@ -1063,7 +1087,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
 
 extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio,
                                     const char *const *paths, int n_paths, const char *filtered_path,
-                                    const char *rest_path, int with_probs, gs_host_totals *totals) {
+                                    const char *rest_path, int with_probs, gs_host_totals *totals) try {
     if (!bloom || !paths || n_paths < 0) return hfail(GS_E_INVALID, "NULL argument");
     FilterCtx c;
     c.with_probs = with_probs != 0;
@@ -1096,4 +1120,8 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
         totals->seconds_gpu = c.t_gpu;
     }
     return err;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }

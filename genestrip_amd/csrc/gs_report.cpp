@@ -15,7 +15,7 @@ extern "C" int gs_host_java_double(double v, char *buf, int cap) {
 // completeResults + CSV
 // ---------------------------------------------------------------------------------------------------
 extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, const int64_t *table, const double *dtable,
-                                 const gs_host_totals *totals) {
+                                 const gs_host_totals *totals) try {
     if (!path || !tax || !table || !totals || !tax->parent_vi || !tax->taxids || !tax->db_kmers)
         return hfail(GS_E_INVALID, "NULL argument");
     const int nv = tax->n_values;
@@ -203,4 +203,8 @@ extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, 
     fwrite(o.data(), 1, o.size(), f);
     fclose(f);
     return GS_OK;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
