@@ -526,7 +526,7 @@ struct TextJob {
         int64_t fallback_off = -1, fallback_reads = 0;
         bool last = false;
         if (sl.io_error || !tr.verify_gzip(sl)) {
-            err = hfail(GS_E_INVALID, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
+            err = hfail(tr.gz ? GS_E_INVALID : GS_E_IO, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
         } else {
             err = gs_match_text_select(c.run, bank);
             uint8_t *blk = sl.buf + tr.headroom;
@@ -999,7 +999,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     for (int64_t i = 0; !err; i++) {
         TextSlot &sl = tr.wait_full(i);
         if (sl.io_error || !tr.verify_gzip(sl)) {
-            err = hfail(GS_E_INVALID, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
+            err = hfail(tr.gz ? GS_E_INVALID : GS_E_IO, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
             break;
         }
         uint8_t *blk = sl.buf + tr.headroom;
