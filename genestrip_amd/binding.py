@@ -30,7 +30,7 @@ BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
 ABI_SYMBOLS = (
     "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
     "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
-    "gs_match_begin", "gs_match_submit", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
+    "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
@@ -105,6 +105,7 @@ def lib():
         "gs_db_create": (ci, [vp, ci, ci, i64, vp, vp, i32, vp]), "gs_db_get_info": (ci, [vp, vp]),
         "gs_db_destroy": (ci, [vp]), "gs_db_save": (ci, [vp, C.c_char_p]), "gs_db_load": (ci, [vp, ci, C.c_char_p]),
         "gs_match_begin": (ci, [vp, vp, vp]), "gs_match_submit": (ci, [vp, vp, vp, i64, i64, ci, vp, vp]),
+        "gs_match_submit_async": (ci, [vp, vp, vp, i64, i64, vp, vp, vp]), "gs_match_wait": (ci, [vp, i64]),
         "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
         "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
@@ -255,6 +256,23 @@ class FastqKMerMatcher:
         pf, _ = _ptr(flags)
         _ready(seq, offsets, class_vi, flags)
         _check(lib().gs_match_submit(self.h, ps, po, n_reads, first_read_no, mem, pc, pf))
+
+    def submit_async(self, seq, offsets, first_read_no=0, class_vi=None, flags=None, n_reads=None):
+        """host batch (numpy arrays, best page-locked), queued: returns a ticket for wait(); the arrays must stay as they
+        are until then.  Two batches can be under way (gs_match_submit_async)."""
+        ps, mem = _ptr(seq)
+        po, mem2 = _ptr(offsets)
+        assert mem == mem2 == MEM_HOST, "submit_async takes host arrays"
+        if n_reads is None:
+            n_reads = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
+        pc, _ = _ptr(class_vi)
+        pf, _ = _ptr(flags)
+        ticket = C.c_int64(-1)
+        _check(lib().gs_match_submit_async(self.h, ps, po, n_reads, first_read_no, pc, pf, C.byref(ticket)))
+        return ticket.value
+
+    def wait(self, ticket):
+        _check(lib().gs_match_wait(self.h, ticket))
 
     def match_reads(self, seq, offsets, first_read_no=0):
         """host batch -> (class_vi, flags) numpy arrays (the per-read outcome of matchRead)"""

@@ -554,7 +554,22 @@ struct TextScan {
 };
 enum { GS_TEXT_BANKS = 16 };
 
+// gs_match_submit_async: two sets of device staging buffers, filled by turns on a copy stream, so that the copy of
+// batch i+1 runs while the kernel of batch i works on the other set
+struct BatchStage {
+    uint8_t *d_seq[2] = {nullptr, nullptr};
+    uint64_t *d_off[2] = {nullptr, nullptr};
+    int32_t *d_class[2] = {nullptr, nullptr};
+    uint8_t *d_flags[2] = {nullptr, nullptr};
+    size_t seq_cap[2] = {0, 0}, reads_cap[2] = {0, 0};
+    std::vector<uint64_t> rel[2];  // rebased offsets of a batch whose offsets[0] != 0 (must outlive the copy)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {}, finished[4] = {};  // finished[t % 4]: everything of batch t is through
+    int64_t tickets = 0;
+};
+
 struct gs_run {
+    BatchStage stage;
     gs_db *db = nullptr;
     gs_match_cfg cfg{};
     hipStream_t stream = nullptr;
@@ -780,6 +795,22 @@ static void run_free(gs_run *run) {
     hipFree(run->d_seg_code);
     hipFree(run->d_seg_start);
     text_free(run->text);
+    {
+        BatchStage &g = run->stage;
+        if (g.copy_stream) {
+            hipStreamSynchronize(g.copy_stream);
+            hipStreamDestroy(g.copy_stream);
+        }
+        for (int b = 0; b < 2; b++) {
+            hipFree(g.d_seq[b]);
+            hipFree(g.d_off[b]);
+            hipFree(g.d_class[b]);
+            hipFree(g.d_flags[b]);
+            if (g.copied[b]) hipEventDestroy(g.copied[b]);
+        }
+        for (hipEvent_t ev : g.finished)
+            if (ev) hipEventDestroy(ev);
+    }
     if (run->stream) hipStreamDestroy(run->stream);
     delete run;
 }
@@ -969,6 +1000,87 @@ extern "C" int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *
     if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     return collect_events(run);
+}
+
+// the asynchronous form of a host batch: returns when the work is queued; gs_match_wait(ticket) returns when the
+// batch's per-read outputs are in place and its input arrays may be reused.  Two batches can be under way.
+extern "C" int gs_match_submit_async(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                                     int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) try {
+    if (!run || !ticket) return fail(GS_E_INVALID, "NULL argument");
+    if (n_reads <= 0 || !seq || !offsets) return fail(GS_E_INVALID, "bad batch arrays");
+    HIP_TRY(hipSetDevice(run->db->device));
+    BatchStage &g = run->stage;
+    if (!g.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&g.copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t &ev : g.copied) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (hipEvent_t &ev : g.finished) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int64_t tk = g.tickets;
+    const int b = (int)(tk & 1);
+    const size_t nbytes = (size_t)(offsets[n_reads] - offsets[0]);
+    if (tk >= 2) HIP_TRY(hipEventSynchronize(g.copied[b]));  // rel[b] of the batch before last is free (long done)
+    if (g.seq_cap[b] < nbytes + 1 || g.reads_cap[b] < (size_t)n_reads) {
+        HIP_TRY(hipStreamSynchronize(g.copy_stream));
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        if (g.seq_cap[b] < nbytes + 1) {
+            hipFree(g.d_seq[b]);
+            g.d_seq[b] = nullptr;
+            g.seq_cap[b] = 0;
+            HIP_TRY(hipMalloc((void **)&g.d_seq[b], nbytes + nbytes / 4 + 1));
+            g.seq_cap[b] = nbytes + nbytes / 4 + 1;
+        }
+        if (g.reads_cap[b] < (size_t)n_reads) {
+            hipFree(g.d_off[b]);
+            hipFree(g.d_class[b]);
+            hipFree(g.d_flags[b]);
+            g.d_off[b] = nullptr;
+            g.d_class[b] = nullptr;
+            g.d_flags[b] = nullptr;
+            g.reads_cap[b] = 0;
+            const size_t cap = (size_t)n_reads + (size_t)n_reads / 4;
+            HIP_TRY(hipMalloc((void **)&g.d_off[b], sizeof(uint64_t) * (cap + 1)));
+            HIP_TRY(hipMalloc((void **)&g.d_class[b], sizeof(int32_t) * cap));
+            HIP_TRY(hipMalloc((void **)&g.d_flags[b], cap));
+            g.reads_cap[b] = cap;
+        }
+    }
+    const uint64_t *hoff = offsets;
+    if (offsets[0] != 0) {  // the staged slice starts at 0
+        g.rel[b].resize((size_t)n_reads + 1);
+        for (int64_t i = 0; i <= n_reads; i++) g.rel[b][(size_t)i] = offsets[i] - offsets[0];
+        hoff = g.rel[b].data();
+    }
+    // the batch before last must be through (its kernel read these buffers, its outputs left from them).  Waited for
+    // on the host: a copy that has to wait for an event on the device was seen to start only after the kernel of the
+    // previous batch had ended (rocprofv3 --memory-copy-trace), i.e. not to overlap at all
+    if (tk >= 2) HIP_TRY(hipEventSynchronize(g.finished[(tk - 2) & 3]));
+    HIP_TRY(hipMemcpyAsync(g.d_seq[b], seq + offsets[0], nbytes, hipMemcpyHostToDevice, g.copy_stream));
+    HIP_TRY(hipMemcpyAsync(g.d_off[b], hoff, sizeof(uint64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, g.copy_stream));
+    HIP_TRY(hipEventRecord(g.copied[b], g.copy_stream));
+    HIP_TRY(hipStreamWaitEvent(run->stream, g.copied[b], 0));
+    int rc = launch_batch(run, g.d_seq[b], g.d_off[b], n_reads, first_read_no, class_vi ? g.d_class[b] : nullptr,
+                          flags ? g.d_flags[b] : nullptr);
+    if (rc) return rc;
+    if (class_vi)
+        HIP_TRY(hipMemcpyAsync(class_vi, g.d_class[b], sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, g.d_flags[b], (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipEventRecord(g.finished[tk & 3], run->stream));
+    g.tickets = tk + 1;
+    *ticket = tk;
+    return GS_OK;
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+}
+
+extern "C" int gs_match_wait(gs_run *run, int64_t ticket) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    BatchStage &g = run->stage;
+    if (ticket < 0 || ticket >= g.tickets) return fail(GS_E_INVALID, "unknown ticket");
+    HIP_TRY(hipSetDevice(run->db->device));
+    // (a batch three or more behind the latest is through: the submit of the batch two after it waited for it)
+    if (ticket + 3 <= g.tickets) return GS_OK;
+    HIP_TRY(hipEventSynchronize(g.finished[ticket & 3]));
+    return GS_OK;
 }
 
 // ---- text mode: raw 4-line FASTQ chunks, records found on the device (gs_text.hip) ------------------------------

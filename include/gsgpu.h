@@ -144,6 +144,14 @@ int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg);
 int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
                     int64_t first_read_no, int mem, int32_t *class_vi, uint8_t *flags);
 int gs_match_sync(gs_run *run);
+/* The asynchronous form for HOST batches (the producer thread of AbstractFastqReader fills batch i+1 while batch i is
+ * on the device): returns as soon as the work is queued -- for page-locked arrays (gs_pinned_alloc) that is at once,
+ * and the copy of this batch runs under the kernel of the previous one -- and hands out a ticket.  gs_match_wait(ticket)
+ * returns when class_vi / flags of that batch are filled in and seq / offsets may be reused; at most two batches should
+ * be under way (a third submit waits for the first on the device).  gs_match_sync / gs_match_finish wait for all. */
+int gs_match_submit_async(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
+                          int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket);
+int gs_match_wait(gs_run *run, int64_t ticket);
 
 /* Text mode: a chunk of RAW FASTQ text made of whole four-line records; the device finds the records itself
  * (replaces the producer-thread parse of AbstractFastqReader.doReadFastq, C/fastq/AbstractFastqReader.java:288-368,

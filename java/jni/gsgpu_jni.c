@@ -52,6 +52,20 @@ JNIEXPORT void JNICALL JNAME(matchSubmit)(JNIEnv *env, jclass c, jlong run, jobj
     if (rc) throw_gs(env, rc);
 }
 
+JNIEXPORT jlong JNICALL JNAME(matchSubmitAsync)(JNIEnv *env, jclass c, jlong run, jobject seq, jobject offsets, jlong nReads,
+                                                jlong firstReadNo, jobject classVi, jobject flags) {
+    int64_t ticket = -1;
+    int rc = gs_match_submit_async((gs_run *)(intptr_t)run, (const uint8_t *)addr(env, seq), (const uint64_t *)addr(env, offsets),
+                                   nReads, firstReadNo, (int32_t *)addr(env, classVi), (uint8_t *)addr(env, flags), &ticket);
+    if (rc) throw_gs(env, rc);
+    return ticket;
+}
+
+JNIEXPORT void JNICALL JNAME(matchWait)(JNIEnv *env, jclass c, jlong run, jlong ticket) {
+    int rc = gs_match_wait((gs_run *)(intptr_t)run, ticket);
+    if (rc) throw_gs(env, rc);
+}
+
 JNIEXPORT jlong JNICALL JNAME(matchSubmitText)(JNIEnv *env, jclass c, jlong run, jobject text, jlong nBytes, jlong nLines,
                                                jlong firstReadNo) {
     int64_t ticket = -1;

@@ -37,6 +37,14 @@ public final class GsGpuNative {
 	public static native void matchSubmit(long run, ByteBuffer seq, ByteBuffer offsets, long nReads, long firstReadNo,
 			ByteBuffer classVi, ByteBuffer flags);
 
+	/** gs_match_submit_async: queues a host batch (best in buffers from pinnedAlloc) and returns its ticket; the buffers
+	 *  belong to the library until matchWait(ticket).  Two batches can be under way: the copy of one runs under the
+	 *  kernel of the other. */
+	public static native long matchSubmitAsync(long run, ByteBuffer seq, ByteBuffer offsets, long nReads, long firstReadNo,
+			ByteBuffer classVi, ByteBuffer flags);
+
+	public static native void matchWait(long run, long ticket);
+
 	/** gs_match_submit_text with GS_MEM_HOST: text = a direct buffer holding whole four-line FASTQ records, nLines =
 	 *  number of '\n' in it (a multiple of 4).  Returns the ticket; the buffer may be refilled after matchTextWaitCopy. */
 	public static native long matchSubmitText(long run, ByteBuffer text, long nBytes, long nLines, long firstReadNo);

@@ -280,3 +280,45 @@ def test_max_kmer_res_counts(sdb):
         m2.max_counts()
     m2.close()
     store.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_async_host_batches_equal_the_synchronous_ones(pinned):
+    """gs_match_submit_async: batches queued back to back (two under way, buffer sets taken by turns, a slice with
+    offsets[0] != 0, growing batch sizes) give the table and per-read outputs of the oracle"""
+    import torch
+    sdb = synth.SynthDB(genera=2, species_per_genus=3, genome_len=20_000, seed=7)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    seq, off = synth.reads_host(sdb.genomes, 9000, seed=77)
+    off = off.astype(np.uint64)
+    run = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    want_cv, want_fl = run.submit(seq, off)
+    want_t, _ = run.finish()
+
+    def hold(a):  # page-locked copies are what a C / Java host gets from gs_pinned_alloc
+        return torch.from_numpy(a.copy()).pin_memory().numpy() if pinned else a.copy()
+
+    m = ga.FastqKMerMatcher(store)
+    cuts = [0, 500, 2500, 2501, 6000, 9000]
+    keep, tickets = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == 2501:   # a slice of the big arrays: offsets[0] != 0
+            s, o = hold(seq), hold(off[a:b + 1])
+        else:
+            s, o = hold(seq[int(off[a]):int(off[b])]), hold(off[a:b + 1] - off[a])
+        cv, fl = hold(np.full(b - a, -7, np.int32)), hold(np.full(b - a, 99, np.uint8))
+        keep.append((s, o, cv, fl))
+        tickets.append(m.submit_async(s, o, a, cv, fl))
+        if len(tickets) >= 2:
+            m.wait(tickets[-2])
+            pa, pb = cuts[len(tickets) - 2], cuts[len(tickets) - 1]
+            assert np.array_equal(keep[-2][2], want_cv[pa:pb]) and np.array_equal(keep[-2][3], want_fl[pa:pb])
+    m.wait(tickets[-1])
+    got_t, _ = m.finish()
+    assert np.array_equal(got_t, want_t)
+    assert np.array_equal(np.concatenate([k[2] for k in keep]), want_cv)
+    assert np.array_equal(np.concatenate([k[3] for k in keep]), want_fl)
+    with pytest.raises(ga.GsError):
+        m.wait(99)
+    m.close()
+    store.close()

@@ -35,3 +35,23 @@ for label, s_, o_ in (("pageable", seq, off), ("page-locked", pseq, poff)):
         dt = (time.perf_counter() - t0) / 3
         print(f"{label} host batch of {n} reads, per-read outputs={with_per_read}: {dt*1e3:.1f} ms -> {n*150/dt/1e9:.2f} Gbp/s "
               f"({n*150/dt/1e9:.2f} GB/s of sequence over PCIe)")
+
+# asynchronous batches from page-locked arrays: the copy of batch i+1 under the kernel of batch i (gs_match_submit_async)
+half = n // 2
+parts = []
+for a, b in ((0, half), (half, n)):
+    ps = torch.from_numpy(seq[int(off[a]):int(off[b])].copy()).pin_memory().numpy()
+    po = torch.from_numpy((off[a:b + 1] - off[a]).astype(np.int64)).pin_memory().numpy().view(off.dtype)
+    parts.append((ps, po, a))
+m.reset()
+t0 = time.perf_counter()
+rounds = 6
+last = []
+for r in range(rounds):
+    for ps, po, a in parts:
+        last.append(m.submit_async(ps, po, a))
+        if len(last) > 2:
+            m.wait(last[-3])
+m.sync()
+dt = (time.perf_counter() - t0) / rounds
+print(f"page-locked host batches of {half} reads, asynchronous (two under way): {dt*1e3:.1f} ms per {n} reads -> {n*150/dt/1e9:.2f} Gbp/s")
