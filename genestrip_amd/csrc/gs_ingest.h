@@ -699,31 +699,43 @@ public:
     bool active() const { return f_ != nullptr; }
     // A gzip file is written as a sequence of gzip members (RFC 1952 2.2; gunzip, zcat and java.util.zip.GZIPInputStream
     // read them as one stream), so that the threads that format a chunk can also compress their part of it: pack()
-    // turns a buffer into one member (level 1, like the "wb1" stream it replaces) and write(.., true) passes it
-    // through.  Small buffers are better left to the writer thread, which collects them into members of >= 1 MiB.
+    // turns a buffer into members (BGZF blocks, level 1 like the "wb1" stream it replaces) and write(.., true) passes
+    // them through.  Small buffers are better left to the writer thread, which collects >= 1 MiB before it packs.
     bool gzip() const { return gzip_; }
     bool pack(std::vector<uint8_t> &buf) {
         if (!gzip_ || !active()) return false;
-        const size_t piece = (size_t)1 << 30;  // zlib counts in 32 bits: one member per GiB of input
-        const size_t n_pieces = buf.empty() ? 1 : (buf.size() + piece - 1) / piece;
+        // the members are BGZF blocks (SAM spec 4.1: at most 64 KiB of text each, the member size in a 'BC' extra
+        // subfield), so that bgzip-aware tools -- and GsBgzfReader -- can inflate the file block-parallel
+        const size_t piece = 65280;
+        const size_t n_pieces = (buf.size() + piece - 1) / piece;
         std::vector<uint8_t> out = take();
-        out.resize(buf.size() + buf.size() / 8 + n_pieces * 1024);
+        out.resize(buf.size() + n_pieces * 64 + 64);  // (a block that does not compress is stored: 5 bytes + 26 of frame)
+        z_stream z{};
+        bool ok = deflateInit2(&z, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
         size_t produced = 0;
-        bool ok = true;
         for (size_t i = 0; i < n_pieces && ok; i++) {
             const size_t at = i * piece, n = std::min(piece, buf.size() - at);
-            z_stream z{};
-            ok = deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+            uint8_t *o = out.data() + produced;
+            ok = out.size() - produced >= n + 64 && deflateReset(&z) == Z_OK;
             if (!ok) break;
-            ok = deflateBound(&z, (uLong)n) <= out.size() - produced;
             z.next_in = buf.data() + at;
             z.avail_in = (uInt)n;
-            z.next_out = out.data() + produced;
-            z.avail_out = (uInt)std::min<size_t>(out.size() - produced, 0xffffffffu);
-            ok = ok && deflate(&z, Z_FINISH) == Z_STREAM_END;
-            produced += (size_t)z.total_out;
-            deflateEnd(&z);
+            z.next_out = o + 18;
+            z.avail_out = (uInt)(n + 64 - 26);
+            ok = deflate(&z, Z_FINISH) == Z_STREAM_END;
+            const size_t clen = (size_t)z.total_out, bsize = 18 + clen + 8 - 1;
+            ok = ok && bsize < 65536;
+            static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+            memcpy(o, head, 16);
+            o[16] = (uint8_t)bsize;
+            o[17] = (uint8_t)(bsize >> 8);
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data() + at, (uInt)n), isz = (uint32_t)n;
+            uint8_t *t = o + 18 + clen;
+            for (int q = 0; q < 4; q++) t[q] = (uint8_t)(crc >> (8 * q));
+            for (int q = 0; q < 4; q++) t[4 + q] = (uint8_t)(isz >> (8 * q));
+            produced += 18 + clen + 8;
         }
+        deflateEnd(&z);
         if (!ok) {
             failed_ = true;
             give_back(std::move(out));
@@ -765,9 +777,10 @@ public:
             th_.join();
         }
         if (f_) {
-            if (gzip_ && !wrote_member_) {  // an empty gzip file is one empty member, not zero bytes
-                std::vector<uint8_t> none;
-                if (pack(none)) put(none);
+            if (gzip_) {  // BGZF's end-of-file marker: an empty block (also what makes an empty output a valid gzip file)
+                static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0,
+                                                      3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (!failed_ && fwrite(eof_block, 1, sizeof eof_block, f_) != sizeof eof_block) failed_ = true;
             }
             if (fclose(f_) != 0) failed_ = true;
         }
@@ -789,7 +802,6 @@ private:
     void put(const std::vector<uint8_t> &b) {
         if (failed_ || b.empty()) return;
         if (fwrite(b.data(), 1, b.size(), f_) != b.size()) failed_ = true;
-        wrote_member_ = true;
     }
     void flush_pending() {
         if (pending_.empty()) return;
@@ -819,7 +831,7 @@ private:
         }
         if (gzip_) flush_pending();
     }
-    bool gzip_ = false, wrote_member_ = false;
+    bool gzip_ = false;
     FILE *f_ = nullptr;
     std::thread th_;
     std::mutex m_;
