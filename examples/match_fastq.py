@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--demo", action="store_true", help="synthetic store + synthetic reads")
     ap.add_argument("--csv", default="match.csv")
     ap.add_argument("--kraken-out")
-    ap.add_argument("--filtered")
+    ap.add_argument("--filtered", help="FASTQ of the reads with a hit (a name ending in .gz is written as BGZF)")
+    ap.add_argument("--with-probs", action="store_true", help="written reads keep their quality lines (withProbs)")
     args = ap.parse_args()
     if not args.demo and not (args.store and args.fastq):
         ap.error("give --demo, or --store and FASTQ files")
@@ -52,7 +53,7 @@ def main():
         paths = [tmp.name]
 
     table, dtable, tot = host.match_files(store, paths, kraken_out_path=args.kraken_out, filtered_path=args.filtered,
-                                          taxids=db.taxids if args.kraken_out else None)
+                                          taxids=db.taxids if args.kraken_out else None, with_probs=args.with_probs)
     print(f"{tot.reads} reads, {tot.bps} bases in {tot.seconds_total:.2f} s "
           f"({tot.bps / max(tot.seconds_total, 1e-9) / 1e9:.2f} Gbp/s end to end)")
     db_kmers = np.bincount(db.value_idx, minlength=db.n_values).astype(np.int64)
