@@ -161,10 +161,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         return fail(GS_E_INVALID, "bad store arrays (n_values must be in [1, 2^24])");
     int rc = use_device(device);
     if (rc) return rc;
+    bool ascending = true;
     for (int64_t i = 0; i < n; i++) {
         if (vidx[i] < 0 || vidx[i] >= n_values) return fail(GS_E_INVALID, "value_idx out of range");
-        if (i && kmers[i] <= kmers[i - 1]) return fail(GS_E_INVALID, "kmers_sorted must be strictly ascending");
+        if (i && kmers[i] <= kmers[i - 1]) ascending = false;
         if (kmers[i] < 0 || (k < 31 && (u64)kmers[i] >> (2 * k))) return fail(GS_E_INVALID, "k-mer exceeds 2k bits");
+    }
+    if (!ascending) {
+        // KMerStore.visit order of a RadixKMerStore (C/store/RadixKMerStore.java:714-729: by radix bucket, then by the
+        // remaining bits) is not ascending.  The table does not care about the order, only that the keys are distinct.
+        std::vector<int64_t> sorted(kmers, kmers + n);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(GS_E_INVALID, "k-mers must be distinct");
     }
     // ---- tree arrays
     std::vector<int32_t> parent(n_values), depth(n_values, 0), tin(n_values, 0), tout(n_values, 0);
@@ -406,19 +414,74 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE4"
+    char magic[8];  // "GSSTORE5"
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
     uint64_t mgate_words;  // 32-bit words, a power of two
+    uint64_t checksum;     // store_checksum over table | gate | mgate | tree
 };
+
+// two running 64-bit sums over the payload's 32-bit words (Fletcher style): position sensitive, one pass
+struct StoreChecksum {
+    uint64_t a = 1, b = 0;
+    void add(const void *p, size_t bytes) {
+        const uint32_t *w = (const uint32_t *)p;
+        for (size_t i = 0; i < bytes / 4; i++) {
+            a += w[i];
+            b += a;
+        }
+    }
+    uint64_t value() const { return a ^ (b << 1) ^ (b >> 63); }
+};
+
+// what the kernels index with: every field of a store image that came from a file is checked before it reaches HBM
+static const char *store_image_defect(const GsStoreFileHeader &h, const std::vector<u64> &table, const std::vector<int32_t> &tree) {
+    const gs_db_info &in = h.info;
+    if (in.k < 1 || in.k > 31) return "k outside [1, 31]";
+    if (in.n_values < 1 || in.n_values > (1 << 24)) return "n_values outside [1, 2^24]";
+    if (h.vbits < 1 || h.vbits > 25 || ((u64)in.n_values >> h.vbits) != 0) return "value bits do not hold n_values";
+    if ((int)h.bucket_bits < std::max((int)h.vbits + 1, 4) || h.bucket_bits > 29) return "bucket bits out of range";
+    if (in.n_buckets != ((int64_t)1 << h.bucket_bits) || in.table_bytes != in.n_buckets * 64) return "table size does not match the bucket count";
+    if (in.value_bits != (int32_t)h.vbits) return "value bits disagree";
+    if ((h.gate_words & (h.gate_words - 1)) != 0 || h.gate_words > ((uint64_t)1 << 28)) return "gate size is not a power of two";
+    if (h.gate_words && h.bucket_bits + (uint32_t)bits_for(h.gate_words - 1) > GS_GATE_FIELD_SHIFT) return "gate too large for its index field";
+    if ((h.mgate_words & (h.mgate_words - 1)) != 0 || h.mgate_words > ((uint64_t)1 << 30)) return "minimizer gate size is not a power of two";
+    if (h.mgate_words && in.k < GS_MIN_K) return "minimizer gate on a store with k < 19";
+    if (in.gate_bytes != (int64_t)(h.gate_words * 8) || in.mgate_bytes != (int64_t)(h.mgate_words * 4)) return "gate sizes disagree";
+    if (in.max_displacement < 0 || in.max_displacement > GS_MAX_DISP) return "displacement out of range";
+    const int32_t nv = in.n_values;
+    const int32_t *parent = tree.data(), *depth = parent + nv, *tin = depth + nv, *tout = tin + nv;
+    for (int32_t v = 0; v < nv; v++) {
+        if (parent[v] < -2 || parent[v] >= nv || parent[v] == v) return "tree: parent out of range";
+        if (parent[v] == -2) continue;
+        if (tin[v] < 0 || tout[v] <= tin[v] || tout[v] > nv || depth[v] < 0 || depth[v] >= nv) return "tree: pre-order interval out of range";
+        if (parent[v] >= 0) {  // a child's interval nests strictly inside its parent's, one level down: walks end at a root
+            const int32_t p = parent[v];
+            if (parent[p] == -2 || depth[v] != depth[p] + 1 || tin[v] <= tin[p] || tout[v] > tout[p]) return "tree: child interval not nested in its parent's";
+        } else if (depth[v] != 0)
+            return "tree: root with a depth";
+    }
+    const u64 vmask = ((u64)1 << h.vbits) - 1;
+    int64_t stored = 0;
+    for (size_t i = 0; i < table.size(); i++) {
+        const u64 s = table[i];
+        if (s == 0) continue;
+        const u64 v1 = (s >> 1) & vmask;
+        if (v1 == 0 || v1 > (u64)nv || parent[v1 - 1] == -2) return "table: slot value without a tree node";
+        if (s & 1) return "table: seen bit set in a stored image";
+        stored++;
+    }
+    if (stored != in.n_stored) return "table: entry count disagrees with the header";
+    return nullptr;
+}
 
 extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (!db || !path) return fail(GS_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE4", 8);
+    memcpy(h.magic, "GSSTORE5", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
@@ -432,14 +495,22 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (!gate.empty()) HIP_TRY(hipMemcpy(gate.data(), db->d_gate, gate.size() * sizeof(u64), hipMemcpyDeviceToHost));
     if (!mgate.empty()) HIP_TRY(hipMemcpy(mgate.data(), db->d_mgate, mgate.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tree.data(), db->d_tree, tree.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    {
+        StoreChecksum cs;
+        cs.add(table.data(), table.size() * sizeof(u64));
+        cs.add(gate.data(), gate.size() * sizeof(u64));
+        cs.add(mgate.data(), mgate.size() * sizeof(uint32_t));
+        cs.add(tree.data(), tree.size() * sizeof(int32_t));
+        h.checksum = cs.value();
+    }
     FILE *f = fopen(path, "wb");
-    if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
+    if (!f) return fail(GS_E_IO, std::string("cannot open ") + path);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
               fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
               fwrite(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
               fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     ok = (fclose(f) == 0) && ok;
-    return ok ? GS_OK : fail(GS_E_INVALID, std::string("short write to ") + path);
+    return ok ? GS_OK : fail(GS_E_IO, std::string("short write to ") + path);
 } catch (const std::bad_alloc &) {
     return fail(GS_E_NOMEM, "out of host memory");
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
@@ -454,13 +525,20 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE4", 8) != 0 || h.info.n_values < 1 ||
-        h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.bucket_bits > 29 || h.vbits > 25 ||
-        (h.mgate_words & (h.mgate_words - 1)) != 0 || h.mgate_words > ((uint64_t)1 << 30)) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE5", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+        h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
+        h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30)) {
         fclose(f);
-        return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file");
+        return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file (or one of another layout version)");
     }
     const size_t nv = (size_t)h.info.n_values;
+    {   // the payload the header announces must be exactly what the file holds
+        const uint64_t want = (uint64_t)sizeof(h) + (uint64_t)h.info.n_buckets * 64 + h.gate_words * 8 + h.mgate_words * 4 + (uint64_t)nv * 16;
+        if (fseeko(f, 0, SEEK_END) != 0 || (uint64_t)ftello(f) != want || fseeko(f, (off_t)sizeof(h), SEEK_SET) != 0) {
+            fclose(f);
+            return fail(GS_E_INVALID, std::string(path) + ": file size does not match its header (truncated or damaged)");
+        }
+    }
     std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
     std::vector<uint32_t> mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
@@ -470,6 +548,15 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
                     fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     fclose(f);
     if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
+    {
+        StoreChecksum cs;
+        cs.add(table.data(), table.size() * sizeof(u64));
+        cs.add(gate.data(), gate.size() * sizeof(u64));
+        cs.add(mgate.data(), mgate.size() * sizeof(uint32_t));
+        cs.add(tree.data(), tree.size() * sizeof(int32_t));
+        if (cs.value() != h.checksum) return fail(GS_E_INVALID, std::string(path) + ": payload checksum mismatch (damaged file)");
+    }
+    if (const char *why = store_image_defect(h, table, tree)) return fail(GS_E_INVALID, std::string(path) + ": " + why);
     gs_db *db = new gs_db();
     db->device = device;
     hipDeviceProp_t prop;
@@ -818,7 +905,7 @@ static void run_free(gs_run *run) {
 extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) {
     if (!out || !db || !cfg) return fail(GS_E_INVALID, "NULL argument");
     *out = nullptr;
-    if (cfg->max_paths < 1 || cfg->max_paths > 64) return fail(GS_E_INVALID, "max_paths must be in [1,64]");
+    if (cfg->max_paths < 1 || cfg->max_paths > 128) return fail(GS_E_INVALID, "max_paths must be in [1,128] (C/GSConfigKey.java:350)");
     HIP_TRY(hipSetDevice(db->device));
     if (cfg->count_unique && db->unique_owner)
         return fail(GS_E_STATE, "this store already has an active unique-counting run (the seen bits live in the table)");
@@ -892,6 +979,14 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
         HIP_TRY(hipMalloc((void **)&run->d_serial, waves * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(run->d_scratch, 0, waves * nv * 2 * sizeof(int32_t), run->stream));
         HIP_TRY(hipMemsetAsync(run->d_serial, 0, waves * sizeof(uint32_t), run->stream));
+        if (const char *e = getenv("GS_TEST_LONG_SERIAL")) {
+            // test hook for the serial wrap of gs_match_long_kernel: start every wave's serial just below 2^32 and fill
+            // its tag / count rows with the values the serials take right after the wrap (1, 2, ..): without the clear
+            // on wrap the first reads after it would take stale tags for their own
+            const unsigned long v = strtoul(e, nullptr, 0);
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)run->d_serial, (int)(uint32_t)v, waves, run->stream));
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)run->d_scratch, 1, waves * nv * 2, run->stream));
+        }
     }
     return GS_OK;
 }

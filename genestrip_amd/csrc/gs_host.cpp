@@ -863,6 +863,10 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
 extern "C" int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
                                   int64_t *reads_of_file, gs_host_totals *totals) try {
     if (!run || !db || !paths || n_paths < 0 || !file_index || !reads_of_file) return hfail(GS_E_INVALID, "NULL argument");
+    // the max-contig key keeps 40 bits of the read number (gs_kernels.hip: key_lo): 8 of them are the file, 32 the read
+    for (int i = 0; i < n_paths; i++)
+        if (file_index[i] < 0 || file_index[i] >= GS_HOST_MAX_FILE_INDEX)
+            return hfail(GS_E_UNSUPPORTED, "file_index must be in [0, 256): read numbers are (file << 32 | read) in a 40-bit field");
     MatchCtx c;
     int rc = gs_db_get_info(db, &c.info);
     if (rc) return rc;

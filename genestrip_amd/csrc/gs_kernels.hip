@@ -395,8 +395,10 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // ---------------------------------------------------------------------------------------------------
 // one read on one wave.  LONG = false: max <= 128 (one iteration, distinct nodes kept in registers).
 // LONG = true: any length; tag/cnt are this wave's scratch rows of n_values ints, serial its read tag.
+// WIDE = true: maxClassificationPaths in 65..128 (C/GSConfigKey.java:350 allows 1..128): candidate path i lives in
+// lane i & 63 of register set i >> 6; with WIDE = false there is one set and lane = path.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG, bool FROM_NODES, int KC>
+template <bool LONG, bool FROM_NODES, int KC, bool WIDE>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
@@ -419,7 +421,14 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         int carry_last = GS_NODE_NONE;  // node of the last position of the previous iteration
         int cur_start = 0;
         int dviA = -1, dviB = -1, dcntA = 0, dcntB = 0, nd = 0;  // !LONG: distinct hit nodes (cap 128 >= #contigs)
-        int path = -1, ptin = 0, ptout = 0, used = 0;           // candidate paths, lane i = path i
+        constexpr int NP = WIDE ? 2 : 1;
+        int path[NP], ptin[NP], ptout[NP], used = 0;            // candidate paths: path i in lane i & 63 of set i >> 6
+#pragma unroll
+        for (int h = 0; h < NP; h++) {
+            path[h] = -1;
+            ptin[h] = 0;
+            ptout[h] = 0;
+        }
 
         for (int it = 0; it < n_iter; it++) {
             const int base = it << 7;  // first k-mer position of this iteration
@@ -552,22 +561,33 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         if (lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
                         if (P.classify) {  // mergeReadTaxidPath (:568-586)
                             const int ntin = st.tin[nvj], ntout = st.tout[nvj];
-                            const bool mine = lane < used;
-                            const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
-                            const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
-                            const u64 m = __ballot(a || b);
-                            if (m) {
-                                const int i = __builtin_ctzll(m);
-                                if (lane == i && a) {
-                                    path = nvj;
-                                    ptin = ntin;
-                                    ptout = ntout;
+                            bool related = false;  // the first path (in path order) that is an ancestor or a descendant
+#pragma unroll
+                            for (int h = 0; h < NP; h++) {
+                                if (!related) {
+                                    const bool mine = 64 * h + lane < used;
+                                    const bool a = mine && gs_anc_or_self(ptin[h], ptout[h], ntin);  // path anc-or-self of node
+                                    const bool b = mine && gs_anc_or_self(ntin, ntout, ptin[h]);     // node anc-or-self of path
+                                    const u64 m = __ballot(a || b);
+                                    if (m) {
+                                        const int i = __builtin_ctzll(m);
+                                        if (lane == i && a) {
+                                            path[h] = nvj;
+                                            ptin[h] = ntin;
+                                            ptout[h] = ntout;
+                                        }
+                                        related = true;
+                                    }
                                 }
-                            } else if (used < P.max_paths) {
-                                if (lane == used) {
-                                    path = nvj;
-                                    ptin = ntin;
-                                    ptout = ntout;
+                            }
+                            if (!related && used < P.max_paths) {
+#pragma unroll
+                                for (int h = 0; h < NP; h++) {
+                                    if (64 * h + lane == used) {
+                                        path[h] = nvj;
+                                        ptin[h] = ntin;
+                                        ptout[h] = ntout;
+                                    }
                                 }
                                 used++;
                             }
@@ -596,33 +616,48 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 const bool disabled = m >= 0 && ((m >= 1 && (double)tax_err > m) || ((double)tax_err > m * (double)max));
                 if (!disabled) {
                     // sumCounts per candidate path (SmallTaxTree.java:184-193): lanes = paths
-                    int sum = 0;
+                    int sum[NP];
+#pragma unroll
+                    for (int h = 0; h < NP; h++) sum[h] = 0;
                     if (LONG) {
-                        if (lane < used)
-                            for (int x = path; x >= 0; x = st.parent[x])
-                                if (gs_sc_load(tag + x) == serial) sum += gs_sc_load(cnt + x);
+#pragma unroll
+                        for (int h = 0; h < NP; h++)
+                            if (64 * h + lane < used)
+                                for (int x = path[h]; x >= 0; x = st.parent[x])
+                                    if (gs_sc_load(tag + x) == serial) sum[h] += gs_sc_load(cnt + x);
                     } else {
                         for (int dd = 0; dd < nd; dd++) {
                             const int v = dd < 64 ? gs_readlane(dviA, dd) : gs_readlane(dviB, dd - 64);
                             const int c = dd < 64 ? gs_readlane(dcntA, dd) : gs_readlane(dcntB, dd - 64);
-                            if (lane < used && gs_anc_or_self(st.tin[v], st.tout[v], ptin)) sum += c;
+#pragma unroll
+                            for (int h = 0; h < NP; h++)
+                                if (64 * h + lane < used && gs_anc_or_self(st.tin[v], st.tout[v], ptin[h])) sum[h] += c;
                         }
                     }
                     // max + ties exactly as the in-place scan (:476-487); tie order = path order
                     int best = 0;
-                    u64 tie_mask = 0;
+                    u64 tie_mask[NP];
+#pragma unroll
+                    for (int h = 0; h < NP; h++) tie_mask[h] = 0;
                     for (int i = 0; i < used; i++) {
-                        const int si = gs_readlane(sum, i);
+                        const int si = (!WIDE || i < 64) ? gs_readlane(sum[0], i) : gs_readlane(sum[NP - 1], i - 64);
                         if (si > best) {
                             best = si;
-                            tie_mask = 1ULL << i;
-                        } else if (si == best)
-                            tie_mask |= 1ULL << i;
+#pragma unroll
+                            for (int h = 0; h < NP; h++) tie_mask[h] = 0;
+                        }
+                        if (si >= best) {
+                            if (!WIDE || i < 64)
+                                tie_mask[0] |= 1ULL << i;
+                            else
+                                tie_mask[NP - 1] |= 1ULL << (i - 64);
+                        }
                     }
-                    int cand = path;  // per tied lane: the node entering the LCA fold
+                    int cand[NP];  // per tied lane: the node entering the LCA fold
+#pragma unroll
+                    for (int h = 0; h < NP; h++) cand[h] = path[h];
                     if (P.threshold > 1) {
                         // lowestNodeWhereSumAboveThreshold per tied path (SmallTaxTree.java:208-221)
-                        int mapped = -1;
                         if (!LONG) {
                             s_dvi[wave_in_block][lane] = dviA;
                             s_dcnt[wave_in_block][lane] = dcntA;
@@ -632,39 +667,46 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                             __builtin_amdgcn_wave_barrier();
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         }
-                        if ((tie_mask >> lane) & 1ULL) {
-                            int acc = 0;
-                            for (int x = path; x >= 0 && mapped < 0; x = st.parent[x]) {
-                                if (LONG) {
-                                    if (gs_sc_load(tag + x) == serial) {
-                                        acc += gs_sc_load(cnt + x);
-                                        if (acc >= P.threshold) mapped = x;
-                                    }
-                                } else {
-                                    for (int dd = 0; dd < nd; dd++)
-                                        if (s_dvi[wave_in_block][dd] == x) {
-                                            acc += s_dcnt[wave_in_block][dd];
+#pragma unroll
+                        for (int h = 0; h < NP; h++) {
+                            int mapped = -1;
+                            if ((tie_mask[h] >> lane) & 1ULL) {
+                                int acc = 0;
+                                for (int x = path[h]; x >= 0 && mapped < 0; x = st.parent[x]) {
+                                    if (LONG) {
+                                        if (gs_sc_load(tag + x) == serial) {
+                                            acc += gs_sc_load(cnt + x);
                                             if (acc >= P.threshold) mapped = x;
                                         }
+                                    } else {
+                                        for (int dd = 0; dd < nd; dd++)
+                                            if (s_dvi[wave_in_block][dd] == x) {
+                                                acc += s_dcnt[wave_in_block][dd];
+                                                if (acc >= P.threshold) mapped = x;
+                                            }
+                                    }
                                 }
                             }
+                            cand[h] = mapped;
                         }
-                        cand = mapped;
                     }
                     int cn = -1, first_node = -1;
                     {
                         bool first = true;
-                        u64 tm = tie_mask;
-                        while (tm) {
-                            const int i = __builtin_ctzll(tm);
-                            tm &= tm - 1;
-                            const int x = gs_readlane(cand, i);
-                            if (first) {
-                                cn = x;
-                                first_node = x;
-                                first = false;
-                            } else
-                                cn = gs_lca(st, cn, x);
+#pragma unroll
+                        for (int h = 0; h < NP; h++) {
+                            u64 tm = tie_mask[h];
+                            while (tm) {
+                                const int i = __builtin_ctzll(tm);
+                                tm &= tm - 1;
+                                const int x = gs_readlane(cand[h], i);
+                                if (first) {
+                                    cn = x;
+                                    first_node = x;
+                                    first = false;
+                                } else
+                                    cn = gs_lca(st, cn, x);
+                            }
                         }
                     }
                     out_class = cn;
@@ -773,7 +815,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
     }
 
-template <bool LDS_STATS, bool FROM_NODES, int KC>
+template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false>
 __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAVES, GS_WAVES))) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
@@ -808,13 +850,13 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES, KC>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
+        gs_process_read<false, FROM_NODES, KC, WIDE>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
                                            s_g[wave_in_block]);
     }
     GS_STATS_EPILOGUE()
 }
 
-template <bool LDS_STATS, bool FROM_NODES>
+template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
@@ -828,14 +870,18 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     uint32_t serial = serials[wave_id];
     for (int64_t i = wave_id; i < (int64_t)n_long; i += n_waves) {
         serial++;
-        if (serial == 0) serial = 1;  // tags start zeroed; a wrap after 2^32 reads per wave may alias once
+        if (serial == 0) {  // wrap after 2^32 - 1 long reads on this wave: old tags could alias, so the wave's tag row starts over
+            for (int i = lane; i < nv; i += 64) gs_sc_store(tag + i, 0);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            serial = 1;
+        }
         const int64_t r = (int64_t)P.long_list[i];
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
         const uint32_t none[3] = {0, 0, 0};
         GsPrefetch nopf;
         nopf.rd = nullptr;
-        gs_process_read<true, FROM_NODES, 0>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+        gs_process_read<true, FROM_NODES, 0, WIDE>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
                               (int)serial, none, nopf, s_g[wave_in_block]);
     }
     if (lane == 0) serials[wave_id] = serial;
@@ -1401,6 +1447,20 @@ static size_t gs_stats_lds_bytes(int n_values) {
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->max_paths > 64) {  // two candidate paths per lane (the reference allows up to 128, C/GSConfigKey.java:350)
+        if (P->nodes == nullptr) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        } else {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, true, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, true, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        }
+        return hipGetLastError();
+    }
     // k = 31 (the reference's default and maximum) runs a kernel with k folded in at compile time
     if (P->nodes == nullptr) {
         if (P->db.k == 31) {
@@ -1427,6 +1487,20 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
                                            hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->max_paths > 64) {
+        if (P->nodes == nullptr) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_long_kernel<true, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+            else
+                hipLaunchKernelGGL((gs_match_long_kernel<false, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        } else {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_long_kernel<true, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+            else
+                hipLaunchKernelGGL((gs_match_long_kernel<false, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        }
+        return hipGetLastError();
+    }
     if (P->nodes == nullptr) {
         if (lds_stats)
             hipLaunchKernelGGL((gs_match_long_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);

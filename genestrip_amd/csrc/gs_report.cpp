@@ -200,8 +200,10 @@ extern "C" int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, 
         else if (nmc) o.push_back(';');  // maxKMerCounts == null for rows added as missing ancestors
         o.push_back('\n');
     }
-    fwrite(o.data(), 1, o.size(), f);
-    fclose(f);
+    // the CSV is the bit-exact deliverable: a short write (full disk, I/O error) must not pass for a result
+    const bool written = fwrite(o.data(), 1, o.size(), f) == o.size();
+    const bool closed = fclose(f) == 0;
+    if (!written || !closed) return hfail(GS_E_IO, std::string("short write to ") + path);
     return GS_OK;
 } catch (const std::bad_alloc &) {
     return hfail(GS_E_NOMEM, "out of host memory");

@@ -62,6 +62,8 @@ def match_files_sharded(matcher, paths, group=None, device=None, via_host=False)
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     paths = list(paths)
+    if len(paths) > 256:  # gs_host_match_into: (file << 32 | read) must fit the 40-bit read-number field
+        raise ValueError("match_files_sharded handles at most 256 files per run")
     mine = list(range(rank, len(paths), world))
     counts_mine, tot = _h.match_files_into(matcher, [paths[i] for i in mine], mine)
     st = matcher.device_state()  # syncs the run's stream and refreshes the compact unique bitmap

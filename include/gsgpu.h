@@ -57,8 +57,10 @@ int gs_device_count(int *n);
  * (C/tax/SmallTaxTree.java:184-289).  Filled from the Java side through KMerStore.visit
  * (C/store/KMerSortedArray.java:426-439): (kmer, valueIndex) in ascending kmer order.
  *
- *   kmers_sorted[n_entries]  canonical k-mers in the reference encoding (CGAT.java:66-74,145-147),
- *                            strictly ascending
+ *   kmers_sorted[n_entries]  canonical k-mers in the reference encoding (CGAT.java:66-74,145-147), distinct, in
+ *                            KMerStore.visit order: ascending for the default KMerSortedArray; by radix bucket and
+ *                            remaining bits for the opt-in RadixKMerStore (C/store/RadixKMerStore.java:714-729).
+ *                            Any order of distinct k-mers is accepted (ascending input skips the distinctness sort).
  *   value_idx[n_entries]     store value index of each k-mer, in [0, n_values)
  *   parent_vi[n_values]      value index of the parent tree node; -1 for the root; -2 if the value has
  *                            no tree node (Database.convertKMerStore maps it to null => k-mer is a miss,
@@ -104,7 +106,7 @@ typedef struct gs_run gs_run;
 typedef struct {
     int32_t classify;           /* taxTree != null (MatchResultGoal.java:125-127)                */
     int32_t count_unique;       /* GSConfigKey countUniqueKMers (C/GSConfigKey.java:305)         */
-    int32_t max_paths;          /* maxClassificationPaths (:350), 1..64                          */
+    int32_t max_paths;          /* maxClassificationPaths (:350), 1..128                         */
     int32_t threshold;          /* minKMersForClass (:341)                                       */
     double max_read_tax_err;    /* maxReadTaxErrorCount (:328), -1 = off                         */
     double max_read_class_err;  /* maxReadClassErrorCount (:337), -1 = off                       */

@@ -74,7 +74,9 @@ int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *p
  * merges its run's device state with the others (gs_match_device_state) and finishes.  file_index[n_paths] = position
  * of each file in the global file order; read numbers on the device are (file_index << 32 | read in file), so the
  * max-contig tie-break keeps the global file order; reads_of_file[n_paths] receives the read counts, which turn those
- * numbers into running ones after the merge.  No per-read outputs. */
+ * numbers into running ones after the merge.  No per-read outputs.  file_index[i] must lie in [0, GS_HOST_MAX_FILE_INDEX)
+ * (the max-contig key has 40 bits for the read number: 8 for the file, 32 for the read); GS_E_UNSUPPORTED otherwise. */
+#define GS_HOST_MAX_FILE_INDEX 256
 int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
                        int64_t *reads_of_file, gs_host_totals *totals);
 

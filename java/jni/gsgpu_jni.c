@@ -6,6 +6,7 @@
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "gsgpu.h"
 

@@ -311,6 +311,15 @@ struct orc_db {
     int32_t *depth;
     int has_tree;
     orc_bloom *gate;
+    /* RadixKMerStore layout (C/store/RadixKMerStore.java), radix_bits == 0: KMerSortedArray layout.
+     * radix_entries = the buckets radixIndex[0], radixIndex[1], .. back to back (every bucket exactly full),
+     * bucket_off[r] = bucketOffset[r] after optimize() (:651-655), bucket_off[2^radix_bits] = entries.
+     * kmers[] / vidx[] are then in visit() order (:714-729), i.e. indexed by the global position `pos`. */
+    int radix_bits;
+    int remaining_bits;
+    uint64_t remaining_mask;
+    uint64_t *radix_entries;
+    int64_t *bucket_off;
 };
 
 orc_db *orc_db_create(int k, int64_t n, const int64_t *kmers, const int32_t *vidx, int32_t n_values,
@@ -341,8 +350,105 @@ orc_db *orc_db_create(int k, int64_t n, const int64_t *kmers, const int32_t *vid
     return db;
 }
 
+/* ---- RadixKMerStore (opt-in `useRadixStore`): entry = valueIndex << remainingBits | (kmer >>> radixBits),
+ * bucket = low radixBits bits of the k-mer, buckets sorted by the remaining bits (optimize, :632-655) ---- */
+static uint64_t g_radix_sort_mask; /* qsort has no context argument; the oracle builds stores from one thread */
+static int radix_entry_cmp(const void *a, const void *b) { /* remainingComparator :640-641 */
+    uint64_t x = *(const uint64_t *)a & g_radix_sort_mask, y = *(const uint64_t *)b & g_radix_sort_mask;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int32_t orc_radix_max_values(int radix_bits) { /* maxValuesForRadix :160-164 */
+    if (radix_bits < 16 || radix_bits > 30) return -1; /* checkRadixBits :166-171 */
+    int value_bits = 64 - (62 - radix_bits);
+    if (value_bits > 30) value_bits = 30;
+    return (int32_t)1 << value_bits;
+}
+
+orc_db *orc_db_create_radix(int k, int radix_bits, int64_t n, const int64_t *kmers, const int32_t *vidx,
+                            int32_t n_values, const int32_t *parent_vi, int bloom_gate) {
+    if (orc_radix_max_values(radix_bits) < 0 || n_values > orc_radix_max_values(radix_bits)) return NULL;
+    /* tree arrays and scalar fields as for the sorted layout; the entry arrays are rebuilt below */
+    orc_db *db = orc_db_create(k, 0, kmers, vidx, n_values, parent_vi, 0);
+    const int64_t n_buckets = (int64_t)1 << radix_bits;
+    const uint64_t radix_mask = (uint64_t)n_buckets - 1;
+    db->radix_bits = radix_bits;
+    db->remaining_bits = 62 - radix_bits; /* remainingBitsForRadix :146-148 */
+    db->remaining_mask = (1ULL << db->remaining_bits) - 1;
+    db->n = n;
+    /* the caller of the constructor has counted the k-mers per bucket with radixOf (:306-308); capacities are exact */
+    db->bucket_off = (int64_t *)calloc((size_t)n_buckets + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) db->bucket_off[((uint64_t)kmers[i] & radix_mask) + 1]++;
+    for (int64_t r = 0; r < n_buckets; r++) db->bucket_off[r + 1] += db->bucket_off[r];
+    db->radix_entries = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *fill = (int64_t *)calloc((size_t)n_buckets, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) { /* putLong :319-364 in the given order (no fill-time filter) */
+        const uint64_t radix = (uint64_t)kmers[i] & radix_mask;
+        const uint64_t remaining = (uint64_t)kmers[i] >> radix_bits;                       /* remainingOf :311-313 */
+        db->radix_entries[db->bucket_off[radix] + fill[radix]++] =
+            ((uint64_t)(int64_t)vidx[i] << db->remaining_bits) | remaining;                 /* entryOf :315-317 */
+    }
+    free(fill);
+    g_radix_sort_mask = db->remaining_mask; /* optimize :632-650 */
+    for (int64_t r = 0; r < n_buckets; r++) {
+        const int64_t f = db->bucket_off[r + 1] - db->bucket_off[r];
+        if (f > 1) qsort(db->radix_entries + db->bucket_off[r], (size_t)f, sizeof(uint64_t), radix_entry_cmp);
+    }
+    /* the flat (kmer, value index) arrays in visit() order (:714-729): position pos = bucketOffset[r] + i */
+    free(db->kmers);
+    free(db->vidx);
+    db->kmers = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    db->vidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t r = 0; r < n_buckets; r++)
+        for (int64_t p = db->bucket_off[r]; p < db->bucket_off[r + 1]; p++) {
+            const uint64_t e = db->radix_entries[p];
+            db->kmers[p] = (int64_t)(((e & db->remaining_mask) << radix_bits) | (uint64_t)r);
+            db->vidx[p] = (int32_t)(e >> db->remaining_bits);
+        }
+    if (bloom_gate) { /* optimize :656-671: the optimized filter is refilled from the reassembled k-mers */
+        db->gate = orc_bloom_create(ORC_BLOOM_BLOCKED, n, 0.01);
+        for (int64_t i = 0; i < n; i++) orc_bloom_put(db->gate, db->kmers[i]);
+    }
+    return db;
+}
+
+/* KMerStore.visit (KMerSortedArray.java:426-439 / RadixKMerStore.java:714-729): entry at position pos */
+int64_t orc_db_entries(const orc_db *db) { return db->n; }
+void orc_db_visit(const orc_db *db, int64_t *kmers, int32_t *vidx) {
+    memcpy(kmers, db->kmers, sizeof(int64_t) * (size_t)db->n);
+    memcpy(vidx, db->vidx, sizeof(int32_t) * (size_t)db->n);
+}
+
+/* RadixKMerStore.getLong :369-412 (sorted branch) */
+static int32_t radix_db_get(const orc_db *db, int64_t kmer, int64_t *pos) {
+    const uint64_t radix = (uint64_t)kmer & (((uint64_t)1 << db->radix_bits) - 1);
+    const int64_t fill = db->bucket_off[radix + 1] - db->bucket_off[radix];
+    if (fill == 0) return -1; /* null bucket: return early, even before the filter (:372-375) */
+    if (db->gate && !orc_bloom_contains(db->gate, kmer)) return -1;
+    const uint64_t remaining = (uint64_t)kmer >> db->radix_bits;
+    const uint64_t *bucket = db->radix_entries + db->bucket_off[radix];
+    int64_t lo = 0, hi = fill - 1;
+    while (lo <= hi) {
+        const int64_t mid = (int64_t)(((uint64_t)lo + (uint64_t)hi) >> 1);
+        const uint64_t mid_rem = bucket[mid] & db->remaining_mask;
+        if (mid_rem < remaining)
+            lo = mid + 1;
+        else if (mid_rem > remaining)
+            hi = mid - 1;
+        else {
+            if (pos) *pos = db->bucket_off[radix] + mid; /* posStore[0] = bucketOffset[radix] + pos (:408-410) */
+            const int32_t vi = (int32_t)(bucket[mid] >> db->remaining_bits);
+            if (db->parent[vi] == -2) return -1;
+            return vi;
+        }
+    }
+    return -1;
+}
+
 void orc_db_destroy(orc_db *db) {
     if (!db) return;
+    free(db->radix_entries);
+    free(db->bucket_off);
     free(db->kmers);
     free(db->vidx);
     free(db->parent);
@@ -354,6 +460,7 @@ void orc_db_destroy(orc_db *db) {
 /* KMerSortedArray.getLong :298-349 (sorted branch): gate, then binary search; a value without a
  * tree node converts to null (Database.convertKMerStore :136-143) and so reads as a miss. */
 int32_t orc_db_get(const orc_db *db, int64_t kmer, int64_t *pos) {
+    if (db->radix_bits) return radix_db_get(db, kmer, pos);
     if (db->gate && !orc_bloom_contains(db->gate, kmer)) return -1;
     int64_t lo = 0, hi = db->n - 1;
     while (lo <= hi) { /* java.util.Arrays.binarySearch */

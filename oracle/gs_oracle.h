@@ -75,8 +75,19 @@ typedef struct orc_db orc_db;
  * bloom_gate != 0 builds the Blocked Bloom pre-filter gate (KMerSortedArray.java:299-301). */
 orc_db *orc_db_create(int k, int64_t n_entries, const int64_t *kmers_sorted, const int32_t *value_idx,
                       int32_t n_values, const int32_t *parent_vi, int bloom_gate);
+/* The opt-in RadixKMerStore layout (C/store/RadixKMerStore.java): kmers distinct, in ANY order (putLong order);
+ * radix_bits in [16, 30] (:91-93), n_values <= orc_radix_max_values(radix_bits) (:160-164); NULL otherwise.
+ * getLong follows :369-412: bucket = low radix_bits bits, null bucket => miss before the filter, binary search
+ * over the remaining bits, pos = bucketOffset[radix] + local position. */
+orc_db *orc_db_create_radix(int k, int radix_bits, int64_t n_entries, const int64_t *kmers, const int32_t *value_idx,
+                            int32_t n_values, const int32_t *parent_vi, int bloom_gate);
+int32_t orc_radix_max_values(int radix_bits);
+/* KMerStore.visit order of either layout: (kmer, value index) of positions 0 .. entries-1
+ * (KMerSortedArray.java:426-439: ascending k-mers; RadixKMerStore.java:714-729: by bucket, then remaining bits) */
+int64_t orc_db_entries(const orc_db *db);
+void orc_db_visit(const orc_db *db, int64_t *kmers, int32_t *value_idx);
 void orc_db_destroy(orc_db *db);
-/* returns value index or -1; *pos gets the rank in the sorted array on a hit */
+/* returns value index or -1; *pos gets the store position on a hit (rank in the sorted array / radix position) */
 int32_t orc_db_get(const orc_db *db, int64_t kmer, int64_t *pos);
 int32_t orc_tree_lca(const orc_db *db, int32_t a, int32_t b);            /* SmallTaxTree.java:263-289 */
 int orc_tree_is_ancestor_of(const orc_db *db, int32_t node, int32_t anc); /* :242-252 */

@@ -61,6 +61,8 @@ def lib():
         "orc_filter_accept_read": (C.c_int, [vp, C.c_int, C.c_int, dbl, vp, C.c_int]),
         "orc_filter_batch": (None, [vp, C.c_int, C.c_int, dbl, vp, vp, i64, vp, C.c_int]),
         "orc_db_create": (vp, [C.c_int, i64, vp, vp, i32, vp, C.c_int]), "orc_db_destroy": (None, [vp]),
+        "orc_db_create_radix": (vp, [C.c_int, C.c_int, i64, vp, vp, i32, vp, C.c_int]),
+        "orc_radix_max_values": (i32, [C.c_int]), "orc_db_entries": (i64, [vp]), "orc_db_visit": (None, [vp, vp, vp]),
         "orc_db_get": (i32, [vp, i64, vp]), "orc_tree_lca": (i32, [vp, i32, i32]),
         "orc_tree_is_ancestor_of": (C.c_int, [vp, i32, i32]),
         "orc_match_begin": (vp, [vp, vp]),
@@ -204,14 +206,35 @@ class Bloom:
         return out
 
 
+def radix_max_values(radix_bits):
+    """RadixKMerStore.maxValuesForRadix (-1: radix_bits outside [16, 30])"""
+    return lib().orc_radix_max_values(radix_bits)
+
+
 class DB:
-    def __init__(self, k, kmers, value_idx, n_values, parent_vi=None, bloom_gate=False):
+    """radix_bits = 0: KMerSortedArray layout (kmers ascending); 16..30: RadixKMerStore layout (kmers distinct, any
+    order = putLong order)"""
+
+    def __init__(self, k, kmers, value_idx, n_values, parent_vi=None, bloom_gate=False, radix_bits=0):
         kmers = np.ascontiguousarray(kmers, dtype=np.int64)
         value_idx = np.ascontiguousarray(value_idx, dtype=np.int32)
-        assert np.all(np.diff(kmers) > 0), "kmers must be sorted ascending and distinct"
         pv = None if parent_vi is None else np.ascontiguousarray(parent_vi, dtype=np.int32)
         self.k, self.n_values, self.n = k, n_values, len(kmers)
-        self.h = lib().orc_db_create(k, len(kmers), _p(kmers), _p(value_idx), n_values, _p(pv), int(bloom_gate))
+        if radix_bits:
+            self.h = lib().orc_db_create_radix(k, radix_bits, len(kmers), _p(kmers), _p(value_idx), n_values, _p(pv),
+                                               int(bloom_gate))
+            if not self.h:
+                raise ValueError("radix_bits outside [16, 30] or more values than the radix store can hold")
+        else:
+            assert np.all(np.diff(kmers) > 0), "kmers must be sorted ascending and distinct"
+            self.h = lib().orc_db_create(k, len(kmers), _p(kmers), _p(value_idx), n_values, _p(pv), int(bloom_gate))
+
+    def visit(self):
+        """(kmers, value_idx) in KMerStore.visit order: what a Java host hands to gs_db_create"""
+        n = lib().orc_db_entries(self.h)
+        km, vi = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int32)
+        lib().orc_db_visit(self.h, _p(km), _p(vi))
+        return km, vi
 
     def close(self):
         if self.h:

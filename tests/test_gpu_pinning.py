@@ -1,0 +1,187 @@
+"""Round-2 pinning gaps (VERDICT r01 "What's missing" 1-2, "What's weak" 7, ADVICE): the RadixKMerStore layout (SURVEY 8a
+row a4), maxClassificationPaths up to 128 (C/GSConfigKey.java:350), the serial wrap of the long-read kernel and damaged
+store files.  Needs an MI355X: run with -m gpu."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import genestrip_amd as ga
+from genestrip_amd import synth
+from oracle import gs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _wide_tree(n_values, fan):
+    parent = np.empty(n_values, dtype=np.int32)
+    parent[0] = -1
+    parent[1:fan + 1] = 0
+    parent[fan + 1:] = 1 + (np.arange(n_values - fan - 1) % fan)
+    return parent
+
+
+def _mixed_reads(genomes, n, seed):
+    """150 bp reads plus a tail of long ones (gs_match_long_kernel)"""
+    seq, off = synth.reads_host(genomes, n, read_len=150, seed=seed)
+    lseq, loff = synth.reads_host(genomes, n // 20, read_len=1400, seed=seed + 1)
+    return np.concatenate([seq, lseq]), np.concatenate([off, off[-1] + loff[1:]]).astype(np.uint64)
+
+
+@pytest.mark.parametrize("n_values,radix_bits", [(2500, 17), (70000, 17), (300000, 16)])
+def test_store_filled_in_radix_visit_order(n_values, radix_bits):
+    """a4: a Java host with `useRadixStore` hands gs_db_create the (kmer, valueIndex) stream of RadixKMerStore.visit
+    (:714-729) -- bucket by bucket, not ascending -- and up to 2^(2+radixBits) values (:160-164).  The device table
+    must equal the oracle's radix getLong (:369-412) and, through it, the sorted layout."""
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=40000, seed=5)
+    rng = np.random.default_rng(n_values)
+    parent = _wide_tree(n_values, 300)
+    vals = rng.integers(0, n_values, len(db.kmers)).astype(np.int32)
+    perm = rng.permutation(len(db.kmers))
+    rdb = orc.DB(31, db.kmers[perm], vals[perm], n_values, parent, True, radix_bits=radix_bits)
+    vk, vv = rdb.visit()
+    assert not np.all(np.diff(vk) > 0)
+    seq, off = _mixed_reads(db.genomes, 6000, 9)
+    cfg = dict(threshold=2, max_kmer_res_counts=3)
+    res = []
+    for odb in (rdb, orc.DB(31, db.kmers, vals, n_values, parent, True)):
+        run = orc.MatchRun(odb, **cfg)
+        cv, fl = run.submit(seq, off, threads=8)
+        mc = run.max_counts()
+        res.append((run.finish()[0], cv, fl, mc))
+    store = ga.DeviceKMerStore(31, vk, vv, n_values, parent)
+    assert store.info.n_stored == len(vk)
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(**cfg))
+    gcv, gfl = m.match_reads(seq, off)
+    gmc = m.max_counts()
+    gt, _ = m.finish()
+    m.close()
+    store.close()
+    assert res[0][0][:, orc.C_KMERS].sum() > 300000
+    for want in res:
+        assert np.array_equal(gt, want[0]) and np.array_equal(gcv, want[1]) and np.array_equal(gfl, want[2])
+        assert np.array_equal(gmc, want[3])
+
+
+def test_duplicate_kmers_are_refused_in_any_order():
+    with pytest.raises(ga.GsError) as e:
+        ga.DeviceKMerStore(31, np.array([9, 5, 9], dtype=np.int64), np.array([0, 0, 0], dtype=np.int32), 1, None)
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("max_paths,threshold,fan", [(128, 1, 10), (128, 3, 10), (100, 2, 40), (65, 1, 4), (64, 1, 10), (128, 1, 1)])
+def test_up_to_128_classification_paths(max_paths, threshold, fan):
+    """every k-mer of the genomes maps to one of 400 leaves, so a 150 bp read walks ~60-120 unrelated leaves and a long
+    read many more: the candidate list really fills up beyond 64 entries, and paths beyond max_paths are dropped
+    silently (FastqKMerMatcher.java:568-586)"""
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=2, genome_len=30000, seed=21)
+    rng = np.random.default_rng(max_paths * 7 + threshold)
+    n_values = 1 + fan + 400
+    parent = _wide_tree(n_values, fan)
+    # runs of 1-3 consecutive genome positions share a leaf, so that counts differ and ties are partial
+    vals = (1 + fan + (np.cumsum(rng.integers(0, 3, len(db.kmers)) == 0) * 7919) % 400).astype(np.int32)
+    seq, off = _mixed_reads(db.genomes, 3000, 33)
+    cfg = dict(max_paths=max_paths, threshold=threshold, max_read_class_err=0.95)
+    orun = orc.MatchRun(orc.DB(31, db.kmers, vals, n_values, parent), **cfg)
+    ocv, ofl = orun.submit(seq, off, threads=8)
+    ot, _ = orun.finish()
+    store = ga.DeviceKMerStore(31, db.kmers, vals, n_values, parent)
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(**cfg))
+    gcv, gfl = m.match_reads(seq, off)
+    gt, _ = m.finish()
+    m.close()
+    if max_paths == 128:  # the limit matters: 64 paths give another classification for some reads
+        m64 = ga.FastqKMerMatcher(store, ga.MatchConfig(**dict(cfg, max_paths=64)))
+        cv64, _ = m64.match_reads(seq, off)
+        m64.close()
+        assert not np.array_equal(cv64, gcv) or fan == 1
+    store.close()
+    assert int((ocv >= 0).sum()) > 1000
+    assert np.array_equal(gt, ot), np.argwhere(gt != ot)[:6]
+    assert np.array_equal(gcv, ocv) and np.array_equal(gfl, ofl)
+
+
+def test_max_paths_outside_the_reference_range_is_refused():
+    store = ga.DeviceKMerStore(31, np.array([5], dtype=np.int64), np.array([0], dtype=np.int32), 1, None)
+    for bad in (0, 129):
+        with pytest.raises(ga.GsError):
+            ga.FastqKMerMatcher(store, ga.MatchConfig(max_paths=bad))
+    store.close()
+
+
+def test_long_read_serial_wrap(monkeypatch):
+    """gs_match_long_kernel tags its per-wave scratch rows with a running serial; when the serial wraps, stale tags could
+    pass for the new read's.  GS_TEST_LONG_SERIAL starts the serials three reads below the wrap and pre-fills the rows
+    with the values the serials take right after it."""
+    monkeypatch.setenv("GS_TEST_LONG_SERIAL", "0xFFFFFFFD")
+    db = synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=20000, seed=11)
+    seq, off = synth.reads_host(db.genomes, 6000, read_len=900, seed=3)
+    off = off.astype(np.uint64)
+    for cfg in (dict(), dict(threshold=3, max_paths=128)):
+        orun = orc.MatchRun(orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi), **cfg)
+        ocv, ofl = orun.submit(seq, off, threads=8)
+        ot, _ = orun.finish()
+        store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        m = ga.FastqKMerMatcher(store, ga.MatchConfig(**cfg))
+        gcv, gfl = m.match_reads(seq, off)
+        gt, _ = m.finish()
+        m.close()
+        store.close()
+        assert np.array_equal(gt, ot) and np.array_equal(gcv, ocv) and np.array_equal(gfl, ofl)
+
+
+def test_damaged_store_files_are_refused(tmp_path):
+    """gs_db_load checks the header against the payload before anything reaches HBM: a stale or damaged image must end
+    in GS_E_INVALID, not in out-of-range tree / value indices inside a kernel"""
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=2, genome_len=8000, seed=2)
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    good = tmp_path / "good.gss"
+    store.save(good)
+    info = store.info
+    store.close()
+    raw = bytearray(good.read_bytes())
+    ga.DeviceKMerStore.load(good).close()
+    hdr = 8 + 64 + 8 + 8 + 8 + 8  # magic | gs_db_info | bucket_bits, vbits | gate_words | mgate_words | checksum
+    assert len(raw) == hdr + info.table_bytes + info.gate_bytes + info.mgate_bytes + 16 * info.n_values
+
+    def refused(name, data):
+        p = tmp_path / name
+        p.write_bytes(bytes(data))
+        with pytest.raises(ga.GsError) as e:
+            ga.DeviceKMerStore.load(p)
+        assert e.value.code == -1, name
+        return str(e.value)
+
+    refused("short.gss", raw[:len(raw) - 4])
+    refused("long.gss", raw + b"\0" * 8)
+    refused("magic.gss", b"GSSTORE4" + raw[8:])
+    flip = bytearray(raw)
+    flip[hdr + info.table_bytes // 2] ^= 0x10
+    assert "checksum" in refused("flip.gss", flip)
+    tree_at = len(raw) - 16 * info.n_values
+
+    def with_checksum(data):
+        """a DELIBERATE bad image: the checksum is made to fit, so only the semantic checks can catch it"""
+        w = np.frombuffer(bytes(data[hdr:]), dtype=np.uint32).astype(np.uint64)
+        a = (np.uint64(1) + np.cumsum(w, dtype=np.uint64))
+        b = np.cumsum(a, dtype=np.uint64)[-1]
+        cs = int(a[-1]) ^ ((int(b) << 1) & (2**64 - 1)) ^ (int(b) >> 63)
+        out = bytearray(data)
+        out[hdr - 8:hdr] = struct.pack("<Q", cs)
+        return out
+
+    assert with_checksum(raw) == raw  # the helper reproduces the library's checksum
+    bad = bytearray(raw)
+    bad[tree_at + 4:tree_at + 8] = struct.pack("<i", 10_000)  # parent of value 1 far outside the tree
+    assert "tree" in refused("parent.gss", with_checksum(bad))
+    bad = bytearray(raw)
+    bad[8:12] = struct.pack("<i", 40)  # k
+    assert "k outside" in refused("k.gss", bad)
+    bad = bytearray(raw)
+    first = next(i for i in range(hdr, hdr + info.table_bytes, 8) if any(raw[i:i + 8]))
+    slot = struct.unpack("<Q", raw[first:first + 8])[0]
+    vmask = (1 << info.value_bits) - 1
+    slot = (slot & ~(vmask << 1)) | (vmask << 1)  # value index beyond n_values
+    bad[first:first + 8] = struct.pack("<Q", slot)
+    assert "slot value" in refused("value.gss", with_checksum(bad))

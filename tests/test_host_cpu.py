@@ -334,3 +334,91 @@ def test_writers_under_sanitizers(tmp_path, sanitizer):
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fails 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+# ------------------------------------------------------------------ f4: the report writer against rows the reference prints
+def test_csv_writer_reproduces_the_readme_rows(tmp_path):
+    """README.md:168-181 prints the header and 13 rows of `human_virus_match_sample.csv` (fixture
+    tests/golden/readme_csv/).  Rows 1-12 form one root-to-leaf chain of the tax tree.  Feeding their own integer columns
+    (and the double sums behind the four error columns) to gs_host_write_csv must give back: the header byte for byte,
+    every integer column, every double column that derives from integers as the SAME string (formula order +
+    Double.toString), and -- for rows 5-12, whose only descendant with counts is the leaf -- the accumulated columns.
+    (acc. columns of rows 1-4 include descendants the README does not print.)"""
+    import math
+    lines = open(os.path.join(GOLDEN, "readme_csv", "human_virus_match_sample_rows.csv")).read().split("\n")
+    head = lines[0].split(";")
+    col = {n: i for i, n in enumerate(head)}
+    want = [l.split(";") for l in lines[1:] if l]
+    assert len(want) == 13 and all(len(r) == len(head) for r in want)
+    total, rows = want[0], want[1:]
+    nv = len(rows)
+    parent = [-1] + list(range(nv - 1))
+    assert [r[col["parent taxid"]] for r in rows] == [""] + [r[col["taxid"]] for r in rows[:-1]]  # it is a chain
+    t = np.zeros((nv, 10), dtype=np.int64)
+    d = np.zeros((nv, 4))
+    desc = [None] * nv
+    icols = ["reads", "kmers from reads", "kmers", "unique kmers", "contigs", None, "max contig length", "reads >=1 kmer", "reads bps"]
+    for v, r in enumerate(rows):
+        for j, name in enumerate(icols):
+            if name:
+                t[v, j] = int(r[col[name]])
+        t[v, 9] = -1
+        contigs, kmers, reads = int(r[col["contigs"]]), int(r[col["kmers"]]), int(r[col["reads"]])
+        if r[col["contig len std. dev."]]:  # contigLenSquaredSum is an integer: invert getContigLenStdDev (:475-477)
+            sd = float(r[col["contig len std. dev."]])
+            t[v, 5] = round(sd * sd * (contigs - 1) + kmers * kmers / contigs)
+        if reads:
+            for j, (mean, sd) in enumerate([("mean error", "kmer error std. dev."), ("mean class error", "class error std. dev.")]):
+                s = float(r[col[mean]]) * reads
+                d[v, 2 * j] = s
+                d[v, 2 * j + 1] = float(r[col[sd]]) ** 2 * (reads - 1) + s * s / reads
+        if r[col["max contig desc."]]:
+            desc[v] = r[col["max contig desc."]]
+            t[v, 9] = v  # any read number: the caller maps it to the descriptor
+    tot = host.Totals(int(total[col["reads"]]), int(total[col["kmers"]]), int(total[col["reads bps"]]), 0, 0, 0, 0)
+    out = tmp_path / "readme.csv"
+    host.write_csv(out, parent, [r[col["taxid"]] for r in rows], [int(r[col["db kmers"]]) for r in rows],
+                   int(total[col["db kmers"]]), t, d, tot, names=[r[col["name"]] for r in rows],
+                   ranks=[r[col["rank"]] for r in rows], max_contig_desc=desc)
+    got_lines = out.read_text().split("\n")
+    # all 46 header columns, separators included.  One name differs between the README (printed by an older release) and
+    # the source the writer follows: README.md:168 "acc. class mean error", C/match/CountsPerTaxid.java:563
+    # @MDCDescription(pos = 1003, name = "acc. mean class error") -- the source wins.
+    assert lines[0].count("acc. class mean error;") == 1
+    assert got_lines[0] == lines[0].replace("acc. class mean error;", "acc. mean class error;")
+    col["acc. mean class error"] = col["acc. class mean error"]
+    head = [("acc. mean class error" if n == "acc. class mean error" else n) for n in head]
+    got = [l.split(";") for l in got_lines[1:] if l]
+    assert got[0] == total  # the TOTAL row, every column
+    assert len(got) == 13
+    exact = ["pos", "level", "name", "rank", "taxid", "reads", "kmers from reads", "kmers", "unique kmers", "contigs",
+             "average contig length", "max contig length", "reads >=1 kmer", "reads bps", "avg. read length", "db coverage",
+             "exp. unique kmers", "unique kmers / exp.", "db kmers", "parent taxid", "norm. reads", "norm. kmers",
+             "norm. reads bps", "norm. read >=1 kmer", "norm. reads kmers", "max contig desc.", "contig len std. dev."]
+    acc = [n for n in head if n.startswith("acc. ") and "error" not in n]
+    approx = ["mean error", "kmer error std. dev.", "mean class error", "class error std. dev."]
+    acc_approx = [n for n in head if n.startswith("acc. ") and "error" in n]
+    for g, w in zip(got[1:], rows):
+        for n in exact:
+            assert g[col[n]] == w[col[n]], (w[col["name"]], n, g[col[n]], w[col[n]])
+        for n in approx:
+            assert (g[col[n]] == "") == (w[col[n]] == "")
+            if w[col[n]]:
+                assert math.isclose(float(g[col[n]]), float(w[col[n]]), rel_tol=1e-9), (w[col["name"]], n)
+        if int(w[col["pos"]]) >= 5:  # below Orthornavirae the printed rows hold the whole subtree
+            for n in acc:
+                assert g[col[n]] == w[col[n]], (w[col["name"]], n, g[col[n]], w[col[n]])
+            for n in acc_approx:
+                assert math.isclose(float(g[col[n]]), float(w[col[n]]), rel_tol=1e-9), (w[col["name"]], n)
+
+
+def test_csv_writer_reports_a_failed_write():
+    """a short write must not pass for a result (/dev/full accepts the open and fails the flush)"""
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    t = np.zeros((1, 10), dtype=np.int64)
+    t[0] = [1, 1, 1, 1, 1, 1, 1, 1, 1, 0]
+    from genestrip_amd import binding
+    with pytest.raises(binding.GsError) as e:
+        host.write_csv("/dev/full", [-1], ["1"], [5], 5, t, np.zeros((1, 4)), host.Totals(1, 1, 1, 0, 0, 0, 0))
+    assert e.value.code == -7

@@ -161,7 +161,7 @@ def _k3_recount(read):
 def test_k3_match_read_recount():
     db = _db_k2([("CC", 0), ("GG", 1), ("TT", 1), ("AG", 2)])
     rnd = orc.JRandom(42)
-    for i in range(300):
+    for i in range(2000):  # all 2000 reads of T/match/FastqKMerMatcherTest.java:98
         read = bytes(b"CGAT"[rnd.next_int(4)] for _ in range(500))
         counters, contigs, maxlen = _k3_recount(read)
         # MyFastqMatcher: taxTree == null, maxReadTaxErrorCount 0, maxReadClassErrorCount 0

@@ -51,7 +51,7 @@ for _ in range(5):
     m.submit(dseq, doff, 0, n_reads=n)
 m.sync()
 l1, ms1 = m.kernel_time()
-kms = (ms1 - ms0) / (l1 - l0)
+kms = (ms1 - ms0) / max(1, l1 - l0)
 out["match"] = {"reads": n, "kernel_ms": round(kms, 3), "gbp_s": round(n * 150 / kms / 1e6, 2),
                 "frac_of_8TBs": round(n * 7830 / (kms * 1e-3) / 8e12, 4)}
 print("match:", out["match"], flush=True)
@@ -69,6 +69,9 @@ print("match parity:", out["match"]["bit_exact_100k"], flush=True)
 m.close()
 
 # ---- filter (index filter over the species k-mers = requested taxa)
+if nf <= 0:  # match only (the PMC passes of the match kernel use filter_reads = 0)
+    print(json.dumps(out))
+    sys.exit(0)
 keys = db.kmers[np.isin(db.value_idx, db.species_vi)]
 t0 = time.time()
 ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
@@ -85,7 +88,7 @@ for _ in range(5):
     flt.submit(dseq, doff, acc, n_reads=nf)
 flt.sync()
 l1, ms1 = flt.kernel_time()
-kms = (ms1 - ms0) / (l1 - l0)
+kms = (ms1 - ms0) / max(1, l1 - l0)
 want = ob.filter_batch(31, 1, 0.2, seq, off, threads=16)
 got = acc[:nchk].cpu().numpy()
 out["filter"] = {"reads": nf, "kernel_ms": round(kms, 3), "gbp_s": round(nf * 150 / kms / 1e6, 2),
