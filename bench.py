@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- Gbp/s of the `match` hot path on synthetic 150 bp reads, k=31 (BASELINE.json config 2).
+"""bench.py -- Gbp/s of the `match` hot path on synthetic 150 bp reads, k=31 (BASELINE.json configs[1]).
 
 A step = one pass of the hot path over one batch: gs_match_reset + gs_match_submit (reads already resident
 in HBM) + the per-taxid table merge (RCCL all-reduce / bitmap all-gather when N > 1) + gs_match_finish.
 Weak scaling: every rank classifies `--reads` reads of its own slice of the global read stream against a
-full replica of the store.  Rank 0 prints ONE JSON line.
+full replica of the store.  Rank 0 prints ONE JSON line: `value` is configs[1]; at N = 1 the same line carries
+extra objects for the workloads the headline does not show:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S]
+  large_store   match against a 47 M-k-mer / 526-value store (1 GiB table: HBM resident, not Infinity-Cache resident)
+  filter        the `filter` goal's kernel against the XOR index filter of the same store (~47 M keys, 27 hashes)
+  end_to_end    configs[1] again with the reads in page-locked HOST memory (gs_match_submit_async: PCIe included)
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S] [--legs main,large,filter,e2e]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 GS_BENCH_FORCE_MERGE=1 runs the RCCL merge path even at N = 1 (rehearsal of the multi-GPU code on one GPU).
@@ -26,6 +31,8 @@ READ_LEN = 150
 K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+# committed rocprofv3 --pmc summaries per workload, newest first (r01's large-store passes ran on a smaller store)
+PROFILE_ROUNDS = {"match": ("r02", "r01"), "large_store": ("r02",), "filter": ("r02",)}
 
 
 def _usable_cores():
@@ -47,6 +54,33 @@ class _DevArray:
         self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": typestr, "version": 2}
 
 
+def _pmc_traffic(name):
+    """(bytes per launch through the fabric, file) from a committed rocprofv3 --pmc summary of the same command
+    (FETCH_SIZE + WRITE_SIZE, KiB units; 64-byte requests are counted exactly), or (None, None)"""
+    for rnd in PROFILE_ROUNDS[name]:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.csv")
+        if os.path.exists(path):
+            vals = dict(l.strip().split(",")[:2] for l in open(path) if l[0] not in "#c" and "," in l)
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                return int((float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def _kernel_ms(obj, launch, reps, warm=2):
+    """average device time of one launch: HIP events recorded by the library on its own stream (cfg.profile)"""
+    for _ in range(warm):
+        launch()
+    obj.sync()
+    l0, ms0 = obj.kernel_time()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        launch()
+    obj.sync()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    l1, ms1 = obj.kernel_time()
+    return (ms1 - ms0) / max(1, l1 - l0), wall
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +92,10 @@ def main():
     ap.add_argument("--mode", choices=["sharded", "partitioned"], default="sharded",
                     help="sharded: store replicated, reads sharded (configs[1]/[3], the default bench line); "
                          "partitioned: store split over the ranks by key hash, k-mers routed by all-to-all (configs[4])")
+    ap.add_argument("--legs", default="main,large,filter,e2e",
+                    help="comma list; large / filter / e2e are the extra N = 1 objects (main always runs)")
     args = ap.parse_args()
+    legs = set(args.legs.split(","))
 
     import torch
     import torch.distributed as dist
@@ -166,15 +203,11 @@ def main():
     gbps = total_bases / elapsed / 1e9
     achieved = n * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9  # GB/s, algorithmic bytes of one launch / its duration
 
-    # measured memory-side traffic of one launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    # (profiles/r01_match_pmc_summary.csv, KiB units; 64-byte random requests are counted exactly).  Only valid for
-    # the default workload the profile was taken on.
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_match_pmc_summary.csv")
-    if n == 10_000_000 and not partitioned and os.path.exists(pmc):
-        vals = dict(l.strip().split(",") for l in open(pmc) if l[0] not in "#c" and "," in l)
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            traffic = int((float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024)
+    # measured memory-side traffic of one launch: rocprofv3 --pmc passes of this same command (only valid for the
+    # default workload the profile was taken on)
+    traffic, traffic_src = (None, None)
+    if n == 10_000_000 and not partitioned:
+        traffic, traffic_src = _pmc_traffic("match")
 
     out = {
         "metric": "Gbp/s classified (match goal), k=31, 150bp reads; bit-exact CSV counts",
@@ -187,17 +220,32 @@ def main():
                    "store_table_bytes": int(info.table_bytes), "gate_bytes": int(info.gate_bytes),
                    "parallelism": ("DB-partitioned x%d, k-mers routed by all-to-all" % world) if partitioned
                    else ("read-sharded x%d, store replicated" % world)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `frac` follows SURVEY 8(d)'s convention (one 64-byte line per k-mer position over the HBM peak).  For this
+        # store it is NOT an HBM measurement: the 64 MiB table sits in the 256 MiB Infinity Cache and the minimizer gate
+        # removes the lines of most misses, so the kernel is bound by the fabric's rate of random 64-byte requests
+        # (~59 G/s, tools/probe_bw.hip).  `measured_frac` is what the counters saw; `large_store` below is the
+        # HBM-resident case.
+        "roofline": {"bound": "fabric random 64-byte line rate (table Infinity-Cache resident; HBM peak is the SURVEY 8d convention's denominator)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_note": "bytes per launch through the fabric (rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, "
-                                     "profiles/r01_match_pmc_summary.csv); the 64 MiB table is Infinity-Cache resident",
+                     "measured_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic_note": None if traffic is None else
+                     "bytes per launch through the fabric (rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, %s), not measured in this run" % traffic_src,
                      "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": n * BYTES_PER_READ},
     }
 
     # ---- parity gate.  N = 1: the first --check-reads reads against the CPU oracle (bit-exact integer table).
-    # N > 1: every rank must hold the same merged table, and rank 0 re-checks its own slice against the oracle.
+    # N > 1 sharded: every rank must hold the same merged table, and rank 0 re-checks its own slice against the oracle.
+    # N > 1 partitioned: the first check_reads / N reads of EVERY rank's slice go through the collective pipeline once
+    # more and rank 0 compares the merged table with the oracle over exactly those reads.
     nchk = min(args.check_reads, n)
+    ptable = None
+    if partitioned and world > 1:
+        per = max(1, nchk // world)
+        m.reset()
+        partitioned_match_batch(m, K, dseq, doff, per, first)
+        ptable, _ = partitioned_finish(m, t_sums, t_max, t_dsum)
     if use_dist and world > 1:
         digest = torch.tensor([int(np.asarray(table, dtype=np.int64).sum() % (1 << 62))], dtype=torch.int64, device=cdev)
         lo, hi = digest.clone(), digest.clone()
@@ -208,14 +256,21 @@ def main():
         from oracle import gs_oracle as orc
         cores = _usable_cores()
         odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
-        seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
         orun = orc.MatchRun(odb)
         t1 = time.perf_counter()
-        orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+        if ptable is not None:
+            per = max(1, nchk // world)
+            for r in range(world):
+                seq, off = synth.reads_host(db.genomes, per, read_len=READ_LEN, first=r * n)
+                orun.submit(seq, off, first_read_no=r * n, threads=cores, per_read=False)
+            nchk = per * world
+        else:
+            seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
+            orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
         dt_chk = time.perf_counter() - t1
         otable, _ = orun.finish()
-        if partitioned and world > 1:
-            gtable = otable  # a local re-check would need the other ranks' partitions; the digest check above covers it
+        if ptable is not None:
+            gtable = ptable
         elif world > 1:
             # rank 0 alone re-checks its own slice: no collectives here (the other ranks are already at the barrier)
             m.reset()
@@ -240,10 +295,143 @@ def main():
                 "value": round(ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
                 "sample": "first %d reads of the same stream, C restatement of the Java path (sorted array + "
                           "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
+            del seq, off
+        odb.close()
+        if world == 1 and not partitioned:
+            if "e2e" in legs:
+                out["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
+            m.close()
+            store.close()
+            del dseq, doff
+            torch.cuda.empty_cache()
+            if "large" in legs or "filter" in legs:
+                out.update(legs_large(ga, synth, orc, torch, dev, legs, cores))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):
+    """configs[1] with the reads in page-locked HOST memory (what a JVM host holds after parsing): two batches under
+    way through gs_match_submit_async, the H2D copy of one under the kernel of the other ("submit..finish
+    with reads resident in pinned host memory").  Never `value`."""
+    half = n // 2
+    seq, off = synth.reads_host(db.genomes, n, read_len=READ_LEN)
+    parts = []
+    for a, b in ((0, half), (half, n)):
+        ps = torch.from_numpy(seq[int(off[a]):int(off[b])].copy()).pin_memory().numpy()
+        po = torch.from_numpy((off[a:b + 1] - off[a]).astype(np.int64)).pin_memory().numpy().view(off.dtype)
+        parts.append((ps, po, a))
+    del seq
+
+    def run(rounds):
+        last = []
+        for _ in range(rounds):
+            for ps, po, a in parts:
+                last.append(m.submit_async(ps, po, a))
+                if len(last) > 2:
+                    m.wait(last[-3])
+        m.sync()
+
+    m.reset()
+    run(1)  # allocates the staging buffers
+    m.reset()
+    rounds = 5
+    t0 = time.perf_counter()
+    run(rounds)
+    dt = (time.perf_counter() - t0) / rounds
+    m.reset()
+    run(1)
+    host_table, _ = m.finish()
+    m.reset()
+    m.submit(dseq, doff, 0, n_reads=n)
+    dev_table, _ = m.finish()
+    return {"pinned_host_gbps": round(n * READ_LEN / dt / 1e9, 2), "reads": n, "batches_in_flight": 2,
+            "ms_per_batch_pair": round(dt * 1e3, 3), "h2d_gbs_of_sequence": round(n * READ_LEN / dt / 1e9, 2),
+            "api": "gs_match_submit_async / gs_match_wait (GS_MEM_HOST, page-locked arrays)",
+            "table_equals_device_resident_run": bool(np.array_equal(host_table, dev_table))}
+
+
+def legs_large(ga, synth, orc, torch, dev, legs, cores):
+    """BASELINE.json configs[2] / configs[3] per GPU: a 47 M-k-mer / 526-value store (1 GiB table, four times the
+    Infinity Cache) and the XOR index filter over its species k-mers (~47 M keys, 1.8 G bits, 27 hashes)."""
+    res = {}
+    n, nchk = 10_000_000, 100_000
+    t0 = time.perf_counter()
+    db = synth.SynthDB(k=K, genera=25, species_per_genus=20)
+    t_db = time.perf_counter() - t0
+    gen = torch.from_numpy(db.genomes).to(dev)
+    dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN)
+    torch.cuda.synchronize()
+    seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN)
+    if "large" in legs:
+        t0 = time.perf_counter()
+        store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        t_store = time.perf_counter() - t0
+        info = store.info
+        m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
+
+        def launch():
+            m.reset()
+            m.submit(dseq, doff, 0, n_reads=n)
+
+        kms, wall = _kernel_ms(m, launch, 5)
+        odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
+        orun = orc.MatchRun(odb)
+        orun.submit(seq, off, threads=cores, per_read=False)
+        ot, _ = orun.finish()
+        odb.close()
+        m.reset()
+        m.submit(dseq, doff, 0, n_reads=nchk)
+        gt, _ = m.finish()
+        traffic, src = _pmc_traffic("large_store")
+        ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9
+        res["large_store"] = {
+            "workload": "match: %d reads x 150 bp, k=31, %d-k-mer / %d-value store" % (n, db.n_entries, db.n_values),
+            "store_kmers": int(db.n_entries), "n_values": int(db.n_values), "table_bytes": int(info.table_bytes),
+            "mgate_bytes": int(info.mgate_bytes), "kernel": "gs_match_kernel<global counters, k=31>",
+            "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3), "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2),
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "measured_frac": None if traffic is None else round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_note": None if traffic is None else "rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE per launch, %s" % src,
+            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))},
+            "build_s": {"synthetic_arrays": round(t_db, 1), "gs_db_create": round(t_store, 1)}}
+        m.close()
+        store.close()
+    if "filter" in legs:
+        keys = db.kmers[np.isin(db.value_idx, db.species_vi)]  # BloomIndexGoal: k-mers of the requested taxa
+        bits, hashes, factors = synth.xor_bloom_geometry(len(keys), 1e-8)
+        dwords = torch.zeros((bits + 63) // 64, dtype=torch.int64, device=dev)
+        synth.xor_bloom_device(torch.from_numpy(keys).to(dev), len(keys), bits, torch.from_numpy(factors).to(dev), hashes, dwords)
+        words = dwords.cpu().numpy().view(np.uint64)
+        del dwords
+        bloom = ga.DeviceBloomFilter(ga.BLOOM_XOR, bits, factors, words)
+        flt = ga.FastqBloomFilter(K, bloom, 1, 0.2, profile=True)
+        acc = torch.empty(n, dtype=torch.uint8, device=dev)
+        kms, wall = _kernel_ms(flt, lambda: flt.submit(dseq, doff, acc, n_reads=n), 5)
+        ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)  # the oracle builds its own filter from the same keys
+        ob.put_many(keys, threads=cores)
+        same_filter = bool(ob.bits == bits and np.array_equal(ob.words, words))
+        want = ob.filter_batch(K, 1, 0.2, seq, off, threads=cores)
+        got = acc[:nchk].cpu().numpy()
+        traffic, src = _pmc_traffic("filter")
+        ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9
+        res["filter"] = {
+            "workload": "filter: %d reads x 150 bp, k=31, XOR index filter of %d keys (%d bits, %d hashes), minPosCount 1" % (n, len(keys), bits, hashes),
+            "filter_keys": int(len(keys)), "filter_bytes": int(len(words) * 8), "n_hashes": int(hashes),
+            "kernel": "gs_filter_kernel", "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3),
+            "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2), "accepted_frac": round(float(acc.float().mean()), 4),
+            "bound": "fabric random 64-byte line rate (every filter bit is a random line of the bit array; members need 27)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "lines_per_read": None if traffic is None else round(traffic / 64 / n, 1),
+            "measured_frac": None if traffic is None else round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_note": None if traffic is None else "rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE per launch, %s" % src,
+            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(want, got)), "filter_bits_equal_oracle": same_filter}}
+        bloom.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -51,7 +51,7 @@ def canonical_kmers(seq, k):
 class SynthDB:
     """arrays of a synthetic store: kmers (sorted int64), value_idx, parent_vi, genomes (S_total x genome_len)"""
 
-    def __init__(self, k=31, genera=4, species_per_genus=5, genome_len=100_000, seed=42):
+    def __init__(self, k=31, genera=4, species_per_genus=5, genome_len=100_000, seed=42, native=True):
         self.k, self.genome_len = k, genome_len
         n_species = genera * species_per_genus
         # value indices in pre-order: root 0, genus, its species, next genus ...
@@ -89,29 +89,48 @@ class SynthDB:
                         gen[b * seg:(b + 1) * seg] = src[b * seg:(b + 1) * seg]
                 genomes[i] = gen
         self.genomes = genomes
-        # k-mer -> LCA of the species containing it
-        ks, vs = [], []
-        for i in range(n_species):
-            u = np.unique(canonical_kmers(genomes[i], k))
-            ks.append(u)
-            vs.append(np.full(len(u), species_vi[i], dtype=np.int32))
-        allk = np.concatenate(ks)
-        allv = np.concatenate(vs)
-        order = np.argsort(allk, kind="stable")
-        allk, allv = allk[order], allv[order]
-        first = np.concatenate([[True], allk[1:] != allk[:-1]])
-        starts = np.flatnonzero(first)
-        par = self.parent_vi
-        vmin = np.minimum.reduceat(allv, starts)
-        vmax = np.maximum.reduceat(allv, starts)
-        gmin, gmax = par[vmin], par[vmax]  # genus of the smallest / largest species (pre-order => contiguous)
-        val = np.where(vmin == vmax, vmin, np.where(gmin == gmax, gmin, 0)).astype(np.int32)
-        self.kmers = allk[first]
-        self.value_idx = val
+        self.kmers, self.value_idx = (_build_native if native else _build_numpy)(genomes, k, self.species_vi, self.parent_vi)
 
     @property
     def n_entries(self):
         return len(self.kmers)
+
+
+def _build_numpy(genomes, k, species_vi, parent_vi):
+    """k-mer -> LCA of the species containing it (reference implementation of the recipe; the default is the same in
+    C++ on all cores, _build_native)"""
+    ks, vs = [], []
+    for i in range(len(genomes)):
+        u = np.unique(canonical_kmers(genomes[i], k))
+        ks.append(u)
+        vs.append(np.full(len(u), species_vi[i], dtype=np.int32))
+    allk = np.concatenate(ks)
+    allv = np.concatenate(vs)
+    order = np.argsort(allk, kind="stable")
+    allk, allv = allk[order], allv[order]
+    first = np.concatenate([[True], allk[1:] != allk[:-1]])
+    starts = np.flatnonzero(first)
+    par = parent_vi
+    vmin = np.minimum.reduceat(allv, starts)
+    vmax = np.maximum.reduceat(allv, starts)
+    gmin, gmax = par[vmin], par[vmax]  # genus of the smallest / largest species (pre-order => contiguous)
+    val = np.where(vmin == vmax, vmin, np.where(gmin == gmax, gmin, 0)).astype(np.int32)
+    return allk[first], val
+
+
+def _build_native(genomes, k, species_vi, parent_vi):
+    genomes = np.ascontiguousarray(genomes, dtype=np.uint8)
+    sv = np.ascontiguousarray(species_vi, dtype=np.int32)
+    pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
+    n = C.c_int64(0)
+    h = _syn().gs_synth_db_build(genomes.ctypes.data_as(C.c_void_p), genomes.shape[0], genomes.shape[1], k,
+                                 sv.ctypes.data_as(C.c_void_p), pv.ctypes.data_as(C.c_void_p), C.byref(n))
+    if not h:
+        raise MemoryError("gs_synth_db_build failed")
+    kmers = np.empty(n.value, dtype=np.int64)
+    vals = np.empty(n.value, dtype=np.int32)
+    _syn().gs_synth_db_fetch(h, kmers.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p))
+    return kmers, vals
 
 
 def _syn():
@@ -126,6 +145,12 @@ def _syn():
         args = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.gs_synth_reads_host.restype, L.gs_synth_reads_host.argtypes = None, args
         L.gs_synth_reads_device.restype, L.gs_synth_reads_device.argtypes = C.c_int, args
+        L.gs_synth_db_build.restype = C.c_void_p
+        L.gs_synth_db_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gs_synth_db_fetch.restype, L.gs_synth_db_fetch.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p]
+        bargs = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.gs_synth_bloom_xor_host.restype, L.gs_synth_bloom_xor_host.argtypes = None, bargs
+        L.gs_synth_bloom_xor_device.restype, L.gs_synth_bloom_xor_device.argtypes = C.c_int, bargs
         _SYN = L
     return _SYN
 
@@ -146,3 +171,54 @@ def reads_device(genomes_dev, n_genomes, genome_len, n_reads, seq_dev, off_dev, 
                                       genome_len, C.c_void_p(seq_dev.data_ptr()), C.c_void_p(off_dev.data_ptr()))
     if rc != 0:
         raise RuntimeError(f"gs_synth_reads_device failed: hip error {-rc}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Index filter inputs (the arrays a Java host hands to gs_bloom_create: AbstractKMerBloomFilter fields bits, hashes,
+# hashFactors, bitVector).  Manufactured here, independently of the CPU oracle, so that the filter workloads at
+# BASELINE.json configs[2] scale do not depend on test infrastructure; tests/test_synth_cpu.py compares both.
+# ---------------------------------------------------------------------------------------------------------------
+def java_random_longs(seed, n):
+    """first n values of new java.util.Random(seed).nextLong()"""
+    mask = (1 << 48) - 1
+    s = (seed ^ 0x5DEECE66D) & mask
+    out = []
+
+    def nxt(bits):
+        nonlocal s
+        s = (s * 0x5DEECE66D + 0xB) & mask
+        v = s >> (48 - bits)
+        return v - (1 << bits) if v >= 1 << (bits - 1) else v  # (int) cast
+
+    for _ in range(n):
+        v = ((nxt(32) << 32) + nxt(32)) & ((1 << 64) - 1)
+        out.append(v - (1 << 64) if v >= 1 << 63 else v)
+    return np.array(out, dtype=np.int64)
+
+
+def xor_bloom_geometry(expected_insertions, fpp):
+    """(bits, hashes, hash_factors) of an XORKMerBloomFilter sized for `expected_insertions` keys at `fpp`
+    (AbstractKMerBloomFilter.java:172-185; factors :105-109 from Random(42))"""
+    import math
+    n = int(expected_insertions)
+    bits = max(1, int(-n * math.log(fpp) / (math.log(2.0) * math.log(2.0))))
+    hashes = max(1, int(math.floor(bits / n * math.log(2.0) + 0.5)))
+    return bits, hashes, java_random_longs(42, hashes)
+
+
+def xor_bloom_host(keys, bits, factors):
+    """bit array (uint64 words) of the filter after putLong of every key"""
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    factors = np.ascontiguousarray(factors, dtype=np.int64)
+    words = np.zeros((bits + 63) // 64, dtype=np.uint64)
+    _syn().gs_synth_bloom_xor_host(keys.ctypes.data_as(C.c_void_p), len(keys), bits, factors.ctypes.data_as(C.c_void_p),
+                                   len(factors), words.ctypes.data_as(C.c_void_p))
+    return words
+
+
+def xor_bloom_device(keys_dev, n_keys, bits, factors_dev, n_hashes, words_dev):
+    """the same on the GPU: keys_dev int64[n_keys], factors_dev int64[n_hashes], words_dev zeroed int64[(bits+63)//64]"""
+    rc = _syn().gs_synth_bloom_xor_device(C.c_void_p(keys_dev.data_ptr()), n_keys, bits, C.c_void_p(factors_dev.data_ptr()),
+                                          n_hashes, C.c_void_p(words_dev.data_ptr()))
+    if rc != 0:
+        raise RuntimeError(f"gs_synth_bloom_xor_device failed: hip error {-rc}")

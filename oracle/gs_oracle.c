@@ -237,6 +237,20 @@ void orc_bloom_put_many(orc_bloom *b, const int64_t *keys, int64_t n) {
     for (int64_t i = 0; i < n; i++) orc_bloom_put(b, keys[i]);
 }
 
+/* the same bits, set from several threads (bit sets commute): for filters of tens of millions of keys */
+void orc_bloom_put_many_mt(orc_bloom *b, const int64_t *keys, int64_t n, int threads) {
+    if (threads <= 1 || b->kind == ORC_BLOOM_BLOCKED) {
+        orc_bloom_put_many(b, keys, n);
+        return;
+    }
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t i = 0; i < n; i++)
+        for (int h = 0; h < b->hashes; h++) {
+            int64_t idx = bloom_index(b, keys[i], h);
+            __atomic_fetch_or(&b->words[idx >> 6], 1ULL << (idx & 63), __ATOMIC_RELAXED);
+        }
+}
+
 int orc_bloom_contains(const orc_bloom *b, int64_t key) {
     if (b->kind == ORC_BLOOM_BLOCKED) {
         blocked_probe p = blocked_prepare(b, key);

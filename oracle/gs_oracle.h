@@ -49,6 +49,7 @@ orc_bloom *orc_bloom_create(int kind, int64_t expected_insertions, double fpp);
 void orc_bloom_destroy(orc_bloom *b);
 void orc_bloom_put(orc_bloom *b, int64_t key);
 void orc_bloom_put_many(orc_bloom *b, const int64_t *keys, int64_t n);
+void orc_bloom_put_many_mt(orc_bloom *b, const int64_t *keys, int64_t n, int threads);
 int orc_bloom_contains(const orc_bloom *b, int64_t key);
 int orc_bloom_kind(const orc_bloom *b);
 int64_t orc_bloom_bits(const orc_bloom *b);      /* XOR/Murmur: #bits ; Blocked: #buckets */

@@ -54,7 +54,7 @@ def lib():
         "orc_standard_kmer": (i64, [i64, i64]), "orc_kmer_canonical": (i64, [vp, C.c_int, C.c_int, vp]),
         "orc_bloom_create": (vp, [C.c_int, i64, dbl]), "orc_bloom_destroy": (None, [vp]),
         "orc_bloom_put": (None, [vp, i64]), "orc_bloom_contains": (C.c_int, [vp, i64]),
-        "orc_bloom_put_many": (None, [vp, vp, i64]),
+        "orc_bloom_put_many": (None, [vp, vp, i64]), "orc_bloom_put_many_mt": (None, [vp, vp, i64, C.c_int]),
         "orc_bloom_kind": (C.c_int, [vp]), "orc_bloom_bits": (i64, [vp]), "orc_bloom_hashes": (i32, [vp]),
         "orc_bloom_hash_factors": (vp, [vp]), "orc_bloom_words": (vp, [vp]), "orc_bloom_n_words": (i64, [vp]),
         "orc_murmur_hash64": (i64, [i64, i64]),
@@ -168,9 +168,9 @@ class Bloom:
     def put(self, key):
         lib().orc_bloom_put(self.h, int(key))
 
-    def put_many(self, keys):
+    def put_many(self, keys, threads=1):
         keys = np.ascontiguousarray(keys, dtype=np.int64)
-        lib().orc_bloom_put_many(self.h, _p(keys), len(keys))
+        lib().orc_bloom_put_many_mt(self.h, _p(keys), len(keys), threads)
 
     def contains(self, key):
         return bool(lib().orc_bloom_contains(self.h, int(key)))

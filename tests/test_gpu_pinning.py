@@ -29,7 +29,7 @@ def _mixed_reads(genomes, n, seed):
     return np.concatenate([seq, lseq]), np.concatenate([off, off[-1] + loff[1:]]).astype(np.uint64)
 
 
-@pytest.mark.parametrize("n_values,radix_bits", [(2500, 17), (70000, 17), (300000, 16)])
+@pytest.mark.parametrize("n_values,radix_bits", [(2500, 17), (70000, 17), (262144, 16), (500000, 17)])
 def test_store_filled_in_radix_visit_order(n_values, radix_bits):
     """a4: a Java host with `useRadixStore` hands gs_db_create the (kmer, valueIndex) stream of RadixKMerStore.visit
     (:714-729) -- bucket by bucket, not ascending -- and up to 2^(2+radixBits) values (:160-164).  The device table
@@ -97,7 +97,7 @@ def test_up_to_128_classification_paths(max_paths, threshold, fan):
         m64.close()
         assert not np.array_equal(cv64, gcv) or fan == 1
     store.close()
-    assert int((ocv >= 0).sum()) > 1000
+    assert int((ocv >= 0).sum()) > 500
     assert np.array_equal(gt, ot), np.argwhere(gt != ot)[:6]
     assert np.array_equal(gcv, ocv) and np.array_equal(gfl, ofl)
 
@@ -134,7 +134,7 @@ def test_long_read_serial_wrap(monkeypatch):
 def test_damaged_store_files_are_refused(tmp_path):
     """gs_db_load checks the header against the payload before anything reaches HBM: a stale or damaged image must end
     in GS_E_INVALID, not in out-of-range tree / value indices inside a kernel"""
-    db = synth.SynthDB(k=31, genera=2, species_per_genus=2, genome_len=8000, seed=2)
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=8000, seed=2)  # 9 values: 4 value bits
     store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     good = tmp_path / "good.gss"
     store.save(good)
