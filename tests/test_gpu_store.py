@@ -117,7 +117,7 @@ def test_small_k_against_oracle(k):
 
 def test_argument_errors():
     with pytest.raises(ga.GsError) as e:
-        ga.DeviceKMerStore(31, [5, 5], [0, 0], 1)  # not strictly ascending
+        ga.DeviceKMerStore(31, [5, 5], [0, 0], 1)  # the same k-mer twice
     assert e.value.code == -1
     with pytest.raises(ga.GsError):
         ga.DeviceKMerStore(32, [5], [0], 1)
@@ -127,5 +127,5 @@ def test_argument_errors():
         ga.DeviceKMerStore(31, [5], [0], 2, np.array([1, 0], np.int32))  # cycle
     store = ga.DeviceKMerStore(31, [5], [0], 1)
     with pytest.raises(ga.GsError):
-        ga.FastqKMerMatcher(store, ga.MatchConfig(max_paths=65))
+        ga.FastqKMerMatcher(store, ga.MatchConfig(max_paths=129))  # the reference allows 1..128
     store.close()
