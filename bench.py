@@ -135,7 +135,7 @@ def main():
     # ---- inputs: store replica per GPU, this rank's slice of the read stream generated directly in HBM
     db = synth.SynthDB(k=K)
     store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, device=local_rank,
-                               n_parts=world if partitioned else 1, part=rank if partitioned else 0)
+                               n_parts=world if partitioned else 1, part=rank if partitioned else 0, partition=partitioned)
     info = store.info
     n = args.reads
     first = rank * n

@@ -53,7 +53,8 @@ class GsError(RuntimeError):
 class DbInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("n_values", C.c_int32), ("n_entries", C.c_int64), ("n_stored", C.c_int64),
                 ("n_buckets", C.c_int64), ("table_bytes", C.c_int64), ("max_displacement", C.c_int32),
-                ("value_bits", C.c_int32), ("gate_bytes", C.c_int64), ("mgate_bytes", C.c_int64)]
+                ("value_bits", C.c_int32), ("gate_bytes", C.c_int64), ("mgate_bytes", C.c_int64),
+                ("rec_bytes", C.c_int64), ("n_in_records", C.c_int64)]
 
 
 class _MatchCfg(C.Structure):
@@ -176,7 +177,10 @@ def _ready(*bufs):
 class DeviceKMerStore:
     """k-mer -> value-index store plus taxonomy, resident in HBM (gs_db)."""
 
-    def __init__(self, k, kmers_sorted, value_idx, n_values, parent_vi=None, device=0, n_parts=1, part=0):
+    def __init__(self, k, kmers_sorted, value_idx, n_values, parent_vi=None, device=0, n_parts=1, part=0,
+                 partition=None):
+        """partition: build a partition store for the split pipeline encode -> probe_keys -> reduce (gs_db_create_part:
+        every key in the table); default: n_parts > 1.  Otherwise the store serves the fused kernels (gs_db_create)."""
         kmers = np.ascontiguousarray(kmers_sorted, dtype=np.int64)
         vidx = np.ascontiguousarray(value_idx, dtype=np.int32)
         if len(kmers) != len(vidx):
@@ -186,9 +190,16 @@ class DeviceKMerStore:
             raise ValueError("parent_vi must have n_values entries")
         self.h = C.c_void_p()
         self.k, self.n_values, self.device = k, n_values, device
-        _check(lib().gs_db_create_part(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
-                                       vidx.ctypes.data_as(C.c_void_p), n_values,
-                                       None if pv is None else pv.ctypes.data_as(C.c_void_p), n_parts, part))
+        if partition is None:
+            partition = n_parts > 1
+        if partition:
+            _check(lib().gs_db_create_part(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                           vidx.ctypes.data_as(C.c_void_p), n_values,
+                                           None if pv is None else pv.ctypes.data_as(C.c_void_p), n_parts, part))
+        else:
+            _check(lib().gs_db_create(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                      vidx.ctypes.data_as(C.c_void_p), n_values,
+                                      None if pv is None else pv.ctypes.data_as(C.c_void_p)))
 
     @classmethod
     def load(cls, path, device=0):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,9 +22,10 @@ extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStrea
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
-                                              int32_t n_values, u64 *unique, hipStream_t stream);
-extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, hipStream_t stream);
-extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, hipStream_t stream);
+                                              int32_t n_values, u64 *unique, const u64 *rec, int64_t n_rec, hipStream_t stream);
+extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, u64 *rec, int64_t n_rec, hipStream_t stream);
+extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, const u64 *rec, int64_t n_rec,
+                                                hipStream_t stream);
 extern "C" hipError_t gs_launch_bitmap_or(uint32_t *dst, const uint32_t *parts, int64_t n_words, int64_t n_parts,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_segments(const struct GsSegParams *P, int write, int grid, hipStream_t stream);
@@ -101,10 +103,27 @@ struct gs_db {
     u64 *d_table = nullptr;
     u64 *d_gate = nullptr;
     uint32_t *d_mgate = nullptr;
+    u64 *d_rec = nullptr;       // super-k-mer records (gs_layout.h), GS_REC_WORDS words per bucket
+    int64_t n_rec = 0;          // record buckets (a power of two) or 0
     int32_t *d_tree = nullptr;  // parent | depth | tin | tout
+    int64_t n_slots() const { return info.n_buckets * GS_SLOTS_PER_BUCKET; }
     int n_cu = 256;
     struct gs_run *unique_owner = nullptr;  // the slots' seen bits belong to one unique-counting run at a time
+    // Runs keep a pointer to their store.  A host with garbage-collected wrappers (Java finalizers, Python __del__) may
+    // destroy the store before its runs: gs_db_destroy then only marks it, and the last gs_match_destroy frees it.
+    int live_runs = 0;
+    bool destroy_pending = false;
 };
+
+static void db_free(gs_db *db) {
+    hipSetDevice(db->device);
+    hipFree(db->d_table);
+    hipFree(db->d_gate);
+    hipFree(db->d_mgate);
+    hipFree(db->d_rec);
+    hipFree(db->d_tree);
+    delete db;
+}
 
 // reference (interleaved, first base in the top bits) -> forward planes; also reports reachability:
 // the reference only ever queries max(fwd, revcomp) (CGAT.java:145-147), so a stored key that is smaller
@@ -131,11 +150,11 @@ static int bits_for(u64 v) {
 }
 
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part);
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused);
 
 extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                             int32_t n_values, const int32_t *parent_vi) try {
-    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, 1, 0);
+    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, 1, 0, true);
 } catch (const std::bad_alloc &) {
     return fail(GS_E_NOMEM, "out of host memory");
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
@@ -145,15 +164,17 @@ extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int
 extern "C" int gs_db_create_part(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                                  int32_t n_values, const int32_t *parent_vi, int n_parts, int part) try {
     if (n_parts < 1 || part < 0 || part >= n_parts) return fail(GS_E_INVALID, "bad partition");
-    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, n_parts, part);
+    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, n_parts, part, false);
 } catch (const std::bad_alloc &) {
     return fail(GS_E_NOMEM, "out of host memory");
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
     return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
+// fused: the store serves the fused kernels (gs_match_submit*, gs_match_segments) and may keep k-mers in super-k-mer
+// records; a partition store (gs_db_create_part, any n_parts) keeps every key in the table, where gs_match_probe_keys looks
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part) {
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused) {
     if (!out) return fail(GS_E_INVALID, "out is NULL");
     *out = nullptr;
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
@@ -217,13 +238,23 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
     }
     // ---- keys
+    // Every reachable stored k-mer is looked at from both strands (gs_layout.h: gs_choose_minimizer).  If both views pick
+    // the same minimizer occurrence the k-mer can live in a super-k-mer record; otherwise (and for every k-mer when the
+    // store has no records) it goes to the ordinary table under its mixed key.
+    struct RecEntry {
+        uint32_t bucket, gh, ohi, olo, vj;  // vj = value index << 5 | offset j of the k-mer in its window
+    };
     std::vector<u64> hkey;
     std::vector<int32_t> hval;
-    std::vector<uint32_t> hmin;  // minimizer order hash per reachable key of ANY partition (k >= GS_MIN_K)
+    std::vector<uint32_t> hmin;   // order hash of the minimizer(s) of every reachable key of ANY partition (k >= GS_MIN_K)
+    std::vector<uint32_t> hmore;  // minimizers whose record bucket must send mismatching probes on to the table
+    std::vector<RecEntry> rents;
     hkey.reserve((size_t)n);
     hval.reserve((size_t)n);
     bool want_mgate = k >= GS_MIN_K;
     if (const char *e = getenv("GS_MGATE")) want_mgate = want_mgate && atoi(e) != 0;
+    bool want_rec = want_mgate && fused && n_parts == 1 && n_values <= GS_REC_MAX_VALUES;
+    if (const char *e = getenv("GS_RECORDS")) want_rec = want_rec && atoi(e) != 0;
     if (want_mgate) hmin.reserve((size_t)n);
     const uint32_t kmask = (1u << k) - 1u;
     {
@@ -235,28 +266,49 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         struct Slice {
             std::vector<u64> h;
             std::vector<int32_t> v;
-            std::vector<uint32_t> m;
+            std::vector<uint32_t> m, more;
+            std::vector<RecEntry> r;
         };
         std::vector<Slice> sl((size_t)n_thr);
         auto work = [&](int t) {
             const int64_t lo = n * t / n_thr, hi = n * (t + 1) / n_thr;
             Slice &o = sl[(size_t)t];
-            o.h.reserve((size_t)(hi - lo));
-            o.v.reserve((size_t)(hi - lo));
+            if (want_rec)
+                o.r.reserve((size_t)(hi - lo));
+            else {
+                o.h.reserve((size_t)(hi - lo));
+                o.v.reserve((size_t)(hi - lo));
+            }
             if (want_mgate) o.m.reserve((size_t)(hi - lo));
             for (int64_t i = lo; i < hi; i++) {
                 uint32_t fhi, flo, phi, plo;
                 bool reachable = java_to_planes((u64)kmers[i], k, fhi, flo);
                 if (!reachable || parent[vidx[i]] == -2) continue;
-                gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
-                const u64 hk = gs_mix_planes(phi, plo);
+                bool in_record = false;
                 // the minimizer gate of a partition covers the keys of ALL partitions: the rank that encodes a read
                 // (gs_match_encode) uses it to decide which k-mers are worth routing to their owner at all
-                if (want_mgate) {  // strand symmetric: either orientation gives the same minimizer
-                    uint32_t m = 0xffffffffu;
-                    for (int j = 0; j + GS_MIN_L <= k; j++) m = std::min(m, gs_lmer_hash((phi >> j) & 0x7fffu, (plo >> j) & 0x7fffu));
-                    o.m.push_back(m);
+                if (want_mgate) {
+                    const uint32_t rhi = gs_brev32(fhi) >> (32 - k), rlo = (gs_brev32(flo) >> (32 - k)) ^ kmask;
+                    uint32_t gh1, gh2, ohi1, olo1, ohi2, olo2;
+                    int j1, j2;
+                    gs_min_oriented(fhi, flo, rhi, rlo, k, gs_choose_minimizer(fhi, flo, k), gh1, ohi1, olo1, j1);
+                    gs_min_oriented(rhi, rlo, fhi, flo, k, gs_choose_minimizer(rhi, rlo, k), gh2, ohi2, olo2, j2);
+                    const bool same = gh1 == gh2 && j1 == j2 && ohi1 == ohi2 && olo1 == olo2;
+                    o.m.push_back(gh1);
+                    if (gh2 != gh1) o.m.push_back(gh2);
+                    if (want_rec) {
+                        if (same) {
+                            o.r.push_back(RecEntry{0u, gh1, ohi1, olo1, ((uint32_t)vidx[i] << 5) | (uint32_t)j1});
+                            in_record = true;
+                        } else {  // two strand views: one table slot, reachable from both record buckets
+                            o.more.push_back(gh1);
+                            o.more.push_back(gh2);
+                        }
+                    }
                 }
+                if (in_record) continue;
+                gs_rep_planes(fhi, flo, k, kmask, phi, plo);  // the orientation the table files this k-mer under
+                const u64 hk = gs_mix_planes(phi, plo);
                 if (n_parts > 1 && (int)((hk >> GS_OWNER_SHIFT) % (u64)n_parts) != part) continue;  // another rank owns it
                 o.h.push_back(hk);
                 o.v.push_back(vidx[i]);
@@ -269,13 +321,168 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             for (int t = 0; t < n_thr; t++) th.emplace_back(work, t);
             for (auto &x : th) x.join();
         }
+        size_t nr = 0;
+        for (Slice &o : sl) nr += o.r.size();
+        rents.reserve(nr);
         for (Slice &o : sl) {
             hkey.insert(hkey.end(), o.h.begin(), o.h.end());
             hval.insert(hval.end(), o.v.begin(), o.v.end());
             hmin.insert(hmin.end(), o.m.begin(), o.m.end());
+            hmore.insert(hmore.end(), o.more.begin(), o.more.end());
+            rents.insert(rents.end(), o.r.begin(), o.r.end());
             Slice().h.swap(o.h);
+            std::vector<RecEntry>().swap(o.r);
         }
     }
+    // ---- number of DISTINCT minimizers, estimated by linear counting on a 2^26-bit sketch (a sort of the 32-bit hashes
+    // costs seconds for tens of millions of keys; +-1 % is plenty for power-of-two sizes): sizes the gate and the records
+    const int64_t nm = (int64_t)hmin.size();
+    double distinct_min = 0;
+    if (want_mgate && nm > 0) {
+        const size_t sketch_bits = (size_t)1 << 26;
+        std::vector<u64> sketch(sketch_bits / 64, 0);
+        for (int64_t i = 0; i < nm; i++) {
+            const uint32_t x = hmin[(size_t)i] * 0x9E3779B1u;  // (the hash is a bijection of the 15-mer: no extra collisions)
+            sketch[(x >> 6) & (sketch.size() - 1)] |= 1ULL << (x & 63);
+        }
+        size_t ones = 0;
+        for (u64 w : sketch) ones += (size_t)__builtin_popcountll(w);
+        const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
+        distinct_min = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
+    }
+    // ---- super-k-mer records (gs_layout.h): one window per bucket; the k-mers of windows that lose their bucket join
+    // the table keys
+    std::vector<u64> rec;
+    int rec_bits = 0;
+    int64_t n_in_records = 0;
+    if (want_rec && !rents.empty()) {
+        // windows per bucket before the bucket count doubles: with the power-of-two rounding 0.25 .. 0.5
+        double rload = 0.5;
+        if (const char *e = getenv("GS_REC_LOAD")) {
+            const double v = atof(e);
+            if (v > 0.01 && v <= 4.0) rload = v;
+        }
+        rec_bits = 4;
+        while (rec_bits < 29 && (double)((size_t)1 << rec_bits) * rload < distinct_min) rec_bits++;
+        const size_t n_rec = (size_t)1 << rec_bits;
+        rec.assign(n_rec * GS_REC_WORDS, 0);
+        const int64_t ne = (int64_t)rents.size();
+        int n_thr = (int)std::min<int64_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 32);
+        if (const char *e = getenv("GS_BUILD_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
+        if (ne < 200000) n_thr = 1;
+        // counting sort by the top bits of the bucket, then every chunk is sorted and clustered on its own
+        const int cbits = std::min(rec_bits, 8), cshift = rec_bits - cbits, n_chunks = 1 << cbits;
+        std::vector<int64_t> cstart((size_t)n_chunks + 1, 0);
+        for (int64_t i = 0; i < ne; i++) {
+            rents[(size_t)i].bucket = gs_rec_bucket(rents[(size_t)i].gh, (uint32_t)rec_bits);
+            cstart[(size_t)(rents[(size_t)i].bucket >> cshift) + 1]++;
+        }
+        for (int c = 0; c < n_chunks; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
+        std::vector<RecEntry> sorted((size_t)ne);
+        {
+            std::vector<int64_t> cur(cstart.begin(), cstart.end() - 1);
+            for (int64_t i = 0; i < ne; i++) sorted[(size_t)cur[(size_t)(rents[(size_t)i].bucket >> cshift)]++] = rents[(size_t)i];
+        }
+        std::vector<RecEntry>().swap(rents);
+        struct Lost {
+            std::vector<u64> h;
+            std::vector<int32_t> v;
+            int64_t kept = 0;
+        };
+        std::vector<Lost> lost((size_t)n_chunks);
+        const int c_off = k - GS_MIN_L;  // the minimizer sits at offset c_off - j of the k-mer at window offset j
+        (void)c_off;
+        auto cluster_chunk = [&](int c) {
+            RecEntry *lo = sorted.data() + cstart[(size_t)c], *hi = sorted.data() + cstart[(size_t)c + 1];
+            std::sort(lo, hi, [](const RecEntry &a, const RecEntry &b) {
+                if (a.bucket != b.bucket) return a.bucket < b.bucket;
+                if (a.gh != b.gh) return a.gh < b.gh;
+                if ((a.vj & 31u) != (b.vj & 31u)) return (a.vj & 31u) < (b.vj & 31u);
+                if (a.ohi != b.ohi) return a.ohi < b.ohi;
+                return a.olo < b.olo;
+            });
+            struct Win {
+                u64 whi, wlo, known;
+                uint32_t valid, gh;
+                int count;
+            };
+            std::vector<Win> wins;
+            std::vector<int> owner;  // window of every entry of the current bucket
+            Lost &L = lost[(size_t)c];
+            for (RecEntry *b0 = lo; b0 < hi;) {
+                RecEntry *b1 = b0;
+                while (b1 < hi && b1->bucket == b0->bucket) b1++;
+                wins.clear();
+                owner.assign((size_t)(b1 - b0), -1);
+                for (RecEntry *e = b0; e < b1; e++) {
+                    const int j = (int)(e->vj & 31u);
+                    const u64 eh = (u64)e->ohi << j, el = (u64)e->olo << j, km = (u64)kmask << j;
+                    int w = -1;
+                    for (size_t x = 0; x < wins.size(); x++) {
+                        const Win &W = wins[x];
+                        if (W.gh == e->gh && !((W.valid >> j) & 1u) && ((W.whi ^ eh) & W.known & km) == 0 && ((W.wlo ^ el) & W.known & km) == 0) {
+                            w = (int)x;
+                            break;
+                        }
+                    }
+                    if (w < 0) {
+                        wins.push_back(Win{0, 0, 0, 0u, e->gh, 0});
+                        w = (int)wins.size() - 1;
+                    }
+                    Win &W = wins[(size_t)w];
+                    W.whi |= eh;
+                    W.wlo |= el;
+                    W.known |= km;
+                    W.valid |= 1u << j;
+                    W.count++;
+                    owner[(size_t)(e - b0)] = w;
+                }
+                int best = 0;
+                for (size_t x = 1; x < wins.size(); x++)
+                    if (wins[x].count > wins[(size_t)best].count) best = (int)x;
+                u64 *rp = rec.data() + (size_t)b0->bucket * GS_REC_WORDS;
+                rp[0] = wins[(size_t)best].whi;
+                rp[1] = wins[(size_t)best].wlo | ((u64)wins[(size_t)best].valid << GS_REC_WIN_BITS);
+                bool more = false;
+                for (RecEntry *e = b0; e < b1; e++) {
+                    const int j = (int)(e->vj & 31u);
+                    if (owner[(size_t)(e - b0)] == best) {
+                        rp[2 + j / 3] |= (u64)(e->vj >> 5) << (GS_REC_VAL_BITS * (j % 3));
+                        L.kept++;
+                    } else {
+                        uint32_t phi, plo;
+                        gs_rep_planes(e->ohi, e->olo, k, kmask, phi, plo);
+                        L.h.push_back(gs_mix_planes(phi, plo));
+                        L.v.push_back((int32_t)(e->vj >> 5));
+                        more = true;
+                    }
+                }
+                if (more)
+                    for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
+                b0 = b1;
+            }
+        };
+        if (n_thr == 1) {
+            for (int c = 0; c < n_chunks; c++) cluster_chunk(c);
+        } else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++)
+                th.emplace_back([&] {
+                    for (int c; (c = next.fetch_add(1)) < n_chunks;) cluster_chunk(c);
+                });
+            for (auto &x : th) x.join();
+        }
+        for (Lost &L : lost) {  // (in chunk order: independent of the thread count)
+            hkey.insert(hkey.end(), L.h.begin(), L.h.end());
+            hval.insert(hval.end(), L.v.begin(), L.v.end());
+            n_in_records += L.kept;
+        }
+        for (uint32_t gh : hmore) {
+            u64 *rp = rec.data() + (size_t)gs_rec_bucket(gh, (uint32_t)rec_bits) * GS_REC_WORDS;
+            for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
+        }
+    }  // (no eligible k-mer at all: no records, every key is in the table and the kernels take the table path)
     const int64_t ns = (int64_t)hkey.size();
     const int vbits = std::max(1, bits_for((u64)n_values));
     // keys per 8-slot bucket before the bucket count doubles: with the power-of-two rounding the table ends up at
@@ -330,20 +537,8 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- minimizer gate (gs_layout.h): 16-32 bits per DISTINCT minimizer, 2 bits set per entry, 32-bit words
     std::vector<uint32_t> mgate;
     int mgate_bits = 0;
-    const int64_t nm = (int64_t)hmin.size();
     if (want_mgate && nm > 0) {
-        // size by the number of DISTINCT minimizers, estimated by linear counting on a 2^26-bit sketch (a sort of
-        // the 32-bit hashes costs seconds for tens of millions of keys; +-1 % is plenty for a power-of-two size)
-        const size_t sketch_bits = (size_t)1 << 26;
-        std::vector<u64> sketch(sketch_bits / 64, 0);
-        for (int64_t i = 0; i < nm; i++) {
-            const uint32_t x = hmin[(size_t)i] * 0x9E3779B1u;  // (the hash is a bijection of the 15-mer: no extra collisions)
-            sketch[(x >> 6) & (sketch.size() - 1)] |= 1ULL << (x & 63);
-        }
-        size_t ones = 0;
-        for (u64 w : sketch) ones += (size_t)__builtin_popcountll(w);
-        const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
-        const double distinct = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
+        const double distinct = distinct_min;
         double bits_per_min = 16.0;  // rounded up to a power-of-two word count: 16..32 bits per distinct minimizer
         if (const char *e = getenv("GS_MGATE_BITS_PER_MIN")) bits_per_min = std::max(1.0, atof(e));
         mgate_bits = 6;
@@ -363,6 +558,8 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
     if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !rec.empty()) e = hipMalloc((void **)&db->d_rec, rec.size() * sizeof(u64));
+    if (e == hipSuccess && !rec.empty()) e = hipMemcpy(db->d_rec, rec.data(), rec.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
@@ -372,6 +569,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         hipFree(db->d_table);
         hipFree(db->d_gate);
         hipFree(db->d_mgate);
+        hipFree(db->d_rec);
         hipFree(db->d_tree);
         delete db;
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
@@ -379,7 +577,12 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     db->info.k = k;
     db->info.n_values = n_values;
     db->info.n_entries = n;
-    db->info.n_stored = ns;
+    db->info.n_stored = ns + n_in_records;
+    db->info.n_in_records = n_in_records;
+    db->info.rec_bytes = (int64_t)(rec.size() * sizeof(u64));
+    db->n_rec = rec.empty() ? 0 : (int64_t)1 << rec_bits;
+    db->dev.rec = db->d_rec;
+    db->dev.rec_bits = (uint32_t)rec_bits;
     db->info.n_buckets = (int64_t)1 << b;
     db->info.table_bytes = (int64_t)tbytes;
     db->info.max_displacement = max_disp;
@@ -414,12 +617,13 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE5"
+    char magic[8];  // "GSSTORE6"
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
     uint64_t mgate_words;  // 32-bit words, a power of two
-    uint64_t checksum;     // store_checksum over table | gate | mgate | tree
+    uint64_t rec_buckets;  // super-k-mer record buckets (GS_REC_WORDS words each), a power of two or 0
+    uint64_t checksum;     // store_checksum over table | gate | mgate | records | tree
 };
 
 // two running 64-bit sums over the payload's 32-bit words (Fletcher style): position sensitive, one pass
@@ -436,7 +640,8 @@ struct StoreChecksum {
 };
 
 // what the kernels index with: every field of a store image that came from a file is checked before it reaches HBM
-static const char *store_image_defect(const GsStoreFileHeader &h, const std::vector<u64> &table, const std::vector<int32_t> &tree) {
+static const char *store_image_defect(const GsStoreFileHeader &h, const std::vector<u64> &table, const std::vector<u64> &rec,
+                                      const std::vector<int32_t> &tree) {
     const gs_db_info &in = h.info;
     if (in.k < 1 || in.k > 31) return "k outside [1, 31]";
     if (in.n_values < 1 || in.n_values > (1 << 24)) return "n_values outside [1, 2^24]";
@@ -449,6 +654,9 @@ static const char *store_image_defect(const GsStoreFileHeader &h, const std::vec
     if ((h.mgate_words & (h.mgate_words - 1)) != 0 || h.mgate_words > ((uint64_t)1 << 30)) return "minimizer gate size is not a power of two";
     if (h.mgate_words && in.k < GS_MIN_K) return "minimizer gate on a store with k < 19";
     if (in.gate_bytes != (int64_t)(h.gate_words * 8) || in.mgate_bytes != (int64_t)(h.mgate_words * 4)) return "gate sizes disagree";
+    if ((h.rec_buckets & (h.rec_buckets - 1)) != 0 || h.rec_buckets > ((uint64_t)1 << 29) || (h.rec_buckets && !h.mgate_words)) return "record bucket count is not a power of two";
+    if (in.rec_bytes != (int64_t)(h.rec_buckets * GS_REC_WORDS * 8)) return "record size disagrees";
+    if (h.rec_buckets && in.n_values > GS_REC_MAX_VALUES) return "records on a store with more than 2^21 values";
     if (in.max_displacement < 0 || in.max_displacement > GS_MAX_DISP) return "displacement out of range";
     const int32_t nv = in.n_values;
     const int32_t *parent = tree.data(), *depth = parent + nv, *tin = depth + nv, *tout = tin + nv;
@@ -472,7 +680,22 @@ static const char *store_image_defect(const GsStoreFileHeader &h, const std::vec
         if (s & 1) return "table: seen bit set in a stored image";
         stored++;
     }
-    if (stored != in.n_stored) return "table: entry count disagrees with the header";
+    int64_t in_records = 0;
+    const int c_off = in.k - GS_MIN_L;
+    for (size_t b = 0; b < rec.size() / GS_REC_WORDS; b++) {
+        const u64 *rp = rec.data() + b * GS_REC_WORDS;
+        if (rp[0] >> GS_REC_WIN_BITS) return "records: seen bit set in a stored image";
+        uint32_t valid = (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
+        if (valid >> (c_off + 1)) return "records: k-mer offset beyond the window";
+        for (; valid; valid &= valid - 1) {
+            const int j = __builtin_ctz(valid);
+            const u64 vi = (rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1);
+            if (vi >= (u64)nv || parent[vi] == -2) return "records: value without a tree node";
+            in_records++;
+        }
+    }
+    if (in_records != in.n_in_records) return "records: entry count disagrees with the header";
+    if (stored + in_records != in.n_stored) return "table: entry count disagrees with the header";
     return nullptr;
 }
 
@@ -481,14 +704,17 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE5", 8);
+    memcpy(h.magic, "GSSTORE6", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
     h.gate_words = db->d_gate ? db->dev.gate_mask + 1 : 0;
     h.mgate_words = db->d_mgate ? (uint64_t)1 << db->dev.mgate_bits : 0;
+    h.rec_buckets = (uint64_t)db->n_rec;
     const size_t nv = (size_t)db->info.n_values;
     std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    std::vector<u64> rec((size_t)h.rec_buckets * GS_REC_WORDS);
+    if (!rec.empty()) HIP_TRY(hipMemcpy(rec.data(), db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
     std::vector<uint32_t> mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
     HIP_TRY(hipMemcpy(table.data(), db->d_table, table.size() * sizeof(u64), hipMemcpyDeviceToHost));
@@ -500,6 +726,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
         cs.add(table.data(), table.size() * sizeof(u64));
         cs.add(gate.data(), gate.size() * sizeof(u64));
         cs.add(mgate.data(), mgate.size() * sizeof(uint32_t));
+        cs.add(rec.data(), rec.size() * sizeof(u64));
         cs.add(tree.data(), tree.size() * sizeof(int32_t));
         h.checksum = cs.value();
     }
@@ -508,6 +735,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
               fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
               fwrite(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
+              fwrite(rec.data(), sizeof(u64), rec.size(), f) == rec.size() &&
               fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     ok = (fclose(f) == 0) && ok;
     return ok ? GS_OK : fail(GS_E_IO, std::string("short write to ") + path);
@@ -525,15 +753,15 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE5", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE6", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
         h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
-        h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30)) {
+        h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30) || h.rec_buckets > ((uint64_t)1 << 29)) {
         fclose(f);
         return fail(GS_E_INVALID, std::string(path) + " is not a gsgpu store file (or one of another layout version)");
     }
     const size_t nv = (size_t)h.info.n_values;
     {   // the payload the header announces must be exactly what the file holds
-        const uint64_t want = (uint64_t)sizeof(h) + (uint64_t)h.info.n_buckets * 64 + h.gate_words * 8 + h.mgate_words * 4 + (uint64_t)nv * 16;
+        const uint64_t want = (uint64_t)sizeof(h) + (uint64_t)h.info.n_buckets * 64 + h.gate_words * 8 + h.mgate_words * 4 + h.rec_buckets * GS_REC_WORDS * 8 + (uint64_t)nv * 16;
         if (fseeko(f, 0, SEEK_END) != 0 || (uint64_t)ftello(f) != want || fseeko(f, (off_t)sizeof(h), SEEK_SET) != 0) {
             fclose(f);
             return fail(GS_E_INVALID, std::string(path) + ": file size does not match its header (truncated or damaged)");
@@ -541,10 +769,12 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     }
     std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
     std::vector<uint32_t> mgate((size_t)h.mgate_words);
+    std::vector<u64> rec((size_t)h.rec_buckets * GS_REC_WORDS);
     std::vector<int32_t> tree(4 * nv);
     const bool ok = fread(table.data(), sizeof(u64), table.size(), f) == table.size() &&
                     fread(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
                     fread(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
+                    fread(rec.data(), sizeof(u64), rec.size(), f) == rec.size() &&
                     fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
     fclose(f);
     if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
@@ -553,10 +783,11 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
         cs.add(table.data(), table.size() * sizeof(u64));
         cs.add(gate.data(), gate.size() * sizeof(u64));
         cs.add(mgate.data(), mgate.size() * sizeof(uint32_t));
+        cs.add(rec.data(), rec.size() * sizeof(u64));
         cs.add(tree.data(), tree.size() * sizeof(int32_t));
         if (cs.value() != h.checksum) return fail(GS_E_INVALID, std::string(path) + ": payload checksum mismatch (damaged file)");
     }
-    if (const char *why = store_image_defect(h, table, tree)) return fail(GS_E_INVALID, std::string(path) + ": " + why);
+    if (const char *why = store_image_defect(h, table, rec, tree)) return fail(GS_E_INVALID, std::string(path) + ": " + why);
     gs_db *db = new gs_db();
     db->device = device;
     hipDeviceProp_t prop;
@@ -569,11 +800,14 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
     if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !rec.empty()) e = hipMalloc((void **)&db->d_rec, rec.size() * sizeof(u64));
+    if (e == hipSuccess && !rec.empty()) e = hipMemcpy(db->d_rec, rec.data(), rec.size() * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db->d_tree, tree.data(), tree.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(db->d_table);
         hipFree(db->d_gate);
         hipFree(db->d_mgate);
+        hipFree(db->d_rec);
         hipFree(db->d_tree);
         delete db;
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
@@ -585,6 +819,10 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     db->dev.mgate = db->d_mgate;
     db->dev.mgate_bits = 0;
     while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
+    db->n_rec = (int64_t)h.rec_buckets;
+    db->dev.rec = db->d_rec;
+    db->dev.rec_bits = 0;
+    while (((uint64_t)1 << db->dev.rec_bits) < h.rec_buckets) db->dev.rec_bits++;
     db->dev.bucket_bits = h.bucket_bits;
     db->dev.vbits = h.vbits;
     db->dev.bucket_mask = ((u64)1 << h.bucket_bits) - 1;
@@ -604,12 +842,11 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
 
 extern "C" int gs_db_destroy(gs_db *db) {
     if (!db) return GS_OK;
-    hipSetDevice(db->device);
-    hipFree(db->d_table);
-    hipFree(db->d_gate);
-    hipFree(db->d_mgate);
-    hipFree(db->d_tree);
-    delete db;
+    if (db->live_runs > 0) {  // freed by the last gs_match_destroy
+        db->destroy_pending = true;
+        return GS_OK;
+    }
+    db_free(db);
     return GS_OK;
 }
 
@@ -847,9 +1084,9 @@ static int run_clear(gs_run *run) {
     HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS, run->stream));
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
     if (run->d_hit_counts)
-        HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream));
+        HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)(run->db->n_slots() + run->db->n_rec * GS_REC_SLOTS), run->stream));
     if (run->seen_dirty)
-        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream));
+        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream));
     run->seen_dirty = false;
     run->bitmap_merged = false;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
@@ -913,7 +1150,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     run->db = db;
     run->cfg = *cfg;
     const size_t nv = (size_t)db->info.n_values;
-    run->bitmap_words = (db->info.n_buckets * GS_SLOTS_PER_BUCKET + 31) / 32;
+    run->bitmap_words = (db->n_slots() + 31) / 32 + db->n_rec;  // one word per record bucket behind the table slots' bits
     hipError_t e = hipStreamCreateWithFlags(&run->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_max, sizeof(int64_t) * nv);
@@ -921,7 +1158,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_bitmap, sizeof(uint32_t) * (size_t)run->bitmap_words);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
     if (e == hipSuccess && cfg->max_kmer_res_counts > 0)
-        e = hipMalloc((void **)&run->d_hit_counts, sizeof(uint32_t) * (size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET);
+        e = hipMalloc((void **)&run->d_hit_counts, sizeof(uint32_t) * (size_t)(db->n_slots() + db->n_rec * GS_REC_SLOTS));
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, sizeof(unsigned int));
     if (e != hipSuccess) {
         run_free(run);
@@ -942,6 +1179,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         return rc;
     }
     if (cfg->count_unique) db->unique_owner = run;
+    db->live_runs++;
     *out = run;
     return GS_OK;
 }
@@ -1270,11 +1508,11 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     std::vector<u64> uniq(nv, 0);
     if (run->cfg.count_unique) {
         if (!run->bitmap_merged)
-            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->d_bitmap,
+            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
                                              run->stream));
         HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * nv, run->stream));
-        HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET,
-                                       run->db->dev.vbits, run->db->info.n_values, run->d_unique, run->stream));
+        HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->n_slots(), run->db->dev.vbits,
+                                       run->db->info.n_values, run->d_unique, run->db->d_rec, run->db->n_rec, run->stream));
         HIP_TRY(hipMemcpyAsync(uniq.data(), run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
     }
     HIP_TRY(hipMemcpyAsync(sums.data(), run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToHost, run->stream));
@@ -1318,11 +1556,13 @@ extern "C" int gs_match_destroy(gs_run *run) {
     hipSetDevice(run->db->device);
     hipStreamSynchronize(run->stream);
     if (run->db->unique_owner == run) {
-        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->stream);
+        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream);
         hipStreamSynchronize(run->stream);
         run->db->unique_owner = nullptr;
     }
+    gs_db *db = run->db;
     run_free(run);
+    if (--db->live_runs == 0 && db->destroy_pending) db_free(db);
     return GS_OK;
 }
 
@@ -1331,7 +1571,7 @@ extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, 
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
     if (bitmap && run->cfg.count_unique && !run->bitmap_merged)  // refresh the compact copy of the seen bits
-        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->info.n_buckets * GS_SLOTS_PER_BUCKET, run->d_bitmap,
+        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
                                          run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     if (sums) *sums = run->d_sums;
@@ -1355,6 +1595,7 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
 extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
                                const uint64_t *pos_off, uint64_t *keys) {
     if (!run || (n_reads > 0 && (!seq || !offsets || !pos_off || !keys))) return fail(GS_E_INVALID, "NULL argument");
+    if (run->db->n_rec > 0) return fail(GS_E_STATE, "the split pipeline needs a partition store (gs_db_create_part): this store keeps k-mers in super-k-mer records");
     if (n_reads <= 0) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
     GsEncodeParams P{};
@@ -1374,6 +1615,7 @@ extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *
 
 extern "C" int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32_t *nodes) {
     if (!run || (n_keys > 0 && (!keys || !nodes))) return fail(GS_E_INVALID, "NULL argument");
+    if (run->db->n_rec > 0) return fail(GS_E_STATE, "the split pipeline needs a partition store (gs_db_create_part): this store keeps k-mers in super-k-mer records");
     if (n_keys <= 0) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
     if (run->cfg.count_unique) {
@@ -1603,6 +1845,25 @@ extern "C" int gs_match_max_counts(gs_run *run, int16_t *out) {
         const int16_t c = (int16_t)(uint16_t)(counts[i] & 0xffffu);  // Java short arithmetic wraps
         update(c, out + (size_t)vi * N);
         update(c, out + nv * (size_t)N);
+    }
+    if (run->db->n_rec > 0) {  // the k-mers that live in super-k-mer records
+        const size_t n_rec = (size_t)run->db->n_rec;
+        std::vector<u64> rec(n_rec * GS_REC_WORDS);
+        std::vector<uint32_t> rcounts(n_rec * GS_REC_SLOTS);
+        HIP_TRY(hipMemcpy(rec.data(), run->db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rcounts.data(), run->d_hit_counts + n_slots, rcounts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t b = 0; b < n_rec; b++) {
+            const u64 *rp = rec.data() + b * GS_REC_WORDS;
+            uint32_t seen = (uint32_t)(rp[0] >> GS_REC_WIN_BITS) & (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
+            for (; seen; seen &= seen - 1) {
+                const int j = __builtin_ctz(seen);
+                const size_t vi = (size_t)((rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1));
+                if (vi >= nv) continue;
+                const int16_t c = (int16_t)(uint16_t)(rcounts[b * GS_REC_SLOTS + (size_t)j] & 0xffffu);
+                update(c, out + vi * N);
+                update(c, out + nv * (size_t)N);
+            }
+        }
     }
     return GS_OK;
 }

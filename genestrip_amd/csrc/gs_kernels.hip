@@ -76,24 +76,6 @@ __device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64
     bad = __ballot(b);
 }
 
-// Software pipeline across the reads of one wave: while read r waits for its bucket lines, the first 192 bases of
-// the wave's next read are already on their way (issued AFTER the bucket loads, so the in-order vmcnt wait for
-// the buckets does not cover them).
-struct GsPrefetch {
-    const uint8_t *rd;  // next read's bases (nullptr: nothing to fetch)
-    int L;
-    uint32_t c[3];
-    __device__ __forceinline__ void issue(int lane) {
-        if (rd != nullptr) {
-#pragma unroll
-            for (int w = 0; w < 3; w++) {
-                const int j = 64 * w + lane;
-                c[w] = j < L ? rd[j] : 0u;
-            }
-        }
-    }
-};
-
 // ---------------------------------------------------------------------------------------------------
 // statistics sinks: LDS-privatised (n_values <= GS_NV_LDS) or direct global atomics
 // ---------------------------------------------------------------------------------------------------
@@ -132,7 +114,7 @@ typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 #endif
 
 // (Software pipelining of the next read's bases behind the bucket loads was measured on MI355X: the extra registers
-// cost one wave per SIMD and the net effect was nil, so GsPrefetch::issue is never armed.)
+// cost one wave per SIMD and the net effect was nil; the code is gone.)
 
 #ifndef GS_NT_TABLE
 // Measured on MI355X: non-temporal bucket loads stop the four dwordx4 loads of one 64-byte line from sharing a
@@ -245,150 +227,194 @@ __device__ __forceinline__ int gs_sc_load(const int32_t *p) { return __hip_atomi
 __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---------------------------------------------------------------------------------------------------
-// 128 k-mer positions [base, base+128) of one read: planes -> canonical keys -> gate -> bucket lines -> node codes.
+// 128 k-mer positions [base, base+128) of one read: planes -> minimizer -> gate -> record line (or bucket line) -> node.
 // node[s] for position base + 64 s + lane: value index (hit), GS_NODE_MISS, GS_NODE_INVALID (window holds a
-// non-CGAT byte) or GS_NODE_NONE (position >= max).  slot = global slot index of a hit, fresh = its seen bit was 0.
+// non-CGAT byte) or GS_NODE_NONE (position >= max).  Hits are marked on the spot (mk): the unique-k-mer "seen" bit of
+// the slot / record offset that was just read (KMerUniqueCounterBits.putInlined; a k-mer that is already marked costs
+// nothing, a stale copy only repeats the atomic) and the per-k-mer hit counter (maxKMerResCounts > 0).
 // ---------------------------------------------------------------------------------------------------
-template <bool PREFETCH, int KC>
+struct GsMark {
+    int count_unique;
+    uint32_t *hit_counts;  // [table slots | GS_REC_SLOTS per record bucket] or nullptr
+};
+
+__device__ __forceinline__ void gs_take_hit(const GsDbDev &db, uint32_t slot, int vs, int &node, const GsMark &mk) {
+    node = vs >> 1;
+    if (mk.count_unique && (vs & 1) == 0) atomicOr(const_cast<u64 *>(db.table) + slot, 1ULL);
+    if (mk.hit_counts != nullptr) atomicAdd(mk.hit_counts + slot, 1u);
+}
+
+// the rest of a table lookup for the lanes in `pending` (their k-mer was not decided by the first half of its home
+// bucket, or that half has not been looked at yet: FIRST): second half, then the displaced buckets
+template <bool FIRST>
+__device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, u64 want, uint32_t vmask2, bool pending, int &node,
+                                               const GsMark &mk) {
+    const uint32_t bmask = (uint32_t)db.bucket_mask;
+#pragma unroll
+    for (int half = FIRST ? 0 : 1; half < 2; half++) {
+        if (__ballot(pending) != 0) {  // (second half: more than four entries in the home bucket)
+            if (pending) {
+                GsHalf t;
+                gs_load_half(db.table, bkt, half, t);
+                int vs = -1, sl = 0;
+                const bool done = gs_match_half(t, want, vmask2, vs, sl);
+                if (vs >= 0) gs_take_hit(db, bkt * GS_SLOTS_PER_BUCKET + 4 * half + sl, vs, node, mk);
+                pending = !done;
+            }
+        }
+    }
+    // rare: home bucket full without a match -> walk the displaced buckets
+    for (int disp = 1; disp <= GS_MAX_DISP && __ballot(pending) != 0; disp++) {
+        if (pending) {
+            const uint32_t b2 = (bkt + (uint32_t)disp) & bmask;
+            GsBucket t;
+            gs_load_bucket(db.table, b2, t);
+            int vs = -1, sl = 0;
+            const bool done = gs_match_bucket(t, want | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
+            if (vs >= 0) gs_take_hit(db, b2 * GS_SLOTS_PER_BUCKET + sl, vs, node, mk);
+            pending = !done;
+        }
+    }
+}
+
+// minimizer of the k-mers at positions base + 64 s + lane through the wave's LDS row: rank of every 15-mer of
+// positions base .. base+143, then per lane the minimum over its k-14 positions (one min3 chain; the rank carries the
+// row index, so the minimum is the position as well).  Returns the offset of the chosen 15-mer inside the lane's k-mer.
+template <int KC>
+__device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u64 (&Blo)[3], const uint32_t (&fhi)[2],
+                                                   const uint32_t (&flo)[2], int k, int lane, uint32_t *wave_g, int (&p)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+        wave_g[64 * s + lane] = gs_lmer_rank(gs_lmer_hash(fhi[s] & 0x7fffu, flo[s] & 0x7fffu), (uint32_t)(64 * s + lane));
+    if (lane < 16)
+        wave_g[128 + lane] = gs_lmer_rank(gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu),
+                                          (uint32_t)(128 + lane));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int w = k - GS_MIN_L + 1;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        uint32_t mn = 0xffffffffu;
+#pragma unroll
+        for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
+            if (KC || d < w) {
+                const uint32_t g = wave_g[64 * s + lane + d];
+                mn = g < mn ? g : mn;
+            }
+        }
+        p[s] = (int)(mn & 0xffu) - (64 * s + lane);
+    }
+    __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
+}
+
+template <int KC>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
-                                                const u64 (&Bbad)[3], int base, int max, int lane, GsPrefetch &next,
-                                                int (&node)[2], int (&slot)[2], bool (&fresh)[2], uint32_t *wave_g) {
+                                                const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
+                                                uint32_t *wave_g, const GsMark &mk) {
     const int k = KC ? KC : db.k;  // KC = compile-time k of the specialised kernels (0: any k)
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
     const int shift_rem = (int)db.vbits + 3;
     const uint32_t bmask = (uint32_t)db.bucket_mask;  // n_buckets <= 2^29
     const bool any_bad = (Bbad[0] | Bbad[1] | Bbad[2]) != 0;
-    uint32_t bkt[2], gfield[2];
-    u64 want[2], gword[2];
+    uint32_t fhi[2], flo[2];
     bool act[2];
-#if GS_HALF_BUCKETS
-    GsHalf bk[2];
-#else
-    GsBucket bk[2];
-#endif
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int p = base + 64 * s + lane;
         const bool valid = p < max;
-        const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
-        const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+        fhi[s] = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+        flo[s] = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
         // almost every read is clean: the per-lane window test is skipped on a wave-uniform branch
         const uint32_t wbad = any_bad ? (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask : 0u;
-        const u64 h = gs_kmer_hash(fhi, flo, k, kmask);
-        bkt[s] = (uint32_t)h & bmask;
-        want[s] = (h >> db.bucket_bits) << shift_rem;
-        gfield[s] = (uint32_t)(h >> GS_GATE_FIELD_SHIFT);
         act[s] = valid && (wbad == 0);
         node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
-        slot[s] = 0;
-        fresh[s] = false;
-        gword[s] = ~0ULL;
-        if (db.mgate != nullptr) {
-            // order hash of the 15-mer that starts at this position (positions base+64s+lane)
-            wave_g[64 * s + lane] = gs_lmer_hash(fhi & 0x7fffu, flo & 0x7fffu);
-        } else if (db.gate != nullptr && act[s]) {
-            gword[s] = db.gate[(h >> db.bucket_bits) & db.gate_mask];  // L2-resident
-        }
     }
     if (db.mgate != nullptr) {
-        // minimizer gate: min of the 15-mer hashes over the k-14 positions of each k-mer, through the wave's LDS
-        // row (positions base .. base+143); lanes that share a minimizer read the same gate word -> one request
-        if (lane < 16)
-            wave_g[128 + lane] = gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int w = k - GS_MIN_L + 1;
-        uint32_t mn[2] = {0xffffffffu, 0xffffffffu};
+        // minimizer gate: lanes that share a minimizer read the same gate word -> one request
+        int mp[2];
+        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp);
+        uint32_t gh[2], ohi[2], olo[2];
+        int j[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-#pragma unroll
-            for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
-                if (KC || d < w) {
-                    const uint32_t g = wave_g[64 * s + lane + d];
-                    mn[s] = g < mn[s] ? g : mn[s];
-                }
-            }
+            const uint32_t rhi = __brev(fhi[s]) >> (32 - k);
+            const uint32_t rlo = (__brev(flo[s]) >> (32 - k)) ^ kmask;
+            gs_min_oriented(fhi[s], flo[s], rhi, rlo, k, mp[s], gh[s], ohi[s], olo[s], j[s]);
         }
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             if (act[s]) {
-                const uint32_t bits = gs_mgate_bits(mn[s]);
-                act[s] = (db.mgate[gs_mgate_word(mn[s], db.mgate_bits)] & bits) == bits;
+                const uint32_t bits = gs_mgate_bits(gh[s]);
+                act[s] = (db.mgate[gs_mgate_word(gh[s], db.mgate_bits)] & bits) == bits;  // no false negatives
             }
         }
-        __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
+        if (db.rec != nullptr) {
+            // ---- super-k-mer records: one 16-byte load of the window planes + the 8-byte word that holds this offset's value
+            const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
+            gs_u64x2 A[2];
+            u64 V[2];
+            uint32_t rb[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                rb[s] = gs_rec_bucket(gh[s], db.rec_bits);
+                if (act[s]) {
+                    const u64 *rp = db.rec + (u64)rb[s] * GS_REC_WORDS;
+                    A[s] = *reinterpret_cast<const gs_u64x2 *>(rp);
+                    V[s] = rp[2 + ((j[s] * 11) >> 5)];  // j / 3 for j <= 16
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                bool pending = false;
+                if (act[s]) {
+                    const int jj = j[s];
+                    const bool ok = ((uint32_t)((A[s].x & M47) >> jj) & kmask) == ohi[s] &&
+                                    ((uint32_t)((A[s].y & M47) >> jj) & kmask) == olo[s] && ((A[s].y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
+                    if (ok) {
+                        node[s] = (int)((V[s] >> (GS_REC_VAL_BITS * (jj - 3 * ((jj * 11) >> 5)))) & (GS_REC_MAX_VALUES - 1));
+                        if (mk.count_unique && ((A[s].x >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
+                            atomicOr(const_cast<u64 *>(db.rec) + (u64)rb[s] * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
+                        if (mk.hit_counts != nullptr)
+                            atomicAdd(mk.hit_counts + ((u64)(bmask + 1u) * GS_SLOTS_PER_BUCKET + (u64)rb[s] * GS_REC_SLOTS + (u64)jj), 1u);
+                    }
+                    pending = !ok && (V[s] & GS_REC_MORE) != 0;
+                }
+                // a k-mer that lost its record bucket to another window (or has two strand views) lives in the table
+                if (__ballot(pending) != 0) {
+                    const u64 h = gs_kmer_hash(ohi[s], olo[s], k, kmask);
+                    gs_lookup_rest<true>(db, (uint32_t)h & bmask, (h >> db.bucket_bits) << shift_rem, vmask2, pending, node[s], mk);
+                }
+            }
+            return;
+        }
     }
+    // ---- the ordinary table: one 64-byte bucket line per k-mer (stores without records: k < 19, partitions, > 2^21 values)
+    uint32_t bkt[2];
+    u64 want[2];
+    GsHalf bk[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        if (db.mgate == nullptr) {
-            const u64 gbits = gs_gate_field_bits(gfield[s]);
-            act[s] = act[s] && ((gword[s] & gbits) == gbits);  // gate: no false negatives
+        const u64 h = gs_kmer_hash(fhi[s], flo[s], k, kmask);
+        bkt[s] = (uint32_t)h & bmask;
+        want[s] = (h >> db.bucket_bits) << shift_rem;
+        if (db.mgate == nullptr && db.gate != nullptr && act[s]) {  // word gate (L2-resident), no false negatives
+            const u64 gbits = gs_gate_field_bits((uint32_t)(h >> GS_GATE_FIELD_SHIFT));
+            act[s] = (db.gate[(h >> db.bucket_bits) & db.gate_mask] & gbits) == gbits;
         }
-#if GS_HALF_BUCKETS
-        if (act[s]) gs_load_half(db.table, bkt[s], 0, bk[s]);
-#else
-        if (act[s]) gs_load_bucket(db.table, bkt[s], bk[s]);
-#endif
+        if (act[s]) gs_load_half(db.table, bkt[s], 0, bk[s]);  // both sub-rounds' loads in flight together
     }
-    if (PREFETCH) next.issue(lane);
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         bool pending = false;
-#if GS_HALF_BUCKETS
         if (act[s]) {
             int vs = -1, sl = 0;
             const bool done = gs_match_half(bk[s], want[s], vmask2, vs, sl);
-            if (vs >= 0) {
-                node[s] = vs >> 1;
-                fresh[s] = (vs & 1) == 0;
-                slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
-            }
+            if (vs >= 0) gs_take_hit(db, bkt[s] * GS_SLOTS_PER_BUCKET + sl, vs, node[s], mk);
             pending = !done;
         }
-        if (__ballot(pending) != 0) {  // more than four entries in the home bucket: its second half
-            if (pending) {
-                GsHalf t;
-                gs_load_half(db.table, bkt[s], 1, t);
-                int vs = -1, sl = 0;
-                const bool done = gs_match_half(t, want[s], vmask2, vs, sl);
-                if (vs >= 0) {
-                    node[s] = vs >> 1;
-                    fresh[s] = (vs & 1) == 0;
-                    slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + 4 + sl;
-                }
-                pending = !done;
-            }
-        }
-#else
-        if (act[s]) {
-            int vs = -1, sl = 0;
-            const bool done = gs_match_bucket(bk[s], want[s], vmask2, vs, sl);
-            if (vs >= 0) {
-                node[s] = vs >> 1;
-                fresh[s] = (vs & 1) == 0;
-                slot[s] = (int)(bkt[s] * GS_SLOTS_PER_BUCKET) + sl;
-            }
-            pending = !done;
-        }
-#endif
-        // rare: home bucket full without a match -> walk the displaced buckets
-        for (int disp = 1; disp <= GS_MAX_DISP && __ballot(pending) != 0; disp++) {
-            if (pending) {
-                const uint32_t b2 = (bkt[s] + (uint32_t)disp) & bmask;
-                GsBucket t;
-                gs_load_bucket(db.table, b2, t);
-                int vs = -1, sl = 0;
-                const bool done = gs_match_bucket(t, want[s] | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
-                if (vs >= 0) {
-                    node[s] = vs >> 1;
-                    fresh[s] = (vs & 1) == 0;
-                    slot[s] = (int)(b2 * GS_SLOTS_PER_BUCKET) + sl;
-                }
-                pending = !done;
-            }
-        }
+        gs_lookup_rest<false>(db, bkt[s], want[s], vmask2, pending, node[s], mk);
     }
 }
 
@@ -402,7 +428,7 @@ template <bool LONG, bool FROM_NODES, int KC, bool WIDE>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
-                                                GsPrefetch &next, uint32_t *wave_g) {
+                                                uint32_t *wave_g) {
     const GsDbDev &db = P.db;
     const int k = KC ? KC : db.k;
     const int max = L - k + 1;
@@ -455,8 +481,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 }
             }
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
-            int node[2], slot[2];
-            bool fresh[2];  // hit on a slot whose seen bit was still clear in the copy this lane read
+            int node[2];
             if (FROM_NODES) {
                 // DB-partitioned mode: the node of every position was looked up by the owner of its k-mer
                 // (gs_probe_keys_kernel on the owning rank) and routed back; INVALID windows carry GS_NODE_INVALID
@@ -468,28 +493,16 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     // the stream comes from other ranks: a value outside the store's range must not index anything
                     if (p < max && (v >= db.n_values || v < GS_NODE_INVALID)) v = GS_NODE_MISS;
                     node[s] = v;
-                    slot[s] = 0;
-                    fresh[s] = false;
                 }
             } else {
-                gs_probe_planes<!LONG, KC>(db, Bhi, Blo, Bbad, base, max, lane, next, node, slot, fresh, wave_g);
+                // (4a. unique k-mers and per-k-mer hit counters are marked by the probe itself)
+                const GsMark mk = {P.count_unique, P.hit_counts};
+                gs_probe_planes<KC>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
-            // ---- 4a. unique k-mers (KMerUniqueCounterBits.putInlined): the "seen" bit lives in the slot that was
-            // just read, so a k-mer that is already marked costs nothing; a stale copy only repeats the atomic
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
             found = found || ((hit0 | hit1) != 0);
             n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
-            if (P.count_unique) {
-#pragma unroll
-                for (int s = 0; s < 2; s++)
-                    if (!FROM_NODES && fresh[s]) atomicOr(const_cast<u64 *>(db.table) + (uint32_t)slot[s], 1ULL);
-            }
-            if (!FROM_NODES && P.hit_counts != nullptr) {  // maxKMerResCounts > 0: per-k-mer hit counters
-#pragma unroll
-                for (int s = 0; s < 2; s++)
-                    if (node[s] >= 0) atomicAdd(P.hit_counts + (uint32_t)slot[s], 1u);
-            }
 
             // ---- 4b. contigs and distinct nodes.  Contig statistics are lane parallel: every lane that starts a hit
             // contig finds the next node change in the ballot masks and books the contig itself (:391-413).  Only
@@ -826,8 +839,6 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
     const int k = KC ? KC : P.db.k;
-    GsPrefetch pf;
-    pf.rd = nullptr;
     // The ~40 launch parameters do not fit the scalar register file next to the ballot planes; kept live across
     // the loop they are spilled to VGPR lanes and read back with v_readlane on every use.  Re-reading them from
     // the kernarg segment (scalar cache) once per read is cheaper: the empty asm hides from the compiler that the
@@ -850,8 +861,8 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES, KC, WIDE>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre, pf,
-                                           s_g[wave_in_block]);
+        gs_process_read<false, FROM_NODES, KC, WIDE>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
+                                                     s_g[wave_in_block]);
     }
     GS_STATS_EPILOGUE()
 }
@@ -879,10 +890,8 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
         const uint32_t none[3] = {0, 0, 0};
-        GsPrefetch nopf;
-        nopf.rd = nullptr;
         gs_process_read<true, FROM_NODES, 0, WIDE>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
-                              (int)serial, none, nopf, s_g[wave_in_block]);
+                                                   (int)serial, none, s_g[wave_in_block]);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
@@ -909,7 +918,6 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = KC ? KC : P.k;  // KC = compile-time k (0: any k)
     const uint32_t kmask = (1u << k) - 1u;
-    const int w = k - GS_MIN_L + 1;
     // software pipeline over the wave's reads: the first 192 bases of the next read are loaded while the current
     // one is hashed (a read is a chain of dependent loads: offsets -> bases -> gate word)
     u64 off = 0, pb = 0;
@@ -949,38 +957,29 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
             }
             if (max <= 0) break;
             u64 key[2];
+            uint32_t fhi[2], flo[2];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                const uint32_t fhi = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
-                const uint32_t flo = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+                fhi[s] = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+                flo[s] = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
                 const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
-                key[s] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi, flo, k, kmask);
-                if (P.mgate != nullptr) wave_g[64 * s + lane] = gs_lmer_hash(fhi & 0x7fffu, flo & 0x7fffu);
+                key[s] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi[s], flo[s], k, kmask);
             }
             if (P.mgate != nullptr) {
                 // the store's minimizer gate (which covers the keys of every partition) as in gs_probe_planes: k-mers
                 // it rules out are not routed at all
-                if (lane < 16)
-                    wave_g[128 + lane] = gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int mp[2];
+                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
-                    uint32_t mn = 0xffffffffu;
-#pragma unroll
-                    for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
-                        if (KC || d < w) {
-                            const uint32_t g = wave_g[64 * s + lane + d];
-                            mn = g < mn ? g : mn;
-                        }
-                    }
                     if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
-                        const uint32_t bits = gs_mgate_bits(mn);
-                        if ((P.mgate[gs_mgate_word(mn, P.mgate_bits)] & bits) != bits) key[s] = GS_KEY_MISS;
+                        uint32_t gh, ohi, olo;
+                        int j;
+                        gs_min_oriented(fhi[s], flo[s], 0u, 0u, k, mp[s], gh, ohi, olo, j);  // only the minimizer's hash is needed
+                        const uint32_t bits = gs_mgate_bits(gh);
+                        if ((P.mgate[gs_mgate_word(gh, P.mgate_bits)] & bits) != bits) key[s] = GS_KEY_MISS;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
             }
 #pragma unroll
             for (int s = 0; s < 2; s++) {
@@ -1131,8 +1130,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = db.k;
-    GsPrefetch nopf;
-    nopf.rd = nullptr;
+    const GsMark nomark = {0, nullptr};
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
@@ -1148,9 +1146,8 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
             u64 Bhi[3], Blo[3], Bbad[3];
 #pragma unroll
             for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
-            int node[2], slot[2];
-            bool fresh[2];
-            gs_probe_planes<false, 0>(db, Bhi, Blo, Bbad, base, max, lane, nopf, node, slot, fresh, s_g[threadIdx.x >> 6]);
+            int node[2];
+            gs_probe_planes<0>(db, Bhi, Blo, Bbad, base, max, lane, node, s_g[threadIdx.x >> 6], nomark);
             const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
             const int last0 = gs_readlane(node[0], 63);
             const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
@@ -1224,6 +1221,53 @@ __global__ __launch_bounds__(256) void gs_clear_seen_kernel(u64 *table, int64_t 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const u64 s = table[i];
         if (s & 1ULL) table[i] = s & ~1ULL;
+    }
+}
+
+// ---- the same three sweeps over the super-k-mer records: the compact bitmap holds one 32-bit word per record bucket
+// (bit j = seen bit of offset j) behind the words of the table slots
+__global__ __launch_bounds__(256) void gs_rec_bitmap_extract_kernel(const u64 *rec, int64_t n_rec, uint32_t *bitmap_rec) {
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rec; b += (int64_t)gridDim.x * blockDim.x)
+        bitmap_rec[b] = (uint32_t)(rec[b * GS_REC_WORDS] >> GS_REC_WIN_BITS);
+}
+
+__global__ __launch_bounds__(256) void gs_rec_unique_count_kernel(const u64 *rec, const uint32_t *bitmap_rec, int64_t n_rec,
+                                                                 int32_t n_values, u64 *unique) {
+    __shared__ unsigned int s_cnt[GS_NV_LDS];
+    const bool lds = n_values <= GS_NV_LDS;
+    if (lds) {
+        for (int i = threadIdx.x; i < n_values; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rec; b += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = bitmap_rec[b];
+        if (bits == 0) continue;
+        const u64 *rp = rec + b * GS_REC_WORDS;
+        bits &= (uint32_t)(rp[1] >> GS_REC_WIN_BITS);  // only offsets that hold a k-mer (a merged bitmap comes from other ranks)
+        while (bits) {
+            const int j = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int vi = (int)((rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1));
+            if (vi < n_values) {
+                if (lds)
+                    atomicAdd(&s_cnt[vi], 1u);
+                else
+                    atomicAdd(&unique[vi], 1ULL);
+            }
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_values; i += blockDim.x)
+            if (s_cnt[i]) atomicAdd(&unique[i], (u64)s_cnt[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_rec_clear_seen_kernel(u64 *rec, int64_t n_rec) {
+    const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_rec; b += (int64_t)gridDim.x * blockDim.x) {
+        const u64 w = rec[b * GS_REC_WORDS];
+        if (w >> GS_REC_WIN_BITS) rec[b * GS_REC_WORDS] = w & M47;
     }
 }
 
@@ -1529,23 +1573,34 @@ extern "C" int gs_filter_occupancy() {
     return e == hipSuccess ? n : 0;
 }
 
+// the compact bitmap: (n_slots + 31) / 32 words for the table slots, then one word per record bucket (rec may be NULL)
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
-                                              int32_t n_values, u64 *unique, hipStream_t stream) {
+                                              int32_t n_values, u64 *unique, const u64 *rec, int64_t n_rec, hipStream_t stream) {
     int64_t n_words = (n_slots + 31) / 32;
     int grid = (int)((n_words + 255) / 256);
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(gs_unique_count_kernel, dim3(grid), dim3(256), 0, stream, table, bitmap, n_slots, vbits, n_values, unique);
+    if (rec != nullptr && n_rec > 0) {
+        grid = (int)std::min<int64_t>((n_rec + 255) / 256, 4096);
+        hipLaunchKernelGGL(gs_rec_unique_count_kernel, dim3(grid), dim3(256), 0, stream, rec, bitmap + n_words, n_rec, n_values, unique);
+    }
     return hipGetLastError();
 }
 
-extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, hipStream_t stream) {
+extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, const u64 *rec, int64_t n_rec,
+                                                hipStream_t stream) {
     hipLaunchKernelGGL(gs_bitmap_extract_kernel, dim3(4096), dim3(256), 0, stream, table, n_slots, bitmap);
+    if (rec != nullptr && n_rec > 0)
+        hipLaunchKernelGGL(gs_rec_bitmap_extract_kernel, dim3((int)std::min<int64_t>((n_rec + 255) / 256, 4096)), dim3(256), 0, stream,
+                           rec, n_rec, bitmap + (n_slots + 31) / 32);
     return hipGetLastError();
 }
 
-extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, hipStream_t stream) {
+extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, u64 *rec, int64_t n_rec, hipStream_t stream) {
     hipLaunchKernelGGL(gs_clear_seen_kernel, dim3(4096), dim3(256), 0, stream, table, n_slots);
+    if (rec != nullptr && n_rec > 0)
+        hipLaunchKernelGGL(gs_rec_clear_seen_kernel, dim3((int)std::min<int64_t>((n_rec + 255) / 256, 4096)), dim3(256), 0, stream, rec, n_rec);
     return hipGetLastError();
 }
 

@@ -94,6 +94,63 @@ GS_HD uint32_t gs_lmer_hash(uint32_t fh, uint32_t fl) {  // 15-bit planes of a 1
     return g * 0x9E3779B1u;            // odd multiplier: a bijection on 32 bits; the order is set by the well-mixed top bits
 }
 
+// Which 15-mer of a k-mer is "its" minimizer: the occurrence with the smallest RANK = order hash with the low 8 bits
+// replaced by the position (a wave finds minimum and position with one min3 chain over its LDS row), i.e. the smallest
+// hash by its top 24 bits, leftmost on a tie.  "Leftmost" depends on the strand a k-mer is read from, so a stored k-mer
+// can have two choices (the same 15-mer twice inside the k-mer, or two 15-mers whose hashes agree in 24 bits: ~1e-5 of
+// the k-mers): the builder evaluates BOTH strand views of every stored k-mer (gs_choose_minimizer on the planes and on
+// their reverse complement) and files the k-mer under each, so whatever strand a read shows, the probe's choice is one
+// the builder has seen.  Everything keyed by the minimizer (gate, record bucket) uses the EXACT canonical 15-mer of the
+// chosen occurrence (gs_min_oriented), never the truncated rank.
+GS_HD uint32_t gs_lmer_rank(uint32_t hash, uint32_t idx) { return (hash & 0xffffff00u) | idx; }
+
+GS_HD int gs_choose_minimizer(uint32_t hi, uint32_t lo, int k) {  // host / reference form of the wave's min3 chain
+    uint32_t best = 0xffffffffu;
+    for (int d = 0; d + GS_MIN_L <= k; d++) {
+        const uint32_t x = gs_lmer_rank(gs_lmer_hash((hi >> d) & 0x7fffu, (lo >> d) & 0x7fffu), (uint32_t)d);
+        best = x < best ? x : best;
+    }
+    return (int)(best & 0xffu);
+}
+
+// The chosen occurrence (offset p inside the k-mer with forward planes fhi/flo and reverse-complement planes rhi/rlo):
+// gh = order hash of its canonical 15-mer (a bijection of the 15-mer: the key of gate and record bucket), and the k-mer
+// in the orientation in which that 15-mer is the canonical one (ohi, olo), where it sits at offset (k-15) - j.
+GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rlo, int k, int p, uint32_t &gh,
+                           uint32_t &ohi, uint32_t &olo, int &j) {
+    const uint32_t M = (1u << GS_MIN_L) - 1u;
+    const uint32_t ch = (fhi >> p) & M, cl = (flo >> p) & M;
+    const uint32_t rh = gs_brev32(ch) >> (32 - GS_MIN_L);
+    const uint32_t rl = (gs_brev32(cl) >> (32 - GS_MIN_L)) ^ M;
+    const uint32_t f = (ch << GS_MIN_L) | cl, r = (rh << GS_MIN_L) | rl;
+    const bool fwd = f < r;  // a 15-mer is never its own reverse complement (odd length)
+    gh = (fwd ? f : r) * 0x9E3779B1u;
+    ohi = fwd ? fhi : rhi;
+    olo = fwd ? flo : rlo;
+    j = fwd ? (k - GS_MIN_L) - p : p;
+}
+
+// Super-k-mer records (fused kernels, k >= GS_MIN_K): the k-mers of a read that share a minimizer occurrence are ~9
+// consecutive positions, and in the store they are the substrings of ONE window of 2k-15 bases around that 15-mer.  A
+// record is one 64-byte line holding such a window in the minimizer's canonical orientation:
+//   w0 = window code-hi plane (47 bits) | seen bits  << 47      seen[j]: unique-k-mer mark of the k-mer at offset j
+//   w1 = window code-lo plane (47 bits) | valid bits << 47      valid[j]: the k-mer at offset j (bases j..j+k-1) is stored
+//   w2..w7: value indices, three per word (21 bits each; offset j in word 2 + j/3), bit 63 of EVERY word = `more`
+// bucket = gs_rec_bucket(gh).  A k-mer whose minimizer sits at offset c - j of its oriented form (c = k-15) is stored iff
+// valid[j] and its planes equal the window's bits [j, j+k).  One bucket holds one window; k-mers that lose their bucket
+// (another window of the same or of a colliding minimizer lives there) and the rare k-mers with two strand views go to
+// the ordinary table below, and the bucket's `more` bit tells a mismatching probe to look there.  The lanes of a wave
+// that share a minimizer load the same line, so a read from the store costs ~13 record lines instead of ~110 bucket
+// lines.
+#define GS_REC_WORDS 8
+#define GS_REC_WIN_BITS 47
+#define GS_REC_VAL_BITS 21
+#define GS_REC_MAX_VALUES (1 << GS_REC_VAL_BITS)
+#define GS_REC_MORE (1ULL << 63)
+#define GS_REC_SLOTS 32  // virtual slots per record bucket (hit counters, compact bitmap): 17 used
+
+GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits) { return (gh * 0x27D4EB2Fu) >> (32 - rec_bits); }
+
 // minimizer gate word (32 bits) and the two bits an entry sets in it
 GS_HD uint32_t gs_mgate_word(uint32_t m, uint32_t word_bits) { return (m * 0x85EBCA77u) >> (32 - word_bits); }
 GS_HD uint32_t gs_mgate_bits(uint32_t m) {
@@ -107,7 +164,8 @@ struct GsDbDev {
     uint64_t gate_mask;
     const uint32_t *mgate;  // minimizer gate: 2^mgate_bits 32-bit words, or nullptr
     uint32_t mgate_bits;
-    uint32_t pad0;
+    uint32_t rec_bits;      // 2^rec_bits record buckets (rec != nullptr)
+    const unsigned long long *rec;  // super-k-mer records, GS_REC_WORDS words per bucket, or nullptr
     uint32_t bucket_bits;
     uint32_t vbits;
     uint64_t bucket_mask;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 enum {
     GS_OK = 0,
@@ -75,12 +75,14 @@ typedef struct {
     int32_t n_values;
     int64_t n_entries;      /* entries handed in                                            */
     int64_t n_stored;       /* entries in the device table (reachable + with a tree node)   */
-    int64_t n_buckets;      /* 64-byte buckets of 8 slots                                   */
+    int64_t n_buckets;      /* 64-byte buckets of 8 slots (table)                           */
     int64_t table_bytes;
     int32_t max_displacement;
     int32_t value_bits;
     int64_t gate_bytes;     /* L2-resident pre-filter (0 = not built: store too large for it)  */
     int64_t mgate_bytes;    /* minimizer gate (0 = not built: k < 19)                           */
+    int64_t rec_bytes;      /* super-k-mer records (0 = not built: k < 19, partition, > 2^21 values) */
+    int64_t n_in_records;   /* stored k-mers that live in records (the others are table slots)  */
 } gs_db_info;
 
 int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,

@@ -65,7 +65,7 @@ def test_partitioned_pipeline_emulated(sdb, world, device_routing):
     n = len(off) - 1
     want, wcv, wfl = _oracle(sdb, seq, off)
     dev = torch.device("cuda")
-    stores = [ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=world, part=p)
+    stores = [ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=world, part=p, partition=True)
               for p in range(world)]
     assert sum(s.info.n_stored for s in stores) == ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values,
                                                                       sdb.parent_vi).info.n_stored
@@ -150,7 +150,7 @@ def test_partitioned_collective_path_single_rank(sdb):
         seq, off = _reads(sdb, 3000)
         n = len(off) - 1
         want, wcv, wfl = _oracle(sdb, seq, off)
-        store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=1, part=0)
+        store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=1, part=0, partition=True)
         m = ga.FastqKMerMatcher(store)
         dseq = torch.from_numpy(seq).to(dev)
         doff = torch.from_numpy(off.astype(np.int64)).to(dev)

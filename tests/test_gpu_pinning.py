@@ -142,8 +142,9 @@ def test_damaged_store_files_are_refused(tmp_path):
     store.close()
     raw = bytearray(good.read_bytes())
     ga.DeviceKMerStore.load(good).close()
-    hdr = 8 + 64 + 8 + 8 + 8 + 8  # magic | gs_db_info | bucket_bits, vbits | gate_words | mgate_words | checksum
-    assert len(raw) == hdr + info.table_bytes + info.gate_bytes + info.mgate_bytes + 16 * info.n_values
+    hdr = 8 + 80 + 8 + 8 + 8 + 8 + 8  # magic | gs_db_info | bucket_bits, vbits | gate_words | mgate_words | rec_buckets | checksum
+    assert info.rec_bytes > 0 and info.n_in_records > 0.5 * info.n_stored
+    assert len(raw) == hdr + info.table_bytes + info.gate_bytes + info.mgate_bytes + info.rec_bytes + 16 * info.n_values
 
     def refused(name, data):
         p = tmp_path / name
@@ -155,7 +156,7 @@ def test_damaged_store_files_are_refused(tmp_path):
 
     refused("short.gss", raw[:len(raw) - 4])
     refused("long.gss", raw + b"\0" * 8)
-    refused("magic.gss", b"GSSTORE4" + raw[8:])
+    refused("magic.gss", b"GSSTORE5" + raw[8:])
     flip = bytearray(raw)
     flip[hdr + info.table_bytes // 2] ^= 0x10
     assert "checksum" in refused("flip.gss", flip)
@@ -178,8 +179,17 @@ def test_damaged_store_files_are_refused(tmp_path):
     bad = bytearray(raw)
     bad[8:12] = struct.pack("<i", 40)  # k
     assert "k outside" in refused("k.gss", bad)
+    rec_at = hdr + info.table_bytes + info.gate_bytes + info.mgate_bytes
+    rfirst = next(i for i in range(rec_at, rec_at + info.rec_bytes, 64) if any(raw[i + 8:i + 16]))
     bad = bytearray(raw)
-    first = next(i for i in range(hdr, hdr + info.table_bytes, 8) if any(raw[i:i + 8]))
+    bad[rfirst + 16:rfirst + 64] = b"\xff" * 48  # every value of the record beyond n_values
+    assert "records: value" in refused("recvalue.gss", with_checksum(bad))
+    bad = bytearray(raw)
+    bad[rfirst + 7] |= 0x80  # a seen bit
+    assert "seen" in refused("recseen.gss", with_checksum(bad))
+    bad = bytearray(raw)
+    first = next((i for i in range(hdr, hdr + info.table_bytes, 8) if any(raw[i:i + 8])), None)
+    assert first is not None  # some k-mers lose their record bucket and live in the table
     slot = struct.unpack("<Q", raw[first:first + 8])[0]
     vmask = (1 << info.value_bits) - 1
     slot = (slot & ~(vmask << 1)) | (vmask << 1)  # value index beyond n_values
