@@ -350,116 +350,69 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
         distinct_min = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
     }
-    // ---- super-k-mer records (gs_layout.h): one window per bucket; the k-mers of windows that lose their bucket join
-    // the table keys
+    // ---- super-k-mer records (gs_layout.h): the k-mers of one minimizer are clustered into windows, every window gets one
+    // of its minimizer's two buckets (cuckoo placement); the k-mers of windows that find no place join the table keys
     std::vector<u64> rec;
     int rec_bits = 0;
     int64_t n_in_records = 0;
     if (want_rec && !rents.empty()) {
-        // windows per bucket before the bucket count doubles: with the power-of-two rounding 0.25 .. 0.5
-        double rload = 0.5;
-        if (const char *e = getenv("GS_REC_LOAD")) {
-            const double v = atof(e);
-            if (v > 0.01 && v <= 4.0) rload = v;
-        }
-        rec_bits = 4;
-        while (rec_bits < 29 && (double)((size_t)1 << rec_bits) * rload < distinct_min) rec_bits++;
-        const size_t n_rec = (size_t)1 << rec_bits;
-        rec.assign(n_rec * GS_REC_WORDS, 0);
         const int64_t ne = (int64_t)rents.size();
         int n_thr = (int)std::min<int64_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 32);
         if (const char *e = getenv("GS_BUILD_THREADS")) n_thr = std::max(1, std::min(64, atoi(e)));
         if (ne < 200000) n_thr = 1;
-        // counting sort by the top bits of the bucket, then every chunk is sorted and clustered on its own
-        const int cbits = std::min(rec_bits, 8), cshift = rec_bits - cbits, n_chunks = 1 << cbits;
+        // counting sort by the top bits of the minimizer hash, then every chunk is sorted and clustered on its own
+        const int cbits = 8, cshift = 32 - cbits, n_chunks = 1 << cbits;
         std::vector<int64_t> cstart((size_t)n_chunks + 1, 0);
-        for (int64_t i = 0; i < ne; i++) {
-            rents[(size_t)i].bucket = gs_rec_bucket(rents[(size_t)i].gh, (uint32_t)rec_bits);
-            cstart[(size_t)(rents[(size_t)i].bucket >> cshift) + 1]++;
-        }
+        for (int64_t i = 0; i < ne; i++) cstart[(size_t)(rents[(size_t)i].gh >> cshift) + 1]++;
         for (int c = 0; c < n_chunks; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
         std::vector<RecEntry> sorted((size_t)ne);
         {
             std::vector<int64_t> cur(cstart.begin(), cstart.end() - 1);
-            for (int64_t i = 0; i < ne; i++) sorted[(size_t)cur[(size_t)(rents[(size_t)i].bucket >> cshift)]++] = rents[(size_t)i];
+            for (int64_t i = 0; i < ne; i++) sorted[(size_t)cur[(size_t)(rents[(size_t)i].gh >> cshift)]++] = rents[(size_t)i];
         }
         std::vector<RecEntry>().swap(rents);
-        struct Lost {
-            std::vector<u64> h;
-            std::vector<int32_t> v;
-            int64_t kept = 0;
+        struct Win {
+            u64 whi, wlo, known;
+            uint32_t valid, gh;
+            int32_t val[17];  // offsets 0 .. k - 15 <= 16
         };
-        std::vector<Lost> lost((size_t)n_chunks);
-        const int c_off = k - GS_MIN_L;  // the minimizer sits at offset c_off - j of the k-mer at window offset j
-        (void)c_off;
+        std::vector<std::vector<Win>> chunk_wins((size_t)n_chunks);
         auto cluster_chunk = [&](int c) {
             RecEntry *lo = sorted.data() + cstart[(size_t)c], *hi = sorted.data() + cstart[(size_t)c + 1];
             std::sort(lo, hi, [](const RecEntry &a, const RecEntry &b) {
-                if (a.bucket != b.bucket) return a.bucket < b.bucket;
                 if (a.gh != b.gh) return a.gh < b.gh;
                 if ((a.vj & 31u) != (b.vj & 31u)) return (a.vj & 31u) < (b.vj & 31u);
                 if (a.ohi != b.ohi) return a.ohi < b.ohi;
                 return a.olo < b.olo;
             });
-            struct Win {
-                u64 whi, wlo, known;
-                uint32_t valid, gh;
-                int count;
-            };
-            std::vector<Win> wins;
-            std::vector<int> owner;  // window of every entry of the current bucket
-            Lost &L = lost[(size_t)c];
-            for (RecEntry *b0 = lo; b0 < hi;) {
-                RecEntry *b1 = b0;
-                while (b1 < hi && b1->bucket == b0->bucket) b1++;
-                wins.clear();
-                owner.assign((size_t)(b1 - b0), -1);
-                for (RecEntry *e = b0; e < b1; e++) {
+            std::vector<Win> &wins = chunk_wins[(size_t)c];
+            for (RecEntry *g0 = lo; g0 < hi;) {  // the entries of one minimizer
+                RecEntry *g1 = g0;
+                while (g1 < hi && g1->gh == g0->gh) g1++;
+                const size_t first = wins.size();
+                for (RecEntry *e = g0; e < g1; e++) {
                     const int j = (int)(e->vj & 31u);
                     const u64 eh = (u64)e->ohi << j, el = (u64)e->olo << j, km = (u64)kmask << j;
-                    int w = -1;
-                    for (size_t x = 0; x < wins.size(); x++) {
-                        const Win &W = wins[x];
-                        if (W.gh == e->gh && !((W.valid >> j) & 1u) && ((W.whi ^ eh) & W.known & km) == 0 && ((W.wlo ^ el) & W.known & km) == 0) {
-                            w = (int)x;
-                            break;
-                        }
+                    size_t w = first;
+                    for (; w < wins.size(); w++) {  // first window that agrees on every base both know and has offset j free
+                        const Win &W = wins[w];
+                        if (!((W.valid >> j) & 1u) && ((W.whi ^ eh) & W.known & km) == 0 && ((W.wlo ^ el) & W.known & km) == 0) break;
                     }
-                    if (w < 0) {
-                        wins.push_back(Win{0, 0, 0, 0u, e->gh, 0});
-                        w = (int)wins.size() - 1;
+                    if (w == wins.size()) {
+                        wins.push_back(Win{});
+                        wins.back().gh = e->gh;
                     }
-                    Win &W = wins[(size_t)w];
+                    Win &W = wins[w];
                     W.whi |= eh;
                     W.wlo |= el;
                     W.known |= km;
                     W.valid |= 1u << j;
-                    W.count++;
-                    owner[(size_t)(e - b0)] = w;
+                    W.val[j] = (int32_t)(e->vj >> 5);
                 }
-                int best = 0;
-                for (size_t x = 1; x < wins.size(); x++)
-                    if (wins[x].count > wins[(size_t)best].count) best = (int)x;
-                u64 *rp = rec.data() + (size_t)b0->bucket * GS_REC_WORDS;
-                rp[0] = wins[(size_t)best].whi;
-                rp[1] = wins[(size_t)best].wlo | ((u64)wins[(size_t)best].valid << GS_REC_WIN_BITS);
-                bool more = false;
-                for (RecEntry *e = b0; e < b1; e++) {
-                    const int j = (int)(e->vj & 31u);
-                    if (owner[(size_t)(e - b0)] == best) {
-                        rp[2 + j / 3] |= (u64)(e->vj >> 5) << (GS_REC_VAL_BITS * (j % 3));
-                        L.kept++;
-                    } else {
-                        uint32_t phi, plo;
-                        gs_rep_planes(e->ohi, e->olo, k, kmask, phi, plo);
-                        L.h.push_back(gs_mix_planes(phi, plo));
-                        L.v.push_back((int32_t)(e->vj >> 5));
-                        more = true;
-                    }
-                }
-                if (more)
-                    for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
-                b0 = b1;
+                // the fullest windows of a minimizer first: only two of them can find a bucket
+                std::stable_sort(wins.begin() + (ptrdiff_t)first, wins.end(),
+                                 [](const Win &a, const Win &b) { return __builtin_popcount(a.valid) > __builtin_popcount(b.valid); });
+                g0 = g1;
             }
         };
         if (n_thr == 1) {
@@ -473,15 +426,78 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 });
             for (auto &x : th) x.join();
         }
-        for (Lost &L : lost) {  // (in chunk order: independent of the thread count)
-            hkey.insert(hkey.end(), L.h.begin(), L.h.end());
-            hval.insert(hval.end(), L.v.begin(), L.v.end());
-            n_in_records += L.kept;
+        std::vector<RecEntry>().swap(sorted);
+        size_t n_win = 0;
+        for (auto &v : chunk_wins) n_win += v.size();
+        // windows per bucket before the bucket count doubles: with the power-of-two rounding 0.2 .. 0.4 (two-choice cuckoo
+        // placement with one window per bucket works up to 0.5)
+        double rload = 0.4;
+        if (const char *e = getenv("GS_REC_LOAD")) {
+            const double v = atof(e);
+            if (v > 0.01 && v <= 0.5) rload = v;
         }
-        for (uint32_t gh : hmore) {
-            u64 *rp = rec.data() + (size_t)gs_rec_bucket(gh, (uint32_t)rec_bits) * GS_REC_WORDS;
-            for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
+        rec_bits = 4;
+        while (rec_bits < 29 && (double)((size_t)1 << rec_bits) * rload < (double)n_win) rec_bits++;
+        const size_t n_rec = (size_t)1 << rec_bits;
+        // cuckoo placement (sequential, in chunk order: the result does not depend on the thread count)
+        std::vector<const Win *> slot(n_rec, nullptr);
+        std::vector<const Win *> homeless;
+        uint64_t rng = 0x9E3779B97F4A7C15ULL;
+        for (auto &v : chunk_wins)
+            for (const Win &W0 : v) {
+                const Win *cur = &W0;
+                uint32_t at = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 0);
+                for (int kick = 0; cur != nullptr && kick < 500; kick++) {
+                    const uint32_t b0 = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 0), b1 = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 1);
+                    if (slot[b0] == nullptr) {
+                        slot[b0] = cur;
+                        cur = nullptr;
+                    } else if (slot[b1] == nullptr) {
+                        slot[b1] = cur;
+                        cur = nullptr;
+                    } else {  // both taken: evict one of them (not the bucket we just came from) and carry it on
+                        const bool sib0 = slot[b0]->gh == cur->gh, sib1 = slot[b1]->gh == cur->gh;
+                        if (sib0 && sib1) break;  // its own sibling windows hold both buckets: no place for a third
+                        rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
+                        uint32_t victim = (rng >> 40) & 1 ? b1 : b0;
+                        if (kick > 0 && victim == at && b0 != b1) victim = victim == b0 ? b1 : b0;
+                        if (slot[victim]->gh == cur->gh) victim = victim == b0 ? b1 : b0;  // (fuller siblings stay)
+                        std::swap(cur, slot[victim]);
+                        at = victim;
+                    }
+                }
+                if (cur != nullptr) homeless.push_back(cur);
+            }
+        rec.assign(n_rec * GS_REC_WORDS, 0);
+        for (size_t b = 0; b < n_rec; b++) {
+            const Win *W = slot[b];
+            if (W == nullptr) continue;
+            u64 *rp = rec.data() + b * GS_REC_WORDS;
+            rp[0] = W->whi;
+            rp[1] = W->wlo | ((u64)W->valid << GS_REC_WIN_BITS);
+            for (uint32_t m = W->valid; m; m &= m - 1) {
+                const int j = __builtin_ctz(m);
+                rp[2 + j / 3] |= (u64)W->val[j] << (GS_REC_VAL_BITS * (j % 3));
+                n_in_records++;
+            }
         }
+        auto set_more = [&](uint32_t gh) {
+            for (int ch = 0; ch < 2; ch++) {
+                u64 *rp = rec.data() + (size_t)gs_rec_bucket(gh, (uint32_t)rec_bits, ch) * GS_REC_WORDS;
+                for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
+            }
+        };
+        for (const Win *W : homeless) {  // their k-mers become table keys, reachable through both buckets' `more` bit
+            for (uint32_t m = W->valid; m; m &= m - 1) {
+                const int j = __builtin_ctz(m);
+                uint32_t phi, plo;
+                gs_rep_planes((uint32_t)(W->whi >> j) & kmask, (uint32_t)(W->wlo >> j) & kmask, k, kmask, phi, plo);
+                hkey.push_back(gs_mix_planes(phi, plo));
+                hval.push_back(W->val[j]);
+            }
+            set_more(W->gh);
+        }
+        for (uint32_t gh : hmore) set_more(gh);
     }  // (no eligible k-mer at all: no records, every key is in the table and the kernels take the table path)
     const int64_t ns = (int64_t)hkey.size();
     const int vbits = std::max(1, bits_for((u64)n_values));

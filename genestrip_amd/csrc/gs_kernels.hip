@@ -106,6 +106,10 @@ typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 // The fused kernels look at the first half of a bucket first (two loads, four compares, half the registers) and run
 // at 8 waves per SIMD with 64 VGPRs.  Measured against whole-bucket probes at 6 waves: bench stream equal (10.26 ms),
 // miss-only stream 5.94 -> 5.56 ms, 47 M-k-mer store 16.3 -> 16.0 ms.
+// developer ablations (tools/ablate.sh): 1 = no per-read reduce, 2 = no record / table probe, 4 = no gate either
+#ifndef GS_ABLATE
+#define GS_ABLATE 0
+#endif
 #ifndef GS_HALF_BUCKETS
 #define GS_HALF_BUCKETS 1
 #endif
@@ -345,43 +349,47 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         }
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            if (act[s]) {
+            if ((GS_ABLATE & 4) == 0 && act[s]) {
                 const uint32_t bits = gs_mgate_bits(gh[s]);
                 act[s] = (db.mgate[gs_mgate_word(gh[s], db.mgate_bits)] & bits) == bits;  // no false negatives
             }
         }
-        if (db.rec != nullptr) {
-            // ---- super-k-mer records: one 16-byte load of the window planes + the 8-byte word that holds this offset's value
-            const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
-            gs_u64x2 A[2];
-            u64 V[2];
-            uint32_t rb[2];
+        if (GS_ABLATE & 6) {  // keep the values alive, look nothing up
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                rb[s] = gs_rec_bucket(gh[s], db.rec_bits);
-                if (act[s]) {
-                    const u64 *rp = db.rec + (u64)rb[s] * GS_REC_WORDS;
-                    A[s] = *reinterpret_cast<const gs_u64x2 *>(rp);
-                    V[s] = rp[2 + ((j[s] * 11) >> 5)];  // j / 3 for j <= 16
-                }
-            }
+            for (int s = 0; s < 2; s++)
+                if (act[s] && (gh[s] ^ ohi[s] ^ olo[s] ^ (uint32_t)j[s]) == 0x12345u) node[s] = 0;
+            return;
+        }
+        if (db.rec != nullptr) {
+            // ---- super-k-mer records: both candidate buckets of the minimizer at once -- per bucket one 16-byte load of
+            // the window planes + the 8-byte word that holds this offset's value
+            const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
                 if (act[s]) {
                     const int jj = j[s];
-                    const bool ok = ((uint32_t)((A[s].x & M47) >> jj) & kmask) == ohi[s] &&
-                                    ((uint32_t)((A[s].y & M47) >> jj) & kmask) == olo[s] && ((A[s].y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
-                    if (ok) {
-                        node[s] = (int)((V[s] >> (GS_REC_VAL_BITS * (jj - 3 * ((jj * 11) >> 5)))) & (GS_REC_MAX_VALUES - 1));
-                        if (mk.count_unique && ((A[s].x >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
-                            atomicOr(const_cast<u64 *>(db.rec) + (u64)rb[s] * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
+                    const int jw = (jj * 11) >> 5;  // j / 3 for j <= 16
+                    const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
+                    const u64 *r0 = db.rec + (u64)b0 * GS_REC_WORDS, *r1 = db.rec + (u64)b1 * GS_REC_WORDS;
+                    const gs_u64x2 A0 = *reinterpret_cast<const gs_u64x2 *>(r0), A1 = *reinterpret_cast<const gs_u64x2 *>(r1);
+                    const u64 V0 = r0[2 + jw], V1 = r1[2 + jw];
+                    const bool ok0 = ((uint32_t)((A0.x & M47) >> jj) & kmask) == ohi[s] && ((uint32_t)((A0.y & M47) >> jj) & kmask) == olo[s] &&
+                                     ((A0.y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
+                    const bool ok1 = ((uint32_t)((A1.x & M47) >> jj) & kmask) == ohi[s] && ((uint32_t)((A1.y & M47) >> jj) & kmask) == olo[s] &&
+                                     ((A1.y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
+                    if (ok0 || ok1) {  // (an eligible k-mer is filed in exactly one window)
+                        const u64 V = ok0 ? V0 : V1, Ax = ok0 ? A0.x : A1.x;
+                        const uint32_t rb = ok0 ? b0 : b1;
+                        node[s] = (int)((V >> (GS_REC_VAL_BITS * (jj - 3 * jw))) & (GS_REC_MAX_VALUES - 1));
+                        if (mk.count_unique && ((Ax >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
+                            atomicOr(const_cast<u64 *>(db.rec) + (u64)rb * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
                         if (mk.hit_counts != nullptr)
-                            atomicAdd(mk.hit_counts + ((u64)(bmask + 1u) * GS_SLOTS_PER_BUCKET + (u64)rb[s] * GS_REC_SLOTS + (u64)jj), 1u);
+                            atomicAdd(mk.hit_counts + ((u64)(bmask + 1u) * GS_SLOTS_PER_BUCKET + (u64)rb * GS_REC_SLOTS + (u64)jj), 1u);
                     }
-                    pending = !ok && (V[s] & GS_REC_MORE) != 0;
+                    pending = !(ok0 || ok1) && ((V0 | V1) & GS_REC_MORE) != 0;
                 }
-                // a k-mer that lost its record bucket to another window (or has two strand views) lives in the table
+                // a k-mer whose window found no bucket (or that has two strand views) lives in the table
                 if (__ballot(pending) != 0) {
                     const u64 h = gs_kmer_hash(ohi[s], olo[s], k, kmask);
                     gs_lookup_rest<true>(db, (uint32_t)h & bmask, (h >> db.bucket_bits) << shift_rem, vmask2, pending, node[s], mk);
@@ -510,7 +518,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // (read, tax id) pair once (:434-439) and mergeReadTaxidPath (:568-586) is idempotent for a node it
             // has already seen (paths only ever move down the tree), so repeats need no work.  The per-node vote
             // count of the read (incCount, :380-388) is the number of positions holding that node.
-            if ((hit0 | hit1) != 0 || carry_last >= 0) {
+            if ((GS_ABLATE & 1) == 0 && ((hit0 | hit1) != 0 || carry_last >= 0)) {
                 int prev[2];
                 {
                     const int up0 = __shfl_up(node[0], 1);
@@ -615,7 +623,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             }
         }
 
-        if (found) {
+        if ((GS_ABLATE & 1) == 0 && found) {
             out_flags = GS_F_FOUND | GS_F_RETURNED;
             // tail flush (:455-473): the last contig if it is a hit contig
             if (carry_last >= 0) {

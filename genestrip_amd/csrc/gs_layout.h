@@ -136,12 +136,13 @@ GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rl
 //   w0 = window code-hi plane (47 bits) | seen bits  << 47      seen[j]: unique-k-mer mark of the k-mer at offset j
 //   w1 = window code-lo plane (47 bits) | valid bits << 47      valid[j]: the k-mer at offset j (bases j..j+k-1) is stored
 //   w2..w7: value indices, three per word (21 bits each; offset j in word 2 + j/3), bit 63 of EVERY word = `more`
-// bucket = gs_rec_bucket(gh).  A k-mer whose minimizer sits at offset c - j of its oriented form (c = k-15) is stored iff
-// valid[j] and its planes equal the window's bits [j, j+k).  One bucket holds one window; k-mers that lose their bucket
-// (another window of the same or of a colliding minimizer lives there) and the rare k-mers with two strand views go to
-// the ordinary table below, and the bucket's `more` bit tells a mismatching probe to look there.  The lanes of a wave
-// that share a minimizer load the same line, so a read from the store costs ~13 record lines instead of ~110 bucket
-// lines.
+// A k-mer whose minimizer sits at offset c - j of its oriented form (c = k-15) is stored iff valid[j] and its planes equal
+// the window's bits [j, j+k).  One bucket holds one window, and a window lives in one of the TWO buckets of its minimizer,
+// gs_rec_bucket(gh, 0 / 1) (cuckoo placement by the builder: at <= 0.4 windows per bucket practically every window finds
+// a place); a probe loads both lines at once, so there is no dependent second access.  What cannot be placed -- a third
+// window of the same minimizer, the rare k-mers with two strand views -- goes to the ordinary table below, and the
+// `more` bit of both buckets tells a mismatching probe to look there.  The lanes of a wave that share a minimizer load
+// the same lines, so a read from the store costs ~26 record lines instead of ~110 bucket lines.
 #define GS_REC_WORDS 8
 #define GS_REC_WIN_BITS 47
 #define GS_REC_VAL_BITS 21
@@ -149,7 +150,9 @@ GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rl
 #define GS_REC_MORE (1ULL << 63)
 #define GS_REC_SLOTS 32  // virtual slots per record bucket (hit counters, compact bitmap): 17 used
 
-GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits) { return (gh * 0x27D4EB2Fu) >> (32 - rec_bits); }
+GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits, int choice) {
+    return (gh * (choice ? 0x165667B1u : 0x27D4EB2Fu)) >> (32 - rec_bits);
+}
 
 // minimizer gate word (32 bits) and the two bits an entry sets in it
 GS_HD uint32_t gs_mgate_word(uint32_t m, uint32_t word_bits) { return (m * 0x85EBCA77u) >> (32 - word_bits); }
