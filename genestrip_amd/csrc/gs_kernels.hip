@@ -284,15 +284,25 @@ __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, 
 // minimizer of the k-mers at positions base + 64 s + lane through the wave's LDS row: rank of every 15-mer of
 // positions base .. base+143, then per lane the minimum over its k-14 positions (one min3 chain; the rank carries the
 // row index, so the minimum is the position as well).  Returns the offset of the chosen 15-mer inside the lane's k-mer.
+#define GS_ROW 160  // one LDS row: 128 + 16 positions, padded
+
+// wave_g: two rows of GS_ROW words per wave -- the ranks, and behind them (canonical 15-mer << 1 | strand) of every position,
+// which the lane that picks a position reads back instead of recomputing it.  cf[s] = that word for the lane's minimizer.
 template <int KC>
 __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u64 (&Blo)[3], const uint32_t (&fhi)[2],
-                                                   const uint32_t (&flo)[2], int k, int lane, uint32_t *wave_g, int (&p)[2]) {
+                                                   const uint32_t (&flo)[2], int k, int lane, uint32_t *wave_g, int (&p)[2],
+                                                   uint32_t (&cf)[2]) {
 #pragma unroll
-    for (int s = 0; s < 2; s++)
-        wave_g[64 * s + lane] = gs_lmer_rank(gs_lmer_hash(fhi[s] & 0x7fffu, flo[s] & 0x7fffu), (uint32_t)(64 * s + lane));
-    if (lane < 16)
-        wave_g[128 + lane] = gs_lmer_rank(gs_lmer_hash((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu),
-                                          (uint32_t)(128 + lane));
+    for (int s = 0; s < 2; s++) {
+        const uint32_t c = gs_lmer_canon(fhi[s] & 0x7fffu, flo[s] & 0x7fffu);
+        wave_g[64 * s + lane] = gs_lmer_rank(gs_canon_hash(c >> 1), (uint32_t)(64 * s + lane));
+        wave_g[GS_ROW + 64 * s + lane] = c;
+    }
+    if (lane < 16) {
+        const uint32_t c = gs_lmer_canon((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
+        wave_g[128 + lane] = gs_lmer_rank(gs_canon_hash(c >> 1), (uint32_t)(128 + lane));
+        wave_g[GS_ROW + 128 + lane] = c;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -307,9 +317,11 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
                 mn = g < mn ? g : mn;
             }
         }
-        p[s] = (int)(mn & 0xffu) - (64 * s + lane);
+        const int idx = (int)(mn & 0xffu);
+        cf[s] = wave_g[GS_ROW + idx];
+        p[s] = idx - (64 * s + lane);
     }
-    __builtin_amdgcn_wave_barrier();  // the row is rewritten by the next iteration / read
+    __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next iteration / read
 }
 
 template <int KC>
@@ -338,14 +350,15 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
     if (db.mgate != nullptr) {
         // minimizer gate: lanes that share a minimizer read the same gate word -> one request
         int mp[2];
-        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp);
+        uint32_t cf[2];
+        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
         uint32_t gh[2], ohi[2], olo[2];
         int j[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const uint32_t rhi = __brev(fhi[s]) >> (32 - k);
             const uint32_t rlo = (__brev(flo[s]) >> (32 - k)) ^ kmask;
-            gs_min_oriented(fhi[s], flo[s], rhi, rlo, k, mp[s], gh[s], ohi[s], olo[s], j[s]);
+            gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi, rlo, k, mp[s], gh[s], ohi[s], olo[s], j[s]);
         }
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -455,6 +468,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         int carry_last = GS_NODE_NONE;  // node of the last position of the previous iteration
         int cur_start = 0;
         int dviA = -1, dviB = -1, dcntA = 0, dcntB = 0, nd = 0;  // !LONG: distinct hit nodes (cap 128 >= #contigs)
+        int one_vi = -1, one_cnt = 0;                              // !LONG: the first of them, wave-uniform
         constexpr int NP = WIDE ? 2 : 1;
         int path[NP], ptin[NP], ptout[NP], used = 0;            // candidate paths: path i in lane i & 63 of set i >> 6
 #pragma unroll
@@ -549,6 +563,33 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     cur_start = base + 63 - __builtin_clzll(chg0);
                 // distinct hit nodes of this iteration, in order of first appearance
                 u64 m0 = hit0, m1 = hit1;
+                if (!LONG) {
+                    // The first node is the only one in ~90 % of the reads that hit a store of species-specific k-mers:
+                    // its id and count stay in scalar registers (one_vi, one_cnt), and the candidate-path state is set
+                    // up only if a second node follows.
+                    const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
+                    one_vi = j < 64 ? gs_readlane(node[0], j) : gs_readlane(node[1], j - 64);
+                    const u64 e0 = __ballot(node[0] == one_vi), e1 = __ballot(node[1] == one_vi);
+                    one_cnt = __popcll(e0) + __popcll(e1);
+                    m0 &= ~e0;
+                    m1 &= ~e1;
+                    nd = 1;
+                    if (lane == 0) st.add(one_vi, GS_S_READS_1KMER, 1);  // first k-mer of this tax id in the read (:434-439)
+                    if ((m0 | m1) != 0) {
+                        if (lane == 0) {
+                            dviA = one_vi;
+                            dcntA = one_cnt;
+                        }
+                        if (P.classify) {  // mergeReadTaxidPath into the empty list (max_paths >= 1)
+                            if (lane == 0) {
+                                path[0] = one_vi;
+                                ptin[0] = st.tin[one_vi];
+                                ptout[0] = st.tout[one_vi];
+                            }
+                            used = 1;
+                        }
+                    }
+                }
                 while ((m0 | m1) != 0) {
                     const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
                     const int nvj = j < 64 ? gs_readlane(node[0], j) : gs_readlane(node[1], j - 64);
@@ -636,6 +677,14 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 const double m = P.max_read_tax_err;
                 const bool disabled = m >= 0 && ((m >= 1 && (double)tax_err > m) || ((double)tax_err > m * (double)max));
                 if (!disabled) {
+                    int cn = -1, first_node = -1, best = 0;
+                    // one distinct node v with c positions: the only candidate path is v, its sum is c, and the threshold
+                    // mapping (:488-492) keeps v if c >= threshold and finds nothing above it otherwise
+                    const bool single = !LONG && nd == 1;
+                    if (single) {
+                        best = one_cnt;
+                        cn = (P.threshold <= 1 || one_cnt >= P.threshold) ? one_vi : -1;
+                    } else {
                     // sumCounts per candidate path (SmallTaxTree.java:184-193): lanes = paths
                     int sum[NP];
 #pragma unroll
@@ -656,7 +705,6 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         }
                     }
                     // max + ties exactly as the in-place scan (:476-487); tie order = path order
-                    int best = 0;
                     u64 tie_mask[NP];
 #pragma unroll
                     for (int h = 0; h < NP; h++) tie_mask[h] = 0;
@@ -711,7 +759,6 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                             cand[h] = mapped;
                         }
                     }
-                    int cn = -1, first_node = -1;
                     {
                         bool first = true;
 #pragma unroll
@@ -730,12 +777,13 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                             }
                         }
                     }
+                    }  // !single
                     out_class = cn;
                     if (cn < 0) {
                         out_flags &= ~GS_F_RETURNED;  // "return false" (:497-500)
                     } else {
                         int read_kmers = best;
-                        if (P.threshold > 1) {  // sumCounts(readTaxIdNode[0]) after the promotion (:506-507)
+                        if (P.threshold > 1 && !single) {  // sumCounts(readTaxIdNode[0]) after the promotion (:506-507)
                             read_kmers = 0;
                             if (LONG) {
                                 for (int x = first_node; x >= 0; x = st.parent[x])
@@ -841,7 +889,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
-    __shared__ uint32_t s_g[GS_BLOCK / 64][160];  // 15-mer order hashes of the wave's current 144 positions
+    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];  // 15-mer order hashes of the wave's current 144 positions
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
@@ -882,7 +930,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
-    __shared__ uint32_t s_g[GS_BLOCK / 64][160];
+    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];
     const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
     int32_t *cnt = tag + nv;
@@ -919,7 +967,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
 
 template <int KC>
 __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
-    __shared__ uint32_t s_g[GS_BLOCK / 64][160];  // 15-mer order hashes of the wave's current 128 + 16 positions
+    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];  // 15-mer order hashes of the wave's current 128 + 16 positions
     const int lane = gs_lane();
     uint32_t *wave_g = s_g[threadIdx.x >> 6];
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
@@ -977,13 +1025,12 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
                 // the store's minimizer gate (which covers the keys of every partition) as in gs_probe_planes: k-mers
                 // it rules out are not routed at all
                 int mp[2];
-                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp);
+                uint32_t cf[2];
+                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
-                        uint32_t gh, ohi, olo;
-                        int j;
-                        gs_min_oriented(fhi[s], flo[s], 0u, 0u, k, mp[s], gh, ohi, olo, j);  // only the minimizer's hash is needed
+                        const uint32_t gh = gs_canon_hash(cf[s] >> 1);  // only the minimizer's hash is needed
                         const uint32_t bits = gs_mgate_bits(gh);
                         if ((P.mgate[gs_mgate_word(gh, P.mgate_bits)] & bits) != bits) key[s] = GS_KEY_MISS;
                     }
@@ -1132,7 +1179,7 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
 // ---------------------------------------------------------------------------------------------------
 template <bool WRITE>
 __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
-    __shared__ uint32_t s_g[GS_BLOCK / 64][160];
+    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];
     const GsDbDev &db = P.db;
     const int lane = gs_lane();
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);

@@ -85,14 +85,18 @@ GS_HD uint64_t gs_gate_bits(uint64_t h) { return gs_gate_field_bits((uint32_t)(h
 #define GS_MIN_L 15
 #define GS_MIN_K 19
 
-GS_HD uint32_t gs_lmer_hash(uint32_t fh, uint32_t fl) {  // 15-bit planes of a 15-mer (base 0 in bit 0) -> order hash
+// 15-bit planes of a 15-mer (base 0 in bit 0) -> (canonical 15-mer << 1) | (1 if the given strand is the canonical one).
+// A 15-mer is never its own reverse complement (odd length).
+GS_HD uint32_t gs_lmer_canon(uint32_t fh, uint32_t fl) {
     const uint32_t M = (1u << GS_MIN_L) - 1u;
     const uint32_t rh = gs_brev32(fh) >> (32 - GS_MIN_L);
     const uint32_t rl = (gs_brev32(fl) >> (32 - GS_MIN_L)) ^ M;
     const uint32_t f = (fh << GS_MIN_L) | fl, r = (rh << GS_MIN_L) | rl;
-    const uint32_t g = f < r ? f : r;  // canonical 15-mer (30 bits)
-    return g * 0x9E3779B1u;            // odd multiplier: a bijection on 32 bits; the order is set by the well-mixed top bits
+    return f < r ? (f << 1) | 1u : r << 1;
 }
+// order hash of a canonical 15-mer (30 bits): odd multiplier = a bijection on 32 bits, the order is set by the well-mixed top bits
+GS_HD uint32_t gs_canon_hash(uint32_t g) { return g * 0x9E3779B1u; }
+GS_HD uint32_t gs_lmer_hash(uint32_t fh, uint32_t fl) { return gs_canon_hash(gs_lmer_canon(fh, fl) >> 1); }
 
 // Which 15-mer of a k-mer is "its" minimizer: the occurrence with the smallest RANK = order hash with the low 8 bits
 // replaced by the position (a wave finds minimum and position with one min3 chain over its LDS row), i.e. the smallest
@@ -116,18 +120,19 @@ GS_HD int gs_choose_minimizer(uint32_t hi, uint32_t lo, int k) {  // host / refe
 // The chosen occurrence (offset p inside the k-mer with forward planes fhi/flo and reverse-complement planes rhi/rlo):
 // gh = order hash of its canonical 15-mer (a bijection of the 15-mer: the key of gate and record bucket), and the k-mer
 // in the orientation in which that 15-mer is the canonical one (ohi, olo), where it sits at offset (k-15) - j.
-GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rlo, int k, int p, uint32_t &gh,
-                           uint32_t &ohi, uint32_t &olo, int &j) {
-    const uint32_t M = (1u << GS_MIN_L) - 1u;
-    const uint32_t ch = (fhi >> p) & M, cl = (flo >> p) & M;
-    const uint32_t rh = gs_brev32(ch) >> (32 - GS_MIN_L);
-    const uint32_t rl = (gs_brev32(cl) >> (32 - GS_MIN_L)) ^ M;
-    const uint32_t f = (ch << GS_MIN_L) | cl, r = (rh << GS_MIN_L) | rl;
-    const bool fwd = f < r;  // a 15-mer is never its own reverse complement (odd length)
-    gh = (fwd ? f : r) * 0x9E3779B1u;
+// cf = gs_lmer_canon of the chosen 15-mer (the wave reads it back from its LDS row instead of recomputing it)
+GS_HD void gs_min_oriented_cf(uint32_t cf, uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rlo, int k, int p, uint32_t &gh,
+                              uint32_t &ohi, uint32_t &olo, int &j) {
+    const bool fwd = (cf & 1u) != 0;
+    gh = gs_canon_hash(cf >> 1);
     ohi = fwd ? fhi : rhi;
     olo = fwd ? flo : rlo;
     j = fwd ? (k - GS_MIN_L) - p : p;
+}
+GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rlo, int k, int p, uint32_t &gh,
+                           uint32_t &ohi, uint32_t &olo, int &j) {
+    const uint32_t M = (1u << GS_MIN_L) - 1u;
+    gs_min_oriented_cf(gs_lmer_canon((fhi >> p) & M, (flo >> p) & M), fhi, flo, rhi, rlo, k, p, gh, ohi, olo, j);
 }
 
 // Super-k-mer records (fused kernels, k >= GS_MIN_K): the k-mers of a read that share a minimizer occurrence are ~9
