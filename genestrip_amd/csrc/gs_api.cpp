@@ -1607,6 +1607,124 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
     return GS_OK;
 }
 
+// ---- merge of runs that live in one process (gs_merge.hip)
+extern "C" hipError_t gs_launch_merge_i64(void *dst, const void *src, int64_t n, int op, hipStream_t stream);
+extern "C" hipError_t gs_launch_merge_f64(void *dst, const void *src, int64_t n, hipStream_t stream);
+extern "C" int gs_rccl_merge_leaders(int n_dev, const int *devices, void *const *sums, void *const *maxk, void *const *dsums,
+                                     void *const *bitmap, void *const *gather, int64_t n_sums, int64_t n_max, int64_t n_dsums,
+                                     int64_t n_words, const hipStream_t *streams, const char **msg);
+
+extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
+    if (!runs || n_runs < 1) return fail(GS_E_INVALID, "bad argument");
+    for (int i = 0; i < n_runs; i++) {
+        if (!runs[i]) return fail(GS_E_INVALID, "run is NULL");
+        for (int j = 0; j < i; j++)
+            if (runs[j] == runs[i]) return fail(GS_E_INVALID, "the same run twice");
+    }
+    const gs_run *r0 = runs[0];
+    const gs_db_info &i0 = r0->db->info;
+    for (int i = 1; i < n_runs; i++) {  // the stores must be replicas: the bitmap is indexed by table slot / record offset
+        const gs_db_info &x = runs[i]->db->info;
+        if (x.k != i0.k || x.n_values != i0.n_values || x.n_stored != i0.n_stored || x.n_buckets != i0.n_buckets ||
+            x.rec_bytes != i0.rec_bytes || x.n_in_records != i0.n_in_records || runs[i]->bitmap_words != r0->bitmap_words)
+            return fail(GS_E_INVALID, "gs_match_merge needs runs on replicas of one store");
+        if (runs[i]->cfg.count_unique != r0->cfg.count_unique) return fail(GS_E_INVALID, "runs differ in count_unique");
+    }
+    const size_t nv = (size_t)i0.n_values;
+    const bool uniq = r0->cfg.count_unique != 0;
+    const int64_t words = r0->bitmap_words;
+    // every run's compact bitmap up to date, every stream drained
+    for (int i = 0; i < n_runs; i++) {
+        gs_run *run = runs[i];
+        HIP_TRY(hipSetDevice(run->db->device));
+        if (uniq && !run->bitmap_merged)
+            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec, run->stream));
+        HIP_TRY(hipStreamSynchronize(run->stream));
+    }
+    // ---- stage A: the runs of one device into that device's first run (its leader)
+    std::vector<int> devices;
+    std::vector<gs_run *> leader;
+    for (int i = 0; i < n_runs; i++) {
+        gs_run *run = runs[i];
+        size_t d = 0;
+        while (d < devices.size() && devices[d] != run->db->device) d++;
+        if (d == devices.size()) {
+            devices.push_back(run->db->device);
+            leader.push_back(run);
+            continue;
+        }
+        gs_run *L = leader[d];
+        HIP_TRY(hipSetDevice(L->db->device));
+        HIP_TRY(gs_launch_merge_i64(L->d_sums, run->d_sums, (int64_t)(nv * GS_N_SUMS), 0, L->stream));
+        HIP_TRY(gs_launch_merge_i64(L->d_max, run->d_max, (int64_t)nv, 1, L->stream));
+        HIP_TRY(gs_launch_merge_f64(L->d_dsums, run->d_dsums, (int64_t)(nv * GS_N_DCOLS), L->stream));
+        if (uniq) HIP_TRY(gs_launch_bitmap_or(L->d_bitmap, run->d_bitmap, words, 1, L->stream));
+    }
+    // ---- stage B: the leaders among each other over RCCL (GS_MERGE_FORCE_RCCL=1: also for a single device, as a rehearsal)
+    const int n_dev = (int)devices.size();
+    const char *force = getenv("GS_MERGE_FORCE_RCCL");
+    if (n_dev > 1 || (force && atoi(force) != 0)) {
+        std::vector<void *> ps((size_t)n_dev), pm((size_t)n_dev), pd((size_t)n_dev), pb((size_t)n_dev), pg((size_t)n_dev, nullptr);
+        std::vector<hipStream_t> st((size_t)n_dev);
+        int rc = GS_OK;
+        for (int d = 0; d < n_dev && rc == GS_OK; d++) {
+            gs_run *L = leader[(size_t)d];
+            ps[(size_t)d] = L->d_sums;
+            pm[(size_t)d] = L->d_max;
+            pd[(size_t)d] = L->d_dsums;
+            pb[(size_t)d] = L->d_bitmap;
+            st[(size_t)d] = L->stream;
+            if (uniq) {
+                hipSetDevice(L->db->device);
+                if (hipMalloc(&pg[(size_t)d], sizeof(uint32_t) * (size_t)words * (size_t)n_dev) != hipSuccess)
+                    rc = fail(GS_E_NOMEM, "merge scratch");
+            }
+        }
+        const char *msg = "";
+        if (rc == GS_OK) {
+            const int m = gs_rccl_merge_leaders(n_dev, devices.data(), ps.data(), pm.data(), pd.data(), pb.data(), pg.data(),
+                                                (int64_t)(nv * GS_N_SUMS), (int64_t)nv, (int64_t)(nv * GS_N_DCOLS), uniq ? words : 0,
+                                                st.data(), &msg);
+            if (m != 0) rc = fail(m == -4 ? GS_E_UNSUPPORTED : GS_E_HIP, msg);
+        }
+        for (int d = 0; d < n_dev && rc == GS_OK; d++) {
+            gs_run *L = leader[(size_t)d];
+            hipSetDevice(L->db->device);
+            if (uniq && gs_launch_bitmap_or(L->d_bitmap, (const uint32_t *)pg[(size_t)d], words, n_dev, L->stream) != hipSuccess)
+                rc = fail(GS_E_HIP, "bitmap OR");
+            if (rc == GS_OK && hipStreamSynchronize(L->stream) != hipSuccess) rc = fail(GS_E_HIP, "merge sync");
+        }
+        for (int d = 0; d < n_dev; d++)
+            if (pg[(size_t)d]) {
+                hipSetDevice(devices[(size_t)d]);
+                hipFree(pg[(size_t)d]);
+            }
+        if (rc != GS_OK) return rc;
+    }
+    // ---- stage C: the global state back into every run of the device
+    for (int i = 0; i < n_runs; i++) {
+        gs_run *run = runs[i];
+        size_t d = 0;
+        while (devices[d] != run->db->device) d++;
+        gs_run *L = leader[d];
+        HIP_TRY(hipSetDevice(L->db->device));
+        if (run != L) {
+            HIP_TRY(hipMemcpyAsync(run->d_sums, L->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(hipMemcpyAsync(run->d_max, L->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToDevice, L->stream));
+            HIP_TRY(hipMemcpyAsync(run->d_dsums, L->d_dsums, sizeof(double) * nv * GS_N_DCOLS, hipMemcpyDeviceToDevice, L->stream));
+            if (uniq) HIP_TRY(hipMemcpyAsync(run->d_bitmap, L->d_bitmap, sizeof(uint32_t) * (size_t)words, hipMemcpyDeviceToDevice, L->stream));
+        }
+        run->bitmap_merged = uniq;  // gs_match_finish counts from the merged bitmap
+    }
+    for (gs_run *L : leader) {
+        HIP_TRY(hipSetDevice(L->db->device));
+        HIP_TRY(hipStreamSynchronize(L->stream));
+    }
+    return GS_OK;
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+}
+
 // ---- DB-partitioned mode: encode / probe / reduce as separate steps (all pointers are device pointers)
 extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
                                const uint64_t *pos_off, uint64_t *keys) {

@@ -800,6 +800,9 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
 
 }  // namespace
 
+extern "C" int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
+                                  int64_t *reads_of_file, gs_host_totals *totals);
+
 extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
                                    const gs_host_match_opts *opts, int64_t *table, double *dtable,
                                    gs_host_totals *totals) try {
@@ -854,6 +857,77 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
+
+// runMatcher over the files of a sample on SEVERAL devices of this process: dbs[d] = a replica of the store on device d
+// (the same arrays through gs_db_create, or the same store file).  File i goes to replica i % n_dbs; every replica has its
+// own run and its own worker thread (reader pool, device text path, as gs_host_match_into); read numbers are
+// (file << 32 | read), so that the max-contig tie-break keeps the file order; the runs are merged by gs_match_merge
+// (kernels on one device, RCCL between devices) and finished once.  No per-read outputs (they would interleave).
+extern "C" int gs_host_match_files_multi(gs_db *const *dbs, int n_dbs, const gs_match_cfg *cfg, const char *const *paths,
+                                         int n_paths, int64_t *table, double *dtable, gs_host_totals *totals) try {
+    if (!dbs || n_dbs < 1 || !cfg || !paths || n_paths < 0 || !table) return hfail(GS_E_INVALID, "NULL argument");
+    if (n_paths > GS_HOST_MAX_FILE_INDEX) return hfail(GS_E_UNSUPPORTED, "at most 256 files per call");
+    const double t_start = now_s();
+    std::vector<gs_run *> runs((size_t)n_dbs, nullptr);
+    int err = GS_OK;
+    for (int d = 0; d < n_dbs && !err; d++) {
+        if (!dbs[d]) err = hfail(GS_E_INVALID, "a store is NULL");
+        if (!err) err = gs_match_begin(&runs[(size_t)d], dbs[d], cfg);
+    }
+    std::vector<std::vector<int32_t>> mine((size_t)n_dbs);
+    for (int i = 0; i < n_paths; i++) mine[(size_t)(i % n_dbs)].push_back(i);
+    std::vector<int64_t> reads_of_file((size_t)n_paths, 0);
+    std::vector<gs_host_totals> tot((size_t)n_dbs);
+    std::vector<int> rcs((size_t)n_dbs, GS_OK);
+    std::vector<std::string> msgs((size_t)n_dbs);
+    if (!err) {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_dbs; d++)
+            th.emplace_back([&, d] {
+                const std::vector<int32_t> &idx = mine[(size_t)d];
+                if (idx.empty()) return;
+                std::vector<const char *> p;
+                for (int32_t i : idx) p.push_back(paths[i]);
+                std::vector<int64_t> rof(idx.size(), 0);
+                rcs[(size_t)d] = gs_host_match_into(runs[(size_t)d], dbs[d], p.data(), (int)p.size(), idx.data(), rof.data(), &tot[(size_t)d]);
+                if (rcs[(size_t)d]) msgs[(size_t)d] = gs_host_last_error();  // (the message is per thread)
+                for (size_t x = 0; x < idx.size(); x++) reads_of_file[(size_t)idx[x]] = rof[x];
+            });
+        for (auto &t : th) t.join();
+        for (int d = 0; d < n_dbs && !err; d++)
+            if (rcs[(size_t)d]) err = hfail(rcs[(size_t)d], msgs[(size_t)d]);
+    }
+    if (!err) err = gs_match_merge(runs.data(), n_dbs);
+    if (!err) err = gs_match_finish(runs[0], table, dtable);
+    if (!err) {  // (file << 32 | read in file) -> running read number over the files in order
+        gs_db_info info{};
+        gs_db_get_info(dbs[0], &info);
+        std::vector<int64_t> before((size_t)n_paths + 1, 0);
+        for (int i = 0; i < n_paths; i++) before[(size_t)i + 1] = before[(size_t)i] + reads_of_file[(size_t)i];
+        for (int32_t v = 0; v < info.n_values; v++) {
+            int64_t &x = table[(size_t)v * GS_N_COLS + GS_C_MAX_CONTIG_READ_NO];
+            if (x >= 0) x = before[(size_t)(x >> 32)] + (x & 0xffffffffLL);
+        }
+    }
+    for (gs_run *r : runs)
+        if (r) gs_match_destroy(r);
+    if (totals) {
+        *totals = gs_host_totals{};
+        for (const gs_host_totals &t : tot) {
+            totals->reads += t.reads;
+            totals->kmers += t.kmers;
+            totals->bps += t.bps;
+            totals->seconds_parse += t.seconds_parse;
+            totals->seconds_gpu += t.seconds_gpu;
+        }
+        totals->seconds_total = now_s() - t_start;
+    }
+    return err;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
 
 // The same, into a run the caller began and will finish: for one-process-per-GPU runs that share the files of a sample
 // (genestrip_amd/distributed.py: match_files_sharded) -- every process takes some of the files, merges the device state

@@ -48,6 +48,7 @@ def lib():
         "gs_fastq_totals": (ci, [vp, vp, vp, vp]), "gs_fastq_close": (ci, [vp]),
         "gs_host_match_files": (ci, [vp, vp, vp, ci, vp, vp, vp, vp]),
         "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
+        "gs_host_match_files_multi": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
         "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, ci, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
@@ -134,6 +135,20 @@ def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=N
     tot = Totals()
     _check(lib().gs_host_match_files(store.h, C.byref(cfg), parr, len(paths), C.byref(opts),
                                      table.ctypes.data_as(C.c_void_p), dtable.ctypes.data_as(C.c_void_p), C.byref(tot)))
+    return table, dtable, tot
+
+
+def match_files_multi(stores, paths, config=None):
+    """gs_host_match_files_multi: the files of a sample over several store replicas (one per device) of this process"""
+    cfg = (config or _b.MatchConfig())._c()
+    parr = _cstr_array(list(paths))
+    darr = (C.c_void_p * len(stores))(*[s.h for s in stores])
+    nv = stores[0].n_values
+    table = np.zeros((nv, _b.N_COLS), dtype=np.int64)
+    dtable = np.zeros((nv, _b.N_DCOLS), dtype=np.float64)
+    tot = Totals()
+    _check(lib().gs_host_match_files_multi(darr, len(stores), C.byref(cfg), parr, len(paths),
+                                           table.ctypes.data_as(C.c_void_p), dtable.ctypes.data_as(C.c_void_p), C.byref(tot)))
     return table, dtable, tot
 
 

@@ -211,6 +211,15 @@ int gs_match_device_state(gs_run *run, void **sums, void **max_keys, void **dsum
 /* bitmap |= OR of n_parts device bitmaps laid out back to back at `parts` (each bitmap_words long) */
 int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
 
+/* The same merge for runs that live in ONE process -- what a JVM host does with one gs_run per GPU of the node (the
+ * reference is a single process: C/fastq/AbstractFastqReader.java:85-104; it has no counterpart of torch.distributed).
+ * Every run must work on a replica of the same store (same arrays through gs_db_create / the same store file).  Runs on
+ * the same device are reduced by kernels, the devices among each other by RCCL collectives over xGMI (all-reduce SUM of
+ * `sums` / `dsums`, all-reduce MAX of `max_keys`, all-gather + OR of the unique bitmaps; librccl is loaded on first
+ * use).  Afterwards EVERY run holds the global state: gs_match_finish on any of them returns the table a single run
+ * over all the reads would have produced (give the runs disjoint read numbers: first_read_no).  Synchronous. */
+int gs_match_merge(gs_run *const *runs, int n_runs);
+
 /* ---------------------------------------------------------------------------------------------------
  * DB-partitioned match (BASELINE.json configs[4]): the store is split over the GPUs of a node by
  * key hash (gs_db_create_part keeps the keys with (h >> 40) % n_parts == part, h = the library's mixed key), reads stay

@@ -80,6 +80,13 @@ int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *p
 int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const int32_t *file_index,
                        int64_t *reads_of_file, gs_host_totals *totals);
 
+/* runMatcher over the files of a sample on several devices of THIS process (what a JVM host with 8 GPUs calls):
+ * dbs[d] = a replica of the store on device d; file i goes to replica i % n_dbs, every replica runs on a thread of its
+ * own (as gs_host_match_into), the runs are merged with gs_match_merge (RCCL between devices) and finished once.  The
+ * table equals the one gs_host_match_files returns for the same files in the same order.  No per-read outputs. */
+int gs_host_match_files_multi(gs_db *const *dbs, int n_dbs, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
+                              int64_t *table, double *dtable, gs_host_totals *totals);
+
 /* ---- runFilter: accepted reads -> filtered_path, the rest -> rest_path (either may be NULL); with_probs as above ---- */
 int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const char *const *paths,
                          int n_paths, const char *filtered_path, const char *rest_path, int with_probs,

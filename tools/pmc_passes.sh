@@ -1,6 +1,6 @@
 #!/bin/bash
-# PMC passes over the match kernel (developer tool; run on the GPU box from the repo root):
-#   tools/pmc_passes.sh <tag> [python script + args ...]
+# PMC passes over one kernel (developer tool; run on the GPU box from the repo root):
+#   [GS_PMC_KERNEL=gs_filter_kernel] tools/pmc_passes.sh <tag> [python script + args ...]
 # One rocprofv3 --pmc run per counter group (never combined with trace domains), then a per-kernel summary
 # (mean over the full-size launches) in gpurun_out/pmc_<tag>.csv.
 set -u
@@ -22,4 +22,4 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
     timeout -k 10 240 rocprofv3 --pmc $grp --output-format csv -d "$out/g$i" -o run -- python3 "$@" > "$out/g$i.log" 2>&1 || echo "pass $i failed" >> "$out/fail.log"
     echo "pass $i done: $grp"
 done
-python3 tools/pmc_summary.py "$out"
+python3 tools/pmc_summary.py "$out" "${GS_PMC_KERNEL:-gs_match_kernel}"
