@@ -29,7 +29,7 @@ BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
 # every symbol include/gsgpu.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = (
     "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
-    "gs_match_merge", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
+    "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
@@ -109,7 +109,7 @@ def lib():
         "gs_match_submit_async": (ci, [vp, vp, vp, i64, i64, vp, vp, vp]), "gs_match_wait": (ci, [vp, i64]),
         "gs_match_sync": (ci, [vp]), "gs_match_finish": (ci, [vp, vp, vp]), "gs_match_reset": (ci, [vp]),
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
-        "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_merge": (ci, [vp, ci]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
+        "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_merge": (ci, [vp, ci]), "gs_match_max_contig_reads": (ci, [vp, vp]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
@@ -413,6 +413,12 @@ class FastqKMerMatcher:
 
     def reset(self):
         _check(lib().gs_match_reset(self.h))
+
+    def max_contig_reads(self):
+        """per value index: the read number that holds the longest contig so far (-1: none); synchronises"""
+        out = np.zeros(self.store.n_values, dtype=np.int64)
+        _check(lib().gs_match_max_contig_reads(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def device_state(self):
         """raw device pointers of the accumulators: dict(sums, max_keys, dsums, bitmap, bitmap_words)"""

@@ -1556,6 +1556,22 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     return GS_OK;
 }
 
+extern "C" int gs_match_max_contig_reads(gs_run *run, int64_t *read_no) {
+    if (!run || !read_no) return fail(GS_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    const size_t nv = (size_t)run->db->info.n_values;
+    std::vector<int64_t> maxk(nv);
+    HIP_TRY(hipMemcpyAsync(maxk.data(), run->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    int rc = collect_events(run);
+    if (rc) return rc;
+    for (size_t v = 0; v < nv; v++) {
+        const u64 key = (u64)maxk[v];
+        read_no[v] = key ? (int64_t)(((1ULL << 40) - 1) - (key & ((1ULL << 40) - 1))) : -1;
+    }
+    return GS_OK;
+}
+
 extern "C" int gs_match_reset(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));

@@ -187,6 +187,12 @@ int gs_pinned_free(void *p);
 /* table: n_values x GS_N_COLS int64 ; dtable (may be NULL): n_values x GS_N_DCOLS double (sums of doubles
  * accumulate in device order: not bit-reproducible, as with threads > 0 in the reference).  Host pointers. */
 int gs_match_finish(gs_run *run, int64_t *table, double *dtable);
+/* The reference copies the read's descriptor whenever a contig beats the current maximum of its tax id
+ * (CountsPerTaxid.maxContigDescriptor, FastqKMerMatcher.java:401-407).  A host that cannot keep the descriptors of all
+ * reads asks after every batch: read_no[n_values] (host) = read number that currently holds the maximum (-1: none).  A
+ * maximum only ever moves to a LATER batch's read by beating it, so the descriptor a host copies when the answer falls
+ * into the batch it just submitted is, at the end, the one gs_match_finish reports.  Synchronises. */
+int gs_match_max_contig_reads(gs_run *run, int64_t *read_no);
 int gs_match_reset(gs_run *run); /* same matcher, next key: clears stats + unique bitmap */
 int gs_match_destroy(gs_run *run);
 

@@ -1,6 +1,7 @@
 /*
  * gsgpu_jni.c -- JNI shim between org.metagene.genestrip.gpu.GsGpuNative and the C ABI (include/gsgpu.h).
- * SOURCE ONLY: not compiled in the build container (no JDK / jni.h).  Build on a host with a JDK:
+ * Not built in the build container (no JDK / jni.h); tests/test_java_glue_cpu.py syntax-checks it against a minimal
+ * stand-in for jni.h (tests/native/jni_stub/jni.h: declarations only).  Build on a host with a JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
  *       -o libgsgpu_jni.so gsgpu_jni.c -L../../genestrip_amd -lgsgpu
  */
@@ -37,9 +38,25 @@ JNIEXPORT jlong JNICALL JNAME(dbCreate)(JNIEnv *env, jclass c, jint device, jint
 
 JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db_destroy((gs_db *)(intptr_t)db); }
 
+JNIEXPORT void JNICALL JNAME(dbSave)(JNIEnv *env, jclass c, jlong db, jstring path) {
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    int rc = gs_db_save((gs_db *)(intptr_t)db, p);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT jlong JNICALL JNAME(dbLoad)(JNIEnv *env, jclass c, jint device, jstring path) {
+    gs_db *db = NULL;
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    int rc = gs_db_load(&db, device, p);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)db;
+}
+
 JNIEXPORT jlong JNICALL JNAME(matchBegin)(JNIEnv *env, jclass c, jlong db, jboolean classify, jboolean countUnique,
-                                          jint maxPaths, jint threshold, jdouble taxErr, jdouble classErr) {
-    gs_match_cfg cfg = {classify ? 1 : 0, countUnique ? 1 : 0, maxPaths, threshold, taxErr, classErr, 0, 0 /* maxKMerResCounts */};
+                                          jint maxPaths, jint threshold, jdouble taxErr, jdouble classErr, jint maxKmerResCounts) {
+    gs_match_cfg cfg = {classify ? 1 : 0, countUnique ? 1 : 0, maxPaths, threshold, taxErr, classErr, 0, maxKmerResCounts};
     gs_run *run = NULL;
     int rc = gs_match_begin(&run, (gs_db *)(intptr_t)db, &cfg);
     if (rc) throw_gs(env, rc);
@@ -107,6 +124,40 @@ JNIEXPORT jobject JNICALL JNAME(pinnedAlloc)(JNIEnv *env, jclass c, jlong bytes)
 
 JNIEXPORT void JNICALL JNAME(pinnedFree)(JNIEnv *env, jclass c, jobject buf) {
     int rc = gs_pinned_free(addr(env, buf));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchSegments)(JNIEnv *env, jclass c, jlong run, jobject seq, jobject offsets, jlong nReads,
+                                            jobject segOff) {
+    int rc = gs_match_segments((gs_run *)(intptr_t)run, (const uint8_t *)addr(env, seq), (const uint64_t *)addr(env, offsets),
+                               nReads, GS_MEM_HOST, (uint64_t *)addr(env, segOff));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchSegmentsFetch)(JNIEnv *env, jclass c, jlong run, jobject codes, jobject starts) {
+    int rc = gs_match_segments_fetch((gs_run *)(intptr_t)run, (int32_t *)addr(env, codes), (int32_t *)addr(env, starts));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchMaxContigReads)(JNIEnv *env, jclass c, jlong run, jobject readNo) {
+    int rc = gs_match_max_contig_reads((gs_run *)(intptr_t)run, (int64_t *)addr(env, readNo));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(matchMaxCounts)(JNIEnv *env, jclass c, jlong run, jobject out) {
+    int rc = gs_match_max_counts((gs_run *)(intptr_t)run, (int16_t *)addr(env, out));
+    if (rc) throw_gs(env, rc);
+}
+
+/* the runs of this JVM (one per GPU) into a global state held by each (RCCL between devices) */
+JNIEXPORT void JNICALL JNAME(matchMerge)(JNIEnv *env, jclass c, jlongArray runs) {
+    jsize n = (*env)->GetArrayLength(env, runs);
+    jlong *h = (*env)->GetLongArrayElements(env, runs, NULL);
+    gs_run *r[64];
+    int rc = n > 64 ? GS_E_INVALID : GS_OK;
+    for (jsize i = 0; i < n && rc == GS_OK; i++) r[i] = (gs_run *)(intptr_t)h[i];
+    if (rc == GS_OK) rc = gs_match_merge(r, (int)n);
+    (*env)->ReleaseLongArrayElements(env, runs, h, JNI_ABORT);
     if (rc) throw_gs(env, rc);
 }
 

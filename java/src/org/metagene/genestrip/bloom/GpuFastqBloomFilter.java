@@ -1,26 +1,33 @@
 /*
  * GPU-backed drop-in for FastqBloomFilter (reference: core/src/main/java/org/metagene/genestrip/bloom/
- * FastqBloomFilter.java).  SOURCE ONLY -- not compiled in the build container (no JDK); see INTEGRATION.md.
+ * FastqBloomFilter.java).  SOURCE ONLY -- not compiled in the build container (no JDK); tools/check_java_glue.py checks
+ * every reference member used here against the reference's sources.  See INTEGRATION.md.
  *
  * It lives in the reference's bloom package because the index filter's state is held in protected fields
  * (AbstractKMerBloomFilter.java:52-62: bits, bitVector, hashes, hashFactors; LargeBitVector.bits/largeBits are public).
  * The device copy replicates the bit array and the hash factors exactly, so false positives are identical.
  *
- * Hook: FilterGoal.makeFile (goals/FilterGoal.java:80-108) constructs the FastqBloomFilter; a subclass of FilterGoal
- * constructs this class instead.  Reads are batched in nextEntry(); the accept flags come back per batch and the
- * reads are rewritten in input order exactly like the reference's nextEntry (FastqBloomFilter.java:92-105).
+ * Hook: GpuFilterGoal.makeFile constructs this class where FilterGoal.makeFile (goals/FilterGoal.java:80-108) constructs
+ * the FastqBloomFilter.  Reads are batched in nextEntry(); the accept flags come back per batch and the reads are
+ * rewritten in input order exactly like the reference's nextEntry (FastqBloomFilter.java:92-105).  The two output
+ * streams of the reference are private, so runFilter is overridden with streams of its own.
  */
 package org.metagene.genestrip.bloom;
 
+import java.io.File;
 import java.io.IOException;
+import java.io.OutputStream;
 import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 import java.util.ArrayList;
+import java.util.Arrays;
 import java.util.List;
 
 import org.metagene.genestrip.DefaultExecutionContext;
 import org.metagene.genestrip.ExecutionContext;
 import org.metagene.genestrip.gpu.GsGpuNative;
+import org.metagene.genestrip.io.StreamProvider;
+import org.metagene.genestrip.io.StreamingResourceStream;
 
 public class GpuFastqBloomFilter extends FastqBloomFilter {
 	private static final int BATCH_READS = 1 << 20;
@@ -35,6 +42,7 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 	private final ByteBuffer accept = ByteBuffer.allocateDirect(BATCH_READS);
 	// descriptor / read / quality copies of the batch, for the rewrite in input order
 	private final List<byte[][]> pending = new ArrayList<>();
+	private OutputStream accepted, rejected;
 
 	public GpuFastqBloomFilter(int k, AbstractKMerBloomFilter filter, int minPosCount, double positiveRatio,
 			int initialReadSize, int maxQueueSize, ExecutionContext bundle, boolean withProbs, int device) {
@@ -43,11 +51,27 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 		this.kk = k;
 		this.minPos = minPosCount;
 		this.ratio = positiveRatio;
-		long[] words = filter.bitVector.bits; // small variant; largeBits is handed over segment by segment
+		if (filter.bitVector.isLarge()) {
+			throw new UnsupportedOperationException("index filters beyond 2^31 words: hand largeBits over segment by segment");
+		}
+		long[] words = filter.bitVector.bits;
 		ByteBuffer w = ByteBuffer.allocateDirect(8 * words.length).order(ByteOrder.nativeOrder());
 		w.asLongBuffer().put(words);
-		int kind = filter instanceof XORKMerBloomFilter ? 0 : 1; // GS_BLOOM_XOR / GS_BLOOM_MURMUR
+		int kind = filter instanceof XORKMerBloomFilter ? GsGpuNative.BLOOM_XOR : GsGpuNative.BLOOM_MURMUR;
 		bloom = GsGpuNative.bloomCreate(device, kind, filter.bits, filter.hashes, filter.hashFactors, w, words.length);
+	}
+
+	@Override
+	public void runFilter(StreamingResourceStream fastqs, File filteredFile, File restFile) throws IOException {
+		try (OutputStream a = filteredFile != null ? StreamProvider.getOutputStreamForFile(filteredFile) : null;
+				OutputStream r = restFile != null ? StreamProvider.getOutputStreamForFile(restFile) : null) {
+			accepted = a;
+			rejected = r;
+			processFastqStreams(fastqs);
+			flush();
+		}
+		accepted = null;
+		rejected = null;
 	}
 
 	@Override
@@ -61,13 +85,13 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 		}
 		seq.put(readStruct.read, 0, readStruct.readSize);
 		offsets.putLong(seq.position());
-		pending.add(new byte[][] { java.util.Arrays.copyOf(readStruct.readDescriptor, readStruct.readDescriptorSize),
-				java.util.Arrays.copyOf(readStruct.read, readStruct.readSize),
+		pending.add(new byte[][] { Arrays.copyOf(readStruct.readDescriptor, readStruct.readDescriptorSize),
+				Arrays.copyOf(readStruct.read, readStruct.readSize),
 				readStruct.readProbs == null || readStruct.readProbsSize < 0 ? null
-						: java.util.Arrays.copyOf(readStruct.readProbs, readStruct.readProbsSize) });
+						: Arrays.copyOf(readStruct.readProbs, readStruct.readProbsSize) });
 	}
 
-	/** submit the batch, then write every read to `indexed` or `notIndexed` in input order */
+	/** submit the batch, then write every read to the accepted or the rejected stream in input order */
 	public void flush() throws IOException {
 		if (pending.isEmpty()) {
 			return;
@@ -80,8 +104,8 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 		seq.clear();
 	}
 
-	private void writeRecord(byte[][] rec, boolean accepted) throws IOException {
-		java.io.OutputStream out = accepted ? indexed : notIndexed;
+	private void writeRecord(byte[][] rec, boolean ok) throws IOException {
+		OutputStream out = ok ? accepted : rejected;
 		if (out == null) {
 			return;
 		}
@@ -99,6 +123,7 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 			}
 		}
 		out.write('\n');
+		updateWriteStats();
 	}
 
 	public void close() {

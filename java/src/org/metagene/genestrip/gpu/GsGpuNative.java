@@ -1,6 +1,7 @@
 /*
  * Reference-side binding of include/gsgpu.h.  SOURCE ONLY: the build container has no JDK (no javac, no jni.h),
- * so this file and java/jni/gsgpu_jni.c are not compiled or tested here; see INTEGRATION.md.
+ * so this file and java/jni/gsgpu_jni.c are not compiled here; tools/check_java_glue.py checks every use of a reference
+ * member in java/src against the reference's sources instead (see INTEGRATION.md).
  *
  * One static native method per C entry point.  Handles travel as long; batches as direct ByteBuffers
  * (address + length are taken with GetDirectBufferAddress, no copies on the Java side).
@@ -21,16 +22,21 @@ public final class GsGpuNative {
 	/** gs_device_count */
 	public static native int deviceCount();
 
-	/** gs_db_create: kmers = n_entries x int64 (ascending, reference encoding), valueIdx = n_entries x int32,
-	 *  parentVi = n_values x int32 (-1 root, -2 no node) or null. Returns the gs_db handle. */
+	/** gs_db_create: kmers = n_entries x int64 in KMerStore.visit order (reference encoding), valueIdx = n_entries x
+	 *  int32, parentVi = n_values x int32 (-1 root, -2 no node) or null.  Returns the gs_db handle. */
 	public static native long dbCreate(int device, int k, long nEntries, ByteBuffer kmers, ByteBuffer valueIdx,
 			int nValues, ByteBuffer parentVi);
+
+	/** gs_db_save / gs_db_load: the native image of the device store */
+	public static native void dbSave(long db, String path);
+
+	public static native long dbLoad(int device, String path);
 
 	public static native void dbDestroy(long db);
 
 	/** gs_match_begin */
 	public static native long matchBegin(long db, boolean classify, boolean countUnique, int maxPaths, int threshold,
-			double maxReadTaxErr, double maxReadClassErr);
+			double maxReadTaxErr, double maxReadClassErr, int maxKmerResCounts);
 
 	/** gs_match_submit with GS_MEM_HOST: seq = concatenated read bytes, offsets = (nReads+1) x uint64,
 	 *  classVi = nReads x int32 (or null), flags = nReads x uint8 (or null). */
@@ -64,6 +70,21 @@ public final class GsGpuNative {
 
 	public static native void pinnedFree(ByteBuffer buf);
 
+	/** gs_match_segments with GS_MEM_HOST: the Kraken-style runs of the reads of a batch; segOff = (nReads+1) x uint64 */
+	public static native void matchSegments(long run, ByteBuffer seq, ByteBuffer offsets, long nReads, ByteBuffer segOff);
+
+	/** gs_match_segments_fetch: codes / starts = n_segments x int32 (n_segments = segOff[nReads]) */
+	public static native void matchSegmentsFetch(long run, ByteBuffer codes, ByteBuffer starts);
+
+	/** gs_match_max_contig_reads: readNo = n_values x int64 */
+	public static native void matchMaxContigReads(long run, ByteBuffer readNo);
+
+	/** gs_match_max_counts: out = (n_values + 1) x maxKmerResCounts int16 */
+	public static native void matchMaxCounts(long run, ByteBuffer out);
+
+	/** gs_match_merge: the runs of this process (one per GPU) into a global state held by each */
+	public static native void matchMerge(long[] runs);
+
 	/** gs_match_finish: table = n_values x GS_N_COLS int64, dtable = n_values x GS_N_DCOLS double. */
 	public static native void matchFinish(long run, ByteBuffer table, ByteBuffer dtable);
 
@@ -87,4 +108,5 @@ public final class GsGpuNative {
 			C_MAX_CONTIG_READ_NO = 9, N_COLS = 10;
 	public static final int D_ERR_SUM = 0, D_ERR_SQ_SUM = 1, D_CLASS_ERR_SUM = 2, D_CLASS_ERR_SQ_SUM = 3, N_DCOLS = 4;
 	public static final int F_FOUND = 1, F_RETURNED = 2, F_COUNTED = 4;
+	public static final int BLOOM_XOR = 0, BLOOM_MURMUR = 1, BLOOM_BLOCKED = 2;
 }

@@ -1,6 +1,7 @@
 /*
  * GPU-backed drop-in for FastqKMerMatcher (reference: core/src/main/java/org/metagene/genestrip/match/
- * FastqKMerMatcher.java).  SOURCE ONLY -- not compiled in the build container (no JDK); see INTEGRATION.md.
+ * FastqKMerMatcher.java).  SOURCE ONLY -- not compiled in the build container (no JDK); tools/check_java_glue.py checks
+ * every reference member used here against the reference's sources.  See INTEGRATION.md.
  *
  * It lives in the reference's own package because it fills the protected CountsPerTaxid fields
  * (CountsPerTaxid.java:127-159) and the protected statsIndex array (FastqKMerMatcher.java:76).
@@ -8,19 +9,24 @@
  * How it hooks in (all seams are the reference's own virtual methods):
  *   - the parser stays the reference's (AbstractFastqReader.doReadFastq); with a zero-consumer execution context it
  *     calls nextEntry -> matchRead(entry, 0) on the producer thread (AbstractFastqReader.java:350-352);
- *   - matchRead() only appends the read to a direct-buffer batch; a full batch goes to gs_match_submit;
+ *   - matchRead() only appends the read to a direct-buffer batch; a full batch goes to gs_match_submit, and the
+ *     per-read outcome (class, flags, Kraken-style runs) drives the same writeback afterMatch does
+ *     (FastqKMerMatcher.java:304-315), in input order;
  *   - processFastqStreams() flushes the last batch and turns the device table into CountsPerTaxid objects before
  *     runMatcher() collects them (FastqKMerMatcher.java:199-204);
- *   - unique k-mer counts come from the device bitmap, so runMatcher() is called without a KMerUniqueCounterBits and
- *     the counts are patched into the result afterwards (FastqKMerMatcher.java:207-213).
+ *   - unique k-mer counts come from the device, so runMatcher() is called without a KMerUniqueCounterBits and the
+ *     counts are patched into the result afterwards (FastqKMerMatcher.java:207-213).
  */
 package org.metagene.genestrip.match;
 
 import java.io.File;
 import java.io.IOException;
 import java.io.InputStream;
+import java.io.OutputStream;
 import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
+import java.nio.charset.StandardCharsets;
+import java.util.Arrays;
 
 import org.metagene.genestrip.DefaultExecutionContext;
 import org.metagene.genestrip.ExecutionContext;
@@ -34,20 +40,31 @@ import org.metagene.genestrip.tax.SmallTaxTree.SmallTaxIdNode;
 public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	private static final int BATCH_READS = 1 << 20;
 	private static final int BATCH_BYTES = 256 << 20;
+	private static final long UPLOAD_SLICE = 1L << 26; // entries per direct-buffer slice of the store hand-over
 
 	private final long db;
 	private final long run;
 	private final int nValues;
+	private final boolean keepQualities;
 	private final SmallTaxIdNode[] nodeOfValue; // value index -> tree node (null: value without node)
+	private final byte[][] taxidBytes;          // value index -> tax id as bytes (Kraken-style lines)
 
 	private final ByteBuffer seq = direct(BATCH_BYTES);
-	private final ByteBuffer offsets = direct(8 * (BATCH_READS + 1));
-	private final ByteBuffer classVi = direct(4 * BATCH_READS);
+	private final ByteBuffer offsets = direct(8L * (BATCH_READS + 1));
+	private final ByteBuffer classVi = direct(4L * BATCH_READS);
 	private final ByteBuffer flags = direct(BATCH_READS);
+	private final ByteBuffer segOff = direct(8L * (BATCH_READS + 1));
+	private final ByteBuffer maxReadNo;
+	private ByteBuffer segCodes = direct(4L << 20), segStarts = direct(4L << 20);
+	// descriptors (and qualities, if they are written) of the batch, for the writeback after the submit
+	private byte[] descs = new byte[64 << 20], quals = new byte[0];
+	private final int[] descOff = new int[BATCH_READS + 1], qualOff = new int[BATCH_READS + 1];
 	private int batchReads;
 	private long batchFirstReadNo;
 	private long globalReadNo; // file-order read number over all files of this runMatcher call
 	private long[] uniqueCounts;
+	private short[][] maxCounts;
+	private final byte[][] maxContigDescriptor; // per value index: descriptor of the read that holds the longest contig
 
 	public GpuFastqKMerMatcher(KMerStore<SmallTaxIdNode> kmerStore, int initialReadSize, int maxQueueSize,
 			ExecutionContext bundle, boolean withProbs, int maxKmerResCounts, SmallTaxTree taxTree, int maxPaths,
@@ -59,32 +76,47 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 				maxKmerResCounts, taxTree, maxPaths, maxReadTaxErrorCount, maxReadClassErrorCount, writeAll, threshold,
 				dbMD5);
 		nValues = kmerStore.getNValues();
+		keepQualities = withProbs;
 		nodeOfValue = new SmallTaxIdNode[nValues];
+		taxidBytes = new byte[nValues][];
+		maxContigDescriptor = new byte[nValues][];
+		maxReadNo = direct(8L * nValues);
 		db = upload(kmerStore, taxTree, device);
 		run = GsGpuNative.matchBegin(db, taxTree != null, true, maxPaths, threshold, maxReadTaxErrorCount,
-				maxReadClassErrorCount);
+				maxReadClassErrorCount, maxKmerResCounts);
 	}
 
-	private static ByteBuffer direct(int bytes) {
-		return ByteBuffer.allocateDirect(bytes).order(ByteOrder.nativeOrder());
+	private static ByteBuffer direct(long bytes) {
+		if (bytes > Integer.MAX_VALUE - 8) {
+			throw new IllegalArgumentException("direct buffer of " + bytes + " bytes");
+		}
+		return ByteBuffer.allocateDirect((int) bytes).order(ByteOrder.nativeOrder());
 	}
 
-	/** KMerStore.visit (KMerSortedArray.java:426-439) yields (kmer, valueIndex) in ascending kmer order. */
+	/**
+	 * KMerStore.visit yields (kmer, valueIndex, pos) for positions 0 .. entries-1: ascending k-mers for the
+	 * KMerSortedArray (KMerSortedArray.java:426-439), bucket by bucket for the RadixKMerStore
+	 * (RadixKMerStore.java:714-729); gs_db_create takes either order.  Stores beyond one direct buffer are handed over
+	 * through two file-backed mappings instead (not shown: FileChannel.map in slices of UPLOAD_SLICE entries).
+	 */
 	private long upload(KMerStore<SmallTaxIdNode> store, SmallTaxTree tree, int device) {
 		long n = store.getEntries();
-		// for stores beyond 2^27 entries the buffers would be filled and handed over in slices (not shown)
-		ByteBuffer kmers = direct((int) (8 * n));
-		ByteBuffer vidx = direct((int) (4 * n));
+		if (n > UPLOAD_SLICE * 4) {
+			throw new UnsupportedOperationException("store of " + n + " k-mers: hand it over through mapped slices");
+		}
+		ByteBuffer kmers = direct(8L * n);
+		ByteBuffer vidx = direct(4L * n);
 		store.visit((s, kmer, index, pos) -> {
 			kmers.putLong(kmer);
 			vidx.putInt(index);
 		});
 		for (int v = 0; v < nValues; v++) {
 			nodeOfValue[v] = store.getValueForIndex(v);
+			taxidBytes[v] = nodeOfValue[v] == null ? null : nodeOfValue[v].getTaxId().getBytes(StandardCharsets.UTF_8);
 		}
 		ByteBuffer parent = null;
 		if (tree != null) {
-			parent = direct(4 * nValues);
+			parent = direct(4L * nValues);
 			for (int v = 0; v < nValues; v++) {
 				SmallTaxIdNode node = nodeOfValue[v];
 				// every tree node has a store index (Database.initStoreIndices, Database.java:107-128)
@@ -100,75 +132,191 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		GsGpuNative.matchReset(run); // stats + unique bitmap start cleared per key (FastqKMerMatcher.java:192-193)
 		globalReadNo = 0;
 		uniqueCounts = null;
+		maxCounts = null;
+		Arrays.fill(maxContigDescriptor, null);
+		// the base class opens `indexed` / `out`, runs processFastqStreams (overridden below) and collects statsIndex
 		MatchingResult res = super.runMatcher(fastqs, filteredFile, krakenOutStyleFile, null);
-		for (CountsPerTaxid stats : res.getTaxid2Stats().values()) {
-			int vi = kmerStore.getIndexForValue(taxTreeNode(stats.getTaxid()));
-			stats.uniqueKmers = uniqueCounter == null || vi < 0 ? -1 : uniqueCounts[vi];
-		}
-		return res;
-	}
-
-	private SmallTaxIdNode taxTreeNode(String taxid) {
-		for (SmallTaxIdNode n : nodeOfValue) {
-			if (n != null && taxid.equals(n.getTaxId())) {
-				return n;
+		for (int vi = 0; vi < nValues; vi++) {
+			CountsPerTaxid stats = statsIndex[vi];
+			if (stats != null) {
+				stats.uniqueKmers = uniqueCounter == null ? -1 : uniqueCounts[vi];
+				if (maxCounts != null) {
+					stats.maxKMerCounts = maxCounts[vi];
+				}
 			}
 		}
-		return null;
+		return res;
 	}
 
 	@Override
 	public void processFastqStreams(StreamingResourceStream fastqs) throws IOException {
 		super.processFastqStreams(fastqs);
+		flush();
 		fillStatsFromDevice();
 	}
 
 	@Override
 	protected void readFastq(InputStream inputStream, boolean fasta) throws IOException {
 		super.readFastq(inputStream, fasta);
-		flush(); // per-file read numbers restart (AbstractFastqReader.java:226-228); keep batches inside one file
+		flush(); // the writeback of a file's last reads belongs before the next file starts
 	}
 
 	/** Called by the (final) nextEntry for every parsed read; only batches the read. */
 	@Override
 	protected boolean matchRead(final MatcherReadEntry entry, final int index) {
-		if (batchReads == BATCH_READS || seq.remaining() < entry.readSize) {
-			flush();
+		final boolean outputs = indexed != null || out != null;
+		if (batchReads == BATCH_READS || seq.remaining() < entry.readSize
+				|| descOff[batchReads] + entry.readDescriptorSize > descs.length) {
+			try {
+				flush();
+			} catch (IOException e) {
+				throw new RuntimeException(e);
+			}
 		}
 		if (batchReads == 0) {
 			batchFirstReadNo = globalReadNo;
 			offsets.clear();
 			offsets.putLong(0);
+			descOff[0] = 0;
+			qualOff[0] = 0;
 		}
 		seq.put(entry.read, 0, entry.readSize);
 		offsets.putLong(seq.position());
+		// descriptors are kept for every batch: the longest contig of a tax id may turn up in any read
+		System.arraycopy(entry.readDescriptor, 0, descs, descOff[batchReads], entry.readDescriptorSize);
+		descOff[batchReads + 1] = descOff[batchReads] + entry.readDescriptorSize;
+		int q = qualOff[batchReads];
+		if (outputs && keepQualities && entry.readProbs != null && entry.readProbsSize >= 0) {
+			if (q + entry.readProbsSize > quals.length) {
+				quals = Arrays.copyOf(quals, Math.max(2 * quals.length, q + entry.readProbsSize + (1 << 20)));
+			}
+			System.arraycopy(entry.readProbs, 0, quals, q, entry.readProbsSize);
+			q += entry.readProbsSize;
+		}
+		qualOff[batchReads + 1] = q;
 		batchReads++;
 		globalReadNo++;
-		return false; // the per-read outcome arrives with the batch
+		return false; // the per-read outcome arrives with the batch: afterMatch below has nothing to do per read
 	}
 
 	@Override
 	protected void afterMatch(MatcherReadEntry myEntry, boolean found) throws IOException {
-		// filtered-FASTQ / Kraken-style writeback is driven from flush() with the per-read class + flags of the
-		// batch (classVi, flags); it needs the descriptors and qualities of the batch kept beside `seq` (omitted
-		// here: this sketch covers the CSV path, which is the bit-exact contract).
+		// the writeback happens per batch in flush(): it needs the outcome of the device
 	}
 
-	private void flush() {
+	private void flush() throws IOException {
 		if (batchReads == 0) {
 			return;
 		}
 		GsGpuNative.matchSubmit(run, seq, offsets, batchReads, batchFirstReadNo, classVi, flags);
+		if (out != null) {
+			GsGpuNative.matchSegments(run, seq, offsets, batchReads, segOff);
+			long nSeg = segOff.getLong(8 * batchReads);
+			if (4 * nSeg > segCodes.capacity()) {
+				segCodes = direct(8 * nSeg);
+				segStarts = direct(8 * nSeg);
+			}
+			GsGpuNative.matchSegmentsFetch(run, segCodes, segStarts);
+		}
+		// maxContigDescriptor (FastqKMerMatcher.java:401-407): the read that holds a tax id's longest contig right now
+		GsGpuNative.matchMaxContigReads(run, maxReadNo);
+		for (int vi = 0; vi < nValues; vi++) {
+			long r = maxReadNo.getLong(8 * vi) - batchFirstReadNo;
+			if (r >= 0 && r < batchReads) {
+				int i = (int) r;
+				int end = indexOfBlank(descs, descOff[i] + 1, descOff[i + 1]);
+				maxContigDescriptor[vi] = Arrays.copyOfRange(descs, descOff[i] + 1, end); // chars after '@' up to the first blank
+			}
+		}
+		for (int i = 0; i < batchReads; i++) {
+			int f = flags.get(i);
+			int cls = classVi.getInt(4 * i);
+			if ((f & GsGpuNative.F_RETURNED) != 0 && indexed != null) {
+				writeRead(indexed, i); // rewriteInput(myEntry, indexed) of afterMatch
+				updateWriteStats();
+			}
+			if (out != null && (writeAll || cls >= 0)) {
+				writeKrakenLine(out, i, cls);
+			}
+		}
 		seq.clear();
 		batchReads = 0;
 	}
 
+	private static int indexOfBlank(byte[] a, int from, int to) {
+		for (int i = from; i < to; i++) {
+			if (a[i] == ' ') {
+				return i;
+			}
+		}
+		return to;
+	}
+
+	/** ReadEntry.write (AbstractFastqReader.java:570-584) for read i of the batch */
+	private void writeRead(OutputStream o, int i) throws IOException {
+		int s0 = (int) offsets.getLong(8 * i), s1 = (int) offsets.getLong(8 * (i + 1));
+		byte[] line = new byte[s1 - s0];
+		o.write(descs, descOff[i], descOff[i + 1] - descOff[i]);
+		o.write('\n');
+		for (int j = 0; j < line.length; j++) {
+			line[j] = seq.get(s0 + j);
+		}
+		o.write(line);
+		o.write('\n');
+		o.write('+');
+		o.write('\n');
+		if (qualOff[i + 1] > qualOff[i]) {
+			o.write(quals, qualOff[i], qualOff[i + 1] - qualOff[i]);
+		} else {
+			Arrays.fill(line, (byte) '~');
+			o.write(line);
+		}
+		o.write('\n');
+	}
+
+	/** MatcherReadEntry.writeMatchDetails (FastqKMerMatcher.java:723-756) from the device's runs of read i */
+	private void writeKrakenLine(OutputStream o, int i, int cls) throws IOException {
+		long s0 = segOff.getLong(8 * i), s1 = segOff.getLong(8 * (i + 1));
+		if (s1 == s0) {
+			return; // no k-mer position: the reference has no buffer for this read
+		}
+		int len = (int) (offsets.getLong(8 * (i + 1)) - offsets.getLong(8 * i));
+		int max = len - k + 1;
+		StringBuilder sb = new StringBuilder();
+		sb.append(cls >= 0 ? 'C' : 'U').append('\t');
+		int end = indexOfBlank(descs, descOff[i] + 1, descOff[i + 1]);
+		sb.append(new String(descs, descOff[i] + 1, end - descOff[i] - 1, StandardCharsets.ISO_8859_1)).append('\t');
+		sb.append(cls >= 0 ? new String(taxidBytes[cls], StandardCharsets.UTF_8) : "0").append('\t').append(len).append('\t');
+		for (long s = s0; s < s1; s++) {
+			int code = segCodes.getInt((int) (4 * s));
+			int start = segStarts.getInt((int) (4 * s));
+			int stop = s + 1 < s1 ? segStarts.getInt((int) (4 * (s + 1))) : max;
+			if (s > s0) {
+				sb.append(' ');
+			}
+			sb.append(code >= 0 ? new String(taxidBytes[code], StandardCharsets.UTF_8) : code == -1 ? "0" : "A");
+			sb.append(':').append(stop - start);
+		}
+		sb.append('\n');
+		o.write(sb.toString().getBytes(StandardCharsets.ISO_8859_1));
+	}
+
 	/** device table -> CountsPerTaxid objects in statsIndex (what matchRead would have accumulated). */
 	private void fillStatsFromDevice() {
-		ByteBuffer table = direct(8 * GsGpuNative.N_COLS * nValues);
-		ByteBuffer dtable = direct(8 * GsGpuNative.N_DCOLS * nValues);
+		ByteBuffer table = direct(8L * GsGpuNative.N_COLS * nValues);
+		ByteBuffer dtable = direct(8L * GsGpuNative.N_DCOLS * nValues);
 		GsGpuNative.matchFinish(run, table, dtable);
 		uniqueCounts = new long[nValues];
+		if (maxKmerResCounts > 0) {
+			ByteBuffer mc = direct(2L * maxKmerResCounts * (nValues + 1));
+			GsGpuNative.matchMaxCounts(run, mc);
+			maxCounts = new short[nValues + 1][maxKmerResCounts];
+			for (int v = 0; v <= nValues; v++) {
+				for (int j = 0; j < maxKmerResCounts; j++) {
+					maxCounts[v][j] = mc.getShort(2 * (v * maxKmerResCounts + j));
+				}
+			}
+		}
 		for (int vi = 0; vi < nValues; vi++) {
 			int row = 8 * GsGpuNative.N_COLS * vi;
 			long reads = table.getLong(row + 8 * GsGpuNative.C_READS);
@@ -191,8 +339,12 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 			stats.errorSquaredSum = dtable.getDouble(drow + 8 * GsGpuNative.D_ERR_SQ_SUM);
 			stats.classErrorSum = dtable.getDouble(drow + 8 * GsGpuNative.D_CLASS_ERR_SUM);
 			stats.classErrorSquaredSum = dtable.getDouble(drow + 8 * GsGpuNative.D_CLASS_ERR_SQ_SUM);
-			// max contig descriptor: C_MAX_CONTIG_READ_NO is the global file-order read number of the first read with
-			// the maximum; the descriptor is looked up from the batch that contained it (kept by flush(), omitted).
+			byte[] d = maxContigDescriptor[vi];
+			if (d != null && stats.maxContigDescriptor.length > 0) { // copied and NUL-terminated as in :404-408
+				int n = Math.min(d.length, stats.maxContigDescriptor.length - 1);
+				System.arraycopy(d, 0, stats.maxContigDescriptor, 0, n);
+				stats.maxContigDescriptor[n] = 0;
+			}
 		}
 	}
 
