@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
-    "gs_match_submit_text", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
+    "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
     "gs_pinned_alloc", "gs_pinned_free",
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
@@ -116,6 +116,7 @@ def lib():
         "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
+        "gs_match_submit_fasta": (ci, [vp, vp, i64, i64, i64, ci, i64, vp, vp, vp]),
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
         "gs_match_text_clear_error": (ci, [vp]), "gs_match_text_select": (ci, [vp, ci]),
         "gs_match_segments_text": (ci, [vp, vp]), "gs_match_text_newlines": (ci, [vp, vp]),
@@ -318,6 +319,27 @@ class FastqKMerMatcher:
         ticket = C.c_int64(-1)
         self._text_keep = text  # the copy is asynchronous
         _check(lib().gs_match_submit_text(self.h, pt, n_bytes, int(n_lines), mem, first_read_no, pc, pf, C.byref(ticket)))
+        return ticket.value
+
+    def submit_fasta(self, text, n_lines=None, n_records=None, first_read_no=0, class_vi=None, flags=None):
+        """raw FASTA text of whole records (gs_match_submit_fasta); returns the ticket"""
+        if isinstance(text, (bytes, bytearray)):
+            text = np.frombuffer(bytes(text), dtype=np.uint8)
+        n_bytes = int(text.shape[0])
+        if n_lines is None or n_records is None:
+            host = text if isinstance(text, np.ndarray) else text.cpu().numpy()
+            nl = np.flatnonzero(host == 10)
+            starts = np.concatenate([[0], nl[:-1] + 1]) if len(nl) else np.zeros(0, dtype=np.int64)
+            n_lines = len(nl) if n_lines is None else n_lines
+            n_records = int((host[starts] == ord(">")).sum()) if n_records is None else n_records
+        pt, mem = _ptr(text) if n_bytes else (None, MEM_HOST)
+        pc, _ = _ptr(class_vi)
+        pf, _ = _ptr(flags)
+        _ready(text, class_vi, flags)
+        ticket = C.c_int64(-1)
+        self._text_keep = text
+        _check(lib().gs_match_submit_fasta(self.h, pt, n_bytes, int(n_lines), int(n_records), mem, first_read_no, pc, pf,
+                                           C.byref(ticket)))
         return ticket.value
 
     def text_wait_copy(self, ticket):

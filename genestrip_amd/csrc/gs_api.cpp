@@ -883,6 +883,12 @@ struct TextScan {
     size_t tile_cap = 0, nl_cap = 0;
     u64 *d_off2 = nullptr;
     size_t off2_cap = 0;
+    // FASTA mode: per-line scan words, per-block totals, per-line destinations, the gathered sequences
+    u64 *d_fa_scan = nullptr, *d_fa_block = nullptr;
+    uint32_t *d_line_dst = nullptr;
+    uint8_t *d_fa_seq = nullptr;
+    size_t fa_scan_cap = 0, fa_block_cap = 0, line_dst_cap = 0, fa_seq_cap = 0;
+    bool last_fasta = false;
     // GS_TEXT_BANKS independent streams of chunks (files read side by side): a refusal in one must not silence the
     // others, so the status words and totals exist once per bank; `bank` is the one the next calls work on
     uint32_t *d_status = nullptr;  // GS_TEXT_BANKS x GS_TS_WORDS
@@ -948,7 +954,15 @@ struct gs_run {
 };
 
 
+static void text_free_fasta(TextScan &t) {
+    hipFree(t.d_fa_scan);
+    hipFree(t.d_fa_block);
+    hipFree(t.d_line_dst);
+    hipFree(t.d_fa_seq);
+}
+
 static void text_free(TextScan &t) {
+    text_free_fasta(t);
     if (t.copy_stream) {
         hipStreamSynchronize(t.copy_stream);
         hipStreamDestroy(t.copy_stream);
@@ -1003,10 +1017,14 @@ extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket
 
 // copies the chunk to the device and runs the record scan; *ticket identifies the chunk.  After it the (start, end)
 // pairs of the sequence lines are in t.d_off2, the newline offsets in t.d_nl and the skip flag in t.d_status.
+// fasta_records < 0: four-line FASTQ; >= 0: FASTA with that many header lines (gs_text.hip)
 static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int k,
-                       int64_t *ticket) {
-    if (n_bytes < 0 || n_lines < 0 || (n_lines & 3) != 0 || (n_bytes > 0 && !text) || n_lines > n_bytes)
+                       int64_t *ticket, int64_t fasta_records = -1) {
+    const bool fasta = fasta_records >= 0;
+    if (n_bytes < 0 || n_lines < 0 || (!fasta && (n_lines & 3) != 0) || (n_bytes > 0 && !text) || n_lines > n_bytes)
         return fail(GS_E_INVALID, "bad text chunk (n_lines must be a multiple of 4)");
+    if (fasta && (fasta_records > n_lines || fasta_records >= ((int64_t)1 << 24)))
+        return fail(GS_E_INVALID, "bad FASTA chunk (at most 2^24 - 1 records, not more records than lines)");
     if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
     if (!t.d_status) {
@@ -1018,7 +1036,7 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
         for (hipEvent_t &ev : t.done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
     }
-    const int64_t n_reads = n_lines >> 2;
+    const int64_t n_reads = fasta ? fasta_records : (n_lines >> 2);
     const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
     const int64_t tk = t.tickets;
     const int b = (int)(tk & 1);
@@ -1028,6 +1046,12 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     if ((rc = grow(&t.d_tile, &t.tile_cap, padded / 4096 + 1, stream))) return rc;
     if ((rc = grow(&t.d_nl, &t.nl_cap, (size_t)n_lines + 4, stream))) return rc;
     if ((rc = grow(&t.d_off2, &t.off2_cap, 2 * (size_t)n_reads + 2, stream))) return rc;
+    if (fasta) {
+        if ((rc = grow(&t.d_fa_scan, &t.fa_scan_cap, (size_t)n_lines + 1, stream))) return rc;
+        if ((rc = grow(&t.d_fa_block, &t.fa_block_cap, (size_t)n_lines / GS_FA_BLOCK + 2, stream))) return rc;
+        if ((rc = grow(&t.d_line_dst, &t.line_dst_cap, (size_t)n_lines + 1, stream))) return rc;
+        if ((rc = grow(&t.d_fa_seq, &t.fa_seq_cap, (size_t)n_bytes + 256, stream))) return rc;
+    }
     t.d_text = t.d_buf[b];
     // the copy waits for the kernels of the chunk before last (they read this buffer), the scan for the copy
     if (t.done_valid[b]) HIP_TRY(hipStreamWaitEvent(t.copy_stream, t.done[b], 0));
@@ -1048,6 +1072,12 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     T.run_totals = T.chunk_totals + 3;
     T.status = t.d_status + (size_t)t.bank * GS_TS_WORDS;
     T.k = k;
+    T.n_records = fasta ? fasta_records : -1;
+    T.fa_scan = (unsigned long long *)t.d_fa_scan;
+    T.fa_block = (unsigned long long *)t.d_fa_block;
+    T.line_dst = t.d_line_dst;
+    T.fa_seq = t.d_fa_seq;
+    t.last_fasta = fasta;
     HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
     HIP_TRY(hipEventRecord(t.done[b], stream));
     t.done_valid[b] = true;
@@ -1446,12 +1476,27 @@ extern "C" int gs_pinned_free(void *p) {
     return GS_OK;
 }
 
+static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
+                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records);
+
 extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
                                     int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) {
+    return match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, class_vi, flags, ticket, -1);
+}
+
+extern "C" int gs_match_submit_fasta(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int64_t n_records, int mem,
+                                     int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) {
+    if (n_records < 0) return fail(GS_E_INVALID, "n_records < 0");
+    return match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, class_vi, flags, ticket, n_records);
+}
+
+static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
+                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
-    const int64_t n_reads = n_lines >> 2;
-    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket);
+    const bool fasta = fasta_records >= 0;
+    const int64_t n_reads = fasta ? fasta_records : (n_lines >> 2);
+    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket, fasta_records);
     if (rc) return rc;
     if (n_reads == 0) return GS_OK;
     const bool dev_out = mem == GS_MEM_DEVICE;
@@ -1471,8 +1516,9 @@ extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_
     }
     int32_t *dc = class_vi ? (dev_out ? class_vi : run->d_class) : nullptr;
     uint8_t *df = flags ? (dev_out ? flags : run->d_flags) : nullptr;
-    rc = launch_batch(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, first_read_no, dc, df, nullptr, nullptr, 2,
-                      run->text.d_status + (size_t)run->text.bank * GS_TS_WORDS + GS_TS_SKIP);
+    // FASTQ: the sequence lines in place, (start, end) pairs; FASTA: the gathered sequences, running offsets
+    rc = launch_batch(run, fasta ? run->text.d_fa_seq : run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, first_read_no, dc,
+                      df, nullptr, nullptr, fasta ? 1 : 2, run->text.d_status + (size_t)run->text.bank * GS_TS_WORDS + GS_TS_SKIP);
     if (rc) return rc;
     if ((rc = text_touched(run->text, run->stream))) return rc;
     if (!dev_out) {  // complete after gs_match_sync
@@ -1938,7 +1984,9 @@ extern "C" int gs_match_segments_text(gs_run *run, uint64_t *seg_off) {
     const int64_t n_reads = run->text.last_reads;
     if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
     if (n_reads == 0) return GS_OK;
-    const int rc = segments_core(run, run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads, 2, seg_off);
+    const bool fasta = run->text.last_fasta;  // (the gathered sequences stay in place until the next FASTA chunk)
+    const int rc = segments_core(run, fasta ? run->text.d_fa_seq : run->text.d_text, (const uint64_t *)run->text.d_off2, n_reads,
+                                 fasta ? 1 : 2, seg_off);
     if (rc) return rc;
     return text_touched(run->text, run->stream);
 }

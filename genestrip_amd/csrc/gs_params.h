@@ -55,7 +55,14 @@ struct GsTextParams {
     uint32_t *status;      // GS_TS_WORDS words
     int32_t k;
     int32_t pad;
+    // FASTA mode (gs_match_submit_fasta): n_records > = 0 header lines expected, reads gathered into fa_seq
+    int64_t n_records;                // -1: FASTQ mode
+    unsigned long long *fa_scan;      // per line: exclusive prefix inside its block of (header ? 1 << 40 : length)
+    unsigned long long *fa_block;     // per block of GS_FA_BLOCK lines: total, then exclusive prefix
+    uint32_t *line_dst;               // per line: destination of its bytes in fa_seq, ~0 for header lines
+    uint8_t *fa_seq;                  // the sequences of the chunk's records back to back; off2[0 .. n_records] = their bounds
 };
+#define GS_FA_BLOCK 256
 
 struct GsFilterParams {
     int32_t kind;           // GS_BLOOM_*

@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "gs_params.h"
 
 typedef unsigned long long u64;
@@ -150,6 +152,133 @@ __global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_text_records_kernel(GsTextPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// FASTA mode (AbstractFastqReader.doReadFasta, C/fastq/AbstractFastqReader.java:375-438): a record is a header line
+// (first byte '>') and the sequence lines up to the next header line, concatenated.  '>' never opens a sequence line,
+// so the record boundaries are known from the first byte of every line and the whole parse is two prefix sums over the
+// LINES of the chunk: headers before a line = its record, sequence bytes before a line = where its bytes go in the
+// compacted read buffer.  Accepted only if the chunk is what the reference would split the same way: it starts with a
+// header line, holds exactly the header lines the host counted, no NUL byte and NO EMPTY LINE (on an empty line the
+// reference's loop looks at a stale byte of its read buffer, :386-392: such input goes to the reference-exact parser).
+//   gs_fasta_lines_kernel   per line: header? length; exclusive scan inside blocks of 256 lines
+//   gs_fasta_scan_kernel    one block: prefix over the block totals, header count check, off2[n_records]
+//   gs_fasta_emit_kernel    per line: record start offsets (off2) / destination of a sequence line
+//   gs_fasta_gather_kernel  one wave per sequence line: bytes -> fa_seq
+//   gs_fasta_totals_kernel  per record: k-mer and base totals
+// ---------------------------------------------------------------------------------------------------
+#define GS_FA_HDR (1ULL << 40)
+#define GS_FA_LEN_MASK (GS_FA_HDR - 1)
+
+__device__ __forceinline__ void gs_fa_line(const GsTextParams &P, int64_t i, uint32_t &start, uint32_t &len, bool &hdr) {
+    start = i ? P.nl[i - 1] + 1 : 0;
+    len = P.nl[i] - start;
+    hdr = len > 0 && P.text[start] == '>';
+}
+
+__global__ __launch_bounds__(GS_FA_BLOCK) void gs_fasta_lines_kernel(GsTextParams P) {
+    __shared__ u64 s_wave[GS_FA_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * GS_FA_BLOCK + threadIdx.x;
+    const bool live = i < P.n_lines && P.status[GS_TS_CHUNK_ERR] == 0;  // (a count mismatch leaves nl[] partly unwritten)
+    u64 v = 0;
+    if (live) {
+        uint32_t start, len;
+        bool hdr;
+        gs_fa_line(P, i, start, len, hdr);
+        if (len == 0 || (i == 0 && !hdr)) {
+            atomicOr(&P.status[GS_TS_CHUNK_ERR], GS_TE_SHAPE);
+            atomicMin(&P.status[GS_TS_FIRST_BAD], (uint32_t)i);
+        }
+        v = hdr ? GS_FA_HDR : (u64)len;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u64 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 x = __shfl_up(inc, d);
+        if (lane >= d) inc += x;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    u64 before = 0;
+    for (int w = 0; w < wv; w++) before += s_wave[w];
+    if (i < P.n_lines) P.fa_scan[i] = before + inc - v;
+    if (threadIdx.x == GS_FA_BLOCK - 1) P.fa_block[blockIdx.x] = before + inc;
+}
+
+__global__ __launch_bounds__(1024) void gs_fasta_scan_kernel(GsTextParams P, int64_t n_blocks) {
+    __shared__ u64 s_part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n_blocks + 1023) / 1024;
+    const int64_t a = (int64_t)t * per, b = a + per < n_blocks ? a + per : n_blocks;
+    u64 sum = 0;
+    for (int64_t i = a; i < b; i++) sum += P.fa_block[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const u64 x = t >= d ? s_part[t - d] : 0;
+        __syncthreads();
+        s_part[t] += x;
+        __syncthreads();
+    }
+    u64 run = s_part[t] - sum;
+    for (int64_t i = a; i < b; i++) {
+        const u64 c = P.fa_block[i];
+        P.fa_block[i] = run;
+        run += c;
+    }
+    if (t == 1023) {
+        const u64 total = s_part[1023];
+        if ((int64_t)(total >> 40) != P.n_records)
+            atomicOr(&P.status[GS_TS_CHUNK_ERR], GS_TE_COUNT);
+        else
+            P.off2[P.n_records] = total & GS_FA_LEN_MASK;
+    }
+}
+
+__global__ __launch_bounds__(GS_FA_BLOCK) void gs_fasta_emit_kernel(GsTextParams P) {
+    const int64_t i = (int64_t)blockIdx.x * GS_FA_BLOCK + threadIdx.x;
+    if (i >= P.n_lines || P.status[GS_TS_CHUNK_ERR] != 0) return;
+    uint32_t start, len;
+    bool hdr;
+    gs_fa_line(P, i, start, len, hdr);
+    const u64 pre = P.fa_scan[i] + P.fa_block[blockIdx.x];
+    if (hdr) {
+        P.off2[pre >> 40] = pre & GS_FA_LEN_MASK;  // (the header count was checked: pre >> 40 < n_records)
+        P.line_dst[i] = 0xffffffffu;
+    } else {
+        P.line_dst[i] = (uint32_t)(pre & GS_FA_LEN_MASK);
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_fasta_gather_kernel(GsTextParams P) {
+    if (P.status[GS_TS_CHUNK_ERR] != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < P.n_lines; i += n_waves) {
+        const uint32_t dst = P.line_dst[i];
+        if (dst == 0xffffffffu) continue;
+        const uint32_t start = i ? P.nl[i - 1] + 1 : 0, len = P.nl[i] - start;
+        for (uint32_t j = (uint32_t)lane; j < len; j += 64) P.fa_seq[(size_t)dst + j] = P.text[(size_t)start + j];
+    }
+}
+
+__global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_fasta_totals_kernel(GsTextParams P) {
+    __shared__ u64 s_tot[2];
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * GS_TEXT_BLOCK + threadIdx.x;
+    if (r < P.n_records && P.status[GS_TS_CHUNK_ERR] == 0) {
+        const int64_t len = (int64_t)(P.off2[r + 1] - P.off2[r]);
+        if (len >= P.k) atomicAdd(&s_tot[0], (u64)(len - P.k + 1));
+        atomicAdd(&s_tot[1], (u64)len);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_tot[0]) atomicAdd(&P.chunk_totals[1], s_tot[0]);
+        if (s_tot[1]) atomicAdd(&P.chunk_totals[2], s_tot[1]);
+    }
+}
+
 __global__ void gs_text_commit_kernel(GsTextParams P, uint32_t ticket) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (P.status[GS_TS_STICKY] == 0 && P.status[GS_TS_CHUNK_ERR] != 0) {
@@ -160,7 +289,7 @@ __global__ void gs_text_commit_kernel(GsTextParams P, uint32_t ticket) {
         P.status[GS_TS_SKIP] = 1;
     } else {
         P.status[GS_TS_SKIP] = 0;
-        P.run_totals[0] += (u64)(P.n_lines >> 2);
+        P.run_totals[0] += (u64)(P.n_records >= 0 ? P.n_records : (P.n_lines >> 2));
         P.run_totals[1] += P.chunk_totals[1];
         P.run_totals[2] += P.chunk_totals[2];
     }
@@ -173,10 +302,23 @@ extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket
         hipLaunchKernelGGL(gs_text_count_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
         hipLaunchKernelGGL(gs_text_scan_kernel, dim3(1), dim3(1024), 0, stream, *P, n_tiles);
         hipLaunchKernelGGL(gs_text_lines_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
-        const int64_t n_rec = P->n_lines >> 2;
-        if (n_rec > 0)
-            hipLaunchKernelGGL(gs_text_records_kernel, dim3((unsigned)((n_rec + GS_TEXT_BLOCK - 1) / GS_TEXT_BLOCK)),
-                               dim3(GS_TEXT_BLOCK), 0, stream, *P);
+        if (P->n_records >= 0) {  // FASTA
+            const int64_t n_blocks = (P->n_lines + GS_FA_BLOCK - 1) / GS_FA_BLOCK;
+            if (n_blocks > 0) {
+                hipLaunchKernelGGL(gs_fasta_lines_kernel, dim3((unsigned)n_blocks), dim3(GS_FA_BLOCK), 0, stream, *P);
+                hipLaunchKernelGGL(gs_fasta_scan_kernel, dim3(1), dim3(1024), 0, stream, *P, n_blocks);
+                hipLaunchKernelGGL(gs_fasta_emit_kernel, dim3((unsigned)n_blocks), dim3(GS_FA_BLOCK), 0, stream, *P);
+                hipLaunchKernelGGL(gs_fasta_gather_kernel, dim3((unsigned)std::min<int64_t>((P->n_lines + 3) / 4, 8192)), dim3(256), 0, stream, *P);
+            }
+            if (P->n_records > 0)
+                hipLaunchKernelGGL(gs_fasta_totals_kernel, dim3((unsigned)((P->n_records + GS_TEXT_BLOCK - 1) / GS_TEXT_BLOCK)),
+                                   dim3(GS_TEXT_BLOCK), 0, stream, *P);
+        } else {
+            const int64_t n_rec = P->n_lines >> 2;
+            if (n_rec > 0)
+                hipLaunchKernelGGL(gs_text_records_kernel, dim3((unsigned)((n_rec + GS_TEXT_BLOCK - 1) / GS_TEXT_BLOCK)),
+                                   dim3(GS_TEXT_BLOCK), 0, stream, *P);
+        }
     }
     hipLaunchKernelGGL(gs_text_commit_kernel, dim3(1), dim3(64), 0, stream, *P, ticket);
     return hipGetLastError();

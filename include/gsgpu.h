@@ -173,6 +173,16 @@ int gs_match_wait(gs_run *run, int64_t ticket);
  * (AbstractFastqReader.java:343-349).  Chunks are limited to 1 GiB. */
 int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
                          int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket);
+/* The same for FASTA (AbstractFastqReader.doReadFasta, C/fastq/AbstractFastqReader.java:375-438): a chunk of raw FASTA
+ * text made of whole records -- it starts with a header line ('>'), ends with a newline, n_lines = its newlines,
+ * n_records = its header lines (lines whose first byte is '>'), both counted by the caller.  Read i is the concatenation
+ * of the sequence lines of record i ('\r' kept; a record without sequence lines is a read of length 0).  The device finds
+ * the records with two prefix sums over the lines and gathers the sequences.  Refused (as above, same status calls) if
+ * the counts do not match, the chunk does not start with a header, it holds a NUL byte, or ANY line is empty (there the
+ * reference's loop looks at a stale byte of its buffer, :386-392: such input belongs to the reference-exact parser).
+ * n_records < 2^24 per chunk.  class_vi / flags: n_records entries. */
+int gs_match_submit_fasta(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int64_t n_records, int mem,
+                          int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket);
 int gs_match_text_wait_copy(gs_run *run, int64_t ticket);
 int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_match_text_clear_error(gs_run *run);

@@ -322,3 +322,29 @@ def test_async_host_batches_equal_the_synchronous_ones(pinned):
         m.wait(99)
     m.close()
     store.close()
+
+
+def test_max_contig_reads_captured_per_batch_equal_the_final_answer(sdb):
+    """gs_match_max_contig_reads: a host that cannot keep every descriptor asks after each batch which read holds a tax
+    id's longest contig; what it captured when the answer fell into the batch it had just submitted must be the read
+    gs_match_finish reports (the reference's maxContigDescriptor bookkeeping, FastqKMerMatcher.java:401-407)"""
+    seq, off = synth.reads_host(sdb.genomes, 20000, read_len=150, seed=91)
+    off = off.astype(np.uint64)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    captured = np.full(sdb.n_values, -1, dtype=np.int64)
+    cuts = [0, 1500, 1501, 9000, 9000, 16000, 20000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            m.submit(seq[int(off[a]):int(off[b])], off[a:b + 1] - off[a], a, n_reads=b - a)
+        now = m.max_contig_reads()
+        inside = (now >= a) & (now < b)
+        captured[inside] = now[inside]
+    table, _ = m.finish()
+    assert np.array_equal(captured, table[:, 9])
+    assert (captured >= 0).sum() >= 5
+    orun = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    orun.submit(seq, off, threads=4, per_read=False)
+    assert np.array_equal(orun.finish()[0], table)
+    m.close()
+    store.close()
