@@ -195,9 +195,9 @@ struct Producer {
     double seconds = 0;
     std::string error;
     // path from byte `offset` on, or the memory range [mem, mem + mem_n) when path is empty
-    void start(const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int k, int64_t batch_reads) {
-        th = std::thread([this, path, offset, mem, mem_n, k, batch_reads] {
-            FastqParser parser(k, !path.empty() && is_fasta_name(path));
+    void start(const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int k, int64_t batch_reads, bool mem_fasta = false) {
+        th = std::thread([this, path, offset, mem, mem_n, k, batch_reads, mem_fasta] {
+            FastqParser parser(k, path.empty() ? mem_fasta : is_fasta_name(path));
             bool ok_open = true;
             if (path.empty())
                 parser.open_mem(mem, mem_n);
@@ -408,9 +408,10 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
 }
 
 // the general path: the reference's record parser on a producer thread (file from `offset`, or a memory range)
-int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int64_t &read_no) {
+int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, int64_t &read_no,
+                  bool mem_fasta = false) {
     Producer prod;
-    prod.start(path, offset, mem, mem_n, c.info.k, c.opts->batch_reads > 0 ? c.opts->batch_reads : (int64_t)1 << 20);
+    prod.start(path, offset, mem, mem_n, c.info.k, c.opts->batch_reads > 0 ? c.opts->batch_reads : (int64_t)1 << 20, mem_fasta);
     int err = GS_OK;
     for (;;) {
         std::unique_ptr<Batch> b = prod.q.pop();
@@ -484,8 +485,13 @@ struct TextJob {
     std::future<void> formatting;  // per-read outputs of the previous chunk on their way to the writers
     int64_t n_formatted = 0;
     int64_t held_ticket = -1, held_block = -1;
+    // FASTA files (AbstractFastqReader.doReadFasta): chunks are cut in front of a header line, the device finds the
+    // records (gs_match_submit_fasta); no per-read outputs on this path
+    bool fasta = false;
+    int64_t carry_headers = 0;
 
-    TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no) : c(ctx), path(p), bank(bank_), read_no(first_read_no) {}
+    TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
+        : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
     ~TextJob() { abort(); }
     // stops the readers (after the writers of the last chunk are through with its block)
     void abort() {
@@ -518,6 +524,7 @@ struct TextJob {
 
     // 1: a block was handled, 0: none ready (blocking = false only); `done` is set when the file is through
     int step(bool blocking, int *err_out) {
+        if (fasta) return step_fasta(blocking, err_out);
         int err = GS_OK;
         const int64_t i = next_block;
         bool keep_block = false;
@@ -604,6 +611,107 @@ struct TextJob {
             }
         }
         if (!keep_block) tr.release(i);  // (else: format_chunk releases it)
+        next_block = i + 1;
+        if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
+        *err_out = err;
+        return 1;
+    }
+
+    // The FASTA form of step(): the chunk ends in front of the block's last header line (everything up to there is whole
+    // records), the rest is carried into the next block.  Headers and newlines are counted here (memchr over the block:
+    // '>' is rare, the tail behind the last header is one record), the device checks the counts.
+    int step_fasta(bool blocking, int *err_out) {
+        int err = GS_OK;
+        const int64_t i = next_block;
+        bool keep_block = false;
+        if (!blocking && !tr.is_full(i)) return 0;
+        TextSlot &sl = tr.wait_full(i);
+        int64_t fallback_off = -1, fallback_reads = 0;
+        bool last = false;
+        if (sl.io_error || !tr.verify_gzip(sl)) {
+            err = hfail(tr.gz ? GS_E_INVALID : GS_E_IO, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
+        } else {
+            err = gs_match_text_select(c.run, bank);
+            uint8_t *blk = sl.buf + tr.headroom;
+            const int64_t n = (int64_t)sl.n;
+            last = sl.eof;
+            // header lines that start inside this block
+            bool at_line_start = carry.empty() || carry.back() == '\n';
+            int64_t headers = 0, last_hdr = -1;
+            for (const uint8_t *p = blk, *end = blk + n; p < end;) {
+                const uint8_t *q = (const uint8_t *)memchr(p, '>', (size_t)(end - p));
+                if (!q) break;
+                if (q == blk ? at_line_start : q[-1] == '\n') {
+                    headers++;
+                    last_hdr = q - blk;
+                }
+                p = q + 1;
+            }
+            // where the chunk ends (exclusive): at EOF behind the final newline, else in front of the last header line
+            int64_t cut = -1, cut_headers = 0;
+            if (last && n > 0 && blk[n - 1] == '\n') {
+                cut = n;
+                cut_headers = headers;
+            } else if (last && n == 0 && !carry.empty() && carry.back() == '\n') {
+                cut = 0;
+            } else if (last_hdr > 0 || (last_hdr == 0 && !carry.empty())) {
+                cut = last_hdr;
+                cut_headers = headers - 1;
+            }
+            if (err) {
+                // (the bank could not be selected: reported below)
+            } else if (cut < 0) {  // no record boundary in this block: keep everything
+                carry.insert(carry.end(), blk, blk + n);
+                carry_lines += sl.newlines;
+                carry_headers += headers;
+                if (carry.size() > tr.headroom && !last) {  // a record longer than a block: the general parser takes over
+                    fallback_off = carry_file_off;
+                    fallback_reads = reads_in_file;
+                }
+            } else if (carry.size() > tr.headroom) {
+                fallback_off = carry_file_off;
+                fallback_reads = reads_in_file;
+            } else {
+                int64_t tail_lines = 0;
+                for (const uint8_t *p = blk + cut, *end = blk + n; p < end;) {
+                    const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+                    if (!q) break;
+                    tail_lines++;
+                    p = q + 1;
+                }
+                const int64_t lines = carry_lines + sl.newlines - tail_lines, records = carry_headers + cut_headers;
+                uint8_t *start = blk - carry.size();
+                if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+                int64_t ticket = -1;
+                if (records >= ((int64_t)1 << 24)) {  // (more records than one chunk may hold: the general parser)
+                    fallback_off = carry_file_off;
+                    fallback_reads = reads_in_file;
+                } else if ((int64_t)carry.size() + cut > 0) {
+                    err = gs_match_submit_fasta(c.run, start, (int64_t)carry.size() + cut, lines, records, GS_MEM_HOST,
+                                                read_no + reads_in_file, nullptr, nullptr, &ticket);
+                }
+                if (!err && fallback_off < 0) {
+                    if (ticket >= 0) {
+                        if (first_ticket < 0) first_ticket = ticket;
+                        chunks.push_back({carry_file_off, reads_in_file, ticket});
+                    }
+                    reads_in_file += records;
+                    carry_file_off = i * (int64_t)tr.block + cut;
+                    carry.assign(blk + cut, blk + n);
+                    carry_lines = tail_lines;
+                    carry_headers = headers - cut_headers;
+                    if (ticket >= 0) {
+                        err = release_held();
+                        held_ticket = ticket;
+                        held_block = i;
+                        keep_block = true;
+                    }
+                }
+                if (!err && fallback_off < 0 && (chunks.size() == 1 || (chunks.size() & 15) == 0))
+                    err = check_refusal(&fallback_off, &fallback_reads);
+            }
+        }
+        if (!keep_block) tr.release(i);
         next_block = i + 1;
         if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
         *err_out = err;
@@ -702,7 +810,7 @@ private:
         }
         read_no += reads_in_file;
         // what is left after the last whole four-line group (no final newline, truncated record): the general parser
-        if (!carry.empty()) return parsed_source(c, std::string(), 0, carry.data(), carry.size(), read_no);
+        if (!carry.empty()) return parsed_source(c, std::string(), 0, carry.data(), carry.size(), read_no, fasta);
         return GS_OK;
     }
 };
@@ -722,9 +830,11 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
     int err = GS_OK;
     std::vector<int> kind((size_t)n_paths, 0);
     int n_gzip = 0;
+    const bool per_read_out = c.filtered.active() || c.kraken.active();
     for (int i = 0; i < n_paths; i++) {
         kind[(size_t)i] = fast ? text_path_kind(paths[i]) : 0;
-        n_gzip += kind[(size_t)i] == 2;
+        if (kind[(size_t)i] >= 3 && per_read_out) kind[(size_t)i] = 0;  // FASTA on the device: tables only
+        n_gzip += kind[(size_t)i] == 2 || kind[(size_t)i] == 4;
     }
     const int default_readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
     // one gzip file at a time: its inflating threads are all the parallelism there is (measured on the MI355X box,
@@ -743,8 +853,9 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
         for (int i = 0; i < n_paths && !err; i++) {
             const std::string path(paths[i]);
             if (kind[(size_t)i]) {
-                TextJob job(c, path, 0, read_no);
-                err = job.open(kind[(size_t)i] == 2, kind[(size_t)i] == 2 ? gzip_threads : default_readers);
+                const bool gz = kind[(size_t)i] == 2 || kind[(size_t)i] == 4;
+                TextJob job(c, path, 0, read_no, kind[(size_t)i] >= 3);
+                err = job.open(gz, gz ? gzip_threads : default_readers);
                 while (!err && !job.done) job.step(true, &err);
                 if (!job.done) job.abort();
                 read_no = job.read_no;
@@ -766,8 +877,8 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
                         for (auto &j : active) used = used || j->bank == bank;
                         if (!used) break;
                     }
-                    auto job = std::make_unique<TextJob>(c, std::string(paths[next]), bank, base);
-                    err = job->open(kind[(size_t)next] == 2, std::max(2, 2 * default_readers / std::min(n_paths, 8)));
+                    auto job = std::make_unique<TextJob>(c, std::string(paths[next]), bank, base, kind[(size_t)next] >= 3);
+                    err = job->open(kind[(size_t)next] == 2 || kind[(size_t)next] == 4, std::max(2, 2 * default_readers / std::min(n_paths, 8)));
                     active.push_back(std::move(job));
                     file_of.push_back(next);
                 } else {  // FASTA etc.: the general parser, on its own
@@ -1180,7 +1291,8 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     int err = GS_OK;
     for (int f = 0; f < n_paths && !err; f++) {
         const std::string path(paths[f]);
-        const int kind = fast ? text_path_kind(path) : 0;
+        int kind = fast ? text_path_kind(path) : 0;
+        if (kind >= 3) kind = 0;  // FASTA: the general parser (the filter goal rewrites every read)
         if (kind)
             err = filter_text_file(c, path, kind == 2);
         else

@@ -669,16 +669,16 @@ struct TextReader {
     }
 };
 
-// 0: not for the text path (FASTA), 1: plain FASTQ (parallel pread), 2: gzip FASTQ (one inflating thread)
+// 0: not for the text path, 1: plain FASTQ (parallel pread), 2: gzip FASTQ (inflating threads), 3 / 4: the same for FASTA
+// (file type by name as the reference decides it, FastqMapGoal.java:188-201)
 inline int text_path_kind(const std::string &path) {
-    if (is_fasta_name(path)) return 0;
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return 0;
     unsigned char mg[2] = {0, 0};
     const size_t n = fread(mg, 1, 2, f);
     fclose(f);
     const bool gzip_content = n == 2 && mg[0] == 0x1f && mg[1] == 0x8b;  // zlib decides by content, so do we
-    return gzip_content ? 2 : 1;
+    return (gzip_content ? 2 : 1) + (is_fasta_name(path) ? 2 : 0);
 }
 
 

@@ -1,0 +1,139 @@
+"""Device-side FASTA record scan (gs_match_submit_fasta, gs_text.hip): raw FASTA text -> records by
+two prefix sums over the lines -> gathered reads -> match, against the oracle's restatement of
+AbstractFastqReader.doReadFasta (C/fastq/AbstractFastqReader.java:375-438).  Needs an MI355X: run with -m gpu."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import genestrip_amd as ga
+from genestrip_amd import host, synth
+from oracle import gs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sdb():
+    return synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=20000, seed=11)
+
+
+def _fasta(sdb, n, seed, width=60, crlf=False):
+    """contigs of 0 .. 5000 bases cut from the genomes, wrapped at `width`; some with a stray N, one header right after
+    another (a read of length 0), header text with '>' and blanks inside"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        g = sdb.genomes[int(rng.integers(0, len(sdb.genomes)))]
+        L = int(rng.choice([0, 20, 31, 150, int(rng.integers(200, 5000))], p=[0.03, 0.05, 0.05, 0.37, 0.5]))
+        p = int(rng.integers(0, len(g) - L + 1))
+        s = bytearray(g[p:p + L].tobytes())
+        if L and rng.random() < 0.2:
+            s[int(rng.integers(0, L))] = ord("N")
+        eol = b"\r\n" if crlf else b"\n"
+        out.append(b">c%d len=%d a>b" % (i, L) + eol)
+        w = width if rng.random() < 0.8 else int(rng.integers(1, 200))
+        for j in range(0, L, w):
+            out.append(bytes(s[j:j + w]) + eol)
+    return b"".join(out)
+
+
+def _oracle(sdb, text, **cfg):
+    rd = orc.parse_fastq(text, fasta=True, k=31)
+    run = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi), **cfg)
+    cv, fl = run.submit(rd["seq"], rd["seq_off"], threads=4)
+    return run.finish()[0], cv, fl, rd
+
+
+@pytest.mark.parametrize("seed,crlf", [(1, False), (2, False), (3, True)])
+def test_fasta_chunks_on_the_device(sdb, seed, crlf):
+    text = _fasta(sdb, 3000, seed, crlf=crlf)
+    want, wcv, wfl, rd = _oracle(sdb, text)
+    n = rd["n_reads"]
+    assert n == 3000
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    # several chunks, cut at header lines, with per-read outputs
+    starts = [i for i in range(len(text)) if text[i:i + 1] == b">" and (i == 0 or text[i - 1:i] == b"\n")]
+    assert len(starts) == n
+    cuts = [0, starts[1], starts[700], starts[701], starts[2200], len(text)]
+    recs = [0, 1, 700, 701, 2200, n]
+    cv = np.full(n, -9, dtype=np.int32)
+    fl = np.full(n, 77, dtype=np.uint8)
+    keep = []
+    for a, b, ra, rb in zip(cuts[:-1], cuts[1:], recs[:-1], recs[1:]):
+        ccv, cfl = np.zeros(rb - ra, dtype=np.int32), np.zeros(rb - ra, dtype=np.uint8)
+        keep.append((ra, rb, ccv, cfl))
+        m.submit_fasta(text[a:b], first_read_no=ra, class_vi=ccv, flags=cfl)
+        m.sync()
+    for ra, rb, ccv, cfl in keep:
+        cv[ra:rb], fl[ra:rb] = ccv, cfl
+    failed, bad, tot = m.text_status()
+    assert failed == -1
+    assert tot == (n, rd["total_kmers"], rd["total_bps"])
+    got, _ = m.finish()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:6]
+    assert np.array_equal(cv, wcv) and np.array_equal(fl, wfl)
+    m.close()
+    store.close()
+
+
+def test_fasta_chunks_the_device_must_refuse(sdb):
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    good = _fasta(sdb, 50, 9)
+    body = bytes(sdb.genomes[0][:120].tobytes())
+    cases = {
+        "empty line": b">a\n" + body[:60] + b"\n\n" + body[60:] + b"\n",
+        "no header first": body[:60] + b"\n>a\n" + body + b"\n",
+        "nul": b">a\n" + body[:30] + b"\0" + body[30:] + b"\n",
+        "wrong record count": None,
+    }
+    for name, text in cases.items():
+        if text is None:
+            m.submit_fasta(good, n_records=49)
+        else:
+            m.submit_fasta(text)
+        failed, bad, tot = m.text_status()
+        assert failed >= 0, name
+        assert tot == (0, 0, 0), name
+        m.clear_text_error() if hasattr(m, "clear_text_error") else m.text_clear_error()
+        m.submit_fasta(good)  # the run goes on after the refusal was cleared
+        failed, bad, tot = m.text_status()
+        assert failed == -1, name
+        m.reset()
+    m.close()
+    store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("block", [None, 4096, 700])
+def test_fasta_files_through_the_host_pipeline(sdb, tmp_path, monkeypatch, gz, block):
+    """gs_host_match_files on .fasta / .fa.gz files: raw blocks cut in front of header lines -> gs_match_submit_fasta;
+    records longer than a block, a tail without a final newline and a file with an empty line take the reference-exact
+    parser, in the middle of the file if need be -- the table and the totals are the oracle's either way"""
+    if block:
+        monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+    texts = [_fasta(sdb, 1200, 21), _fasta(sdb, 300, 22)[:-1],                   # no final newline: the last byte is lost
+             _fasta(sdb, 200, 23) + b">x\nACGT\n\nACGTACGT\n" + _fasta(sdb, 100, 24)]  # an empty line in the middle
+    paths = []
+    for i, t in enumerate(texts):
+        p = str(tmp_path / (f"c{i}.fa.gz" if gz else f"c{i}.fasta"))
+        with (gzip.open(p, "wb", compresslevel=1) if gz else open(p, "wb")) as f:
+            f.write(t)
+        paths.append(p)
+    run = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    reads = kmers = bps = 0
+    first = 0
+    for t in texts:
+        rd = orc.parse_fastq(t, fasta=True, k=31)
+        run.submit(rd["seq"], rd["seq_off"], first_read_no=first, threads=4, per_read=False)
+        first += rd["n_reads"]
+        reads, kmers, bps = reads + rd["n_reads"], kmers + rd["total_kmers"], bps + rd["total_bps"]
+    want, _ = run.finish()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    table, _, tot = host.match_files(store, paths)
+    assert (tot.reads, tot.kmers, tot.bps) == (reads, kmers, bps)
+    assert np.array_equal(table, want), np.argwhere(table != want)[:6]
+    store.close()
