@@ -117,8 +117,9 @@ typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 #define GS_WAVES 8
 #endif
 
-// (Software pipelining of the next read's bases behind the bucket loads was measured on MI355X: the extra registers
-// cost one wave per SIMD and the net effect was nil; the code is gone.)
+// (Software pipelining across the reads of a wave -- offsets two reads ahead, bases one read ahead -- was measured on
+// MI355X in round 1 and again in round 2 on the record layout, also on the HBM-resident 47 M-k-mer store: within noise
+// (7.67 / 7.79 ms, 10.45 / 10.53 ms) while costing 4 more spilled VGPRs; the code is gone.)
 
 #ifndef GS_NT_TABLE
 // Measured on MI355X: non-temporal bucket loads stop the four dwordx4 loads of one 64-byte line from sharing a
