@@ -217,7 +217,8 @@ def main():
         "config": {"workload": "match: %d synthetic 150 bp reads per GPU, k=31, %d-k-mer / %d-taxid store resident in HBM "
                                "(BASELINE.json configs[1])" % (n, db.n_entries, len(db.species_vi)),
                    "reads_per_gpu": n, "read_len": READ_LEN, "k": K, "store_kmers": int(db.n_entries),
-                   "store_table_bytes": int(info.table_bytes), "gate_bytes": int(info.gate_bytes),
+                   "store_record_bytes": int(info.rec_bytes), "store_table_bytes": int(info.table_bytes),
+                   "gate_bytes": int(info.mgate_bytes or info.gate_bytes),
                    "parallelism": ("DB-partitioned x%d, k-mers routed by all-to-all" % world) if partitioned
                    else ("read-sharded x%d, store replicated" % world)},
         # `frac` follows SURVEY 8(d)'s convention (one 64-byte line per k-mer position over the HBM peak).  For this
@@ -391,7 +392,7 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores):
         ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9
         res["large_store"] = {
             "workload": "match: %d reads x 150 bp, k=31, %d-k-mer / %d-value store" % (n, db.n_entries, db.n_values),
-            "store_kmers": int(db.n_entries), "n_values": int(db.n_values), "table_bytes": int(info.table_bytes),
+            "store_kmers": int(db.n_entries), "n_values": int(db.n_values), "record_bytes": int(info.rec_bytes), "table_bytes": int(info.table_bytes),
             "mgate_bytes": int(info.mgate_bytes), "kernel": "gs_match_kernel<global counters, k=31>",
             "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3), "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2),
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
