@@ -33,6 +33,8 @@ extern "C" hipError_t gs_launch_encode(const struct GsEncodeParams *P, int grid,
 extern "C" hipError_t gs_launch_probe_keys(const GsDbDev *db, const u64 *keys, int64_t n, int32_t *nodes, int count_unique,
                                             hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_stat_reduce(const GsStatRec *recs, const void *count, int64_t n_max, int n_values, void *sums, void *maxk,
+                                             void *dsums, hipStream_t stream);
 extern "C" int gs_match_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
 
@@ -919,9 +921,15 @@ struct gs_run {
     gs_db *db = nullptr;
     gs_match_cfg cfg{};
     hipStream_t stream = nullptr;
-    int64_t *d_sums = nullptr;
+    int64_t *d_sums = nullptr;   // [stat_copies][n_values][GS_N_SUMS]; copy 0 is the one everything outside the kernels sees
     int64_t *d_max = nullptr;
     double *d_dsums = nullptr;
+    GsStatRec *d_stat_recs = nullptr;  // deferred statistics of the current batch (global-atomic counters only)
+    u64 *d_stat_rec_count = nullptr;
+    size_t stat_recs_cap = 0;
+    bool use_stat_recs = false;
+    int stat_copies = 1;         // > 1: global-atomic counters spread over several copies (GsMatchParams::stat_copies)
+    bool stats_spread = false;   // some copy other than 0 may be non-zero: fold_stats() before reading
     uint32_t *d_hit_counts = nullptr;  // per slot, only when cfg.max_kmer_res_counts > 0
     uint32_t *d_bitmap = nullptr;  // compact copy of the slots' seen bits (built on demand: finish / device_state)
     int64_t bitmap_words = 0;
@@ -1125,9 +1133,11 @@ static int text_status(TextScan &t, hipStream_t stream, int64_t *failed_ticket, 
 
 static int run_clear(gs_run *run) {
     const size_t nv = (size_t)run->db->info.n_values;
-    HIP_TRY(hipMemsetAsync(run->d_sums, 0, sizeof(int64_t) * nv * GS_N_SUMS, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS, run->stream));
+    const size_t cp = (size_t)run->stat_copies;
+    HIP_TRY(hipMemsetAsync(run->d_sums, 0, sizeof(int64_t) * nv * GS_N_SUMS * cp, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv * cp, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS * cp, run->stream));
+    run->stats_spread = false;
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
     if (run->d_hit_counts)
         HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)(run->db->n_slots() + run->db->n_rec * GS_REC_SLOTS), run->stream));
@@ -1149,6 +1159,8 @@ static void run_free(gs_run *run) {
     hipFree(run->d_sums);
     hipFree(run->d_max);
     hipFree(run->d_dsums);
+    hipFree(run->d_stat_recs);
+    hipFree(run->d_stat_rec_count);
     hipFree(run->d_bitmap);
     hipFree(run->d_hit_counts);
     hipFree(run->d_unique);
@@ -1198,9 +1210,23 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     const size_t nv = (size_t)db->info.n_values;
     run->bitmap_words = (db->n_slots() + 31) / 32 + db->n_rec;  // one word per record bucket behind the table slots' bits
     hipError_t e = hipStreamCreateWithFlags(&run->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS);
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_max, sizeof(int64_t) * nv);
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_dsums, sizeof(double) * nv * GS_N_DCOLS);
+    // Counters that do not fit the LDS are global atomics: 12 bytes x 8 per tax id in three cache lines that every CU
+    // hits.  Measured on the 47 M-k-mer / 526-value store: they cost 8 of 16.7 ms on reads from the store; spread over
+    // 16 copies (one per group of workgroups) the lines are 16 times colder.
+    if (nv > GS_NV_LDS) {
+        int copies = 16;
+        if (const char *ev = getenv("GS_STAT_COPIES")) copies = std::max(1, std::min(64, atoi(ev)));
+        while (copies > 1 && (size_t)copies * nv * 96 > ((size_t)64 << 20)) copies /= 2;
+        run->stat_copies = copies;
+        // and most reads need no atomics at all: the hit k-mers of a read usually carry one tax id, whose statistics go
+        // into one 64-byte record per read that a second kernel adds up in LDS (gs_stat_reduce_kernel)
+        run->use_stat_recs = nv <= GS_STAT_REC_MAX_VALUES;
+        if (const char *ev = getenv("GS_STAT_RECS")) run->use_stat_recs = run->use_stat_recs && atoi(ev) != 0;
+    }
+    const size_t cp = (size_t)run->stat_copies;
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS * cp);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_max, sizeof(int64_t) * nv * cp);
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_dsums, sizeof(double) * nv * GS_N_DCOLS * cp);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_bitmap, sizeof(uint32_t) * (size_t)run->bitmap_words);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
     if (e == hipSuccess && cfg->max_kmer_res_counts > 0)
@@ -1296,6 +1322,8 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.sums = run->d_sums;
     P.max_keys = run->d_max;
     P.dsums = run->d_dsums;
+    P.stat_copies = run->stat_copies;
+    run->stats_spread = run->stat_copies > 1;
     P.bitmap = run->d_bitmap;
     P.hit_counts = run->d_hit_counts;
     P.class_vi = d_class;
@@ -1306,9 +1334,17 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.pos_off = (const unsigned long long *)d_pos_off;
     P.off_stride = off_stride;
     P.skip = d_skip;
-    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + (GS_BLOCK / 64) - 1) / (GS_BLOCK / 64));
     if (grid < 1) grid = 1;
+    const int64_t rec_room = n_reads + (int64_t)grid * (GS_BLOCK / 64) * 64;  // every wave may leave one chunk of 64 partly used
+    if (run->use_stat_recs) {
+        if ((rc = grow(&run->d_stat_recs, &run->stat_recs_cap, (size_t)rec_room, run->stream))) return rc;
+        if (!run->d_stat_rec_count) HIP_TRY(hipMalloc((void **)&run->d_stat_rec_count, sizeof(u64)));
+        HIP_TRY(hipMemsetAsync(run->d_stat_rec_count, 0, sizeof(u64), run->stream));
+        P.stat_recs = run->d_stat_recs;
+        P.stat_rec_count = (unsigned long long *)run->d_stat_rec_count;
+    }
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (run->cfg.profile) {
         HIP_TRY(hipEventCreate(&e0));
@@ -1320,6 +1356,9 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         run->bitmap_merged = false;
     }
     HIP_TRY(gs_launch_match(&P, grid, run->stream));
+    if (P.stat_recs)  // (into copy 0 of the counters; part of the timed region)
+        HIP_TRY(gs_launch_stat_reduce(P.stat_recs, run->d_stat_rec_count, rec_room, run->db->info.n_values, run->d_sums, run->d_max,
+                                      run->d_dsums, run->stream));
     if (run->cfg.profile) {
         HIP_TRY(hipEventRecord(e1, run->stream));
         run->pending.push_back({e0, e1});
@@ -1555,6 +1594,26 @@ extern "C" int gs_match_text_clear_error(gs_run *run) {
     return text_reset(run->text, false, run->stream);
 }
 
+extern "C" hipError_t gs_launch_merge_i64(void *dst, const void *src, int64_t n, int op, hipStream_t stream);
+extern "C" hipError_t gs_launch_merge_f64(void *dst, const void *src, int64_t n, hipStream_t stream);
+
+// the copies of the global-atomic counters into copy 0 (the others start from zero again)
+static int fold_stats(gs_run *run) {
+    if (!run->stats_spread) return GS_OK;
+    const size_t nv = (size_t)run->db->info.n_values;
+    for (int c = 1; c < run->stat_copies; c++) {
+        HIP_TRY(gs_launch_merge_i64(run->d_sums, run->d_sums + (size_t)c * nv * GS_N_SUMS, (int64_t)(nv * GS_N_SUMS), 0, run->stream));
+        HIP_TRY(gs_launch_merge_i64(run->d_max, run->d_max + (size_t)c * nv, (int64_t)nv, 1, run->stream));
+        HIP_TRY(gs_launch_merge_f64(run->d_dsums, run->d_dsums + (size_t)c * nv * GS_N_DCOLS, (int64_t)(nv * GS_N_DCOLS), run->stream));
+    }
+    const size_t rest = (size_t)run->stat_copies - 1;
+    HIP_TRY(hipMemsetAsync(run->d_sums + nv * GS_N_SUMS, 0, sizeof(int64_t) * nv * GS_N_SUMS * rest, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_max + nv, 0, sizeof(int64_t) * nv * rest, run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_dsums + nv * GS_N_DCOLS, 0, sizeof(double) * nv * GS_N_DCOLS * rest, run->stream));
+    run->stats_spread = false;
+    return GS_OK;
+}
+
 extern "C" int gs_match_sync(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
@@ -1568,6 +1627,10 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     const size_t nv = (size_t)run->db->info.n_values;
     std::vector<int64_t> sums(nv * GS_N_SUMS), maxk(nv);
     std::vector<u64> uniq(nv, 0);
+    {
+        const int frc = fold_stats(run);
+        if (frc) return frc;
+    }
     if (run->cfg.count_unique) {
         if (!run->bitmap_merged)
             HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
@@ -1607,6 +1670,10 @@ extern "C" int gs_match_max_contig_reads(gs_run *run, int64_t *read_no) {
     HIP_TRY(hipSetDevice(run->db->device));
     const size_t nv = (size_t)run->db->info.n_values;
     std::vector<int64_t> maxk(nv);
+    {
+        const int frc = fold_stats(run);
+        if (frc) return frc;
+    }
     HIP_TRY(hipMemcpyAsync(maxk.data(), run->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     int rc = collect_events(run);
@@ -1648,6 +1715,10 @@ extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, 
                                      int64_t *bitmap_words) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
+    {
+        const int frc = fold_stats(run);
+        if (frc) return frc;
+    }
     if (bitmap && run->cfg.count_unique && !run->bitmap_merged)  // refresh the compact copy of the seen bits
         HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
                                          run->stream));
@@ -1670,8 +1741,6 @@ extern "C" int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_part
 }
 
 // ---- merge of runs that live in one process (gs_merge.hip)
-extern "C" hipError_t gs_launch_merge_i64(void *dst, const void *src, int64_t n, int op, hipStream_t stream);
-extern "C" hipError_t gs_launch_merge_f64(void *dst, const void *src, int64_t n, hipStream_t stream);
 extern "C" int gs_rccl_merge_leaders(int n_dev, const int *devices, void *const *sums, void *const *maxk, void *const *dsums,
                                      void *const *bitmap, void *const *gather, int64_t n_sums, int64_t n_max, int64_t n_dsums,
                                      int64_t n_words, const hipStream_t *streams, const char **msg);
@@ -1699,6 +1768,10 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
     for (int i = 0; i < n_runs; i++) {
         gs_run *run = runs[i];
         HIP_TRY(hipSetDevice(run->db->device));
+        {
+            const int frc = fold_stats(run);
+            if (frc) return frc;
+        }
         if (uniq && !run->bitmap_merged)
             HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec, run->stream));
         HIP_TRY(hipStreamSynchronize(run->stream));

@@ -27,6 +27,12 @@
 #include "gs_layout.h"
 #include "gs_params.h"
 
+// developer ablations (tools/ablate.sh): 1 = no per-read reduce, 2 = no record / table probe, 4 = no gate either,
+// 8 = no statistics atomics
+#ifndef GS_ABLATE
+#define GS_ABLATE 0
+#endif
+
 #define GS_NODE_MISS (-1)
 #define GS_NODE_INVALID (-2)
 #define GS_NODE_NONE (-3)
@@ -79,6 +85,11 @@ __device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64
 // ---------------------------------------------------------------------------------------------------
 // statistics sinks: LDS-privatised (n_values <= GS_NV_LDS) or direct global atomics
 // ---------------------------------------------------------------------------------------------------
+// a wave's place in the record array: it takes 64 slots at a time with one atomic and fills them read by read.  The
+// cursor lives in LDS (the scalar registers of the read loop are all taken): [0] = base of the chunk, [1] = slots used
+// (64: no chunk in hand)
+typedef unsigned long long GsRecCursor[2];
+
 struct GsStats {
     u64 *sums;      // [nv][GS_N_SUMS]
     u64 *maxk;      // [nv]
@@ -86,9 +97,15 @@ struct GsStats {
     // the taxonomy next to the counters: LDS copies when the counters are in LDS (a tree walk is a chain of dependent
     // loads; from HBM/L2 each link costs the better part of a microsecond), the store's arrays otherwise
     const int32_t *parent, *tin, *tout;
-    __device__ __forceinline__ void add(int vi, int col, u64 v) const { atomicAdd(&sums[(size_t)vi * GS_N_SUMS + col], v); }
-    __device__ __forceinline__ void max(int vi, u64 key) const { atomicMax(&maxk[vi], key); }
-    __device__ __forceinline__ void dadd(int vi, int col, double v) const { atomicAdd(&dsums[(size_t)vi * GS_N_DCOLS + col], v); }
+    __device__ __forceinline__ void add(int vi, int col, u64 v) const {
+        if (!(GS_ABLATE & 8)) atomicAdd(&sums[(size_t)vi * GS_N_SUMS + col], v);
+    }
+    __device__ __forceinline__ void max(int vi, u64 key) const {
+        if (!(GS_ABLATE & 8)) atomicMax(&maxk[vi], key);
+    }
+    __device__ __forceinline__ void dadd(int vi, int col, double v) const {
+        if (!(GS_ABLATE & 8)) atomicAdd(&dsums[(size_t)vi * GS_N_DCOLS + col], v);
+    }
     // contig flush (FastqKMerMatcher.java:396-411 / :457-471)
     __device__ __forceinline__ void contig(int vi, int len, u64 key_lo) const {
         add(vi, GS_S_KMERS, (u64)len);
@@ -106,10 +123,6 @@ typedef unsigned long long gs_u64x2 __attribute__((ext_vector_type(2)));
 // The fused kernels look at the first half of a bucket first (two loads, four compares, half the registers) and run
 // at 8 waves per SIMD with 64 VGPRs.  Measured against whole-bucket probes at 6 waves: bench stream equal (10.26 ms),
 // miss-only stream 5.94 -> 5.56 ms, 47 M-k-mer store 16.3 -> 16.0 ms.
-// developer ablations (tools/ablate.sh): 1 = no per-read reduce, 2 = no record / table probe, 4 = no gate either
-#ifndef GS_ABLATE
-#define GS_ABLATE 0
-#endif
 #ifndef GS_HALF_BUCKETS
 #define GS_HALF_BUCKETS 1
 #endif
@@ -446,11 +459,11 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // WIDE = true: maxClassificationPaths in 65..128 (C/GSConfigKey.java:350 allows 1..128): candidate path i lives in
 // lane i & 63 of register set i >> 6; with WIDE = false there is one set and lane = path.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG, bool FROM_NODES, int KC, bool WIDE>
+template <bool LONG, bool FROM_NODES, int KC, bool WIDE, bool REC>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
-                                                uint32_t *wave_g) {
+                                                uint32_t *wave_g, unsigned long long *cur) {
     const GsDbDev &db = P.db;
     const int k = KC ? KC : db.k;
     const int max = L - k + 1;
@@ -470,6 +483,9 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         int cur_start = 0;
         int dviA = -1, dviB = -1, dcntA = 0, dcntB = 0, nd = 0;  // !LONG: distinct hit nodes (cap 128 >= #contigs)
         int one_vi = -1, one_cnt = 0;                              // !LONG: the first of them, wave-uniform
+        bool deferred = false;                                     // REC: its statistics go into a GsStatRec (P.stat_recs)
+        int def_contigs = 0, def_max = 0, def_sq = 0;              // (at most 128 positions: 128^2 fits)
+        int def_counted = 0, def_read_kmers = 0, def_tax_err = 0;
         constexpr int NP = WIDE ? 2 : 1;
         int path[NP], ptin[NP], ptout[NP], used = 0;            // candidate paths: path i in lane i & 63 of set i >> 6
 #pragma unroll
@@ -533,6 +549,23 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // (read, tax id) pair once (:434-439) and mergeReadTaxidPath (:568-586) is idempotent for a node it
             // has already seen (paths only ever move down the tree), so repeats need no work.  The per-node vote
             // count of the read (incCount, :380-388) is the number of positions holding that node.
+            // the first distinct hit node; in ~90 % of the reads that hit a store of species-specific k-mers it is the
+            // only one: its id and count stay in scalar registers (one_vi, one_cnt)
+            u64 m0 = hit0, m1 = hit1;
+#define GS_FIRST_NODE()                                                                                   \
+    {                                                                                                     \
+        const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);                                \
+        one_vi = j < 64 ? gs_readlane(node[0], j) : gs_readlane(node[1], j - 64);                         \
+        const u64 e0 = __ballot(node[0] == one_vi), e1 = __ballot(node[1] == one_vi);                     \
+        one_cnt = __popcll(e0) + __popcll(e1);                                                            \
+        m0 &= ~e0;                                                                                        \
+        m1 &= ~e1;                                                                                        \
+        nd = 1;                                                                                           \
+    }
+            if (REC && (hit0 | hit1) != 0) {  // (needed before the contigs are booked: one record instead of atomics?)
+                GS_FIRST_NODE()
+                deferred = (m0 | m1) == 0 && P.stat_recs != nullptr;  // one tax id, counters in HBM: no atomics, one record
+            }
             if ((GS_ABLATE & 1) == 0 && ((hit0 | hit1) != 0 || carry_last >= 0)) {
                 int prev[2];
                 {
@@ -554,28 +587,37 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     const int e1 = chg1 ? 64 + __builtin_ctzll(chg1) : -1;
                     const int end0 = a0 ? lane + 1 + __builtin_ctzll(a0) : e1;
                     const int end1 = a1 ? 64 + lane + 1 + __builtin_ctzll(a1) : -1;
-                    if (node[0] >= 0 && node[0] != prev[0] && end0 >= 0) st.contig(node[0], end0 - lane, key_lo);
-                    if (node[1] >= 0 && node[1] != prev[1] && end1 >= 0) st.contig(node[1], end1 - 64 - lane, key_lo);
+                    const bool c0 = node[0] >= 0 && node[0] != prev[0] && end0 >= 0;
+                    const bool c1 = node[1] >= 0 && node[1] != prev[1] && end1 >= 0;
+                    if (REC && deferred) {  // every contig belongs to one_vi: add them up in scalar registers
+                        const int len0 = c0 ? end0 - lane : 0, len1 = c1 ? end1 - 64 - lane : 0;
+                        for (u64 sm = __ballot(c0); sm; sm &= sm - 1) {
+                            const int l = gs_readlane(len0, __builtin_ctzll(sm));
+                            def_contigs++;
+                            def_sq += l * l;
+                            def_max = l > def_max ? l : def_max;
+                        }
+                        for (u64 sm = __ballot(c1); sm; sm &= sm - 1) {
+                            const int l = gs_readlane(len1, __builtin_ctzll(sm));
+                            def_contigs++;
+                            def_sq += l * l;
+                            def_max = l > def_max ? l : def_max;
+                        }
+                    } else {
+                        if (c0) st.contig(node[0], end0 - lane, key_lo);
+                        if (c1) st.contig(node[1], end1 - 64 - lane, key_lo);
+                    }
                 }
                 // start of the contig that is still open at the end of this iteration
                 if (chg1)
                     cur_start = base + 127 - __builtin_clzll(chg1);
                 else if (chg0)
                     cur_start = base + 63 - __builtin_clzll(chg0);
-                // distinct hit nodes of this iteration, in order of first appearance
-                u64 m0 = hit0, m1 = hit1;
+                // distinct hit nodes of this iteration, in order of first appearance (the first one is known already;
+                // the candidate-path state is set up only if a second node follows)
                 if (!LONG) {
-                    // The first node is the only one in ~90 % of the reads that hit a store of species-specific k-mers:
-                    // its id and count stay in scalar registers (one_vi, one_cnt), and the candidate-path state is set
-                    // up only if a second node follows.
-                    const int j = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);
-                    one_vi = j < 64 ? gs_readlane(node[0], j) : gs_readlane(node[1], j - 64);
-                    const u64 e0 = __ballot(node[0] == one_vi), e1 = __ballot(node[1] == one_vi);
-                    one_cnt = __popcll(e0) + __popcll(e1);
-                    m0 &= ~e0;
-                    m1 &= ~e1;
-                    nd = 1;
-                    if (lane == 0) st.add(one_vi, GS_S_READS_1KMER, 1);  // first k-mer of this tax id in the read (:434-439)
+                    if (!REC) GS_FIRST_NODE()
+                    if (!(REC && deferred) && lane == 0) st.add(one_vi, GS_S_READS_1KMER, 1);  // first k-mer of this tax id in the read (:434-439)
                     if ((m0 | m1) != 0) {
                         if (lane == 0) {
                             dviA = one_vi;
@@ -670,7 +712,12 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             // tail flush (:455-473): the last contig if it is a hit contig
             if (carry_last >= 0) {
                 const int len = max - cur_start;
-                if (lane == 0) st.contig(carry_last, len, key_lo);
+                if (REC && deferred) {
+                    def_contigs++;
+                    def_sq += len * len;
+                    def_max = len > def_max ? len : def_max;
+                } else if (lane == 0)
+                    st.contig(carry_last, len, key_lo);
             }
             // ---- 4c. classification (:474-531)
             if (P.classify) {
@@ -802,7 +849,11 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                         const double mc = P.max_read_class_err;
                         if (mc < 0 || (mc >= 1 && (double)class_err <= mc) || ((double)class_err <= mc * (double)max)) {
                             out_flags |= GS_F_COUNTED;
-                            if (lane == 0) {
+                            if (REC && deferred) {  // (cn == one_vi: the only candidate)
+                                def_counted = 1;
+                                def_read_kmers = read_kmers;
+                                def_tax_err = tax_err;
+                            } else if (lane == 0) {
                                 const double err = (double)tax_err / (double)max;
                                 const double cerr = (double)class_err / (double)max;
                                 st.add(cn, GS_S_READS, 1);
@@ -817,6 +868,28 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     }
                 }
             }
+        }
+        if (REC && deferred && lane == 0) {
+            u64 rbase = cur[0], used = cur[1];
+            if (used == 64) {  // a fresh chunk of 64 records for this wave
+                rbase = atomicAdd(P.stat_rec_count, 64ULL);
+                used = 0;
+                cur[0] = rbase;
+            }
+            cur[1] = used + 1;
+            GsStatRec rec;
+            rec.vi = one_vi;
+            rec.contigs = def_contigs;
+            rec.kmers = one_cnt;
+            rec.sq = def_sq;
+            rec.max_key = ((u64)def_max << 40) | key_lo;
+            rec.counted = def_counted;
+            rec.read_kmers = def_read_kmers;
+            rec.read_len = L;
+            rec.pad = 0;
+            rec.err = (double)def_tax_err / (double)max;
+            rec.cerr = (double)(max - def_read_kmers) / (double)max;
+            P.stat_recs[rbase + used] = rec;
         }
     }
     if (lane == 0) {
@@ -866,9 +939,10 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         st.tin = s_tree + nv;                                                                         \
         st.tout = s_tree + 2 * nv;                                                                    \
     } else {                                                                                          \
-        st.sums = (u64 *)P.sums;                                                                      \
-        st.maxk = (u64 *)P.max_keys;                                                                  \
-        st.dsums = P.dsums;                                                                           \
+        const size_t copy = P.stat_copies > 1 ? (size_t)(blockIdx.x % (unsigned)P.stat_copies) : 0;   \
+        st.sums = (u64 *)P.sums + copy * (size_t)nv * GS_N_SUMS;                                      \
+        st.maxk = (u64 *)P.max_keys + copy * (size_t)nv;                                              \
+        st.dsums = P.dsums + copy * (size_t)nv * GS_N_DCOLS;                                          \
         st.parent = tree_lds ? s_tree : P.db.parent;                                                  \
         st.tin = tree_lds ? s_tree + nv : P.db.tin;                                                   \
         st.tout = tree_lds ? s_tree + 2 * nv : P.db.tout;                                             \
@@ -904,6 +978,11 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     const GsKernargPtr kp0 = (GsKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // text mode: a chunk that the device-side record scan refused is skipped as a whole (gs_text.hip)
     const int64_t n_reads = (P.skip != nullptr && *P.skip != 0) ? 0 : P.n_reads;
+    __shared__ GsRecCursor s_cur[GS_BLOCK / 64];
+    if (lane == 0) {
+        s_cur[wave_in_block][0] = 0;
+        s_cur[wave_in_block][1] = 64;
+    }
     for (int64_t r = wave_id; r < n_reads; r += n_waves) {
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
@@ -918,8 +997,13 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES, KC, WIDE>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
-                                                     s_g[wave_in_block]);
+        gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
+                                                     s_g[wave_in_block], s_cur[wave_in_block]);
+    }
+    if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const u64 base = s_cur[wave_in_block][0], used = s_cur[wave_in_block][1];
+        if (used < 64 && (u64)lane >= used) P.stat_recs[base + (u64)lane].vi = -1;
     }
     GS_STATS_EPILOGUE()
 }
@@ -947,11 +1031,70 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
         const uint32_t none[3] = {0, 0, 0};
-        gs_process_read<true, FROM_NODES, 0, WIDE>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
-                                                   (int)serial, none, s_g[wave_in_block]);
+        gs_process_read<true, FROM_NODES, 0, WIDE, false>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+                                                   (int)serial, none, s_g[wave_in_block], nullptr);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the deferred statistics (GsStatRec) of a batch into the counters: one LDS table per workgroup for the value indices
+// [lo, hi) -- this kernel has the whole LDS for it --, flushed with one global atomic per touched counter and workgroup
+// ---------------------------------------------------------------------------------------------------
+#define GS_REDUCE_VALUES 640
+__global__ __launch_bounds__(1024) void gs_stat_reduce_kernel(const GsStatRec *recs, const u64 *count, int lo, int hi, u64 *sums,
+                                                              u64 *maxk, double *dsums) {
+    const int64_t n = (int64_t)*count;  // (0 for a refused text chunk: the match kernel handed out no records)
+    if (n == 0) return;
+    __shared__ u64 s_sums[GS_REDUCE_VALUES * GS_N_SUMS];
+    __shared__ u64 s_max[GS_REDUCE_VALUES];
+    __shared__ double s_d[GS_REDUCE_VALUES * GS_N_DCOLS];
+    const int nvl = hi - lo;
+    for (int i = threadIdx.x; i < nvl * GS_N_SUMS; i += blockDim.x) s_sums[i] = 0;
+    for (int i = threadIdx.x; i < nvl; i += blockDim.x) s_max[i] = 0;
+    for (int i = threadIdx.x; i < nvl * GS_N_DCOLS; i += blockDim.x) s_d[i] = 0.0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int vi = recs[i].vi;
+        if (vi < lo || vi >= hi) continue;
+        const GsStatRec rc = recs[i];
+        u64 *row = s_sums + (size_t)(vi - lo) * GS_N_SUMS;
+        atomicAdd(&row[GS_S_READS_1KMER], 1ULL);
+        atomicAdd(&row[GS_S_KMERS], (u64)rc.kmers);
+        atomicAdd(&row[GS_S_CONTIGS], (u64)rc.contigs);
+        atomicAdd(&row[GS_S_CONTIG_LEN_SQ_SUM], (u64)rc.sq);
+        atomicMax(&s_max[vi - lo], rc.max_key);
+        if (rc.counted) {
+            double *dr = s_d + (size_t)(vi - lo) * GS_N_DCOLS;
+            atomicAdd(&row[GS_S_READS], 1ULL);
+            atomicAdd(&row[GS_S_READS_KMERS], (u64)rc.read_kmers);
+            atomicAdd(&row[GS_S_READS_BPS], (u64)rc.read_len);
+            atomicAdd(&dr[GS_D_ERR_SUM], rc.err);
+            atomicAdd(&dr[GS_D_ERR_SQ_SUM], rc.err * rc.err);
+            atomicAdd(&dr[GS_D_CLASS_ERR_SUM], rc.cerr);
+            atomicAdd(&dr[GS_D_CLASS_ERR_SQ_SUM], rc.cerr * rc.cerr);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvl * GS_N_SUMS; i += blockDim.x)
+        if (s_sums[i]) atomicAdd(&sums[(size_t)lo * GS_N_SUMS + i], s_sums[i]);
+    for (int i = threadIdx.x; i < nvl; i += blockDim.x)
+        if (s_max[i]) atomicMax(&maxk[lo + i], s_max[i]);
+    for (int i = threadIdx.x; i < nvl * GS_N_DCOLS; i += blockDim.x)
+        if (s_d[i] != 0.0) atomicAdd(&dsums[(size_t)lo * GS_N_DCOLS + i], s_d[i]);
+}
+
+// n_values <= GS_STAT_REC_MAX_VALUES: a pass of gs_stat_reduce_kernel per 640 values
+// n_max: upper bound of the record count (the kernels read the real one from *count)
+extern "C" hipError_t gs_launch_stat_reduce(const GsStatRec *recs, const void *count, int64_t n_max, int n_values, void *sums, void *maxk,
+                                             void *dsums, hipStream_t stream) {
+    if (n_max <= 0) return hipSuccess;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_max + 8191) / 8192, 512));
+    for (int lo = 0; lo < n_values; lo += GS_REDUCE_VALUES)
+        hipLaunchKernelGGL(gs_stat_reduce_kernel, dim3(grid), dim3(1024), 0, stream, recs, (const u64 *)count, lo,
+                           std::min(n_values, lo + GS_REDUCE_VALUES), (u64 *)sums, (u64 *)maxk, (double *)dsums);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

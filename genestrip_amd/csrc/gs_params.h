@@ -10,6 +10,23 @@
 #define GS_NV_LDS 128  // per-taxid counters are privatised in LDS up to this many value indices: 25 values 10.2 ms in LDS against 49 ms with global atomics on 25 hot counters; 211 values 11.5 ms in LDS (the footprint costs occupancy) against 10.7 ms global
 #endif
 #define GS_NV_TREE_LDS 2048   // up to here the taxonomy arrays (12 B per value) still travel in LDS
+#define GS_STAT_REC_MAX_VALUES 5120  // deferred statistics (GsStatRec): at most 8 passes of 640 values over the records
+
+// Deferred statistics of a read whose hit k-mers all carry ONE tax id (the usual case).  When the per-taxid counters do
+// not fit the LDS, such a read writes this record instead of ~20 global atomics, and gs_stat_reduce_kernel adds the
+// records up in LDS tables of its own (a kernel that has the whole LDS for them).
+struct GsStatRec {
+    int32_t vi;          // value index, -1: nothing deferred (no hit, several tax ids, long read)
+    int32_t contigs;
+    int64_t kmers;
+    int64_t sq;          // sum of squared contig lengths
+    uint64_t max_key;    // (longest contig << 40) | (2^40 - 1 - read number)
+    int32_t counted;     // 1: the read was classified to vi and passed the class-error gate
+    int32_t read_kmers;
+    int32_t read_len;
+    int32_t pad;
+    double err, cerr;
+};
 
 struct GsMatchParams {
     GsDbDev db;
@@ -35,8 +52,13 @@ struct GsMatchParams {
     // else 1: n_reads + 1 running offsets), and the whole launch is skipped when *skip != 0 (chunk refused by the
     // device-side record scan, gs_text.hip)
     int32_t off_stride;
-    int32_t pad1;
+    // direct global-atomic counters (n_values > GS_NV_LDS) exist in `stat_copies` copies, one per group of workgroups
+    // (blockIdx % stat_copies): the atomics of one tax id are spread over that many cache lines; the copies are
+    // folded into copy 0 before anything reads the accumulators
+    int32_t stat_copies;
     const uint32_t *skip;
+    GsStatRec *stat_recs;  // deferred statistics (global-atomic counters only) or nullptr: room for n_reads + 64 per wave
+    unsigned long long *stat_rec_count;  // records handed out so far (waves take them 64 at a time)
 };
 
 // device-side FASTQ record scan (gs_text.hip)
