@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -112,6 +112,8 @@ def lib():
         "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_merge": (ci, [vp, ci]), "gs_match_max_contig_reads": (ci, [vp, vp]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
+        "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
+        "gs_unroute_region": (ci, [vp, vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
         "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
         "gs_match_max_counts": (ci, [vp, vp]),
@@ -371,6 +373,20 @@ class FastqKMerMatcher:
     def probe_keys(self, keys, nodes, n_keys):
         _ready(keys, nodes)
         _check(lib().gs_match_probe_keys(self.h, C.c_void_p(keys.data_ptr()), n_keys, C.c_void_p(nodes.data_ptr())))
+
+    def encode_route(self, seq, offsets, pos_off, n_reads, n_parts, cap, send_keys, send_idx, nodes):
+        """gs_match_encode_route: returns (per-owner slot counts, overflow flag)"""
+        counts = (C.c_int64 * n_parts)()
+        over = C.c_int(0)
+        _ready(seq, offsets, pos_off, send_keys, send_idx, nodes)
+        _check(lib().gs_match_encode_route(self.h, C.c_void_p(seq.data_ptr()), C.c_void_p(offsets.data_ptr()), n_reads,
+                                           C.c_void_p(pos_off.data_ptr()), n_parts, cap, C.c_void_p(send_keys.data_ptr()),
+                                           C.c_void_p(send_idx.data_ptr()), C.c_void_p(nodes.data_ptr()), counts, C.byref(over)))
+        return list(counts), bool(over.value)
+
+    def unroute_region(self, idx, back, n, nodes):
+        _ready(idx, back, nodes)
+        _check(lib().gs_unroute_region(self.h, C.c_void_p(idx.data_ptr()), C.c_void_p(back.data_ptr()), n, C.c_void_p(nodes.data_ptr())))
 
     def route_keys(self, keys, n_keys, n_parts, send_keys, idx, nodes=None):
         """device counting sort of the valid keys by owner rank; returns the per-owner counts (python list).

@@ -924,6 +924,7 @@ struct gs_run {
     int64_t *d_sums = nullptr;   // [stat_copies][n_values][GS_N_SUMS]; copy 0 is the one everything outside the kernels sees
     int64_t *d_max = nullptr;
     double *d_dsums = nullptr;
+    u64 *d_route_cursors = nullptr;    // gs_match_encode_route: slots handed out per owner + overflow flag
     GsStatRec *d_stat_recs = nullptr;  // deferred statistics of the current batch (global-atomic counters only)
     u64 *d_stat_rec_count = nullptr;
     size_t stat_recs_cap = 0;
@@ -1161,6 +1162,7 @@ static void run_free(gs_run *run) {
     hipFree(run->d_dsums);
     hipFree(run->d_stat_recs);
     hipFree(run->d_stat_rec_count);
+    hipFree(run->d_route_cursors);
     hipFree(run->d_bitmap);
     hipFree(run->d_hit_counts);
     hipFree(run->d_unique);
@@ -1879,6 +1881,56 @@ extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *
     int grid = (int)std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4);
     if (grid < 1) grid = 1;
     HIP_TRY(gs_launch_encode(&P, grid, run->stream));
+    return GS_OK;
+}
+
+extern "C" hipError_t gs_launch_encode_route(const GsEncodeParams *P, const GsRouteParams *R, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_unroute_region(const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes, hipStream_t stream);
+
+extern "C" int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
+                                     int n_parts, int64_t cap, uint64_t *send_keys, uint32_t *send_idx, int32_t *nodes,
+                                     int64_t *counts, int *overflow) {
+    if (!run || !counts || !overflow || n_parts < 1 || n_parts > 64 || cap < GS_ROUTE_CHUNK || (cap % GS_ROUTE_CHUNK) != 0 ||
+        (n_reads > 0 && (!seq || !offsets || !pos_off || !send_keys || !send_idx || !nodes)))
+        return fail(GS_E_INVALID, "bad argument (cap must be a multiple of 2048)");
+    if (run->db->n_rec > 0) return fail(GS_E_STATE, "the split pipeline needs a partition store (gs_db_create_part): this store keeps k-mers in super-k-mer records");
+    for (int i = 0; i < n_parts; i++) counts[i] = 0;
+    *overflow = 0;
+    if (n_reads <= 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (!run->d_route_cursors) HIP_TRY(hipMalloc((void **)&run->d_route_cursors, sizeof(u64) * 65));
+    HIP_TRY(hipMemsetAsync(run->d_route_cursors, 0, sizeof(u64) * 65, run->stream));
+    GsEncodeParams P{};
+    P.k = run->db->info.k;
+    P.seq = seq;
+    P.off = offsets;
+    P.n_reads = n_reads;
+    P.pos_off = (const unsigned long long *)pos_off;
+    P.keys = nullptr;
+    P.mgate = run->db->dev.mgate;
+    P.mgate_bits = run->db->dev.mgate_bits;
+    GsRouteParams R{};
+    R.n_parts = n_parts;
+    R.cap = (unsigned long long)cap;
+    R.cursors = (unsigned long long *)run->d_route_cursors;
+    R.send_keys = (unsigned long long *)send_keys;
+    R.send_idx = send_idx;
+    R.nodes = nodes;
+    int grid = (int)std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4);
+    if (grid < 1) grid = 1;
+    HIP_TRY(gs_launch_encode_route(&P, &R, grid, run->stream));
+    u64 h[65];
+    HIP_TRY(hipMemcpyAsync(h, run->d_route_cursors, sizeof(h), hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    for (int i = 0; i < n_parts; i++) counts[i] = (int64_t)std::min<u64>(h[i], (u64)cap);
+    *overflow = h[64] != 0;
+    return GS_OK;
+}
+
+extern "C" int gs_unroute_region(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes) {
+    if (!run || (n > 0 && (!idx || !back || !nodes))) return fail(GS_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(gs_launch_unroute_region(idx, back, n, nodes, run->stream));
     return GS_OK;
 }
 

@@ -1194,6 +1194,139 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
     }
 }
 
+// ---- encode and routing in one pass: what gs_encode_kernel + gs_route_count_kernel + gs_route_scatter_kernel do through
+// an 8-byte key per k-mer POSITION that is written once and read twice.  Here a wave appends the keys of its reads
+// straight to the owners' send regions: it holds one chunk of GS_ROUTE_CHUNK slots per owner (cursor in LDS), takes a
+// new one with a single global atomic when the chunk cannot take a sub-round's keys (the rest of the old chunk becomes
+// sentinels), and pads its open chunks at the end.  Keys leave in no particular order inside an owner's region.
+template <int KC>
+__global__ __launch_bounds__(GS_BLOCK) void gs_encode_route_kernel(GsEncodeParams P, GsRouteParams R) {
+    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];
+    __shared__ unsigned long long s_base[GS_BLOCK / 64][64];  // per wave and owner: base of the chunk in hand
+    __shared__ uint32_t s_used[GS_BLOCK / 64][64];            // slots used in it (GS_ROUTE_CHUNK: none in hand)
+    const int lane = gs_lane();
+    const int wv = threadIdx.x >> 6;
+    uint32_t *wave_g = s_g[wv];
+    const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wv;
+    const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
+    const int k = KC ? KC : P.k;
+    const uint32_t kmask = (1u << k) - 1u;
+    const int n_parts = R.n_parts;
+    if (lane < n_parts) {
+        s_base[wv][lane] = 0;
+        s_used[wv][lane] = GS_ROUTE_CHUNK;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
+        const u64 off = P.off[r];
+        const int L = (int)(P.off[r + 1] - off);
+        const u64 pb = P.pos_off[r];
+        const int max = L - k + 1;
+        const uint8_t *rd = P.seq + off;
+        for (int base = 0; base < max; base += 128) {
+            u64 Bhi[3], Blo[3], Bbad[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) gs_load_word(rd, L, (base >> 6) + i, lane, Bhi[i], Blo[i], Bbad[i]);
+            u64 key[2];
+            uint32_t fhi[2], flo[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                fhi[s] = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
+                flo[s] = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
+                const uint32_t wbad = (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask;
+                key[s] = wbad ? GS_KEY_INVALID : gs_kmer_hash(fhi[s], flo[s], k, kmask);
+            }
+            if (P.mgate != nullptr) {
+                int mp[2];
+                uint32_t cf[2];
+                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
+                        const uint32_t gh = gs_canon_hash(cf[s] >> 1);
+                        const uint32_t bits = gs_mgate_bits(gh);
+                        if ((P.mgate[gs_mgate_word(gh, P.mgate_bits)] & bits) != bits) key[s] = GS_KEY_MISS;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int p = base + 64 * s + lane;
+                const bool in = p < max;
+                const bool routed = in && GS_KEY_ROUTED(key[s]);
+                if (in) R.nodes[pb + (u64)p] = key[s] == GS_KEY_INVALID ? GS_NODE_INVALID : GS_NODE_MISS;  // (routed: overwritten later)
+                const int owner = routed ? (int)((key[s] >> GS_OWNER_SHIFT) % (u64)n_parts) : -1;
+                u64 todo = __ballot(routed);
+                while (todo) {  // one owner after the other
+                    const int o = gs_readlane(owner, __builtin_ctzll(todo));
+                    const u64 mine = __ballot(owner == o);
+                    const uint32_t cnt = (uint32_t)__popcll(mine);
+                    uint32_t used = s_used[wv][o];
+                    u64 cbase = s_base[wv][o];
+                    if (used + cnt > GS_ROUTE_CHUNK) {
+                        // the rest of the chunk in hand becomes sentinels; a new chunk
+                        if (used < GS_ROUTE_CHUNK && cbase + GS_ROUTE_CHUNK <= R.cap)
+                            for (uint32_t j = used + (uint32_t)lane; j < GS_ROUTE_CHUNK; j += 64) {
+                                R.send_keys[(u64)o * R.cap + cbase + j] = GS_KEY_INVALID;
+                                R.send_idx[(u64)o * R.cap + cbase + j] = 0xffffffffu;
+                            }
+                        u64 nb = 0;
+                        if (lane == 0) nb = atomicAdd(&R.cursors[o], (u64)GS_ROUTE_CHUNK);
+                        cbase = ((u64)(uint32_t)gs_rfl((int)(nb >> 32)) << 32) | (uint32_t)gs_rfl((int)nb);
+                        used = 0;
+                        if (lane == 0) s_base[wv][o] = cbase;
+                    }
+                    const bool fits = cbase + GS_ROUTE_CHUNK <= R.cap;  // (else: the region is full, the host falls back)
+                    if (!fits && lane == 0) R.cursors[64] = 1;
+                    if (owner == o && fits) {
+                        const u64 at = (u64)o * R.cap + cbase + used + (u64)__popcll(mine & ((1ULL << lane) - 1));
+                        R.send_keys[at] = key[s];
+                        R.send_idx[at] = (uint32_t)(pb + (u64)p);
+                    }
+                    if (lane == 0) s_used[wv][o] = used + cnt;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    todo &= ~mine;
+                }
+            }
+        }
+    }
+    // pad the chunks that are still open
+    for (int o = 0; o < n_parts; o++) {
+        const uint32_t used = s_used[wv][o];
+        const u64 cbase = s_base[wv][o];
+        if (used < GS_ROUTE_CHUNK && cbase + GS_ROUTE_CHUNK <= R.cap)
+            for (uint32_t j = used + (uint32_t)lane; j < GS_ROUTE_CHUNK; j += 64) {
+                R.send_keys[(u64)o * R.cap + cbase + j] = GS_KEY_INVALID;
+                R.send_idx[(u64)o * R.cap + cbase + j] = 0xffffffffu;
+            }
+    }
+}
+
+// scatter of the answers of one owner region: nodes[idx[i]] = back[i] (sentinel slots skipped)
+__global__ __launch_bounds__(256) void gs_unroute_region_kernel(const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t at = idx[i];
+        if (at != 0xffffffffu) nodes[at] = back[i];
+    }
+}
+
+extern "C" hipError_t gs_launch_encode_route(const GsEncodeParams *P, const GsRouteParams *R, int grid, hipStream_t stream) {
+    if (P->k == 31)
+        hipLaunchKernelGGL(gs_encode_route_kernel<31>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, *R);
+    else
+        hipLaunchKernelGGL(gs_encode_route_kernel<0>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P, *R);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_launch_unroute_region(const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gs_unroute_region_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 256 * 16)), dim3(256), 0, stream, idx, back, n, nodes);
+    return hipGetLastError();
+}
+
 // ---- routing of the keys to their owner ranks (counting sort by owner; order inside an owner group is arbitrary,
 // idx remembers where every routed key came from)
 __global__ __launch_bounds__(256) void gs_route_count_kernel(const u64 *keys, int64_t n, int n_parts, u64 *counts) {

@@ -10,7 +10,7 @@
 #define GS_NV_LDS 128  // per-taxid counters are privatised in LDS up to this many value indices: 25 values 10.2 ms in LDS against 49 ms with global atomics on 25 hot counters; 211 values 11.5 ms in LDS (the footprint costs occupancy) against 10.7 ms global
 #endif
 #define GS_NV_TREE_LDS 2048   // up to here the taxonomy arrays (12 B per value) still travel in LDS
-#define GS_STAT_REC_MAX_VALUES 5120  // deferred statistics (GsStatRec): at most 8 passes of 640 values over the records
+#define GS_STAT_REC_MAX_VALUES 10240  // deferred statistics (GsStatRec): at most 16 passes of 640 values over the records
 
 // Deferred statistics of a read whose hit k-mers all carry ONE tax id (the usual case).  When the per-taxid counters do
 // not fit the LDS, such a read writes this record instead of ~20 global atomics, and gs_stat_reduce_kernel adds the
@@ -132,4 +132,18 @@ struct GsEncodeParams {
     const uint32_t *mgate;              // the store's minimizer gate (covers every partition's keys) or NULL
     uint32_t mgate_bits;
     uint32_t pad2;
+};
+
+// fused encode + routing of the DB-partitioned mode (gs_encode_route_kernel): owner o's keys go to
+// send_keys[o * cap ..), handed out to the waves in chunks of GS_ROUTE_CHUNK slots; idx = position of the key in the
+// batch (~0: a slot that was handed out but not used, its key is the invalid-window sentinel)
+#define GS_ROUTE_CHUNK 2048
+struct GsRouteParams {
+    int32_t n_parts;
+    int32_t pad;
+    unsigned long long cap;        // slots per owner region (a multiple of GS_ROUTE_CHUNK)
+    unsigned long long *cursors;   // [n_parts] slots handed out per owner; [64] = overflow flag
+    unsigned long long *send_keys;
+    uint32_t *send_idx;
+    int32_t *nodes;                // per k-mer position: node of the positions that are not routed
 };

@@ -163,7 +163,75 @@ def exchange_all_to_all(send, send_counts, group=None):
     return recv, rc
 
 
-def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, group=None, class_vi=None, flags=None):
+ROUTE_CHUNK = 2048  # genestrip_amd/csrc/gs_params.h: GS_ROUTE_CHUNK
+
+
+def _all_to_all_views(recv, recv_counts, send_views, send_counts, group):
+    """variable-size all-to-all whose send side is a list of views (one region per destination).  RCCL takes the list as
+    it is (grouped send / recv, no staging copy); other backends (gloo in the rehearsal tests) get one contiguous buffer"""
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(list(torch.split(recv, recv_counts)), send_views, group=group)
+    else:
+        send = torch.cat(send_views) if send_views else recv.new_empty(0)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+
+
+def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, group=None, class_vi=None, flags=None,
+                            cap=None):
+    """One batch in DB-partitioned mode on this rank (matcher's store = this rank's partition).
+    seq / offsets: device tensors (uint8 / int64).  Collective: every rank of the group must call it.
+    cap: slots per owner region (tests; default: sized from the batch).
+
+    encode + routing in one kernel (gs_match_encode_route: the keys go straight into one send region per owner, in
+    chunks of 2048 slots, unused slots carry sentinels) -> all-to-all of the regions -> probe on the owner -> all-to-all
+    back -> scatter per region -> reduce.  If a region overflows (keys that all hash to one owner: degenerate input)
+    the batch goes through the unfused steps (partitioned_match_batch_unfused)."""
+    world = dist.get_world_size(group)
+    dev = seq.device
+    pos_off = position_offsets(offsets[:n_reads + 1], k)
+    n_keys = int(pos_off[-1].item())
+    if n_keys == 0:
+        nodes = torch.empty(1, dtype=torch.int32, device=dev)
+        matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
+        matcher.sync()
+        return
+    # room per owner: its fair share of ALL positions with a quarter on top (only gate-passing k-mers are routed, and a
+    # chunk is given up when it cannot take the keys of a sub-round) + one chunk per wave that may stay partly used
+    if cap is None:
+        n_waves = min(256 * 8 * 4, (n_reads + 3) // 4 * 4)
+        cap = n_keys // world + n_keys // (4 * world) + (n_waves + 2) * ROUTE_CHUNK
+    cap = (cap + ROUTE_CHUNK - 1) // ROUTE_CHUNK * ROUTE_CHUNK
+    send_keys = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    send_idx = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    nodes = torch.empty(n_keys, dtype=torch.int32, device=dev)
+    counts, overflow = matcher.encode_route(seq, offsets, pos_off, n_reads, world, cap, send_keys, send_idx, nodes)
+    flag = torch.tensor([int(overflow)], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)  # every rank takes the same route
+    if int(flag.item()):
+        return partitioned_match_batch_unfused(matcher, k, seq, offsets, n_reads, first_read_no, group, class_vi, flags)
+    sc = torch.tensor(counts, dtype=torch.int64, device=dev)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcl = rc.tolist()
+    send_list = [send_keys[o * cap:o * cap + counts[o]] for o in range(world)]
+    n_recv = sum(rcl)
+    recv_keys = torch.empty(max(n_recv, 1), dtype=torch.int64, device=dev)
+    _all_to_all_views(recv_keys[:n_recv], rcl, send_list, counts, group)
+    recv_nodes = torch.empty(max(n_recv, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    matcher.probe_keys(recv_keys, recv_nodes, n_recv)
+    matcher.sync()
+    back = torch.empty(max(sum(counts), 1), dtype=torch.int32, device=dev)
+    back_list = list(torch.split(back[:sum(counts)], counts))
+    _all_to_all_views(back[:sum(counts)], counts, list(torch.split(recv_nodes[:n_recv], rcl)), rcl, group)
+    torch.cuda.synchronize(dev)
+    for o in range(world):
+        matcher.unroute_region(send_idx[o * cap:o * cap + counts[o]], back_list[o], counts[o], nodes)
+    matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
+    matcher.sync()
+
+
+def partitioned_match_batch_unfused(matcher, k, seq, offsets, n_reads, first_read_no=0, group=None, class_vi=None, flags=None):
     """One batch in DB-partitioned mode on this rank (matcher's store = this rank's partition).
     seq / offsets: device tensors (uint8 / int64).  Collective: every rank of the group must call it."""
     world = dist.get_world_size(group)

@@ -251,6 +251,18 @@ int gs_db_create_part(gs_db **out, int device, int k, int64_t n_entries, const i
 int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
                     uint64_t *keys);
 int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32_t *nodes);
+/* gs_match_encode + gs_route_keys in one pass, without the 8-byte key per k-mer position in between: the keys of owner o
+ * go to send_keys[o * cap ..), send_idx holds their position in the batch (~0: a slot that was handed out to a wave but
+ * not used -- its key is the invalid-window sentinel, the owner answers it with -2 and gs_unroute_region skips it); the
+ * waves take slots 2048 at a time, so counts[o] (HOST array, slots handed out for owner o) is a multiple of 2048 and at
+ * most cap; `nodes` receives the node of every position that is NOT routed (the routed ones are overwritten by
+ * gs_unroute_region).  cap: a multiple of 2048; *overflow != 0: some region was too small, nothing of the batch may be
+ * used (call gs_match_encode + gs_route_keys instead).  Synchronous. */
+int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
+                          int n_parts, int64_t cap, uint64_t *send_keys, uint32_t *send_idx, int32_t *nodes, int64_t *counts,
+                          int *overflow);
+/* nodes[idx[i]] = back[i] for the n answers of one owner region (idx ~0 skipped); asynchronous on the run's stream */
+int gs_unroute_region(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes);
 int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int64_t first_read_no,
                     const uint64_t *pos_off, const int32_t *nodes, int32_t *class_vi, uint8_t *flags);
 /* Routing helpers around the two all-to-alls (device counting sort by owner rank, synchronous):

@@ -174,6 +174,86 @@ def test_partitioned_collective_path_single_rank(sdb):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_fused_encode_route_equals_encode_plus_route(sdb, world):
+    """gs_match_encode_route against gs_match_encode + gs_route_keys: the same keys with the same positions in every
+    owner's region (in any order), sentinels in the unused slots, the same nodes for the positions that are not routed"""
+    seq, off = _reads(sdb, 5000)
+    n = len(off) - 1
+    dev = torch.device("cuda")
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=world, part=0, partition=True)
+    m = ga.FastqKMerMatcher(store)
+    dseq = torch.from_numpy(seq).to(dev)
+    doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+    pos_off = gd.position_offsets(doff, 31)
+    nk = int(pos_off[-1].item())
+    keys = torch.empty(nk, dtype=torch.int64, device=dev)
+    m.encode(dseq, doff, pos_off, keys, n)
+    m.sync()
+    send = torch.empty(nk, dtype=torch.int64, device=dev)
+    idx = torch.empty(nk, dtype=torch.int32, device=dev)
+    nodes0 = torch.full((nk,), -9, dtype=torch.int32, device=dev)
+    counts0 = m.route_keys(keys, nk, world, send, idx, nodes0)
+    cap = ((nk // world) * 2 + 8192 * gd.ROUTE_CHUNK + gd.ROUTE_CHUNK - 1) // gd.ROUTE_CHUNK * gd.ROUTE_CHUNK
+    sk = torch.empty(world * cap, dtype=torch.int64, device=dev)
+    si = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    nodes1 = torch.full((nk,), -9, dtype=torch.int32, device=dev)
+    counts1, over = m.encode_route(dseq, doff, pos_off, n, world, cap, sk, si, nodes1)
+    assert not over
+    start = 0
+    for o in range(world):
+        assert counts1[o] % gd.ROUTE_CHUNK == 0 and counts1[o] >= counts0[o]
+        rk, ri = sk[o * cap:o * cap + counts1[o]].cpu().numpy(), si[o * cap:o * cap + counts1[o]].cpu().numpy()
+        used = ri != -1
+        assert np.all(rk[~used] == -1)  # sentinels
+        want_k, want_i = send[start:start + counts0[o]].cpu().numpy(), idx[start:start + counts0[o]].cpu().numpy()
+        a, b = np.argsort(ri[used], kind="stable"), np.argsort(want_i, kind="stable")
+        assert np.array_equal(ri[used][a], want_i[b]) and np.array_equal(rk[used][a], want_k[b])
+        start += counts0[o]
+    routed = (keys >= 0).cpu().numpy()
+    assert np.array_equal(nodes1.cpu().numpy()[~routed], nodes0.cpu().numpy()[~routed])
+    # a region that is too small is reported, not overrun
+    small = gd.ROUTE_CHUNK * 4
+    sk2 = torch.full((world * small + 1,), 12345, dtype=torch.int64, device=dev)
+    si2 = torch.empty(world * small, dtype=torch.int32, device=dev)
+    c2, over2 = m.encode_route(dseq, doff, pos_off, n, world, small, sk2, si2, nodes1)
+    assert over2 and all(c <= small for c in c2) and int(sk2[-1].item()) == 12345
+    m.close()
+    store.close()
+
+
+def test_partitioned_batch_fused_unfused_and_overflow_fallback(sdb):
+    """partitioned_match_batch under a 1-rank RCCL group: the fused route, the explicit unfused route and the fallback
+    when a region is too small all end in the oracle's table"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        seq, off = _reads(sdb, 3000)
+        n = len(off) - 1
+        want, wcv, wfl = _oracle(sdb, seq, off)
+        store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=1, part=0, partition=True)
+        dseq = torch.from_numpy(seq).to(dev)
+        doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+        for how in ("fused", "unfused", "overflow"):
+            m = ga.FastqKMerMatcher(store)
+            cv = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+            if how == "unfused":
+                gd.partitioned_match_batch_unfused(m, 31, dseq, doff, n, 0, class_vi=cv, flags=fl)
+            else:
+                gd.partitioned_match_batch(m, 31, dseq, doff, n, 0, class_vi=cv, flags=fl, cap=None if how == "fused" else gd.ROUTE_CHUNK)
+            table, _ = m.finish()
+            assert np.array_equal(table, want), how
+            assert np.array_equal(cv.cpu().numpy(), wcv) and np.array_equal(fl.cpu().numpy(), wfl), how
+            m.close()
+        store.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("mode", ["partitioned", "sharded"])
 def test_two_rank_bench_flow_over_gloo(mode):
     """bench.py's multi-rank control flow (barriers, routing all-to-alls or state merge, rank-0-only legs) with two
