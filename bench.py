@@ -89,9 +89,15 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--check-reads", type=int, default=200_000, help="reads cross-checked against the oracle")
-    ap.add_argument("--mode", choices=["sharded", "partitioned"], default="sharded",
+    ap.add_argument("--mode", choices=["sharded", "striped", "partitioned"], default="sharded",
                     help="sharded: store replicated, reads sharded (configs[1]/[3], the default bench line); "
-                         "partitioned: store split over the ranks by key hash, k-mers routed by all-to-all (configs[4])")
+                         "striped: ONE store, its record table split over the GPUs' HBM, foreign record lines loaded over "
+                         "xGMI by the same fused kernel, reads sharded (configs[4]); "
+                         "partitioned: round 1's split pipeline, store split by key hash, k-mers routed by all-to-all")
+    ap.add_argument("--stripes", type=int, default=8,
+                    help="--mode striped with ONE rank: stripes of the record table, all in this GPU's HBM (prices the "
+                         "stripe arithmetic of the kernel; with N ranks there is one stripe per rank)")
+    ap.add_argument("--genera", type=int, default=0, help="size of the synthetic store: genera of 20 species (0: configs[1]'s store)")
     ap.add_argument("--legs", default="main,large,filter,e2e",
                     help="comma list; large / filter / e2e are the extra N = 1 objects (main always runs)")
     args = ap.parse_args()
@@ -102,7 +108,7 @@ def main():
 
     import genestrip_amd as ga
     from genestrip_amd import synth
-    from genestrip_amd.distributed import merge_run_state, partitioned_finish, partitioned_match_batch
+    from genestrip_amd.distributed import merge_run_state, partitioned_finish, partitioned_match_batch, striped_store
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -122,6 +128,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearsal else dev  # where the small control tensors of the collectives live
     partitioned = args.mode == "partitioned"
+    striped = args.mode == "striped"
     force_merge = os.environ.get("GS_BENCH_FORCE_MERGE", "") == "1" or partitioned
     use_dist = world > 1 or force_merge
     if use_dist:
@@ -133,9 +140,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- inputs: store replica per GPU, this rank's slice of the read stream generated directly in HBM
-    db = synth.SynthDB(k=K)
-    store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, device=local_rank,
-                               n_parts=world if partitioned else 1, part=rank if partitioned else 0, partition=partitioned)
+    db = synth.SynthDB(k=K, genera=args.genera, species_per_genus=20) if args.genera else synth.SynthDB(k=K)
+    others = []
+    if striped and world > 1:  # one stripe per rank, the others attached through IPC handles
+        store = striped_store(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, device=local_rank)
+    elif striped:
+        others = ga.DeviceKMerStore.striped(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, devices=(local_rank,) * args.stripes)
+        store = others.pop(0)
+    else:
+        store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, device=local_rank,
+                                   n_parts=world if partitioned else 1, part=rank if partitioned else 0, partition=partitioned)
     info = store.info
     n = args.reads
     first = rank * n
@@ -206,7 +220,7 @@ def main():
     # measured memory-side traffic of one launch: rocprofv3 --pmc passes of this same command (only valid for the
     # default workload the profile was taken on)
     traffic, traffic_src = (None, None)
-    if n == 10_000_000 and not partitioned:
+    if n == 10_000_000 and not partitioned and not striped and not args.genera:
         traffic, traffic_src = _pmc_traffic("match")
 
     out = {
@@ -215,11 +229,14 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "match: %d synthetic 150 bp reads per GPU, k=31, %d-k-mer / %d-taxid store resident in HBM "
-                               "(BASELINE.json configs[1])" % (n, db.n_entries, len(db.species_vi)),
+                               "(BASELINE.json %s)" % (n, db.n_entries, len(db.species_vi),
+                                                       "configs[4]: a store spread over the GPUs' HBM" if striped else "configs[1]"),
                    "reads_per_gpu": n, "read_len": READ_LEN, "k": K, "store_kmers": int(db.n_entries),
                    "store_record_bytes": int(info.rec_bytes), "store_table_bytes": int(info.table_bytes),
                    "gate_bytes": int(info.mgate_bytes or info.gate_bytes),
                    "parallelism": ("DB-partitioned x%d, k-mers routed by all-to-all" % world) if partitioned
+                   else ("reads sharded x%d, ONE store with its record table in %d stripes (%s)"
+                         % (world, info.n_stripes, "one per GPU, foreign lines over xGMI" if world > 1 else "all in this GPU's HBM")) if striped
                    else ("read-sharded x%d, store replicated" % world)},
         # `frac` follows SURVEY 8(d)'s convention (one 64-byte line per k-mer position over the HBM peak).  For this
         # store it is NOT an HBM measurement: the 64 MiB table sits in the 256 MiB Infinity Cache and the minimizer gate
@@ -298,7 +315,7 @@ def main():
                           "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
             del seq, off
         odb.close()
-        if world == 1 and not partitioned:
+        if world == 1 and not partitioned and not striped and not args.genera:
             if "e2e" in legs:
                 out["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
             m.close()

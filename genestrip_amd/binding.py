@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -54,7 +54,8 @@ class DbInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("n_values", C.c_int32), ("n_entries", C.c_int64), ("n_stored", C.c_int64),
                 ("n_buckets", C.c_int64), ("table_bytes", C.c_int64), ("max_displacement", C.c_int32),
                 ("value_bits", C.c_int32), ("gate_bytes", C.c_int64), ("mgate_bytes", C.c_int64),
-                ("rec_bytes", C.c_int64), ("n_in_records", C.c_int64)]
+                ("rec_bytes", C.c_int64), ("n_in_records", C.c_int64), ("n_stripes", C.c_int32), ("stripe", C.c_int32),
+                ("stripe_bytes", C.c_int64)]
 
 
 class _MatchCfg(C.Structure):
@@ -111,6 +112,10 @@ def lib():
         "gs_match_destroy": (ci, [vp]), "gs_match_device_state": (ci, [vp, vp, vp, vp, vp, vp]),
         "gs_match_or_bitmap": (ci, [vp, vp, i64]), "gs_match_merge": (ci, [vp, ci]), "gs_match_max_contig_reads": (ci, [vp, vp]), "gs_match_kernel_time": (ci, [vp, vp, vp]),
         "gs_db_create_part": (ci, [vp, ci, ci, i64, vp, vp, i32, vp, ci, ci]),
+        "gs_db_create_striped": (ci, [vp, vp, ci, ci, i64, vp, vp, i32, vp]),
+        "gs_db_create_stripe": (ci, [vp, ci, ci, ci, ci, i64, vp, vp, i32, vp]),
+        "gs_db_stripe_export": (ci, [vp, vp]),
+        "gs_db_stripe_attach": (ci, [vp, ci, vp]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
         "gs_unroute_region": (ci, [vp, vp, vp, i64, vp]),
@@ -203,6 +208,57 @@ class DeviceKMerStore:
             _check(lib().gs_db_create(C.byref(self.h), device, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
                                       vidx.ctypes.data_as(C.c_void_p), n_values,
                                       None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+
+    @staticmethod
+    def _arrays(kmers, value_idx, n_values, parent_vi):
+        kmers = np.ascontiguousarray(kmers, dtype=np.int64)
+        vidx = np.ascontiguousarray(value_idx, dtype=np.int32)
+        if len(kmers) != len(vidx):
+            raise ValueError("kmers / value_idx length mismatch")
+        pv = None if parent_vi is None else np.ascontiguousarray(parent_vi, dtype=np.int32)
+        if pv is not None and len(pv) != n_values:
+            raise ValueError("parent_vi must have n_values entries")
+        return kmers, vidx, pv
+
+    @classmethod
+    def _wrap(cls, h, k, n_values, device):
+        self = cls.__new__(cls)
+        self.h, self.k, self.n_values, self.device = h, k, n_values, device
+        return self
+
+    @classmethod
+    def striped(cls, k, kmers, value_idx, n_values, parent_vi=None, devices=(0, 0)):
+        """gs_db_create_striped: ONE record table split over `devices` (stripe p in the HBM of devices[p]; a device may
+        repeat), gates / overflow table / tree on each.  Returns one handle per stripe; every handle serves the fused
+        kernels on its device and reads foreign stripes over peer access."""
+        kmers, vidx, pv = cls._arrays(kmers, value_idx, n_values, parent_vi)
+        n = len(devices)
+        out = (C.c_void_p * n)()
+        dev = (C.c_int * n)(*devices)
+        _check(lib().gs_db_create_striped(out, dev, n, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                          vidx.ctypes.data_as(C.c_void_p), n_values,
+                                          None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+        return [cls._wrap(C.c_void_p(out[p]), k, n_values, devices[p]) for p in range(n)]
+
+    @classmethod
+    def stripe(cls, k, kmers, value_idx, n_values, parent_vi=None, device=0, n_stripes=2, stripe=0):
+        """gs_db_create_stripe: this process's stripe of a striped store (one process per GPU); the other stripes are
+        attached from their owners' handles: export_stripe() -> all-gather -> attach_stripe()
+        (genestrip_amd.distributed.striped_store does all of it)."""
+        kmers, vidx, pv = cls._arrays(kmers, value_idx, n_values, parent_vi)
+        h = C.c_void_p()
+        _check(lib().gs_db_create_stripe(C.byref(h), device, n_stripes, stripe, k, len(kmers), kmers.ctypes.data_as(C.c_void_p),
+                                         vidx.ctypes.data_as(C.c_void_p), n_values,
+                                         None if pv is None else pv.ctypes.data_as(C.c_void_p)))
+        return cls._wrap(h, k, n_values, device)
+
+    def export_stripe(self):
+        buf = C.create_string_buffer(64)
+        _check(lib().gs_db_stripe_export(self.h, buf))
+        return buf.raw
+
+    def attach_stripe(self, stripe, handle):
+        _check(lib().gs_db_stripe_attach(self.h, stripe, C.c_char_p(bytes(handle))))
 
     @classmethod
     def load(cls, path, device=0):

@@ -9,8 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "gs_layout.h"
@@ -23,6 +25,8 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
                                               int32_t n_values, u64 *unique, const u64 *rec, int64_t n_rec, hipStream_t stream);
+extern "C" hipError_t gs_launch_rec_unique_count(const u64 *rec, const uint32_t *bitmap_rec, int64_t n_rec, int32_t n_values,
+                                                  u64 *unique, hipStream_t stream);
 extern "C" hipError_t gs_launch_clear_seen(u64 *table, int64_t n_slots, u64 *rec, int64_t n_rec, hipStream_t stream);
 extern "C" hipError_t gs_launch_bitmap_extract(const u64 *table, int64_t n_slots, uint32_t *bitmap, const u64 *rec, int64_t n_rec,
                                                 hipStream_t stream);
@@ -115,14 +119,47 @@ struct gs_db {
     // destroy the store before its runs: gs_db_destroy then only marks it, and the last gs_match_destroy frees it.
     int live_runs = 0;
     bool destroy_pending = false;
+    // striped store (gs_layout.h, GsDbDev::rec_biased): d_rec is THIS handle's stripe, buckets [rec_first, rec_first +
+    // rec_local) of the n_rec buckets; stripe_base[q] = where this process sees stripe q
+    int n_parts = 0, part = 0;
+    int64_t rec_first = 0, rec_local = 0;
+    const u64 *stripe_base[GS_MAX_STRIPES] = {};
+    unsigned present = 0;                      // bit q: stripe q is known
+    std::shared_ptr<struct StripeGroup> group; // all stripes in one process: they are freed with the last handle
+    std::vector<void *> ipc_opened;            // stripes of other processes (hipIpcOpenMemHandle)
+    bool striped() const { return n_parts > 1; }
+    bool complete() const { return n_parts <= 1 || present == (1u << n_parts) - 1u; }
 };
+
+struct StripeGroup {
+    std::vector<std::pair<int, void *>> allocs;
+    ~StripeGroup() {
+        for (auto &a : allocs) {
+            hipSetDevice(a.first);
+            hipFree(a.second);
+        }
+    }
+};
+
+// the sweeps over the records' seen bits (extract / clear / count) do not apply to a striped store: its record lines are
+// read-only and the seen bits are written straight into the run's bitmap
+static inline u64 *sweep_rec(const gs_db *db) { return db->striped() ? nullptr : db->d_rec; }
+static inline int64_t sweep_n_rec(const gs_db *db) { return db->striped() ? 0 : db->n_rec; }
+
+static void db_set_stripe(gs_db *db, int q, const u64 *base) {
+    db->stripe_base[q] = base;
+    db->present |= 1u << q;
+    // (biased: the kernels add bucket * GS_REC_WORDS with the GLOBAL bucket number)
+    db->dev.rec_biased[q] = base - (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q) * GS_REC_WORDS;
+}
 
 static void db_free(gs_db *db) {
     hipSetDevice(db->device);
+    for (void *p : db->ipc_opened) hipIpcCloseMemHandle(p);
     hipFree(db->d_table);
     hipFree(db->d_gate);
     hipFree(db->d_mgate);
-    hipFree(db->d_rec);
+    if (!db->group) hipFree(db->d_rec);
     hipFree(db->d_tree);
     delete db;
 }
@@ -152,7 +189,8 @@ static int bits_for(u64 v) {
 }
 
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused);
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused, int stripes = 1,
+                          const int *stripe_devices = nullptr, int stripe_only = -1);
 
 extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                             int32_t n_values, const int32_t *parent_vi) try {
@@ -173,12 +211,68 @@ extern "C" int gs_db_create_part(gs_db **out, int device, int k, int64_t n, cons
     return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
+// ---- striped store (include/gsgpu.h)
+extern "C" int gs_db_create_striped(gs_db **out, const int *devices, int n_stripes, int k, int64_t n, const int64_t *kmers,
+                                    const int32_t *vidx, int32_t n_values, const int32_t *parent_vi) try {
+    if (!out || !devices || n_stripes < 2 || n_stripes > GS_MAX_STRIPES) return fail(GS_E_INVALID, "a striped store spans 2..8 devices");
+    for (int p = 0; p < n_stripes; p++) {
+        out[p] = nullptr;
+        const int rc = use_device(devices[p]);
+        if (rc) return rc;
+    }
+    return db_create_impl(out, devices[0], k, n, kmers, vidx, n_values, parent_vi, 1, 0, true, n_stripes, devices, -1);
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
+
+extern "C" int gs_db_create_stripe(gs_db **out, int device, int n_stripes, int stripe, int k, int64_t n, const int64_t *kmers,
+                                   const int32_t *vidx, int32_t n_values, const int32_t *parent_vi) try {
+    if (!out || n_stripes < 2 || n_stripes > GS_MAX_STRIPES || stripe < 0 || stripe >= n_stripes)
+        return fail(GS_E_INVALID, "a striped store spans 2..8 devices");
+    return db_create_impl(out, device, k, n, kmers, vidx, n_values, parent_vi, 1, 0, true, n_stripes, nullptr, stripe);
+} catch (const std::bad_alloc &) {
+    return fail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {
+    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
+
+extern "C" int gs_db_stripe_export(gs_db *db, void *handle) {
+    if (!db || !handle) return fail(GS_E_INVALID, "NULL argument");
+    if (!db->striped() || db->group) return fail(GS_E_STATE, "not a stripe of gs_db_create_stripe");
+    static_assert(sizeof(hipIpcMemHandle_t) <= GS_STRIPE_HANDLE_BYTES, "IPC handle size");
+    HIP_TRY(hipSetDevice(db->device));
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, db->d_rec));
+    memset(handle, 0, GS_STRIPE_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    return GS_OK;
+}
+
+extern "C" int gs_db_stripe_attach(gs_db *db, int stripe, const void *handle) {
+    if (!db || !handle) return fail(GS_E_INVALID, "NULL argument");
+    if (!db->striped() || db->group) return fail(GS_E_STATE, "not a stripe of gs_db_create_stripe");
+    if (stripe < 0 || stripe >= db->n_parts || stripe == db->part) return fail(GS_E_INVALID, "stripe out of range (or this handle's own)");
+    if (db->present & (1u << stripe)) return fail(GS_E_STATE, "stripe already attached");
+    if (db->live_runs > 0) return fail(GS_E_STATE, "the store has runs");
+    HIP_TRY(hipSetDevice(db->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void *p = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    db->ipc_opened.push_back(p);
+    db_set_stripe(db, stripe, (const u64 *)p);
+    return GS_OK;
+}
+
 // fused: the store serves the fused kernels (gs_match_submit*, gs_match_segments) and may keep k-mers in super-k-mer
 // records; a partition store (gs_db_create_part, any n_parts) keeps every key in the table, where gs_match_probe_keys looks
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
-                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused) {
+                          int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused, int stripes,
+                          const int *stripe_devices, int stripe_only) {
     if (!out) return fail(GS_E_INVALID, "out is NULL");
-    *out = nullptr;
+    for (int p = 0; p < (stripes > 1 && stripe_only < 0 ? stripes : 1); p++) out[p] = nullptr;
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
     if (n < 0 || n_values < 1 || n_values > (1 << 24) || (n > 0 && (!kmers || !vidx)))
         return fail(GS_E_INVALID, "bad store arrays (n_values must be in [1, 2^24])");
@@ -564,65 +658,123 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         mgate.assign((size_t)1 << mgate_bits, 0);
         for (int64_t i = 0; i < nm; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    gs_db *db = new gs_db();
-    db->device = device;
-    db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t tbytes = table.size() * sizeof(u64);
-    hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
-    if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
-    if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
-    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !rec.empty()) e = hipMalloc((void **)&db->d_rec, rec.size() * sizeof(u64));
-    if (e == hipSuccess && !rec.empty()) e = hipMemcpy(db->d_rec, rec.data(), rec.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        hipFree(db->d_table);
-        hipFree(db->d_gate);
-        hipFree(db->d_mgate);
-        hipFree(db->d_rec);
-        hipFree(db->d_tree);
-        delete db;
-        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
+    // ---- upload.  A striped store (stripes > 1) puts the record buckets of stripe p -- gs_stripe_first(p) up to
+    // gs_stripe_first(p + 1) -- on one device and everything else (gates, overflow table, tree) on every device.
+    const int64_t n_rec_total = rec.empty() ? 0 : (int64_t)1 << rec_bits;
+    if (stripes > 1 && rec.empty())
+        return fail(GS_E_UNSUPPORTED, "a striped store needs super-k-mer records (k >= 19, at most 2^21 values, a non-empty store)");
+    auto upload = [&](int dev_no, int part, gs_db **res) -> int {
+        *res = nullptr;
+        HIP_TRY(hipSetDevice(dev_no));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev_no));
+        gs_db *db = new gs_db();
+        db->device = dev_no;
+        db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int64_t rfirst = 0, rlocal = n_rec_total;
+        if (stripes > 1) {
+            rfirst = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part);
+            rlocal = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part + 1) - rfirst;
+        }
+        const size_t tbytes = table.size() * sizeof(u64);
+        const size_t rbytes = (size_t)rlocal * GS_REC_WORDS * sizeof(u64);
+        const u64 *rsrc = rec.data() + (size_t)rfirst * GS_REC_WORDS;
+        hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
+        if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
+        if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
+        if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
+        if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            db_free(db);
+            return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
+        }
+        db->info.k = k;
+        db->info.n_values = n_values;
+        db->info.n_entries = n;
+        db->info.n_stored = ns + n_in_records;
+        db->info.n_in_records = n_in_records;
+        db->info.rec_bytes = (int64_t)(rec.size() * sizeof(u64));
+        db->n_rec = n_rec_total;
+        db->dev.rec = stripes > 1 ? nullptr : db->d_rec;
+        db->dev.rec_bits = (uint32_t)rec_bits;
+        db->info.n_buckets = (int64_t)1 << b;
+        db->info.table_bytes = (int64_t)tbytes;
+        db->info.max_displacement = max_disp;
+        db->info.value_bits = vbits;
+        db->dev.table = db->d_table;
+        db->dev.gate = db->d_gate;
+        db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
+        db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
+        db->dev.mgate = db->d_mgate;
+        db->dev.mgate_bits = 0;
+        while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
+        db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(uint32_t));
+        db->dev.bucket_bits = (uint32_t)b;
+        db->dev.vbits = (uint32_t)vbits;
+        db->dev.bucket_mask = (1ULL << b) - 1;
+        db->dev.k = k;
+        db->dev.n_values = n_values;
+        db->dev.parent = db->d_tree;
+        db->dev.depth = db->d_tree + n_values;
+        db->dev.tin = db->d_tree + 2 * (size_t)n_values;
+        db->dev.tout = db->d_tree + 3 * (size_t)n_values;
+        if (stripes > 1) {
+            db->n_parts = stripes;
+            db->part = part;
+            db->rec_first = rfirst;
+            db->rec_local = rlocal;
+            db->info.n_stripes = stripes;
+            db->info.stripe = part;
+            db->info.stripe_bytes = (int64_t)rbytes;
+            db->dev.n_parts = (uint32_t)stripes;
+            db_set_stripe(db, part, db->d_rec);
+        }
+        *res = db;
+        return GS_OK;
+    };
+    if (stripes <= 1) return upload(device, 0, out);
+    if (stripe_only >= 0) return upload(device, stripe_only, out);  // the other stripes arrive through gs_db_stripe_attach
+    // every stripe in this process: the handles know each other's stripes, which belong to all of them together
+    auto group = std::make_shared<StripeGroup>();
+    std::vector<gs_db *> made;
+    for (int p = 0; p < stripes && rc == GS_OK; p++) {
+        gs_db *db = nullptr;
+        rc = upload(stripe_devices[p], p, &db);
+        if (rc == GS_OK) {
+            made.push_back(db);
+            group->allocs.push_back({db->device, db->d_rec});
+            db->group = group;
+        }
     }
-    db->info.k = k;
-    db->info.n_values = n_values;
-    db->info.n_entries = n;
-    db->info.n_stored = ns + n_in_records;
-    db->info.n_in_records = n_in_records;
-    db->info.rec_bytes = (int64_t)(rec.size() * sizeof(u64));
-    db->n_rec = rec.empty() ? 0 : (int64_t)1 << rec_bits;
-    db->dev.rec = db->d_rec;
-    db->dev.rec_bits = (uint32_t)rec_bits;
-    db->info.n_buckets = (int64_t)1 << b;
-    db->info.table_bytes = (int64_t)tbytes;
-    db->info.max_displacement = max_disp;
-    db->info.value_bits = vbits;
-    db->dev.table = db->d_table;
-    db->dev.gate = db->d_gate;
-    db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
-    db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
-    db->dev.mgate = db->d_mgate;
-    db->dev.mgate_bits = 0;
-    while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
-    db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(uint32_t));
-    db->dev.bucket_bits = (uint32_t)b;
-    db->dev.vbits = (uint32_t)vbits;
-    db->dev.bucket_mask = (1ULL << b) - 1;
-    db->dev.k = k;
-    db->dev.n_values = n_values;
-    db->dev.parent = db->d_tree;
-    db->dev.depth = db->d_tree + n_values;
-    db->dev.tin = db->d_tree + 2 * (size_t)n_values;
-    db->dev.tout = db->d_tree + 3 * (size_t)n_values;
-    *out = db;
+    for (int p = 0; p < stripes && rc == GS_OK; p++)
+        for (int q = 0; q < stripes && rc == GS_OK; q++) {
+            if (q == p) continue;
+            if (made[(size_t)p]->device != made[(size_t)q]->device) {
+                hipSetDevice(made[(size_t)p]->device);
+                int can = 0;
+                hipDeviceCanAccessPeer(&can, made[(size_t)p]->device, made[(size_t)q]->device);
+                if (!can) rc = fail(GS_E_UNSUPPORTED, "the devices of a striped store need peer access to each other");
+                else {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(made[(size_t)q]->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) rc = fail(GS_E_HIP, std::string("peer access: ") + hipGetErrorString(pe));
+                    (void)hipGetLastError();
+                }
+            }
+            if (rc == GS_OK) db_set_stripe(made[(size_t)p], q, made[(size_t)q]->d_rec);
+        }
+    if (rc != GS_OK) {
+        for (gs_db *db : made) db_free(db);
+        return rc;
+    }
+    for (int p = 0; p < stripes; p++) out[p] = made[(size_t)p];
     return GS_OK;
 }
 
@@ -721,6 +873,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (!db || !path) return fail(GS_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(db->device));
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
+    if (db->striped()) return fail(GS_E_UNSUPPORTED, "a striped store is not saved as such: save the store built by gs_db_create");
     GsStoreFileHeader h{};
     memcpy(h.magic, "GSSTORE6", 8);
     h.info = db->info;
@@ -1143,7 +1296,7 @@ static int run_clear(gs_run *run) {
     if (run->d_hit_counts)
         HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)(run->db->n_slots() + run->db->n_rec * GS_REC_SLOTS), run->stream));
     if (run->seen_dirty)
-        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream));
+        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
     run->seen_dirty = false;
     run->bitmap_merged = false;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
@@ -1204,6 +1357,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     *out = nullptr;
     if (cfg->max_paths < 1 || cfg->max_paths > 128) return fail(GS_E_INVALID, "max_paths must be in [1,128] (C/GSConfigKey.java:350)");
     HIP_TRY(hipSetDevice(db->device));
+    if (!db->complete()) return fail(GS_E_STATE, "striped store: not every stripe is attached yet (gs_db_stripe_attach)");
     if (cfg->count_unique && db->unique_owner)
         return fail(GS_E_STATE, "this store already has an active unique-counting run (the seen bits live in the table)");
     gs_run *run = new gs_run();
@@ -1635,11 +1789,20 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     }
     if (run->cfg.count_unique) {
         if (!run->bitmap_merged)
-            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
+            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db),
                                              run->stream));
         HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * nv, run->stream));
         HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->n_slots(), run->db->dev.vbits,
-                                       run->db->info.n_values, run->d_unique, run->db->d_rec, run->db->n_rec, run->stream));
+                                       run->db->info.n_values, run->d_unique, sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
+        if (run->db->striped()) {  // every stripe against its part of the bitmap (a foreign stripe is read over xGMI, once)
+            const gs_db *db = run->db;
+            const uint32_t *brec = run->d_bitmap + (db->n_slots() + 31) / 32;
+            for (int q = 0; q < db->n_parts; q++) {
+                const int64_t first = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
+                const int64_t local = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - first;
+                HIP_TRY(gs_launch_rec_unique_count(db->stripe_base[q], brec + first, local, db->info.n_values, run->d_unique, run->stream));
+            }
+        }
         HIP_TRY(hipMemcpyAsync(uniq.data(), run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
     }
     HIP_TRY(hipMemcpyAsync(sums.data(), run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToHost, run->stream));
@@ -1703,7 +1866,7 @@ extern "C" int gs_match_destroy(gs_run *run) {
     hipSetDevice(run->db->device);
     hipStreamSynchronize(run->stream);
     if (run->db->unique_owner == run) {
-        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream);
+        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), sweep_rec(run->db), sweep_n_rec(run->db), run->stream);
         hipStreamSynchronize(run->stream);
         run->db->unique_owner = nullptr;
     }
@@ -1722,7 +1885,7 @@ extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, 
         if (frc) return frc;
     }
     if (bitmap && run->cfg.count_unique && !run->bitmap_merged)  // refresh the compact copy of the seen bits
-        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec,
+        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db),
                                          run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     if (sums) *sums = run->d_sums;
@@ -1775,7 +1938,7 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
             if (frc) return frc;
         }
         if (uniq && !run->bitmap_merged)
-            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec, run->stream));
+            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
         HIP_TRY(hipStreamSynchronize(run->stream));
     }
     // ---- stage A: the runs of one device into that device's first run (its leader)
@@ -2173,11 +2336,22 @@ extern "C" int gs_match_max_counts(gs_run *run, int16_t *out) {
         const size_t n_rec = (size_t)run->db->n_rec;
         std::vector<u64> rec(n_rec * GS_REC_WORDS);
         std::vector<uint32_t> rcounts(n_rec * GS_REC_SLOTS);
-        HIP_TRY(hipMemcpy(rec.data(), run->db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> rseen;  // striped store: the seen bits are the run's own (one word per record bucket)
+        const gs_db *db = run->db;
+        if (db->striped()) {
+            for (int q = 0; q < db->n_parts; q++) {
+                const size_t first = (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
+                const size_t local = (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - first;
+                HIP_TRY(hipMemcpy(rec.data() + first * GS_REC_WORDS, db->stripe_base[q], local * GS_REC_WORDS * sizeof(u64), hipMemcpyDeviceToHost));
+            }
+            rseen.resize(n_rec);
+            HIP_TRY(hipMemcpy(rseen.data(), run->d_bitmap + (n_slots + 31) / 32, n_rec * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        } else
+            HIP_TRY(hipMemcpy(rec.data(), run->db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(rcounts.data(), run->d_hit_counts + n_slots, rcounts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (size_t b = 0; b < n_rec; b++) {
             const u64 *rp = rec.data() + b * GS_REC_WORDS;
-            uint32_t seen = (uint32_t)(rp[0] >> GS_REC_WIN_BITS) & (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
+            uint32_t seen = (db->striped() ? rseen[b] : (uint32_t)(rp[0] >> GS_REC_WIN_BITS)) & (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
             for (; seen; seen &= seen - 1) {
                 const int j = __builtin_ctz(seen);
                 const size_t vi = (size_t)((rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1));

@@ -254,6 +254,7 @@ __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_st
 struct GsMark {
     int count_unique;
     uint32_t *hit_counts;  // [table slots | GS_REC_SLOTS per record bucket] or nullptr
+    uint32_t *rec_seen;    // striped store: this run's seen bits, one word per record bucket (the record lines stay read-only)
 };
 
 __device__ __forceinline__ void gs_take_hit(const GsDbDev &db, uint32_t slot, int vs, int &node, const GsMark &mk) {
@@ -338,7 +339,7 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
     __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next iteration / read
 }
 
-template <int KC>
+template <int KC, bool STRIPED>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
                                                 uint32_t *wave_g, const GsMark &mk) {
@@ -387,7 +388,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                 if (act[s] && (gh[s] ^ ohi[s] ^ olo[s] ^ (uint32_t)j[s]) == 0x12345u) node[s] = 0;
             return;
         }
-        if (db.rec != nullptr) {
+        if (STRIPED || db.rec != nullptr) {
             // ---- super-k-mer records: both candidate buckets of the minimizer at once -- per bucket one 16-byte load of
             // the window planes + the 8-byte word that holds this offset's value
             const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
@@ -398,7 +399,15 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     const int jj = j[s];
                     const int jw = (jj * 11) >> 5;  // j / 3 for j <= 16
                     const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
-                    const u64 *r0 = db.rec + (u64)b0 * GS_REC_WORDS, *r1 = db.rec + (u64)b1 * GS_REC_WORDS;
+                    const u64 *r0, *r1;
+                    if (STRIPED) {  // the stripe's (biased) base pointer from the wave's copy of the table, behind the hash rows
+                        const u64 *const *stripe = reinterpret_cast<const u64 *const *>(wave_g + 2 * GS_ROW);
+                        r0 = stripe[(b0 * db.n_parts) >> db.rec_bits] + (u64)b0 * GS_REC_WORDS;
+                        r1 = stripe[(b1 * db.n_parts) >> db.rec_bits] + (u64)b1 * GS_REC_WORDS;
+                    } else {
+                        r0 = db.rec + (u64)b0 * GS_REC_WORDS;
+                        r1 = db.rec + (u64)b1 * GS_REC_WORDS;
+                    }
                     const gs_u64x2 A0 = *reinterpret_cast<const gs_u64x2 *>(r0), A1 = *reinterpret_cast<const gs_u64x2 *>(r1);
                     const u64 V0 = r0[2 + jw], V1 = r1[2 + jw];
                     const bool ok0 = ((uint32_t)((A0.x & M47) >> jj) & kmask) == ohi[s] && ((uint32_t)((A0.y & M47) >> jj) & kmask) == olo[s] &&
@@ -409,7 +418,9 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                         const u64 V = ok0 ? V0 : V1, Ax = ok0 ? A0.x : A1.x;
                         const uint32_t rb = ok0 ? b0 : b1;
                         node[s] = (int)((V >> (GS_REC_VAL_BITS * (jj - 3 * jw))) & (GS_REC_MAX_VALUES - 1));
-                        if (mk.count_unique && ((Ax >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
+                        if (STRIPED) {
+                            if (mk.count_unique && ((mk.rec_seen[rb] >> jj) & 1u) == 0) atomicOr(mk.rec_seen + rb, 1u << jj);
+                        } else if (mk.count_unique && ((Ax >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
                             atomicOr(const_cast<u64 *>(db.rec) + (u64)rb * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
                         if (mk.hit_counts != nullptr)
                             atomicAdd(mk.hit_counts + ((u64)(bmask + 1u) * GS_SLOTS_PER_BUCKET + (u64)rb * GS_REC_SLOTS + (u64)jj), 1u);
@@ -459,7 +470,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // WIDE = true: maxClassificationPaths in 65..128 (C/GSConfigKey.java:350 allows 1..128): candidate path i lives in
 // lane i & 63 of register set i >> 6; with WIDE = false there is one set and lane = path.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG, bool FROM_NODES, int KC, bool WIDE, bool REC>
+template <bool LONG, bool FROM_NODES, int KC, bool WIDE, bool REC, bool STRIPED>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
@@ -535,8 +546,8 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 }
             } else {
                 // (4a. unique k-mers and per-k-mer hit counters are marked by the probe itself)
-                const GsMark mk = {P.count_unique, P.hit_counts};
-                gs_probe_planes<KC>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
+                const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
+                gs_probe_planes<KC, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
@@ -959,12 +970,23 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
             if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
     }
 
-template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false>
+// STRIPED: the record table is split over several devices (GsDbDev::rec_biased); every wave keeps the stripe pointers in
+// LDS behind its hash rows, where a lane picks the one of its bucket with a single ds_read
+#define GS_STRIPE_TABLE(kernarg)                                                                                        \
+    if (STRIPED) {                                                                                                       \
+        if (lane < GS_MAX_STRIPES)                                                                                       \
+            reinterpret_cast<const u64 **>(s_g[wave_in_block] + 2 * GS_ROW)[lane] = (kernarg)->db.rec_biased[lane];      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                           \
+        __builtin_amdgcn_wave_barrier();                                                                                 \
+    }
+
+template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false, bool STRIPED = false>
 __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAVES, GS_WAVES))) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
-    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];  // 15-mer order hashes of the wave's current 144 positions
+    // 15-mer order hashes of the wave's current 144 positions (+ the stripe pointers)
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
@@ -983,6 +1005,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         s_cur[wave_in_block][0] = 0;
         s_cur[wave_in_block][1] = 64;
     }
+    GS_STRIPE_TABLE((const GsMatchParams *)kp0)
     for (int64_t r = wave_id; r < n_reads; r += n_waves) {
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
@@ -997,7 +1020,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         uint32_t pre[3];
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
-        gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
+        gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
                                                      s_g[wave_in_block], s_cur[wave_in_block]);
     }
     if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
@@ -1008,14 +1031,15 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     GS_STATS_EPILOGUE()
 }
 
-template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false>
+template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false, bool STRIPED = false>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
-    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
+    GS_STRIPE_TABLE(&P)
     const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
     int32_t *cnt = tag + nv;
@@ -1031,7 +1055,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
         const uint32_t none[3] = {0, 0, 0};
-        gs_process_read<true, FROM_NODES, 0, WIDE, false>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
+        gs_process_read<true, FROM_NODES, 0, WIDE, false, STRIPED>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
                                                    (int)serial, none, s_g[wave_in_block], nullptr);
     }
     if (lane == 0) serials[wave_id] = serial;
@@ -1454,15 +1478,17 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
 // of equal node over the k-mer positions of a read.  WRITE = false counts them per read; WRITE = true stores
 // (code, start) of every run at seg_off[r] + i (code = value index, -1 miss "0", -2 INVALID "A").
 // ---------------------------------------------------------------------------------------------------
-template <bool WRITE>
+template <bool WRITE, bool STRIPED>
 __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
-    __shared__ uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW];
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
     const GsDbDev &db = P.db;
     const int lane = gs_lane();
+    const int wave_in_block = (int)(threadIdx.x >> 6);
+    GS_STRIPE_TABLE(&P)
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = db.k;
-    const GsMark nomark = {0, nullptr};
+    const GsMark nomark = {0, nullptr, nullptr};
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
@@ -1479,7 +1505,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
 #pragma unroll
             for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
             int node[2];
-            gs_probe_planes<0>(db, Bhi, Blo, Bbad, base, max, lane, node, s_g[threadIdx.x >> 6], nomark);
+            gs_probe_planes<0, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, s_g[wave_in_block], nomark);
             const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
             const int last0 = gs_readlane(node[0], 63);
             const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
@@ -1823,6 +1849,26 @@ static size_t gs_stats_lds_bytes(int n_values) {
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->db.n_parts > 1) {  // striped store (always probed locally: nodes == nullptr)
+        if (P->nodes != nullptr) return hipErrorInvalidValue;
+        if (P->max_paths > 64) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        } else if (P->db.k == 31) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 31, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 31, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        } else {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            else
+                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        }
+        return hipGetLastError();
+    }
     if (P->max_paths > 64) {  // two candidate paths per lane (the reference allows up to 128, C/GSConfigKey.java:350)
         if (P->nodes == nullptr) {
             if (lds_stats)
@@ -1863,6 +1909,21 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
                                            hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    if (P->db.n_parts > 1) {
+        if (P->nodes != nullptr) return hipErrorInvalidValue;
+        if (P->max_paths > 64) {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_long_kernel<true, false, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+            else
+                hipLaunchKernelGGL((gs_match_long_kernel<false, false, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        } else {
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_long_kernel<true, false, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+            else
+                hipLaunchKernelGGL((gs_match_long_kernel<false, false, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        }
+        return hipGetLastError();
+    }
     if (P->max_paths > 64) {
         if (P->nodes == nullptr) {
             if (lds_stats)
@@ -1917,6 +1978,15 @@ extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *b
         grid = (int)std::min<int64_t>((n_rec + 255) / 256, 4096);
         hipLaunchKernelGGL(gs_rec_unique_count_kernel, dim3(grid), dim3(256), 0, stream, rec, bitmap + n_words, n_rec, n_values, unique);
     }
+    return hipGetLastError();
+}
+
+// one stripe of a striped store: `rec` = the stripe's lines, `bitmap_rec` = the bitmap words of ITS buckets
+extern "C" hipError_t gs_launch_rec_unique_count(const u64 *rec, const uint32_t *bitmap_rec, int64_t n_rec, int32_t n_values,
+                                                  u64 *unique, hipStream_t stream) {
+    if (n_rec <= 0) return hipSuccess;
+    const int grid = (int)std::min<int64_t>((n_rec + 255) / 256, 4096);
+    hipLaunchKernelGGL(gs_rec_unique_count_kernel, dim3(grid), dim3(256), 0, stream, rec, bitmap_rec, n_rec, n_values, unique);
     return hipGetLastError();
 }
 
@@ -1992,10 +2062,15 @@ extern "C" hipError_t gs_launch_probe_keys(const GsDbDev *db, const u64 *keys, i
 }
 
 extern "C" hipError_t gs_launch_segments(const GsSegParams *P, int write, int grid, hipStream_t stream) {
-    if (write)
-        hipLaunchKernelGGL(gs_segments_kernel<true>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    if (P->db.n_parts > 1) {
+        if (write)
+            hipLaunchKernelGGL((gs_segments_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        else
+            hipLaunchKernelGGL((gs_segments_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+    } else if (write)
+        hipLaunchKernelGGL((gs_segments_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     else
-        hipLaunchKernelGGL(gs_segments_kernel<false>, dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
+        hipLaunchKernelGGL((gs_segments_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), 0, stream, *P);
     return hipGetLastError();
 }
 

@@ -154,6 +154,11 @@ GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rl
 #define GS_REC_MAX_VALUES (1 << GS_REC_VAL_BITS)
 #define GS_REC_MORE (1ULL << 63)
 #define GS_REC_SLOTS 32  // virtual slots per record bucket (hit counters, compact bitmap): 17 used
+#define GS_MAX_STRIPES 8 // devices a striped store spans (one node: 8 GPUs on xGMI)
+// first bucket of stripe p when 2^rec_bits buckets are split n_parts ways (the inverse of (b * n_parts) >> rec_bits)
+GS_HD uint64_t gs_stripe_first(uint32_t rec_bits, uint32_t n_parts, uint32_t p) {
+    return (((uint64_t)p << rec_bits) + n_parts - 1) / n_parts;
+}
 
 GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits, int choice) {
     return (gh * (choice ? 0x165667B1u : 0x27D4EB2Fu)) >> (32 - rec_bits);
@@ -184,4 +189,12 @@ struct GsDbDev {
     const int32_t *depth;
     const int32_t *tin;
     const int32_t *tout;
+    // striped store (gs_db_create_striped / gs_db_create_stripe): the record buckets are split into n_parts contiguous
+    // stripes, stripe p in the HBM of one device; a bucket b belongs to stripe (b * n_parts) >> rec_bits and its line is
+    // at rec_biased[p] + b * GS_REC_WORDS (the stripe's base pointer minus its first bucket).  Foreign stripes are read
+    // over xGMI peer access and never written: the seen bits of a striped store live in the run's own bitmap.
+    // n_parts <= 1: plain store (`rec` above).
+    uint32_t n_parts;
+    uint32_t pad_;
+    const unsigned long long *rec_biased[GS_MAX_STRIPES];
 };

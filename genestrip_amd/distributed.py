@@ -98,6 +98,29 @@ def match_files_sharded(matcher, paths, group=None, device=None, via_host=False)
     return table, dtable, tuple(int(x) for x in counts[len(paths):])
 
 
+def striped_store(k, kmers, value_idx, n_values, parent_vi=None, device=0, group=None):
+    """Collective.  ONE store over the HBM of all ranks' GPUs (include/gsgpu.h, "striped store"): every rank builds the
+    layout from the same arrays and keeps stripe `rank` of the super-k-mer record table (gs_db_create_stripe), exports it
+    as a HIP IPC memory handle, and attaches the stripes of the others.  The returned store serves the ordinary fused path
+    (FastqKMerMatcher.submit*): record lines of foreign stripes are loaded over xGMI, there is no exchange step per batch.
+    The runs of the ranks merge like runs on replicas (merge_run_state).  One rank: a plain store."""
+    from .binding import DeviceKMerStore
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return DeviceKMerStore(k, kmers, value_idx, n_values, parent_vi, device=device)
+    if world > 8:
+        raise ValueError("a striped store spans the GPUs of one node (at most 8 ranks)")
+    rank = dist.get_rank(group)
+    store = DeviceKMerStore.stripe(k, kmers, value_idx, n_values, parent_vi, device=device, n_stripes=world, stripe=rank)
+    handles = [None] * world
+    dist.all_gather_object(handles, store.export_stripe(), group=group)
+    for q in range(world):
+        if q != rank:
+            store.attach_stripe(q, handles[q])
+    dist.barrier(group)  # nobody runs before every stripe is attached everywhere, nobody frees before that either
+    return store
+
+
 def shard_bounds(n_total, rank, world):
     """contiguous read range [lo, hi) of `rank` (global readNo is kept)"""
     base, rem = divmod(n_total, world)

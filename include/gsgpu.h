@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 enum {
     GS_OK = 0,
@@ -83,6 +83,9 @@ typedef struct {
     int64_t mgate_bytes;    /* minimizer gate (0 = not built: k < 19)                           */
     int64_t rec_bytes;      /* super-k-mer records (0 = not built: k < 19, partition, > 2^21 values) */
     int64_t n_in_records;   /* stored k-mers that live in records (the others are table slots)  */
+    int32_t n_stripes;      /* striped store: devices the record table is split over (else 0)  */
+    int32_t stripe;         /* ... and which stripe this handle's device holds                  */
+    int64_t stripe_bytes;   /* ... and its size                                                  */
 } gs_db_info;
 
 int gs_db_create(gs_db **out, int device, int k, int64_t n_entries, const int64_t *kmers_sorted,
@@ -237,8 +240,37 @@ int gs_match_or_bitmap(gs_run *run, const void *parts, int64_t n_parts);
 int gs_match_merge(gs_run *const *runs, int n_runs);
 
 /* ---------------------------------------------------------------------------------------------------
- * DB-partitioned match (BASELINE.json configs[4]): the store is split over the GPUs of a node by
- * key hash (gs_db_create_part keeps the keys with (h >> 40) % n_parts == part, h = the library's mixed key), reads stay
+ * Striped store (BASELINE.json configs[4]: a store that does not fit one GPU).  The super-k-mer
+ * record table -- the bulk of a store -- is split into n_stripes runs of consecutive buckets, stripe p in the HBM of one
+ * device; gates, overflow table and tree are small and live on every device.  Reads stay on their home GPU and go
+ * through the SAME fused kernel as with a replicated store (gs_match_submit* / gs_match_segments): a record line of a
+ * foreign stripe is simply loaded over xGMI peer access (64 bytes per minimizer run that passed the gate), there is no
+ * exchange step, no materialised key stream and no host synchronisation per batch.  Record lines are never written:
+ * the seen bits of a striped store are kept in each run's own bitmap, and gs_match_merge / the torch.distributed merge
+ * OR them exactly as for replicas.  With one stripe this IS gs_db_create.  No counterpart in the single-process
+ * reference.
+ *
+ * gs_db_create_striped: all stripes from ONE process (a JVM host with one gs_run per GPU): out[p] = handle on
+ *   devices[p] (2..8 devices that can access each other; a device may appear more than once, which puts several stripes
+ *   on it -- how the tests rehearse this on one GPU).  The stripes are freed with the last of the handles.
+ * gs_db_create_stripe: ONE stripe per process (torch.distributed, one process per GPU): every process builds the layout
+ *   from the same arrays and keeps stripe `stripe`; then every process exports its stripe (gs_db_stripe_export: 64 opaque
+ *   bytes, a HIP IPC memory handle), the hosts exchange them (all-gather), and each attaches the others
+ *   (gs_db_stripe_attach).  gs_match_begin refuses a handle whose stripes are not all attached.  The exporting process
+ *   must keep its handle alive while others use the stripe.
+ * ------------------------------------------------------------------------------------------------- */
+#define GS_MAX_STRIPES 8
+#define GS_STRIPE_HANDLE_BYTES 64
+int gs_db_create_striped(gs_db **out, const int *devices, int n_stripes, int k, int64_t n_entries, const int64_t *kmers,
+                         const int32_t *value_idx, int32_t n_values, const int32_t *parent_vi);
+int gs_db_create_stripe(gs_db **out, int device, int n_stripes, int stripe, int k, int64_t n_entries, const int64_t *kmers,
+                        const int32_t *value_idx, int32_t n_values, const int32_t *parent_vi);
+int gs_db_stripe_export(gs_db *db, void *handle);
+int gs_db_stripe_attach(gs_db *db, int stripe, const void *handle);
+
+/* ---------------------------------------------------------------------------------------------------
+ * DB-partitioned match, the split pipeline of round 1 (kept: it also serves stores without records): the store is split
+ * over the GPUs of a node by key hash (gs_db_create_part keeps the keys with (h >> 40) % n_parts == part, h = the library's mixed key), reads stay
  * on their home GPU.  Per batch: gs_match_encode (reads -> h of every k-mer position; ~0 marks a window with a
  * non-CGAT base) -> all-to-all of the keys to their owners -> gs_match_probe_keys on the owner (node = value index,
  * -1 miss, -2 invalid; marks unique k-mers in the owner's table) -> all-to-all back -> gs_match_reduce on the home

@@ -18,7 +18,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(ga.ABI_SYMBOLS), declared ^ set(ga.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert ga.abi_version() == 2
+    assert ga.abi_version() == 3
     assert L.gs_strerror(-6).decode() == "no usable gfx950 device"
 
 
