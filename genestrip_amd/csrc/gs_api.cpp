@@ -123,6 +123,7 @@ struct gs_db {
     // rec_local) of the n_rec buckets; stripe_base[q] = where this process sees stripe q
     int n_parts = 0, part = 0;
     int64_t rec_first = 0, rec_local = 0;
+    int64_t tab_first = 0, tab_local = 0;      // its buckets of the overflow table: they follow the record lines in d_rec
     const u64 *stripe_base[GS_MAX_STRIPES] = {};
     unsigned present = 0;                      // bit q: stripe q is known
     std::shared_ptr<struct StripeGroup> group; // all stripes in one process: they are freed with the last handle
@@ -141,22 +142,29 @@ struct StripeGroup {
     }
 };
 
-// the sweeps over the records' seen bits (extract / clear / count) do not apply to a striped store: its record lines are
-// read-only and the seen bits are written straight into the run's bitmap
-static inline u64 *sweep_rec(const gs_db *db) { return db->striped() ? nullptr : db->d_rec; }
-static inline int64_t sweep_n_rec(const gs_db *db) { return db->striped() ? 0 : db->n_rec; }
-
 static void db_set_stripe(gs_db *db, int q, const u64 *base) {
     db->stripe_base[q] = base;
     db->present |= 1u << q;
     // (biased: the kernels add bucket * GS_REC_WORDS with the GLOBAL bucket number)
-    db->dev.rec_biased[q] = base - (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q) * GS_REC_WORDS;
+    const size_t first = (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
+    const size_t local = (size_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - first;
+    db->dev.rec_biased[q] = base - first * GS_REC_WORDS;
+    db->dev.tab_biased[q] = base + local * GS_REC_WORDS -
+                            (size_t)gs_tab_stripe_first(db->dev.bucket_bits, (uint32_t)db->n_parts, (uint32_t)q) * GS_SLOTS_PER_BUCKET;
+}
+// the table buckets of stripe q as this process sees them
+static const u64 *stripe_table(const gs_db *db, int q, int64_t *first, int64_t *local) {
+    const int64_t rf = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
+    const int64_t rl = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - rf;
+    *first = (int64_t)gs_tab_stripe_first(db->dev.bucket_bits, (uint32_t)db->n_parts, (uint32_t)q);
+    *local = (int64_t)gs_tab_stripe_first(db->dev.bucket_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - *first;
+    return db->stripe_base[q] + (size_t)rl * GS_REC_WORDS;
 }
 
 static void db_free(gs_db *db) {
     hipSetDevice(db->device);
     for (void *p : db->ipc_opened) hipIpcCloseMemHandle(p);
-    hipFree(db->d_table);
+    if (!db->striped()) hipFree(db->d_table);  // (a stripe's table buckets live behind its record lines)
     hipFree(db->d_gate);
     hipFree(db->d_mgate);
     if (!db->group) hipFree(db->d_rec);
@@ -604,7 +612,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         double v = atof(e);
         if (v > 0.05 && v <= 6.0) load = v;
     }
-    int b = std::max(vbits + 1, 4);  // slot bits: (62-b) rem + 2 disp + vbits value + 1 seen <= 64
+    int b = std::max(vbits + 1, stripes > 1 ? 5 : 4);  // slot bits: (62-b) rem + 2 disp + vbits value + 1 seen <= 64
     while ((double)(1ULL << b) * load < (double)ns) b++;
     std::vector<u64> table;
     int max_disp = 0;
@@ -671,28 +679,39 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         gs_db *db = new gs_db();
         db->device = dev_no;
         db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        int64_t rfirst = 0, rlocal = n_rec_total;
+        int64_t rfirst = 0, rlocal = n_rec_total, tfirst = 0, tlocal = (int64_t)1 << b;
         if (stripes > 1) {
             rfirst = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part);
             rlocal = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part + 1) - rfirst;
+            tfirst = (int64_t)gs_tab_stripe_first((uint32_t)b, (uint32_t)stripes, (uint32_t)part);
+            tlocal = (int64_t)gs_tab_stripe_first((uint32_t)b, (uint32_t)stripes, (uint32_t)part + 1) - tfirst;
         }
-        const size_t tbytes = table.size() * sizeof(u64);
+        const size_t tbytes = (size_t)tlocal * GS_SLOTS_PER_BUCKET * sizeof(u64);
         const size_t rbytes = (size_t)rlocal * GS_REC_WORDS * sizeof(u64);
         const u64 *rsrc = rec.data() + (size_t)rfirst * GS_REC_WORDS;
-        hipError_t e = hipMalloc((void **)&db->d_table, tbytes);
+        const u64 *tsrc = table.data() + (size_t)tfirst * GS_SLOTS_PER_BUCKET;
+        hipError_t e = hipSuccess;
+        if (stripes > 1) {  // ONE allocation per stripe (one IPC handle): its record lines, then its table buckets
+            e = hipMalloc((void **)&db->d_rec, rbytes + tbytes);
+            if (e == hipSuccess) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+            if (e == hipSuccess) db->d_table = db->d_rec + (size_t)rlocal * GS_REC_WORDS;
+        } else {
+            e = hipMalloc((void **)&db->d_table, tbytes);
+            if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
+            if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
         if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
         if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
         if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
         if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
-        if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), tbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_table, tsrc, tbytes, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
+            if (stripes > 1) db->d_table = nullptr;  // (inside d_rec)
             db_free(db);
             return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
         }
@@ -706,10 +725,10 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         db->dev.rec = stripes > 1 ? nullptr : db->d_rec;
         db->dev.rec_bits = (uint32_t)rec_bits;
         db->info.n_buckets = (int64_t)1 << b;
-        db->info.table_bytes = (int64_t)tbytes;
+        db->info.table_bytes = (int64_t)(table.size() * sizeof(u64));
         db->info.max_displacement = max_disp;
         db->info.value_bits = vbits;
-        db->dev.table = db->d_table;
+        db->dev.table = stripes > 1 ? nullptr : db->d_table;
         db->dev.gate = db->d_gate;
         db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
         db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
@@ -731,9 +750,11 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             db->part = part;
             db->rec_first = rfirst;
             db->rec_local = rlocal;
+            db->tab_first = tfirst;
+            db->tab_local = tlocal;
             db->info.n_stripes = stripes;
             db->info.stripe = part;
-            db->info.stripe_bytes = (int64_t)rbytes;
+            db->info.stripe_bytes = (int64_t)(rbytes + tbytes);
             db->dev.n_parts = (uint32_t)stripes;
             db_set_stripe(db, part, db->d_rec);
         }
@@ -1295,8 +1316,8 @@ static int run_clear(gs_run *run) {
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
     if (run->d_hit_counts)
         HIP_TRY(hipMemsetAsync(run->d_hit_counts, 0, sizeof(uint32_t) * (size_t)(run->db->n_slots() + run->db->n_rec * GS_REC_SLOTS), run->stream));
-    if (run->seen_dirty)
-        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
+    if (run->seen_dirty && !run->db->striped())  // (a striped store's seen bits are the bitmap that was just cleared)
+        HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream));
     run->seen_dirty = false;
     run->bitmap_merged = false;
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
@@ -1358,7 +1379,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     if (cfg->max_paths < 1 || cfg->max_paths > 128) return fail(GS_E_INVALID, "max_paths must be in [1,128] (C/GSConfigKey.java:350)");
     HIP_TRY(hipSetDevice(db->device));
     if (!db->complete()) return fail(GS_E_STATE, "striped store: not every stripe is attached yet (gs_db_stripe_attach)");
-    if (cfg->count_unique && db->unique_owner)
+    if (cfg->count_unique && db->unique_owner && !db->striped())
         return fail(GS_E_STATE, "this store already has an active unique-counting run (the seen bits live in the table)");
     gs_run *run = new gs_run();
     run->db = db;
@@ -1406,7 +1427,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         run_free(run);
         return rc;
     }
-    if (cfg->count_unique) db->unique_owner = run;
+    if (cfg->count_unique && !db->striped()) db->unique_owner = run;  // (a striped store is read-only: any number of runs)
     db->live_runs++;
     *out = run;
     return GS_OK;
@@ -1753,6 +1774,37 @@ extern "C" int gs_match_text_clear_error(gs_run *run) {
 extern "C" hipError_t gs_launch_merge_i64(void *dst, const void *src, int64_t n, int op, hipStream_t stream);
 extern "C" hipError_t gs_launch_merge_f64(void *dst, const void *src, int64_t n, hipStream_t stream);
 
+// seen bits of the store -> the run's compact bitmap.  The kernels of a striped store write the bitmap themselves (the
+// store's memory, partly another GPU's, is never written).
+static int run_extract_bitmap(gs_run *run) {
+    if (run->db->striped()) return GS_OK;
+    HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, run->db->d_rec, run->db->n_rec, run->stream));
+    return GS_OK;
+}
+
+// unique k-mers per value index from the bitmap (own or merged) into d_unique
+static int run_unique_counts(gs_run *run) {
+    const gs_db *db = run->db;
+    HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * (size_t)db->info.n_values, run->stream));
+    if (!db->striped()) {
+        HIP_TRY(gs_launch_unique_count(db->d_table, run->d_bitmap, db->n_slots(), db->dev.vbits, db->info.n_values, run->d_unique,
+                                       db->d_rec, db->n_rec, run->stream));
+        return GS_OK;
+    }
+    // every stripe against its part of the bitmap (a foreign stripe is read over xGMI, once)
+    const uint32_t *brec = run->d_bitmap + (db->n_slots() + 31) / 32;
+    for (int q = 0; q < db->n_parts; q++) {
+        int64_t tfirst = 0, tlocal = 0;
+        const u64 *tq = stripe_table(db, q, &tfirst, &tlocal);
+        HIP_TRY(gs_launch_unique_count(tq, run->d_bitmap + tfirst * GS_SLOTS_PER_BUCKET / 32, tlocal * GS_SLOTS_PER_BUCKET, db->dev.vbits,
+                                       db->info.n_values, run->d_unique, nullptr, 0, run->stream));
+        const int64_t first = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
+        const int64_t local = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - first;
+        HIP_TRY(gs_launch_rec_unique_count(db->stripe_base[q], brec + first, local, db->info.n_values, run->d_unique, run->stream));
+    }
+    return GS_OK;
+}
+
 // the copies of the global-atomic counters into copy 0 (the others start from zero again)
 static int fold_stats(gs_run *run) {
     if (!run->stats_spread) return GS_OK;
@@ -1788,20 +1840,13 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
         if (frc) return frc;
     }
     if (run->cfg.count_unique) {
-        if (!run->bitmap_merged)
-            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db),
-                                             run->stream));
-        HIP_TRY(hipMemsetAsync(run->d_unique, 0, sizeof(u64) * nv, run->stream));
-        HIP_TRY(gs_launch_unique_count(run->db->d_table, run->d_bitmap, run->db->n_slots(), run->db->dev.vbits,
-                                       run->db->info.n_values, run->d_unique, sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
-        if (run->db->striped()) {  // every stripe against its part of the bitmap (a foreign stripe is read over xGMI, once)
-            const gs_db *db = run->db;
-            const uint32_t *brec = run->d_bitmap + (db->n_slots() + 31) / 32;
-            for (int q = 0; q < db->n_parts; q++) {
-                const int64_t first = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q);
-                const int64_t local = (int64_t)gs_stripe_first(db->dev.rec_bits, (uint32_t)db->n_parts, (uint32_t)q + 1) - first;
-                HIP_TRY(gs_launch_rec_unique_count(db->stripe_base[q], brec + first, local, db->info.n_values, run->d_unique, run->stream));
-            }
+        if (!run->bitmap_merged) {
+            const int xrc = run_extract_bitmap(run);
+            if (xrc) return xrc;
+        }
+        {
+            const int urc = run_unique_counts(run);
+            if (urc) return urc;
         }
         HIP_TRY(hipMemcpyAsync(uniq.data(), run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
     }
@@ -1866,7 +1911,8 @@ extern "C" int gs_match_destroy(gs_run *run) {
     hipSetDevice(run->db->device);
     hipStreamSynchronize(run->stream);
     if (run->db->unique_owner == run) {
-        if (run->seen_dirty) gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), sweep_rec(run->db), sweep_n_rec(run->db), run->stream);
+        if (run->seen_dirty && !run->db->striped())
+            gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream);
         hipStreamSynchronize(run->stream);
         run->db->unique_owner = nullptr;
     }
@@ -1884,9 +1930,10 @@ extern "C" int gs_match_device_state(gs_run *run, void **sums, void **max_keys, 
         const int frc = fold_stats(run);
         if (frc) return frc;
     }
-    if (bitmap && run->cfg.count_unique && !run->bitmap_merged)  // refresh the compact copy of the seen bits
-        HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db),
-                                         run->stream));
+    if (bitmap && run->cfg.count_unique && !run->bitmap_merged) {  // refresh the compact copy of the seen bits
+        const int xrc = run_extract_bitmap(run);
+        if (xrc) return xrc;
+    }
     HIP_TRY(hipStreamSynchronize(run->stream));
     if (sums) *sums = run->d_sums;
     if (max_keys) *max_keys = run->d_max;
@@ -1937,8 +1984,10 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
             const int frc = fold_stats(run);
             if (frc) return frc;
         }
-        if (uniq && !run->bitmap_merged)
-            HIP_TRY(gs_launch_bitmap_extract(run->db->d_table, run->db->n_slots(), run->d_bitmap, sweep_rec(run->db), sweep_n_rec(run->db), run->stream));
+        if (uniq && !run->bitmap_merged) {
+            const int xrc = run_extract_bitmap(run);
+            if (xrc) return xrc;
+        }
         HIP_TRY(hipStreamSynchronize(run->stream));
     }
     // ---- stage A: the runs of one device into that device's first run (its leader)
@@ -2311,7 +2360,17 @@ extern "C" int gs_match_max_counts(gs_run *run, int16_t *out) {
     std::vector<u64> table(n_slots);
     std::vector<uint32_t> counts(n_slots);
     HIP_TRY(hipStreamSynchronize(run->stream));
-    HIP_TRY(hipMemcpy(table.data(), run->db->d_table, n_slots * sizeof(u64), hipMemcpyDeviceToHost));
+    if (run->db->striped()) {  // the slices of the table from their stripes, the seen bits from the run's bitmap
+        std::vector<uint32_t> tseen((n_slots + 31) / 32);
+        HIP_TRY(hipMemcpy(tseen.data(), run->d_bitmap, tseen.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int q = 0; q < run->db->n_parts; q++) {
+            int64_t tfirst = 0, tlocal = 0;
+            const u64 *tq = stripe_table(run->db, q, &tfirst, &tlocal);
+            HIP_TRY(hipMemcpy(table.data() + (size_t)tfirst * GS_SLOTS_PER_BUCKET, tq, (size_t)tlocal * GS_SLOTS_PER_BUCKET * sizeof(u64), hipMemcpyDeviceToHost));
+        }
+        for (size_t i = 0; i < n_slots; i++) table[i] = (table[i] & ~1ULL) | ((tseen[i >> 5] >> (i & 31)) & 1u);
+    } else
+        HIP_TRY(hipMemcpy(table.data(), run->db->d_table, n_slots * sizeof(u64), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(counts.data(), run->d_hit_counts, n_slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::fill(out, out + (nv + 1) * (size_t)N, (int16_t)0);
     const u64 vmask = ((u64)1 << run->db->dev.vbits) - 1;

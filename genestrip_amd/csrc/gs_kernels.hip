@@ -254,30 +254,51 @@ __device__ __forceinline__ void gs_sc_store(int32_t *p, int v) { __hip_atomic_st
 struct GsMark {
     int count_unique;
     uint32_t *hit_counts;  // [table slots | GS_REC_SLOTS per record bucket] or nullptr
-    uint32_t *rec_seen;    // striped store: this run's seen bits, one word per record bucket (the record lines stay read-only)
+    // striped store: the store's memory is read-only (foreign stripes belong to other GPUs); the seen bits are this run's
+    uint32_t *tab_seen;    // one bit per table slot
+    uint32_t *rec_seen;    // one word per record bucket
 };
 
+// where a striped store keeps the pointers of its stripes: behind the two hash rows of the wave's LDS block
+// (GS_STRIPE_TABLE): GS_MAX_STRIPES record stripes, then GS_MAX_STRIPES table stripes, all biased (gs_layout.h)
+#define GS_ROW 160  // one LDS row: 128 + 16 positions, padded
+#define GS_STRIPE_WORDS (4 * GS_MAX_STRIPES)
+__device__ __forceinline__ const u64 *gs_rec_stripe(const GsDbDev &db, const uint32_t *wave_g, uint32_t bucket) {
+    return reinterpret_cast<const u64 *const *>(wave_g + 2 * GS_ROW)[(bucket * db.n_parts) >> db.rec_bits];
+}
+__device__ __forceinline__ const u64 *gs_tab_stripe(const GsDbDev &db, const uint32_t *wave_g, uint32_t bucket) {
+    return reinterpret_cast<const u64 *const *>(wave_g + 2 * GS_ROW)[GS_MAX_STRIPES + (((bucket >> 2) * db.n_parts) >> (db.bucket_bits - 2))];
+}
+
+template <bool STRIPED>
 __device__ __forceinline__ void gs_take_hit(const GsDbDev &db, uint32_t slot, int vs, int &node, const GsMark &mk) {
     node = vs >> 1;
-    if (mk.count_unique && (vs & 1) == 0) atomicOr(const_cast<u64 *>(db.table) + slot, 1ULL);
+    if (STRIPED) {
+        if (mk.count_unique) {
+            uint32_t *w = mk.tab_seen + (slot >> 5);
+            const uint32_t bit = 1u << (slot & 31);
+            if ((*w & bit) == 0) atomicOr(w, bit);
+        }
+    } else if (mk.count_unique && (vs & 1) == 0)
+        atomicOr(const_cast<u64 *>(db.table) + slot, 1ULL);
     if (mk.hit_counts != nullptr) atomicAdd(mk.hit_counts + slot, 1u);
 }
 
 // the rest of a table lookup for the lanes in `pending` (their k-mer was not decided by the first half of its home
 // bucket, or that half has not been looked at yet: FIRST): second half, then the displaced buckets
-template <bool FIRST>
+template <bool FIRST, bool STRIPED>
 __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, u64 want, uint32_t vmask2, bool pending, int &node,
-                                               const GsMark &mk) {
+                                               const GsMark &mk, const uint32_t *wave_g) {
     const uint32_t bmask = (uint32_t)db.bucket_mask;
 #pragma unroll
     for (int half = FIRST ? 0 : 1; half < 2; half++) {
         if (__ballot(pending) != 0) {  // (second half: more than four entries in the home bucket)
             if (pending) {
                 GsHalf t;
-                gs_load_half(db.table, bkt, half, t);
+                gs_load_half(STRIPED ? gs_tab_stripe(db, wave_g, bkt) : db.table, bkt, half, t);
                 int vs = -1, sl = 0;
                 const bool done = gs_match_half(t, want, vmask2, vs, sl);
-                if (vs >= 0) gs_take_hit(db, bkt * GS_SLOTS_PER_BUCKET + 4 * half + sl, vs, node, mk);
+                if (vs >= 0) gs_take_hit<STRIPED>(db, bkt * GS_SLOTS_PER_BUCKET + 4 * half + sl, vs, node, mk);
                 pending = !done;
             }
         }
@@ -287,10 +308,10 @@ __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, 
         if (pending) {
             const uint32_t b2 = (bkt + (uint32_t)disp) & bmask;
             GsBucket t;
-            gs_load_bucket(db.table, b2, t);
+            gs_load_bucket(STRIPED ? gs_tab_stripe(db, wave_g, b2) : db.table, b2, t);
             int vs = -1, sl = 0;
             const bool done = gs_match_bucket(t, want | ((u64)disp << (db.vbits + 1)), vmask2, vs, sl);
-            if (vs >= 0) gs_take_hit(db, b2 * GS_SLOTS_PER_BUCKET + sl, vs, node, mk);
+            if (vs >= 0) gs_take_hit<STRIPED>(db, b2 * GS_SLOTS_PER_BUCKET + sl, vs, node, mk);
             pending = !done;
         }
     }
@@ -299,8 +320,6 @@ __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, 
 // minimizer of the k-mers at positions base + 64 s + lane through the wave's LDS row: rank of every 15-mer of
 // positions base .. base+143, then per lane the minimum over its k-14 positions (one min3 chain; the rank carries the
 // row index, so the minimum is the position as well).  Returns the offset of the chosen 15-mer inside the lane's k-mer.
-#define GS_ROW 160  // one LDS row: 128 + 16 positions, padded
-
 // wave_g: two rows of GS_ROW words per wave -- the ranks, and behind them (canonical 15-mer << 1 | strand) of every position,
 // which the lane that picks a position reads back instead of recomputing it.  cf[s] = that word for the lane's minimizer.
 template <int KC>
@@ -401,9 +420,8 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
                     const u64 *r0, *r1;
                     if (STRIPED) {  // the stripe's (biased) base pointer from the wave's copy of the table, behind the hash rows
-                        const u64 *const *stripe = reinterpret_cast<const u64 *const *>(wave_g + 2 * GS_ROW);
-                        r0 = stripe[(b0 * db.n_parts) >> db.rec_bits] + (u64)b0 * GS_REC_WORDS;
-                        r1 = stripe[(b1 * db.n_parts) >> db.rec_bits] + (u64)b1 * GS_REC_WORDS;
+                        r0 = gs_rec_stripe(db, wave_g, b0) + (u64)b0 * GS_REC_WORDS;
+                        r1 = gs_rec_stripe(db, wave_g, b1) + (u64)b1 * GS_REC_WORDS;
                     } else {
                         r0 = db.rec + (u64)b0 * GS_REC_WORDS;
                         r1 = db.rec + (u64)b1 * GS_REC_WORDS;
@@ -430,7 +448,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                 // a k-mer whose window found no bucket (or that has two strand views) lives in the table
                 if (__ballot(pending) != 0) {
                     const u64 h = gs_kmer_hash(ohi[s], olo[s], k, kmask);
-                    gs_lookup_rest<true>(db, (uint32_t)h & bmask, (h >> db.bucket_bits) << shift_rem, vmask2, pending, node[s], mk);
+                    gs_lookup_rest<true, STRIPED>(db, (uint32_t)h & bmask, (h >> db.bucket_bits) << shift_rem, vmask2, pending, node[s], mk, wave_g);
                 }
             }
             return;
@@ -457,10 +475,10 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         if (act[s]) {
             int vs = -1, sl = 0;
             const bool done = gs_match_half(bk[s], want[s], vmask2, vs, sl);
-            if (vs >= 0) gs_take_hit(db, bkt[s] * GS_SLOTS_PER_BUCKET + sl, vs, node[s], mk);
+            if (vs >= 0) gs_take_hit<false>(db, bkt[s] * GS_SLOTS_PER_BUCKET + sl, vs, node[s], mk);
             pending = !done;
         }
-        gs_lookup_rest<false>(db, bkt[s], want[s], vmask2, pending, node[s], mk);
+        gs_lookup_rest<false, false>(db, bkt[s], want[s], vmask2, pending, node[s], mk, wave_g);
     }
 }
 
@@ -546,7 +564,8 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 }
             } else {
                 // (4a. unique k-mers and per-k-mer hit counters are marked by the probe itself)
-                const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
+                const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap : nullptr,
+                                   STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
                 gs_probe_planes<KC, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
@@ -974,8 +993,9 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
 // LDS behind its hash rows, where a lane picks the one of its bucket with a single ds_read
 #define GS_STRIPE_TABLE(kernarg)                                                                                        \
     if (STRIPED) {                                                                                                       \
-        if (lane < GS_MAX_STRIPES)                                                                                       \
-            reinterpret_cast<const u64 **>(s_g[wave_in_block] + 2 * GS_ROW)[lane] = (kernarg)->db.rec_biased[lane];      \
+        if (lane < 2 * GS_MAX_STRIPES)                                                                                   \
+            reinterpret_cast<const u64 **>(s_g[wave_in_block] + 2 * GS_ROW)[lane] =                                      \
+                lane < GS_MAX_STRIPES ? (kernarg)->db.rec_biased[lane] : (kernarg)->db.tab_biased[lane - GS_MAX_STRIPES]; \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                           \
         __builtin_amdgcn_wave_barrier();                                                                                 \
     }
@@ -986,7 +1006,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
     __shared__ int s_dcnt[GS_BLOCK / 64][128];
     // 15-mer order hashes of the wave's current 144 positions (+ the stripe pointers)
-    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
-    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
     GS_STRIPE_TABLE(&P)
     const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
@@ -1480,7 +1500,7 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
 // ---------------------------------------------------------------------------------------------------
 template <bool WRITE, bool STRIPED>
 __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
-    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? 2 * GS_MAX_STRIPES : 0)];
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
     const GsDbDev &db = P.db;
     const int lane = gs_lane();
     const int wave_in_block = (int)(threadIdx.x >> 6);
@@ -1488,7 +1508,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = db.k;
-    const GsMark nomark = {0, nullptr, nullptr};
+    const GsMark nomark = {0, nullptr, nullptr, nullptr};
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];

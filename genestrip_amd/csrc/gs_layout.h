@@ -159,6 +159,10 @@ GS_HD void gs_min_oriented(uint32_t fhi, uint32_t flo, uint32_t rhi, uint32_t rl
 GS_HD uint64_t gs_stripe_first(uint32_t rec_bits, uint32_t n_parts, uint32_t p) {
     return (((uint64_t)p << rec_bits) + n_parts - 1) / n_parts;
 }
+// ... and the first table bucket of stripe p (groups of four buckets; bucket_bits >= 5 in a striped store)
+GS_HD uint64_t gs_tab_stripe_first(uint32_t bucket_bits, uint32_t n_parts, uint32_t p) {
+    return 4 * gs_stripe_first(bucket_bits - 2, n_parts, p);
+}
 
 GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits, int choice) {
     return (gh * (choice ? 0x165667B1u : 0x27D4EB2Fu)) >> (32 - rec_bits);
@@ -194,7 +198,11 @@ struct GsDbDev {
     // at rec_biased[p] + b * GS_REC_WORDS (the stripe's base pointer minus its first bucket).  Foreign stripes are read
     // over xGMI peer access and never written: the seen bits of a striped store live in the run's own bitmap.
     // n_parts <= 1: plain store (`rec` above).
+    // The overflow table is striped the same way in units of four buckets (so that a stripe starts on a word of the slot
+    // bitmap): bucket b belongs to stripe ((b >> 2) * n_parts) >> (bucket_bits - 2), its line is at tab_biased[p] +
+    // b * GS_SLOTS_PER_BUCKET; `table` is nullptr then.
     uint32_t n_parts;
     uint32_t pad_;
     const unsigned long long *rec_biased[GS_MAX_STRIPES];
+    const unsigned long long *tab_biased[GS_MAX_STRIPES];
 };

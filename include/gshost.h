@@ -81,7 +81,7 @@ int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_p
                        int64_t *reads_of_file, gs_host_totals *totals);
 
 /* runMatcher over the files of a sample on several devices of THIS process (what a JVM host with 8 GPUs calls):
- * dbs[d] = a replica of the store on device d; file i goes to replica i % n_dbs, every replica runs on a thread of its
+ * dbs[d] = a replica of the store on device d (or the handles of ONE striped store, gs_db_create_striped); file i goes to replica i % n_dbs, every replica runs on a thread of its
  * own (as gs_host_match_into), the runs are merged with gs_match_merge (RCCL between devices) and finished once.  The
  * table equals the one gs_host_match_files returns for the same files in the same order.  No per-read outputs. */
 int gs_host_match_files_multi(gs_db *const *dbs, int n_dbs, const gs_match_cfg *cfg, const char *const *paths, int n_paths,

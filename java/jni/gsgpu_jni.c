@@ -36,6 +36,22 @@ JNIEXPORT jlong JNICALL JNAME(dbCreate)(JNIEnv *env, jclass c, jint device, jint
     return (jlong)(intptr_t)db;
 }
 
+JNIEXPORT void JNICALL JNAME(dbCreateStriped)(JNIEnv *env, jclass c, jlongArray devicesThenHandles, jint k, jlong n, jobject kmers,
+                                              jobject vidx, jint nValues, jobject parentVi) {
+    jsize ns = (*env)->GetArrayLength(env, devicesThenHandles);
+    jlong *h = (*env)->GetLongArrayElements(env, devicesThenHandles, NULL);
+    int devices[GS_MAX_STRIPES];
+    gs_db *dbs[GS_MAX_STRIPES];
+    int rc = (ns < 2 || ns > GS_MAX_STRIPES) ? GS_E_INVALID : GS_OK;
+    for (jsize i = 0; i < ns && rc == GS_OK; i++) devices[i] = (int)h[i];
+    if (rc == GS_OK)
+        rc = gs_db_create_striped(dbs, devices, (int)ns, k, n, (const int64_t *)addr(env, kmers), (const int32_t *)addr(env, vidx),
+                                  nValues, (const int32_t *)addr(env, parentVi));
+    for (jsize i = 0; i < ns && rc == GS_OK; i++) h[i] = (jlong)(intptr_t)dbs[i];
+    (*env)->ReleaseLongArrayElements(env, devicesThenHandles, h, rc == GS_OK ? 0 : JNI_ABORT);
+    if (rc) throw_gs(env, rc);
+}
+
 JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db_destroy((gs_db *)(intptr_t)db); }
 
 JNIEXPORT void JNICALL JNAME(dbSave)(JNIEnv *env, jclass c, jlong db, jstring path) {

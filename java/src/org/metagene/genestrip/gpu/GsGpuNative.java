@@ -27,6 +27,12 @@ public final class GsGpuNative {
 	public static native long dbCreate(int device, int k, long nEntries, ByteBuffer kmers, ByteBuffer valueIdx,
 			int nValues, ByteBuffer parentVi);
 
+	/** gs_db_create_striped: ONE store whose record table is split over several GPUs (a store that does not fit one of
+	 *  them).  devicesThenHandles holds the device of every stripe on entry and the gs_db handle of every stripe on return;
+	 *  begin one run per handle (matchBegin), deal the reads to them, matchMerge, matchFinish on any. */
+	public static native void dbCreateStriped(long[] devicesThenHandles, int k, long nEntries, ByteBuffer kmers,
+			ByteBuffer valueIdx, int nValues, ByteBuffer parentVi);
+
 	/** gs_db_save / gs_db_load: the native image of the device store */
 	public static native void dbSave(long db, String path);
 

@@ -70,6 +70,44 @@ def test_match_on_the_47m_kmer_store(big):
     store.close()
 
 
+def test_the_47m_kmer_store_striped_eight_ways(big):
+    """configs[4]'s shape on one GPU: the record table in 8 stripes (what 8 GPUs would each hold), three runs on different
+    handles over disjoint shards of the reads, merged -- against ONE run on the plain store, and the oracle"""
+    from genestrip_amd import binding
+    db, dseq, doff, seq, off = big
+    plain = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    m = ga.FastqKMerMatcher(plain)
+    m.submit(dseq, doff, 0, n_reads=N_READS)
+    whole, _ = m.finish()
+    m.close()
+    pinfo = plain.info
+    plain.close()
+    stores = ga.DeviceKMerStore.striped(31, db.kmers, db.value_idx, db.n_values, db.parent_vi, devices=(0,) * 8)
+    infos = [s.info for s in stores]
+    assert sum(i.stripe_bytes for i in infos) == pinfo.rec_bytes + pinfo.table_bytes and infos[3].n_in_records == pinfo.n_in_records
+    assert max(i.stripe_bytes for i in infos) - min(i.stripe_bytes for i in infos) <= 64 + 4 * 64  # one record line, four buckets
+    ms = [ga.FastqKMerMatcher(stores[i]) for i in (0, 3, 7)]
+    cuts = [0, 650_001, 1_300_000, N_READS]
+    for r, (a, b) in zip(ms, zip(cuts[:-1], cuts[1:])):
+        r.submit(dseq, doff[a:].contiguous(), a, n_reads=b - a)
+    binding.merge_runs(ms)
+    for r in ms:
+        t, _ = r.finish()
+        assert np.array_equal(t, whole), np.argwhere(t != whole)[:6]
+    odb = orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
+    orun = orc.MatchRun(odb)
+    orun.submit(seq, off, threads=16, per_read=False)
+    ot, _ = orun.finish()
+    ms[1].reset()
+    ms[1].submit(dseq, doff, 0, n_reads=N_CHECK)
+    gt, _ = ms[1].finish()
+    assert np.array_equal(ot, gt)
+    for r in ms:
+        r.close()
+    for s in stores:
+        s.close()
+
+
 def test_filter_on_the_full_size_index(big):
     import torch
     db, dseq, doff, seq, off = big

@@ -254,10 +254,11 @@ def test_partitioned_batch_fused_unfused_and_overflow_fallback(sdb):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["partitioned", "sharded"])
+@pytest.mark.parametrize("mode", ["partitioned", "sharded", "striped"])
 def test_two_rank_bench_flow_over_gloo(mode):
     """bench.py's multi-rank control flow (barriers, routing all-to-alls or state merge, rank-0-only legs) with two
-    processes on this one GPU; the collectives run over gloo on host copies (GS_BENCH_BACKEND=gloo, a rehearsal mode:
+    processes on this one GPU (striped: each rank owns one stripe of the record table and reads the other through a HIP IPC
+    handle -- real cross-process peer mapping, only not across xGMI); the collectives run over gloo on host copies (GS_BENCH_BACKEND=gloo, a rehearsal mode:
     the numbers mean nothing).  Both ranks must end with the same merged table, bit-exact against the oracle."""
     import json
     import subprocess

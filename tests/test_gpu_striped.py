@@ -39,7 +39,7 @@ def test_one_run_on_a_striped_store_equals_the_oracle(sdb, reads, n_stripes, cfg
     stores = ga.DeviceKMerStore.striped(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, devices=(0,) * n_stripes)
     infos = [s.info for s in stores]
     assert [i.stripe for i in infos] == list(range(n_stripes)) and all(i.n_stripes == n_stripes for i in infos)
-    assert sum(i.stripe_bytes for i in infos) == infos[0].rec_bytes and infos[0].n_in_records > 0
+    assert sum(i.stripe_bytes for i in infos) == infos[0].rec_bytes + infos[0].table_bytes and infos[0].n_in_records > 0
     # any of the handles serves the whole store
     for s in (stores[0], stores[-1]):
         m = ga.FastqKMerMatcher(s, ga.MatchConfig(**cfg))
@@ -73,6 +73,32 @@ def test_striped_runs_merge_like_replicas(sdb, reads):
         t = m.finish()[0]
         assert np.array_equal(t, want), np.argwhere(t != want)[:6]
         m.close()
+    for s in stores:
+        s.close()
+
+
+def test_files_over_the_handles_of_a_striped_store(sdb, tmp_path):
+    """gs_host_match_files_multi (what a JVM host with one gs_run per GPU calls) takes the handles of ONE striped store just
+    like replicas: files dealt to the handles, one thread each, merged, finished once"""
+    from genestrip_amd import host
+    seq, off = synth.reads_host(sdb.genomes, 9000, read_len=150, seed=77)
+    off = off.astype(np.uint64)
+    cuts = [0, 2500, 2501, 6000, 9000]
+    paths = []
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        p = str(tmp_path / f"s{i}.fastq")
+        with open(p, "wb") as f:
+            for r in range(a, b):
+                rd = seq[int(off[r]):int(off[r + 1])].tobytes()
+                f.write(b"@r%d\n%s\n+\n%s\n" % (r, rd, b"F" * len(rd)))
+        paths.append(p)
+    want = _oracle(sdb, seq, off)[0][0]
+    stores = ga.DeviceKMerStore.striped(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, devices=(0, 0, 0))
+    table, _, tot = host.match_files_multi(stores, paths)
+    assert tot.reads == 9000
+    assert np.array_equal(table, want), np.argwhere(table != want)[:6]
+    single, _, _ = host.match_files(stores[2], paths)
+    assert np.array_equal(single, want)
     for s in stores:
         s.close()
 
