@@ -808,7 +808,7 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE6"
+    char magic[8];  // "GSSTORE7"
     gs_db_info info;
     uint32_t bucket_bits, vbits;
     uint64_t gate_words;
@@ -896,7 +896,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     if (db->striped()) return fail(GS_E_UNSUPPORTED, "a striped store is not saved as such: save the store built by gs_db_create");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE6", 8);
+    memcpy(h.magic, "GSSTORE7", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
@@ -945,7 +945,7 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE6", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE7", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
         h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
         h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30) || h.rec_buckets > ((uint64_t)1 << 29)) {
         fclose(f);

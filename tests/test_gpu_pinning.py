@@ -142,7 +142,7 @@ def test_damaged_store_files_are_refused(tmp_path):
     store.close()
     raw = bytearray(good.read_bytes())
     ga.DeviceKMerStore.load(good).close()
-    hdr = 8 + 80 + 8 + 8 + 8 + 8 + 8  # magic | gs_db_info | bucket_bits, vbits | gate_words | mgate_words | rec_buckets | checksum
+    hdr = 8 + 96 + 8 + 8 + 8 + 8 + 8  # magic | gs_db_info | bucket_bits, vbits | gate_words | mgate_words | rec_buckets | checksum
     assert info.rec_bytes > 0 and info.n_in_records > 0.5 * info.n_stored
     assert len(raw) == hdr + info.table_bytes + info.gate_bytes + info.mgate_bytes + info.rec_bytes + 16 * info.n_values
 
