@@ -98,8 +98,8 @@ def main():
                     help="--mode striped with ONE rank: stripes of the record table, all in this GPU's HBM (prices the "
                          "stripe arithmetic of the kernel; with N ranks there is one stripe per rank)")
     ap.add_argument("--genera", type=int, default=0, help="size of the synthetic store: genera of 20 species (0: configs[1]'s store)")
-    ap.add_argument("--legs", default="main,large,filter,e2e",
-                    help="comma list; large / filter / e2e are the extra N = 1 objects (main always runs)")
+    ap.add_argument("--legs", default="main,large,filter,e2e,striped",
+                    help="comma list; large / filter / e2e / striped are the extra N = 1 objects (main always runs)")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
 
@@ -316,6 +316,8 @@ def main():
             del seq, off
         odb.close()
         if world == 1 and not partitioned and not striped and not args.genera:
+            if "striped" in legs:
+                out["striped_store"] = leg_striped(ga, db, local_rank, dseq, doff, n, nchk, otable, kern_ms)
             if "e2e" in legs:
                 out["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
             m.close()
@@ -328,6 +330,32 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def leg_striped(ga, db, device, dseq, doff, n, nchk, otable, plain_ms, stripes=8):
+    """BASELINE.json configs[4] (a store spread over 8 GPUs) as far as ONE GPU can show it: the same store with its record
+    and overflow tables in 8 stripes (gs_db_create_striped, all stripes in this GPU's HBM), the same 10 M reads through the
+    striped instantiation of the fused kernel -- stripe pointer per bucket from LDS, seen bits in the run's bitmap.  What
+    is not in this number is the xGMI hop of a foreign line.  Parity: the first nchk reads against the oracle table."""
+    stores = ga.DeviceKMerStore.striped(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, devices=(device,) * stripes)
+    ms = ga.FastqKMerMatcher(stores[stripes // 2], ga.MatchConfig(profile=True))
+    info = stores[0].info
+
+    def launch():
+        ms.reset()
+        ms.submit(dseq, doff, 0, n_reads=n)
+
+    kms, _ = _kernel_ms(ms, launch, 5)
+    ms.reset()
+    ms.submit(dseq, doff, 0, n_reads=nchk)
+    table, _ = ms.finish()
+    ms.close()
+    for s in stores:
+        s.close()
+    return {"stripes": stripes, "stripe_bytes": int(info.stripe_bytes), "kernel_ms": round(kms, 4),
+            "gbps": round(n * READ_LEN / kms / 1e6, 2), "kernel_ms_plain_store": round(plain_ms, 4),
+            "over_plain": round(kms / plain_ms, 4), "where": "all stripes in this GPU's HBM (no xGMI hop in this number)",
+            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
 
 
 def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):
