@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -116,6 +116,8 @@ def lib():
         "gs_db_create_stripe": (ci, [vp, ci, ci, ci, ci, i64, vp, vp, i32, vp]),
         "gs_db_stripe_export": (ci, [vp, vp]),
         "gs_db_stripe_attach": (ci, [vp, ci, vp]),
+        "gs_db_load_striped": (ci, [vp, vp, ci, C.c_char_p]),
+        "gs_db_load_stripe": (ci, [vp, ci, ci, ci, C.c_char_p]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
         "gs_unroute_region": (ci, [vp, vp, vp, i64, vp]),
@@ -251,6 +253,30 @@ class DeviceKMerStore:
                                          vidx.ctypes.data_as(C.c_void_p), n_values,
                                          None if pv is None else pv.ctypes.data_as(C.c_void_p)))
         return cls._wrap(h, k, n_values, device)
+
+    @classmethod
+    def load_striped(cls, path, devices=(0, 0)):
+        """gs_db_load_striped: a store file (save() of a plain store) into the HBM of `devices`, one stripe each"""
+        n = len(devices)
+        out = (C.c_void_p * n)()
+        _check(lib().gs_db_load_striped(out, (C.c_int * n)(*devices), n, str(path).encode()))
+        res = []
+        for p in range(n):
+            s = cls._wrap(C.c_void_p(out[p]), 0, 0, devices[p])
+            i = s.info
+            s.k, s.n_values = i.k, i.n_values
+            res.append(s)
+        return res
+
+    @classmethod
+    def load_stripe(cls, path, device=0, n_stripes=2, stripe=0):
+        """gs_db_load_stripe: this process's stripe of a store file (then export_stripe / attach_stripe as for stripe())"""
+        h = C.c_void_p()
+        _check(lib().gs_db_load_stripe(C.byref(h), device, n_stripes, stripe, str(path).encode()))
+        s = cls._wrap(h, 0, 0, device)
+        i = s.info
+        s.k, s.n_values = i.k, i.n_values
+        return s
 
     def export_stripe(self):
         buf = C.create_string_buffer(64)

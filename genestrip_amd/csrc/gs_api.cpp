@@ -274,6 +274,163 @@ extern "C" int gs_db_stripe_attach(gs_db *db, int stripe, const void *handle) {
     return GS_OK;
 }
 
+// ---- a built store on the host (from the builder or from a store file) and its way into HBM
+struct StoreImage {
+    int k = 0, n_values = 0;
+    int64_t n_entries = 0, n_stored = 0, n_in_records = 0;
+    int b = 0, vbits = 0, rec_bits = 0, max_disp = 0;
+    const u64 *table = nullptr;
+    size_t table_words = 0;
+    const u64 *gate = nullptr;
+    size_t gate_words = 0;
+    const uint32_t *mgate = nullptr;
+    size_t mgate_words = 0;
+    const u64 *rec = nullptr;
+    size_t rec_words = 0;
+    const int32_t *parent = nullptr, *depth = nullptr, *tin = nullptr, *tout = nullptr;
+};
+
+// one handle: the whole store (stripes <= 1), or stripe `part` of `stripes` -- the record buckets gs_stripe_first(part) up
+// to gs_stripe_first(part + 1) and the table buckets gs_tab_stripe_first(..) in ONE allocation (one IPC handle), and
+// everything else (gates, tree) in full
+static int store_upload(const StoreImage &im, int dev_no, int stripes, int part, gs_db **res) {
+    *res = nullptr;
+    HIP_TRY(hipSetDevice(dev_no));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev_no));
+    gs_db *db = new gs_db();
+    db->device = dev_no;
+    db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const int n_values = im.n_values;
+    const int64_t n_rec_total = im.rec_words ? (int64_t)1 << im.rec_bits : 0;
+    int64_t rfirst = 0, rlocal = n_rec_total, tfirst = 0, tlocal = (int64_t)1 << im.b;
+    if (stripes > 1) {
+        rfirst = (int64_t)gs_stripe_first((uint32_t)im.rec_bits, (uint32_t)stripes, (uint32_t)part);
+        rlocal = (int64_t)gs_stripe_first((uint32_t)im.rec_bits, (uint32_t)stripes, (uint32_t)part + 1) - rfirst;
+        tfirst = (int64_t)gs_tab_stripe_first((uint32_t)im.b, (uint32_t)stripes, (uint32_t)part);
+        tlocal = (int64_t)gs_tab_stripe_first((uint32_t)im.b, (uint32_t)stripes, (uint32_t)part + 1) - tfirst;
+    }
+    const size_t tbytes = (size_t)tlocal * GS_SLOTS_PER_BUCKET * sizeof(u64);
+    const size_t rbytes = (size_t)rlocal * GS_REC_WORDS * sizeof(u64);
+    const u64 *rsrc = im.rec + (size_t)rfirst * GS_REC_WORDS;
+    const u64 *tsrc = im.table + (size_t)tfirst * GS_SLOTS_PER_BUCKET;
+    hipError_t e = hipSuccess;
+    if (stripes > 1) {
+        e = hipMalloc((void **)&db->d_rec, rbytes + tbytes);
+        if (e == hipSuccess) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) db->d_table = db->d_rec + (size_t)rlocal * GS_REC_WORDS;
+    } else {
+        e = hipMalloc((void **)&db->d_table, tbytes);
+        if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
+        if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
+    if (e == hipSuccess && im.gate_words) e = hipMalloc((void **)&db->d_gate, im.gate_words * sizeof(u64));
+    if (e == hipSuccess && im.gate_words) e = hipMemcpy(db->d_gate, im.gate, im.gate_words * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && im.mgate_words) e = hipMalloc((void **)&db->d_mgate, im.mgate_words * sizeof(uint32_t));
+    if (e == hipSuccess && im.mgate_words) e = hipMemcpy(db->d_mgate, im.mgate, im.mgate_words * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_table, tsrc, tbytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree, im.parent, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, im.depth, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, im.tin, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, im.tout, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (stripes > 1) db->d_table = nullptr;  // (inside d_rec)
+        db_free(db);
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
+    }
+    db->info.k = im.k;
+    db->info.n_values = n_values;
+    db->info.n_entries = im.n_entries;
+    db->info.n_stored = im.n_stored;
+    db->info.n_in_records = im.n_in_records;
+    db->info.rec_bytes = (int64_t)(im.rec_words * sizeof(u64));
+    db->n_rec = n_rec_total;
+    db->dev.rec = stripes > 1 ? nullptr : db->d_rec;
+    db->dev.rec_bits = (uint32_t)im.rec_bits;
+    db->info.n_buckets = (int64_t)1 << im.b;
+    db->info.table_bytes = (int64_t)(im.table_words * sizeof(u64));
+    db->info.max_displacement = im.max_disp;
+    db->info.value_bits = im.vbits;
+    db->dev.table = stripes > 1 ? nullptr : db->d_table;
+    db->dev.gate = db->d_gate;
+    db->dev.gate_mask = im.gate_words ? (u64)im.gate_words - 1 : 0;
+    db->info.gate_bytes = (int64_t)(im.gate_words * sizeof(u64));
+    db->dev.mgate = db->d_mgate;
+    db->dev.mgate_bits = 0;
+    while (((size_t)1 << db->dev.mgate_bits) < im.mgate_words) db->dev.mgate_bits++;
+    db->info.mgate_bytes = (int64_t)(im.mgate_words * sizeof(uint32_t));
+    db->dev.bucket_bits = (uint32_t)im.b;
+    db->dev.vbits = (uint32_t)im.vbits;
+    db->dev.bucket_mask = (1ULL << im.b) - 1;
+    db->dev.k = im.k;
+    db->dev.n_values = n_values;
+    db->dev.parent = db->d_tree;
+    db->dev.depth = db->d_tree + n_values;
+    db->dev.tin = db->d_tree + 2 * (size_t)n_values;
+    db->dev.tout = db->d_tree + 3 * (size_t)n_values;
+    if (stripes > 1) {
+        db->n_parts = stripes;
+        db->part = part;
+        db->rec_first = rfirst;
+        db->rec_local = rlocal;
+        db->tab_first = tfirst;
+        db->tab_local = tlocal;
+        db->info.n_stripes = stripes;
+        db->info.stripe = part;
+        db->info.stripe_bytes = (int64_t)(rbytes + tbytes);
+        db->dev.n_parts = (uint32_t)stripes;
+        db_set_stripe(db, part, db->d_rec);
+    }
+    *res = db;
+    return GS_OK;
+}
+
+// stripes <= 1: out[0] on `device`.  stripe_only >= 0: out[0] = that stripe on `device` (the others arrive through
+// gs_db_stripe_attach).  Else every stripe in this process, out[p] on stripe_devices[p]: the handles know each other's
+// stripes, which belong to all of them together.
+static int store_place(const StoreImage &im, int device, int stripes, const int *stripe_devices, int stripe_only, gs_db **out) {
+    if (stripes > 1 && im.rec_words == 0)
+        return fail(GS_E_UNSUPPORTED, "a striped store needs super-k-mer records (k >= 19, at most 2^21 values, a non-empty store)");
+    if (stripes <= 1) return store_upload(im, device, 1, 0, out);
+    if (stripe_only >= 0) return store_upload(im, device, stripes, stripe_only, out);
+    int rc = GS_OK;
+    auto group = std::make_shared<StripeGroup>();
+    std::vector<gs_db *> made;
+    for (int p = 0; p < stripes && rc == GS_OK; p++) {
+        gs_db *db = nullptr;
+        rc = store_upload(im, stripe_devices[p], stripes, p, &db);
+        if (rc == GS_OK) {
+            made.push_back(db);
+            group->allocs.push_back({db->device, db->d_rec});
+            db->group = group;
+        }
+    }
+    for (int p = 0; p < stripes && rc == GS_OK; p++)
+        for (int q = 0; q < stripes && rc == GS_OK; q++) {
+            if (q == p) continue;
+            if (made[(size_t)p]->device != made[(size_t)q]->device) {
+                hipSetDevice(made[(size_t)p]->device);
+                int can = 0;
+                hipDeviceCanAccessPeer(&can, made[(size_t)p]->device, made[(size_t)q]->device);
+                if (!can)
+                    rc = fail(GS_E_UNSUPPORTED, "the devices of a striped store need peer access to each other");
+                else {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(made[(size_t)q]->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) rc = fail(GS_E_HIP, std::string("peer access: ") + hipGetErrorString(pe));
+                    (void)hipGetLastError();
+                }
+            }
+            if (rc == GS_OK) db_set_stripe(made[(size_t)p], q, made[(size_t)q]->d_rec);
+        }
+    if (rc != GS_OK) {
+        for (gs_db *db : made) db_free(db);
+        return rc;
+    }
+    for (int p = 0; p < stripes; p++) out[p] = made[(size_t)p];
+    return GS_OK;
+}
+
 // fused: the store serves the fused kernels (gs_match_submit*, gs_match_segments) and may keep k-mers in super-k-mer
 // records; a partition store (gs_db_create_part, any n_parts) keeps every key in the table, where gs_match_probe_keys looks
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
@@ -666,137 +823,29 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         mgate.assign((size_t)1 << mgate_bits, 0);
         for (int64_t i = 0; i < nm; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
     }
-    // ---- upload.  A striped store (stripes > 1) puts the record buckets of stripe p -- gs_stripe_first(p) up to
-    // gs_stripe_first(p + 1) -- on one device and everything else (gates, overflow table, tree) on every device.
-    const int64_t n_rec_total = rec.empty() ? 0 : (int64_t)1 << rec_bits;
-    if (stripes > 1 && rec.empty())
-        return fail(GS_E_UNSUPPORTED, "a striped store needs super-k-mer records (k >= 19, at most 2^21 values, a non-empty store)");
-    auto upload = [&](int dev_no, int part, gs_db **res) -> int {
-        *res = nullptr;
-        HIP_TRY(hipSetDevice(dev_no));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dev_no));
-        gs_db *db = new gs_db();
-        db->device = dev_no;
-        db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        int64_t rfirst = 0, rlocal = n_rec_total, tfirst = 0, tlocal = (int64_t)1 << b;
-        if (stripes > 1) {
-            rfirst = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part);
-            rlocal = (int64_t)gs_stripe_first((uint32_t)rec_bits, (uint32_t)stripes, (uint32_t)part + 1) - rfirst;
-            tfirst = (int64_t)gs_tab_stripe_first((uint32_t)b, (uint32_t)stripes, (uint32_t)part);
-            tlocal = (int64_t)gs_tab_stripe_first((uint32_t)b, (uint32_t)stripes, (uint32_t)part + 1) - tfirst;
-        }
-        const size_t tbytes = (size_t)tlocal * GS_SLOTS_PER_BUCKET * sizeof(u64);
-        const size_t rbytes = (size_t)rlocal * GS_REC_WORDS * sizeof(u64);
-        const u64 *rsrc = rec.data() + (size_t)rfirst * GS_REC_WORDS;
-        const u64 *tsrc = table.data() + (size_t)tfirst * GS_SLOTS_PER_BUCKET;
-        hipError_t e = hipSuccess;
-        if (stripes > 1) {  // ONE allocation per stripe (one IPC handle): its record lines, then its table buckets
-            e = hipMalloc((void **)&db->d_rec, rbytes + tbytes);
-            if (e == hipSuccess) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
-            if (e == hipSuccess) db->d_table = db->d_rec + (size_t)rlocal * GS_REC_WORDS;
-        } else {
-            e = hipMalloc((void **)&db->d_table, tbytes);
-            if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
-            if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
-        }
-        if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
-        if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
-        if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
-        if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
-        if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_table, tsrc, tbytes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_tree, parent.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, depth.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            if (stripes > 1) db->d_table = nullptr;  // (inside d_rec)
-            db_free(db);
-            return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
-        }
-        db->info.k = k;
-        db->info.n_values = n_values;
-        db->info.n_entries = n;
-        db->info.n_stored = ns + n_in_records;
-        db->info.n_in_records = n_in_records;
-        db->info.rec_bytes = (int64_t)(rec.size() * sizeof(u64));
-        db->n_rec = n_rec_total;
-        db->dev.rec = stripes > 1 ? nullptr : db->d_rec;
-        db->dev.rec_bits = (uint32_t)rec_bits;
-        db->info.n_buckets = (int64_t)1 << b;
-        db->info.table_bytes = (int64_t)(table.size() * sizeof(u64));
-        db->info.max_displacement = max_disp;
-        db->info.value_bits = vbits;
-        db->dev.table = stripes > 1 ? nullptr : db->d_table;
-        db->dev.gate = db->d_gate;
-        db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
-        db->info.gate_bytes = (int64_t)(gate.size() * sizeof(u64));
-        db->dev.mgate = db->d_mgate;
-        db->dev.mgate_bits = 0;
-        while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
-        db->info.mgate_bytes = (int64_t)(mgate.size() * sizeof(uint32_t));
-        db->dev.bucket_bits = (uint32_t)b;
-        db->dev.vbits = (uint32_t)vbits;
-        db->dev.bucket_mask = (1ULL << b) - 1;
-        db->dev.k = k;
-        db->dev.n_values = n_values;
-        db->dev.parent = db->d_tree;
-        db->dev.depth = db->d_tree + n_values;
-        db->dev.tin = db->d_tree + 2 * (size_t)n_values;
-        db->dev.tout = db->d_tree + 3 * (size_t)n_values;
-        if (stripes > 1) {
-            db->n_parts = stripes;
-            db->part = part;
-            db->rec_first = rfirst;
-            db->rec_local = rlocal;
-            db->tab_first = tfirst;
-            db->tab_local = tlocal;
-            db->info.n_stripes = stripes;
-            db->info.stripe = part;
-            db->info.stripe_bytes = (int64_t)(rbytes + tbytes);
-            db->dev.n_parts = (uint32_t)stripes;
-            db_set_stripe(db, part, db->d_rec);
-        }
-        *res = db;
-        return GS_OK;
-    };
-    if (stripes <= 1) return upload(device, 0, out);
-    if (stripe_only >= 0) return upload(device, stripe_only, out);  // the other stripes arrive through gs_db_stripe_attach
-    // every stripe in this process: the handles know each other's stripes, which belong to all of them together
-    auto group = std::make_shared<StripeGroup>();
-    std::vector<gs_db *> made;
-    for (int p = 0; p < stripes && rc == GS_OK; p++) {
-        gs_db *db = nullptr;
-        rc = upload(stripe_devices[p], p, &db);
-        if (rc == GS_OK) {
-            made.push_back(db);
-            group->allocs.push_back({db->device, db->d_rec});
-            db->group = group;
-        }
-    }
-    for (int p = 0; p < stripes && rc == GS_OK; p++)
-        for (int q = 0; q < stripes && rc == GS_OK; q++) {
-            if (q == p) continue;
-            if (made[(size_t)p]->device != made[(size_t)q]->device) {
-                hipSetDevice(made[(size_t)p]->device);
-                int can = 0;
-                hipDeviceCanAccessPeer(&can, made[(size_t)p]->device, made[(size_t)q]->device);
-                if (!can) rc = fail(GS_E_UNSUPPORTED, "the devices of a striped store need peer access to each other");
-                else {
-                    const hipError_t pe = hipDeviceEnablePeerAccess(made[(size_t)q]->device, 0);
-                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) rc = fail(GS_E_HIP, std::string("peer access: ") + hipGetErrorString(pe));
-                    (void)hipGetLastError();
-                }
-            }
-            if (rc == GS_OK) db_set_stripe(made[(size_t)p], q, made[(size_t)q]->d_rec);
-        }
-    if (rc != GS_OK) {
-        for (gs_db *db : made) db_free(db);
-        return rc;
-    }
-    for (int p = 0; p < stripes; p++) out[p] = made[(size_t)p];
-    return GS_OK;
+    StoreImage im{};
+    im.k = k;
+    im.n_values = n_values;
+    im.n_entries = n;
+    im.n_stored = ns + n_in_records;
+    im.n_in_records = n_in_records;
+    im.b = b;
+    im.vbits = vbits;
+    im.rec_bits = rec_bits;
+    im.max_disp = max_disp;
+    im.table = table.data();
+    im.table_words = table.size();
+    im.gate = gate.data();
+    im.gate_words = gate.size();
+    im.mgate = mgate.data();
+    im.mgate_words = mgate.size();
+    im.rec = rec.data();
+    im.rec_words = rec.size();
+    im.parent = parent.data();
+    im.depth = depth.data();
+    im.tin = tin.data();
+    im.tout = tout.data();
+    return store_place(im, device, stripes, stripe_devices, stripe_only, out);
 }
 
 extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
@@ -937,9 +986,10 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
-extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
+// a store file into HBM: whole (stripes <= 1) or striped, as store_place
+static int db_load_impl(gs_db **out, int device, const char *path, int stripes, const int *stripe_devices, int stripe_only) {
     if (!out || !path) return fail(GS_E_INVALID, "NULL argument");
-    *out = nullptr;
+    for (int p = 0; p < (stripes > 1 && stripe_only < 0 ? stripes : 1); p++) out[p] = nullptr;
     int rc = use_device(device);
     if (rc) return rc;
     FILE *f = fopen(path, "rb");
@@ -980,57 +1030,58 @@ extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
         if (cs.value() != h.checksum) return fail(GS_E_INVALID, std::string(path) + ": payload checksum mismatch (damaged file)");
     }
     if (const char *why = store_image_defect(h, table, rec, tree)) return fail(GS_E_INVALID, std::string(path) + ": " + why);
-    gs_db *db = new gs_db();
-    db->device = device;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e == hipSuccess) db->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (e == hipSuccess) e = hipMalloc((void **)&db->d_table, table.size() * sizeof(u64));
-    if (e == hipSuccess && !gate.empty()) e = hipMalloc((void **)&db->d_gate, gate.size() * sizeof(u64));
-    if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, tree.size() * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMemcpy(db->d_table, table.data(), table.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !gate.empty()) e = hipMemcpy(db->d_gate, gate.data(), gate.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !mgate.empty()) e = hipMalloc((void **)&db->d_mgate, mgate.size() * sizeof(uint32_t));
-    if (e == hipSuccess && !mgate.empty()) e = hipMemcpy(db->d_mgate, mgate.data(), mgate.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !rec.empty()) e = hipMalloc((void **)&db->d_rec, rec.size() * sizeof(u64));
-    if (e == hipSuccess && !rec.empty()) e = hipMemcpy(db->d_rec, rec.data(), rec.size() * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree, tree.data(), tree.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        hipFree(db->d_table);
-        hipFree(db->d_gate);
-        hipFree(db->d_mgate);
-        hipFree(db->d_rec);
-        hipFree(db->d_tree);
-        delete db;
-        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("store upload: ") + hipGetErrorString(e));
-    }
-    db->info = h.info;
-    db->dev.table = db->d_table;
-    db->dev.gate = db->d_gate;
-    db->dev.gate_mask = gate.empty() ? 0 : (u64)gate.size() - 1;
-    db->dev.mgate = db->d_mgate;
-    db->dev.mgate_bits = 0;
-    while (((size_t)1 << db->dev.mgate_bits) < mgate.size()) db->dev.mgate_bits++;
-    db->n_rec = (int64_t)h.rec_buckets;
-    db->dev.rec = db->d_rec;
-    db->dev.rec_bits = 0;
-    while (((uint64_t)1 << db->dev.rec_bits) < h.rec_buckets) db->dev.rec_bits++;
-    db->dev.bucket_bits = h.bucket_bits;
-    db->dev.vbits = h.vbits;
-    db->dev.bucket_mask = ((u64)1 << h.bucket_bits) - 1;
-    db->dev.k = h.info.k;
-    db->dev.n_values = h.info.n_values;
-    db->dev.parent = db->d_tree;
-    db->dev.depth = db->d_tree + nv;
-    db->dev.tin = db->d_tree + 2 * nv;
-    db->dev.tout = db->d_tree + 3 * nv;
-    *out = db;
-    return GS_OK;
-} catch (const std::bad_alloc &) {
-    return fail(GS_E_NOMEM, "out of host memory");
-} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
-    return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+    StoreImage im{};
+    im.k = h.info.k;
+    im.n_values = h.info.n_values;
+    im.n_entries = h.info.n_entries;
+    im.n_stored = h.info.n_stored;
+    im.n_in_records = h.info.n_in_records;
+    im.b = (int)h.bucket_bits;
+    im.vbits = (int)h.vbits;
+    im.rec_bits = 0;
+    while (((uint64_t)1 << im.rec_bits) < h.rec_buckets) im.rec_bits++;
+    im.max_disp = h.info.max_displacement;
+    im.table = table.data();
+    im.table_words = table.size();
+    im.gate = gate.data();
+    im.gate_words = gate.size();
+    im.mgate = mgate.data();
+    im.mgate_words = mgate.size();
+    im.rec = rec.data();
+    im.rec_words = rec.size();
+    im.parent = tree.data();
+    im.depth = tree.data() + nv;
+    im.tin = tree.data() + 2 * nv;
+    im.tout = tree.data() + 3 * nv;
+    return store_place(im, device, stripes, stripe_devices, stripe_only, out);
 }
+
+#define GS_API_CATCH                                                                  \
+    catch (const std::bad_alloc &) { return fail(GS_E_NOMEM, "out of host memory"); } \
+    catch (const std::exception &e) { return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what()); }
+
+extern "C" int gs_db_load(gs_db **out, int device, const char *path) try {
+    return db_load_impl(out, device, path, 1, nullptr, -1);
+}
+GS_API_CATCH
+
+extern "C" int gs_db_load_striped(gs_db **out, const int *devices, int n_stripes, const char *path) try {
+    if (!out || !devices || n_stripes < 2 || n_stripes > GS_MAX_STRIPES) return fail(GS_E_INVALID, "a striped store spans 2..8 devices");
+    for (int p = 0; p < n_stripes; p++) {
+        out[p] = nullptr;
+        const int rc = use_device(devices[p]);
+        if (rc) return rc;
+    }
+    return db_load_impl(out, devices[0], path, n_stripes, devices, -1);
+}
+GS_API_CATCH
+
+extern "C" int gs_db_load_stripe(gs_db **out, int device, int n_stripes, int stripe, const char *path) try {
+    if (!out || n_stripes < 2 || n_stripes > GS_MAX_STRIPES || stripe < 0 || stripe >= n_stripes)
+        return fail(GS_E_INVALID, "a striped store spans 2..8 devices");
+    return db_load_impl(out, device, path, n_stripes, nullptr, stripe);
+}
+GS_API_CATCH
 
 extern "C" int gs_db_destroy(gs_db *db) {
     if (!db) return GS_OK;

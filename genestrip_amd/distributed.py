@@ -98,6 +98,29 @@ def match_files_sharded(matcher, paths, group=None, device=None, via_host=False)
     return table, dtable, tuple(int(x) for x in counts[len(paths):])
 
 
+def _attach_all(store, rank, world, group):
+    handles = [None] * world
+    dist.all_gather_object(handles, store.export_stripe(), group=group)
+    for q in range(world):
+        if q != rank:
+            store.attach_stripe(q, handles[q])
+    dist.barrier(group)  # nobody runs before every stripe is attached everywhere, nobody frees before that either
+    return store
+
+
+def striped_store_from_file(path, device=0, group=None):
+    """Collective.  As striped_store, from a store file (DeviceKMerStore.save of the store built once): every rank reads the
+    image, keeps its stripe and attaches the others; nobody rebuilds the layout."""
+    from .binding import DeviceKMerStore
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return DeviceKMerStore.load(path, device=device)
+    if world > 8:
+        raise ValueError("a striped store spans the GPUs of one node (at most 8 ranks)")
+    rank = dist.get_rank(group)
+    return _attach_all(DeviceKMerStore.load_stripe(path, device=device, n_stripes=world, stripe=rank), rank, world, group)
+
+
 def striped_store(k, kmers, value_idx, n_values, parent_vi=None, device=0, group=None):
     """Collective.  ONE store over the HBM of all ranks' GPUs (include/gsgpu.h, "striped store"): every rank builds the
     layout from the same arrays and keeps stripe `rank` of the super-k-mer record table (gs_db_create_stripe), exports it
@@ -112,13 +135,7 @@ def striped_store(k, kmers, value_idx, n_values, parent_vi=None, device=0, group
         raise ValueError("a striped store spans the GPUs of one node (at most 8 ranks)")
     rank = dist.get_rank(group)
     store = DeviceKMerStore.stripe(k, kmers, value_idx, n_values, parent_vi, device=device, n_stripes=world, stripe=rank)
-    handles = [None] * world
-    dist.all_gather_object(handles, store.export_stripe(), group=group)
-    for q in range(world):
-        if q != rank:
-            store.attach_stripe(q, handles[q])
-    dist.barrier(group)  # nobody runs before every stripe is attached everywhere, nobody frees before that either
-    return store
+    return _attach_all(store, rank, world, group)
 
 
 def shard_bounds(n_total, rank, world):

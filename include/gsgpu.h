@@ -267,6 +267,10 @@ int gs_db_create_stripe(gs_db **out, int device, int n_stripes, int stripe, int 
                         const int32_t *value_idx, int32_t n_values, const int32_t *parent_vi);
 int gs_db_stripe_export(gs_db *db, void *handle);
 int gs_db_stripe_attach(gs_db *db, int stripe, const void *handle);
+/* The same from a store file (gs_db_save of the store built ONCE by gs_db_create): nobody rebuilds the layout, every process
+ * reads the image, checks it as gs_db_load does and keeps its stripe.  The usual way to bring a big store up. */
+int gs_db_load_striped(gs_db **out, const int *devices, int n_stripes, const char *path);
+int gs_db_load_stripe(gs_db **out, int device, int n_stripes, int stripe, const char *path);
 
 /* ---------------------------------------------------------------------------------------------------
  * DB-partitioned match, the split pipeline of round 1 (kept: it also serves stores without records): the store is split

@@ -125,6 +125,40 @@ def test_striped_store_long_reads_segments_and_max_counts(sdb):
         s.close()
 
 
+def test_a_store_file_loads_as_stripes(sdb, reads, tmp_path):
+    """build once, save, load striped: the stripes of a store file serve the same tables as the store that was saved; a
+    damaged file is refused before anything reaches HBM, as by gs_db_load"""
+    seq, off = reads
+    want = _oracle(sdb, seq, off)[0][0]
+    plain = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    path = tmp_path / "store.gss"
+    plain.save(path)
+    pinfo = plain.info
+    plain.close()
+    stores = ga.DeviceKMerStore.load_striped(path, devices=(0, 0, 0, 0, 0))
+    assert [s.info.stripe for s in stores] == [0, 1, 2, 3, 4] and stores[0].n_values == sdb.n_values and stores[0].k == 31
+    assert stores[2].info.n_in_records == pinfo.n_in_records and stores[2].info.n_stored == pinfo.n_stored
+    m = ga.FastqKMerMatcher(stores[3])
+    m.submit(seq, off, 0)
+    t = m.finish()[0]
+    assert np.array_equal(t, want), np.argwhere(t != want)[:6]
+    m.close()
+    for s in stores:
+        s.close()
+    one = ga.DeviceKMerStore.load_stripe(path, device=0, n_stripes=3, stripe=2)
+    assert one.info.n_stripes == 3 and one.info.stripe == 2
+    with pytest.raises(ga.GsError):
+        ga.FastqKMerMatcher(one)  # the other stripes are not attached
+    one.close()
+    raw = bytearray(path.read_bytes())
+    raw[len(raw) // 2] ^= 0x40
+    bad = tmp_path / "bad.gss"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ga.GsError) as e:
+        ga.DeviceKMerStore.load_striped(bad, devices=(0, 0))
+    assert e.value.code == -1 and "checksum" in str(e.value)
+
+
 def test_striped_store_argument_errors(sdb):
     with pytest.raises(ga.GsError) as e:
         ga.DeviceKMerStore.striped(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, devices=(0,))
