@@ -2,9 +2,11 @@
 // stream/event plumbing.  No CPU fallback exists: every entry point needs a HIP device and fails with
 // GS_E_NODEVICE / GS_E_HIP otherwise.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -431,6 +433,68 @@ static int store_place(const StoreImage &im, int device, int stripes, const int 
     return GS_OK;
 }
 
+// a zero-filled array whose pages are first touched by whoever writes them (calloc of a large block hands out untouched
+// zero pages): std::vector would fill gigabytes from one thread before the parallel writers start
+template <typename T>
+struct Zeroed {
+    T *p = nullptr;
+    size_t n = 0;
+    Zeroed() = default;
+    Zeroed(const Zeroed &) = delete;
+    Zeroed &operator=(const Zeroed &) = delete;
+    size_t mapped = 0;
+    ~Zeroed() { release(); }
+    void release() {
+        if (p) munmap(p, mapped);
+        p = nullptr;
+        n = mapped = 0;
+    }
+    void reset(size_t count) {
+        release();
+        if (count == 0) return;
+        // anonymous mapping = untouched zero pages; transparent huge pages where the kernel grants them: the builder's
+        // random accesses into gigabyte arrays (cuckoo slots, record lines, gate) otherwise miss the TLB every time
+        const size_t bytes = (count * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        madvise(m, bytes, MADV_HUGEPAGE);
+        p = (T *)m;
+        n = count;
+        mapped = bytes;
+    }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// [0, n) in n_thr contiguous slices, one thread each (fn(t, lo, hi)); slices do not depend on timing
+template <typename F>
+static void parallel_slices(int n_thr, int64_t n, F fn) {
+    if (n_thr <= 1 || n < 4096) {
+        fn(0, (int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_thr; t++) th.emplace_back([=] { fn(t, n * t / n_thr, n * (t + 1) / n_thr); });
+    for (auto &x : th) x.join();
+}
+
+// GS_BUILD_TRACE=1: phase times of the host builder on stderr (developer aid)
+struct BuildTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    BuildTrace() : on(getenv("GS_BUILD_TRACE") != nullptr && atoi(getenv("GS_BUILD_TRACE")) != 0), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gs_db_create] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // fused: the store serves the fused kernels (gs_match_submit*, gs_match_segments) and may keep k-mers in super-k-mer
 // records; a partition store (gs_db_create_part, any n_parts) keeps every key in the table, where gs_match_probe_keys looks
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
@@ -441,8 +505,11 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
     if (n < 0 || n_values < 1 || n_values > (1 << 24) || (n > 0 && (!kmers || !vidx)))
         return fail(GS_E_INVALID, "bad store arrays (n_values must be in [1, 2^24])");
-    int rc = use_device(device);
+    // GS_BUILD_DRYRUN=1 (developer aid, with GS_BUILD_TRACE): the host layout is built and timed, nothing is uploaded
+    const bool dryrun = getenv("GS_BUILD_DRYRUN") != nullptr && atoi(getenv("GS_BUILD_DRYRUN")) != 0;
+    int rc = dryrun ? GS_OK : use_device(device);
     if (rc) return rc;
+    BuildTrace trace;
     bool ascending = true;
     for (int64_t i = 0; i < n; i++) {
         if (vidx[i] < 0 || vidx[i] >= n_values) return fail(GS_E_INVALID, "value_idx out of range");
@@ -498,6 +565,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         for (int32_t v = 0; v < n_values; v++) nodes += parent[v] != -2;
         if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
     }
+    trace.mark("checks + tree");
     // ---- keys
     // Every reachable stored k-mer is looked at from both strands (gs_layout.h: gs_choose_minimizer).  If both views pick
     // the same minimizer occurrence the k-mer can live in a super-k-mer record; otherwise (and for every k-mer when the
@@ -552,8 +620,23 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                     const uint32_t rhi = gs_brev32(fhi) >> (32 - k), rlo = (gs_brev32(flo) >> (32 - k)) ^ kmask;
                     uint32_t gh1, gh2, ohi1, olo1, ohi2, olo2;
                     int j1, j2;
-                    gs_min_oriented(fhi, flo, rhi, rlo, k, gs_choose_minimizer(fhi, flo, k), gh1, ohi1, olo1, j1);
-                    gs_min_oriented(rhi, rlo, fhi, flo, k, gs_choose_minimizer(rhi, rlo, k), gh2, ohi2, olo2, j2);
+                    // the reverse strand sees the same canonical 15-mers at mirrored offsets: one pass over the order hashes
+                    // serves both views (the leftmost of equal ranks in one view is the rightmost in the other)
+                    int p1 = 0, p2 = 0;
+                    {
+                        uint32_t best1 = 0xffffffffu, best2 = 0xffffffffu;
+                        const int last = k - GS_MIN_L;
+                        for (int d = 0; d <= last; d++) {
+                            const uint32_t h = gs_lmer_hash((fhi >> d) & 0x7fffu, (flo >> d) & 0x7fffu);
+                            const uint32_t x1 = gs_lmer_rank(h, (uint32_t)d), x2 = gs_lmer_rank(h, (uint32_t)(last - d));
+                            best1 = x1 < best1 ? x1 : best1;
+                            best2 = x2 < best2 ? x2 : best2;
+                        }
+                        p1 = (int)(best1 & 0xffu);
+                        p2 = (int)(best2 & 0xffu);
+                    }
+                    gs_min_oriented(fhi, flo, rhi, rlo, k, p1, gh1, ohi1, olo1, j1);
+                    gs_min_oriented(rhi, rlo, fhi, flo, k, p2, gh2, ohi2, olo2, j2);
                     const bool same = gh1 == gh2 && j1 == j2 && ohi1 == ohi2 && olo1 == olo2;
                     o.m.push_back(gh1);
                     if (gh2 != gh1) o.m.push_back(gh2);
@@ -582,19 +665,40 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             for (int t = 0; t < n_thr; t++) th.emplace_back(work, t);
             for (auto &x : th) x.join();
         }
-        size_t nr = 0;
-        for (Slice &o : sl) nr += o.r.size();
-        rents.reserve(nr);
-        for (Slice &o : sl) {
-            hkey.insert(hkey.end(), o.h.begin(), o.h.end());
-            hval.insert(hval.end(), o.v.begin(), o.v.end());
-            hmin.insert(hmin.end(), o.m.begin(), o.m.end());
-            hmore.insert(hmore.end(), o.more.begin(), o.more.end());
-            rents.insert(rents.end(), o.r.begin(), o.r.end());
+        // the slices one behind the other (every thread copies its own)
+        std::vector<size_t> oh((size_t)n_thr + 1, 0), om((size_t)n_thr + 1, 0), omo((size_t)n_thr + 1, 0), orr((size_t)n_thr + 1, 0);
+        for (int t = 0; t < n_thr; t++) {
+            oh[(size_t)t + 1] = oh[(size_t)t] + sl[(size_t)t].h.size();
+            om[(size_t)t + 1] = om[(size_t)t] + sl[(size_t)t].m.size();
+            omo[(size_t)t + 1] = omo[(size_t)t] + sl[(size_t)t].more.size();
+            orr[(size_t)t + 1] = orr[(size_t)t] + sl[(size_t)t].r.size();
+        }
+        hkey.resize(oh[(size_t)n_thr]);
+        hval.resize(oh[(size_t)n_thr]);
+        hmin.resize(om[(size_t)n_thr]);
+        hmore.resize(omo[(size_t)n_thr]);
+        rents.resize(orr[(size_t)n_thr]);
+        auto gather = [&](int t) {
+            Slice &o = sl[(size_t)t];
+            std::copy(o.h.begin(), o.h.end(), hkey.begin() + (ptrdiff_t)oh[(size_t)t]);
+            std::copy(o.v.begin(), o.v.end(), hval.begin() + (ptrdiff_t)oh[(size_t)t]);
+            std::copy(o.m.begin(), o.m.end(), hmin.begin() + (ptrdiff_t)om[(size_t)t]);
+            std::copy(o.more.begin(), o.more.end(), hmore.begin() + (ptrdiff_t)omo[(size_t)t]);
+            std::copy(o.r.begin(), o.r.end(), rents.begin() + (ptrdiff_t)orr[(size_t)t]);
             Slice().h.swap(o.h);
+            std::vector<int32_t>().swap(o.v);
+            std::vector<uint32_t>().swap(o.m);
             std::vector<RecEntry>().swap(o.r);
+        };
+        if (n_thr == 1)
+            gather(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(gather, t);
+            for (auto &x : th) x.join();
         }
     }
+    trace.mark("per-key minimizers");
     // ---- number of DISTINCT minimizers, estimated by linear counting on a 2^26-bit sketch (a sort of the 32-bit hashes
     // costs seconds for tens of millions of keys; +-1 % is plenty for power-of-two sizes): sizes the gate and the records
     const int64_t nm = (int64_t)hmin.size();
@@ -611,9 +715,10 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         const double zero_frac = std::max(1e-9, 1.0 - (double)ones / (double)sketch_bits);
         distinct_min = std::min((double)nm, -(double)sketch_bits * std::log(zero_frac));
     }
+    trace.mark("distinct-minimizer sketch");
     // ---- super-k-mer records (gs_layout.h): the k-mers of one minimizer are clustered into windows, every window gets one
     // of its minimizer's two buckets (cuckoo placement); the k-mers of windows that find no place join the table keys
-    std::vector<u64> rec;
+    Zeroed<u64> rec;
     int rec_bits = 0;
     int64_t n_in_records = 0;
     if (want_rec && !rents.empty()) {
@@ -624,14 +729,30 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         // counting sort by the top bits of the minimizer hash, then every chunk is sorted and clustered on its own
         const int cbits = 8, cshift = 32 - cbits, n_chunks = 1 << cbits;
         std::vector<int64_t> cstart((size_t)n_chunks + 1, 0);
-        for (int64_t i = 0; i < ne; i++) cstart[(size_t)(rents[(size_t)i].gh >> cshift) + 1]++;
-        for (int c = 0; c < n_chunks; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
         std::vector<RecEntry> sorted((size_t)ne);
-        {
-            std::vector<int64_t> cur(cstart.begin(), cstart.end() - 1);
-            for (int64_t i = 0; i < ne; i++) sorted[(size_t)cur[(size_t)(rents[(size_t)i].gh >> cshift)]++] = rents[(size_t)i];
+        {   // stable: thread t's entries of a chunk go behind those of the threads before it
+            std::vector<std::vector<int64_t>> hist((size_t)n_thr, std::vector<int64_t>((size_t)n_chunks, 0));
+            parallel_slices(n_thr, ne, [&](int t, int64_t lo, int64_t hi) {
+                std::vector<int64_t> &h = hist[(size_t)t];
+                for (int64_t i = lo; i < hi; i++) h[(size_t)(rents[(size_t)i].gh >> cshift)]++;
+            });
+            int64_t run = 0;
+            for (int c = 0; c < n_chunks; c++) {
+                cstart[(size_t)c] = run;
+                for (int t = 0; t < n_thr; t++) {
+                    const int64_t x = hist[(size_t)t][(size_t)c];
+                    hist[(size_t)t][(size_t)c] = run;
+                    run += x;
+                }
+            }
+            cstart[(size_t)n_chunks] = run;
+            parallel_slices(n_thr, ne, [&](int t, int64_t lo, int64_t hi) {
+                std::vector<int64_t> &cur = hist[(size_t)t];
+                for (int64_t i = lo; i < hi; i++) sorted[(size_t)cur[(size_t)(rents[(size_t)i].gh >> cshift)]++] = rents[(size_t)i];
+            });
         }
         std::vector<RecEntry>().swap(rents);
+        trace.mark("counting sort into chunks");
         struct Win {
             u64 whi, wlo, known;
             uint32_t valid, gh;
@@ -688,6 +809,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             for (auto &x : th) x.join();
         }
         std::vector<RecEntry>().swap(sorted);
+        trace.mark("sort + cluster windows");
         size_t n_win = 0;
         for (auto &v : chunk_wins) n_win += v.size();
         // windows per bucket before the bucket count doubles: with the power-of-two rounding 0.2 .. 0.4 (two-choice cuckoo
@@ -700,54 +822,135 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         rec_bits = 4;
         while (rec_bits < 29 && (double)((size_t)1 << rec_bits) * rload < (double)n_win) rec_bits++;
         const size_t n_rec = (size_t)1 << rec_bits;
-        // cuckoo placement (sequential, in chunk order: the result does not depend on the thread count)
-        std::vector<const Win *> slot(n_rec, nullptr);
+        // cuckoo placement.  Windows are numbered in chunk order (within a minimizer: fullest first).  Two parallel rounds
+        // whose outcome does not depend on timing -- every window bids for its first bucket, then the losers for their
+        // second bucket among those still free, and the LOWEST number wins a bucket (atomic min) -- place ~95 % of the
+        // windows; the rest goes through the sequential eviction walk.
+        std::vector<const Win *> order;
+        order.reserve(n_win);
+        for (auto &v : chunk_wins)
+            for (const Win &W0 : v) order.push_back(&W0);
+        if (order.size() >= 0xffffffffull) return fail(GS_E_UNSUPPORTED, "store too large: more than 2^32 windows");
+        const uint32_t EMPTY = 0xffffffffu;
+        const int64_t nw = (int64_t)order.size();
+        std::vector<uint32_t> slot(n_rec, EMPTY), bid;
+        std::vector<uint8_t> placed((size_t)nw, 0);
+        parallel_slices(n_thr, nw, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                uint32_t *p = &slot[gs_rec_bucket(order[(size_t)i]->gh, (uint32_t)rec_bits, 0)];
+                uint32_t seen = __atomic_load_n(p, __ATOMIC_RELAXED);
+                while ((uint32_t)i < seen && !__atomic_compare_exchange_n(p, &seen, (uint32_t)i, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                }
+            }
+        });
+        parallel_slices(n_thr, nw, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) placed[(size_t)i] = slot[gs_rec_bucket(order[(size_t)i]->gh, (uint32_t)rec_bits, 0)] == (uint32_t)i;
+        });
+        bid.assign(n_rec, EMPTY);
+        parallel_slices(n_thr, nw, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                if (placed[(size_t)i]) continue;
+                const uint32_t b1 = gs_rec_bucket(order[(size_t)i]->gh, (uint32_t)rec_bits, 1);
+                if (slot[b1] != EMPTY) continue;  // (round 1 is over: slot is read-only here)
+                uint32_t *p = &bid[b1];
+                uint32_t seen = __atomic_load_n(p, __ATOMIC_RELAXED);
+                while ((uint32_t)i < seen && !__atomic_compare_exchange_n(p, &seen, (uint32_t)i, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                }
+            }
+        });
+        parallel_slices(n_thr, (int64_t)n_rec, [&](int, int64_t lo, int64_t hi) {
+            for (int64_t b = lo; b < hi; b++)
+                if (bid[(size_t)b] != EMPTY) {  // (only buckets that were free after round 1 got bids)
+                    slot[(size_t)b] = bid[(size_t)b];
+                    placed[bid[(size_t)b]] = 1;
+                }
+        });
+        std::vector<uint32_t>().swap(bid);
         std::vector<const Win *> homeless;
         uint64_t rng = 0x9E3779B97F4A7C15ULL;
-        for (auto &v : chunk_wins)
-            for (const Win &W0 : v) {
-                const Win *cur = &W0;
-                uint32_t at = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 0);
-                for (int kick = 0; cur != nullptr && kick < 500; kick++) {
-                    const uint32_t b0 = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 0), b1 = gs_rec_bucket(cur->gh, (uint32_t)rec_bits, 1);
-                    if (slot[b0] == nullptr) {
-                        slot[b0] = cur;
-                        cur = nullptr;
-                    } else if (slot[b1] == nullptr) {
-                        slot[b1] = cur;
-                        cur = nullptr;
-                    } else {  // both taken: evict one of them (not the bucket we just came from) and carry it on
-                        const bool sib0 = slot[b0]->gh == cur->gh, sib1 = slot[b1]->gh == cur->gh;
-                        if (sib0 && sib1) break;  // its own sibling windows hold both buckets: no place for a third
-                        rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
-                        uint32_t victim = (rng >> 40) & 1 ? b1 : b0;
-                        if (kick > 0 && victim == at && b0 != b1) victim = victim == b0 ? b1 : b0;
-                        if (slot[victim]->gh == cur->gh) victim = victim == b0 ? b1 : b0;  // (fuller siblings stay)
-                        std::swap(cur, slot[victim]);
-                        at = victim;
+        // A walk that has not ended after 16 evictions rarely ends at all: what blocks it is not the load but the
+        // minimizers with two windows -- their two buckets are taken for good, and a window whose both buckets are such
+        // (or a second pair that shares a bucket with the first) has no place whatever the walk does.  At 473 M k-mers
+        // 19 % of the minimizers have two windows and 5 % more (the space of 15-mers that can BE a minimizer is only
+        // ~4^15 / 2 / 9 = 60 M): 2.1 M windows are third siblings, 2.9 M walks are hopeless (the same count with 48 or 500
+        // steps; 500 steps of three cache misses each made this loop a third of the build).  Those windows go to the table.
+        int max_kicks = 16;
+        if (const char *e = getenv("GS_REC_KICKS")) max_kicks = std::max(1, std::min(5000, atoi(e)));
+        int64_t n_walks = 0, n_kicks = 0, n_sib_first = 0, n_sib_later = 0, n_exhausted = 0;
+        for (int64_t wi = 0; wi < nw; wi++) {
+            if (placed[(size_t)wi]) continue;
+            n_walks++;
+            uint32_t cur = (uint32_t)wi;
+            uint32_t at = gs_rec_bucket(order[cur]->gh, (uint32_t)rec_bits, 0);
+            for (int kick = 0; cur != EMPTY && kick < max_kicks; kick++) {
+                n_kicks++;
+                const uint32_t gh = order[cur]->gh;
+                const uint32_t b0 = gs_rec_bucket(gh, (uint32_t)rec_bits, 0), b1 = gs_rec_bucket(gh, (uint32_t)rec_bits, 1);
+                if (slot[b0] == EMPTY) {
+                    slot[b0] = cur;
+                    cur = EMPTY;
+                } else if (slot[b1] == EMPTY) {
+                    slot[b1] = cur;
+                    cur = EMPTY;
+                } else {  // both taken: evict one of them (not the bucket we just came from) and carry it on
+                    const bool sib0 = order[slot[b0]]->gh == gh, sib1 = order[slot[b1]]->gh == gh;
+                    if (sib0 && sib1) {  // its own sibling windows hold both buckets: no place for a third
+                        (kick == 0 ? n_sib_first : n_sib_later)++;
+                        break;
+                    }
+                    rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
+                    uint32_t victim = (rng >> 40) & 1 ? b1 : b0;
+                    if (kick > 0 && victim == at && b0 != b1) victim = victim == b0 ? b1 : b0;
+                    if (order[slot[victim]]->gh == gh) victim = victim == b0 ? b1 : b0;  // (fuller siblings stay)
+                    std::swap(cur, slot[victim]);
+                    at = victim;
+                    if (kick == max_kicks - 1) n_exhausted++;
+                }
+            }
+            if (cur != EMPTY) homeless.push_back(order[cur]);
+        }
+        std::vector<uint8_t>().swap(placed);
+        if (trace.on) {
+            int64_t hist[5] = {0, 0, 0, 0, 0}, wsum[5] = {0, 0, 0, 0, 0};
+            for (int64_t i = 0; i < nw;) {
+                int64_t j = i;
+                while (j < nw && order[(size_t)j]->gh == order[(size_t)i]->gh) j++;
+                const int64_t c = j - i, slot_no = c >= 17 ? 4 : c >= 3 ? 3 : c;
+                hist[slot_no]++;
+                wsum[slot_no] += c;
+                i = j;
+            }
+            fprintf(stderr, "[gs_db_create] minimizers with 1 / 2 / 3..16 / 17+ windows: %lld / %lld / %lld / %lld (windows: %lld / %lld / %lld / %lld)\n",
+                    (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4], (long long)wsum[1], (long long)wsum[2],
+                    (long long)wsum[3], (long long)wsum[4]);
+        }
+        if (trace.on)
+            fprintf(stderr, "[gs_db_create] %lld windows in %lld buckets (%.3f), %lld walks, %lld steps, %lld windows to the table (third sibling at once %lld, later %lld, walk given up %lld)\n",
+                    (long long)nw, (long long)n_rec, (double)nw / (double)n_rec, (long long)n_walks, (long long)n_kicks, (long long)homeless.size(),
+                    (long long)n_sib_first, (long long)n_sib_later, (long long)n_exhausted);
+        trace.mark("cuckoo placement");
+        rec.reset(n_rec * GS_REC_WORDS);
+        {
+            std::vector<int64_t> cnt((size_t)n_thr, 0);
+            parallel_slices(n_thr, (int64_t)n_rec, [&](int t, int64_t lo, int64_t hi) {
+                int64_t mine = 0;
+                for (int64_t b = lo; b < hi; b++) {
+                    if (b + 8 < hi && slot[(size_t)b + 8] != EMPTY) __builtin_prefetch(order[slot[(size_t)b + 8]]);
+                    if (slot[(size_t)b] == EMPTY) continue;
+                    const Win *W = order[slot[(size_t)b]];
+                    u64 *rp = rec.data() + (size_t)b * GS_REC_WORDS;
+                    rp[0] = W->whi;
+                    rp[1] = W->wlo | ((u64)W->valid << GS_REC_WIN_BITS);
+                    for (uint32_t m = W->valid; m; m &= m - 1) {
+                        const int j = __builtin_ctz(m);
+                        rp[2 + j / 3] |= (u64)W->val[j] << (GS_REC_VAL_BITS * (j % 3));
+                        mine++;
                     }
                 }
-                if (cur != nullptr) homeless.push_back(cur);
-            }
-        rec.assign(n_rec * GS_REC_WORDS, 0);
-        for (size_t b = 0; b < n_rec; b++) {
-            const Win *W = slot[b];
-            if (W == nullptr) continue;
-            u64 *rp = rec.data() + b * GS_REC_WORDS;
-            rp[0] = W->whi;
-            rp[1] = W->wlo | ((u64)W->valid << GS_REC_WIN_BITS);
-            for (uint32_t m = W->valid; m; m &= m - 1) {
-                const int j = __builtin_ctz(m);
-                rp[2 + j / 3] |= (u64)W->val[j] << (GS_REC_VAL_BITS * (j % 3));
-                n_in_records++;
-            }
+                cnt[(size_t)t] = mine;
+            });
+            for (int64_t x : cnt) n_in_records += x;
         }
-        auto set_more = [&](uint32_t gh) {
-            for (int ch = 0; ch < 2; ch++) {
-                u64 *rp = rec.data() + (size_t)gs_rec_bucket(gh, (uint32_t)rec_bits, ch) * GS_REC_WORDS;
-                for (int x = 2; x < GS_REC_WORDS; x++) rp[x] |= GS_REC_MORE;
-            }
-        };
         for (const Win *W : homeless) {  // their k-mers become table keys, reachable through both buckets' `more` bit
             for (uint32_t m = W->valid; m; m &= m - 1) {
                 const int j = __builtin_ctz(m);
@@ -756,9 +959,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 hkey.push_back(gs_mix_planes(phi, plo));
                 hval.push_back(W->val[j]);
             }
-            set_more(W->gh);
+            hmore.push_back(W->gh);
         }
-        for (uint32_t gh : hmore) set_more(gh);
+        // the `more` bit of both buckets of these minimizers (OR is order-free: threads + atomics give the same lines)
+        parallel_slices(n_thr, (int64_t)hmore.size(), [&](int, int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++)
+                for (int ch = 0; ch < 2; ch++) {
+                    u64 *rp = rec.data() + (size_t)gs_rec_bucket(hmore[(size_t)i], (uint32_t)rec_bits, ch) * GS_REC_WORDS;
+                    if (__atomic_load_n(&rp[2], __ATOMIC_RELAXED) & GS_REC_MORE) continue;  // (set by an earlier entry: every word of the line has it then, or will)
+                    for (int x = 2; x < GS_REC_WORDS; x++) __atomic_fetch_or(&rp[x], GS_REC_MORE, __ATOMIC_RELAXED);
+                }
+        });
+        trace.mark("record lines + more bits");
     }  // (no eligible k-mer at all: no records, every key is in the table and the kernels take the table path)
     const int64_t ns = (int64_t)hkey.size();
     const int vbits = std::max(1, bits_for((u64)n_values));
@@ -796,6 +1008,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         }
         if (ok) break;
     }
+    trace.mark("overflow table");
     // ---- L2-resident gate (see gs_layout.h): ~8-16 bits per key, only if it fits the per-XCD L2 budget
     std::vector<u64> gate;
     {
@@ -812,7 +1025,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         }
     }
     // ---- minimizer gate (gs_layout.h): 16-32 bits per DISTINCT minimizer, 2 bits set per entry, 32-bit words
-    std::vector<uint32_t> mgate;
+    Zeroed<uint32_t> mgate;
     int mgate_bits = 0;
     if (want_mgate && nm > 0) {
         const double distinct = distinct_min;
@@ -820,9 +1033,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (const char *e = getenv("GS_MGATE_BITS_PER_MIN")) bits_per_min = std::max(1.0, atof(e));
         mgate_bits = 6;
         while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < distinct * bits_per_min) mgate_bits++;
-        mgate.assign((size_t)1 << mgate_bits, 0);
-        for (int64_t i = 0; i < nm; i++) mgate[gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits)] |= gs_mgate_bits(hmin[(size_t)i]);
+        mgate.reset((size_t)1 << mgate_bits);
+        int g_thr = (int)std::min<int64_t>(std::max<unsigned>(1, std::thread::hardware_concurrency()), 32);
+        if (const char *e = getenv("GS_BUILD_THREADS")) g_thr = std::max(1, std::min(64, atoi(e)));
+        parallel_slices(nm < 200000 ? 1 : g_thr, nm, [&](int, int64_t lo, int64_t hi) {  // (OR is order-free)
+            for (int64_t i = lo; i < hi; i++) {
+                uint32_t *w = mgate.data() + gs_mgate_word(hmin[(size_t)i], (uint32_t)mgate_bits);
+                const uint32_t bits = gs_mgate_bits(hmin[(size_t)i]);
+                if ((__atomic_load_n(w, __ATOMIC_RELAXED) & bits) != bits) __atomic_fetch_or(w, bits, __ATOMIC_RELAXED);
+            }
+        });
     }
+    trace.mark("gates");
     StoreImage im{};
     im.k = k;
     im.n_values = n_values;
@@ -845,7 +1067,10 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     im.depth = depth.data();
     im.tin = tin.data();
     im.tout = tout.data();
-    return store_place(im, device, stripes, stripe_devices, stripe_only, out);
+    if (dryrun) return fail(GS_E_UNSUPPORTED, "GS_BUILD_DRYRUN: layout built, nothing uploaded");
+    rc = store_place(im, device, stripes, stripe_devices, stripe_only, out);
+    trace.mark("upload");
+    return rc;
 }
 
 extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
