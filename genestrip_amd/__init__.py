@@ -7,11 +7,11 @@ without a GPU (so the C ABI can be inspected), but every compute entry point fai
 """
 from .binding import (  # noqa: F401
     GsError, lib, lib_path, device_count, abi_version, DeviceKMerStore, MatchConfig, FastqKMerMatcher,
-    DeviceBloomFilter, FastqBloomFilter, N_COLS, N_DCOLS, N_SUMS, COLS, MEM_HOST, MEM_DEVICE,
+    DeviceBloomFilter, FastqBloomFilter, DeviceDbBuilder, N_COLS, N_DCOLS, N_SUMS, COLS, MEM_HOST, MEM_DEVICE,
     F_FOUND, F_RETURNED, F_COUNTED, BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED, ABI_SYMBOLS,
 )
 
 __all__ = [
     "GsError", "lib", "lib_path", "device_count", "abi_version", "DeviceKMerStore", "MatchConfig",
-    "FastqKMerMatcher", "DeviceBloomFilter", "FastqBloomFilter",
+    "FastqKMerMatcher", "DeviceBloomFilter", "FastqBloomFilter", "DeviceDbBuilder",
 ]

@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -118,6 +118,11 @@ def lib():
         "gs_db_stripe_attach": (ci, [vp, ci, vp]),
         "gs_db_load_striped": (ci, [vp, vp, ci, C.c_char_p]),
         "gs_db_load_stripe": (ci, [vp, ci, ci, ci, C.c_char_p]),
+        "gs_dbbuild_begin": (ci, [vp, ci, ci, i32, vp, ci, ci, ci]),
+        "gs_dbbuild_add": (ci, [vp, vp, vp, vp, i64, ci, ci]),
+        "gs_dbbuild_finish": (ci, [vp, vp]),
+        "gs_dbbuild_fetch": (ci, [vp, vp, vp]),
+        "gs_dbbuild_destroy": (ci, [vp]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
         "gs_unroute_region": (ci, [vp, vp, vp, i64, vp]),
@@ -309,6 +314,51 @@ class DeviceKMerStore:
     def close(self):
         if getattr(self, "h", None):
             lib().gs_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceDbBuilder:
+    """gs_dbbuild: distinct canonical k-mers of genome regions with the LCA of the nodes that hold them (FillDBGoal + DBGoal)"""
+
+    def __init__(self, k, n_values, parent_vi, device=0, lower_case_bases=True, max_dust=-1, step_size=1):
+        pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
+        if len(pv) != n_values:
+            raise ValueError("parent_vi must have n_values entries")
+        self.h = C.c_void_p()
+        self.k, self.n_values = k, n_values
+        _check(lib().gs_dbbuild_begin(C.byref(self.h), device, k, n_values, pv.ctypes.data_as(C.c_void_p), int(lower_case_bases),
+                                      max_dust, step_size))
+
+    def add(self, seq, offsets, node_vi, update=False):
+        """regions: seq (uint8) + offsets (uint64, n + 1, from 0), both numpy or both device tensors; node_vi: numpy int32[n]"""
+        ps, mem = _ptr(seq)
+        po, mem2 = _ptr(offsets)
+        assert mem == mem2, "seq and offsets must live in the same memory space"
+        nv = np.ascontiguousarray(node_vi, dtype=np.int32)
+        n = (offsets.shape[0] if hasattr(offsets, "shape") else len(offsets)) - 1
+        if len(nv) != n:
+            raise ValueError("node_vi must have one entry per region")
+        _ready(seq, offsets)
+        _check(lib().gs_dbbuild_add(self.h, ps, po, nv.ctypes.data_as(C.c_void_p), n, mem, int(update)))
+
+    def finish(self):
+        """-> (kmers int64 ascending, value_idx int32): what DeviceKMerStore takes"""
+        n = C.c_int64(0)
+        _check(lib().gs_dbbuild_finish(self.h, C.byref(n)))
+        kmers = np.zeros(n.value, dtype=np.int64)
+        vals = np.zeros(n.value, dtype=np.int32)
+        _check(lib().gs_dbbuild_fetch(self.h, kmers.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p)))
+        return kmers, vals
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gs_dbbuild_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -2350,6 +2350,257 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
     return fail(GS_E_NOMEM, "out of host memory");
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// DB construction on the device (gs_build.hip; include/gsgpu.h "gs_dbbuild")
+// ---------------------------------------------------------------------------------------------------
+extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
+                                            uint32_t first_region, int update, u64 *keys, uint32_t *vals, hipStream_t stream);
+extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, u64 **keys_out,
+                                    uint32_t **vals_out, hipStream_t stream);
+extern "C" hipError_t gs_launch_build_count(const u64 *keys, int64_t n, u64 *n_valid, hipStream_t stream);
+extern "C" hipError_t gs_build_reduce(const u64 *keys, const uint32_t *vals, int64_t n, const int32_t *node_of_region, const int32_t *parent,
+                                      const int32_t *depth, uint32_t *flag, int32_t *value, u64 *pos, int64_t *n_out, hipStream_t stream);
+extern "C" hipError_t gs_launch_build_scatter(const u64 *keys, const int32_t *value, const uint32_t *flag, const u64 *pos, int64_t n,
+                                              int64_t *out_keys, int32_t *out_vals, hipStream_t stream);
+
+struct gs_dbbuild {
+    int device = 0, k = 0, lower = 1, step = 1;
+    int32_t n_values = 0;
+    hipStream_t stream = nullptr;
+    int32_t *d_tree = nullptr;  // parent | depth
+    u64 *d_keys = nullptr;      // one pair per genome base handed in so far (placeholders where no k-mer starts)
+    uint32_t *d_vals = nullptr;
+    size_t cap = 0, n_pairs = 0;
+    std::vector<int32_t> node_of_region;
+    std::vector<int32_t> parent;
+    uint8_t *d_seq = nullptr;  // staging of host input
+    size_t seq_cap = 0;
+    u64 *d_off = nullptr;
+    size_t off_cap = 0;
+    int64_t *d_out_keys = nullptr;
+    int32_t *d_out_vals = nullptr;
+    int64_t n_out = 0, n_kmers_seen = 0;
+    bool finished = false;
+};
+
+static void dbbuild_free(gs_dbbuild *b) {
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    hipFree(b->d_tree);
+    hipFree(b->d_keys);
+    hipFree(b->d_vals);
+    hipFree(b->d_seq);
+    hipFree(b->d_off);
+    hipFree(b->d_out_keys);
+    hipFree(b->d_out_vals);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases,
+                                int max_dust, int step_size) try {
+    if (!out) return fail(GS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
+    if (n_values < 1 || n_values > (1 << 24) || !parent_vi) return fail(GS_E_INVALID, "bad tree arrays (n_values must be in [1, 2^24])");
+    if (step_size < 1) return fail(GS_E_INVALID, "stepSize must be >= 1 (C/GSConfigKey.java:236)");
+    if (max_dust >= 0)
+        return fail(GS_E_UNSUPPORTED, "maxDust >= 0 (the streaming low-complexity filter of CGATLongBuffer) is not done on the device: build on the host");
+    // depths by parent walks; exactly one root: TaxTree.getLowestCommonAncestor answers null for nodes of different trees
+    // and the update then keeps the old value (DBGoal.java:243), which depends on the order of the regions
+    std::vector<int32_t> depth((size_t)n_values, -1);
+    int roots = 0;
+    for (int32_t v = 0; v < n_values; v++) {
+        const int32_t p = parent_vi[v];
+        if (p < -2 || p >= n_values || p == v) return fail(GS_E_INVALID, "parent_vi out of range");
+        roots += p == -1;
+    }
+    if (roots != 1) return fail(GS_E_UNSUPPORTED, "gs_dbbuild needs a tree with exactly one root");
+    for (int32_t v = 0; v < n_values; v++) {
+        if (parent_vi[v] == -2 || depth[(size_t)v] >= 0) continue;
+        std::vector<int32_t> path;
+        int32_t x = v;
+        while (x >= 0 && depth[(size_t)x] < 0) {
+            if (parent_vi[x] == -2) return fail(GS_E_INVALID, "parent_vi points at a value without a node");
+            path.push_back(x);
+            if ((int32_t)path.size() > n_values) return fail(GS_E_INVALID, "parent_vi contains a cycle");
+            x = parent_vi[x];
+        }
+        int32_t d = x >= 0 ? depth[(size_t)x] + 1 : 0;
+        for (size_t i = path.size(); i-- > 0;) depth[(size_t)path[i]] = d++;
+    }
+    int rc = use_device(device);
+    if (rc) return rc;
+    gs_dbbuild *b = new gs_dbbuild();
+    b->device = device;
+    b->k = k;
+    b->lower = lower_case_bases != 0;
+    b->step = step_size;
+    b->n_values = n_values;
+    b->parent.assign(parent_vi, parent_vi + n_values);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_tree, sizeof(int32_t) * 2 * (size_t)n_values);
+    if (e == hipSuccess) e = hipMemcpy(b->d_tree, parent_vi, sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_tree + n_values, depth.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        dbbuild_free(b);
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_dbbuild_begin: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return GS_OK;
+}
+GS_API_CATCH
+
+extern "C" int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions, int mem,
+                              int update) try {
+    if (!b || n_regions < 0 || (n_regions > 0 && (!seq || !offsets || !node_vi))) return fail(GS_E_INVALID, "bad argument");
+    if (b->finished) return fail(GS_E_STATE, "gs_dbbuild_finish has been called");
+    if (n_regions == 0) return GS_OK;
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->node_of_region.size() + (size_t)n_regions >= ((size_t)1 << 31)) return fail(GS_E_UNSUPPORTED, "more than 2^31 regions");
+    // node_vi is a host array in both cases (one entry per region)
+    for (int64_t r = 0; r < n_regions; r++)
+        if (node_vi[r] < 0 || node_vi[r] >= b->n_values || b->parent[(size_t)node_vi[r]] == -2) return fail(GS_E_INVALID, "node_vi: not a node of the tree");
+    std::vector<uint64_t> hoff;
+    const uint64_t *off_host = offsets;
+    if (mem == GS_MEM_DEVICE) {
+        hoff.resize((size_t)n_regions + 1);
+        HIP_TRY(hipMemcpy(hoff.data(), offsets, sizeof(uint64_t) * ((size_t)n_regions + 1), hipMemcpyDeviceToHost));
+        off_host = hoff.data();
+    }
+    if (off_host[0] != 0) return fail(GS_E_INVALID, "offsets[0] must be 0");
+    for (int64_t r = 0; r < n_regions; r++)
+        if (off_host[r + 1] < off_host[r]) return fail(GS_E_INVALID, "offsets must not decrease");
+    const int64_t total = (int64_t)off_host[n_regions];
+    const uint8_t *d_seq = seq;
+    const u64 *d_off = (const u64 *)offsets;
+    if (mem == GS_MEM_HOST) {
+        int rc = grow(&b->d_seq, &b->seq_cap, (size_t)std::max<int64_t>(total, 1), b->stream);
+        if (!rc) rc = grow(&b->d_off, &b->off_cap, (size_t)n_regions + 1, b->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(b->d_seq, seq, (size_t)total, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->d_off, offsets, sizeof(u64) * ((size_t)n_regions + 1), hipMemcpyHostToDevice, b->stream));
+        d_seq = b->d_seq;
+        d_off = b->d_off;
+    }
+    if (b->n_pairs + (size_t)total > b->cap) {  // the pair buffers grow by doubling
+        size_t want = std::max(b->cap * 2, b->n_pairs + (size_t)total);
+        want = std::max<size_t>(want, 1 << 20);
+        u64 *nk = nullptr;
+        uint32_t *nv = nullptr;
+        hipError_t e = hipMalloc((void **)&nk, want * sizeof(u64));
+        if (e == hipSuccess) e = hipMalloc((void **)&nv, want * sizeof(uint32_t));
+        if (e == hipSuccess && b->n_pairs) e = hipMemcpyAsync(nk, b->d_keys, b->n_pairs * sizeof(u64), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess && b->n_pairs) e = hipMemcpyAsync(nv, b->d_vals, b->n_pairs * sizeof(uint32_t), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) {
+            hipFree(nk);
+            hipFree(nv);
+            return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_dbbuild_add: ") + hipGetErrorString(e));
+        }
+        hipFree(b->d_keys);
+        hipFree(b->d_vals);
+        b->d_keys = nk;
+        b->d_vals = nv;
+        b->cap = want;
+    }
+    HIP_TRY(gs_launch_build_kmers(d_seq, d_off, n_regions, total, b->k, b->lower, b->step, (uint32_t)b->node_of_region.size(), update != 0,
+                                  b->d_keys + b->n_pairs, b->d_vals + b->n_pairs, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));  // (the caller's arrays and the staging buffers are free again)
+    b->n_pairs += (size_t)total;
+    b->node_of_region.insert(b->node_of_region.end(), node_vi, node_vi + n_regions);
+    return GS_OK;
+}
+GS_API_CATCH
+
+extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
+    if (!b || !n_kmers) return fail(GS_E_INVALID, "NULL argument");
+    if (b->finished) {
+        *n_kmers = b->n_out;
+        return GS_OK;
+    }
+    *n_kmers = 0;
+    HIP_TRY(hipSetDevice(b->device));
+    hipFree(b->d_seq);
+    hipFree(b->d_off);
+    b->d_seq = nullptr;
+    b->d_off = nullptr;
+    b->seq_cap = b->off_cap = 0;
+    const int64_t n = (int64_t)b->n_pairs;
+    int rc = GS_OK;
+    u64 *keys_alt = nullptr, *pos = nullptr, *d_nvalid = nullptr;
+    uint32_t *vals_alt = nullptr, *flag = nullptr;
+    int32_t *value = nullptr, *d_nor = nullptr;
+    auto cleanup = [&] {
+        hipFree(keys_alt);
+        hipFree(vals_alt);
+        hipFree(pos);
+        hipFree(flag);
+        hipFree(value);
+        hipFree(d_nor);
+        hipFree(d_nvalid);
+    };
+    auto check = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == GS_OK) rc = fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_dbbuild_finish (") + what + "): " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (n > 0) {
+        u64 *ks = nullptr;
+        uint32_t *vs = nullptr;
+        u64 n_valid = 0;
+        bool ok = check(hipMalloc((void **)&keys_alt, (size_t)n * sizeof(u64)), "sort buffers") &&
+                  check(hipMalloc((void **)&vals_alt, (size_t)n * sizeof(uint32_t)), "sort buffers") &&
+                  check(gs_build_sort(b->d_keys, keys_alt, b->d_vals, vals_alt, n, &ks, &vs, b->stream), "sort") &&
+                  check(hipMalloc((void **)&d_nvalid, sizeof(u64)), "count") && check(gs_launch_build_count(ks, n, d_nvalid, b->stream), "count") &&
+                  check(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(u64), hipMemcpyDeviceToHost, b->stream), "count") &&
+                  check(hipStreamSynchronize(b->stream), "count");
+        b->n_kmers_seen = (int64_t)n_valid;
+        if (ok && n_valid > 0) {
+            const size_t nr = std::max<size_t>(b->node_of_region.size(), 1);
+            ok = check(hipMalloc((void **)&d_nor, nr * sizeof(int32_t)), "regions") &&
+                 check(hipMemcpy(d_nor, b->node_of_region.data(), b->node_of_region.size() * sizeof(int32_t), hipMemcpyHostToDevice), "regions") &&
+                 check(hipMalloc((void **)&flag, (size_t)n_valid * sizeof(uint32_t)), "scratch") &&
+                 check(hipMalloc((void **)&value, (size_t)n_valid * sizeof(int32_t)), "scratch") &&
+                 check(hipMalloc((void **)&pos, (size_t)n_valid * sizeof(u64)), "scratch") &&
+                 check(gs_build_reduce(ks, vs, (int64_t)n_valid, d_nor, b->d_tree, b->d_tree + b->n_values, flag, value, pos, &b->n_out, b->stream), "reduce");
+            if (ok && b->n_out > 0)
+                ok = check(hipMalloc((void **)&b->d_out_keys, (size_t)b->n_out * sizeof(int64_t)), "result") &&
+                     check(hipMalloc((void **)&b->d_out_vals, (size_t)b->n_out * sizeof(int32_t)), "result") &&
+                     check(gs_launch_build_scatter(ks, value, flag, pos, (int64_t)n_valid, b->d_out_keys, b->d_out_vals, b->stream), "scatter") &&
+                     check(hipStreamSynchronize(b->stream), "scatter");
+        }
+    }
+    cleanup();
+    hipFree(b->d_keys);
+    hipFree(b->d_vals);
+    b->d_keys = nullptr;
+    b->d_vals = nullptr;
+    b->cap = b->n_pairs = 0;
+    if (rc != GS_OK) return rc;
+    b->finished = true;
+    *n_kmers = b->n_out;
+    return GS_OK;
+}
+GS_API_CATCH
+
+extern "C" int gs_dbbuild_fetch(gs_dbbuild *b, int64_t *kmers, int32_t *value_idx) {
+    if (!b || (b->n_out > 0 && (!kmers || !value_idx))) return fail(GS_E_INVALID, "NULL argument");
+    if (!b->finished) return fail(GS_E_STATE, "gs_dbbuild_finish first");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n_out > 0) {
+        HIP_TRY(hipMemcpy(kmers, b->d_out_keys, (size_t)b->n_out * sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(value_idx, b->d_out_vals, (size_t)b->n_out * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_dbbuild_destroy(gs_dbbuild *b) {
+    if (b) dbbuild_free(b);
+    return GS_OK;
+}
+
 // ---- DB-partitioned mode: encode / probe / reduce as separate steps (all pointers are device pointers)
 extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
                                const uint64_t *pos_off, uint64_t *keys) {

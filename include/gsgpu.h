@@ -273,6 +273,41 @@ int gs_db_load_striped(gs_db **out, const int *devices, int n_stripes, const cha
 int gs_db_load_stripe(gs_db **out, int device, int n_stripes, int stripe, const char *path);
 
 /* ---------------------------------------------------------------------------------------------------
+ * DB construction: the compute core of FillDBGoal + DBGoal -- every k-mer of every genome region of
+ * the requested taxa is stored under its tax node (C/goals/refseq/FillDBGoal.java:297ff -> KMerSortedArray.putLong,
+ * C/store/KMerSortedArray.java:168-202: the first region that holds a k-mer sets its value), then every region of the whole
+ * reference collection updates the k-mers it shares with the store to the lowest common ancestor of the old value and its own
+ * node (C/goals/refseq/DBGoal.java:233-256, :299-311 -> KMerStore.update, TaxTree.getLowestCommonAncestor,
+ * C/tax/TaxTree.java:160-187).  K-mers are formed as AbstractStoreFastaReader.dataLine does (C/refseq/
+ * AbstractStoreFastaReader.java:87-115 over C/util/CGATLongBuffer.java:137-229): per region a window of the last k bases,
+ * reset by any byte that is not C, G, A, T (after upper-casing a, c, g, t if lower_case_bases: GSConfigKey lowerCaseBases,
+ * default on), taken when (bases of the region so far) % step_size == 0, stored as CGAT.standardKMer.
+ *
+ *   gs_dbbuild_begin   tree as for gs_db_create (parent_vi: -1 the ONE root, -2 no node); max_dust must be -1 (the streaming
+ *                      low-complexity filter is not done on the device: GS_E_UNSUPPORTED).
+ *   gs_dbbuild_add     regions = FASTA records without their header and line ends (seq, offsets[n_regions + 1], offsets[0] = 0;
+ *                      `mem` says where seq / offsets live), node_vi[n_regions] (host) = value index of each region's node
+ *                      (FillDBGoal / DBGoal reworkNode: the host's mapping).  update = 0: a FillDBGoal region (its k-mers are
+ *                      stored), update = 1: a DBGoal region (only LCA updates).  Regions count in the order they are added.
+ *   gs_dbbuild_finish  one stable radix sort of all (k-mer, region) pairs + one pass over the runs of equal k-mers.
+ *   gs_dbbuild_fetch   kmers ascending (the reference's encoding) + value_idx: the arrays gs_db_create takes.
+ *
+ * Differences to the reference, all of them run-to-run variations of the reference itself: putLong drops a new k-mer
+ * when the fill Bloom filter reports a false positive (:175-186) -- which k-mers depends on the insertion order of its
+ * reader threads -- and with several reader threads "first" is a race; here every k-mer of a fill region is stored and the
+ * first region in the order of the add calls wins.  maxKMersPerTaxid / maxGenomesPerTaxid / a full store (:187-190) are the
+ * host's business (they decide which regions are handed in).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gs_dbbuild gs_dbbuild;
+int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int max_dust,
+                     int step_size);
+int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions, int mem,
+                   int update);
+int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers);
+int gs_dbbuild_fetch(gs_dbbuild *b, int64_t *kmers, int32_t *value_idx);
+int gs_dbbuild_destroy(gs_dbbuild *b);
+
+/* ---------------------------------------------------------------------------------------------------
  * DB-partitioned match, the split pipeline of round 1 (kept: it also serves stores without records): the store is split
  * over the GPUs of a node by key hash (gs_db_create_part keeps the keys with (h >> 40) % n_parts == part, h = the library's mixed key), reads stay
  * on their home GPU.  Per batch: gs_match_encode (reads -> h of every k-mer position; ~0 marks a window with a

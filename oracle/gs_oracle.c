@@ -1109,3 +1109,213 @@ void orc_reads_free(orc_reads *r) {
     free(r->qual_off);
     free(r);
 }
+
+
+/* =====================================================================================================
+ * DB construction (test infrastructure like everything in this file): FillDBGoal + DBGoal, one region after the other
+ * ===================================================================================================== */
+struct orc_build {
+    int k, lower, step;
+    int32_t n_values;
+    int32_t *parent, *depth;
+    int64_t *kmers;   /* entries in insertion order, sorted by orc_build_optimize */
+    int32_t *vals;
+    int64_t n, cap;
+    int64_t *set;     /* open addressing over the stored k-mers (putLong's duplicate check, exact); -1 = empty */
+    int64_t set_cap;
+    int sorted;
+};
+
+static int32_t build_depth(const int32_t *parent, int32_t v) {
+    int32_t d = 0;
+    while (parent[v] >= 0) {
+        v = parent[v];
+        d++;
+    }
+    return d;
+}
+
+int32_t orc_taxtree_lca(int32_t n_values, const int32_t *parent_vi, int32_t a, int32_t b) {
+    (void)n_values;
+    if (a == b) return a;       /* :162-164 */
+    if (a < 0 || b < 0) return -1; /* :165-167 */
+    int32_t da = build_depth(parent_vi, a), db = build_depth(parent_vi, b);
+    while (da > db) {           /* :175-177 */
+        a = parent_vi[a];
+        da--;
+    }
+    while (db > da) {           /* :178-180 */
+        b = parent_vi[b];
+        db--;
+    }
+    while (a != b) {            /* :181-184 (parent of a root = null) */
+        a = a >= 0 ? parent_vi[a] : -1;
+        b = b >= 0 ? parent_vi[b] : -1;
+        if (a < 0 || b < 0) return a == b ? a : -1;
+    }
+    return a;
+}
+
+orc_build *orc_build_begin(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size) {
+    orc_build *b = (orc_build *)calloc(1, sizeof(orc_build));
+    b->k = k;
+    b->lower = lower_case_bases;
+    b->step = step_size;
+    b->n_values = n_values;
+    b->parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_values);
+    memcpy(b->parent, parent_vi, sizeof(int32_t) * (size_t)n_values);
+    b->cap = 1024;
+    b->kmers = (int64_t *)malloc(sizeof(int64_t) * (size_t)b->cap);
+    b->vals = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->cap);
+    b->set_cap = 4096;
+    b->set = (int64_t *)malloc(sizeof(int64_t) * (size_t)b->set_cap);
+    for (int64_t i = 0; i < b->set_cap; i++) b->set[i] = -1;
+    return b;
+}
+
+static uint64_t build_mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    return x;
+}
+
+/* 1: newly inserted, 0: was there */
+static int build_set_put(orc_build *b, int64_t kmer) {
+    if ((b->n + 1) * 2 > b->set_cap) {
+        const int64_t nc = b->set_cap * 2;
+        int64_t *ns = (int64_t *)malloc(sizeof(int64_t) * (size_t)nc);
+        for (int64_t i = 0; i < nc; i++) ns[i] = -1;
+        for (int64_t i = 0; i < b->set_cap; i++)
+            if (b->set[i] >= 0) {
+                uint64_t h = build_mix((uint64_t)b->set[i]) & (uint64_t)(nc - 1);
+                while (ns[h] >= 0) h = (h + 1) & (uint64_t)(nc - 1);
+                ns[h] = b->set[i];
+            }
+        free(b->set);
+        b->set = ns;
+        b->set_cap = nc;
+    }
+    uint64_t h = build_mix((uint64_t)kmer) & (uint64_t)(b->set_cap - 1);
+    while (b->set[h] >= 0) {
+        if (b->set[h] == kmer) return 0;
+        h = (h + 1) & (uint64_t)(b->set_cap - 1);
+    }
+    b->set[h] = kmer;
+    return 1;
+}
+
+/* one region through CGATLongBuffer.put + AbstractStoreFastaReader.dataLine; handle(b, kmer, node) per taken k-mer */
+static void build_region(orc_build *b, const uint8_t *seq, int64_t len, int32_t node, void (*handle)(orc_build *, int64_t, int32_t)) {
+    const int k = b->k;
+    int64_t kmer = 0, rev = 0;      /* reset(): :263-268 */
+    int bp_counter = 0, filled = 0;
+    int64_t bps_in_region = 0;      /* AbstractRefSeqFastaReader.java:149 */
+    const int64_t mask = k == 32 ? -1 : (((int64_t)1 << (2 * k)) - 1);
+    for (int64_t i = 0; i < len; i++) {
+        uint8_t c = seq[i];
+        if (b->lower) {             /* CGAT.cgatToUpperCase, C/util/CGAT.java:91-99 */
+            if (c == 'a') c = 'A';
+            else if (c == 'c') c = 'C';
+            else if (c == 'g') c = 'G';
+            else if (c == 't') c = 'T';
+        }
+        int bp = c == 'C' ? 0 : c == 'G' ? 1 : c == 'A' ? 2 : c == 'T' ? 3 : -1;  /* CGAT_JUMP_TABLE */
+        if (bp < 0) {               /* :141-144 */
+            kmer = rev = 0;
+            bp_counter = 0;
+            filled = 0;
+        } else {
+            kmer = ((kmer << 2) & mask) | (int64_t)bp;                                  /* :146 */
+            rev = (int64_t)((uint64_t)rev >> 2) | ((int64_t)(bp ^ 1) << (2 * (k - 1)));  /* :147 */
+            bp_counter++;                                                                /* :196-201 */
+            if (bp_counter == k) {
+                bp_counter = 0;
+                filled = 1;
+            }
+        }
+        bps_in_region++;                                   /* AbstractStoreFastaReader.java:102 */
+        if (bps_in_region % b->step == 0 && filled)        /* :103-104 (isDust() is false with maxDust = -1) */
+            handle(b, kmer > rev ? kmer : rev, node);      /* getStandardKMer: CGAT.standardKMer */
+    }
+}
+
+static void build_put(orc_build *b, int64_t kmer, int32_t node) { /* KMerSortedArray.putLong :168-202 */
+    if (!build_set_put(b, kmer)) return;
+    if (b->n == b->cap) {
+        b->cap *= 2;
+        b->kmers = (int64_t *)realloc(b->kmers, sizeof(int64_t) * (size_t)b->cap);
+        b->vals = (int32_t *)realloc(b->vals, sizeof(int32_t) * (size_t)b->cap);
+    }
+    b->kmers[b->n] = kmer;
+    b->vals[b->n] = node;
+    b->n++;
+}
+
+void orc_build_fill(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions) {
+    for (int64_t r = 0; r < n_regions; r++)
+        build_region(b, seq + offsets[r], (int64_t)(offsets[r + 1] - offsets[r]), node_vi[r], build_put);
+}
+
+static int64_t *g_sort_keys;
+static int build_cmp(const void *x, const void *y) {
+    const int64_t a = g_sort_keys[*(const int64_t *)x], c = g_sort_keys[*(const int64_t *)y];
+    return a < c ? -1 : a > c;
+}
+
+int64_t orc_build_optimize(orc_build *b) {
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)(b->n ? b->n : 1));
+    for (int64_t i = 0; i < b->n; i++) idx[i] = i;
+    g_sort_keys = b->kmers;
+    qsort(idx, (size_t)b->n, sizeof(int64_t), build_cmp);
+    int64_t *nk = (int64_t *)malloc(sizeof(int64_t) * (size_t)(b->n ? b->n : 1));
+    int32_t *nv = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b->n ? b->n : 1));
+    for (int64_t i = 0; i < b->n; i++) {
+        nk[i] = b->kmers[idx[i]];
+        nv[i] = b->vals[idx[i]];
+    }
+    free(idx);
+    free(b->kmers);
+    free(b->vals);
+    b->kmers = nk;
+    b->vals = nv;
+    b->cap = b->n ? b->n : 1;
+    b->sorted = 1;
+    return b->n;
+}
+
+static void build_update(orc_build *b, int64_t kmer, int32_t node) { /* KMerSortedArray.update + DBGoal's provider :233-256 */
+    int64_t lo = 0, hi = b->n - 1;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (b->kmers[mid] < kmer)
+            lo = mid + 1;
+        else if (b->kmers[mid] > kmer)
+            hi = mid - 1;
+        else {
+            const int32_t l = orc_taxtree_lca(b->n_values, b->parent, b->vals[mid], node);
+            if (l >= 0) b->vals[mid] = l;  /* lcaNode != null ? lcaNode.getTaxId() : oldValue */
+            return;
+        }
+    }
+}
+
+void orc_build_update(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions) {
+    for (int64_t r = 0; r < n_regions; r++)
+        build_region(b, seq + offsets[r], (int64_t)(offsets[r + 1] - offsets[r]), node_vi[r], build_update);
+}
+
+void orc_build_fetch(const orc_build *b, int64_t *kmers, int32_t *value_idx) {
+    memcpy(kmers, b->kmers, sizeof(int64_t) * (size_t)b->n);
+    memcpy(value_idx, b->vals, sizeof(int32_t) * (size_t)b->n);
+}
+
+void orc_build_destroy(orc_build *b) {
+    if (!b) return;
+    free(b->parent);
+    free(b->depth);
+    free(b->kmers);
+    free(b->vals);
+    free(b->set);
+    free(b);
+}

@@ -158,6 +158,22 @@ typedef struct {
 orc_reads *orc_parse_fastq(const uint8_t *data, size_t len, int fasta, int k);
 void orc_reads_free(orc_reads *r);
 
+/* ---- DB construction: FillDBGoal (C/goals/refseq/FillDBGoal.java:297ff) + store.optimize + DBGoal
+ *      (C/goals/refseq/DBGoal.java:188-311) over AbstractStoreFastaReader.dataLine (C/refseq/
+ *      AbstractStoreFastaReader.java:87-115) and CGATLongBuffer.put (C/util/CGATLongBuffer.java:137-229, maxDust = -1).
+ *      Regions are walked one after the other, as a single reader thread does; putLong's Bloom filter is taken as exact
+ *      (no false positives: C/store/KMerSortedArray.java:175-186 would drop a few new k-mers, which ones depends on the
+ *      insertion order of the reference's reader threads). ---- */
+typedef struct orc_build orc_build;
+orc_build *orc_build_begin(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size);
+void orc_build_fill(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions);
+int64_t orc_build_optimize(orc_build *b);  /* store.optimize(): sorted, returns the number of entries */
+void orc_build_update(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions);
+void orc_build_fetch(const orc_build *b, int64_t *kmers, int32_t *value_idx);
+void orc_build_destroy(orc_build *b);
+/* TaxTree.getLowestCommonAncestor (C/tax/TaxTree.java:160-187) over value indices; -1 = null */
+int32_t orc_taxtree_lca(int32_t n_values, const int32_t *parent_vi, int32_t a, int32_t b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,10 @@ def lib():
         "orc_match_segments": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int]),
         "orc_parse_fastq": (C.POINTER(_Reads), [vp, C.c_size_t, C.c_int, C.c_int]),
         "orc_reads_free": (None, [C.POINTER(_Reads)]),
+        "orc_build_begin": (vp, [C.c_int, i32, vp, C.c_int, C.c_int]), "orc_build_fill": (None, [vp, vp, vp, vp, i64]),
+        "orc_build_optimize": (i64, [vp]), "orc_build_update": (None, [vp, vp, vp, vp, i64]),
+        "orc_build_fetch": (None, [vp, vp, vp]), "orc_build_destroy": (None, [vp]),
+        "orc_taxtree_lca": (i32, [i32, vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -347,3 +351,52 @@ def parse_fastq(data, fasta=False, k=31):
                qual=arr(rr.qual, C.c_uint8, int(qo[-1])))
     lib().orc_reads_free(r)
     return out
+
+
+def taxtree_lca(parent_vi, a, b):
+    """TaxTree.getLowestCommonAncestor over value indices (-1 = null)"""
+    pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
+    return int(lib().orc_taxtree_lca(len(pv), _p(pv), int(a), int(b)))
+
+
+class DbBuild:
+    """FillDBGoal + store.optimize + DBGoal, one region after the other (the CPU restatement the device build is checked
+    against): fill(regions) ..., optimize(), update(regions) ..., fetch() -> (kmers ascending, value_idx)"""
+
+    def __init__(self, k, n_values, parent_vi, lower_case_bases=True, step_size=1):
+        pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
+        self.h = C.c_void_p(lib().orc_build_begin(k, n_values, _p(pv), int(lower_case_bases), step_size))
+        self.n = 0
+
+    def _regions(self, seq, offsets, node_vi):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        if len(seq) == 0:
+            seq = np.zeros(1, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nv = np.ascontiguousarray(node_vi, dtype=np.int32)
+        assert len(nv) == len(off) - 1
+        return seq, off, nv
+
+    def fill(self, seq, offsets, node_vi):
+        seq, off, nv = self._regions(seq, offsets, node_vi)
+        lib().orc_build_fill(self.h, _p(seq), _p(off), _p(nv), len(nv))
+
+    def optimize(self):
+        self.n = int(lib().orc_build_optimize(self.h))
+        return self.n
+
+    def update(self, seq, offsets, node_vi):
+        seq, off, nv = self._regions(seq, offsets, node_vi)
+        lib().orc_build_update(self.h, _p(seq), _p(off), _p(nv), len(nv))
+
+    def fetch(self):
+        k = np.zeros(self.n, dtype=np.int64)
+        v = np.zeros(self.n, dtype=np.int32)
+        if self.n:
+            lib().orc_build_fetch(self.h, _p(k), _p(v))
+        return k, v
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().orc_build_destroy(self.h)
+            self.h = None
