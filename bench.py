@@ -98,7 +98,7 @@ def main():
                     help="--mode striped with ONE rank: stripes of the record table, all in this GPU's HBM (prices the "
                          "stripe arithmetic of the kernel; with N ranks there is one stripe per rank)")
     ap.add_argument("--genera", type=int, default=0, help="size of the synthetic store: genera of 20 species (0: configs[1]'s store)")
-    ap.add_argument("--legs", default="main,large,filter,e2e,striped",
+    ap.add_argument("--legs", default="main,large,filter,e2e,striped,dbbuild",
                     help="comma list; large / filter / e2e / striped are the extra N = 1 objects (main always runs)")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
@@ -324,7 +324,7 @@ def main():
             store.close()
             del dseq, doff
             torch.cuda.empty_cache()
-            if "large" in legs or "filter" in legs:
+            if "large" in legs or "filter" in legs or "dbbuild" in legs:
                 out.update(legs_large(ga, synth, orc, torch, dev, legs, cores))
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -399,6 +399,48 @@ def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):
             "table_equals_device_resident_run": bool(np.array_equal(host_table, dev_table))}
 
 
+def leg_db_build(ga, orc, torch, db, gen):
+    """the compute core of FillDBGoal + DBGoal on the device (gs_dbbuild): the 47 M-k-mer store of the large-store
+    leg from its 500 genomes -- every genome as a fill region and again as an update region (DBGoal walks the whole
+    collection), one radix sort of the (k-mer, region) pairs, LCA fold -- with the genomes already in HBM; the arrays must equal
+    the store the host recipe built.  Beside it the CPU restatement (one thread = one reader thread of the reference) on the
+    first genomes."""
+    g = db.genomes
+    n_g, g_len = g.shape
+    doff = (torch.arange(n_g + 1, dtype=torch.int64, device=gen.device) * g_len)
+    flat = gen.reshape(-1)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        b = ga.DeviceDbBuilder(K, db.n_values, db.parent_vi)
+        b.add(flat, doff, db.species_vi, update=False)
+        b.add(flat, doff, db.species_vi, update=True)
+        keys, vals = b.finish()
+        dt = time.perf_counter() - t0
+        b.close()
+        best = dt if best is None else min(best, dt)
+    same = bool(np.array_equal(keys, db.kmers) and np.array_equal(vals, db.value_idx))
+    ns = min(12, n_g)
+    hseq = np.ascontiguousarray(g[:ns]).reshape(-1)
+    hoff = (np.arange(ns + 1) * g_len).astype(np.uint64)
+    t0 = time.perf_counter()
+    ob = orc.DbBuild(K, db.n_values, db.parent_vi)
+    ob.fill(hseq, hoff, db.species_vi[:ns])
+    ob.optimize()
+    ob.update(hseq, hoff, db.species_vi[:ns])
+    ob.fetch()
+    ob.close()
+    dt_cpu = time.perf_counter() - t0
+    bases = int(n_g) * int(g_len)
+    return {"workload": "FillDBGoal + DBGoal: %d genomes x %d bp, k=31 -> %d distinct k-mers with LCA values" % (n_g, g_len, len(keys)),
+            "genome_bases": bases, "pairs_sorted": 2 * bases, "seconds": round(best, 4),
+            "mbases_per_s": round(bases / best / 1e6, 1), "includes": "k-mer kernel, radix sort, LCA fold, compaction, D2H of the result arrays",
+            "arrays_equal_host_built_store": same,
+            "cpu_baseline": {"mbases_per_s": round(ns * g_len / dt_cpu / 1e6, 2), "cores": 1, "kind": "port",
+                             "sample": "the first %d genomes through orc_build_* (fill, sort, update)" % ns}}
+
+
 def legs_large(ga, synth, orc, torch, dev, legs, cores):
     """BASELINE.json configs[2] / configs[3] per GPU: a 47 M-k-mer / 526-value store (1 GiB table, four times the
     Infinity Cache) and the XOR index filter over its species k-mers (~47 M keys, 1.8 G bits, 27 hashes)."""
@@ -413,6 +455,8 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores):
     synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN)
     torch.cuda.synchronize()
     seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN)
+    if "dbbuild" in legs:
+        res["db_build"] = leg_db_build(ga, orc, torch, db, gen)
     if "large" in legs:
         t0 = time.perf_counter()
         store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)

@@ -29,39 +29,83 @@ __device__ __forceinline__ uint32_t gs_build_code(uint8_t c, int lower) {
     return c == 'C' ? 0u : c == 'G' ? 1u : c == 'A' ? 2u : c == 'T' ? 3u : 4u;
 }
 
-// one thread per base position p of the concatenated regions: the k-mer that STARTS at p, if it lies in one region and holds
-// only bases.  The reference's ring buffer is reset by a non-base and at a region start
-// (CGATLongBuffer.put :141-144, AbstractStoreFastaReader.startRegion), and emits the window of the last k bases whenever it
-// is filled and (bases of the region so far) % stepSize == 0 (:103-104): the k-mer over region bases [s, s + k) is taken iff
-// all k are bases and (s + k) % stepSize == 0.
+// bit i of v -> bit 2 i
+__device__ __forceinline__ u64 gs_build_spread(uint32_t v) {
+    u64 x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & 0x5555555555555555ULL;
+    return x;
+}
+
+// k bits of the 128-bit string {b (high), a (low)} from bit s (s in 0..63, k <= 31)
+__device__ __forceinline__ uint32_t gs_build_funnel(u64 a, u64 b, int s, uint32_t kmask) {
+    return (uint32_t)((a >> s) | ((b << 1) << (63 - s))) & kmask;
+}
+
+// One wave per tile of 64 consecutive base positions of the concatenated regions; lane = the k-mer that STARTS at position
+// p0 + lane.  The tile's 64 + k - 1 bytes become three ballot planes (code bit 1, code bit 0, "not a base"), a lane cuts
+// its k-mer out of the planes with a funnel shift and interleaves them into the reference's encoding (first base in the top
+// bits) -- ~40 integer instructions per k-mer instead of a 31-step loop over bytes.  The reference's ring buffer is reset by
+// a non-base and at a region start (CGATLongBuffer.put :141-144, AbstractStoreFastaReader.startRegion) and emits the window of
+// the last k bases whenever it is filled and (bases of the region so far) % stepSize == 0 (:103-104): the k-mer over region
+// bases [s, s + k) is taken iff all k are bases and (s + k) % stepSize == 0.  Positions without a k-mer get a placeholder
+// key that sorts behind every k-mer.
 __global__ __launch_bounds__(256) void gs_build_kmers_kernel(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k,
                                                              int lower, int step, uint32_t first_region, uint32_t update_flag,
                                                              u64 *keys, uint32_t *vals) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-        // region of p: the last r with off[r] <= base + p  (off is relative to seq, off[0] = 0)
-        int64_t lo = 0, hi = n_regions;  // invariant: off[lo] <= p < off[hi]
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t kmask = (uint32_t)((1ULL << k) - 1);
+    const int64_t n_tiles = (total + 63) >> 6;
+    for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const int64_t p0 = tile << 6, p = p0 + lane;
+        // bytes p0 .. p0 + 63 and p0 + 64 .. p0 + 64 + k - 2
+        const uint32_t c0 = p < total ? gs_build_code(seq[p], lower) : 4u;
+        const uint32_t c1 = (lane < k - 1 && p + 64 < total) ? gs_build_code(seq[p + 64], lower) : 4u;
+        const u64 hi0 = __ballot((c0 >> 1) & 1u), lo0 = __ballot(c0 & 1u), bad0 = __ballot(c0 >> 2);
+        const u64 hi1 = __ballot((c1 >> 1) & 1u), lo1 = __ballot(c1 & 1u), bad1 = __ballot(c1 >> 2);
+        // region of the tile's first position: the last r with off[r] <= p0 (the same search on every lane: scalar loads)
+        int64_t lo = 0, hi = n_regions;  // invariant: off[lo] <= p0 < off[hi]
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
-            if (off[mid] <= (u64)p)
+            if (off[mid] <= (u64)p0)
                 lo = mid;
             else
                 hi = mid;
         }
-        u64 key = GS_BUILD_NONE;
-        const int64_t s = p - (int64_t)off[lo];
-        if ((u64)p + (u64)k <= off[lo + 1] && (s + k) % step == 0) {
-            u64 fwd = 0, rev = 0;
-            bool ok = true;
-            for (int i = 0; i < k; i++) {
-                const uint32_t c = gs_build_code(seq[p + i], lower);
-                ok = ok && c < 4u;
-                fwd = (fwd << 2) | (u64)(c & 3u);
-                rev = (rev >> 2) | ((u64)((c & 3u) ^ 1u) << (2 * (k - 1)));  // complement: C<->G, A<->T (CGAT.java:71-74)
+        int64_t r = lo;
+        u64 r_begin = off[lo], r_end = off[lo + 1];
+        if (r_end < (u64)(p0 + 64 + k - 1) && r_end < (u64)total) {  // a region ends inside the tile: every lane finds its own
+            int64_t l2 = lo, h2 = n_regions;
+            while (h2 - l2 > 1) {
+                const int64_t mid = (l2 + h2) >> 1;
+                if (off[mid] <= (u64)p)
+                    l2 = mid;
+                else
+                    h2 = mid;
             }
-            if (ok) key = fwd > rev ? fwd : rev;  // CGAT.standardKMer (:145-147)
+            r = l2;
+            r_begin = off[l2];
+            r_end = off[l2 + 1];
+        }
+        if (p >= total) continue;
+        u64 key = GS_BUILD_NONE;
+        const uint32_t wbad = gs_build_funnel(bad0, bad1, lane, kmask);
+        const int64_t s_in = p - (int64_t)r_begin;
+        if (wbad == 0 && (u64)p + (u64)k <= r_end && (s_in + k) % step == 0) {
+            // planes: bit i = base p + i.  Reference encoding: base p in the top bit pair.
+            const uint32_t fhi = gs_build_funnel(hi0, hi1, lane, kmask), flo = gs_build_funnel(lo0, lo1, lane, kmask);
+            const uint32_t rhi = __brev(fhi) >> (32 - k), rlo = __brev(flo) >> (32 - k);
+            const u64 fwd = (gs_build_spread(rhi) << 1) | gs_build_spread(rlo);
+            const u64 rev = (gs_build_spread(fhi) << 1) | gs_build_spread((flo ^ kmask) & kmask);  // complement: C<->G, A<->T, reversed
+            key = fwd > rev ? fwd : rev;  // CGAT.standardKMer (:145-147)
         }
         keys[p] = key;
-        vals[p] = update_flag | (first_region + (uint32_t)lo);
+        vals[p] = update_flag | (first_region + (uint32_t)r);
     }
 }
 
@@ -125,11 +169,16 @@ static int gs_build_grid(int64_t n) {
     if (g > 65536) g = 65536;
     return g < 1 ? 1 : (int)g;
 }
+static int gs_build_tile_grid(int64_t total) {  // 4 waves per workgroup, one tile of 64 positions per wave and step
+    int64_t g = ((total + 63) / 64 + 3) / 4;
+    if (g > 16384) g = 16384;
+    return g < 1 ? 1 : (int)g;
+}
 
 extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
                                             uint32_t first_region, int update, u64 *keys, uint32_t *vals, hipStream_t stream) {
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gs_build_kmers_kernel, dim3(gs_build_grid(total)), dim3(256), 0, stream, seq, off, n_regions, total, k, lower, step,
+    hipLaunchKernelGGL(gs_build_kmers_kernel, dim3(gs_build_tile_grid(total)), dim3(256), 0, stream, seq, off, n_regions, total, k, lower, step,
                        first_region, update ? GS_BUILD_UPDATE : 0u, keys, vals);
     return hipGetLastError();
 }

@@ -52,6 +52,35 @@ JNIEXPORT void JNICALL JNAME(dbCreateStriped)(JNIEnv *env, jclass c, jlongArray 
     if (rc) throw_gs(env, rc);
 }
 
+JNIEXPORT jlong JNICALL JNAME(dbBuildBegin)(JNIEnv *env, jclass c, jint device, jint k, jint nValues, jobject parentVi,
+                                            jboolean lowerCaseBases, jint maxDust, jint stepSize) {
+    gs_dbbuild *b = NULL;
+    int rc = gs_dbbuild_begin(&b, device, k, nValues, (const int32_t *)addr(env, parentVi), lowerCaseBases ? 1 : 0, maxDust, stepSize);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)b;
+}
+
+JNIEXPORT void JNICALL JNAME(dbBuildAdd)(JNIEnv *env, jclass c, jlong builder, jobject bases, jobject offsets, jobject nodeVi,
+                                         jlong nRegions, jboolean update) {
+    int rc = gs_dbbuild_add((gs_dbbuild *)(intptr_t)builder, (const uint8_t *)addr(env, bases), (const uint64_t *)addr(env, offsets),
+                            (const int32_t *)addr(env, nodeVi), nRegions, GS_MEM_HOST, update ? 1 : 0);
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT jlong JNICALL JNAME(dbBuildFinish)(JNIEnv *env, jclass c, jlong builder) {
+    int64_t n = 0;
+    int rc = gs_dbbuild_finish((gs_dbbuild *)(intptr_t)builder, &n);
+    if (rc) throw_gs(env, rc);
+    return (jlong)n;
+}
+
+JNIEXPORT void JNICALL JNAME(dbBuildFetch)(JNIEnv *env, jclass c, jlong builder, jobject kmers, jobject valueIdx) {
+    int rc = gs_dbbuild_fetch((gs_dbbuild *)(intptr_t)builder, (int64_t *)addr(env, kmers), (int32_t *)addr(env, valueIdx));
+    if (rc) throw_gs(env, rc);
+}
+
+JNIEXPORT void JNICALL JNAME(dbBuildDestroy)(JNIEnv *env, jclass c, jlong builder) { gs_dbbuild_destroy((gs_dbbuild *)(intptr_t)builder); }
+
 JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db_destroy((gs_db *)(intptr_t)db); }
 
 JNIEXPORT void JNICALL JNAME(dbSave)(JNIEnv *env, jclass c, jlong db, jstring path) {

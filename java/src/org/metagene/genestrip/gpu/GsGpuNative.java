@@ -33,6 +33,23 @@ public final class GsGpuNative {
 	public static native void dbCreateStriped(long[] devicesThenHandles, int k, long nEntries, ByteBuffer kmers,
 			ByteBuffer valueIdx, int nValues, ByteBuffer parentVi);
 
+	/** gs_dbbuild_begin: DB construction on the device (FillDBGoal + DBGoal); parentVi as for dbCreate, exactly one root */
+	public static native long dbBuildBegin(int device, int k, int nValues, ByteBuffer parentVi, boolean lowerCaseBases,
+			int maxDust, int stepSize);
+
+	/** gs_dbbuild_add: nRegions regions (bases without headers and line ends, offsets = nRegions + 1 x int64 from 0,
+	 *  nodeVi = nRegions x int32, all direct buffers in native order); update = a DBGoal region */
+	public static native void dbBuildAdd(long builder, ByteBuffer bases, ByteBuffer offsets, ByteBuffer nodeVi, long nRegions,
+			boolean update);
+
+	/** gs_dbbuild_finish: sort + LCA fold; returns the number of stored k-mers */
+	public static native long dbBuildFinish(long builder);
+
+	/** gs_dbbuild_fetch: kmers (n x int64 ascending, the reference's encoding) and value indices (n x int32) */
+	public static native void dbBuildFetch(long builder, ByteBuffer kmers, ByteBuffer valueIdx);
+
+	public static native void dbBuildDestroy(long builder);
+
 	/** gs_db_save / gs_db_load: the native image of the device store */
 	public static native void dbSave(long db, String path);
 
