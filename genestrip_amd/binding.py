@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -120,6 +120,7 @@ def lib():
         "gs_db_load_stripe": (ci, [vp, ci, ci, ci, C.c_char_p]),
         "gs_dbbuild_begin": (ci, [vp, ci, ci, i32, vp, ci, ci, ci]),
         "gs_dbbuild_add": (ci, [vp, vp, vp, vp, i64, ci, ci]),
+        "gs_dbbuild_set_range": (ci, [vp, C.c_uint64, C.c_uint64]),
         "gs_dbbuild_finish": (ci, [vp, vp]),
         "gs_dbbuild_fetch": (ci, [vp, vp, vp]),
         "gs_dbbuild_destroy": (ci, [vp]),
@@ -323,6 +324,15 @@ class DeviceKMerStore:
             pass
 
 
+def kmer_ranges(k, n):
+    """n ranges [lo, hi) of the canonical k-mer with about equal shares of the k-mers (a canonical k-mer is the larger of
+    two strands: P(x <= t) ~ (t / 4^k)^2): for gs_dbbuild_set_range"""
+    import math
+    top = 1 << (2 * k)
+    cuts = [math.isqrt(top * top * i // n) for i in range(n)] + [top]
+    return [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i] < cuts[i + 1]]
+
+
 class DeviceDbBuilder:
     """gs_dbbuild: distinct canonical k-mers of genome regions with the LCA of the nodes that hold them (FillDBGoal + DBGoal)"""
 
@@ -334,6 +344,10 @@ class DeviceDbBuilder:
         self.k, self.n_values = k, n_values
         _check(lib().gs_dbbuild_begin(C.byref(self.h), device, k, n_values, pv.ctypes.data_as(C.c_void_p), int(lower_case_bases),
                                       max_dust, step_size))
+
+    def set_range(self, lo, hi):
+        """keep only the canonical k-mers in [lo, hi) (before the first add): one builder per range of kmer_ranges()"""
+        _check(lib().gs_dbbuild_set_range(self.h, lo, hi))
 
     def add(self, seq, offsets, node_vi, update=False):
         """regions: seq (uint8) + offsets (uint64, n + 1, from 0), both numpy or both device tensors; node_vi: numpy int32[n]"""

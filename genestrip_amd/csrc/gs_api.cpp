@@ -2355,10 +2355,10 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
 // DB construction on the device (gs_build.hip; include/gsgpu.h "gs_dbbuild")
 // ---------------------------------------------------------------------------------------------------
 extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
-                                            uint32_t first_region, int update, u64 *keys, uint32_t *vals, hipStream_t stream);
-extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, u64 **keys_out,
+                                            uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
+                                            u64 *n_out, hipStream_t stream);
+extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, int key_bits, u64 **keys_out,
                                     uint32_t **vals_out, hipStream_t stream);
-extern "C" hipError_t gs_launch_build_count(const u64 *keys, int64_t n, u64 *n_valid, hipStream_t stream);
 extern "C" hipError_t gs_build_reduce(const u64 *keys, const uint32_t *vals, int64_t n, const int32_t *node_of_region, const int32_t *parent,
                                       const int32_t *depth, uint32_t *flag, int32_t *value, u64 *pos, int64_t *n_out, hipStream_t stream);
 extern "C" hipError_t gs_launch_build_scatter(const u64 *keys, const int32_t *value, const uint32_t *flag, const u64 *pos, int64_t n,
@@ -2369,9 +2369,11 @@ struct gs_dbbuild {
     int32_t n_values = 0;
     hipStream_t stream = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth
-    u64 *d_keys = nullptr;      // one pair per genome base handed in so far (placeholders where no k-mer starts)
+    u64 *d_keys = nullptr;      // the (k-mer, region | update bit) pairs handed in so far
     uint32_t *d_vals = nullptr;
+    u64 *d_count = nullptr;     // their number, counted by the kernel
     size_t cap = 0, n_pairs = 0;
+    u64 range_lo = 0, range_hi = ~0ULL;  // gs_dbbuild_set_range
     std::vector<int32_t> node_of_region;
     std::vector<int32_t> parent;
     uint8_t *d_seq = nullptr;  // staging of host input
@@ -2390,6 +2392,7 @@ static void dbbuild_free(gs_dbbuild *b) {
     hipFree(b->d_tree);
     hipFree(b->d_keys);
     hipFree(b->d_vals);
+    hipFree(b->d_count);
     hipFree(b->d_seq);
     hipFree(b->d_off);
     hipFree(b->d_out_keys);
@@ -2440,6 +2443,8 @@ extern "C" int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_v
     b->n_values = n_values;
     b->parent.assign(parent_vi, parent_vi + n_values);
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_count, sizeof(u64));
+    if (e == hipSuccess) e = hipMemset(b->d_count, 0, sizeof(u64));
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_tree, sizeof(int32_t) * 2 * (size_t)n_values);
     if (e == hipSuccess) e = hipMemcpy(b->d_tree, parent_vi, sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_tree + n_values, depth.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice);
@@ -2507,13 +2512,23 @@ extern "C" int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t 
         b->cap = want;
     }
     HIP_TRY(gs_launch_build_kmers(d_seq, d_off, n_regions, total, b->k, b->lower, b->step, (uint32_t)b->node_of_region.size(), update != 0,
-                                  b->d_keys + b->n_pairs, b->d_vals + b->n_pairs, b->stream));
+                                  b->range_lo, b->range_hi, b->d_keys, b->d_vals, b->d_count, b->stream));
+    u64 have = 0;
+    HIP_TRY(hipMemcpyAsync(&have, b->d_count, sizeof(u64), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));  // (the caller's arrays and the staging buffers are free again)
-    b->n_pairs += (size_t)total;
+    b->n_pairs = (size_t)have;
     b->node_of_region.insert(b->node_of_region.end(), node_vi, node_vi + n_regions);
     return GS_OK;
 }
 GS_API_CATCH
+
+extern "C" int gs_dbbuild_set_range(gs_dbbuild *b, uint64_t lo, uint64_t hi) {
+    if (!b || lo >= hi) return fail(GS_E_INVALID, "bad range");
+    if (b->n_pairs > 0 || !b->node_of_region.empty()) return fail(GS_E_STATE, "gs_dbbuild_set_range comes before the first gs_dbbuild_add");
+    b->range_lo = lo;
+    b->range_hi = hi;
+    return GS_OK;
+}
 
 extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
     if (!b || !n_kmers) return fail(GS_E_INVALID, "NULL argument");
@@ -2530,7 +2545,7 @@ extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
     b->seq_cap = b->off_cap = 0;
     const int64_t n = (int64_t)b->n_pairs;
     int rc = GS_OK;
-    u64 *keys_alt = nullptr, *pos = nullptr, *d_nvalid = nullptr;
+    u64 *keys_alt = nullptr, *pos = nullptr;
     uint32_t *vals_alt = nullptr, *flag = nullptr;
     int32_t *value = nullptr, *d_nor = nullptr;
     auto cleanup = [&] {
@@ -2540,7 +2555,6 @@ extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
         hipFree(flag);
         hipFree(value);
         hipFree(d_nor);
-        hipFree(d_nvalid);
     };
     auto check = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && rc == GS_OK) rc = fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_dbbuild_finish (") + what + "): " + hipGetErrorString(e));
@@ -2549,13 +2563,10 @@ extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
     if (n > 0) {
         u64 *ks = nullptr;
         uint32_t *vs = nullptr;
-        u64 n_valid = 0;
+        const u64 n_valid = (u64)n;
         bool ok = check(hipMalloc((void **)&keys_alt, (size_t)n * sizeof(u64)), "sort buffers") &&
                   check(hipMalloc((void **)&vals_alt, (size_t)n * sizeof(uint32_t)), "sort buffers") &&
-                  check(gs_build_sort(b->d_keys, keys_alt, b->d_vals, vals_alt, n, &ks, &vs, b->stream), "sort") &&
-                  check(hipMalloc((void **)&d_nvalid, sizeof(u64)), "count") && check(gs_launch_build_count(ks, n, d_nvalid, b->stream), "count") &&
-                  check(hipMemcpyAsync(&n_valid, d_nvalid, sizeof(u64), hipMemcpyDeviceToHost, b->stream), "count") &&
-                  check(hipStreamSynchronize(b->stream), "count");
+                  check(gs_build_sort(b->d_keys, keys_alt, b->d_vals, vals_alt, n, 2 * b->k, &ks, &vs, b->stream), "sort");
         b->n_kmers_seen = (int64_t)n_valid;
         if (ok && n_valid > 0) {
             const size_t nr = std::max<size_t>(b->node_of_region.size(), 1);

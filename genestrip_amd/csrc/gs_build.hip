@@ -2,13 +2,13 @@
 // FillDBGoal + DBGoal (C/goals/refseq/FillDBGoal.java:297-end, C/goals/refseq/DBGoal.java:188-311 over
 // C/refseq/AbstractStoreFastaReader.java:87-115 and C/util/CGATLongBuffer.java:137-229):
 //   every k-mer of every genome region -> (canonical k-mer, region) pairs        gs_build_kmers_kernel
-//   all pairs sorted by k-mer                                                    rocPRIM radix sort (stable)
+//   all pairs sorted by k-mer                                                    rocPRIM radix sort over the 2k key bits
 //   per distinct k-mer: stored iff a FILL region holds it (KMerSortedArray.putLong, first writer), value = the node of
 //   the first such region, then the lowest common ancestor with the node of every UPDATE region that holds it
 //   (KMerStore.update + TaxTree.getLowestCommonAncestor, C/tax/TaxTree.java:160-187)       gs_build_reduce_kernel
 //   compaction of the stored k-mers in ascending order                                      scan + scatter
 // The reference walks the genomes twice with a hash-free sorted array and a Bloom filter in front of it; here one sort
-// replaces both walks.  Byte / integer work, HBM-bound (12 bytes per genome base through an 8-pass radix sort).
+// replaces both walks.  Byte / integer work, HBM-bound (12 bytes per genome base through a radix sort of 2k / 8 passes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,18 +51,21 @@ __device__ __forceinline__ uint32_t gs_build_funnel(u64 a, u64 b, int s, uint32_
 // bits) -- ~40 integer instructions per k-mer instead of a 31-step loop over bytes.  The reference's ring buffer is reset by
 // a non-base and at a region start (CGATLongBuffer.put :141-144, AbstractStoreFastaReader.startRegion) and emits the window of
 // the last k bases whenever it is filled and (bases of the region so far) % stepSize == 0 (:103-104): the k-mer over region
-// bases [s, s + k) is taken iff all k are bases and (s + k) % stepSize == 0.  Positions without a k-mer get a placeholder
-// key that sorts behind every k-mer.
-__global__ __launch_bounds__(256) void gs_build_kmers_kernel(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k,
+// bases [s, s + k) is taken iff all k are bases and (s + k) % stepSize == 0.  Only real pairs are written (compacted per wave).
+#define GS_BUILD_BLOCK 1024  // 16 waves: one atomic on the pair counter per workgroup and step
+__global__ __launch_bounds__(GS_BUILD_BLOCK) void gs_build_kmers_kernel(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k,
                                                              int lower, int step, uint32_t first_region, uint32_t update_flag,
-                                                             u64 *keys, uint32_t *vals) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+                                                             u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals, u64 *n_out) {
+    constexpr int WAVES = GS_BUILD_BLOCK / 64;
+    __shared__ uint32_t s_cnt[WAVES];
+    __shared__ u64 s_base;
+    const int lane = (int)(threadIdx.x & 63), wib = (int)(threadIdx.x >> 6);
     const uint32_t kmask = (uint32_t)((1ULL << k) - 1);
     const int64_t n_tiles = (total + 63) >> 6;
-    for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
-        const int64_t p0 = tile << 6, p = p0 + lane;
+    // (the loop is uniform over the workgroup: its waves take WAVES consecutive tiles per step and meet at the barriers)
+    for (int64_t tile0 = (int64_t)blockIdx.x * WAVES; tile0 < n_tiles; tile0 += (int64_t)gridDim.x * WAVES) {
+        const int64_t tile = tile0 + wib;
+        const int64_t p0 = tile << 6, p = p0 + lane;  // (tile >= n_tiles: p >= total, every lane idles)
         // bytes p0 .. p0 + 63 and p0 + 64 .. p0 + 64 + k - 2
         const uint32_t c0 = p < total ? gs_build_code(seq[p], lower) : 4u;
         const uint32_t c1 = (lane < k - 1 && p + 64 < total) ? gs_build_code(seq[p + 64], lower) : 4u;
@@ -70,16 +73,17 @@ __global__ __launch_bounds__(256) void gs_build_kmers_kernel(const uint8_t *seq,
         const u64 hi1 = __ballot((c1 >> 1) & 1u), lo1 = __ballot(c1 & 1u), bad1 = __ballot(c1 >> 2);
         // region of the tile's first position: the last r with off[r] <= p0 (the same search on every lane: scalar loads)
         int64_t lo = 0, hi = n_regions;  // invariant: off[lo] <= p0 < off[hi]
+        const u64 p0c = p0 < total ? (u64)p0 : (u64)(total - 1);
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
-            if (off[mid] <= (u64)p0)
+            if (off[mid] <= p0c)
                 lo = mid;
             else
                 hi = mid;
         }
         int64_t r = lo;
         u64 r_begin = off[lo], r_end = off[lo + 1];
-        if (r_end < (u64)(p0 + 64 + k - 1) && r_end < (u64)total) {  // a region ends inside the tile: every lane finds its own
+        if (p0 < total && r_end < (u64)(p0 + 64 + k - 1) && r_end < (u64)total) {  // a region ends inside the tile: every lane finds its own
             int64_t l2 = lo, h2 = n_regions;
             while (h2 - l2 > 1) {
                 const int64_t mid = (l2 + h2) >> 1;
@@ -92,27 +96,36 @@ __global__ __launch_bounds__(256) void gs_build_kmers_kernel(const uint8_t *seq,
             r_begin = off[l2];
             r_end = off[l2 + 1];
         }
-        if (p >= total) continue;
         u64 key = GS_BUILD_NONE;
         const uint32_t wbad = gs_build_funnel(bad0, bad1, lane, kmask);
         const int64_t s_in = p - (int64_t)r_begin;
-        if (wbad == 0 && (u64)p + (u64)k <= r_end && (s_in + k) % step == 0) {
+        if (p < total && wbad == 0 && (u64)p + (u64)k <= r_end && (s_in + k) % step == 0) {
             // planes: bit i = base p + i.  Reference encoding: base p in the top bit pair.
             const uint32_t fhi = gs_build_funnel(hi0, hi1, lane, kmask), flo = gs_build_funnel(lo0, lo1, lane, kmask);
             const uint32_t rhi = __brev(fhi) >> (32 - k), rlo = __brev(flo) >> (32 - k);
             const u64 fwd = (gs_build_spread(rhi) << 1) | gs_build_spread(rlo);
             const u64 rev = (gs_build_spread(fhi) << 1) | gs_build_spread((flo ^ kmask) & kmask);  // complement: C<->G, A<->T, reversed
             key = fwd > rev ? fwd : rev;  // CGAT.standardKMer (:145-147)
+            if (key < range_lo || key >= range_hi) key = GS_BUILD_NONE;  // (gs_dbbuild_set_range: another pass takes it)
         }
-        keys[p] = key;
-        vals[p] = update_flag | (first_region + (uint32_t)r);
+        // the workgroup's pairs go behind each other at the end of the pair arrays: one atomic per workgroup and step
+        const u64 have = __ballot(key != GS_BUILD_NONE);
+        if (lane == 0) s_cnt[wib] = (uint32_t)__popcll(have);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < WAVES; w++) sum += s_cnt[w];
+            s_base = sum ? atomicAdd(n_out, (u64)sum) : 0;
+        }
+        __syncthreads();
+        if (key != GS_BUILD_NONE) {
+            u64 at = s_base + (u64)__popcll(have & ((1ULL << lane) - 1));
+            for (int w = 0; w < wib; w++) at += s_cnt[w];
+            keys[at] = key;
+            vals[at] = update_flag | (first_region + (uint32_t)r);
+        }
+        __syncthreads();  // (s_cnt / s_base are rewritten by the next step)
     }
-}
-
-// number of real pairs in the sorted key array (the placeholders sort to the end)
-__global__ void gs_build_count_kernel(const u64 *keys, int64_t n, u64 *n_valid) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if (keys[i] != GS_BUILD_NONE && (i + 1 == n || keys[i + 1] == GS_BUILD_NONE)) *n_valid = (u64)(i + 1);
 }
 
 // TaxTree.getLowestCommonAncestor (C/tax/TaxTree.java:160-187) over value indices; one tree (the API refuses forests)
@@ -169,23 +182,25 @@ static int gs_build_grid(int64_t n) {
     if (g > 65536) g = 65536;
     return g < 1 ? 1 : (int)g;
 }
-static int gs_build_tile_grid(int64_t total) {  // 4 waves per workgroup, one tile of 64 positions per wave and step
-    int64_t g = ((total + 63) / 64 + 3) / 4;
-    if (g > 16384) g = 16384;
+static int gs_build_tile_grid(int64_t total) {  // 16 waves per workgroup, one tile of 64 positions per wave and step
+    int64_t g = ((total + 63) / 64 + 15) / 16;
+    if (g > 4096) g = 4096;
     return g < 1 ? 1 : (int)g;
 }
 
+// keys / vals: room for `total` more pairs behind *n_out (device counter of the pairs written so far)
 extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
-                                            uint32_t first_region, int update, u64 *keys, uint32_t *vals, hipStream_t stream) {
+                                            uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
+                                            u64 *n_out, hipStream_t stream) {
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gs_build_kmers_kernel, dim3(gs_build_tile_grid(total)), dim3(256), 0, stream, seq, off, n_regions, total, k, lower, step,
-                       first_region, update ? GS_BUILD_UPDATE : 0u, keys, vals);
+    hipLaunchKernelGGL(gs_build_kmers_kernel, dim3(gs_build_tile_grid(total)), dim3(GS_BUILD_BLOCK), 0, stream, seq, off, n_regions, total, k, lower, step,
+                       first_region, update ? GS_BUILD_UPDATE : 0u, range_lo, range_hi, keys, vals, n_out);
     return hipGetLastError();
 }
 
 // keys / vals: n pairs, sorted in place through the alternate buffers (keys_alt / vals_alt: n each).  Returns the sorted arrays
 // in *keys_out / *vals_out (one of the two buffers each).
-extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, u64 **keys_out,
+extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, int key_bits, u64 **keys_out,
                                     uint32_t **vals_out, hipStream_t stream) {
     *keys_out = keys;
     *vals_out = vals;
@@ -193,24 +208,17 @@ extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, ui
     rocprim::double_buffer<u64> dk(keys, keys_alt);
     rocprim::double_buffer<uint32_t> dv(vals, vals_alt);
     size_t tmp_bytes = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)n, 0, 64, stream);
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, (size_t)n, 0, (unsigned)key_bits, stream);
     if (e != hipSuccess) return e;
     void *tmp = nullptr;
     e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, (size_t)n, 0, 64, stream);
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, (size_t)n, 0, (unsigned)key_bits, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     hipFree(tmp);
     *keys_out = dk.current();
     *vals_out = dv.current();
     return e;
-}
-
-extern "C" hipError_t gs_launch_build_count(const u64 *keys, int64_t n, u64 *n_valid, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(n_valid, 0, sizeof(u64), stream);
-    if (e != hipSuccess || n <= 0) return e;
-    hipLaunchKernelGGL(gs_build_count_kernel, dim3(gs_build_grid(n)), dim3(256), 0, stream, keys, n, n_valid);
-    return hipGetLastError();
 }
 
 // flag / value / pos: n entries of scratch each.  *n_out = number of stored k-mers; out_keys / out_vals must hold them (call

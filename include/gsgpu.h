@@ -303,6 +303,11 @@ int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_values, cons
                      int step_size);
 int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions, int mem,
                    int update);
+/* A collection whose pairs do not fit the GPU (40 bytes per genome base at the peak) is built in passes over disjoint ranges of
+ * the canonical k-mer: before the first gs_dbbuild_add, keep only the k-mers in [lo, hi); hand the same regions to one builder
+ * per range; the results of ascending ranges, one behind the other, are the result of a single build.  (Canonical k-mers are
+ * the larger of two strands, so equal shares of the k-mers lie between 4^k * sqrt(i / n): genestrip_amd.binding.kmer_ranges.) */
+int gs_dbbuild_set_range(gs_dbbuild *b, uint64_t lo, uint64_t hi);
 int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers);
 int gs_dbbuild_fetch(gs_dbbuild *b, int64_t *kmers, int32_t *value_idx);
 int gs_dbbuild_destroy(gs_dbbuild *b);

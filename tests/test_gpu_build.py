@@ -97,6 +97,34 @@ def test_device_build_reproduces_the_synthetic_store_and_serves_a_match():
     m.close(), store.close(), odb.close()
 
 
+def test_build_in_kmer_ranges_equals_one_build():
+    """a collection too big for one pass: one builder per range of the canonical k-mer, results one behind the other"""
+    from genestrip_amd.binding import kmer_ranges
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=30000, seed=12)
+    g = db.genomes
+    seq = np.ascontiguousarray(g).reshape(-1)
+    off = (np.arange(g.shape[0] + 1) * g.shape[1]).astype(np.uint64)
+    ranges = kmer_ranges(31, 5)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 1 << 62 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    parts, sizes = [], []
+    for lo, hi in ranges:
+        b = ga.DeviceDbBuilder(31, db.n_values, db.parent_vi)
+        b.set_range(lo, hi)
+        b.add(seq, off, db.species_vi, update=False)
+        b.add(seq, off, db.species_vi, update=True)
+        k, v = b.finish()
+        assert len(k) == 0 or (k[0] >= lo and k[-1] < hi)
+        parts.append((k, v))
+        sizes.append(len(k))
+        with pytest.raises(ga.GsError):
+            b.set_range(0, 5)  # only before the first add
+        b.close()
+    keys = np.concatenate([p[0] for p in parts])
+    vals = np.concatenate([p[1] for p in parts])
+    assert np.array_equal(keys, db.kmers) and np.array_equal(vals, db.value_idx)
+    assert max(sizes) < 1.25 * min(sizes)  # the ranges are balanced
+
+
 def test_device_build_from_device_memory_and_the_dengue_fixture():
     import torch
     raw = open(os.path.join(GOLDEN, "dengue1", "dengue1.fasta"), "rb").read()
