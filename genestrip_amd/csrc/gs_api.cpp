@@ -495,6 +495,270 @@ struct BuildTrace {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------
+// the layout built on the device (gs_layout_build.hip): same rules as the host builder below
+// ---------------------------------------------------------------------------------------------------
+enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_COUNTERS };
+extern "C" hipError_t gs_lb_perkey(const int64_t *kmers, const int32_t *vidx, int64_t n, int k, const int32_t *parent, uint32_t *e_gh, uint32_t *e_ohi,
+                                   uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort, u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh,
+                                   u64 *cnt, hipStream_t stream);
+extern "C" hipError_t gs_lb_sort_entries(u64 *e_sort, u64 *e_sort2, u64 *sort_alt, uint32_t *perm, uint32_t *perm_alt, int64_t n, const uint32_t *e_gh,
+                                         const uint32_t *e_ohi, const uint32_t *e_olo, const uint32_t *e_vj, uint32_t *s_gh, uint32_t *s_ohi,
+                                         uint32_t *s_olo, uint32_t *s_vj, hipStream_t stream);
+extern "C" hipError_t gs_lb_groups(const uint32_t *s_gh, int64_t n, uint32_t *head, uint32_t *group, uint32_t *g_start, int64_t *n_groups,
+                                   hipStream_t stream);
+extern "C" hipError_t gs_lb_cluster(const uint32_t *s_gh, const uint32_t *s_ohi, const uint32_t *s_olo, const uint32_t *s_vj, const uint32_t *g_start,
+                                    int64_t n_groups, int k, uint8_t *assign, u64 *w_hi, u64 *w_lo, uint32_t *w_valid, uint32_t *w_gh, u64 *cnt,
+                                    hipStream_t stream);
+extern "C" hipError_t gs_lb_place(const uint32_t *w_valid, const uint32_t *w_gh, int64_t n_w, uint32_t rec_bits, int max_rounds, uint32_t *slot,
+                                  uint32_t *slot2, uint32_t *claim, uint32_t *state, uint32_t *win_bucket, u64 *changes, int *rounds_done,
+                                  hipStream_t stream);
+extern "C" hipError_t gs_lb_lines(const uint32_t *slot, uint32_t rec_bits, const u64 *w_hi, const u64 *w_lo, const uint32_t *w_valid, const uint32_t *s_gh,
+                                  const uint32_t *s_ohi, const uint32_t *s_olo, const uint32_t *s_vj, const uint32_t *group, const uint8_t *assign,
+                                  const uint32_t *win_bucket, int64_t n_e, int k, u64 *rec, u64 *t_key, int32_t *t_val, uint32_t *m_gh, u64 *cnt,
+                                  hipStream_t stream);
+extern "C" hipError_t gs_lb_more(const uint32_t *m_gh, int64_t n_m, uint32_t rec_bits, u64 *rec, hipStream_t stream);
+extern "C" hipError_t gs_lb_table(const u64 *t_key, const int32_t *t_val, int64_t n_t, int b, int vbits, u64 *rot_a, u64 *rot_b, int32_t *val_b,
+                                  int32_t *val_c, uint32_t *start, uint32_t *left, uint32_t *pos, uint32_t *perm, uint32_t *perm_alt, uint32_t *fill_a,
+                                  uint32_t *fill_b, u64 *table, int64_t *overflow, int *max_disp, hipStream_t stream);
+extern "C" hipError_t gs_lb_distinct(uint32_t *h_gh, uint32_t *h_alt, int64_t n_h, u64 *d_scratch, int64_t *distinct, uint32_t **sorted,
+                                     hipStream_t stream);
+extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream);
+
+// device scratch that goes when the build is over (or fails)
+struct DevPool {
+    std::vector<void *> all;
+    hipError_t err = hipSuccess;
+    ~DevPool() {
+        for (void *p : all) hipFree(p);
+    }
+    template <typename T>
+    T *get(size_t count) {
+        void *p = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (err != hipSuccess) return nullptr;
+        all.push_back(p);
+        return (T *)p;
+    }
+    void drop(void *p) {
+        for (void *&x : all)
+            if (x == p && p) {
+                hipFree(p);
+                x = nullptr;
+            }
+    }
+    void *keep(void *p) {  // the pointer leaves the pool (it becomes part of the store)
+        for (void *&x : all)
+            if (x == p) x = nullptr;
+        return p;
+    }
+};
+
+// 1: built (*out), 0: this store is for the host builder (no record entries), < 0: error
+static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx, int32_t n_values,
+                               const std::vector<int32_t> &parent, const std::vector<int32_t> &depth, const std::vector<int32_t> &tin,
+                               const std::vector<int32_t> &tout, BuildTrace &trace) {
+    hipStream_t stream = nullptr;
+    DevPool pool;
+    auto bad = [&](hipError_t e, const char *what) {
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("device layout build (") + what + "): " + hipGetErrorString(e));
+    };
+#define LB_TRY(expr, what)                                        \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ == hipSuccess && pool.err != hipSuccess) e_ = pool.err; \
+        if (e_ != hipSuccess) return bad(e_, what);               \
+    } while (0)
+    const size_t sn = (size_t)n;
+    int64_t *d_k = pool.get<int64_t>(sn);
+    int32_t *d_v = pool.get<int32_t>(sn);
+    int32_t *d_parent = pool.get<int32_t>((size_t)n_values);
+    uint32_t *e_gh = pool.get<uint32_t>(sn), *e_ohi = pool.get<uint32_t>(sn), *e_olo = pool.get<uint32_t>(sn), *e_vj = pool.get<uint32_t>(sn);
+    u64 *e_sort = pool.get<u64>(sn), *e_sort2 = pool.get<u64>(sn);
+    u64 *t_key = pool.get<u64>(sn);
+    int32_t *t_val = pool.get<int32_t>(sn);
+    uint32_t *m_gh = pool.get<uint32_t>(2 * sn), *h_gh = pool.get<uint32_t>(2 * sn);
+    u64 *cnt = pool.get<u64>(GS_LB_COUNTERS);
+    LB_TRY(pool.err, "buffers");
+    LB_TRY(hipMemcpy(d_k, kmers, sn * sizeof(int64_t), hipMemcpyHostToDevice), "upload");
+    LB_TRY(hipMemcpy(d_v, vidx, sn * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
+    LB_TRY(hipMemcpy(d_parent, parent.data(), (size_t)n_values * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
+    LB_TRY(hipMemset(cnt, 0, GS_LB_COUNTERS * sizeof(u64)), "counters");
+    trace.mark("device: upload");
+    LB_TRY(gs_lb_perkey(d_k, d_v, n, k, d_parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, cnt, stream), "per key");
+    u64 c[GS_LB_COUNTERS];
+    LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "per key");
+    pool.drop(d_k);
+    pool.drop(d_v);
+    const int64_t n_e = (int64_t)c[GS_LB_N_E], n_h = (int64_t)c[GS_LB_N_H];
+    trace.mark("device: per key");
+    if (n_e == 0) return 0;  // nothing for records: the host builder's table-only store
+    // ---- entries sorted by minimizer, minimizers -> windows
+    const size_t se = (size_t)n_e;
+    u64 *sort_alt = pool.get<u64>(se);
+    uint32_t *perm = pool.get<uint32_t>(se), *perm_alt = pool.get<uint32_t>(se);
+    uint32_t *s_gh = pool.get<uint32_t>(se), *s_ohi = pool.get<uint32_t>(se), *s_olo = pool.get<uint32_t>(se), *s_vj = pool.get<uint32_t>(se);
+    LB_TRY(pool.err, "sort buffers");
+    LB_TRY(gs_lb_sort_entries(e_sort, e_sort2, sort_alt, perm, perm_alt, n_e, e_gh, e_ohi, e_olo, e_vj, s_gh, s_ohi, s_olo, s_vj, stream), "sort");
+    pool.drop(e_sort2);
+    pool.drop(e_gh);
+    pool.drop(e_ohi);
+    pool.drop(e_olo);
+    pool.drop(e_vj);
+    pool.drop(e_sort);
+    pool.drop(sort_alt);
+    pool.drop(perm);
+    pool.drop(perm_alt);
+    trace.mark("device: sort");
+    uint32_t *head = pool.get<uint32_t>(se), *group = pool.get<uint32_t>(se), *g_start = pool.get<uint32_t>(se + 1);
+    LB_TRY(pool.err, "group buffers");
+    int64_t n_groups = 0;
+    LB_TRY(gs_lb_groups(s_gh, n_e, head, group, g_start, &n_groups, stream), "groups");
+    pool.drop(head);
+    const size_t sw = 2 * (size_t)n_groups;
+    uint8_t *assign = pool.get<uint8_t>(se);
+    u64 *w_hi = pool.get<u64>(sw), *w_lo = pool.get<u64>(sw);
+    uint32_t *w_valid = pool.get<uint32_t>(sw), *w_gh = pool.get<uint32_t>(sw);
+    LB_TRY(pool.err, "window buffers");
+    LB_TRY(gs_lb_cluster(s_gh, s_ohi, s_olo, s_vj, g_start, n_groups, k, assign, w_hi, w_lo, w_valid, w_gh, cnt, stream), "cluster");
+    LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "cluster");
+    pool.drop(g_start);
+    const int64_t n_win = (int64_t)c[GS_LB_N_WIN];
+    trace.mark("device: cluster");
+    // ---- buckets
+    double rload = 0.4;
+    if (const char *e = getenv("GS_REC_LOAD")) {
+        const double v = atof(e);
+        if (v > 0.01 && v <= 0.5) rload = v;
+    }
+    int rec_bits = 4;
+    while (rec_bits < 29 && (double)((size_t)1 << rec_bits) * rload < (double)n_win) rec_bits++;
+    const size_t n_rec = (size_t)1 << rec_bits;
+    int max_rounds = 64, rounds_done = 0;
+    if (const char *e = getenv("GS_REC_ROUNDS")) max_rounds = std::max(2, std::min(5000, atoi(e)));
+    uint32_t *slot = pool.get<uint32_t>(n_rec), *slot2 = pool.get<uint32_t>(n_rec), *claim = pool.get<uint32_t>(n_rec);
+    uint32_t *wstate = pool.get<uint32_t>(sw), *win_bucket = pool.get<uint32_t>(sw);
+    u64 *d_rec = pool.get<u64>(n_rec * GS_REC_WORDS);
+    LB_TRY(pool.err, "record buffers");
+    LB_TRY(gs_lb_place(w_valid, w_gh, (int64_t)sw, (uint32_t)rec_bits, max_rounds, slot, slot2, claim, wstate, win_bucket, cnt + GS_LB_OVERFLOW,
+                       &rounds_done, stream), "placement");
+    pool.drop(wstate);
+    pool.drop(slot2);
+    pool.drop(claim);
+    LB_TRY(gs_lb_lines(slot, (uint32_t)rec_bits, w_hi, w_lo, w_valid, s_gh, s_ohi, s_olo, s_vj, group, assign, win_bucket, n_e, k, d_rec, t_key, t_val,
+                       m_gh, cnt, stream), "lines");
+    LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "lines");
+    const int64_t n_t = (int64_t)c[GS_LB_N_T], n_m = (int64_t)c[GS_LB_N_M], n_in_records = (int64_t)c[GS_LB_IN_REC];
+    LB_TRY(gs_lb_more(m_gh, n_m, (uint32_t)rec_bits, d_rec, stream), "more bits");
+    LB_TRY(hipDeviceSynchronize(), "more bits");
+    for (void *p : {(void *)slot, (void *)win_bucket, (void *)assign, (void *)w_hi, (void *)w_lo, (void *)w_valid, (void *)w_gh, (void *)s_gh, (void *)s_ohi,
+                    (void *)s_olo, (void *)s_vj, (void *)group, (void *)m_gh})
+        pool.drop(p);
+    trace.mark("device: placement + lines");
+    if (trace.on)
+        fprintf(stderr, "[gs_db_create] device: %lld entries, %lld minimizers, %lld windows in %lld buckets (%.3f, %d bidding rounds), %lld k-mers in records, %lld in the table\n",
+                (long long)n_e, (long long)n_groups, (long long)n_win, (long long)n_rec, (double)n_win / (double)n_rec, rounds_done,
+                (long long)n_in_records, (long long)n_t);
+    // ---- overflow table
+    const int vbits = std::max(1, bits_for((u64)n_values));
+    double load = 3.0;
+    if (const char *e = getenv("GS_BUCKET_LOAD")) {
+        double v = atof(e);
+        if (v > 0.05 && v <= 6.0) load = v;
+    }
+    int b = std::max(vbits + 1, 4);
+    while ((double)(1ULL << b) * load < (double)n_t) b++;
+    u64 *d_table = nullptr;
+    int max_disp = 0;
+    {
+        const size_t st = (size_t)std::max<int64_t>(n_t, 1);
+        u64 *rot_a = pool.get<u64>(st), *rot_b = pool.get<u64>(st);
+        int32_t *val_b = pool.get<int32_t>(st), *val_c = pool.get<int32_t>(st);
+        uint32_t *t_start = pool.get<uint32_t>(st), *t_left = pool.get<uint32_t>(st), *t_pos = pool.get<uint32_t>(st), *t_perm = pool.get<uint32_t>(st),
+                 *t_perm2 = pool.get<uint32_t>(st);
+        LB_TRY(pool.err, "table buffers");
+        for (;; b++) {
+            if (b > 29) return fail(GS_E_UNSUPPORTED, "store too large for 32-bit slot indices");
+            uint32_t *fill_a = pool.get<uint32_t>((size_t)1 << b), *fill_b = pool.get<uint32_t>((size_t)1 << b);
+            d_table = pool.get<u64>(((size_t)1 << b) * GS_SLOTS_PER_BUCKET);
+            LB_TRY(pool.err, "table buffers");
+            int64_t overflow = 0;
+            LB_TRY(gs_lb_table(t_key, t_val, n_t, b, vbits, rot_a, rot_b, val_b, val_c, t_start, t_left, t_pos, t_perm, t_perm2, fill_a, fill_b, d_table,
+                               &overflow, &max_disp, stream), "table");
+            pool.drop(fill_a);
+            pool.drop(fill_b);
+            if (overflow == 0) break;
+            pool.drop(d_table);  // a key found no slot within GS_MAX_DISP buckets: twice the buckets
+        }
+        for (void *p : {(void *)rot_a, (void *)rot_b, (void *)val_b, (void *)val_c, (void *)t_start, (void *)t_left, (void *)t_pos, (void *)t_perm, (void *)t_perm2}) pool.drop(p);
+    }
+    pool.drop(t_key);
+    pool.drop(t_val);
+    trace.mark("device: overflow table");
+    // ---- minimizer gate
+    uint32_t *h_alt = pool.get<uint32_t>((size_t)std::max<int64_t>(n_h, 1));
+    LB_TRY(pool.err, "gate buffers");
+    int64_t distinct = 0;
+    uint32_t *h_sorted = h_gh;
+    LB_TRY(gs_lb_distinct(h_gh, h_alt, n_h, cnt, &distinct, &h_sorted, stream), "distinct minimizers");
+    double bits_per_min = 16.0;
+    if (const char *e = getenv("GS_MGATE_BITS_PER_MIN")) bits_per_min = std::max(1.0, atof(e));
+    int mgate_bits = 6;
+    while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < (double)distinct * bits_per_min) mgate_bits++;
+    uint32_t *d_mgate = pool.get<uint32_t>((size_t)1 << mgate_bits);
+    LB_TRY(pool.err, "gate");
+    LB_TRY(gs_lb_gate(h_sorted, n_h, (uint32_t)mgate_bits, d_mgate, stream), "gate");
+    int32_t *d_tree = pool.get<int32_t>(4 * (size_t)n_values);
+    LB_TRY(pool.err, "tree");
+    LB_TRY(hipMemcpy(d_tree, parent.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
+    LB_TRY(hipMemcpy(d_tree + n_values, depth.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
+    LB_TRY(hipMemcpy(d_tree + 2 * (size_t)n_values, tin.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
+    LB_TRY(hipMemcpy(d_tree + 3 * (size_t)n_values, tout.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
+    LB_TRY(hipDeviceSynchronize(), "gate");
+    trace.mark("device: gate");
+#undef LB_TRY
+    hipDeviceProp_t prop;
+    gs_db *db = new gs_db();
+    db->device = device;
+    db->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    db->d_rec = (u64 *)pool.keep(d_rec);
+    db->d_table = (u64 *)pool.keep(d_table);
+    db->d_mgate = (uint32_t *)pool.keep(d_mgate);
+    db->d_tree = (int32_t *)pool.keep(d_tree);
+    db->n_rec = (int64_t)n_rec;
+    db->info.k = k;
+    db->info.n_values = n_values;
+    db->info.n_entries = n;
+    db->info.n_stored = n_t + n_in_records;
+    db->info.n_in_records = n_in_records;
+    db->info.rec_bytes = (int64_t)(n_rec * GS_REC_WORDS * sizeof(u64));
+    db->info.n_buckets = (int64_t)1 << b;
+    db->info.table_bytes = (int64_t)(((size_t)1 << b) * GS_SLOTS_PER_BUCKET * sizeof(u64));
+    db->info.max_displacement = max_disp;
+    db->info.value_bits = vbits;
+    db->info.gate_bytes = 0;
+    db->info.mgate_bytes = (int64_t)(((size_t)1 << mgate_bits) * sizeof(uint32_t));
+    db->dev.table = db->d_table;
+    db->dev.gate = nullptr;
+    db->dev.gate_mask = 0;
+    db->dev.mgate = db->d_mgate;
+    db->dev.mgate_bits = (uint32_t)mgate_bits;
+    db->dev.rec = db->d_rec;
+    db->dev.rec_bits = (uint32_t)rec_bits;
+    db->dev.bucket_bits = (uint32_t)b;
+    db->dev.vbits = (uint32_t)vbits;
+    db->dev.bucket_mask = (1ULL << b) - 1;
+    db->dev.k = k;
+    db->dev.n_values = n_values;
+    db->dev.parent = db->d_tree;
+    db->dev.depth = db->d_tree + n_values;
+    db->dev.tin = db->d_tree + 2 * (size_t)n_values;
+    db->dev.tout = db->d_tree + 3 * (size_t)n_values;
+    *out = db;
+    return 1;
+}
+
 // fused: the store serves the fused kernels (gs_match_submit*, gs_match_segments) and may keep k-mers in super-k-mer
 // records; a partition store (gs_db_create_part, any n_parts) keeps every key in the table, where gs_match_probe_keys looks
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
@@ -566,6 +830,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
     }
     trace.mark("checks + tree");
+    // ---- the layout on the device: plain fused stores with records (k >= 19, at most 2^21 values).  GS_BUILD_HOST=1 keeps
+    // the host builder (the reference for the layout rules; striped / partition / table-only stores are always its job)
+    {
+        bool on_device = fused && n_parts == 1 && stripes <= 1 && !dryrun && k >= GS_MIN_K && n_values <= GS_REC_MAX_VALUES && n > 0;
+        if (const char *e = getenv("GS_BUILD_HOST")) on_device = on_device && atoi(e) == 0;
+        if (const char *e = getenv("GS_MGATE")) on_device = on_device && atoi(e) != 0;
+        if (const char *e = getenv("GS_RECORDS")) on_device = on_device && atoi(e) != 0;
+        if (on_device) {
+            const int drc = db_create_on_device(out, device, k, n, kmers, vidx, n_values, parent, depth, tin, tout, trace);
+            if (drc != 0) return drc < 0 ? drc : GS_OK;
+        }
+    }
     // ---- keys
     // Every reachable stored k-mer is looked at from both strands (gs_layout.h: gs_choose_minimizer).  If both views pick
     // the same minimizer occurrence the k-mer can live in a super-k-mer record; otherwise (and for every k-mer when the
