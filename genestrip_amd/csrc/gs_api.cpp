@@ -833,7 +833,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- the layout on the device: plain fused stores with records (k >= 19, at most 2^21 values).  GS_BUILD_HOST=1 keeps
     // the host builder (the reference for the layout rules; striped / partition / table-only stores are always its job)
     {
-        bool on_device = fused && n_parts == 1 && stripes <= 1 && !dryrun && k >= GS_MIN_K && n_values <= GS_REC_MAX_VALUES && n > 0;
+        bool on_device = fused && n_parts == 1 && stripes <= 1 && !dryrun && k >= GS_MIN_K && n_values <= GS_REC_MAX_VALUES && n > 0 && n < ((int64_t)1 << 31);
         if (const char *e = getenv("GS_BUILD_HOST")) on_device = on_device && atoi(e) == 0;
         if (const char *e = getenv("GS_MGATE")) on_device = on_device && atoi(e) != 0;
         if (const char *e = getenv("GS_RECORDS")) on_device = on_device && atoi(e) != 0;

@@ -195,3 +195,34 @@ def test_damaged_store_files_are_refused(tmp_path):
     slot = (slot & ~(vmask << 1)) | (vmask << 1)  # value index beyond n_values
     bad[first:first + 8] = struct.pack("<Q", slot)
     assert "slot value" in refused("value.gss", with_checksum(bad))
+
+
+def test_device_and_host_layout_builds_are_reproducible_and_answer_alike(tmp_path, monkeypatch):
+    """gs_db_create lays the store out on the device (gs_layout_build.hip); GS_BUILD_HOST=1 keeps the host builder.  Each of them
+    gives the same bytes every time (the merge of runs on separately built replicas indexes the unique-k-mer bitmap by slot),
+    and both layouts answer every read alike."""
+    db = synth.SynthDB(k=31, genera=3, species_per_genus=4, genome_len=30000, seed=21)
+    seq, off = synth.reads_host(db.genomes, 6000, read_len=150, seed=3)
+    off = off.astype(np.uint64)
+    images, tables = {}, {}
+    for how in ("device", "device", "host", "host"):
+        if how == "host":
+            monkeypatch.setenv("GS_BUILD_HOST", "1")
+        else:
+            monkeypatch.delenv("GS_BUILD_HOST", raising=False)
+        store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        p = tmp_path / ("%s_%d.gss" % (how, len(images)))
+        store.save(p)
+        m = ga.FastqKMerMatcher(store)
+        m.submit(seq, off, 0)
+        t = m.finish()[0]
+        m.close()
+        store.close()
+        raw = p.read_bytes()
+        if how in images:
+            assert images[how] == raw, how  # the same bytes again
+            assert np.array_equal(tables[how], t)
+        images[how], tables[how] = raw, t
+    assert images["device"] != images["host"]  # two builders, two (valid) layouts
+    assert np.array_equal(tables["device"], tables["host"]) and tables["device"][:, 3].sum() > 0
+    ga.DeviceKMerStore.load(tmp_path / "device_0.gss").close()  # and the loader's checks accept the device's image
