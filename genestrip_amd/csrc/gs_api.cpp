@@ -1617,6 +1617,11 @@ struct TextScan {
     uint8_t *d_fa_seq = nullptr;
     size_t fa_scan_cap = 0, fa_block_cap = 0, line_dst_cap = 0, fa_seq_cap = 0;
     bool last_fasta = false;
+    // general FASTQ (gs_match_submit_fastq_ml): per-line record structure
+    uint32_t *d_ml_next = nullptr, *d_ml_plus = nullptr, *d_ml_ja = nullptr, *d_ml_jb = nullptr;
+    uint8_t *d_ml_mark = nullptr, *d_ml_class = nullptr;
+    u64 *d_ml_out = nullptr;
+    size_t ml_next_cap = 0, ml_plus_cap = 0, ml_ja_cap = 0, ml_jb_cap = 0, ml_mark_cap = 0, ml_class_cap = 0;
     // GS_TEXT_BANKS independent streams of chunks (files read side by side): a refusal in one must not silence the
     // others, so the status words and totals exist once per bank; `bank` is the one the next calls work on
     uint32_t *d_status = nullptr;  // GS_TEXT_BANKS x GS_TS_WORDS
@@ -1690,6 +1695,13 @@ struct gs_run {
 
 
 static void text_free_fasta(TextScan &t) {
+    hipFree(t.d_ml_next);
+    hipFree(t.d_ml_plus);
+    hipFree(t.d_ml_ja);
+    hipFree(t.d_ml_jb);
+    hipFree(t.d_ml_mark);
+    hipFree(t.d_ml_class);
+    hipFree(t.d_ml_out);
     hipFree(t.d_fa_scan);
     hipFree(t.d_fa_block);
     hipFree(t.d_line_dst);
@@ -1749,15 +1761,24 @@ static int text_reset(TextScan &t, bool totals, hipStream_t stream, bool all = f
 }
 
 extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket, hipStream_t stream);
+extern "C" hipError_t gs_launch_text_ml(const GsTextParams *P, uint8_t *line_class, hipStream_t stream);
 
 // copies the chunk to the device and runs the record scan; *ticket identifies the chunk.  After it the (start, end)
 // pairs of the sequence lines are in t.d_off2, the newline offsets in t.d_nl and the skip flag in t.d_status.
 // fasta_records < 0: four-line FASTQ; >= 0: FASTA with that many header lines (gs_text.hip)
+// ml_out != nullptr: general FASTQ -- the record structure is found on the device first (this call then waits for it) and
+// ml_out[0] = complete records, ml_out[1] = bytes they cover
 static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int k,
-                       int64_t *ticket, int64_t fasta_records = -1) {
-    const bool fasta = fasta_records >= 0;
+                       int64_t *ticket, int64_t fasta_records = -1, int64_t *ml_out = nullptr) {
+    const bool ml = ml_out != nullptr;
+    const bool fasta = fasta_records >= 0 || ml;
+    if (ml) {
+        ml_out[0] = ml_out[1] = 0;
+        fasta_records = 0;
+    }
     if (n_bytes < 0 || n_lines < 0 || (!fasta && (n_lines & 3) != 0) || (n_bytes > 0 && !text) || n_lines > n_bytes)
         return fail(GS_E_INVALID, "bad text chunk (n_lines must be a multiple of 4)");
+    if (ml && n_lines >= ((int64_t)1 << 26)) return fail(GS_E_INVALID, "general FASTQ chunks are limited to 2^26 lines");
     if (fasta && (fasta_records > n_lines || fasta_records >= ((int64_t)1 << 24)))
         return fail(GS_E_INVALID, "bad FASTA chunk (at most 2^24 - 1 records, not more records than lines)");
     if (n_bytes > ((int64_t)1 << 30)) return fail(GS_E_INVALID, "text chunks are limited to 1 GiB");
@@ -1771,7 +1792,7 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
         for (hipEvent_t &ev : t.done) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&t.copy_stream, hipStreamNonBlocking));
     }
-    const int64_t n_reads = fasta ? fasta_records : (n_lines >> 2);
+    int64_t n_reads = ml ? n_lines / 4 + 1 : (fasta ? fasta_records : (n_lines >> 2));  // (ml: an upper bound for now)
     const size_t padded = ((size_t)n_bytes + 4095) & ~(size_t)4095;
     const int64_t tk = t.tickets;
     const int b = (int)(tk & 1);
@@ -1786,6 +1807,16 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
         if ((rc = grow(&t.d_fa_block, &t.fa_block_cap, (size_t)n_lines / GS_FA_BLOCK + 2, stream))) return rc;
         if ((rc = grow(&t.d_line_dst, &t.line_dst_cap, (size_t)n_lines + 1, stream))) return rc;
         if ((rc = grow(&t.d_fa_seq, &t.fa_seq_cap, (size_t)n_bytes + 256, stream))) return rc;
+    }
+    if (ml) {
+        const size_t nl1 = (size_t)n_lines + 1;
+        if ((rc = grow(&t.d_ml_next, &t.ml_next_cap, nl1, stream))) return rc;
+        if ((rc = grow(&t.d_ml_plus, &t.ml_plus_cap, nl1, stream))) return rc;
+        if ((rc = grow(&t.d_ml_ja, &t.ml_ja_cap, nl1, stream))) return rc;
+        if ((rc = grow(&t.d_ml_jb, &t.ml_jb_cap, nl1, stream))) return rc;
+        if ((rc = grow(&t.d_ml_mark, &t.ml_mark_cap, nl1, stream))) return rc;
+        if ((rc = grow(&t.d_ml_class, &t.ml_class_cap, nl1, stream))) return rc;
+        if (!t.d_ml_out) HIP_TRY(hipMalloc((void **)&t.d_ml_out, sizeof(u64) * 4));
     }
     t.d_text = t.d_buf[b];
     // the copy waits for the kernels of the chunk before last (they read this buffer), the scan for the copy
@@ -1813,6 +1844,44 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     T.line_dst = t.d_line_dst;
     T.fa_seq = t.d_fa_seq;
     t.last_fasta = fasta;
+    if (ml) {
+        // first half: newlines + record structure; then this thread waits for the counts (the match launch needs the number
+        // of reads, the caller the bytes that belong to the next chunk)
+        T.ml_next = t.d_ml_next;
+        T.ml_plus = t.d_ml_plus;
+        T.ml_jump_a = t.d_ml_ja;
+        T.ml_jump_b = t.d_ml_jb;
+        T.ml_mark = t.d_ml_mark;
+        T.ml_out = (unsigned long long *)t.d_ml_out;
+        const u64 init[4] = {0, (u64)n_lines, 0, 0};
+        HIP_TRY(hipMemcpyAsync(t.d_ml_out, init, sizeof(init), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(t.d_ml_class, 0, (size_t)n_lines + 1, stream));
+        HIP_TRY(gs_launch_text_ml(&T, t.d_ml_class, stream));
+        u64 got[4] = {0, 0, 0, 0};
+        uint32_t st[GS_TS_WORDS];
+        HIP_TRY(hipMemcpyAsync(got, t.d_ml_out, sizeof(got), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(st, T.status, sizeof(st), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int64_t lines_done = 0, bytes_done = 0;
+        n_reads = 0;
+        if (st[GS_TS_CHUNK_ERR] == 0 && st[GS_TS_STICKY] == 0 && n_lines > 0) {
+            n_reads = (int64_t)got[0];
+            lines_done = (int64_t)got[1];
+            if (lines_done > 0) {
+                uint32_t last_nl = 0;
+                HIP_TRY(hipMemcpy(&last_nl, t.d_nl + (lines_done - 1), sizeof(uint32_t), hipMemcpyDeviceToHost));
+                bytes_done = (int64_t)last_nl + 1;
+            }
+        }
+        ml_out[0] = n_reads;
+        ml_out[1] = bytes_done;
+        // second half on what is whole: the FASTA kernels under the line classes (or, after an error, only the commit)
+        T.n_lines = lines_done;
+        T.n_bytes = bytes_done > 0 ? bytes_done : n_bytes;
+        T.n_records = n_reads;
+        T.line_class = t.d_ml_class;
+        n_lines = lines_done;
+    }
     HIP_TRY(gs_launch_text_scan(&T, (uint32_t)tk, stream));
     HIP_TRY(hipEventRecord(t.done[b], stream));
     t.done_valid[b] = true;
@@ -2245,7 +2314,17 @@ extern "C" int gs_pinned_free(void *p) {
 }
 
 static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records);
+                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records, int64_t *ml_out = nullptr);
+
+extern "C" int gs_match_submit_fastq_ml(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
+                                        int64_t *n_records, int64_t *consumed_bytes, int64_t *ticket) {
+    if (!n_records || !consumed_bytes) return fail(GS_E_INVALID, "NULL argument");
+    int64_t out[2] = {0, 0};
+    const int rc = match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, nullptr, nullptr, ticket, -1, out);
+    *n_records = out[0];
+    *consumed_bytes = out[1];
+    return rc;
+}
 
 extern "C" int gs_match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem,
                                     int64_t first_read_no, int32_t *class_vi, uint8_t *flags, int64_t *ticket) {
@@ -2259,13 +2338,13 @@ extern "C" int gs_match_submit_fasta(gs_run *run, const uint8_t *text, int64_t n
 }
 
 static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records) {
+                             int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records, int64_t *ml_out) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
-    const bool fasta = fasta_records >= 0;
-    const int64_t n_reads = fasta ? fasta_records : (n_lines >> 2);
-    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket, fasta_records);
+    const bool fasta = fasta_records >= 0 || ml_out != nullptr;
+    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket, fasta_records, ml_out);
     if (rc) return rc;
+    const int64_t n_reads = ml_out ? ml_out[0] : (fasta ? fasta_records : (n_lines >> 2));
     if (n_reads == 0) return GS_OK;
     const bool dev_out = mem == GS_MEM_DEVICE;
     if ((class_vi || flags) && !dev_out && run->reads_cap < (size_t)n_reads) {

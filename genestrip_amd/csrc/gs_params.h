@@ -83,7 +83,17 @@ struct GsTextParams {
     unsigned long long *fa_block;     // per block of GS_FA_BLOCK lines: total, then exclusive prefix
     uint32_t *line_dst;               // per line: destination of its bytes in fa_seq, ~0 for header lines
     uint8_t *fa_seq;                  // the sequences of the chunk's records back to back; off2[0 .. n_records] = their bounds
+    // general FASTQ (gs_match_submit_fastq_ml: sequence and quality over any number of lines): the record structure is found
+    // on the device first, then the FASTA kernels gather the sequence lines under these classes
+    const uint8_t *line_class;        // per line: 1 descriptor line, 2 sequence line, 0 anything else; nullptr in the other modes
+    uint32_t *ml_next, *ml_plus;      // per line i, IF a record starts there: the line behind its last quality line, its '+' line
+    uint32_t *ml_jump_a, *ml_jump_b;  // pointer doubling
+    uint8_t *ml_mark;                 // 1: a record starts at this line
+    unsigned long long *ml_out;       // [0] complete records [1] lines they cover [2] bytes they cover
 };
+#define GS_ML_NONE 0xffffffffu
+#define GS_ML_TOO_LONG 0xfffffffeu
+#define GS_ML_MAX_LINES 4096  // lines one record may span before the chunk is refused (the host parser takes over)
 #define GS_FA_BLOCK 256
 
 struct GsFilterParams {

@@ -172,6 +172,12 @@ __global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_text_records_kernel(GsTextPa
 __device__ __forceinline__ void gs_fa_line(const GsTextParams &P, int64_t i, uint32_t &start, uint32_t &len, bool &hdr) {
     start = i ? P.nl[i - 1] + 1 : 0;
     len = P.nl[i] - start;
+    if (P.line_class != nullptr) {  // general FASTQ: the classes were found by gs_ml_class_kernel
+        const uint8_t c = P.line_class[i];
+        hdr = c == 1;
+        if (c != 2) len = 0;
+        return;
+    }
     hdr = len > 0 && P.text[start] == '>';
 }
 
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(GS_FA_BLOCK) void gs_fasta_lines_kernel(GsTextParam
         uint32_t start, len;
         bool hdr;
         gs_fa_line(P, i, start, len, hdr);
-        if (len == 0 || (i == 0 && !hdr)) {
+        if (P.line_class == nullptr && (len == 0 || (i == 0 && !hdr))) {  // (FASTA: no empty lines, a header first)
             atomicOr(&P.status[GS_TS_CHUNK_ERR], GS_TE_SHAPE);
             atomicMin(&P.status[GS_TS_FIRST_BAD], (uint32_t)i);
         }
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(GS_FA_BLOCK) void gs_fasta_emit_kernel(GsTextParams
         P.off2[pre >> 40] = pre & GS_FA_LEN_MASK;  // (the header count was checked: pre >> 40 < n_records)
         P.line_dst[i] = 0xffffffffu;
     } else {
-        P.line_dst[i] = (uint32_t)(pre & GS_FA_LEN_MASK);
+        P.line_dst[i] = len ? (uint32_t)(pre & GS_FA_LEN_MASK) : 0xffffffffu;  // (general FASTQ: '+' and quality lines carry nothing)
     }
 }
 
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void gs_fasta_gather_kernel(GsTextParams P) {
     for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < P.n_lines; i += n_waves) {
         const uint32_t dst = P.line_dst[i];
         if (dst == 0xffffffffu) continue;
-        const uint32_t start = i ? P.nl[i - 1] + 1 : 0, len = P.nl[i] - start;
+        const uint32_t start = i ? P.nl[i - 1] + 1 : 0, len = P.nl[i] - start;  // (a line with a destination is copied whole)
         for (uint32_t j = (uint32_t)lane; j < len; j += 64) P.fa_seq[(size_t)dst + j] = P.text[(size_t)start + j];
     }
 }
@@ -279,6 +285,103 @@ __global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_fasta_totals_kernel(GsTextPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// General FASTQ: AbstractFastqReader.doReadFastq (C/fastq/AbstractFastqReader.java:288-368) lets the sequence and the quality of
+// a record run over any number of lines: descriptor line (ANY line: no '@' is asked for); one sequence line, then further ones
+// until a line STARTS with '+' (:301-308); one quality line, then further ones until they hold at least as many characters as
+// the sequence (:320-341).  Where a record starts therefore depends on everything before it -- a '@' may open a quality line
+// -- which is a sequential parse on the face of it.  On the device:
+//   gs_ml_next_kernel   per line i: IF a record started here, where would the next one start (and where is its '+' line)?  A
+//                       handful of line lengths and first bytes per line, every line at once
+//   gs_ml_orbit_kernel  the records of the chunk are the orbit of line 0 under that map: pointer doubling marks it in
+//                       log2(lines) rounds (one workgroup, the line arrays are small)
+//   gs_ml_class_kernel  every marked line classifies the lines of its record (descriptor / sequence / other) and counts it;
+//                       the first marked line whose record does not end inside the chunk is where the next chunk has to start
+// and then the FASTA kernels above gather the sequence lines of every record into one read (gs_fa_line reads the classes).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gs_ml_start(const GsTextParams &P, uint32_t i) { return i ? P.nl[i - 1] + 1 : 0; }
+__device__ __forceinline__ uint32_t gs_ml_len(const GsTextParams &P, uint32_t i) { return P.nl[i] - gs_ml_start(P, i); }
+
+__global__ __launch_bounds__(256) void gs_ml_next_kernel(GsTextParams P) {
+    const uint32_t n = (uint32_t)P.n_lines;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || P.status[GS_TS_CHUNK_ERR] != 0) return;
+    uint32_t next = GS_ML_NONE, plus = GS_ML_NONE;
+    const uint32_t s = i + 1;  // the first sequence line, whatever it starts with
+    if (s < n) {
+        u64 L = gs_ml_len(P, s);
+        uint32_t p = s + 1, steps = 0;
+        for (; p < n; p++, steps++) {
+            if (steps == GS_ML_MAX_LINES) break;
+            const uint32_t st = gs_ml_start(P, p);
+            if (P.nl[p] > st && P.text[st] == '+') break;
+            L += P.nl[p] - st;
+        }
+        if (steps == GS_ML_MAX_LINES) {
+            next = GS_ML_TOO_LONG;  // (an error only if a record really starts here: gs_ml_class_kernel)
+        } else if (p < n) {
+            plus = p;
+            uint32_t q = p + 1;  // the first quality line, whatever its length
+            if (q < n) {
+                u64 acc = gs_ml_len(P, q);
+                q++;
+                steps = 0;
+                while (acc < L && q < n && steps < GS_ML_MAX_LINES) {
+                    acc += gs_ml_len(P, q);
+                    q++;
+                    steps++;
+                }
+                if (steps == GS_ML_MAX_LINES)
+                    next = GS_ML_TOO_LONG;
+                else if (acc >= L)
+                    next = q;  // (q <= n: the record ends inside the chunk)
+            }
+        }
+    }
+    P.ml_next[i] = next;
+    P.ml_plus[i] = plus;
+}
+
+__global__ __launch_bounds__(1024) void gs_ml_orbit_kernel(GsTextParams P) {
+    const uint32_t n = (uint32_t)P.n_lines;
+    if (P.status[GS_TS_CHUNK_ERR] != 0) return;
+    uint32_t *ja = P.ml_jump_a, *jb = P.ml_jump_b;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        P.ml_mark[i] = i == 0;
+        ja[i] = P.ml_next[i] < n ? P.ml_next[i] : GS_ML_NONE;  // (next == n: the record ends with the chunk, nothing follows)
+    }
+    __syncthreads();
+    for (uint32_t span = 1; span < n; span <<= 1) {  // after the round every start within 2 * span records of line 0 is marked
+        for (uint32_t i = threadIdx.x; i < n; i += 1024)
+            if (P.ml_mark[i] && ja[i] != GS_ML_NONE) P.ml_mark[ja[i]] = 1;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) jb[i] = ja[i] != GS_ML_NONE ? ja[ja[i]] : GS_ML_NONE;
+        __syncthreads();
+        uint32_t *t = ja;
+        ja = jb;
+        jb = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gs_ml_class_kernel(GsTextParams P, uint8_t *line_class) {
+    const uint32_t n = (uint32_t)P.n_lines;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || P.status[GS_TS_CHUNK_ERR] != 0 || !P.ml_mark[i]) return;
+    const uint32_t next = P.ml_next[i];
+    if (next == GS_ML_TOO_LONG) {  // a record of more than GS_ML_MAX_LINES lines: the host parser's case
+        atomicOr(&P.status[GS_TS_CHUNK_ERR], GS_TE_SHAPE);
+        atomicMin(&P.status[GS_TS_FIRST_BAD], i);
+        return;
+    }
+    if (next == GS_ML_NONE) {  // the record goes on behind the chunk: the next chunk starts with this line
+        atomicMin(&P.ml_out[1], (u64)i);
+        return;
+    }
+    line_class[i] = 1;
+    for (uint32_t j = i + 1; j < P.ml_plus[i]; j++) line_class[j] = 2;
+    atomicAdd(&P.ml_out[0], 1ULL);
+}
+
 __global__ void gs_text_commit_kernel(GsTextParams P, uint32_t ticket) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (P.status[GS_TS_STICKY] == 0 && P.status[GS_TS_CHUNK_ERR] != 0) {
@@ -296,13 +399,31 @@ __global__ void gs_text_commit_kernel(GsTextParams P, uint32_t ticket) {
     P.status[GS_TS_CHUNK_ERR] = 0;
 }
 
+// general FASTQ, first half: newline offsets + record structure.  ml_out: [0] = 0, [1] = n_lines before the launch; afterwards
+// [0] complete records, [1] the lines they cover (the caller reads them back, sets n_lines / n_records / line_class and calls
+// gs_launch_text_scan for the second half with lines_done = 1)
+extern "C" hipError_t gs_launch_text_ml(const GsTextParams *P, uint8_t *line_class, hipStream_t stream) {
+    const int64_t n_tiles = (P->n_bytes + GS_TEXT_TILE - 1) / GS_TEXT_TILE;
+    if (n_tiles <= 0 || P->n_lines <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gs_text_count_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
+    hipLaunchKernelGGL(gs_text_scan_kernel, dim3(1), dim3(1024), 0, stream, *P, n_tiles);
+    hipLaunchKernelGGL(gs_text_lines_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
+    const unsigned g = (unsigned)((P->n_lines + 255) / 256);
+    hipLaunchKernelGGL(gs_ml_next_kernel, dim3(g), dim3(256), 0, stream, *P);
+    hipLaunchKernelGGL(gs_ml_orbit_kernel, dim3(1), dim3(1024), 0, stream, *P);
+    hipLaunchKernelGGL(gs_ml_class_kernel, dim3(g), dim3(256), 0, stream, *P, line_class);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t gs_launch_text_scan(const GsTextParams *P, uint32_t ticket, hipStream_t stream) {
     const int64_t n_tiles = (P->n_bytes + GS_TEXT_TILE - 1) / GS_TEXT_TILE;
     if (n_tiles > 0) {
-        hipLaunchKernelGGL(gs_text_count_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
-        hipLaunchKernelGGL(gs_text_scan_kernel, dim3(1), dim3(1024), 0, stream, *P, n_tiles);
-        hipLaunchKernelGGL(gs_text_lines_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
-        if (P->n_records >= 0) {  // FASTA
+        if (P->line_class == nullptr) {  // (general FASTQ: gs_launch_text_ml has found the newlines already)
+            hipLaunchKernelGGL(gs_text_count_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
+            hipLaunchKernelGGL(gs_text_scan_kernel, dim3(1), dim3(1024), 0, stream, *P, n_tiles);
+            hipLaunchKernelGGL(gs_text_lines_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
+        }
+        if (P->n_records >= 0) {  // FASTA, general FASTQ
             const int64_t n_blocks = (P->n_lines + GS_FA_BLOCK - 1) / GS_FA_BLOCK;
             if (n_blocks > 0) {
                 hipLaunchKernelGGL(gs_fasta_lines_kernel, dim3((unsigned)n_blocks), dim3(GS_FA_BLOCK), 0, stream, *P);

@@ -1,0 +1,121 @@
+"""General FASTQ on the device (gs_match_submit_fastq_ml; VERDICT r01 "what's missing" 7): records whose sequence and quality run
+over any number of lines (AbstractFastqReader.doReadFastq, :288-368) -- where a record starts depends on everything before it
+('@' and '+' may open quality lines), which the device resolves with one "where would the next record start" step per line and
+pointer doubling.  Against the parser restatement (orc.parse_fastq, pinned by the reference's SimpleTest.fastq fixture) and the
+match tables it leads to.  Needs an MI355X: run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+import genestrip_amd as ga
+from genestrip_amd import host, synth
+from conftest import GOLDEN
+from oracle import gs_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sdb():
+    return synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=33)
+
+
+def _multiline_fastq(sdb, n, seed, max_seq_lines=4, nasty=True):
+    """records as a sequencer would never write them, and the reference still reads them"""
+    rng = np.random.default_rng(seed)
+    seq, off = synth.reads_host(sdb.genomes, n, read_len=150, seed=seed)
+    out = []
+    for r in range(n):
+        s = seq[int(off[r]):int(off[r + 1])].tobytes()
+        if nasty and r % 17 == 3:
+            s = b"+" + s[1:]  # the first sequence line may start with '+': it is still sequence
+        if nasty and r % 29 == 5:
+            s = s[:40]
+        desc = b"@r%d some text" % r if (not nasty or r % 11) else b"no at sign %d" % r
+        cuts = sorted(set([0, len(s)] + [int(x) for x in rng.integers(1, max(2, len(s)), int(rng.integers(0, max_seq_lines)))]))
+        lines = [s[a:b] for a, b in zip(cuts[:-1], cuts[1:])] or [b""]
+        lines = [lines[0]] + [l for l in lines[1:] if not l.startswith(b"+")] if len(lines) > 1 else lines
+        s2 = b"".join(lines)
+        q = bytes(rng.choice(np.frombuffer(b"@+IIIFFF#5~", dtype=np.uint8), len(s2) + (int(rng.integers(0, 5)) if nasty else 0)))
+        qc = sorted(set([0, len(q)] + [int(x) for x in rng.integers(1, max(2, len(q)), int(rng.integers(0, 3)))]))
+        qlines = [q[a:b] for a, b in zip(qc[:-1], qc[1:])] or [b""]
+        # quality is read until it holds at least len(sequence) characters: a split that reaches that early ends the record early
+        acc, keep = 0, []
+        for ql in qlines:
+            keep.append(ql)
+            acc += len(ql)
+            if acc >= len(s2):
+                break
+        out.append(desc + b"\n" + b"\n".join(lines) + b"\n+" + (b"anything" if r % 5 == 0 else b"") + b"\n" + b"\n".join(keep) + b"\n")
+    return b"".join(out)
+
+
+def _oracle_table(sdb, data):
+    rd = orc.parse_fastq(data, fasta=False, k=31)
+    run = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    run.submit(rd["seq"], rd["seq_off"], threads=8, per_read=False)
+    return run.finish()[0], rd
+
+
+@pytest.mark.parametrize("piece", [1 << 30, 50_000, 7_001, 997])
+def test_multiline_chunks_against_the_parser_restatement(sdb, piece):
+    data = _multiline_fastq(sdb, 3000, seed=5)
+    want, rd = _oracle_table(sdb, data)
+    assert rd["n_reads"] == 3000  # (the generator and the restatement agree on what a record is)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    carry, done, pos = b"", 0, 0
+    while pos < len(data) or carry:
+        nxt = data[pos:pos + piece]
+        pos += len(nxt)
+        buf = carry + nxt
+        cut = buf.rfind(b"\n") + 1
+        chunk, rest = buf[:cut], buf[cut:]
+        if chunk:
+            n_rec, used = m.submit_fastq_ml(np.frombuffer(chunk, dtype=np.uint8), first_read_no=done)
+            done += n_rec
+            carry = chunk[used:] + rest
+        else:
+            carry = buf
+        if pos >= len(data):
+            # what is left is an incomplete record (or nothing): the general parser's share, as in the file pipeline
+            if carry:
+                tail = orc.parse_fastq(carry, fasta=False, k=31)
+                if tail["n_reads"]:
+                    m.submit(tail["seq"], tail["seq_off"], done, n_reads=tail["n_reads"])
+                    done += tail["n_reads"]
+            break
+    m.sync()
+    failed, bad, totals = m.text_status()
+    assert failed < 0
+    table = m.finish()[0]
+    assert done == 3000
+    assert np.array_equal(table, want), np.argwhere(table != want)[:6]
+    m.close()
+    store.close()
+
+
+def test_reference_fixture_and_refusals(sdb):
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    raw = open(os.path.join(GOLDEN, "fastq", "SimpleTest.fastq"), "rb").read()
+    rd = orc.parse_fastq(raw, fasta=False, k=31)
+    cut = raw.rfind(b"\n") + 1
+    n_rec, used = m.submit_fastq_ml(np.frombuffer(raw[:cut], dtype=np.uint8))
+    m.sync()
+    failed, bad, totals = m.text_status()
+    assert failed < 0
+    # every record of the fixture that ends inside the text is found, with the lengths the parser restatement gives
+    assert n_rec in (rd["n_reads"], rd["n_reads"] - 1) and used <= cut
+    lens = (rd["seq_off"][1:] - rd["seq_off"][:-1])[:n_rec]
+    assert totals[0] == n_rec and totals[2] == int(lens.sum())
+    # a NUL byte: the reference drops it from the line, the device refuses the chunk (the host parser takes the file)
+    bad_text = b"@a\nACGT\x00ACGT\n+\nIIIIIIII\n"
+    m.reset()
+    n_rec, used = m.submit_fastq_ml(np.frombuffer(bad_text, dtype=np.uint8))
+    m.sync()
+    failed, _, _ = m.text_status()
+    assert n_rec == 0 and used == 0 and failed >= 0
+    m.close()
+    store.close()
