@@ -132,7 +132,7 @@ def lib():
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
         "gs_match_submit_fasta": (ci, [vp, vp, i64, i64, i64, ci, i64, vp, vp, vp]),
-        "gs_match_submit_fastq_ml": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
+        "gs_match_submit_fastq_ml": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp, vp]),
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
         "gs_match_text_clear_error": (ci, [vp]), "gs_match_text_select": (ci, [vp, ci]),
         "gs_match_segments_text": (ci, [vp, vp]), "gs_match_text_newlines": (ci, [vp, vp]),
@@ -500,9 +500,9 @@ class FastqKMerMatcher:
             n_lines = int(np.count_nonzero(np.asarray(text) == 10)) if mem == MEM_HOST else int((text == 10).sum().item())
         n_rec, used, ticket = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
         _ready(text)
-        _check(lib().gs_match_submit_fastq_ml(self.h, pt, n_bytes, n_lines, mem, first_read_no, C.byref(n_rec), C.byref(used),
+        _check(lib().gs_match_submit_fastq_ml(self.h, pt, n_bytes, n_lines, mem, first_read_no, C.byref(n_rec), C.byref(used), None,
                                               C.byref(ticket)))
-        return n_rec.value, used.value
+        return max(n_rec.value, 0), used.value
 
     def text_wait_copy(self, ticket):
         _check(lib().gs_match_text_wait_copy(self.h, ticket))

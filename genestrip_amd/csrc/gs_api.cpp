@@ -1767,13 +1767,13 @@ extern "C" hipError_t gs_launch_text_ml(const GsTextParams *P, uint8_t *line_cla
 // pairs of the sequence lines are in t.d_off2, the newline offsets in t.d_nl and the skip flag in t.d_status.
 // fasta_records < 0: four-line FASTQ; >= 0: FASTA with that many header lines (gs_text.hip)
 // ml_out != nullptr: general FASTQ -- the record structure is found on the device first (this call then waits for it) and
-// ml_out[0] = complete records, ml_out[1] = bytes they cover
+// ml_out[0] = complete records (-1: the chunk was refused), ml_out[1] = bytes, ml_out[2] = lines they cover
 static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int k,
                        int64_t *ticket, int64_t fasta_records = -1, int64_t *ml_out = nullptr) {
     const bool ml = ml_out != nullptr;
     const bool fasta = fasta_records >= 0 || ml;
     if (ml) {
-        ml_out[0] = ml_out[1] = 0;
+        ml_out[0] = ml_out[1] = ml_out[2] = 0;
         fasta_records = 0;
     }
     if (n_bytes < 0 || n_lines < 0 || (!fasta && (n_lines & 3) != 0) || (n_bytes > 0 && !text) || n_lines > n_bytes)
@@ -1873,8 +1873,9 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
                 bytes_done = (int64_t)last_nl + 1;
             }
         }
-        ml_out[0] = n_reads;
+        ml_out[0] = (st[GS_TS_CHUNK_ERR] != 0 || st[GS_TS_STICKY] != 0) ? -1 : n_reads;
         ml_out[1] = bytes_done;
+        ml_out[2] = lines_done;
         // second half on what is whole: the FASTA kernels under the line classes (or, after an error, only the commit)
         T.n_lines = lines_done;
         T.n_bytes = bytes_done > 0 ? bytes_done : n_bytes;
@@ -2317,12 +2318,13 @@ static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, 
                              int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records, int64_t *ml_out = nullptr);
 
 extern "C" int gs_match_submit_fastq_ml(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                                        int64_t *n_records, int64_t *consumed_bytes, int64_t *ticket) {
+                                        int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket) {
     if (!n_records || !consumed_bytes) return fail(GS_E_INVALID, "NULL argument");
-    int64_t out[2] = {0, 0};
+    int64_t out[3] = {0, 0, 0};
     const int rc = match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, nullptr, nullptr, ticket, -1, out);
     *n_records = out[0];
     *consumed_bytes = out[1];
+    if (consumed_lines) *consumed_lines = out[2];
     return rc;
 }
 
@@ -2344,7 +2346,7 @@ static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, 
     const bool fasta = fasta_records >= 0 || ml_out != nullptr;
     int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket, fasta_records, ml_out);
     if (rc) return rc;
-    const int64_t n_reads = ml_out ? ml_out[0] : (fasta ? fasta_records : (n_lines >> 2));
+    const int64_t n_reads = ml_out ? std::max<int64_t>(ml_out[0], 0) : (fasta ? fasta_records : (n_lines >> 2));
     if (n_reads == 0) return GS_OK;
     const bool dev_out = mem == GS_MEM_DEVICE;
     if ((class_vi || flags) && !dev_out && run->reads_cap < (size_t)n_reads) {

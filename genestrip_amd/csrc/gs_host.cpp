@@ -428,6 +428,8 @@ int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const ui
     return err;
 }
 
+std::atomic<int64_t> g_ml_chunks{0};  // chunks matched through the general FASTQ device path (gs_host_stat(0))
+
 struct TextChunk {
     int64_t file_off;  // of the chunk's first byte
     int64_t reads_before;  // reads of this file in earlier chunks
@@ -489,6 +491,12 @@ struct TextJob {
     // records (gs_match_submit_fasta); no per-read outputs on this path
     bool fasta = false;
     int64_t carry_headers = 0;
+    // general FASTQ (sequence / quality over several lines): chunks of whole lines that start at a record's descriptor line; the
+    // device finds the records (gs_match_submit_fastq_ml) and says how much of the chunk they cover, the rest is carried into the
+    // next one.  A FASTQ file whose first chunk is not four-line FASTQ is read again this way (finish()); no per-read outputs.
+    bool general = false;
+    bool gz_ = false;
+    int readers_ = 2;
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
@@ -514,6 +522,8 @@ struct TextJob {
             if (v >= 1 && v <= 32) readers = v;
         }
         t0 = now_s();
+        gz_ = gzip;
+        readers_ = readers;
         int err = tr.open(path, block, readers, gzip);
         if (!err) err = gs_match_text_select(c.run, bank);
         int64_t failed = -1, bad = -1;
@@ -524,6 +534,7 @@ struct TextJob {
 
     // 1: a block was handled, 0: none ready (blocking = false only); `done` is set when the file is through
     int step(bool blocking, int *err_out) {
+        if (general) return step_general(blocking, err_out);
         if (fasta) return step_fasta(blocking, err_out);
         int err = GS_OK;
         const int64_t i = next_block;
@@ -718,6 +729,64 @@ struct TextJob {
         return 1;
     }
 
+    // The general form of step(): everything up to the block's last newline goes to the device together with what the last chunk
+    // left over; the device reports how many records END in it and how many bytes they cover.
+    int step_general(bool blocking, int *err_out) {
+        int err = GS_OK;
+        const int64_t i = next_block;
+        if (!blocking && !tr.is_full(i)) return 0;
+        TextSlot &sl = tr.wait_full(i);
+        int64_t fallback_off = -1, fallback_reads = 0;
+        bool last = false;
+        if (sl.io_error || !tr.verify_gzip(sl)) {
+            err = hfail(tr.gz ? GS_E_INVALID : GS_E_IO, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
+        } else {
+            err = gs_match_text_select(c.run, bank);
+            uint8_t *blk = sl.buf + tr.headroom;
+            const int64_t n = (int64_t)sl.n;
+            last = sl.eof;
+            if (err) {
+                // (the bank could not be selected: reported below)
+            } else if (sl.newlines == 0) {  // not one whole line: keep everything
+                carry.insert(carry.end(), blk, blk + n);
+                if (carry.size() > tr.headroom && !last) {
+                    fallback_off = carry_file_off;
+                    fallback_reads = reads_in_file;
+                }
+            } else if (carry.size() > tr.headroom) {  // a record longer than a block: the general parser takes over
+                fallback_off = carry_file_off;
+                fallback_reads = reads_in_file;
+            } else {
+                const int64_t cut = (int64_t)sl.last4[0] + 1;  // behind the block's last newline
+                uint8_t *start = blk - carry.size();
+                if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+                const int64_t bytes = (int64_t)carry.size() + cut, lines = carry_lines + sl.newlines;
+                int64_t n_rec = 0, used = 0, used_lines = 0, ticket = -1;
+                err = gs_match_submit_fastq_ml(c.run, start, bytes, lines, GS_MEM_HOST, read_no + reads_in_file, &n_rec, &used, &used_lines, &ticket);
+                if (!err && n_rec < 0) {  // refused (NUL byte, a record of thousands of lines): the general parser from here
+                    err = gs_match_text_clear_error(c.run);
+                    fallback_off = carry_file_off;
+                    fallback_reads = reads_in_file;
+                } else if (!err) {
+                    g_ml_chunks.fetch_add(1);
+                    if (first_ticket < 0) first_ticket = ticket;
+                    reads_in_file += n_rec;
+                    carry_file_off += used;
+                    // what the records did not cover + what lies behind the last newline (the text has been copied)
+                    std::vector<uint8_t> rest(start + used, start + bytes);
+                    rest.insert(rest.end(), blk + cut, blk + n);
+                    carry.swap(rest);
+                    carry_lines = lines - used_lines;
+                }
+            }
+        }
+        tr.release(i);
+        next_block = i + 1;
+        if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
+        *err_out = err;
+        return 1;
+    }
+
 private:
     // filtered FASTQ (afterMatch, :304-307) and Kraken-style lines (:723-756) of the chunk that was just matched, from
     // the raw block: the device returns the record geometry (newline offsets) and the segments (fetch_chunk_results,
@@ -806,6 +875,19 @@ private:
         c.bps += tot[2] - base_tot[2];
         if (fallback_off >= 0) {
             read_no += fallback_reads;
+            // a FASTQ file that is not four lines per record from its very first chunk: once more with the records found on the
+            // device (GS_HOST_ML=0: straight to the reference-exact parser, which also takes over whatever that pass refuses)
+            bool ml = fallback_off == 0 && fallback_reads == 0 && !fasta && !general && !c.filtered.active() && !c.kraken.active();
+            if (const char *e = getenv("GS_HOST_ML")) ml = ml && atoi(e) != 0;
+            if (ml) {
+                TextJob g(c, path, bank, read_no, false);
+                g.general = true;
+                int gerr = g.open(gz_, readers_);
+                while (!gerr && !g.done) g.step(true, &gerr);
+                if (!g.done) g.abort();
+                read_no = g.read_no;
+                return gerr;
+            }
             return parsed_source(c, path, fallback_off, nullptr, 0, read_no);
         }
         read_no += reads_in_file;
@@ -1314,4 +1396,8 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     return hfail(GS_E_NOMEM, "out of host memory");
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
     return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
+
+extern "C" int64_t gs_host_stat(int which) {
+    return which == 0 ? g_ml_chunks.load() : -1;
 }

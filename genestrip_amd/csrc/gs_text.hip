@@ -293,8 +293,8 @@ __global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_fasta_totals_kernel(GsTextPa
 // -- which is a sequential parse on the face of it.  On the device:
 //   gs_ml_next_kernel   per line i: IF a record started here, where would the next one start (and where is its '+' line)?  A
 //                       handful of line lengths and first bytes per line, every line at once
-//   gs_ml_orbit_kernel  the records of the chunk are the orbit of line 0 under that map: pointer doubling marks it in
-//                       log2(lines) rounds (one workgroup, the line arrays are small)
+//   gs_ml_orbit_*       the records of the chunk are the orbit of line 0 under that map: pointer doubling marks it in
+//                       log2(lines) rounds (one small launch per round)
 //   gs_ml_class_kernel  every marked line classifies the lines of its record (descriptor / sequence / other) and counts it;
 //                       the first marked line whose record does not end inside the chunk is where the next chunk has to start
 // and then the FASTA kernels above gather the sequence lines of every record into one read (gs_fa_line reads the classes).
@@ -342,25 +342,24 @@ __global__ __launch_bounds__(256) void gs_ml_next_kernel(GsTextParams P) {
     P.ml_plus[i] = plus;
 }
 
-__global__ __launch_bounds__(1024) void gs_ml_orbit_kernel(GsTextParams P) {
+__global__ __launch_bounds__(256) void gs_ml_orbit_init_kernel(GsTextParams P) {
     const uint32_t n = (uint32_t)P.n_lines;
-    if (P.status[GS_TS_CHUNK_ERR] != 0) return;
-    uint32_t *ja = P.ml_jump_a, *jb = P.ml_jump_b;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        P.ml_mark[i] = i == 0;
-        ja[i] = P.ml_next[i] < n ? P.ml_next[i] : GS_ML_NONE;  // (next == n: the record ends with the chunk, nothing follows)
-    }
-    __syncthreads();
-    for (uint32_t span = 1; span < n; span <<= 1) {  // after the round every start within 2 * span records of line 0 is marked
-        for (uint32_t i = threadIdx.x; i < n; i += 1024)
-            if (P.ml_mark[i] && ja[i] != GS_ML_NONE) P.ml_mark[ja[i]] = 1;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) jb[i] = ja[i] != GS_ML_NONE ? ja[ja[i]] : GS_ML_NONE;
-        __syncthreads();
-        uint32_t *t = ja;
-        ja = jb;
-        jb = t;
-    }
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || P.status[GS_TS_CHUNK_ERR] != 0) return;
+    P.ml_mark[i] = i == 0;
+    P.ml_jump_a[i] = P.ml_next[i] < n ? P.ml_next[i] : GS_ML_NONE;  // (next == n: the record ends with the chunk, nothing follows)
+}
+
+// one round of pointer doubling: ja = next^(2^r) -> jb = next^(2^(r+1)); every marked line marks where ja leads.  (A mark that
+// appears during the round may or may not be passed on in the same round: marks only ever land on starts of records, and after
+// round r all starts within 2^(r+1) records of line 0 are marked either way.)
+__global__ __launch_bounds__(256) void gs_ml_orbit_round_kernel(GsTextParams P, const uint32_t *ja, uint32_t *jb) {
+    const uint32_t n = (uint32_t)P.n_lines;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || P.status[GS_TS_CHUNK_ERR] != 0) return;
+    const uint32_t j = ja[i];
+    if (j != GS_ML_NONE && P.ml_mark[i]) P.ml_mark[j] = 1;
+    jb[i] = j != GS_ML_NONE ? ja[j] : GS_ML_NONE;
 }
 
 __global__ __launch_bounds__(256) void gs_ml_class_kernel(GsTextParams P, uint8_t *line_class) {
@@ -410,7 +409,12 @@ extern "C" hipError_t gs_launch_text_ml(const GsTextParams *P, uint8_t *line_cla
     hipLaunchKernelGGL(gs_text_lines_kernel, dim3((unsigned)n_tiles), dim3(GS_TEXT_BLOCK), 0, stream, *P);
     const unsigned g = (unsigned)((P->n_lines + 255) / 256);
     hipLaunchKernelGGL(gs_ml_next_kernel, dim3(g), dim3(256), 0, stream, *P);
-    hipLaunchKernelGGL(gs_ml_orbit_kernel, dim3(1), dim3(1024), 0, stream, *P);
+    hipLaunchKernelGGL(gs_ml_orbit_init_kernel, dim3(g), dim3(256), 0, stream, *P);
+    uint32_t *ja = P->ml_jump_a, *jb = P->ml_jump_b;
+    for (int64_t span = 1; span < P->n_lines; span <<= 1) {
+        hipLaunchKernelGGL(gs_ml_orbit_round_kernel, dim3(g), dim3(256), 0, stream, *P, ja, jb);
+        std::swap(ja, jb);
+    }
     hipLaunchKernelGGL(gs_ml_class_kernel, dim3(g), dim3(256), 0, stream, *P, line_class);
     return hipGetLastError();
 }

@@ -49,6 +49,7 @@ def lib():
         "gs_host_match_files": (ci, [vp, vp, vp, ci, vp, vp, vp, vp]),
         "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
         "gs_host_match_files_multi": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
+        "gs_host_stat": (C.c_int64, [ci]),
         "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, ci, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
@@ -136,6 +137,11 @@ def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=N
     _check(lib().gs_host_match_files(store.h, C.byref(cfg), parr, len(paths), C.byref(opts),
                                      table.ctypes.data_as(C.c_void_p), dtable.ctypes.data_as(C.c_void_p), C.byref(tot)))
     return table, dtable, tot
+
+
+def stat(which=0):
+    """gs_host_stat: 0 = chunks that went through the general (multi-line) FASTQ device path in this process so far"""
+    return int(lib().gs_host_stat(which))
 
 
 def match_files_multi(stores, paths, config=None):

@@ -190,10 +190,12 @@ int gs_match_submit_fasta(gs_run *run, const uint8_t *text, int64_t n_bytes, int
  * number of lines): `text` = whole lines (n_lines newlines, the last byte is one) that START with a record's descriptor line.  The
  * device finds the record structure -- per line where the next record would start if one started here, then the orbit of line 0
  * by pointer doubling -- and matches the records that END inside the chunk; *n_records is their number, *consumed_bytes what they
- * cover: the caller puts the rest in front of the next chunk.  The call waits for the structure (not for the match).  A chunk
- * with a NUL byte or a record of more than 4096 lines is refused like a malformed four-line chunk (gs_match_text_status). */
+ * cover (*consumed_lines, may be NULL: their lines): the caller puts the rest in front of the next chunk.  The call waits for the
+ * structure (not for the match; the text has been copied when it returns).  A chunk with a NUL byte or a record of more than
+ * 4096 lines is refused like a malformed four-line chunk: *n_records = -1, nothing is matched, gs_match_text_status /
+ * gs_match_text_clear_error as there. */
 int gs_match_submit_fastq_ml(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                             int64_t *n_records, int64_t *consumed_bytes, int64_t *ticket);
+                             int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket);
 int gs_match_text_wait_copy(gs_run *run, int64_t ticket);
 int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_match_text_clear_error(gs_run *run);

@@ -119,3 +119,37 @@ def test_reference_fixture_and_refusals(sdb):
     assert n_rec == 0 and used == 0 and failed >= 0
     m.close()
     store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_multiline_fastq_files_go_through_the_device(sdb, tmp_path, monkeypatch, gz):
+    """gs_host_match_files on a FASTQ file that is not four lines per record: the four-line scan refuses the first chunk, the file
+    is read again with the records found on the device, and what that leaves at the end goes to the reference-exact parser"""
+    import gzip
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(1 << 16))  # many chunks, records across every block border
+    data = _multiline_fastq(sdb, 6000, seed=9) + b"@last without a newline at the end\nACGTACGTAC\nGT\n+\nIIIIIIIIIIII"
+    want, rd = _oracle_table(sdb, data)
+    p = tmp_path / ("ml.fastq.gz" if gz else "ml.fastq")
+    (gzip.open(p, "wb") if gz else open(p, "wb")).write(data)
+    plain = tmp_path / "plain.fastq"  # a four-line file in the same call: the usual path, untouched
+    rs, ro = synth.reads_host(sdb.genomes, 500, read_len=150, seed=77)
+    with open(plain, "wb") as f:
+        for i in range(500):
+            s = rs[int(ro[i]):int(ro[i + 1])].tobytes()
+            f.write(b"@p%d\n%s\n+\n%s\n" % (i, s, b"F" * len(s)))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    before = host.stat(0)
+    table, _, tot = host.match_files(store, [str(p)])
+    assert host.stat(0) > before + 5  # chunks DID go through the device's record search
+    assert np.array_equal(table, want), np.argwhere(table != want)[:6]
+    assert (tot.reads, tot.bps, tot.kmers) == (rd["n_reads"], int(rd["total_bps"]), int(rd["total_kmers"]))
+    # the same through the reference-exact parser alone, and mixed with a four-line file
+    monkeypatch.setenv("GS_HOST_ML", "0")
+    t2, _, tot2 = host.match_files(store, [str(p)])
+    monkeypatch.delenv("GS_HOST_ML")
+    assert np.array_equal(t2, want) and tot2.reads == tot.reads
+    both = _oracle_table(sdb, data + b"\n" + open(plain, "rb").read())[0]
+    t3, _, tot3 = host.match_files(store, [str(p), str(plain)])
+    assert tot3.reads == rd["n_reads"] + 500
+    assert np.array_equal(t3[:, [0, 1, 2, 3, 4, 5]], both[:, [0, 1, 2, 3, 4, 5]])
+    store.close()
