@@ -14,7 +14,8 @@
 //   * the number of newlines equals what the host counted and the text ends with one.
 // '\r' stays part of its line exactly as in the reference (and is then an invalid base).  Anything else sets a sticky
 // error: this chunk and all later ones are skipped by the match kernel (GsMatchParams::skip), the run's state stays
-// untouched, and the host re-parses from the start of the failing chunk with the general parser.
+// untouched, and the host re-parses from the start of the failing chunk -- a file that fails in its very first chunk once more
+// through the general FASTQ kernels at the end of this file (records over any number of lines), the rest with the general parser.
 //
 // Kernels (tiles of 4096 bytes, one uint4 per thread):
 //   gs_text_count_kernel    newlines per tile, NUL check                      streaming, 1 B read per byte
