@@ -833,13 +833,54 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     // ---- the layout on the device: plain fused stores with records (k >= 19, at most 2^21 values).  GS_BUILD_HOST=1 keeps
     // the host builder (the reference for the layout rules; striped / partition / table-only stores are always its job)
     {
-        bool on_device = fused && n_parts == 1 && stripes <= 1 && !dryrun && k >= GS_MIN_K && n_values <= GS_REC_MAX_VALUES && n > 0 && n < ((int64_t)1 << 31);
+        bool on_device = fused && n_parts == 1 && !dryrun && k >= GS_MIN_K && n_values <= GS_REC_MAX_VALUES && n > 0 && n < ((int64_t)1 << 31);
         if (const char *e = getenv("GS_BUILD_HOST")) on_device = on_device && atoi(e) == 0;
         if (const char *e = getenv("GS_MGATE")) on_device = on_device && atoi(e) != 0;
         if (const char *e = getenv("GS_RECORDS")) on_device = on_device && atoi(e) != 0;
-        if (on_device) {
+        if (on_device && stripes <= 1) {
             const int drc = db_create_on_device(out, device, k, n, kmers, vidx, n_values, parent, depth, tin, tout, trace);
             if (drc != 0) return drc < 0 ? drc : GS_OK;
+        } else if (on_device) {
+            // a striped store: the layout on one device (the first stripe's, or this process's), its image to the host, the
+            // stripes cut from that
+            gs_db *whole = nullptr;
+            const int bdev = stripe_only >= 0 ? device : stripe_devices[0];
+            HIP_TRY(hipSetDevice(bdev));
+            const int drc = db_create_on_device(&whole, bdev, k, n, kmers, vidx, n_values, parent, depth, tin, tout, trace);
+            if (drc < 0) return drc;
+            if (drc == 1) {
+                std::vector<u64> h_table((size_t)whole->info.n_buckets * GS_SLOTS_PER_BUCKET), h_rec((size_t)whole->n_rec * GS_REC_WORDS);
+                std::vector<uint32_t> h_mgate((size_t)1 << whole->dev.mgate_bits);
+                hipError_t e = hipMemcpy(h_table.data(), whole->d_table, h_table.size() * sizeof(u64), hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(h_rec.data(), whole->d_rec, h_rec.size() * sizeof(u64), hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(h_mgate.data(), whole->d_mgate, h_mgate.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                StoreImage im{};
+                im.k = k;
+                im.n_values = n_values;
+                im.n_entries = n;
+                im.n_stored = whole->info.n_stored;
+                im.n_in_records = whole->info.n_in_records;
+                im.b = (int)whole->dev.bucket_bits;
+                im.vbits = (int)whole->dev.vbits;
+                im.rec_bits = (int)whole->dev.rec_bits;
+                im.max_disp = whole->info.max_displacement;
+                db_free(whole);
+                if (e != hipSuccess) return fail(GS_E_HIP, std::string("striped store: image of the device build: ") + hipGetErrorString(e));
+                trace.mark("device: image to the host");
+                im.table = h_table.data();
+                im.table_words = h_table.size();
+                im.mgate = h_mgate.data();
+                im.mgate_words = h_mgate.size();
+                im.rec = h_rec.data();
+                im.rec_words = h_rec.size();
+                im.parent = parent.data();
+                im.depth = depth.data();
+                im.tin = tin.data();
+                im.tout = tout.data();
+                rc = store_place(im, device, stripes, stripe_devices, stripe_only, out);
+                trace.mark("stripes");
+                return rc;
+            }
         }
     }
     // ---- keys

@@ -148,3 +148,19 @@ def test_dengue1_genome_gives_the_kmer_set_behind_the_kraken_golden_line():
     want = np.unique(orc.canonical_kmers(genome, 31))
     assert n == len(want) and np.array_equal(keys, want) and not vals.any()
     assert len(genome) == 10735  # (tests/test_gpu_host.py: the same store reproduces R/projects/dengue1/test.out byte for byte)
+
+
+def test_build_restatement_under_sanitizers(tmp_path):
+    """orc_build_* compiled with AddressSanitizer + UBSan (CPU only: GPU sanitizers are not available on this pool)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_build_sanitize")
+    b = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=alignment", "-fopenmp", "-o", exe,
+                        os.path.join(root, "tests", "native", "oracle_build_sanitize.c"), os.path.join(root, "oracle", "gs_oracle.c"), "-lm"],
+                       capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "k=31 stored=" in r.stdout and "ERROR" not in r.stderr
