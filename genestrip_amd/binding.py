@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_to_db", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_submit_fastq_ml", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
@@ -123,6 +123,7 @@ def lib():
         "gs_dbbuild_set_range": (ci, [vp, C.c_uint64, C.c_uint64]),
         "gs_dbbuild_finish": (ci, [vp, vp]),
         "gs_dbbuild_fetch": (ci, [vp, vp, vp]),
+        "gs_dbbuild_to_db": (ci, [vp, vp]),
         "gs_dbbuild_destroy": (ci, [vp]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
@@ -370,6 +371,19 @@ class DeviceDbBuilder:
         vals = np.zeros(n.value, dtype=np.int32)
         _check(lib().gs_dbbuild_fetch(self.h, kmers.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p)))
         return kmers, vals
+
+    def finish_count(self):
+        """sort + fold only: the number of stored k-mers (the arrays stay on the device: fetch() or to_store())"""
+        n = C.c_int64(0)
+        _check(lib().gs_dbbuild_finish(self.h, C.byref(n)))
+        return n.value
+
+    def to_store(self, device=0):
+        """gs_dbbuild_to_db: the store over the built arrays, laid out on the device, nothing through the host"""
+        self.finish_count()
+        h = C.c_void_p()
+        _check(lib().gs_dbbuild_to_db(self.h, C.byref(h)))
+        return DeviceKMerStore._wrap(h, self.k, self.n_values, device)
 
     def close(self):
         if getattr(self, "h", None):

@@ -496,6 +496,54 @@ struct BuildTrace {
 };
 
 
+// parent / depth / pre-order interval of every value index from parent_vi (-1 root, -2 no node; NULL: every value a root)
+static int tree_arrays(int32_t n_values, const int32_t *parent_vi, std::vector<int32_t> &parent, std::vector<int32_t> &depth,
+                       std::vector<int32_t> &tin, std::vector<int32_t> &tout) {
+    parent.assign((size_t)n_values, -1);
+    depth.assign((size_t)n_values, 0);
+    tin.assign((size_t)n_values, 0);
+    tout.assign((size_t)n_values, 0);
+    for (int32_t v = 0; v < n_values; v++) {
+        int32_t p = parent_vi ? parent_vi[v] : -1;
+        if (p < -2 || p >= n_values || p == v) return fail(GS_E_INVALID, "parent_vi out of range");
+        parent[v] = p;
+    }
+    std::vector<std::vector<int32_t>> kids(n_values);
+    std::vector<int32_t> roots;
+    for (int32_t v = 0; v < n_values; v++) {
+        if (parent[v] >= 0) {
+            if (parent[parent[v]] == -2) return fail(GS_E_INVALID, "parent_vi points at a value without a node");
+            kids[parent[v]].push_back(v);
+        } else if (parent[v] == -1)
+            roots.push_back(v);
+    }
+    int32_t counter = 0, visited = 0;
+    std::vector<std::pair<int32_t, size_t>> stack;
+    for (int32_t root : roots) {
+        stack.push_back({root, 0});
+        tin[root] = counter++;
+        depth[root] = 0;
+        visited++;
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second < kids[top.first].size()) {
+                int32_t c = kids[top.first][top.second++];
+                tin[c] = counter++;
+                depth[c] = (int32_t)stack.size();
+                visited++;
+                stack.push_back({c, 0});
+            } else {
+                tout[top.first] = counter;
+                stack.pop_back();
+            }
+        }
+    }
+    int32_t nodes = 0;
+    for (int32_t v = 0; v < n_values; v++) nodes += parent[v] != -2;
+    if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
+    return GS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the layout built on the device (gs_layout_build.hip): same rules as the host builder below
 // ---------------------------------------------------------------------------------------------------
@@ -556,9 +604,10 @@ struct DevPool {
 };
 
 // 1: built (*out), 0: this store is for the host builder (no record entries), < 0: error
+// kmers / vidx: host arrays, or (on_dev) arrays in this device's memory, which are only read
 static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx, int32_t n_values,
                                const std::vector<int32_t> &parent, const std::vector<int32_t> &depth, const std::vector<int32_t> &tin,
-                               const std::vector<int32_t> &tout, BuildTrace &trace) {
+                               const std::vector<int32_t> &tout, BuildTrace &trace, bool on_dev = false) {
     hipStream_t stream = nullptr;
     DevPool pool;
     auto bad = [&](hipError_t e, const char *what) {
@@ -571,8 +620,8 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
         if (e_ != hipSuccess) return bad(e_, what);               \
     } while (0)
     const size_t sn = (size_t)n;
-    int64_t *d_k = pool.get<int64_t>(sn);
-    int32_t *d_v = pool.get<int32_t>(sn);
+    int64_t *d_k = on_dev ? const_cast<int64_t *>(kmers) : pool.get<int64_t>(sn);
+    int32_t *d_v = on_dev ? const_cast<int32_t *>(vidx) : pool.get<int32_t>(sn);
     int32_t *d_parent = pool.get<int32_t>((size_t)n_values);
     uint32_t *e_gh = pool.get<uint32_t>(sn), *e_ohi = pool.get<uint32_t>(sn), *e_olo = pool.get<uint32_t>(sn), *e_vj = pool.get<uint32_t>(sn);
     u64 *e_sort = pool.get<u64>(sn), *e_sort2 = pool.get<u64>(sn);
@@ -581,16 +630,20 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     uint32_t *m_gh = pool.get<uint32_t>(2 * sn), *h_gh = pool.get<uint32_t>(2 * sn);
     u64 *cnt = pool.get<u64>(GS_LB_COUNTERS);
     LB_TRY(pool.err, "buffers");
-    LB_TRY(hipMemcpy(d_k, kmers, sn * sizeof(int64_t), hipMemcpyHostToDevice), "upload");
-    LB_TRY(hipMemcpy(d_v, vidx, sn * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
+    if (!on_dev) {
+        LB_TRY(hipMemcpy(d_k, kmers, sn * sizeof(int64_t), hipMemcpyHostToDevice), "upload");
+        LB_TRY(hipMemcpy(d_v, vidx, sn * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
+    }
     LB_TRY(hipMemcpy(d_parent, parent.data(), (size_t)n_values * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
     LB_TRY(hipMemset(cnt, 0, GS_LB_COUNTERS * sizeof(u64)), "counters");
     trace.mark("device: upload");
     LB_TRY(gs_lb_perkey(d_k, d_v, n, k, d_parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, cnt, stream), "per key");
     u64 c[GS_LB_COUNTERS];
     LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "per key");
-    pool.drop(d_k);
-    pool.drop(d_v);
+    if (!on_dev) {
+        pool.drop(d_k);
+        pool.drop(d_v);
+    }
     const int64_t n_e = (int64_t)c[GS_LB_N_E], n_h = (int64_t)c[GS_LB_N_H];
     trace.mark("device: per key");
     if (n_e == 0) return 0;  // nothing for records: the host builder's table-only store
@@ -788,47 +841,9 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(GS_E_INVALID, "k-mers must be distinct");
     }
     // ---- tree arrays
-    std::vector<int32_t> parent(n_values), depth(n_values, 0), tin(n_values, 0), tout(n_values, 0);
-    for (int32_t v = 0; v < n_values; v++) {
-        int32_t p = parent_vi ? parent_vi[v] : -1;
-        if (p < -2 || p >= n_values || p == v) return fail(GS_E_INVALID, "parent_vi out of range");
-        parent[v] = p;
-    }
-    {
-        std::vector<std::vector<int32_t>> kids(n_values);
-        std::vector<int32_t> roots;
-        for (int32_t v = 0; v < n_values; v++) {
-            if (parent[v] >= 0) {
-                if (parent[parent[v]] == -2) return fail(GS_E_INVALID, "parent_vi points at a value without a node");
-                kids[parent[v]].push_back(v);
-            } else if (parent[v] == -1)
-                roots.push_back(v);
-        }
-        int32_t counter = 0, visited = 0;
-        std::vector<std::pair<int32_t, size_t>> stack;
-        for (int32_t root : roots) {
-            stack.push_back({root, 0});
-            tin[root] = counter++;
-            depth[root] = 0;
-            visited++;
-            while (!stack.empty()) {
-                auto &top = stack.back();
-                if (top.second < kids[top.first].size()) {
-                    int32_t c = kids[top.first][top.second++];
-                    tin[c] = counter++;
-                    depth[c] = (int32_t)stack.size();
-                    visited++;
-                    stack.push_back({c, 0});
-                } else {
-                    tout[top.first] = counter;
-                    stack.pop_back();
-                }
-            }
-        }
-        int32_t nodes = 0;
-        for (int32_t v = 0; v < n_values; v++) nodes += parent[v] != -2;
-        if (visited != nodes) return fail(GS_E_INVALID, "parent_vi contains a cycle");
-    }
+    std::vector<int32_t> parent, depth, tin, tout;
+    rc = tree_arrays(n_values, parent_vi, parent, depth, tin, tout);
+    if (rc) return rc;
     trace.mark("checks + tree");
     // ---- the layout on the device: plain fused stores with records (k >= 19, at most 2^21 values).  GS_BUILD_HOST=1 keeps
     // the host builder (the reference for the layout rules; striped / partition / table-only stores are always its job)
@@ -3004,6 +3019,23 @@ extern "C" int gs_dbbuild_fetch(gs_dbbuild *b, int64_t *kmers, int32_t *value_id
     }
     return GS_OK;
 }
+
+extern "C" int gs_dbbuild_to_db(gs_dbbuild *b, gs_db **out) try {
+    if (!b || !out) return fail(GS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (!b->finished) return fail(GS_E_STATE, "gs_dbbuild_finish first");
+    if (b->n_out <= 0 || b->k < GS_MIN_K || b->n_values > GS_REC_MAX_VALUES || b->n_out >= ((int64_t)1 << 31))
+        return fail(GS_E_UNSUPPORTED, "gs_dbbuild_to_db serves stores with records (k >= 19, at most 2^21 values, 1 .. 2^31 - 1 k-mers): fetch the arrays and call gs_db_create");
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<int32_t> parent, depth, tin, tout;
+    int rc = tree_arrays(b->n_values, b->parent.data(), parent, depth, tin, tout);
+    if (rc) return rc;
+    BuildTrace trace;
+    rc = db_create_on_device(out, b->device, b->k, b->n_out, b->d_out_keys, b->d_out_vals, b->n_values, parent, depth, tin, tout, trace, true);
+    if (rc == 0) return fail(GS_E_UNSUPPORTED, "gs_dbbuild_to_db: no k-mer of this build fits a record: fetch the arrays and call gs_db_create");
+    return rc < 0 ? rc : GS_OK;
+}
+GS_API_CATCH
 
 extern "C" int gs_dbbuild_destroy(gs_dbbuild *b) {
     if (b) dbbuild_free(b);

@@ -320,6 +320,10 @@ int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t *offsets, c
 int gs_dbbuild_set_range(gs_dbbuild *b, uint64_t lo, uint64_t hi);
 int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers);
 int gs_dbbuild_fetch(gs_dbbuild *b, int64_t *kmers, int32_t *value_idx);
+/* ... or straight into a store on the builder's device, without the arrays ever leaving the GPU: genomes -> gs_dbbuild_add ->
+ * gs_dbbuild_finish -> gs_dbbuild_to_db -> gs_match_begin (and gs_db_save for later processes).  Every k-mer of the build must
+ * be reachable, which it is by construction (canonical k-mers).  Stores without records: GS_E_UNSUPPORTED (fetch + gs_db_create). */
+int gs_dbbuild_to_db(gs_dbbuild *b, gs_db **out);
 int gs_dbbuild_destroy(gs_dbbuild *b);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -79,6 +79,13 @@ JNIEXPORT void JNICALL JNAME(dbBuildFetch)(JNIEnv *env, jclass c, jlong builder,
     if (rc) throw_gs(env, rc);
 }
 
+JNIEXPORT jlong JNICALL JNAME(dbBuildToDb)(JNIEnv *env, jclass c, jlong builder) {
+    gs_db *db = NULL;
+    int rc = gs_dbbuild_to_db((gs_dbbuild *)(intptr_t)builder, &db);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)db;
+}
+
 JNIEXPORT void JNICALL JNAME(dbBuildDestroy)(JNIEnv *env, jclass c, jlong builder) { gs_dbbuild_destroy((gs_dbbuild *)(intptr_t)builder); }
 
 JNIEXPORT void JNICALL JNAME(dbDestroy)(JNIEnv *env, jclass c, jlong db) { gs_db_destroy((gs_db *)(intptr_t)db); }

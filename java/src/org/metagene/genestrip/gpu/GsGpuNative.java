@@ -48,6 +48,9 @@ public final class GsGpuNative {
 	/** gs_dbbuild_fetch: kmers (n x int64 ascending, the reference's encoding) and value indices (n x int32) */
 	public static native void dbBuildFetch(long builder, ByteBuffer kmers, ByteBuffer valueIdx);
 
+	/** gs_dbbuild_to_db: the store over the built arrays, laid out on the device (returns a gs_db handle as dbCreate does) */
+	public static native long dbBuildToDb(long builder);
+
 	public static native void dbBuildDestroy(long builder);
 
 	/** gs_db_save / gs_db_load: the native image of the device store */

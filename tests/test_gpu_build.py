@@ -97,6 +97,33 @@ def test_device_build_reproduces_the_synthetic_store_and_serves_a_match():
     m.close(), store.close(), odb.close()
 
 
+def test_genomes_to_store_without_leaving_the_device():
+    """gs_dbbuild_to_db: genomes -> (k-mer, LCA) arrays -> store layout, all on the GPU; the store answers like one built from the
+    host recipe's arrays, and its file loads"""
+    import torch
+    db = synth.SynthDB(k=31, genera=3, species_per_genus=4, genome_len=40000, seed=5)
+    g = db.genomes
+    dseq = torch.from_numpy(np.ascontiguousarray(g).reshape(-1)).cuda()
+    doff = torch.arange(g.shape[0] + 1, dtype=torch.int64, device="cuda") * g.shape[1]
+    gb = ga.DeviceDbBuilder(31, db.n_values, db.parent_vi)
+    gb.add(dseq, doff, db.species_vi, update=False)
+    gb.add(dseq, doff, db.species_vi, update=True)
+    store = gb.to_store()
+    gb.close()
+    assert store.info.n_stored == len(db.kmers) and store.info.n_in_records > 0.9 * len(db.kmers)
+    rs, ro = synth.reads_host(g, 4000, read_len=150, seed=9)
+    m = ga.FastqKMerMatcher(store)
+    m.submit(rs, ro.astype(np.uint64), 0)
+    table = m.finish()[0]
+    m.close()
+    odb = orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    run = orc.MatchRun(odb)
+    run.submit(rs, ro, threads=8, per_read=False)
+    assert np.array_equal(table, run.finish()[0])
+    odb.close()
+    store.close()
+
+
 def test_build_in_kmer_ranges_equals_one_build():
     """a collection too big for one pass: one builder per range of the canonical k-mer, results one behind the other"""
     from genestrip_amd.binding import kmer_ranges
