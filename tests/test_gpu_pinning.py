@@ -226,3 +226,62 @@ def test_device_and_host_layout_builds_are_reproducible_and_answer_alike(tmp_pat
     assert images["device"] != images["host"]  # two builders, two (valid) layouts
     assert np.array_equal(tables["device"], tables["host"]) and tables["device"][:, 3].sum() > 0
     ga.DeviceKMerStore.load(tmp_path / "device_0.gss").close()  # and the loader's checks accept the device's image
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_layout_builder_on_awkward_stores(seed, monkeypatch):
+    """stores that stress the layout rules -- the same 15-mers in many contexts (more than two windows per minimizer, more than
+    eight per minimizer: the clustering cap), low-complexity sequence, tiny stores, every k from 19 to 31 -- built by the device
+    and by the host builder: reads from the same material must get identical tables (and the oracle's)"""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(19, 32))
+    n_values = int(rng.integers(1, 40))
+    parent = np.array([-1] + [int(rng.integers(0, i)) for i in range(1, n_values)], dtype=np.int32)
+    core = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 400)
+    genomes = []
+    for g in range(int(rng.integers(1, 30))):
+        L = int(rng.integers(k, 3000))
+        body = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L)
+        if L > 500 and g % 2 == 0:  # the same core in many different surroundings: one minimizer, many windows
+            for _ in range(int(rng.integers(1, 12))):
+                a = int(rng.integers(0, L - 120))
+                body[a:a + 100] = core[:100]
+                body[a + 40 + int(rng.integers(0, 20))] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8))
+        if g % 5 == 1:
+            body[:min(L, 200)] = np.frombuffer((b"AT" * 100)[:min(L, 200)], dtype=np.uint8)  # low complexity
+        genomes.append(body)
+    keys, vals = {}, {}
+    for gi, body in enumerate(genomes):
+        for x in orc.canonical_kmers(body.tobytes().decode(), k).tolist():
+            keys.setdefault(int(x), int(rng.integers(0, n_values)))
+    kk = np.array(sorted(keys), dtype=np.int64)
+    vv = np.array([keys[int(x)] for x in kk], dtype=np.int32)
+    reads = []
+    for body in genomes:
+        for _ in range(6):
+            a = int(rng.integers(0, max(1, len(body) - 60)))
+            r = body[a:a + int(rng.integers(k, 260))].copy()
+            if len(r) > 5 and rng.random() < 0.3:
+                r[int(rng.integers(0, len(r)))] = ord("N")
+            reads.append(r.tobytes() if rng.random() < 0.5 else r.tobytes()[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))
+    reads += [rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150).tobytes() for _ in range(20)]
+    seq, off = orc.pack_reads(reads)
+    odb = orc.DB(k, kk, vv, n_values, parent)
+    run = orc.MatchRun(odb)
+    wcv, wfl = run.submit(seq, off, threads=4)
+    want = run.finish()[0]
+    odb.close()
+    for how in ("device", "host"):
+        if how == "host":
+            monkeypatch.setenv("GS_BUILD_HOST", "1")
+        else:
+            monkeypatch.delenv("GS_BUILD_HOST", raising=False)
+        store = ga.DeviceKMerStore(k, kk, vv, n_values, parent)
+        assert store.info.n_stored == len(kk), how
+        m = ga.FastqKMerMatcher(store)
+        cv, fl = m.match_reads(seq, off, 0)
+        t = m.finish()[0]
+        assert np.array_equal(t, want), (how, k, len(kk), np.argwhere(t != want)[:5])
+        assert np.array_equal(cv, wcv) and np.array_equal(fl, wfl), how
+        m.close()
+        store.close()
