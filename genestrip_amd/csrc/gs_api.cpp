@@ -2768,7 +2768,7 @@ extern "C" int gs_match_merge(gs_run *const *runs, int n_runs) try {
 // DB construction on the device (gs_build.hip; include/gsgpu.h "gs_dbbuild")
 // ---------------------------------------------------------------------------------------------------
 extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
-                                            uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
+                                            int max_dust, uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
                                             u64 *n_out, hipStream_t stream);
 extern "C" hipError_t gs_build_sort(u64 *keys, u64 *keys_alt, uint32_t *vals, uint32_t *vals_alt, int64_t n, int key_bits, u64 **keys_out,
                                     uint32_t **vals_out, hipStream_t stream);
@@ -2778,7 +2778,7 @@ extern "C" hipError_t gs_launch_build_scatter(const u64 *keys, const int32_t *va
                                               int64_t *out_keys, int32_t *out_vals, hipStream_t stream);
 
 struct gs_dbbuild {
-    int device = 0, k = 0, lower = 1, step = 1;
+    int device = 0, k = 0, lower = 1, step = 1, max_dust = -1;
     int32_t n_values = 0;
     hipStream_t stream = nullptr;
     int32_t *d_tree = nullptr;  // parent | depth
@@ -2821,8 +2821,7 @@ extern "C" int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_v
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
     if (n_values < 1 || n_values > (1 << 24) || !parent_vi) return fail(GS_E_INVALID, "bad tree arrays (n_values must be in [1, 2^24])");
     if (step_size < 1) return fail(GS_E_INVALID, "stepSize must be >= 1 (C/GSConfigKey.java:236)");
-    if (max_dust >= 0)
-        return fail(GS_E_UNSUPPORTED, "maxDust >= 0 (the streaming low-complexity filter of CGATLongBuffer) is not done on the device: build on the host");
+    if (max_dust > 32767) return fail(GS_E_INVALID, "maxDust > Short.MAX_VALUE (C/util/CGATLongBuffer.java:78-80)");
     // depths by parent walks; exactly one root: TaxTree.getLowestCommonAncestor answers null for nodes of different trees
     // and the update then keeps the old value (DBGoal.java:243), which depends on the order of the regions
     std::vector<int32_t> depth((size_t)n_values, -1);
@@ -2853,6 +2852,7 @@ extern "C" int gs_dbbuild_begin(gs_dbbuild **out, int device, int k, int32_t n_v
     b->k = k;
     b->lower = lower_case_bases != 0;
     b->step = step_size;
+    b->max_dust = max_dust < 0 ? -1 : max_dust;
     b->n_values = n_values;
     b->parent.assign(parent_vi, parent_vi + n_values);
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -2924,7 +2924,7 @@ extern "C" int gs_dbbuild_add(gs_dbbuild *b, const uint8_t *seq, const uint64_t 
         b->d_vals = nv;
         b->cap = want;
     }
-    HIP_TRY(gs_launch_build_kmers(d_seq, d_off, n_regions, total, b->k, b->lower, b->step, (uint32_t)b->node_of_region.size(), update != 0,
+    HIP_TRY(gs_launch_build_kmers(d_seq, d_off, n_regions, total, b->k, b->lower, b->step, b->max_dust, (uint32_t)b->node_of_region.size(), update != 0,
                                   b->range_lo, b->range_hi, b->d_keys, b->d_vals, b->d_count, b->stream));
     u64 have = 0;
     HIP_TRY(hipMemcpyAsync(&have, b->d_count, sizeof(u64), hipMemcpyDeviceToHost, b->stream));

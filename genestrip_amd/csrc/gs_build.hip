@@ -40,6 +40,30 @@ __device__ __forceinline__ u64 gs_build_spread(uint32_t v) {
     return x;
 }
 
+// The reference's low-complexity score of a k-mer (CGATLongBuffer.getDustValue, C/util/CGATLongBuffer.java:146-229; its test
+// T/util/CGATLongBufferTest.java:280-313 states it for a window): for the periods 1, 2, 3 every maximal run of L consecutive
+// positions whose base equals the base `period` earlier adds fib(L), fib = 0, 1, 2, 3, 5, 8 ...  On planes: one mask of matches
+// per period, then a walk over its runs of ones.
+__device__ __forceinline__ int gs_build_dust(uint32_t fhi, uint32_t flo, int k) {
+    int d = 0;
+    for (int p = 1; p <= 3 && p < k; p++) {
+        uint32_t m = ~((fhi ^ (fhi >> p)) | (flo ^ (flo >> p))) & ((1u << (k - p)) - 1u);
+        while (m) {
+            m >>= __builtin_ctz(m);
+            const int len = __builtin_ctz(~m);  // (m < 2^31: a zero bit always follows)
+            int a = 1, b = 2;                   // fib(1), fib(2)
+            for (int i = 1; i < len; i++) {
+                const int c = a + b;
+                a = b;
+                b = c;
+            }
+            d += a;
+            m >>= len;
+        }
+    }
+    return d;
+}
+
 // k bits of the 128-bit string {b (high), a (low)} from bit s (s in 0..63, k <= 31)
 __device__ __forceinline__ uint32_t gs_build_funnel(u64 a, u64 b, int s, uint32_t kmask) {
     return (uint32_t)((a >> s) | ((b << 1) << (63 - s))) & kmask;
@@ -54,7 +78,7 @@ __device__ __forceinline__ uint32_t gs_build_funnel(u64 a, u64 b, int s, uint32_
 // bases [s, s + k) is taken iff all k are bases and (s + k) % stepSize == 0.  Only real pairs are written (compacted per wave).
 #define GS_BUILD_BLOCK 1024  // 16 waves: one atomic on the pair counter per workgroup and step
 __global__ __launch_bounds__(GS_BUILD_BLOCK) void gs_build_kmers_kernel(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k,
-                                                             int lower, int step, uint32_t first_region, uint32_t update_flag,
+                                                             int lower, int step, int max_dust, uint32_t first_region, uint32_t update_flag,
                                                              u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals, u64 *n_out) {
     constexpr int WAVES = GS_BUILD_BLOCK / 64;
     __shared__ uint32_t s_cnt[WAVES];
@@ -107,6 +131,7 @@ __global__ __launch_bounds__(GS_BUILD_BLOCK) void gs_build_kmers_kernel(const ui
             const u64 rev = (gs_build_spread(fhi) << 1) | gs_build_spread((flo ^ kmask) & kmask);  // complement: C<->G, A<->T, reversed
             key = fwd > rev ? fwd : rev;  // CGAT.standardKMer (:145-147)
             if (key < range_lo || key >= range_hi) key = GS_BUILD_NONE;  // (gs_dbbuild_set_range: another pass takes it)
+            if (max_dust >= 0 && key != GS_BUILD_NONE && gs_build_dust(fhi, flo, k) > max_dust) key = GS_BUILD_NONE;  // isDust(): skipped (:105-107)
         }
         // the workgroup's pairs go behind each other at the end of the pair arrays: one atomic per workgroup and step
         const u64 have = __ballot(key != GS_BUILD_NONE);
@@ -190,11 +215,11 @@ static int gs_build_tile_grid(int64_t total) {  // 16 waves per workgroup, one t
 
 // keys / vals: room for `total` more pairs behind *n_out (device counter of the pairs written so far)
 extern "C" hipError_t gs_launch_build_kmers(const uint8_t *seq, const u64 *off, int64_t n_regions, int64_t total, int k, int lower, int step,
-                                            uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
+                                            int max_dust, uint32_t first_region, int update, u64 range_lo, u64 range_hi, u64 *keys, uint32_t *vals,
                                             u64 *n_out, hipStream_t stream) {
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(gs_build_kmers_kernel, dim3(gs_build_tile_grid(total)), dim3(GS_BUILD_BLOCK), 0, stream, seq, off, n_regions, total, k, lower, step,
-                       first_region, update ? GS_BUILD_UPDATE : 0u, range_lo, range_hi, keys, vals, n_out);
+                       max_dust, first_region, update ? GS_BUILD_UPDATE : 0u, range_lo, range_hi, keys, vals, n_out);
     return hipGetLastError();
 }
 

@@ -293,8 +293,9 @@ int gs_db_load_stripe(gs_db **out, int device, int n_stripes, int stripe, const 
  * reset by any byte that is not C, G, A, T (after upper-casing a, c, g, t if lower_case_bases: GSConfigKey lowerCaseBases,
  * default on), taken when (bases of the region so far) % step_size == 0, stored as CGAT.standardKMer.
  *
- *   gs_dbbuild_begin   tree as for gs_db_create (parent_vi: -1 the ONE root, -2 no node); max_dust must be -1 (the streaming
- *                      low-complexity filter is not done on the device: GS_E_UNSUPPORTED).
+ *   gs_dbbuild_begin   tree as for gs_db_create (parent_vi: -1 the ONE root, -2 no node); max_dust = GSConfigKey maxDust (-1 off):
+ *                      k-mers whose low-complexity score (CGATLongBuffer.getDustValue, the sum of fib(run length) over the runs of
+ *                      period 1, 2 and 3 inside the k-mer) exceeds it are skipped in both passes (:105-107).
  *   gs_dbbuild_add     regions = FASTA records without their header and line ends (seq, offsets[n_regions + 1], offsets[0] = 0;
  *                      `mem` says where seq / offsets live), node_vi[n_regions] (host) = value index of each region's node
  *                      (FillDBGoal / DBGoal reworkNode: the host's mapping).  update = 0: a FillDBGoal region (its k-mers are

@@ -1115,7 +1115,7 @@ void orc_reads_free(orc_reads *r) {
  * DB construction (test infrastructure like everything in this file): FillDBGoal + DBGoal, one region after the other
  * ===================================================================================================== */
 struct orc_build {
-    int k, lower, step;
+    int k, lower, step, max_dust;
     int32_t n_values;
     int32_t *parent, *depth;
     int64_t *kmers;   /* entries in insertion order, sorted by orc_build_optimize */
@@ -1157,7 +1157,12 @@ int32_t orc_taxtree_lca(int32_t n_values, const int32_t *parent_vi, int32_t a, i
 }
 
 orc_build *orc_build_begin(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size) {
+    return orc_build_begin_dust(k, n_values, parent_vi, lower_case_bases, step_size, -1);
+}
+
+orc_build *orc_build_begin_dust(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size, int max_dust) {
     orc_build *b = (orc_build *)calloc(1, sizeof(orc_build));
+    b->max_dust = max_dust;
     b->k = k;
     b->lower = lower_case_bases;
     b->step = step_size;
@@ -1211,6 +1216,14 @@ static void build_region(orc_build *b, const uint8_t *seq, int64_t len, int32_t 
     int64_t kmer = 0, rev = 0;      /* reset(): :263-268 */
     int bp_counter = 0, filled = 0;
     int64_t bps_in_region = 0;      /* AbstractRefSeqFastaReader.java:149 */
+    /* the streaming low-complexity score (maxDust >= 0): CGATLongBuffer.java:96-110 (weights), :149-228 (put), :263-281 (reset) */
+    const int dust = b->max_dust >= 0;
+    int diff[32], srl0b[32], srl1b[32], srl2b[32];
+    int d = 0, srl0 = 0, srl1 = 0, srl2 = 0, l1 = -1, l2 = -1, l3 = -1;
+    for (int i = 0; i < 32; i++) {
+        diff[i] = i < 3 ? 1 : diff[i - 1] + diff[i - 2];
+        srl0b[i] = srl1b[i] = srl2b[i] = 0;
+    }
     const int64_t mask = k == 32 ? -1 : (((int64_t)1 << (2 * k)) - 1);
     for (int64_t i = 0; i < len; i++) {
         uint8_t c = seq[i];
@@ -1225,18 +1238,73 @@ static void build_region(orc_build *b, const uint8_t *seq, int64_t len, int32_t 
             kmer = rev = 0;
             bp_counter = 0;
             filled = 0;
+            d = srl0 = srl1 = srl2 = 0;
+            l1 = l2 = l3 = -1;
+            for (int j = 0; j < k; j++) srl0b[j] = srl1b[j] = srl2b[j] = 0;
         } else {
             kmer = ((kmer << 2) & mask) | (int64_t)bp;                                  /* :146 */
             rev = (int64_t)((uint64_t)rev >> 2) | ((int64_t)(bp ^ 1) << (2 * (k - 1)));  /* :147 */
+            if (dust) {
+                if ((int)c == l1) {  /* :149-159 */
+                    int pos = bp_counter - 1 - srl0;
+                    if (pos < 0) pos += k;
+                    srl0b[pos]++;
+                    d += diff[srl0];
+                    if (srl0 < k - 1) srl0++;
+                } else
+                    srl0 = 0;
+                if ((int)c == l2) {  /* :160-172 */
+                    int pos = bp_counter - 2 - srl1;
+                    if (pos < 0) pos += k;
+                    srl1b[pos]++;
+                    d += diff[srl1];
+                    if (srl1 < k - 2) srl1++;
+                } else
+                    srl1 = 0;
+                if ((int)c == l3) {  /* :173-185 */
+                    int pos = bp_counter - 3 - srl2;
+                    if (pos < 0) pos += k;
+                    srl2b[pos]++;
+                    d += diff[srl2];
+                    if (srl2 < k - 3) srl2++;
+                } else
+                    srl2 = 0;
+                l3 = l2;
+                l2 = l1;
+                l1 = (int)c;
+            }
+            const int old_bp = bp_counter;
             bp_counter++;                                                                /* :196-201 */
             if (bp_counter == k) {
                 bp_counter = 0;
                 filled = 1;
             }
+            if (filled && dust) {                                                        /* :202-227 */
+                int oc = srl0b[old_bp];
+                srl0b[old_bp] = 0;
+                if (oc > 0) {
+                    d -= diff[oc - 1];
+                    srl0b[bp_counter] = oc - 1;
+                }
+                oc = srl1b[old_bp];
+                srl1b[old_bp] = 0;
+                if (oc > 0) {
+                    d -= diff[oc - 1];
+                    srl1b[bp_counter] = oc - 1;
+                }
+                oc = srl2b[old_bp];
+                srl2b[old_bp] = 0;
+                if (oc > 0) {
+                    d -= diff[oc - 1];
+                    srl2b[bp_counter] = oc - 1;
+                }
+            }
         }
         bps_in_region++;                                   /* AbstractStoreFastaReader.java:102 */
-        if (bps_in_region % b->step == 0 && filled)        /* :103-104 (isDust() is false with maxDust = -1) */
+        if (bps_in_region % b->step == 0 && filled) {      /* :103-104 */
+            if (dust && d > b->max_dust) continue;         /* isDust(): dustCounter++, not stored (:105-106) */
             handle(b, kmer > rev ? kmer : rev, node);      /* getStandardKMer: CGAT.standardKMer */
+        }
     }
 }
 
@@ -1318,4 +1386,23 @@ void orc_build_destroy(orc_build *b) {
     free(b->vals);
     free(b->set);
     free(b);
+}
+
+
+/* the streaming score after the bytes of `s` (a fresh buffer of size k): CGATLongBuffer.getDustValue, for the known answers of
+ * T/util/CGATLongBufferTest.java:56-108.  -1 while the buffer is not filled... no: the reference reports d as it stands. */
+static void dust_probe_handle(orc_build *b, int64_t kmer, int32_t node) {
+    (void)kmer;
+    (void)node;
+    b->n++; /* counts the k-mers that passed */
+}
+
+int64_t orc_dust_passed(int k, int max_dust, const uint8_t *s, int64_t len) {
+    const int32_t parent[1] = {-1};
+    orc_build *b = orc_build_begin_dust(k, 1, parent, 0, 1, max_dust);
+    build_region(b, s, len, 0, dust_probe_handle);
+    const int64_t n = b->n;
+    b->n = 0;
+    orc_build_destroy(b);
+    return n;
 }

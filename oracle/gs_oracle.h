@@ -166,6 +166,10 @@ void orc_reads_free(orc_reads *r);
  *      insertion order of the reference's reader threads). ---- */
 typedef struct orc_build orc_build;
 orc_build *orc_build_begin(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size);
+/* with GSConfigKey maxDust (-1 off): k-mers whose streaming low-complexity score exceeds it are skipped (CGATLongBuffer.isDust) */
+orc_build *orc_build_begin_dust(int k, int32_t n_values, const int32_t *parent_vi, int lower_case_bases, int step_size, int max_dust);
+/* number of k-mers of `s` (one region) whose score is <= max_dust: for the known answers of T/util/CGATLongBufferTest.java */
+int64_t orc_dust_passed(int k, int max_dust, const uint8_t *s, int64_t len);
 void orc_build_fill(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions);
 int64_t orc_build_optimize(orc_build *b);  /* store.optimize(): sorted, returns the number of entries */
 void orc_build_update(orc_build *b, const uint8_t *seq, const uint64_t *offsets, const int32_t *node_vi, int64_t n_regions);

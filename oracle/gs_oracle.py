@@ -73,7 +73,9 @@ def lib():
         "orc_match_segments": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int]),
         "orc_parse_fastq": (C.POINTER(_Reads), [vp, C.c_size_t, C.c_int, C.c_int]),
         "orc_reads_free": (None, [C.POINTER(_Reads)]),
-        "orc_build_begin": (vp, [C.c_int, i32, vp, C.c_int, C.c_int]), "orc_build_fill": (None, [vp, vp, vp, vp, i64]),
+        "orc_build_begin": (vp, [C.c_int, i32, vp, C.c_int, C.c_int]),
+        "orc_build_begin_dust": (vp, [C.c_int, i32, vp, C.c_int, C.c_int, C.c_int]),
+        "orc_dust_passed": (i64, [C.c_int, C.c_int, vp, i64]), "orc_build_fill": (None, [vp, vp, vp, vp, i64]),
         "orc_build_optimize": (i64, [vp]), "orc_build_update": (None, [vp, vp, vp, vp, i64]),
         "orc_build_fetch": (None, [vp, vp, vp]), "orc_build_destroy": (None, [vp]),
         "orc_taxtree_lca": (i32, [i32, vp, i32, i32]),
@@ -359,13 +361,26 @@ def taxtree_lca(parent_vi, a, b):
     return int(lib().orc_taxtree_lca(len(pv), _p(pv), int(a), int(b)))
 
 
+def dust_value(kmer):
+    """CGATLongBuffer.getDustValue of a buffer of len(kmer) filled with kmer (streaming restatement, probed through the filter)"""
+    s = _seq(kmer)
+    lo, hi = -1, 1 << 22  # the smallest max_dust that lets the k-mer pass is its score
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if lib().orc_dust_passed(len(s), mid, _p(s), len(s)) == 1:
+            hi = mid
+        else:
+            lo = mid
+    return hi
+
+
 class DbBuild:
     """FillDBGoal + store.optimize + DBGoal, one region after the other (the CPU restatement the device build is checked
     against): fill(regions) ..., optimize(), update(regions) ..., fetch() -> (kmers ascending, value_idx)"""
 
-    def __init__(self, k, n_values, parent_vi, lower_case_bases=True, step_size=1):
+    def __init__(self, k, n_values, parent_vi, lower_case_bases=True, step_size=1, max_dust=-1):
         pv = np.ascontiguousarray(parent_vi, dtype=np.int32)
-        self.h = C.c_void_p(lib().orc_build_begin(k, n_values, _p(pv), int(lower_case_bases), step_size))
+        self.h = C.c_void_p(lib().orc_build_begin_dust(k, n_values, _p(pv), int(lower_case_bases), step_size, max_dust))
         self.n = 0
 
     def _regions(self, seq, offsets, node_vi):

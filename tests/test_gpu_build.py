@@ -24,10 +24,10 @@ def _pack(parts):
     return seq, np.cumsum([0] + [len(s) for s in parts]).astype(np.uint64)
 
 
-def _both(k, fill, update, parent, lower=True, step=1, batches=1):
+def _both(k, fill, update, parent, lower=True, step=1, batches=1, max_dust=-1):
     """fill / update: lists of (bytes, node).  -> (device arrays, oracle arrays)"""
-    ob = orc.DbBuild(k, len(parent), parent, lower, step)
-    gb = ga.DeviceDbBuilder(k, len(parent), parent, lower_case_bases=lower, step_size=step)
+    ob = orc.DbBuild(k, len(parent), parent, lower, step, max_dust)
+    gb = ga.DeviceDbBuilder(k, len(parent), parent, lower_case_bases=lower, step_size=step, max_dust=max_dust)
     for upd, regions in ((False, fill), (True, update)):
         if upd:
             ob.optimize()
@@ -70,6 +70,27 @@ def test_device_build_equals_the_restatement_on_noisy_regions(k, lower, step, ba
     # fill only (no DBGoal pass): the first region's node stays
     (gk, gv), (wk, wv) = _both(k, fill, [], PARENT, lower, step, batches)
     assert np.array_equal(gk, wk) and np.array_equal(gv, wv)
+
+
+@pytest.mark.parametrize("k,max_dust", [(31, 0), (31, 20), (31, 500), (21, 8), (5, 2), (3, 1)])
+def test_low_complexity_filter_on_the_device(k, max_dust):
+    """maxDust: k-mers whose score (sum of fib(run length) over the runs of period 1, 2, 3) exceeds it are skipped in both passes;
+    the device scores a k-mer from its planes, the restatement streams like CGATLongBuffer"""
+    rng = np.random.default_rng(7 * k + max_dust)
+    fill = []
+    for r in range(40):
+        parts = []
+        for _ in range(12):
+            parts.append(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(1, 120))).tobytes())
+            unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(rng.integers(1, 4))).tobytes()
+            parts.append((unit * 60)[:int(rng.integers(0, 90))])
+            if rng.random() < 0.2:
+                parts.append(b"N")
+        fill.append((b"".join(parts), int(rng.integers(0, 7))))
+    (gk, gv), (wk, wv) = _both(k, fill, fill[::2], PARENT, True, 1, 2, max_dust)
+    assert np.array_equal(gk, wk) and np.array_equal(gv, wv), (len(gk), len(wk))
+    (nk, _), _ = _both(k, fill, [], PARENT, True, 1, 1, -1)
+    assert len(gk) < len(nk)  # the filter took something out
 
 
 def test_device_build_reproduces_the_synthetic_store_and_serves_a_match():
@@ -168,8 +189,8 @@ def test_device_build_from_device_memory_and_the_dengue_fixture():
 
 def test_device_build_argument_errors():
     with pytest.raises(ga.GsError) as e:
-        ga.DeviceDbBuilder(31, 7, PARENT, max_dust=20)  # the streaming dust filter stays on the host
-    assert e.value.code == -4
+        ga.DeviceDbBuilder(31, 7, PARENT, max_dust=40000)  # beyond Short.MAX_VALUE: the reference refuses it too
+    assert e.value.code == -1
     with pytest.raises(ga.GsError) as e:
         ga.DeviceDbBuilder(31, 3, np.array([-1, -1, 0], np.int32))  # two roots
     assert e.value.code == -4

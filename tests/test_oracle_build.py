@@ -36,7 +36,51 @@ def test_taxtree_lca_known_answers():
             assert orc.taxtree_lca(PARENT, a, b) == want
 
 
-def _py_build(k, regions, parent, lower=True, step=1):
+FIB = [0, 1, 2]
+for _i in range(3, 40):
+    FIB.append(FIB[-1] + FIB[-2])
+
+
+def _naive_dust(w):
+    """the window form of the low-complexity score as T/util/CGATLongBufferTest.java:280-313 states it"""
+    d, srl, last = 0, [0, 0, 0], [None, None, None]
+    for ch in w:
+        for p in range(3):
+            if ch == last[p]:
+                srl[p] += 1
+            else:
+                d += FIB[srl[p]]
+                srl[p] = 0
+        last = [ch, last[0], last[1]]
+    return d + FIB[srl[0]] + FIB[srl[1]] + FIB[srl[2]]
+
+
+def test_dust_known_answers_and_the_window_form():
+    """T/util/CGATLongBufferTest.java:56-108 (known answers) and :119-145 (the streaming score equals the window form on every
+    window of a random sequence, also right after a reset by a non-base)"""
+    assert orc.dust_value("TTTCGCGA") == FIB[2] + FIB[1] + FIB[2]
+    assert [orc.dust_value(x) for x in ("ACAT", "AAAT", "AAAA", "ACAA")] == [FIB[1], FIB[2] + FIB[1], FIB[3] + FIB[2] + FIB[1], 3 * FIB[1]]
+    assert [orc.dust_value(x) for x in ("ACATA", "AAAAA", "AATAA", "TATAT")] == [2 * FIB[1], FIB[4] + FIB[3] + FIB[2], 3 * FIB[1] + FIB[2], FIB[3]]
+    assert orc.dust_value("AC" * 15 + "A") == FIB[29] and orc.dust_value("GC" * 15 + "G") == FIB[29]
+    assert orc.dust_value("C" * 31) == FIB[30] + FIB[29] + FIB[28] == orc.dust_value("T" * 31)
+    rng = np.random.default_rng(10)
+    for k in (4, 9, 31):
+        # sequences with long runs and short periods, cut by N: every window's k-mer passes the filter iff its window score does
+        parts = []
+        for _ in range(30):
+            parts.append(rng.choice(list("ACGT"), int(rng.integers(1, 60))))
+            unit = "".join(rng.choice(list("ACGT"), int(rng.integers(1, 4))))
+            parts.append(list((unit * 40)[:int(rng.integers(0, 50))]))
+            if rng.random() < 0.3:
+                parts.append(["N"])
+        s = "".join("".join(p) for p in parts)
+        for max_dust in (0, 3, 12, 100):
+            want = sum(1 for i in range(len(s) - k + 1) if "N" not in s[i:i + k] and _naive_dust(s[i:i + k]) <= max_dust)
+            got = orc.lib().orc_dust_passed(k, max_dust, orc._p(orc._seq(s)), len(s))
+            assert got == want, (k, max_dust)
+
+
+def _py_build(k, regions, parent, lower=True, step=1, max_dust=-1):
     """dictionary form of FillDBGoal + DBGoal: regions = [(bytes, node, is_update)] in order"""
     comp = {"C": "G", "G": "C", "A": "T", "T": "A"}
     code = {"C": 0, "G": 1, "A": 2, "T": 3}
@@ -64,7 +108,7 @@ def _py_build(k, regions, parent, lower=True, step=1):
             s = "".join({"a": "A", "c": "C", "g": "G", "t": "T"}.get(ch, ch) for ch in s)
         for i in range(len(s) - k + 1):
             w = s[i:i + k]
-            if (i + k) % step == 0 and all(ch in code for ch in w):
+            if (i + k) % step == 0 and all(ch in code for ch in w) and (max_dust < 0 or _naive_dust(w) <= max_dust):
                 yield max(enc(w), enc("".join(comp[ch] for ch in reversed(w))))
 
     store = {}
@@ -83,8 +127,8 @@ def _py_build(k, regions, parent, lower=True, step=1):
     return keys, np.array([store[x] for x in keys], dtype=np.int32)
 
 
-def _orc_build(k, regions, parent, lower=True, step=1):
-    b = orc.DbBuild(k, len(parent), parent, lower, step)
+def _orc_build(k, regions, parent, lower=True, step=1, max_dust=-1):
+    b = orc.DbBuild(k, len(parent), parent, lower, step, max_dust)
     for upd in (False, True):
         part = [(s, n) for s, n, u in regions if u == upd]
         if upd:
@@ -98,8 +142,9 @@ def _orc_build(k, regions, parent, lower=True, step=1):
     return out
 
 
-@pytest.mark.parametrize("k,lower,step", [(5, True, 1), (5, False, 1), (7, True, 3), (31, True, 1), (2, True, 1)])
-def test_build_restatement_equals_the_dictionary_form(k, lower, step):
+@pytest.mark.parametrize("k,lower,step,max_dust", [(5, True, 1, -1), (5, False, 1, -1), (7, True, 3, -1), (31, True, 1, -1), (2, True, 1, -1),
+                                                   (9, True, 1, 6), (31, True, 1, 20), (7, True, 2, 5)])
+def test_build_restatement_equals_the_dictionary_form(k, lower, step, max_dust):
     rng = np.random.default_rng(k * 31 + step)
     alphabet = np.frombuffer(b"ACGTacgtN\r", dtype=np.uint8)
     p = np.array([0.23, 0.23, 0.23, 0.23, 0.02, 0.02, 0.01, 0.01, 0.015, 0.005])
@@ -110,13 +155,17 @@ def test_build_restatement_equals_the_dictionary_form(k, lower, step):
         if r % 3 == 0 and len(body) > 120:  # shared material: the same k-mers under different nodes
             a = int(rng.integers(0, 250))
             body[20:120] = core[a:a + 100]
+        if r % 4 == 1 and len(body) > 200:  # low complexity
+            body[130:190] = (b"AT" * 30) if r % 8 == 1 else (b"A" * 60)
         regions.append((bytes(body), int(rng.integers(0, 7)), False))
     regions += [(s, n, True) for s, n, _ in regions]
     regions += [(core[50:350], 6, True), (b"", 3, True), (b"ACG", 2, False)]
-    wk, wv = _py_build(k, regions, PARENT, lower, step)
-    gk, gv = _orc_build(k, regions, PARENT, lower, step)
+    wk, wv = _py_build(k, regions, PARENT, lower, step, max_dust)
+    gk, gv = _orc_build(k, regions, PARENT, lower, step, max_dust)
     assert np.array_equal(wk, gk) and np.array_equal(wv, gv)
     assert len(wk) > 50 or k == 2
+    if max_dust >= 0:  # the filter did take something out
+        assert len(wk) < len(_py_build(k, regions, PARENT, lower, step, -1)[0])
 
 
 def test_first_region_wins_without_an_update_pass_and_update_only_touches_stored_kmers():
