@@ -3,6 +3,7 @@
 // GS_E_NODEVICE / GS_E_HIP otherwise.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1426,19 +1427,42 @@ struct GsStoreFileHeader {
 // two running 64-bit sums over the payload's 32-bit words (Fletcher style): position sensitive, one pass
 struct StoreChecksum {
     uint64_t a = 1, b = 0;
+    // a and b after the words of [p, p + bytes): slices are summed by all cores with a = b = 0 -- S = sum of the words, T = sum
+    // of their prefix sums -- and chained: a' = a + S, b' = b + n * a + T (the same numbers as the word-by-word loop, mod 2^64)
     void add(const void *p, size_t bytes) {
         const uint32_t *w = (const uint32_t *)p;
-        for (size_t i = 0; i < bytes / 4; i++) {
-            a += w[i];
-            b += a;
+        const size_t n = bytes / 4;
+        int n_thr = n < ((size_t)1 << 22) ? 1 : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        std::vector<uint64_t> S((size_t)n_thr, 0), T((size_t)n_thr, 0);
+        auto part = [&](int t) {
+            const size_t lo = n * (size_t)t / (size_t)n_thr, hi = n * ((size_t)t + 1) / (size_t)n_thr;
+            uint64_t sa = 0, sb = 0;
+            for (size_t i = lo; i < hi; i++) {
+                sa += w[i];
+                sb += sa;
+            }
+            S[(size_t)t] = sa;
+            T[(size_t)t] = sb;
+        };
+        if (n_thr == 1)
+            part(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(part, t);
+            for (auto &x : th) x.join();
+        }
+        for (int t = 0; t < n_thr; t++) {
+            const size_t lo = n * (size_t)t / (size_t)n_thr, hi = n * ((size_t)t + 1) / (size_t)n_thr;
+            b += (uint64_t)(hi - lo) * a + T[(size_t)t];
+            a += S[(size_t)t];
         }
     }
     uint64_t value() const { return a ^ (b << 1) ^ (b >> 63); }
 };
 
 // what the kernels index with: every field of a store image that came from a file is checked before it reaches HBM
-static const char *store_image_defect(const GsStoreFileHeader &h, const std::vector<u64> &table, const std::vector<u64> &rec,
-                                      const std::vector<int32_t> &tree) {
+template <typename Words>
+static const char *store_image_defect(const GsStoreFileHeader &h, const Words &table, const Words &rec, const std::vector<int32_t> &tree) {
     const gs_db_info &in = h.info;
     if (in.k < 1 || in.k > 31) return "k outside [1, 31]";
     if (in.n_values < 1 || in.n_values > (1 << 24)) return "n_values outside [1, 2^24]";
@@ -1467,29 +1491,52 @@ static const char *store_image_defect(const GsStoreFileHeader &h, const std::vec
         } else if (depth[v] != 0)
             return "tree: root with a depth";
     }
+    // the slots and the record lines on all cores (slices; the first defect of the lowest slice is reported)
     const u64 vmask = ((u64)1 << h.vbits) - 1;
-    int64_t stored = 0;
-    for (size_t i = 0; i < table.size(); i++) {
-        const u64 s = table[i];
-        if (s == 0) continue;
-        const u64 v1 = (s >> 1) & vmask;
-        if (v1 == 0 || v1 > (u64)nv || parent[v1 - 1] == -2) return "table: slot value without a tree node";
-        if (s & 1) return "table: seen bit set in a stored image";
-        stored++;
-    }
-    int64_t in_records = 0;
     const int c_off = in.k - GS_MIN_L;
-    for (size_t b = 0; b < rec.size() / GS_REC_WORDS; b++) {
-        const u64 *rp = rec.data() + b * GS_REC_WORDS;
-        if (rp[0] >> GS_REC_WIN_BITS) return "records: seen bit set in a stored image";
-        uint32_t valid = (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
-        if (valid >> (c_off + 1)) return "records: k-mer offset beyond the window";
-        for (; valid; valid &= valid - 1) {
-            const int j = __builtin_ctz(valid);
-            const u64 vi = (rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1);
-            if (vi >= (u64)nv || parent[vi] == -2) return "records: value without a tree node";
-            in_records++;
+    const size_t n_lines = rec.size() / GS_REC_WORDS;
+    const int n_thr = (table.size() + rec.size()) < ((size_t)1 << 22) ? 1 : (int)std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    std::vector<int64_t> c_stored((size_t)n_thr, 0), c_rec((size_t)n_thr, 0);
+    std::vector<const char *> why((size_t)n_thr, nullptr);
+    auto part = [&](int t) {
+        const char *bad = nullptr;
+        int64_t st = 0, ir = 0;
+        for (size_t i = table.size() * (size_t)t / (size_t)n_thr, e = table.size() * ((size_t)t + 1) / (size_t)n_thr; i < e && !bad; i++) {
+            const u64 s = table[i];
+            if (s == 0) continue;
+            const u64 v1 = (s >> 1) & vmask;
+            if (v1 == 0 || v1 > (u64)nv || parent[v1 - 1] == -2) bad = "table: slot value without a tree node";
+            else if (s & 1) bad = "table: seen bit set in a stored image";
+            st++;
         }
+        for (size_t b = n_lines * (size_t)t / (size_t)n_thr, e = n_lines * ((size_t)t + 1) / (size_t)n_thr; b < e && !bad; b++) {
+            const u64 *rp = rec.data() + b * GS_REC_WORDS;
+            if (rp[0] >> GS_REC_WIN_BITS) bad = "records: seen bit set in a stored image";
+            uint32_t valid = (uint32_t)(rp[1] >> GS_REC_WIN_BITS);
+            if (!bad && (valid >> (c_off + 1))) bad = "records: k-mer offset beyond the window";
+            for (; valid && !bad; valid &= valid - 1) {
+                const int j = __builtin_ctz(valid);
+                const u64 vi = (rp[2 + j / 3] >> (GS_REC_VAL_BITS * (j % 3))) & (GS_REC_MAX_VALUES - 1);
+                if (vi >= (u64)nv || parent[vi] == -2) bad = "records: value without a tree node";
+                ir++;
+            }
+        }
+        c_stored[(size_t)t] = st;
+        c_rec[(size_t)t] = ir;
+        why[(size_t)t] = bad;
+    };
+    if (n_thr == 1)
+        part(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_thr; t++) th.emplace_back(part, t);
+        for (auto &x : th) x.join();
+    }
+    int64_t stored = 0, in_records = 0;
+    for (int t = 0; t < n_thr; t++) {
+        if (why[(size_t)t]) return why[(size_t)t];
+        stored += c_stored[(size_t)t];
+        in_records += c_rec[(size_t)t];
     }
     if (in_records != in.n_in_records) return "records: entry count disagrees with the header";
     if (stored + in_records != in.n_stored) return "table: entry count disagrees with the header";
@@ -1510,8 +1557,10 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     h.mgate_words = db->d_mgate ? (uint64_t)1 << db->dev.mgate_bits : 0;
     h.rec_buckets = (uint64_t)db->n_rec;
     const size_t nv = (size_t)db->info.n_values;
-    std::vector<u64> table((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
-    std::vector<u64> rec((size_t)h.rec_buckets * GS_REC_WORDS);
+    Zeroed<u64> table, rec;  // (untouched pages: the copy from the device is the first to touch them)
+    table.reset((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET);
+    rec.reset((size_t)h.rec_buckets * GS_REC_WORDS);
+    std::vector<u64> gate((size_t)h.gate_words);
     if (!rec.empty()) HIP_TRY(hipMemcpy(rec.data(), db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
     std::vector<uint32_t> mgate((size_t)h.mgate_words);
     std::vector<int32_t> tree(4 * nv);
@@ -1530,11 +1579,38 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     }
     FILE *f = fopen(path, "wb");
     if (!f) return fail(GS_E_IO, std::string("cannot open ") + path);
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(table.data(), sizeof(u64), table.size(), f) == table.size() &&
-              fwrite(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
-              fwrite(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
-              fwrite(rec.data(), sizeof(u64), rec.size(), f) == rec.size() &&
-              fwrite(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fflush(f) == 0;
+    // the payload with several threads (pwrite), as gs_db_load reads it
+    const int fd = fileno(f);
+    off_t at = (off_t)sizeof(h);
+    auto par_write = [&](const void *src, size_t bytes) {
+        const int n_thr = bytes < ((size_t)64 << 20) ? 1 : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        std::atomic<bool> good{true};
+        auto part = [&](int t) {
+            size_t lo = bytes * (size_t)t / (size_t)n_thr;
+            const size_t hi = bytes * ((size_t)t + 1) / (size_t)n_thr;
+            while (lo < hi) {
+                const ssize_t r = pwrite(fd, (const char *)src + lo, std::min<size_t>(hi - lo, (size_t)1 << 30), at + (off_t)lo);
+                if (r <= 0) {
+                    good = false;
+                    return;
+                }
+                lo += (size_t)r;
+            }
+        };
+        if (n_thr == 1)
+            part(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(part, t);
+            for (auto &x : th) x.join();
+        }
+        at += (off_t)bytes;
+        return good.load();
+    };
+    ok = ok && par_write(table.data(), table.size() * sizeof(u64)) && par_write(gate.data(), gate.size() * sizeof(u64)) &&
+         par_write(mgate.data(), mgate.size() * sizeof(uint32_t)) && par_write(rec.data(), rec.size() * sizeof(u64)) &&
+         par_write(tree.data(), tree.size() * sizeof(int32_t));
     ok = (fclose(f) == 0) && ok;
     return ok ? GS_OK : fail(GS_E_IO, std::string("short write to ") + path);
 } catch (const std::bad_alloc &) {
@@ -1566,15 +1642,44 @@ static int db_load_impl(gs_db **out, int device, const char *path, int stripes, 
             return fail(GS_E_INVALID, std::string(path) + ": file size does not match its header (truncated or damaged)");
         }
     }
-    std::vector<u64> table((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET), gate((size_t)h.gate_words);
+    // (the big arrays as untouched pages: the reading threads are the first to touch them)
+    Zeroed<u64> table, rec;
+    table.reset((size_t)h.info.n_buckets * GS_SLOTS_PER_BUCKET);
+    rec.reset((size_t)h.rec_buckets * GS_REC_WORDS);
+    std::vector<u64> gate((size_t)h.gate_words);
     std::vector<uint32_t> mgate((size_t)h.mgate_words);
-    std::vector<u64> rec((size_t)h.rec_buckets * GS_REC_WORDS);
     std::vector<int32_t> tree(4 * nv);
-    const bool ok = fread(table.data(), sizeof(u64), table.size(), f) == table.size() &&
-                    fread(gate.data(), sizeof(u64), gate.size(), f) == gate.size() &&
-                    fread(mgate.data(), sizeof(uint32_t), mgate.size(), f) == mgate.size() &&
-                    fread(rec.data(), sizeof(u64), rec.size(), f) == rec.size() &&
-                    fread(tree.data(), sizeof(int32_t), tree.size(), f) == tree.size();
+    // the payload with several threads (pread): one thread copies a page-cached file at 2-3 GB/s, a big store has 10 GB
+    const int fd = fileno(f);
+    off_t at = (off_t)sizeof(h);
+    auto par_read = [&](void *dst, size_t bytes) {
+        const int n_thr = bytes < ((size_t)64 << 20) ? 1 : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        std::atomic<bool> good{true};
+        auto part = [&](int t) {
+            size_t lo = bytes * (size_t)t / (size_t)n_thr;
+            const size_t hi = bytes * ((size_t)t + 1) / (size_t)n_thr;
+            while (lo < hi) {
+                const ssize_t r = pread(fd, (char *)dst + lo, std::min<size_t>(hi - lo, (size_t)1 << 30), at + (off_t)lo);
+                if (r <= 0) {
+                    good = false;
+                    return;
+                }
+                lo += (size_t)r;
+            }
+        };
+        if (n_thr == 1)
+            part(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(part, t);
+            for (auto &x : th) x.join();
+        }
+        at += (off_t)bytes;
+        return good.load();
+    };
+    const bool ok = par_read(table.data(), table.size() * sizeof(u64)) && par_read(gate.data(), gate.size() * sizeof(u64)) &&
+                    par_read(mgate.data(), mgate.size() * sizeof(uint32_t)) && par_read(rec.data(), rec.size() * sizeof(u64)) &&
+                    par_read(tree.data(), tree.size() * sizeof(int32_t));
     fclose(f);
     if (!ok) return fail(GS_E_INVALID, std::string(path) + " is truncated");
     {
