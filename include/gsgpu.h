@@ -67,6 +67,11 @@ int gs_device_count(int *n);
  *                            C/store/Database.java:136-143).  Every tree node has a value index
  *                            (Database.initStoreIndices, C/store/Database.java:107-128).
  *                            NULL => no tree (classification must be off); every value is a node.
+ *
+ * The device layout (super-k-mer records, overflow table, minimizer gate: genestrip_amd/csrc/gs_layout.h) is laid out ON the
+ * device for stores with records (k >= 19, at most 2^21 values): 473 M k-mers in under a second, the same bytes from the same
+ * arrays every time (runs on separately built replicas stay mergeable).  GS_BUILD_HOST=1 selects the host builder, which also
+ * serves the other stores.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct gs_db gs_db;
 
