@@ -202,6 +202,7 @@ static int bits_for(u64 v) {
 static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                           int32_t n_values, const int32_t *parent_vi, int n_parts, int part, bool fused, int stripes = 1,
                           const int *stripe_devices = nullptr, int stripe_only = -1);
+static int db_self_check(gs_db *db);
 
 extern "C" int gs_db_create(gs_db **out, int device, int k, int64_t n, const int64_t *kmers, const int32_t *vidx,
                             int32_t n_values, const int32_t *parent_vi) try {
@@ -855,6 +856,15 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         if (const char *e = getenv("GS_RECORDS")) on_device = on_device && atoi(e) != 0;
         if (on_device && stripes <= 1) {
             const int drc = db_create_on_device(out, device, k, n, kmers, vidx, n_values, parent, depth, tin, tout, trace);
+            if (drc == 1 && getenv("GS_BUILD_VERIFY") != nullptr && atoi(getenv("GS_BUILD_VERIFY")) != 0) {
+                // developer aid: the image through the checks gs_db_load applies to a store file
+                const int vrc = db_self_check(*out);
+                if (vrc) {
+                    db_free(*out);
+                    *out = nullptr;
+                    return vrc;
+                }
+            }
             if (drc != 0) return drc < 0 ? drc : GS_OK;
         } else if (on_device) {
             // a striped store: the layout on one device (the first stripe's, or this process's), its image to the host, the
@@ -1541,6 +1551,28 @@ static const char *store_image_defect(const GsStoreFileHeader &h, const Words &t
     if (in_records != in.n_in_records) return "records: entry count disagrees with the header";
     if (stored + in_records != in.n_stored) return "table: entry count disagrees with the header";
     return nullptr;
+}
+
+// the store's image back to the host and through store_image_defect (GS_BUILD_VERIFY=1: after every device build)
+static int db_self_check(gs_db *db) {
+    GsStoreFileHeader h{};
+    h.info = db->info;
+    h.bucket_bits = db->dev.bucket_bits;
+    h.vbits = db->dev.vbits;
+    h.gate_words = db->d_gate ? db->dev.gate_mask + 1 : 0;
+    h.mgate_words = db->d_mgate ? (uint64_t)1 << db->dev.mgate_bits : 0;
+    h.rec_buckets = (uint64_t)db->n_rec;
+    const size_t nv = (size_t)db->info.n_values;
+    Zeroed<u64> table, rec;
+    table.reset((size_t)db->info.n_buckets * GS_SLOTS_PER_BUCKET);
+    rec.reset((size_t)h.rec_buckets * GS_REC_WORDS);
+    std::vector<int32_t> tree(4 * nv);
+    HIP_TRY(hipMemcpy(table.data(), db->d_table, table.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    if (!rec.empty()) HIP_TRY(hipMemcpy(rec.data(), db->d_rec, rec.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tree.data(), db->d_tree, tree.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (const char *why = store_image_defect(h, table, rec, tree)) return fail(GS_E_HIP, std::string("GS_BUILD_VERIFY: the device-built store fails the image checks: ") + why);
+    if (db->info.n_stored > db->info.n_entries) return fail(GS_E_HIP, "GS_BUILD_VERIFY: more k-mers stored than handed in");
+    return GS_OK;
 }
 
 extern "C" int gs_db_save(gs_db *db, const char *path) try {
