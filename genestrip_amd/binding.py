@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
     "gs_pinned_alloc", "gs_pinned_free",
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
-    "gs_bloom_create", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
+    "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
 
@@ -142,7 +142,9 @@ def lib():
         "gs_filter_text_wait_copy": (ci, [vp, i64]), "gs_filter_text_status": (ci, [vp, vp, vp, vp]),
         "gs_filter_text_reset": (ci, [vp, ci]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
-        "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
+        "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]),
+        "gs_bloom_build": (ci, [vp, ci, ci, vp, i64, ci, i64, C.c_double]),
+        "gs_bloom_get": (ci, [vp, vp, vp, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
         "gs_filter_kernel_time": (ci, [vp, vp, vp]),
     }
@@ -670,6 +672,28 @@ class DeviceBloomFilter:
         self.h = C.c_void_p()
         _check(lib().gs_bloom_create(C.byref(self.h), device, kind, bits, n_hashes, hf.ctypes.data_as(C.c_void_p),
                                      w.ctypes.data_as(C.c_void_p), len(w)))
+
+    @classmethod
+    def build(cls, kmers, expected_insertions=None, fpp=1e-8, device=0):
+        """gs_bloom_build: the XOR index filter over `kmers` (numpy int64 or a device tensor), sized like the reference's
+        (BloomIndexGoal: indexBloomFilterFpp, default 1e-8) and filled on the device"""
+        pk, mem = _ptr(kmers)
+        n = int(kmers.shape[0] if hasattr(kmers, "shape") else len(kmers))
+        _ready(kmers)
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        _check(lib().gs_bloom_build(C.byref(self.h), device, BLOOM_XOR, pk, n, mem, int(expected_insertions or max(n, 1)), float(fpp)))
+        return self
+
+    def get(self, with_words=True):
+        """-> (bits, hash_factors int64[], words uint64[] or None)"""
+        bits, nh = C.c_int64(0), C.c_int32(0)
+        _check(lib().gs_bloom_get(self.h, C.byref(bits), C.byref(nh), None, None, 0))
+        hf = np.zeros(nh.value, dtype=np.int64)
+        words = np.zeros((bits.value + 63) // 64, dtype=np.uint64) if with_words else None
+        _check(lib().gs_bloom_get(self.h, None, None, hf.ctypes.data_as(C.c_void_p),
+                                  None if words is None else words.ctypes.data_as(C.c_void_p), 0 if words is None else len(words)))
+        return bits.value, hf, words
 
     def close(self):
         if getattr(self, "h", None):

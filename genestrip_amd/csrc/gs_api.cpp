@@ -3605,6 +3605,91 @@ extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bit
     return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
+extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, u64 *words,
+                                              hipStream_t stream);
+
+// java.util.Random (the hash factors of the reference's filters are its first nextLong() values for seed 42,
+// C/bloom/AbstractKMerBloomFilter.java:78,105-109)
+struct JavaRandom {
+    uint64_t s;
+    explicit JavaRandom(int64_t seed) : s(((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1)) {}
+    int32_t next(int bits) {
+        s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        return (int32_t)(int64_t)(s >> (48 - bits));
+    }
+    int64_t next_long() {
+        const int64_t hi = (int64_t)next(32), lo = (int64_t)next(32);
+        return (int64_t)(((uint64_t)hi << 32) + (uint64_t)lo);
+    }
+};
+
+extern "C" int gs_bloom_build(gs_bloom **out, int device, int kind, const int64_t *kmers, int64_t n_kmers, int mem, int64_t expected_insertions,
+                              double fpp) try {
+    if (!out) return fail(GS_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (kind != GS_BLOOM_XOR) return fail(GS_E_UNSUPPORTED, "gs_bloom_build makes XOR filters (the reference's index filter); others: gs_bloom_create");
+    if (n_kmers < 0 || (n_kmers > 0 && !kmers) || expected_insertions < 1 || !(fpp > 0.0 && fpp < 1.0)) return fail(GS_E_INVALID, "bad argument");
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    // AbstractKMerBloomFilter.optimalNumOfBits :183-185, optimalNumOfHashFunctions :172-174 (Java double arithmetic)
+    const double dbits = -(double)expected_insertions * std::log(fpp) / (std::log(2.0) * std::log(2.0));
+    int64_t bits = (int64_t)dbits;
+    if (bits < 1) bits = 1;
+    if (bits > ((int64_t)1 << 37)) return fail(GS_E_UNSUPPORTED, "filters above 2^37 bits (16 GiB) are not supported");
+    int64_t nh = (int64_t)std::floor((double)bits / (double)expected_insertions * std::log(2.0) + 0.5);  // Math.round
+    if (nh < 1) nh = 1;
+    if (nh > 64) return fail(GS_E_UNSUPPORTED, "more than 64 hash functions");
+    std::vector<int64_t> factors((size_t)nh);
+    JavaRandom rnd(42);
+    for (int64_t i = 0; i < nh; i++) factors[(size_t)i] = rnd.next_long();
+    int rc = use_device(device);
+    if (rc) return rc;
+    gs_bloom *b = new gs_bloom();
+    b->device = device;
+    b->kind = kind;
+    b->bits = bits;
+    b->n_hashes = (int32_t)nh;
+    b->n_words = (bits + 63) / 64;
+    hipDeviceProp_t prop;
+    int64_t *d_keys = nullptr;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) b->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_words, sizeof(u64) * (size_t)b->n_words);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_factors, sizeof(int64_t) * (size_t)nh);
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_words, 0, sizeof(u64) * (size_t)b->n_words, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->d_factors, factors.data(), sizeof(int64_t) * (size_t)nh, hipMemcpyHostToDevice, b->stream);
+    const int64_t *keys = kmers;
+    if (e == hipSuccess && mem == GS_MEM_HOST && n_kmers > 0) {
+        e = hipMalloc((void **)&d_keys, sizeof(int64_t) * (size_t)n_kmers);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_keys, kmers, sizeof(int64_t) * (size_t)n_kmers, hipMemcpyHostToDevice, b->stream);
+        keys = d_keys;
+    }
+    if (e == hipSuccess) e = gs_launch_bloom_xor_put(keys, n_kmers, bits, b->d_factors, (int)nh, b->d_words, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    hipFree(d_keys);
+    if (e != hipSuccess) {
+        gs_bloom_destroy(b);
+        return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_bloom_build: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return GS_OK;
+}
+GS_API_CATCH
+
+// geometry and contents of a filter (tests, and hosts that keep the filter in the reference's own object): words may be NULL
+extern "C" int gs_bloom_get(gs_bloom *b, int64_t *bits, int32_t *n_hashes, int64_t *hash_factors, uint64_t *words, int64_t n_words) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    if (bits) *bits = b->bits;
+    if (n_hashes) *n_hashes = b->n_hashes;
+    if (hash_factors) HIP_TRY(hipMemcpy(hash_factors, b->d_factors, sizeof(int64_t) * (size_t)b->n_hashes, hipMemcpyDeviceToHost));
+    if (words) {
+        if (n_words < b->n_words) return fail(GS_E_INVALID, "words is shorter than the filter");
+        HIP_TRY(hipMemcpy(words, b->d_words, sizeof(u64) * (size_t)b->n_words, hipMemcpyDeviceToHost));
+    }
+    return GS_OK;
+}
+
 extern "C" int gs_bloom_destroy(gs_bloom *b) {
     if (!b) return GS_OK;
     hipSetDevice(b->device);

@@ -279,3 +279,27 @@ extern "C" hipError_t gs_launch_build_scatter(const u64 *keys, const int32_t *va
     hipLaunchKernelGGL(gs_build_scatter_kernel, dim3(gs_build_grid(n)), dim3(256), 0, stream, keys, value, flag, pos, n, out_keys, out_vals);
     return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Index filter construction (BloomIndexGoal, C/goals/refseq/BloomIndexGoal.java:66-113): AbstractKMerBloomFilter.putLong
+// (C/bloom/AbstractKMerBloomFilter.java:196-203) of every k-mer with the XOR hashes (C/bloom/XORKMerBloomFilter.java:43-59):
+// bit abs((factor_i ^ kmer) % bits) for every hash i.  One thread per (k-mer, hash).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_bloom_xor_put_kernel(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes,
+                                                              u64 *words) {
+    const int64_t total = n * (int64_t)n_hashes;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = (factors[i % n_hashes] ^ keys[i / n_hashes]) % bits;  // (truncating remainder, as in Java)
+        const u64 b = (u64)(r < 0 ? -r : r);
+        const u64 m = 1ULL << (b & 63);
+        if ((words[b >> 6] & m) == 0) atomicOr(&words[b >> 6], m);
+    }
+}
+
+extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, u64 *words,
+                                              hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gs_bloom_xor_put_kernel, dim3(gs_build_grid(n * (int64_t)n_hashes)), dim3(256), 0, stream, keys, n, bits, factors, n_hashes, words);
+    return hipGetLastError();
+}

@@ -408,6 +408,14 @@ enum { GS_BLOOM_XOR = 0, GS_BLOOM_MURMUR = 1, GS_BLOOM_BLOCKED = 2 };
 
 int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bits, int32_t n_hashes,
                     const int64_t *hash_factors, const uint64_t *words, int64_t n_words);
+/* The index filter built on the device (BloomIndexGoal, C/goals/refseq/BloomIndexGoal.java:66-113): an XORKMerBloomFilter sized
+ * for `expected_insertions` k-mers at false-positive rate `fpp` (AbstractKMerBloomFilter.java:172-185: bits, number of hashes;
+ * hash factors = the first nextLong() values of java.util.Random(42), :105-109) with putLong of every k-mer (kmers in host or
+ * device memory, the reference's encoding -- e.g. the result of gs_dbbuild for the requested taxa).  Bit for bit the filter the
+ * reference builds from the same k-mers.  gs_bloom_get returns geometry and contents (words may be NULL; n_words >= (bits+63)/64). */
+int gs_bloom_build(gs_bloom **out, int device, int kind, const int64_t *kmers, int64_t n_kmers, int mem, int64_t expected_insertions,
+                   double fpp);
+int gs_bloom_get(gs_bloom *bloom, int64_t *bits, int32_t *n_hashes, int64_t *hash_factors, uint64_t *words, int64_t n_words);
 int gs_bloom_destroy(gs_bloom *bloom);
 /* accept[i] = isAcceptRead(read i) ? 1 : 0.  profile != 0 records kernel time (gs_filter_kernel_time). */
 int gs_filter_submit(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *seq,

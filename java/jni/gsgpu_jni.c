@@ -225,6 +225,14 @@ JNIEXPORT void JNICALL JNAME(matchReset)(JNIEnv *env, jclass c, jlong run) {
 
 JNIEXPORT void JNICALL JNAME(matchDestroy)(JNIEnv *env, jclass c, jlong run) { gs_match_destroy((gs_run *)(intptr_t)run); }
 
+JNIEXPORT jlong JNICALL JNAME(bloomBuild)(JNIEnv *env, jclass c, jint device, jobject kmers, jlong nKmers, jlong expectedInsertions,
+                                          jdouble fpp) {
+    gs_bloom *b = NULL;
+    int rc = gs_bloom_build(&b, device, GS_BLOOM_XOR, (const int64_t *)addr(env, kmers), nKmers, GS_MEM_HOST, expectedInsertions, fpp);
+    if (rc) throw_gs(env, rc);
+    return (jlong)(intptr_t)b;
+}
+
 JNIEXPORT jlong JNICALL JNAME(bloomCreate)(JNIEnv *env, jclass c, jint device, jint kind, jlong bits, jint nHashes,
                                            jlongArray factors, jobject words, jlong nWords) {
     gs_bloom *b = NULL;

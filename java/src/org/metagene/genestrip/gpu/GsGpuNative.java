@@ -122,6 +122,10 @@ public final class GsGpuNative {
 	public static native long bloomCreate(int device, int kind, long bits, int nHashes, long[] hashFactors,
 			ByteBuffer words, long nWords);
 
+	/** gs_bloom_build: the XOR index filter of BloomIndexGoal built on the device from nKmers k-mers (direct buffer, int64 in
+	 *  native order), sized for expectedInsertions at fpp; returns the gs_bloom handle (as bloomCreate does) */
+	public static native long bloomBuild(int device, ByteBuffer kmers, long nKmers, long expectedInsertions, double fpp);
+
 	public static native void bloomDestroy(long bloom);
 
 	/** gs_filter_submit with GS_MEM_HOST: accept = nReads x uint8 */
