@@ -674,15 +674,15 @@ class DeviceBloomFilter:
                                      w.ctypes.data_as(C.c_void_p), len(w)))
 
     @classmethod
-    def build(cls, kmers, expected_insertions=None, fpp=1e-8, device=0):
-        """gs_bloom_build: the XOR index filter over `kmers` (numpy int64 or a device tensor), sized like the reference's
-        (BloomIndexGoal: indexBloomFilterFpp, default 1e-8) and filled on the device"""
+    def build(cls, kmers, expected_insertions=None, fpp=1e-8, device=0, kind=BLOOM_XOR):
+        """gs_bloom_build: the XOR (or Murmur) index filter over `kmers` (numpy int64 or a device tensor), sized like the
+        reference's (BloomIndexGoal: indexBloomFilterFpp, default 1e-8) and filled on the device"""
         pk, mem = _ptr(kmers)
         n = int(kmers.shape[0] if hasattr(kmers, "shape") else len(kmers))
         _ready(kmers)
         self = cls.__new__(cls)
         self.h = C.c_void_p()
-        _check(lib().gs_bloom_build(C.byref(self.h), device, BLOOM_XOR, pk, n, mem, int(expected_insertions or max(n, 1)), float(fpp)))
+        _check(lib().gs_bloom_build(C.byref(self.h), device, kind, pk, n, mem, int(expected_insertions or max(n, 1)), float(fpp)))
         return self
 
     def get(self, with_words=True):

@@ -3605,8 +3605,8 @@ extern "C" int gs_bloom_create(gs_bloom **out, int device, int kind, int64_t bit
     return fail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
-extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, u64 *words,
-                                              hipStream_t stream);
+extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, int murmur,
+                                              u64 *words, hipStream_t stream);
 
 // java.util.Random (the hash factors of the reference's filters are its first nextLong() values for seed 42,
 // C/bloom/AbstractKMerBloomFilter.java:78,105-109)
@@ -3627,7 +3627,8 @@ extern "C" int gs_bloom_build(gs_bloom **out, int device, int kind, const int64_
                               double fpp) try {
     if (!out) return fail(GS_E_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind != GS_BLOOM_XOR) return fail(GS_E_UNSUPPORTED, "gs_bloom_build makes XOR filters (the reference's index filter); others: gs_bloom_create");
+    if (kind != GS_BLOOM_XOR && kind != GS_BLOOM_MURMUR)
+        return fail(GS_E_UNSUPPORTED, "gs_bloom_build makes XOR and Murmur filters (the reference's index filters); blocked filters: gs_bloom_create");
     if (n_kmers < 0 || (n_kmers > 0 && !kmers) || expected_insertions < 1 || !(fpp > 0.0 && fpp < 1.0)) return fail(GS_E_INVALID, "bad argument");
     if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
     // AbstractKMerBloomFilter.optimalNumOfBits :183-185, optimalNumOfHashFunctions :172-174 (Java double arithmetic)
@@ -3664,7 +3665,7 @@ extern "C" int gs_bloom_build(gs_bloom **out, int device, int kind, const int64_
         if (e == hipSuccess) e = hipMemcpyAsync(d_keys, kmers, sizeof(int64_t) * (size_t)n_kmers, hipMemcpyHostToDevice, b->stream);
         keys = d_keys;
     }
-    if (e == hipSuccess) e = gs_launch_bloom_xor_put(keys, n_kmers, bits, b->d_factors, (int)nh, b->d_words, b->stream);
+    if (e == hipSuccess) e = gs_launch_bloom_xor_put(keys, n_kmers, bits, b->d_factors, (int)nh, kind == GS_BLOOM_MURMUR, b->d_words, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     hipFree(d_keys);
     if (e != hipSuccess) {

@@ -283,23 +283,44 @@ extern "C" hipError_t gs_launch_build_scatter(const u64 *keys, const int32_t *va
 
 // ---------------------------------------------------------------------------------------------------
 // Index filter construction (BloomIndexGoal, C/goals/refseq/BloomIndexGoal.java:66-113): AbstractKMerBloomFilter.putLong
-// (C/bloom/AbstractKMerBloomFilter.java:196-203) of every k-mer with the XOR hashes (C/bloom/XORKMerBloomFilter.java:43-59):
-// bit abs((factor_i ^ kmer) % bits) for every hash i.  One thread per (k-mer, hash).
+// (C/bloom/AbstractKMerBloomFilter.java:196-203) of every k-mer with the XOR hashes (C/bloom/XORKMerBloomFilter.java:43-59: bit
+// abs((factor_i ^ kmer) % bits) for every hash i) or the Murmur ones (MurmurKMerBloomFilter).  One thread per (k-mer, hash).
 // ---------------------------------------------------------------------------------------------------
+// MurmurKMerBloomFilter.hash: MurmurHash3DropIn.hash64(kmer, factor) (C/util/MurmurHash3DropIn.java:60-87)
+__device__ __forceinline__ int64_t gs_build_murmur64(int64_t data_, int64_t base) {
+    const u64 data = (u64)data_;
+    u64 hash = (u64)base;
+    u64 kk = __builtin_bswap64(data);
+    kk *= 0x87c37b91114253d5ULL;
+    kk = (kk << 31) | (kk >> 33);
+    kk *= 0x4cf5ad432745937fULL;
+    hash ^= kk;
+    hash = ((hash << 27) | (hash >> 37)) * 5 + 0x52dce729ULL;
+    hash ^= 8;
+    hash ^= hash >> 33;
+    hash *= 0xff51afd7ed558ccdULL;
+    hash ^= hash >> 33;
+    hash *= 0xc4ceb9fe1a85ec53ULL;
+    hash ^= hash >> 33;
+    return (int64_t)(hash ^ data);
+}
+
 __global__ __launch_bounds__(256) void gs_bloom_xor_put_kernel(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes,
-                                                              u64 *words) {
+                                                              int murmur, u64 *words) {
     const int64_t total = n * (int64_t)n_hashes;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = (factors[i % n_hashes] ^ keys[i / n_hashes]) % bits;  // (truncating remainder, as in Java)
+        const int64_t f = factors[i % n_hashes], key = keys[i / n_hashes];
+        const int64_t r = (murmur ? gs_build_murmur64(key, f) : (f ^ key)) % bits;  // (truncating remainder, as in Java)
         const u64 b = (u64)(r < 0 ? -r : r);
         const u64 m = 1ULL << (b & 63);
         if ((words[b >> 6] & m) == 0) atomicOr(&words[b >> 6], m);
     }
 }
 
-extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, u64 *words,
-                                              hipStream_t stream) {
+extern "C" hipError_t gs_launch_bloom_xor_put(const int64_t *keys, int64_t n, int64_t bits, const int64_t *factors, int n_hashes, int murmur,
+                                              u64 *words, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gs_bloom_xor_put_kernel, dim3(gs_build_grid(n * (int64_t)n_hashes)), dim3(256), 0, stream, keys, n, bits, factors, n_hashes, words);
+    hipLaunchKernelGGL(gs_bloom_xor_put_kernel, dim3(gs_build_grid(n * (int64_t)n_hashes)), dim3(256), 0, stream, keys, n, bits, factors, n_hashes,
+                       murmur, words);
     return hipGetLastError();
 }

@@ -217,21 +217,22 @@ def test_device_build_argument_errors():
     empty.close()
 
 
+@pytest.mark.parametrize("kind", [orc.BLOOM_XOR, orc.BLOOM_MURMUR])
 @pytest.mark.parametrize("n,fpp", [(5000, 1e-8), (200000, 0.01), (1, 1e-8), (37, 0.5)])
-def test_index_filter_built_on_the_device_equals_the_reference_construction(n, fpp):
+def test_index_filter_built_on_the_device_equals_the_reference_construction(n, fpp, kind):
     """gs_bloom_build (BloomIndexGoal): geometry, hash factors and every bit equal the oracle's XOR filter after putLong of the
     same k-mers; a filter goal on it accepts what the oracle's accepts"""
     rng = np.random.default_rng(n)
     keys = np.unique(rng.integers(0, 1 << 62, n, dtype=np.int64))
-    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), fpp)
+    ob = orc.Bloom(kind, len(keys), fpp)
     ob.put_many(keys)
-    f = ga.DeviceBloomFilter.build(keys, fpp=fpp)
+    f = ga.DeviceBloomFilter.build(keys, fpp=fpp, kind=kind)
     bits, hf, words = f.get()
     assert bits == ob.bits and len(hf) == ob.hashes and np.array_equal(hf, ob.hash_factors)
     assert np.array_equal(words, ob.words[:len(words)])
     if n >= 5000:  # the filter goal over it
         import torch
-        g = ga.DeviceBloomFilter.build(torch.from_numpy(keys).cuda(), fpp=fpp)  # the same from device memory
+        g = ga.DeviceBloomFilter.build(torch.from_numpy(keys).cuda(), fpp=fpp, kind=kind)  # the same from device memory
         assert np.array_equal(g.get()[2], words)
         g.close()
     f.close()
