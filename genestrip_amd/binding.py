@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_to_db", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_submit_fastq_ml", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
-    "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines",
+    "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines", "gs_match_text_read_bounds",
     "gs_pinned_alloc", "gs_pinned_free",
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
@@ -137,6 +137,7 @@ def lib():
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
         "gs_match_text_clear_error": (ci, [vp]), "gs_match_text_select": (ci, [vp, ci]),
         "gs_match_segments_text": (ci, [vp, vp]), "gs_match_text_newlines": (ci, [vp, vp]),
+        "gs_match_text_read_bounds": (ci, [vp, vp]),
         "gs_pinned_alloc": (ci, [vp, C.c_size_t]), "gs_pinned_free": (ci, [vp]),
         "gs_filter_submit_text": (ci, [vp, ci, ci, dbl, vp, i64, i64, ci, vp, vp, ci, vp]),
         "gs_filter_text_wait_copy": (ci, [vp, i64]), "gs_filter_text_status": (ci, [vp, vp, vp, vp]),

@@ -3434,6 +3434,16 @@ extern "C" int gs_match_segments_text(gs_run *run, uint64_t *seg_off) {
 }
 
 // newline offsets of the most recent text chunk (the record geometry for per-read writers); synchronises
+extern "C" int gs_match_text_read_bounds(gs_run *run, uint64_t *bounds) {
+    if (!run || !bounds) return fail(GS_E_INVALID, "NULL argument");
+    if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
+    if (!run->text.last_fasta) return fail(GS_E_STATE, "the last chunk was four-line FASTQ: its reads lie in the text (gs_match_text_newlines)");
+    HIP_TRY(hipSetDevice(run->db->device));
+    HIP_TRY(hipMemcpyAsync(bounds, run->text.d_off2, sizeof(uint64_t) * ((size_t)run->text.last_reads + 1), hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
+}
+
 extern "C" int gs_match_text_newlines(gs_run *run, uint32_t *newlines) {
     if (!run || !newlines) return fail(GS_E_INVALID, "NULL argument");
     if (run->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");

@@ -698,8 +698,21 @@ struct TextJob {
                     fallback_off = carry_file_off;
                     fallback_reads = reads_in_file;
                 } else if ((int64_t)carry.size() + cut > 0) {
-                    err = gs_match_submit_fasta(c.run, start, (int64_t)carry.size() + cut, lines, records, GS_MEM_HOST,
-                                                read_no + reads_in_file, nullptr, nullptr, &ticket);
+                    const bool kr = c.kraken.active();
+                    MatchCtx::Results &rs = c.res[0];
+                    if (kr) {
+                        err = rs.cls.resize((size_t)std::max<int64_t>(records, 1));
+                        if (!err) err = rs.flags.resize((size_t)std::max<int64_t>(records, 1));
+                    }
+                    if (!err)
+                        err = gs_match_submit_fasta(c.run, start, (int64_t)carry.size() + cut, lines, records, GS_MEM_HOST,
+                                                    read_no + reads_in_file, kr ? rs.cls.data() : nullptr, kr ? rs.flags.data() : nullptr, &ticket);
+                    if (!err && kr && records > 0) {  // Kraken-style lines of this chunk's records, before the block goes back
+                        chunks.push_back({carry_file_off, reads_in_file, ticket});
+                        err = check_refusal(&fallback_off, &fallback_reads);
+                        chunks.pop_back();
+                        if (!err && fallback_off < 0) err = kraken_lines_fasta(rs, start, (int64_t)carry.size() + cut, records);
+                    }
                 }
                 if (!err && fallback_off < 0) {
                     if (ticket >= 0) {
@@ -785,6 +798,48 @@ struct TextJob {
         if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
         *err_out = err;
         return 1;
+    }
+
+    // Kraken-style lines (MatcherReadEntry.writeMatchDetails, :723-756) of a FASTA chunk that has just been matched: the
+    // descriptors are the header lines of the text (the reference's FASTA reader hands them on with '>' replaced by '@'; the
+    // line starts behind that character either way), read lengths and runs come from the device
+    int kraken_lines_fasta(MatchCtx::Results &rs, const uint8_t *text, int64_t n_bytes, int64_t n_records) {
+        std::vector<uint64_t> bounds((size_t)n_records + 1);
+        int err = gs_match_text_read_bounds(c.run, bounds.data());  // (waits for the chunk: cls / flags are complete)
+        if (!err) err = rs.seg_off.resize((size_t)n_records + 1);
+        if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
+        if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n_records]);
+        if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n_records]);
+        if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
+        if (err) return err;
+        // header lines: the first byte of the chunk, and every '>' behind a newline
+        std::vector<std::pair<size_t, size_t>> hdr;  // (start, length without the newline)
+        hdr.reserve((size_t)n_records);
+        for (const uint8_t *p = text, *end = text + n_bytes; p < end;) {
+            if (*p == '>' && (p == text || p[-1] == '\n')) {
+                const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+                const size_t len = nl ? (size_t)(nl - p) : (size_t)(end - p);
+                hdr.push_back({(size_t)(p - text), len});
+                p += len + 1;
+            } else {
+                const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+                if (!q) break;
+                p = q + 1;
+            }
+        }
+        if ((int64_t)hdr.size() != n_records) return hfail(GS_E_INVALID, "FASTA chunk: the header lines do not match the device's record count");
+        std::vector<FormatPart> parts((size_t)c.pool.threads());
+        MatchCtx &cc = c;
+        c.pool.run(n_records, [&cc, &rs, &parts, &hdr, &bounds, text](int t, int64_t lo, int64_t hi) {
+            FormatPart &p = parts[(size_t)t];
+            p.kraken = cc.kraken.take();
+            for (int64_t r = lo; r < hi; r++)
+                kraken_line(cc, rs, p.kraken, text + hdr[(size_t)r].first, hdr[(size_t)r].second,
+                            (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]), r);
+            p.pack(cc.kraken, cc.filtered);
+        });
+        write_parts(c, parts);
+        return GS_OK;
     }
 
 private:
@@ -912,10 +967,9 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
     int err = GS_OK;
     std::vector<int> kind((size_t)n_paths, 0);
     int n_gzip = 0;
-    const bool per_read_out = c.filtered.active() || c.kraken.active();
     for (int i = 0; i < n_paths; i++) {
         kind[(size_t)i] = fast ? text_path_kind(paths[i]) : 0;
-        if (kind[(size_t)i] >= 3 && per_read_out) kind[(size_t)i] = 0;  // FASTA on the device: tables only
+        if (kind[(size_t)i] >= 3 && c.filtered.active()) kind[(size_t)i] = 0;  // FASTA on the device: tables and Kraken-style lines
         n_gzip += kind[(size_t)i] == 2 || kind[(size_t)i] == 4;
     }
     const int default_readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));

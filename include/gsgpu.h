@@ -388,6 +388,9 @@ int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts);
  * the filtered FASTQ and the Kraken-style lines from its copy of the raw text.  Both synchronise. */
 int gs_match_segments_text(gs_run *run, uint64_t *seg_off);
 int gs_match_text_newlines(gs_run *run, uint32_t *newlines);
+/* After a FASTA or general-FASTQ chunk: bounds[0 .. n_records] of its reads in the gathered sequence buffer, i.e. the read
+ * lengths (bounds[r + 1] - bounds[r]); waits for the chunk. */
+int gs_match_text_read_bounds(gs_run *run, uint64_t *bounds);
 
 /* accumulated device time of the match kernel launches since gs_match_begin (cfg.profile != 0) */
 int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);

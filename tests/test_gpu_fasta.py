@@ -137,3 +137,40 @@ def test_fasta_files_through_the_host_pipeline(sdb, tmp_path, monkeypatch, gz, b
     assert (tot.reads, tot.kmers, tot.bps) == (reads, kmers, bps)
     assert np.array_equal(table, want), np.argwhere(table != want)[:6]
     store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_kraken_style_lines_of_fasta_files_from_the_device_path(sdb, tmp_path, monkeypatch, gz):
+    """FASTA input with Kraken-style output: the records are found and matched on the device, the lines are formatted from the
+    header lines of the text + the device's read lengths and runs; byte for byte what the reference-exact parser path writes"""
+    import gzip
+    rng = np.random.default_rng(12)
+    seq, off = synth.reads_host(sdb.genomes, 3000, read_len=700, seed=41)
+    parts = []
+    for r in range(3000):
+        s = seq[int(off[r]):int(off[r + 1])].tobytes()
+        if r % 13 == 0:
+            s = s[:int(rng.integers(1, 60))]
+        w = int(rng.integers(50, 90))
+        body = b"\n".join(s[i:i + w] for i in range(0, len(s), w))
+        parts.append((b">contig_%d some description=%d\n" % (r, r * 7) if r % 5 else b">c%d\n" % r) + body + b"\n")
+    data = b"".join(parts)
+    p = tmp_path / ("contigs.fasta.gz" if gz else "contigs.fa")
+    (gzip.open(p, "wb") if gz else open(p, "wb")).write(data)
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(1 << 17))
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    taxids = [str(1000 + i) for i in range(sdb.n_values)]
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_FAST", fast)
+        kr = str(tmp_path / ("k%s.out" % fast))
+        for write_all in (True, False):
+            table, _, tot = host.match_files(store, [str(p)], kraken_out_path=kr, taxids=taxids, write_all=write_all)
+            outs[(fast, write_all)] = (open(kr, "rb").read(), table.copy(), tot.reads)
+    for write_all in (True, False):
+        a, b = outs[("1", write_all)], outs[("0", write_all)]
+        assert a[2] == b[2] == 3000 and np.array_equal(a[1], b[1])
+        assert a[0] == b[0] and len(a[0]) > 1000
+    n_all, n_cls = outs[("1", True)][0].count(b"\n"), outs[("1", False)][0].count(b"\n")
+    assert 2500 < n_all <= 3000 and 500 < n_cls < n_all  # (records shorter than k have no runs and no line)
+    store.close()
