@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_to_db", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_submit_fastq_ml", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
-    "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines", "gs_match_text_read_bounds",
+    "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines", "gs_match_text_read_bounds", "gs_match_text_line_classes",
     "gs_pinned_alloc", "gs_pinned_free",
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
@@ -133,7 +133,8 @@ def lib():
         "gs_match_max_counts": (ci, [vp, vp]),
         "gs_match_submit_text": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp]),
         "gs_match_submit_fasta": (ci, [vp, vp, i64, i64, i64, ci, i64, vp, vp, vp]),
-        "gs_match_submit_fastq_ml": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp, vp]),
+        "gs_match_submit_fastq_ml": (ci, [vp, vp, i64, i64, ci, i64, vp, vp, vp, vp, vp, vp]),
+        "gs_match_text_line_classes": (ci, [vp, vp]),
         "gs_match_text_wait_copy": (ci, [vp, i64]), "gs_match_text_status": (ci, [vp, vp, vp, vp]),
         "gs_match_text_clear_error": (ci, [vp]), "gs_match_text_select": (ci, [vp, ci]),
         "gs_match_segments_text": (ci, [vp, vp]), "gs_match_text_newlines": (ci, [vp, vp]),
@@ -517,8 +518,8 @@ class FastqKMerMatcher:
             n_lines = int(np.count_nonzero(np.asarray(text) == 10)) if mem == MEM_HOST else int((text == 10).sum().item())
         n_rec, used, ticket = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
         _ready(text)
-        _check(lib().gs_match_submit_fastq_ml(self.h, pt, n_bytes, n_lines, mem, first_read_no, C.byref(n_rec), C.byref(used), None,
-                                              C.byref(ticket)))
+        _check(lib().gs_match_submit_fastq_ml(self.h, pt, n_bytes, n_lines, mem, first_read_no, None, None, C.byref(n_rec), C.byref(used),
+                                              None, C.byref(ticket)))
         return max(n_rec.value, 0), used.value
 
     def text_wait_copy(self, ticket):

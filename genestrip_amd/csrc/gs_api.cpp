@@ -2511,10 +2511,11 @@ static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, 
                              int32_t *class_vi, uint8_t *flags, int64_t *ticket, int64_t fasta_records, int64_t *ml_out = nullptr);
 
 extern "C" int gs_match_submit_fastq_ml(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                                        int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket) {
+                                        int32_t *class_vi, uint8_t *flags, int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines,
+                                        int64_t *ticket) {
     if (!n_records || !consumed_bytes) return fail(GS_E_INVALID, "NULL argument");
     int64_t out[3] = {0, 0, 0};
-    const int rc = match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, nullptr, nullptr, ticket, -1, out);
+    const int rc = match_submit_text(run, text, n_bytes, n_lines, mem, first_read_no, class_vi, flags, ticket, -1, out);
     *n_records = out[0];
     *consumed_bytes = out[1];
     if (consumed_lines) *consumed_lines = out[2];
@@ -3440,6 +3441,16 @@ extern "C" int gs_match_text_read_bounds(gs_run *run, uint64_t *bounds) {
     if (!run->text.last_fasta) return fail(GS_E_STATE, "the last chunk was four-line FASTQ: its reads lie in the text (gs_match_text_newlines)");
     HIP_TRY(hipSetDevice(run->db->device));
     HIP_TRY(hipMemcpyAsync(bounds, run->text.d_off2, sizeof(uint64_t) * ((size_t)run->text.last_reads + 1), hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
+}
+
+extern "C" int gs_match_text_line_classes(gs_run *run, uint8_t *classes) {
+    if (!run || !classes) return fail(GS_E_INVALID, "NULL argument");
+    if (run->text.tickets == 0 || !run->text.d_ml_class) return fail(GS_E_STATE, "no general FASTQ chunk has been submitted");
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (run->text.last_lines > 0)
+        HIP_TRY(hipMemcpyAsync(classes, run->text.d_ml_class, (size_t)run->text.last_lines, hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     return collect_events(run);
 }

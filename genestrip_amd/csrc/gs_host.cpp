@@ -775,7 +775,16 @@ struct TextJob {
                 if (!carry.empty()) memcpy(start, carry.data(), carry.size());
                 const int64_t bytes = (int64_t)carry.size() + cut, lines = carry_lines + sl.newlines;
                 int64_t n_rec = 0, used = 0, used_lines = 0, ticket = -1;
-                err = gs_match_submit_fastq_ml(c.run, start, bytes, lines, GS_MEM_HOST, read_no + reads_in_file, &n_rec, &used, &used_lines, &ticket);
+                const bool kr = c.kraken.active();
+                MatchCtx::Results &rs = c.res[0];
+                if (kr) {
+                    err = rs.cls.resize((size_t)(lines / 4 + 2));
+                    if (!err) err = rs.flags.resize((size_t)(lines / 4 + 2));
+                }
+                if (!err)
+                    err = gs_match_submit_fastq_ml(c.run, start, bytes, lines, GS_MEM_HOST, read_no + reads_in_file, kr ? rs.cls.data() : nullptr,
+                                                   kr ? rs.flags.data() : nullptr, &n_rec, &used, &used_lines, &ticket);
+                if (!err && kr && n_rec > 0) err = kraken_lines_general(rs, start, used_lines, n_rec);
                 if (!err && n_rec < 0) {  // refused (NUL byte, a record of thousands of lines): the general parser from here
                     err = gs_match_text_clear_error(c.run);
                     fallback_off = carry_file_off;
@@ -798,6 +807,42 @@ struct TextJob {
         if (err || last || fallback_off >= 0) err = finish(err, fallback_off, fallback_reads);
         *err_out = err;
         return 1;
+    }
+
+    // ... and of a general FASTQ chunk: the descriptor lines are the lines the device classified as such
+    int kraken_lines_general(MatchCtx::Results &rs, const uint8_t *text, int64_t n_lines, int64_t n_records) {
+        std::vector<uint64_t> bounds((size_t)n_records + 1);
+        std::vector<uint8_t> cls((size_t)n_lines);
+        int err = gs_match_text_read_bounds(c.run, bounds.data());  // (waits for the chunk: cls / flags are complete)
+        if (!err) err = gs_match_text_line_classes(c.run, cls.data());
+        if (!err) err = rs.nl.resize((size_t)n_lines);
+        if (!err) err = gs_match_text_newlines(c.run, rs.nl.data());
+        if (!err) err = rs.seg_off.resize((size_t)n_records + 1);
+        if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
+        if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n_records]);
+        if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n_records]);
+        if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
+        if (err) return err;
+        std::vector<std::pair<size_t, size_t>> hdr;
+        hdr.reserve((size_t)n_records);
+        for (int64_t i = 0; i < n_lines; i++)
+            if (cls[(size_t)i] == 1) {
+                const size_t a = i ? (size_t)rs.nl[(size_t)i - 1] + 1 : 0;
+                hdr.push_back({a, (size_t)rs.nl[(size_t)i] - a});
+            }
+        if ((int64_t)hdr.size() != n_records) return hfail(GS_E_INVALID, "FASTQ chunk: the descriptor lines do not match the device's record count");
+        std::vector<FormatPart> parts((size_t)c.pool.threads());
+        MatchCtx &cc = c;
+        c.pool.run(n_records, [&cc, &rs, &parts, &hdr, &bounds, text](int t, int64_t lo, int64_t hi) {
+            FormatPart &p = parts[(size_t)t];
+            p.kraken = cc.kraken.take();
+            for (int64_t r = lo; r < hi; r++)
+                kraken_line(cc, rs, p.kraken, text + hdr[(size_t)r].first, hdr[(size_t)r].second,
+                            (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]), r);
+            p.pack(cc.kraken, cc.filtered);
+        });
+        write_parts(c, parts);
+        return GS_OK;
     }
 
     // Kraken-style lines (MatcherReadEntry.writeMatchDetails, :723-756) of a FASTA chunk that has just been matched: the
@@ -932,7 +977,7 @@ private:
             read_no += fallback_reads;
             // a FASTQ file that is not four lines per record from its very first chunk: once more with the records found on the
             // device (GS_HOST_ML=0: straight to the reference-exact parser, which also takes over whatever that pass refuses)
-            bool ml = fallback_off == 0 && fallback_reads == 0 && !fasta && !general && !c.filtered.active() && !c.kraken.active();
+            bool ml = fallback_off == 0 && fallback_reads == 0 && !fasta && !general && !c.filtered.active();
             if (const char *e = getenv("GS_HOST_ML")) ml = ml && atoi(e) != 0;
             if (ml) {
                 TextJob g(c, path, bank, read_no, false);

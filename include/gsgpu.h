@@ -200,7 +200,12 @@ int gs_match_submit_fasta(gs_run *run, const uint8_t *text, int64_t n_bytes, int
  * 4096 lines is refused like a malformed four-line chunk: *n_records = -1, nothing is matched, gs_match_text_status /
  * gs_match_text_clear_error as there. */
 int gs_match_submit_fastq_ml(gs_run *run, const uint8_t *text, int64_t n_bytes, int64_t n_lines, int mem, int64_t first_read_no,
-                             int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket);
+                             int32_t *class_vi, uint8_t *flags, int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines,
+                             int64_t *ticket);
+/* (class_vi / flags: optional per-read outputs as for gs_match_submit_text, room for n_lines / 4 + 1 reads.)  After such a chunk:
+ * classes[0 .. consumed_lines) = 1 for a record's descriptor line, 2 for its sequence lines, 0 otherwise; with
+ * gs_match_text_newlines this is the record geometry for per-read output. */
+int gs_match_text_line_classes(gs_run *run, uint8_t *classes);
 int gs_match_text_wait_copy(gs_run *run, int64_t ticket);
 int gs_match_text_status(gs_run *run, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_match_text_clear_error(gs_run *run);

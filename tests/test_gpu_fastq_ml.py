@@ -153,3 +153,25 @@ def test_multiline_fastq_files_go_through_the_device(sdb, tmp_path, monkeypatch,
     assert tot3.reads == rd["n_reads"] + 500
     assert np.array_equal(t3[:, [0, 1, 2, 3, 4, 5]], both[:, [0, 1, 2, 3, 4, 5]])
     store.close()
+
+
+def test_kraken_style_lines_of_multiline_fastq_from_the_device_path(sdb, tmp_path, monkeypatch):
+    """multi-line FASTQ with Kraken-style output: records found and matched on the device, lines from the descriptor lines the
+    device classified + its read lengths and runs; byte for byte the parser path's output"""
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(1 << 16))
+    data = _multiline_fastq(sdb, 5000, seed=23) + b"@tail\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+    p = tmp_path / "ml.fastq"
+    p.write_bytes(data)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    taxids = [str(500 + i) for i in range(sdb.n_values)]
+    outs = {}
+    for ml in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_ML", ml)
+        before = host.stat(0)
+        kr = str(tmp_path / ("k%s.out" % ml))
+        table, _, tot = host.match_files(store, [str(p)], kraken_out_path=kr, taxids=taxids, write_all=True)
+        outs[ml] = (open(kr, "rb").read(), table.copy(), tot.reads, host.stat(0) - before)
+    assert outs["1"][3] > 3 and outs["0"][3] == 0  # the device path did run (and did not with GS_HOST_ML=0)
+    assert outs["1"][2] == outs["0"][2] == 5001 and np.array_equal(outs["1"][1], outs["0"][1])
+    assert outs["1"][0] == outs["0"][0] and outs["1"][0].count(b"\n") > 4000
+    store.close()
