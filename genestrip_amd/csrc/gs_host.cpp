@@ -698,7 +698,7 @@ struct TextJob {
                     fallback_off = carry_file_off;
                     fallback_reads = reads_in_file;
                 } else if ((int64_t)carry.size() + cut > 0) {
-                    const bool kr = c.kraken.active();
+                    const bool kr = c.kraken.active() || c.filtered.active();
                     MatchCtx::Results &rs = c.res[0];
                     if (kr) {
                         err = rs.cls.resize((size_t)std::max<int64_t>(records, 1));
@@ -707,11 +707,11 @@ struct TextJob {
                     if (!err)
                         err = gs_match_submit_fasta(c.run, start, (int64_t)carry.size() + cut, lines, records, GS_MEM_HOST,
                                                     read_no + reads_in_file, kr ? rs.cls.data() : nullptr, kr ? rs.flags.data() : nullptr, &ticket);
-                    if (!err && kr && records > 0) {  // Kraken-style lines of this chunk's records, before the block goes back
+                    if (!err && kr && records > 0) {  // the per-read outputs of this chunk's records, before the block goes back
                         chunks.push_back({carry_file_off, reads_in_file, ticket});
                         err = check_refusal(&fallback_off, &fallback_reads);
                         chunks.pop_back();
-                        if (!err && fallback_off < 0) err = kraken_lines_fasta(rs, start, (int64_t)carry.size() + cut, records);
+                        if (!err && fallback_off < 0) err = outputs_general(rs, start, lines, records, true);
                     }
                 }
                 if (!err && fallback_off < 0) {
@@ -775,7 +775,7 @@ struct TextJob {
                 if (!carry.empty()) memcpy(start, carry.data(), carry.size());
                 const int64_t bytes = (int64_t)carry.size() + cut, lines = carry_lines + sl.newlines;
                 int64_t n_rec = 0, used = 0, used_lines = 0, ticket = -1;
-                const bool kr = c.kraken.active();
+                const bool kr = c.kraken.active() || c.filtered.active();
                 MatchCtx::Results &rs = c.res[0];
                 if (kr) {
                     err = rs.cls.resize((size_t)(lines / 4 + 2));
@@ -784,7 +784,7 @@ struct TextJob {
                 if (!err)
                     err = gs_match_submit_fastq_ml(c.run, start, bytes, lines, GS_MEM_HOST, read_no + reads_in_file, kr ? rs.cls.data() : nullptr,
                                                    kr ? rs.flags.data() : nullptr, &n_rec, &used, &used_lines, &ticket);
-                if (!err && kr && n_rec > 0) err = kraken_lines_general(rs, start, used_lines, n_rec);
+                if (!err && kr && n_rec > 0) err = outputs_general(rs, start, used_lines, n_rec, false);
                 if (!err && n_rec < 0) {  // refused (NUL byte, a record of thousands of lines): the general parser from here
                     err = gs_match_text_clear_error(c.run);
                     fallback_off = carry_file_off;
@@ -809,78 +809,68 @@ struct TextJob {
         return 1;
     }
 
-    // ... and of a general FASTQ chunk: the descriptor lines are the lines the device classified as such
-    int kraken_lines_general(MatchCtx::Results &rs, const uint8_t *text, int64_t n_lines, int64_t n_records) {
+    // Per-read outputs of a FASTA or general FASTQ chunk that has just been matched.  Record geometry: the newline offsets from the
+    // device and a class per line (1 descriptor, 2 sequence, 0 '+' / quality) -- from the device for general FASTQ, by the
+    // first byte for FASTA.  Kraken-style lines (MatcherReadEntry.writeMatchDetails, :723-756): descriptor up to the first blank
+    // without its first character, class, length, runs.  Filtered FASTQ (ReadEntry.write, AbstractFastqReader.java:570-584):
+    // descriptor (FASTA: '>' replaced by '@', :380), the read in ONE line, "+", then the quality characters of the record (general
+    // FASTQ with withProbs: every quality line that was consumed, joined) or '~' x length.
+    int outputs_general(MatchCtx::Results &rs, const uint8_t *text, int64_t n_lines, int64_t n_records, bool is_fasta) {
         std::vector<uint64_t> bounds((size_t)n_records + 1);
-        std::vector<uint8_t> cls((size_t)n_lines);
+        std::vector<uint8_t> cls((size_t)std::max<int64_t>(n_lines, 1));
         int err = gs_match_text_read_bounds(c.run, bounds.data());  // (waits for the chunk: cls / flags are complete)
-        if (!err) err = gs_match_text_line_classes(c.run, cls.data());
-        if (!err) err = rs.nl.resize((size_t)n_lines);
+        if (!err) err = rs.nl.resize((size_t)std::max<int64_t>(n_lines, 1));
         if (!err) err = gs_match_text_newlines(c.run, rs.nl.data());
-        if (!err) err = rs.seg_off.resize((size_t)n_records + 1);
-        if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
-        if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n_records]);
-        if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n_records]);
-        if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
-        if (err) return err;
-        std::vector<std::pair<size_t, size_t>> hdr;
-        hdr.reserve((size_t)n_records);
-        for (int64_t i = 0; i < n_lines; i++)
-            if (cls[(size_t)i] == 1) {
-                const size_t a = i ? (size_t)rs.nl[(size_t)i - 1] + 1 : 0;
-                hdr.push_back({a, (size_t)rs.nl[(size_t)i] - a});
-            }
-        if ((int64_t)hdr.size() != n_records) return hfail(GS_E_INVALID, "FASTQ chunk: the descriptor lines do not match the device's record count");
-        std::vector<FormatPart> parts((size_t)c.pool.threads());
-        MatchCtx &cc = c;
-        c.pool.run(n_records, [&cc, &rs, &parts, &hdr, &bounds, text](int t, int64_t lo, int64_t hi) {
-            FormatPart &p = parts[(size_t)t];
-            p.kraken = cc.kraken.take();
-            for (int64_t r = lo; r < hi; r++)
-                kraken_line(cc, rs, p.kraken, text + hdr[(size_t)r].first, hdr[(size_t)r].second,
-                            (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]), r);
-            p.pack(cc.kraken, cc.filtered);
-        });
-        write_parts(c, parts);
-        return GS_OK;
-    }
-
-    // Kraken-style lines (MatcherReadEntry.writeMatchDetails, :723-756) of a FASTA chunk that has just been matched: the
-    // descriptors are the header lines of the text (the reference's FASTA reader hands them on with '>' replaced by '@'; the
-    // line starts behind that character either way), read lengths and runs come from the device
-    int kraken_lines_fasta(MatchCtx::Results &rs, const uint8_t *text, int64_t n_bytes, int64_t n_records) {
-        std::vector<uint64_t> bounds((size_t)n_records + 1);
-        int err = gs_match_text_read_bounds(c.run, bounds.data());  // (waits for the chunk: cls / flags are complete)
-        if (!err) err = rs.seg_off.resize((size_t)n_records + 1);
-        if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
-        if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n_records]);
-        if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n_records]);
-        if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
-        if (err) return err;
-        // header lines: the first byte of the chunk, and every '>' behind a newline
-        std::vector<std::pair<size_t, size_t>> hdr;  // (start, length without the newline)
-        hdr.reserve((size_t)n_records);
-        for (const uint8_t *p = text, *end = text + n_bytes; p < end;) {
-            if (*p == '>' && (p == text || p[-1] == '\n')) {
-                const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-                const size_t len = nl ? (size_t)(nl - p) : (size_t)(end - p);
-                hdr.push_back({(size_t)(p - text), len});
-                p += len + 1;
-            } else {
-                const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-                if (!q) break;
-                p = q + 1;
-            }
+        if (!err && !is_fasta) err = gs_match_text_line_classes(c.run, cls.data());
+        if (!err && c.kraken.active()) {
+            err = rs.seg_off.resize((size_t)n_records + 1);
+            if (!err) err = gs_match_segments_text(c.run, rs.seg_off.data());
+            if (!err) err = rs.seg_code.resize((size_t)rs.seg_off[(size_t)n_records]);
+            if (!err) err = rs.seg_start.resize((size_t)rs.seg_off[(size_t)n_records]);
+            if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
         }
-        if ((int64_t)hdr.size() != n_records) return hfail(GS_E_INVALID, "FASTA chunk: the header lines do not match the device's record count");
+        if (err) return err;
+        const uint32_t *nl = rs.nl.p;
+        auto line_start = [nl](int64_t i) { return i ? (size_t)nl[i - 1] + 1 : (size_t)0; };
+        if (is_fasta)
+            for (int64_t i = 0; i < n_lines; i++) cls[(size_t)i] = text[line_start(i)] == '>' && nl[i] > line_start(i) ? 1 : 2;
+        std::vector<int64_t> head;  // descriptor line of every record, + n_lines
+        head.reserve((size_t)n_records + 1);
+        for (int64_t i = 0; i < n_lines; i++)
+            if (cls[(size_t)i] == 1) head.push_back(i);
+        if ((int64_t)head.size() != n_records) return hfail(GS_E_INVALID, "text chunk: the descriptor lines do not match the device's record count");
+        head.push_back(n_lines);
         std::vector<FormatPart> parts((size_t)c.pool.threads());
         MatchCtx &cc = c;
-        c.pool.run(n_records, [&cc, &rs, &parts, &hdr, &bounds, text](int t, int64_t lo, int64_t hi) {
+        const bool probs = c.opts->with_probs != 0 && !is_fasta;
+        c.pool.run(n_records, [&](int t, int64_t lo, int64_t hi) {
             FormatPart &p = parts[(size_t)t];
+            p.filtered = cc.filtered.take();
             p.kraken = cc.kraken.take();
-            for (int64_t r = lo; r < hi; r++)
-                kraken_line(cc, rs, p.kraken, text + hdr[(size_t)r].first, hdr[(size_t)r].second,
-                            (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]), r);
+            for (int64_t r = lo; r < hi; r++) {
+                const int64_t h = head[(size_t)r], next = head[(size_t)r + 1];
+                const size_t d0 = line_start(h), dlen = (size_t)nl[h] - d0;
+                const int64_t L = (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]);
+                if (cc.filtered.active() && (rs.flags[(size_t)r] & GS_F_RETURNED)) {
+                    std::vector<uint8_t> &o = p.filtered;
+                    const size_t at = o.size();
+                    o.insert(o.end(), text + d0, text + d0 + dlen);
+                    if (is_fasta && dlen > 0) o[at] = '@';
+                    o.push_back('\n');
+                    int64_t i = h + 1;
+                    for (; i < next && cls[(size_t)i] == 2; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);
+                    o.push_back('\n');
+                    o.push_back('+');
+                    o.push_back('\n');
+                    if (probs) {
+                        for (i++; i < next; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);  // (behind the '+' line)
+                    } else
+                        o.insert(o.end(), (size_t)L, (uint8_t)'~');
+                    o.push_back('\n');
+                    p.n_filtered++;
+                }
+                if (cc.kraken.active()) kraken_line(cc, rs, p.kraken, text + d0, dlen, L, r);
+            }
             p.pack(cc.kraken, cc.filtered);
         });
         write_parts(c, parts);
@@ -977,7 +967,7 @@ private:
             read_no += fallback_reads;
             // a FASTQ file that is not four lines per record from its very first chunk: once more with the records found on the
             // device (GS_HOST_ML=0: straight to the reference-exact parser, which also takes over whatever that pass refuses)
-            bool ml = fallback_off == 0 && fallback_reads == 0 && !fasta && !general && !c.filtered.active();
+            bool ml = fallback_off == 0 && fallback_reads == 0 && !fasta && !general;
             if (const char *e = getenv("GS_HOST_ML")) ml = ml && atoi(e) != 0;
             if (ml) {
                 TextJob g(c, path, bank, read_no, false);
@@ -1014,7 +1004,6 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
     int n_gzip = 0;
     for (int i = 0; i < n_paths; i++) {
         kind[(size_t)i] = fast ? text_path_kind(paths[i]) : 0;
-        if (kind[(size_t)i] >= 3 && c.filtered.active()) kind[(size_t)i] = 0;  // FASTA on the device: tables and Kraken-style lines
         n_gzip += kind[(size_t)i] == 2 || kind[(size_t)i] == 4;
     }
     const int default_readers = (int)std::min<unsigned>(8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));

@@ -164,13 +164,17 @@ def test_kraken_style_lines_of_fasta_files_from_the_device_path(sdb, tmp_path, m
     for fast in ("1", "0"):
         monkeypatch.setenv("GS_HOST_FAST", fast)
         kr = str(tmp_path / ("k%s.out" % fast))
+        fl = str(tmp_path / ("f%s.fastq" % fast))
         for write_all in (True, False):
-            table, _, tot = host.match_files(store, [str(p)], kraken_out_path=kr, taxids=taxids, write_all=write_all)
-            outs[(fast, write_all)] = (open(kr, "rb").read(), table.copy(), tot.reads)
+            table, _, tot = host.match_files(store, [str(p)], kraken_out_path=kr, filtered_path=fl, taxids=taxids, write_all=write_all,
+                                             with_probs=write_all)
+            outs[(fast, write_all)] = (open(kr, "rb").read(), table.copy(), tot.reads, open(fl, "rb").read(), tot.filtered_reads)
     for write_all in (True, False):
         a, b = outs[("1", write_all)], outs[("0", write_all)]
         assert a[2] == b[2] == 3000 and np.array_equal(a[1], b[1])
         assert a[0] == b[0] and len(a[0]) > 1000
+        # filtered reads: '@' for '>', the sequence in one line, '~' for the quality FASTA does not have
+        assert a[3] == b[3] and a[4] == b[4] > 500 and a[3].startswith(b"@c") and b"~~~~~~~~" in a[3]
     n_all, n_cls = outs[("1", True)][0].count(b"\n"), outs[("1", False)][0].count(b"\n")
     assert 2500 < n_all <= 3000 and 500 < n_cls < n_all  # (records shorter than k have no runs and no line)
     store.close()

@@ -170,8 +170,14 @@ def test_kraken_style_lines_of_multiline_fastq_from_the_device_path(sdb, tmp_pat
         before = host.stat(0)
         kr = str(tmp_path / ("k%s.out" % ml))
         table, _, tot = host.match_files(store, [str(p)], kraken_out_path=kr, taxids=taxids, write_all=True)
-        outs[ml] = (open(kr, "rb").read(), table.copy(), tot.reads, host.stat(0) - before)
+        outs[ml] = [open(kr, "rb").read(), table.copy(), tot.reads, host.stat(0) - before]
+        for probs in (False, True):  # filtered reads, with '~' and with the record's own quality lines
+            fl = str(tmp_path / ("f%s_%d.fastq" % (ml, probs)))
+            _, _, tot = host.match_files(store, [str(p)], filtered_path=fl, with_probs=probs)
+            outs[ml] += [open(fl, "rb").read(), tot.filtered_reads]
     assert outs["1"][3] > 3 and outs["0"][3] == 0  # the device path did run (and did not with GS_HOST_ML=0)
     assert outs["1"][2] == outs["0"][2] == 5001 and np.array_equal(outs["1"][1], outs["0"][1])
     assert outs["1"][0] == outs["0"][0] and outs["1"][0].count(b"\n") > 4000
+    assert outs["1"][4] == outs["0"][4] and outs["1"][5] == outs["0"][5] > 1000 and b"~~~~" in outs["1"][4]
+    assert outs["1"][6] == outs["0"][6] and outs["1"][7] == outs["0"][7] and outs["1"][6] != outs["1"][4]
     store.close()
