@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines", "gs_match_text_read_bounds", "gs_match_text_line_classes",
     "gs_pinned_alloc", "gs_pinned_free",
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
+    "gs_filter_submit_fasta", "gs_filter_submit_fastq_ml", "gs_filter_text_read_bounds", "gs_filter_text_line_classes",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
 )
 
@@ -143,6 +144,9 @@ def lib():
         "gs_filter_submit_text": (ci, [vp, ci, ci, dbl, vp, i64, i64, ci, vp, vp, ci, vp]),
         "gs_filter_text_wait_copy": (ci, [vp, i64]), "gs_filter_text_status": (ci, [vp, vp, vp, vp]),
         "gs_filter_text_reset": (ci, [vp, ci]),
+        "gs_filter_submit_fasta": (ci, [vp, ci, ci, dbl, vp, i64, i64, i64, ci, vp, vp, vp]),
+        "gs_filter_submit_fastq_ml": (ci, [vp, ci, ci, dbl, vp, i64, i64, ci, vp, vp, vp, vp, vp, vp]),
+        "gs_filter_text_read_bounds": (ci, [vp, vp]), "gs_filter_text_line_classes": (ci, [vp, vp]),
         "gs_match_segments": (ci, [vp, vp, vp, i64, ci, vp]), "gs_match_segments_fetch": (ci, [vp, vp, vp]),
         "gs_bloom_create": (ci, [vp, ci, ci, i64, i32, vp, vp, i64]),
         "gs_bloom_build": (ci, [vp, ci, ci, vp, i64, ci, i64, C.c_double]),
@@ -740,6 +744,41 @@ class FastqBloomFilter:
         _check(lib().gs_filter_submit_text(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, pt, n_bytes,
                                            int(n_lines), mem, pa, pn, int(self.profile), C.byref(ticket)))
         return ticket.value
+
+    def submit_fasta(self, text, accept, n_records=None, n_lines=None):
+        """raw FASTA text of whole records (gs_filter_submit_fasta): accept[r] per record; -> read lengths"""
+        text = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text
+        if n_lines is None:
+            n_lines = int((text == 10).sum())
+        if n_records is None:
+            t = np.asarray(text)
+            n_records = int(np.count_nonzero((t == 62) & np.concatenate(([True], t[:-1] == 10))))
+        ticket = C.c_int64(-1)
+        self._text_keep = text
+        _check(lib().gs_filter_submit_fasta(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, _ptr(text)[0], int(text.shape[0]),
+                                            int(n_lines), int(n_records), MEM_HOST, _ptr(accept)[0], None, C.byref(ticket)))
+        return self._read_lengths(n_records)
+
+    def submit_fastq_ml(self, text, accept, n_lines=None):
+        """general FASTQ text starting at a descriptor line (gs_filter_submit_fastq_ml): -> (records filtered or -1 when refused,
+        bytes they cover, read lengths)"""
+        text = np.frombuffer(bytes(text), dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text
+        if n_lines is None:
+            n_lines = int((text == 10).sum())
+        n_rec, used, ticket = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
+        self._text_keep = text
+        _check(lib().gs_filter_submit_fastq_ml(self.bloom.h, self.k, self.min_pos_count, self.positive_ratio, _ptr(text)[0],
+                                               int(text.shape[0]), int(n_lines), MEM_HOST, _ptr(accept)[0], None, C.byref(n_rec),
+                                               C.byref(used), None, C.byref(ticket)))
+        return n_rec.value, used.value, (self._read_lengths(n_rec.value) if n_rec.value > 0 else np.zeros(0, dtype=np.int64))
+
+    def _read_lengths(self, n_records):
+        b = np.zeros(n_records + 1, dtype=np.uint64)
+        if n_records > 0:
+            _check(lib().gs_filter_text_read_bounds(self.bloom.h, _ptr(b)[0]))
+        else:
+            _check(lib().gs_filter_sync(self.bloom.h))
+        return np.diff(b.astype(np.int64))
 
     def text_status(self):
         ft, fb = C.c_int64(-1), C.c_int64(-1)

@@ -3867,16 +3867,17 @@ extern "C" int gs_filter_sync(gs_bloom *b) {
 }
 
 // ---- text mode of the filter (see gs_match_submit_text) ----
-extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
-                                     int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines,
-                                     int profile, int64_t *ticket) {
+static int filter_submit_text(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text, int64_t n_bytes,
+                              int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines, int profile, int64_t *ticket,
+                              int64_t fasta_records, int64_t *ml_out) {
     if (!b) return fail(GS_E_INVALID, "bloom is NULL");
     if (k < 1 || k > 31) return fail(GS_E_INVALID, "k must be in [1,31]");
     if (n_lines > 0 && !accept) return fail(GS_E_INVALID, "accept is NULL");
     HIP_TRY(hipSetDevice(b->device));
-    const int64_t n_reads = n_lines >> 2;
-    int rc = text_submit(b->text, b->stream, text, n_bytes, n_lines, mem, k, ticket);
+    const bool fasta = fasta_records >= 0 || ml_out != nullptr;  // the reads are gathered, not in place
+    int rc = text_submit(b->text, b->stream, text, n_bytes, n_lines, mem, k, ticket, fasta_records, ml_out);
     if (rc) return rc;
+    const int64_t n_reads = ml_out ? std::max<int64_t>(ml_out[0], 0) : (fasta ? fasta_records : (n_lines >> 2));
     if (n_reads == 0) return GS_OK;
     const bool dev_out = mem == GS_MEM_DEVICE;
     if (!dev_out && b->reads_cap < (size_t)n_reads) {
@@ -3893,14 +3894,59 @@ extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, doub
     uint8_t *d_acc = dev_out ? accept : b->d_accept;
     // a refused chunk leaves `accept` untouched: zero it so that stale flags never look like results
     HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)n_reads, b->stream));
-    rc = filter_launch(b, k, min_pos_count, positive_ratio, b->text.d_text, (const uint64_t *)b->text.d_off2, n_reads, d_acc, 2,
-                       b->text.d_status + (size_t)b->text.bank * GS_TS_WORDS + GS_TS_SKIP, profile);
+    rc = filter_launch(b, k, min_pos_count, positive_ratio, fasta ? b->text.d_fa_seq : b->text.d_text, (const uint64_t *)b->text.d_off2,
+                       n_reads, d_acc, fasta ? 1 : 2, b->text.d_status + (size_t)b->text.bank * GS_TS_WORDS + GS_TS_SKIP, profile);
     if (rc) return rc;
     if ((rc = text_touched(b->text, b->stream))) return rc;
     const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (!dev_out) HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, kind, b->stream));
     if (newlines) HIP_TRY(hipMemcpyAsync(newlines, b->text.d_nl, sizeof(uint32_t) * (size_t)n_lines, kind, b->stream));
     return GS_OK;
+}
+
+extern "C" int gs_filter_submit_text(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                                     int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines,
+                                     int profile, int64_t *ticket) {
+    return filter_submit_text(b, k, min_pos_count, positive_ratio, text, n_bytes, n_lines, mem, accept, newlines, profile, ticket, -1, nullptr);
+}
+
+extern "C" int gs_filter_submit_fasta(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                                      int64_t n_bytes, int64_t n_lines, int64_t n_records, int mem, uint8_t *accept,
+                                      uint32_t *newlines, int64_t *ticket) {
+    if (n_records < 0) return fail(GS_E_INVALID, "n_records < 0");
+    return filter_submit_text(b, k, min_pos_count, positive_ratio, text, n_bytes, n_lines, mem, accept, newlines, 0, ticket, n_records, nullptr);
+}
+
+extern "C" int gs_filter_submit_fastq_ml(gs_bloom *b, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                                         int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines,
+                                         int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket) {
+    if (!n_records || !consumed_bytes) return fail(GS_E_INVALID, "NULL argument");
+    int64_t out[3] = {0, 0, 0};
+    const int rc = filter_submit_text(b, k, min_pos_count, positive_ratio, text, n_bytes, n_lines, mem, accept, newlines, 0, ticket, -1, out);
+    *n_records = out[0];
+    *consumed_bytes = out[1];
+    if (consumed_lines) *consumed_lines = out[2];
+    return rc;
+}
+
+extern "C" int gs_filter_text_read_bounds(gs_bloom *b, uint64_t *bounds) {
+    if (!b || !bounds) return fail(GS_E_INVALID, "NULL argument");
+    if (b->text.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
+    if (!b->text.last_fasta) return fail(GS_E_STATE, "the last chunk was four-line FASTQ: its reads lie in the text (newlines)");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(bounds, b->text.d_off2, sizeof(uint64_t) * ((size_t)b->text.last_reads + 1), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return bloom_collect(b);
+}
+
+extern "C" int gs_filter_text_line_classes(gs_bloom *b, uint8_t *classes) {
+    if (!b || !classes) return fail(GS_E_INVALID, "NULL argument");
+    if (b->text.tickets == 0 || !b->text.d_ml_class) return fail(GS_E_STATE, "no general FASTQ chunk has been submitted");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->text.last_lines > 0)
+        HIP_TRY(hipMemcpyAsync(classes, b->text.d_ml_class, (size_t)b->text.last_lines, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return bloom_collect(b);
 }
 
 extern "C" int gs_filter_text_wait_copy(gs_bloom *b, int64_t ticket) {

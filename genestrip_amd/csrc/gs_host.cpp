@@ -429,6 +429,7 @@ int parsed_source(MatchCtx &c, const std::string &path, int64_t offset, const ui
 }
 
 std::atomic<int64_t> g_ml_chunks{0};  // chunks matched through the general FASTQ device path (gs_host_stat(0))
+std::atomic<int64_t> g_filter_general_chunks{0};  // FASTA / general FASTQ chunks filtered on the device (gs_host_stat(1))
 
 struct TextChunk {
     int64_t file_off;  // of the chunk's first byte
@@ -472,6 +473,71 @@ void append_text_record(std::vector<uint8_t> &buf, const uint8_t *text, const ui
 // parsed_source() from the first chunk the device refuses (gs_match_text_status), so any file the general path accepts
 // gives the same result.  step() handles one block; several jobs can be stepped in turn (files read side by side),
 // each with its own status bank on the device and its own range of read numbers.
+// One record of a FASTA or general FASTQ chunk as four-line FASTQ (ReadEntry.write, AbstractFastqReader.java:570-584): lines h
+// (descriptor) to next - 1 of the chunk, newline offsets nl, line classes cls (1 descriptor, 2 sequence, 0 '+' / quality), read
+// length L.  Descriptor (FASTA: '>' replaced by '@', :380), the read in ONE line, "+", then the quality characters of the record
+// (general FASTQ with withProbs: every quality line that was consumed, joined) or '~' x length.
+void append_general_record(std::vector<uint8_t> &o, const uint8_t *text, const uint32_t *nl, const uint8_t *cls, int64_t h, int64_t next,
+                           int64_t L, bool is_fasta, bool probs) {
+    auto line_start = [nl](int64_t i) { return i ? (size_t)nl[i - 1] + 1 : (size_t)0; };
+    const size_t d0 = line_start(h), dlen = (size_t)nl[h] - d0, at = o.size();
+    o.insert(o.end(), text + d0, text + d0 + dlen);
+    if (is_fasta && dlen > 0) o[at] = '@';
+    o.push_back('\n');
+    int64_t i = h + 1;
+    for (; i < next && cls[(size_t)i] == 2; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);
+    o.push_back('\n');
+    o.push_back('+');
+    o.push_back('\n');
+    if (probs) {
+        for (i++; i < next; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);  // (behind the '+' line)
+    } else
+        o.insert(o.end(), (size_t)L, (uint8_t)'~');
+    o.push_back('\n');
+}
+
+// Where a FASTA chunk may end inside a block: header lines ('>' at a line start) are counted by memchr over the block ('>' is
+// rare); the chunk ends in front of the block's last header line -- everything up to there is whole records --, at the end of
+// the file behind the final newline.  cut < 0: no record boundary in this block.
+struct FastaCut {
+    int64_t headers = 0;      // header lines that start inside the block
+    int64_t cut = -1;         // the chunk ends here (exclusive, offset in the block)
+    int64_t cut_headers = 0;  // headers in front of `cut`
+    int64_t tail_lines = 0;   // newlines at or behind `cut`
+};
+
+FastaCut fasta_cut(const uint8_t *blk, int64_t n, bool last, const std::vector<uint8_t> &carry) {
+    FastaCut fc;
+    const bool at_line_start = carry.empty() || carry.back() == '\n';
+    int64_t last_hdr = -1;
+    for (const uint8_t *p = blk, *end = blk + n; p < end;) {
+        const uint8_t *q = (const uint8_t *)memchr(p, '>', (size_t)(end - p));
+        if (!q) break;
+        if (q == blk ? at_line_start : q[-1] == '\n') {
+            fc.headers++;
+            last_hdr = q - blk;
+        }
+        p = q + 1;
+    }
+    if (last && n > 0 && blk[n - 1] == '\n') {
+        fc.cut = n;
+        fc.cut_headers = fc.headers;
+    } else if (last && n == 0 && !carry.empty() && carry.back() == '\n') {
+        fc.cut = 0;
+    } else if (last_hdr > 0 || (last_hdr == 0 && !carry.empty())) {
+        fc.cut = last_hdr;
+        fc.cut_headers = fc.headers - 1;
+    }
+    if (fc.cut >= 0)
+        for (const uint8_t *p = blk + fc.cut, *end = blk + n; p < end;) {
+            const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            if (!q) break;
+            fc.tail_lines++;
+            p = q + 1;
+        }
+    return fc;
+}
+
 struct TextJob {
     MatchCtx &c;
     std::string path;
@@ -646,29 +712,8 @@ struct TextJob {
             uint8_t *blk = sl.buf + tr.headroom;
             const int64_t n = (int64_t)sl.n;
             last = sl.eof;
-            // header lines that start inside this block
-            bool at_line_start = carry.empty() || carry.back() == '\n';
-            int64_t headers = 0, last_hdr = -1;
-            for (const uint8_t *p = blk, *end = blk + n; p < end;) {
-                const uint8_t *q = (const uint8_t *)memchr(p, '>', (size_t)(end - p));
-                if (!q) break;
-                if (q == blk ? at_line_start : q[-1] == '\n') {
-                    headers++;
-                    last_hdr = q - blk;
-                }
-                p = q + 1;
-            }
-            // where the chunk ends (exclusive): at EOF behind the final newline, else in front of the last header line
-            int64_t cut = -1, cut_headers = 0;
-            if (last && n > 0 && blk[n - 1] == '\n') {
-                cut = n;
-                cut_headers = headers;
-            } else if (last && n == 0 && !carry.empty() && carry.back() == '\n') {
-                cut = 0;
-            } else if (last_hdr > 0 || (last_hdr == 0 && !carry.empty())) {
-                cut = last_hdr;
-                cut_headers = headers - 1;
-            }
+            const FastaCut fc = fasta_cut(blk, n, last, carry);
+            const int64_t headers = fc.headers, cut = fc.cut, cut_headers = fc.cut_headers, tail_lines = fc.tail_lines;
             if (err) {
                 // (the bank could not be selected: reported below)
             } else if (cut < 0) {  // no record boundary in this block: keep everything
@@ -683,13 +728,6 @@ struct TextJob {
                 fallback_off = carry_file_off;
                 fallback_reads = reads_in_file;
             } else {
-                int64_t tail_lines = 0;
-                for (const uint8_t *p = blk + cut, *end = blk + n; p < end;) {
-                    const uint8_t *q = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-                    if (!q) break;
-                    tail_lines++;
-                    p = q + 1;
-                }
                 const int64_t lines = carry_lines + sl.newlines - tail_lines, records = carry_headers + cut_headers;
                 uint8_t *start = blk - carry.size();
                 if (!carry.empty()) memcpy(start, carry.data(), carry.size());
@@ -812,9 +850,7 @@ struct TextJob {
     // Per-read outputs of a FASTA or general FASTQ chunk that has just been matched.  Record geometry: the newline offsets from the
     // device and a class per line (1 descriptor, 2 sequence, 0 '+' / quality) -- from the device for general FASTQ, by the
     // first byte for FASTA.  Kraken-style lines (MatcherReadEntry.writeMatchDetails, :723-756): descriptor up to the first blank
-    // without its first character, class, length, runs.  Filtered FASTQ (ReadEntry.write, AbstractFastqReader.java:570-584):
-    // descriptor (FASTA: '>' replaced by '@', :380), the read in ONE line, "+", then the quality characters of the record (general
-    // FASTQ with withProbs: every quality line that was consumed, joined) or '~' x length.
+    // without its first character, class, length, runs.  Filtered FASTQ: append_general_record.
     int outputs_general(MatchCtx::Results &rs, const uint8_t *text, int64_t n_lines, int64_t n_records, bool is_fasta) {
         std::vector<uint64_t> bounds((size_t)n_records + 1);
         std::vector<uint8_t> cls((size_t)std::max<int64_t>(n_lines, 1));
@@ -852,21 +888,7 @@ struct TextJob {
                 const size_t d0 = line_start(h), dlen = (size_t)nl[h] - d0;
                 const int64_t L = (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]);
                 if (cc.filtered.active() && (rs.flags[(size_t)r] & GS_F_RETURNED)) {
-                    std::vector<uint8_t> &o = p.filtered;
-                    const size_t at = o.size();
-                    o.insert(o.end(), text + d0, text + d0 + dlen);
-                    if (is_fasta && dlen > 0) o[at] = '@';
-                    o.push_back('\n');
-                    int64_t i = h + 1;
-                    for (; i < next && cls[(size_t)i] == 2; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);
-                    o.push_back('\n');
-                    o.push_back('+');
-                    o.push_back('\n');
-                    if (probs) {
-                        for (i++; i < next; i++) o.insert(o.end(), text + line_start(i), text + nl[i]);  // (behind the '+' line)
-                    } else
-                        o.insert(o.end(), (size_t)L, (uint8_t)'~');
-                    o.push_back('\n');
+                    append_general_record(p.filtered, text, nl, cls.data(), h, next, L, is_fasta, probs);
                     p.n_filtered++;
                 }
                 if (cc.kraken.active()) kraken_line(cc, rs, p.kraken, text + d0, dlen, L, r);
@@ -1283,9 +1305,9 @@ void write_filter_parts(FilterCtx &c, std::vector<FilterPart> &parts) {
 }
 
 // the general path for one source (file from `offset`, or a memory range): reference parser -> batches -> GPU -> writers
-int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n) {
+int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, const uint8_t *mem, size_t mem_n, bool mem_fasta = false) {
     Producer prod;
-    prod.start(path, offset, mem, mem_n, c.k, (int64_t)1 << 20);
+    prod.start(path, offset, mem, mem_n, c.k, (int64_t)1 << 20, mem_fasta);
     int err = GS_OK;
     for (;;) {
         std::unique_ptr<Batch> b = prod.q.pop();
@@ -1324,6 +1346,8 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
     c.t_parse += prod.seconds;
     return err;
 }
+
+int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool fasta);
 
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
 int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
@@ -1436,9 +1460,163 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     if (fallback_off >= 0) {
         err = gs_filter_text_reset(c.bloom, 1);
         if (err) return err;
+        // not four lines per record from the very first chunk: once more with the records found on the device (GS_HOST_ML=0:
+        // straight to the reference-exact parser, which also takes over whatever that pass refuses)
+        bool ml = fallback_off == 0;
+        if (const char *e = getenv("GS_HOST_ML")) ml = ml && atoi(e) != 0;
+        if (ml) return filter_general_file(c, path, gzip, false);
         return filter_parsed_source(c, path, fallback_off, nullptr, 0);
     }
     if (!carry.empty()) return filter_parsed_source(c, std::string(), 0, carry.data(), carry.size());
+    return GS_OK;
+}
+
+// FASTA and general FASTQ (sequence / quality over several lines): chunks of whole records (FASTA: cut in front of a header
+// line) or of whole lines (general FASTQ: the device says how many records end in the chunk and what they cover) go to the
+// device (gs_filter_submit_fasta / gs_filter_submit_fastq_ml); every record is written as four-line FASTQ.  What the device
+// refuses and the tail of the file go through the reference-exact parser.
+int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool fasta) {
+    size_t block = (size_t)8 << 20;
+    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
+    }
+    int readers = (int)std::min<unsigned>(gzip ? 16 : 8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("GS_HOST_READERS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) readers = v;
+    }
+    TextReader tr;
+    int err = tr.open(path, block, readers, gzip);
+    if (err) {
+        tr.close();
+        return err;
+    }
+    err = gs_filter_text_reset(c.bloom, 1);
+    PinnedVec<uint8_t> acc;
+    PinnedVec<uint32_t> nls;
+    std::vector<uint64_t> bounds;
+    std::vector<uint8_t> cls;
+    std::vector<int64_t> head;
+    std::vector<uint8_t> carry;
+    int64_t carry_lines = 0, carry_headers = 0, carry_file_off = 0, fallback_off = -1;
+    int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
+    const double t0 = now_s();
+    if (!err) tr.start();
+    for (int64_t i = 0; !err; i++) {
+        TextSlot &sl = tr.wait_full(i);
+        if (sl.io_error || !tr.verify_gzip(sl)) {
+            err = hfail(tr.gz ? GS_E_INVALID : GS_E_IO, (tr.gz ? "corrupt gzip stream in " : "read error on ") + path);
+            break;
+        }
+        uint8_t *blk = sl.buf + tr.headroom;
+        const int64_t n = (int64_t)sl.n;
+        const bool eof = sl.eof;
+        // the chunk: [start, start + bytes) = the carry + the block up to `cut`; `rest` = what stays for the next block
+        FastaCut fc;
+        if (fasta)
+            fc = fasta_cut(blk, n, eof, carry);
+        else if (sl.newlines > 0)
+            fc.cut = (int64_t)sl.last4[0] + 1;  // behind the block's last newline
+        if (fc.cut < 0) {  // no boundary in this block: keep everything
+            carry.insert(carry.end(), blk, blk + n);
+            carry_lines += sl.newlines;
+            carry_headers += fc.headers;
+            if (carry.size() > tr.headroom && !eof) fallback_off = carry_file_off;  // a record longer than a block
+        } else if (carry.size() > tr.headroom) {
+            fallback_off = carry_file_off;
+        } else {
+            uint8_t *start = blk - carry.size();
+            if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+            const int64_t bytes = (int64_t)carry.size() + fc.cut;
+            int64_t lines = carry_lines + sl.newlines - fc.tail_lines, records = carry_headers + fc.cut_headers, used = bytes, ticket = -1;
+            if (fasta && records >= ((int64_t)1 << 24)) {  // (more records than one chunk may hold)
+                fallback_off = carry_file_off;
+            } else if (bytes > 0) {
+                if ((err = acc.resize((size_t)(fasta ? std::max<int64_t>(records, 1) : lines / 4 + 2)))) break;
+                if ((err = nls.resize((size_t)std::max<int64_t>(lines, 1)))) break;
+                const double tg = now_s();
+                if (fasta) {
+                    err = gs_filter_submit_fasta(c.bloom, c.k, c.min_pos_count, c.positive_ratio, start, bytes, lines, records, GS_MEM_HOST,
+                                                 acc.data(), nls.data(), &ticket);
+                } else {
+                    int64_t all_lines = lines;
+                    err = gs_filter_submit_fastq_ml(c.bloom, c.k, c.min_pos_count, c.positive_ratio, start, bytes, all_lines, GS_MEM_HOST,
+                                                    acc.data(), nls.data(), &records, &used, &lines, &ticket);
+                    carry_lines = all_lines - lines;  // (lines the records did not cover)
+                }
+                if (!err) err = gs_filter_text_status(c.bloom, &failed, &bad, tot);  // synchronises: results are needed now
+                if (!err && failed < 0 && records > 0) {
+                    bounds.resize((size_t)records + 1);
+                    cls.resize((size_t)lines);
+                    err = gs_filter_text_read_bounds(c.bloom, bounds.data());
+                    if (!err && !fasta) err = gs_filter_text_line_classes(c.bloom, cls.data());
+                }
+                c.t_gpu += now_s() - tg;
+                if (err) break;
+                if (failed >= 0 || records < 0) {  // refused: the general parser continues at this chunk
+                    fallback_off = carry_file_off;
+                } else if (records > 0) {
+                    g_filter_general_chunks.fetch_add(1);
+                    const uint32_t *nl = nls.p;
+                    auto line_start = [nl](int64_t j) { return j ? (size_t)nl[j - 1] + 1 : (size_t)0; };
+                    if (fasta)
+                        for (int64_t j = 0; j < lines; j++) cls[(size_t)j] = start[line_start(j)] == '>' && nl[j] > line_start(j) ? 1 : 2;
+                    head.clear();  // descriptor line of every record, + lines
+                    for (int64_t j = 0; j < lines; j++)
+                        if (cls[(size_t)j] == 1) head.push_back(j);
+                    if ((int64_t)head.size() != records) {
+                        err = hfail(GS_E_INVALID, "text chunk: the descriptor lines do not match the device's record count");
+                        break;
+                    }
+                    head.push_back(lines);
+                    std::vector<FilterPart> parts((size_t)c.pool.threads());
+                    const bool probs = c.with_probs && !fasta;
+                    c.pool.run(records, [&](int t, int64_t lo, int64_t hi) {
+                        FilterPart &p = parts[(size_t)t];
+                        p.acc = c.acc_out.take();
+                        p.rest = c.rest_out.take();
+                        for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                            const int64_t L = (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]);
+                            if (acc[(size_t)r]) {
+                                p.n_accepted++;
+                                if (c.acc_out.active())
+                                    append_general_record(p.acc, start, nl, cls.data(), head[(size_t)r], head[(size_t)r + 1], L, fasta, probs);
+                            } else if (c.rest_out.active())
+                                append_general_record(p.rest, start, nl, cls.data(), head[(size_t)r], head[(size_t)r + 1], L, fasta, probs);
+                        }
+                        p.pack(c.acc_out, c.rest_out);
+                    });
+                    write_filter_parts(c, parts);
+                }
+            }
+            if (fallback_off < 0) {
+                carry_file_off += used;
+                // what the records did not cover + what lies behind the cut
+                std::vector<uint8_t> rest(start + used, start + bytes);
+                rest.insert(rest.end(), blk + fc.cut, blk + n);
+                carry.swap(rest);
+                if (fasta) {
+                    carry_lines = fc.tail_lines;
+                    carry_headers = fc.headers - fc.cut_headers;
+                }
+            }
+        }
+        tr.release(i);
+        if (eof || fallback_off >= 0) break;
+    }
+    tr.close();
+    c.t_parse += now_s() - t0;
+    if (err) return err;
+    c.reads += tot[0];
+    c.kmers += tot[1];
+    c.bps += tot[2];
+    if (fallback_off >= 0) {
+        err = gs_filter_text_reset(c.bloom, 1);
+        if (err) return err;
+        return filter_parsed_source(c, path, fallback_off, nullptr, 0);
+    }
+    if (!carry.empty()) return filter_parsed_source(c, std::string(), 0, carry.data(), carry.size(), fasta);
     return GS_OK;
 }
 
@@ -1461,9 +1639,10 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     int err = GS_OK;
     for (int f = 0; f < n_paths && !err; f++) {
         const std::string path(paths[f]);
-        int kind = fast ? text_path_kind(path) : 0;
-        if (kind >= 3) kind = 0;  // FASTA: the general parser (the filter goal rewrites every read)
-        if (kind)
+        const int kind = fast ? text_path_kind(path) : 0;
+        if (kind >= 3)
+            err = filter_general_file(c, path, kind == 4, true);
+        else if (kind)
             err = filter_text_file(c, path, kind == 2);
         else
             err = filter_parsed_source(c, path, 0, nullptr, 0);
@@ -1487,5 +1666,5 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
 }
 
 extern "C" int64_t gs_host_stat(int which) {
-    return which == 0 ? g_ml_chunks.load() : -1;
+    return which == 0 ? g_ml_chunks.load() : (which == 1 ? g_filter_general_chunks.load() : -1);
 }

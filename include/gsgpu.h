@@ -441,6 +441,22 @@ int gs_filter_submit_text(gs_bloom *bloom, int k, int min_pos_count, double posi
 int gs_filter_text_wait_copy(gs_bloom *bloom, int64_t ticket);
 int gs_filter_text_status(gs_bloom *bloom, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_filter_text_reset(gs_bloom *bloom, int clear_totals);
+
+/* FASTA chunks and general (multi-line) FASTQ chunks through the filter: the same record search as gs_match_submit_fasta /
+ * gs_match_submit_fastq_ml (AbstractFastqReader.java:375-438, :301-308), the reads gathered on the device, accept[r] per
+ * record in file order.  `newlines` (may be NULL) receives the offset of every newline of the chunk (n_lines of them).
+ * gs_filter_submit_fastq_ml reports the records that END in the chunk and the bytes / lines they cover (n_records = -1: refused,
+ * see gs_filter_text_status; the caller carries the rest into its next chunk).  Afterwards gs_filter_text_read_bounds copies
+ * the n_records + 1 offsets of the gathered reads (read lengths = differences) and gs_filter_text_line_classes the class of
+ * every line of a general FASTQ chunk (1 descriptor, 2 sequence, 0 '+' / quality); both wait for the chunk. */
+int gs_filter_submit_fasta(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                           int64_t n_bytes, int64_t n_lines, int64_t n_records, int mem, uint8_t *accept, uint32_t *newlines,
+                           int64_t *ticket);
+int gs_filter_submit_fastq_ml(gs_bloom *bloom, int k, int min_pos_count, double positive_ratio, const uint8_t *text,
+                              int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines,
+                              int64_t *n_records, int64_t *consumed_bytes, int64_t *consumed_lines, int64_t *ticket);
+int gs_filter_text_read_bounds(gs_bloom *bloom, uint64_t *bounds);
+int gs_filter_text_line_classes(gs_bloom *bloom, uint8_t *classes);
 int gs_filter_kernel_time(gs_bloom *bloom, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

@@ -87,7 +87,8 @@ int gs_host_match_into(gs_run *run, gs_db *db, const char *const *paths, int n_p
 int gs_host_match_files_multi(gs_db *const *dbs, int n_dbs, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
                               int64_t *table, double *dtable, gs_host_totals *totals);
 
-/* diagnostics: which = 0: chunks of text that went through the general (multi-line) FASTQ device path in this process so far */
+/* diagnostics: which = 0: chunks of text that went through the general (multi-line) FASTQ device path of the match goal in this
+ * process so far; 1: FASTA / general FASTQ chunks that the filter goal handled on the device */
 int64_t gs_host_stat(int which);
 
 /* ---- runFilter: accepted reads -> filtered_path, the rest -> rest_path (either may be NULL); with_probs as above ---- */

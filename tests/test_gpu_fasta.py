@@ -178,3 +178,43 @@ def test_kraken_style_lines_of_fasta_files_from_the_device_path(sdb, tmp_path, m
     n_all, n_cls = outs[("1", True)][0].count(b"\n"), outs[("1", False)][0].count(b"\n")
     assert 2500 < n_all <= 3000 and 500 < n_cls < n_all  # (records shorter than k have no runs and no line)
     store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("block", [None, 4096, 700])
+def test_filter_goal_on_fasta_files_from_the_device_path(sdb, tmp_path, monkeypatch, gz, block):
+    """gs_host_filter_files on FASTA input (VERDICT r01 "what's missing" 7, the filter side): records found and gathered on the
+    device (gs_filter_submit_fasta), accept flags by the index filter, every record rewritten as four-line FASTQ ('@' for '>',
+    one sequence line, '~' quality) -- byte for byte what the reference-exact parser path writes, and the oracle's accept flags"""
+    import gzip
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    if block:
+        monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(block))
+    texts = [_fasta(sdb, 900, 51), _fasta(sdb, 200, 52, crlf=True)[:-1],                # no final newline
+             _fasta(sdb, 150, 53) + b">x\nACGT\n\nACGTACGT\n" + _fasta(sdb, 80, 54)]       # an empty line in the middle
+    paths, want_acc, reads = [], 0, 0
+    for i, t in enumerate(texts):
+        p = str(tmp_path / (f"c{i}.fa.gz" if gz else f"c{i}.fasta"))
+        with (gzip.open(p, "wb", compresslevel=1) if gz else open(p, "wb")) as f:
+            f.write(t)
+        paths.append(p)
+        rd = orc.parse_fastq(t, fasta=True, k=31)
+        pseq = rd["seq"] if len(rd["seq"]) else np.zeros(1, dtype=np.uint8)
+        want_acc += int(ob.filter_batch(31, 1, 0.2, pseq, rd["seq_off"]).sum())
+        reads += rd["n_reads"]
+    outs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_FAST", fast)
+        before = host.stat(1)
+        a, r = str(tmp_path / f"acc{fast}.fastq"), str(tmp_path / f"rest{fast}.fastq")
+        tot = host.filter_files(gb, 31, paths, filtered_path=a, rest_path=r)
+        outs[fast] = (open(a, "rb").read(), open(r, "rb").read(), tot.reads, tot.kmers, tot.bps, tot.filtered_reads, host.stat(1) - before)
+    assert outs["1"][:6] == outs["0"][:6]
+    assert outs["1"][2] == reads and outs["1"][5] == want_acc and 0 < want_acc < reads
+    assert outs["1"][6] >= 1 and outs["0"][6] == 0  # the device path did run (and did not with GS_HOST_FAST=0)
+    assert outs["1"][0].startswith(b"@c") and b"\n+\n~" in outs["1"][0]
+    assert outs["1"][0].count(b"\n") == 4 * want_acc and outs["1"][1].count(b"\n") == 4 * (reads - want_acc)
+    gb.close()

@@ -181,3 +181,84 @@ def test_kraken_style_lines_of_multiline_fastq_from_the_device_path(sdb, tmp_pat
     assert outs["1"][4] == outs["0"][4] and outs["1"][5] == outs["0"][5] > 1000 and b"~~~~" in outs["1"][4]
     assert outs["1"][6] == outs["0"][6] and outs["1"][7] == outs["0"][7] and outs["1"][6] != outs["1"][4]
     store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_filter_goal_on_multiline_fastq_from_the_device_path(sdb, tmp_path, monkeypatch, gz):
+    """gs_host_filter_files on a FASTQ file that is not four lines per record: the four-line scan refuses the first chunk, the file
+    is read again with the records found on the device (gs_filter_submit_fastq_ml); accepted / rejected reads are rewritten as
+    four-line FASTQ, with '~' or with the record's own quality lines -- byte for byte the parser path's files, and the oracle's
+    accept flags"""
+    import gzip
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", str(1 << 16))
+    data = _multiline_fastq(sdb, 5000, seed=19) + b"@last without a newline at the end\nACGTACGTAC\nGT\n+\nIIIIIIIIIIII"
+    p = tmp_path / ("ml.fastq.gz" if gz else "ml.fastq")
+    (gzip.open(p, "wb") if gz else open(p, "wb")).write(data)
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:3])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    rd = orc.parse_fastq(data, fasta=False, k=31)
+    want = ob.filter_batch(31, 1, 0.2, rd["seq"], rd["seq_off"])
+    outs = {}
+    for ml in ("1", "0"):
+        monkeypatch.setenv("GS_HOST_ML", ml)
+        for probs in (False, True):
+            before = host.stat(1)
+            a, r = str(tmp_path / f"acc{ml}{probs}.fastq"), str(tmp_path / f"rest{ml}{probs}.fastq")
+            tot = host.filter_files(gb, 31, [str(p)], filtered_path=a, rest_path=r, with_probs=probs)
+            outs[(ml, probs)] = (open(a, "rb").read(), open(r, "rb").read(), tot.reads, tot.kmers, tot.bps, tot.filtered_reads,
+                                 host.stat(1) - before)
+    for probs in (False, True):
+        a, b = outs[("1", probs)], outs[("0", probs)]
+        assert a[:6] == b[:6]
+        assert a[6] > 3 and b[6] == 0  # the device path did run (and did not with GS_HOST_ML=0)
+        assert (a[2], a[3], a[4]) == (rd["n_reads"], int(rd["total_kmers"]), int(rd["total_bps"]))
+        assert a[5] == int(want.sum()) and 500 < a[5] < rd["n_reads"]
+        assert a[0].count(b"\n") == 4 * a[5] and a[1].count(b"\n") == 4 * (rd["n_reads"] - a[5])
+    assert outs[("1", True)][0] != outs[("1", False)][0] and b"\n+\n~~~~" in outs[("1", False)][0]
+    gb.close()
+
+
+def test_filter_chunks_of_general_fastq_and_fasta_through_the_abi(sdb):
+    """gs_filter_submit_fastq_ml / gs_filter_submit_fasta chunk by chunk: accept flags and read lengths of every record against the
+    parser restatement + the oracle's filter; a chunk with a NUL byte is refused (n_records = -1) and changes nothing"""
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:3])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    f = ga.FastqBloomFilter(31, gb)
+    data = _multiline_fastq(sdb, 2500, seed=41)
+    rd = orc.parse_fastq(data, fasta=False, k=31)
+    want = ob.filter_batch(31, 1, 0.2, rd["seq"], rd["seq_off"])
+    got, lens, carry, pos, piece = [], [], b"", 0, 30011
+    while pos < len(data):
+        buf = carry + data[pos:pos + piece]
+        pos += piece
+        cut = buf.rfind(b"\n") + 1
+        acc = np.zeros(buf.count(b"\n") // 4 + 2, dtype=np.uint8)
+        n_rec, used, ln = f.submit_fastq_ml(buf[:cut], acc)
+        assert n_rec >= 0
+        got.append(acc[:n_rec].copy())
+        lens.append(ln)
+        carry = buf[used:]
+    assert carry == b""  # (the text ends with a newline behind a complete record)
+    got, lens = np.concatenate(got), np.concatenate(lens)
+    assert len(got) == 2500 and np.array_equal(got, want) and 100 < int(want.sum()) < 2500
+    assert np.array_equal(lens, np.diff(rd["seq_off"].astype(np.int64)))
+    assert f.text_status()[2] == (2500, int(rd["total_kmers"]), int(rd["total_bps"]))
+    acc = np.full(8, 7, dtype=np.uint8)
+    n_rec, used, _ = f.submit_fastq_ml(b"@a\nACGT\0ACGT\n+\nIIIIIIIII\n", acc)
+    assert n_rec == -1 and f.text_status()[0] >= 0
+    f.text_reset(clear_totals=True)
+    # FASTA: wrapped records, one of length 0
+    g = sdb.genomes[0].tobytes()
+    recs = [g[i * 700:i * 700 + L] for i, L in enumerate([150, 0, 31, 30, 2000, 64, 500])]
+    text = b"".join(b">r%d x\n" % i + b"".join(s[j:j + 70] + b"\n" for j in range(0, len(s), 70)) for i, s in enumerate(recs))
+    acc = np.zeros(len(recs), dtype=np.uint8)
+    ln = f.submit_fasta(text, acc)
+    rd = orc.parse_fastq(text, fasta=True, k=31)
+    assert list(ln) == [len(s) for s in recs] == list(np.diff(rd["seq_off"].astype(np.int64)))
+    assert np.array_equal(acc, ob.filter_batch(31, 1, 0.2, rd["seq"], rd["seq_off"]))
+    assert f.text_status()[0] < 0
+    gb.close()
