@@ -292,7 +292,7 @@ struct StoreImage {
     const u64 *rec = nullptr;
     size_t rec_words = 0;
     const int32_t *parent = nullptr, *depth = nullptr, *tin = nullptr, *tout = nullptr;
-};
+};  // (table / gate / mgate / rec may lie in host memory or in a device's: store_upload copies with hipMemcpyDefault)
 
 // one handle: the whole store (stripes <= 1), or stripe `part` of `stripes` -- the record buckets gs_stripe_first(part) up
 // to gs_stripe_first(part + 1) and the table buckets gs_tab_stripe_first(..) in ONE allocation (one IPC handle), and
@@ -321,23 +321,23 @@ static int store_upload(const StoreImage &im, int dev_no, int stripes, int part,
     hipError_t e = hipSuccess;
     if (stripes > 1) {
         e = hipMalloc((void **)&db->d_rec, rbytes + tbytes);
-        if (e == hipSuccess) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyDefault);
         if (e == hipSuccess) db->d_table = db->d_rec + (size_t)rlocal * GS_REC_WORDS;
     } else {
         e = hipMalloc((void **)&db->d_table, tbytes);
         if (e == hipSuccess && rbytes) e = hipMalloc((void **)&db->d_rec, rbytes);
-        if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess && rbytes) e = hipMemcpy(db->d_rec, rsrc, rbytes, hipMemcpyDefault);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&db->d_tree, sizeof(int32_t) * 4 * (size_t)n_values);
     if (e == hipSuccess && im.gate_words) e = hipMalloc((void **)&db->d_gate, im.gate_words * sizeof(u64));
-    if (e == hipSuccess && im.gate_words) e = hipMemcpy(db->d_gate, im.gate, im.gate_words * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && im.gate_words) e = hipMemcpy(db->d_gate, im.gate, im.gate_words * sizeof(u64), hipMemcpyDefault);
     if (e == hipSuccess && im.mgate_words) e = hipMalloc((void **)&db->d_mgate, im.mgate_words * sizeof(uint32_t));
-    if (e == hipSuccess && im.mgate_words) e = hipMemcpy(db->d_mgate, im.mgate, im.mgate_words * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_table, tsrc, tbytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree, im.parent, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, im.depth, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, im.tin, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, im.tout, sizeof(int32_t) * n_values, hipMemcpyHostToDevice);
+    if (e == hipSuccess && im.mgate_words) e = hipMemcpy(db->d_mgate, im.mgate, im.mgate_words * sizeof(uint32_t), hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(db->d_table, tsrc, tbytes, hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree, im.parent, sizeof(int32_t) * n_values, hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + n_values, im.depth, sizeof(int32_t) * n_values, hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 2 * (size_t)n_values, im.tin, sizeof(int32_t) * n_values, hipMemcpyDefault);
+    if (e == hipSuccess) e = hipMemcpy(db->d_tree + 3 * (size_t)n_values, im.tout, sizeof(int32_t) * n_values, hipMemcpyDefault);
     if (e != hipSuccess) {
         if (stripes > 1) db->d_table = nullptr;  // (inside d_rec)
         db_free(db);
@@ -867,19 +867,14 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
             }
             if (drc != 0) return drc < 0 ? drc : GS_OK;
         } else if (on_device) {
-            // a striped store: the layout on one device (the first stripe's, or this process's), its image to the host, the
-            // stripes cut from that
+            // a striped store: the layout on one device (the first stripe's, or this process's), the stripes cut from that
             gs_db *whole = nullptr;
             const int bdev = stripe_only >= 0 ? device : stripe_devices[0];
             HIP_TRY(hipSetDevice(bdev));
             const int drc = db_create_on_device(&whole, bdev, k, n, kmers, vidx, n_values, parent, depth, tin, tout, trace);
             if (drc < 0) return drc;
             if (drc == 1) {
-                std::vector<u64> h_table((size_t)whole->info.n_buckets * GS_SLOTS_PER_BUCKET), h_rec((size_t)whole->n_rec * GS_REC_WORDS);
-                std::vector<uint32_t> h_mgate((size_t)1 << whole->dev.mgate_bits);
-                hipError_t e = hipMemcpy(h_table.data(), whole->d_table, h_table.size() * sizeof(u64), hipMemcpyDeviceToHost);
-                if (e == hipSuccess) e = hipMemcpy(h_rec.data(), whole->d_rec, h_rec.size() * sizeof(u64), hipMemcpyDeviceToHost);
-                if (e == hipSuccess) e = hipMemcpy(h_mgate.data(), whole->d_mgate, h_mgate.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                // (the stripes are copied out of the build's arrays, device to device: no host image)
                 StoreImage im{};
                 im.k = k;
                 im.n_values = n_values;
@@ -890,20 +885,18 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 im.vbits = (int)whole->dev.vbits;
                 im.rec_bits = (int)whole->dev.rec_bits;
                 im.max_disp = whole->info.max_displacement;
-                db_free(whole);
-                if (e != hipSuccess) return fail(GS_E_HIP, std::string("striped store: image of the device build: ") + hipGetErrorString(e));
-                trace.mark("device: image to the host");
-                im.table = h_table.data();
-                im.table_words = h_table.size();
-                im.mgate = h_mgate.data();
-                im.mgate_words = h_mgate.size();
-                im.rec = h_rec.data();
-                im.rec_words = h_rec.size();
+                im.table = whole->d_table;
+                im.table_words = (size_t)whole->info.n_buckets * GS_SLOTS_PER_BUCKET;
+                im.mgate = whole->d_mgate;
+                im.mgate_words = (size_t)1 << whole->dev.mgate_bits;
+                im.rec = whole->d_rec;
+                im.rec_words = (size_t)whole->n_rec * GS_REC_WORDS;
                 im.parent = parent.data();
                 im.depth = depth.data();
                 im.tin = tin.data();
                 im.tout = tout.data();
                 rc = store_place(im, device, stripes, stripe_devices, stripe_only, out);
+                db_free(whole);
                 trace.mark("stripes");
                 return rc;
             }

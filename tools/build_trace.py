@@ -15,3 +15,9 @@ for genera in [int(x) for x in sys.argv[1:]] or [25]:
     store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     print("genera %d: %d k-mers, gs_db_create %.2f s" % (genera, db.n_entries, time.time() - t0), flush=True)
     store.close()
+    if os.environ.get("GS_TRACE_STRIPED"):  # GS_TRACE_STRIPED=8: the same store as 8 stripes (here: all on device 0)
+        t0 = time.time()
+        ss = ga.DeviceKMerStore.striped(31, db.kmers, db.value_idx, db.n_values, db.parent_vi, devices=(0,) * int(os.environ["GS_TRACE_STRIPED"]))
+        print("genera %d: striped create %.2f s" % (genera, time.time() - t0), flush=True)
+        for x in ss:
+            x.close()
