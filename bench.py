@@ -11,7 +11,7 @@ extra objects for the workloads the headline does not show:
   filter        the `filter` goal's kernel against the XOR index filter of the same store (~47 M keys, 27 hashes)
   end_to_end    configs[1] again with the reads in page-locked HOST memory (gs_match_submit_async: PCIe included)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S] [--legs main,large,filter,e2e]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S] [--legs main,large,filter,e2e,striped,dbbuild,long]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 GS_BENCH_FORCE_MERGE=1 runs the RCCL merge path even at N = 1 (rehearsal of the multi-GPU code on one GPU).
@@ -98,7 +98,7 @@ def main():
                     help="--mode striped with ONE rank: stripes of the record table, all in this GPU's HBM (prices the "
                          "stripe arithmetic of the kernel; with N ranks there is one stripe per rank)")
     ap.add_argument("--genera", type=int, default=0, help="size of the synthetic store: genera of 20 species (0: configs[1]'s store)")
-    ap.add_argument("--legs", default="main,large,filter,e2e,striped,dbbuild",
+    ap.add_argument("--legs", default="main,large,filter,e2e,striped,dbbuild,long",
                     help="comma list; large / filter / e2e / striped are the extra N = 1 objects (main always runs)")
     args = ap.parse_args()
     legs = set(args.legs.split(","))
@@ -320,6 +320,8 @@ def main():
                 out["striped_store"] = leg_striped(ga, db, local_rank, dseq, doff, n, nchk, otable, kern_ms)
             if "e2e" in legs:
                 out["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
+            if "long" in legs:
+                out["long_reads"] = leg_long_reads(ga, synth, orc, torch, db, gen, m, dev, cores)
             m.close()
             store.close()
             del dseq, doff
@@ -355,6 +357,39 @@ def leg_striped(ga, db, device, dseq, doff, n, nchk, otable, plain_ms, stripes=8
     return {"stripes": stripes, "stripe_bytes": int(info.stripe_bytes), "kernel_ms": round(kms, 4),
             "gbps": round(n * READ_LEN / kms / 1e6, 2), "kernel_ms_plain_store": round(plain_ms, 4),
             "over_plain": round(kms / plain_ms, 4), "where": "all stripes in this GPU's HBM (no xGMI hop in this number)",
+            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
+
+
+def leg_long_reads(ga, synth, orc, torch, db, gen, m, dev, cores, read_len=1000, n=1_500_000, nchk=20_000):
+    """The same store and the same number of bases as configs[1], as reads of 1000 bp: more than 128 k-mer positions, so they
+    take gs_match_long_kernel (one wave per read, 128 positions per iteration, contig / vote state carried from iteration to
+    iteration; queued by gs_match_kernel in chunks, drawn from a shared cursor).  Whole step (reset, submit, sync) by the
+    host clock, best of 3.  Parity: the first nchk reads against the oracle table."""
+    dseq = torch.empty(n * read_len, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=read_len)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(4):
+        m.reset()
+        m.sync()
+        t0 = time.perf_counter()
+        m.submit(dseq, doff, 0, n_reads=n)
+        m.sync()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    m.reset()
+    m.submit(dseq, doff, 0, n_reads=nchk)
+    table, _ = m.finish()
+    seq, off = synth.reads_host(db.genomes, nchk, read_len=read_len)
+    odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    orun = orc.MatchRun(odb)
+    orun.submit(seq, off, threads=cores, per_read=False)
+    otable, _ = orun.finish()
+    odb.close()
+    del dseq, doff
+    return {"workload": "match: %d reads x %d bp, k=%d, the configs[1] store" % (n, read_len, K), "kernel": "gs_match_kernel (queues) + gs_match_long_kernel",
+            "ms_per_step": round(best * 1e3, 3), "gbps": round(n * read_len / best / 1e9, 2),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
 
 

@@ -43,6 +43,7 @@ extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid,
 extern "C" hipError_t gs_launch_stat_reduce(const GsStatRec *recs, const void *count, int64_t n_max, int n_values, void *sums, void *maxk,
                                              void *dsums, hipStream_t stream);
 extern "C" int gs_match_occupancy(int n_values);
+extern "C" int gs_match_long_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
 
 // ---------------------------------------------------------------------------------------------------
@@ -2128,7 +2129,7 @@ static int run_clear(gs_run *run) {
         HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream));
     run->seen_dirty = false;
     run->bitmap_merged = false;
-    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 2 * sizeof(unsigned int), run->stream));
     return GS_OK;
 }
 
@@ -2216,7 +2217,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
     if (e == hipSuccess && cfg->max_kmer_res_counts > 0)
         e = hipMalloc((void **)&run->d_hit_counts, sizeof(uint32_t) * (size_t)(db->n_slots() + db->n_rec * GS_REC_SLOTS));
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, 2 * sizeof(unsigned int));  // queue length, consumer cursor
     if (e != hipSuccess) {
         run_free(run);
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("run alloc: ") + hipGetErrorString(e));
@@ -2255,18 +2256,28 @@ static int collect_events(gs_run *run) {
 }
 
 static int ensure_long(gs_run *run, int64_t n_reads) {
-    if (run->long_cap < n_reads) {
+    // (the queue is filled in chunks of 64 entries per wave of the match kernel: every wave may leave one partly used)
+    const int64_t room = n_reads + (int64_t)run->grid * (GS_BLOCK / 64) * 64;
+    if (run->long_cap < room) {
         HIP_TRY(hipStreamSynchronize(run->stream));
         hipFree(run->d_long_list);
         run->d_long_list = nullptr;
-        int64_t cap = std::max<int64_t>(n_reads, 1024);
+        int64_t cap = std::max<int64_t>(room, 1024);
         HIP_TRY(hipMalloc((void **)&run->d_long_list, sizeof(uint32_t) * (size_t)cap));
         run->long_cap = cap;
     }
     if (!run->d_scratch) {
-        // long-read kernel: a modest persistent grid, each wave owns tag[n_values] + cnt[n_values]
+        // long-read kernel: a persistent grid that fills the device (the widest variant's occupancy; one wave per SIMD ran
+        // 7-16x below the short-read kernel's rate per base), each wave owns tag[n_values] + cnt[n_values] in HBM
         const size_t nv = (size_t)run->db->info.n_values;
-        int grid = run->db->n_cu;
+        int occ = gs_match_long_occupancy((int)nv);
+        if (occ < 1) occ = 1;
+        if (occ > 8) occ = 8;
+        if (const char *e = getenv("GS_LONG_BLOCKS_PER_CU")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) occ = v;
+        }
+        int grid = run->db->n_cu * occ;
         while (grid > 8 && (size_t)grid * 4 * nv * 2 * sizeof(int32_t) > ((size_t)2 << 30)) grid /= 2;
         run->long_grid = grid;
         const size_t waves = (size_t)grid * (GS_BLOCK / 64);
@@ -2329,7 +2340,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         P.stat_recs = run->d_stat_recs;
         P.stat_rec_count = (unsigned long long *)run->d_stat_rec_count;
     }
-    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, sizeof(unsigned int), run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 2 * sizeof(unsigned int), run->stream));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (run->cfg.profile) {
         HIP_TRY(hipEventCreate(&e0));

@@ -36,6 +36,8 @@
 #define GS_NODE_MISS (-1)
 #define GS_NODE_INVALID (-2)
 #define GS_NODE_NONE (-3)
+#define GS_LONG_CHUNK 64           // entries of the long-read queue a wave reserves at a time (one atomic per chunk)
+#define GS_LONG_NONE 0xffffffffu   // padding of a chunk (a batch holds at most 2^32 - 1 reads)
 
 typedef unsigned long long u64;
 
@@ -1026,6 +1028,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         s_cur[wave_in_block][1] = 64;
     }
     GS_STRIPE_TABLE((const GsMatchParams *)kp0)
+    uint32_t lq_base = 0, lq_used = GS_LONG_CHUNK;  // this wave's chunk of the long-read queue
     for (int64_t r = wave_id; r < n_reads; r += n_waves) {
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
@@ -1034,7 +1037,14 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         const u64 off = po[0];
         const int L = (int)(po[1] - off);
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
-            if (lane == 0) Q.long_list[atomicAdd(Q.long_count, 1u)] = (uint32_t)r;
+            if (lq_used == GS_LONG_CHUNK) {  // a fresh chunk of the queue for this wave
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(Q.long_count, (unsigned int)GS_LONG_CHUNK);
+                lq_base = (uint32_t)gs_rfl((int)b);
+                lq_used = 0;
+            }
+            if (lane == 0) Q.long_list[lq_base + lq_used] = (uint32_t)r;
+            lq_used++;
             continue;
         }
         uint32_t pre[3];
@@ -1043,6 +1053,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
                                                      s_g[wave_in_block], s_cur[wave_in_block]);
     }
+    if (lq_used < GS_LONG_CHUNK && (uint32_t)lane >= lq_used) P.long_list[lq_base + (uint32_t)lane] = GS_LONG_NONE;  // (rest of the last chunk)
     if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const u64 base = s_cur[wave_in_block][0], used = s_cur[wave_in_block][1];
@@ -1051,32 +1062,42 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     GS_STATS_EPILOGUE()
 }
 
-template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false, bool STRIPED = false>
+template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false, bool STRIPED = false, int KC = 0>
 __global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
-    const int64_t n_waves = (int64_t)gs_rfl((int)gridDim.x) * (GS_BLOCK / 64);
     __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
     GS_STRIPE_TABLE(&P)
-    const unsigned int n_long = *P.long_count;  // written by the preceding kernel on the same stream
+    // The queue (written by the preceding kernel on the same stream) comes in chunks of GS_LONG_CHUNK entries, each filled by
+    // one wave of that kernel and padded with GS_LONG_NONE.  The waves of this kernel draw chunks from a shared cursor
+    // (long_count[1]) until the queue is empty: reads of very different lengths spread over the waves by themselves, and
+    // every wave leaves the loop with the first chunk index beyond the end.
+    const unsigned int n_long = P.long_count[0];
     int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
     int32_t *cnt = tag + nv;
     uint32_t serial = serials[wave_id];
-    for (int64_t i = wave_id; i < (int64_t)n_long; i += n_waves) {
-        serial++;
-        if (serial == 0) {  // wrap after 2^32 - 1 long reads on this wave: old tags could alias, so the wave's tag row starts over
-            for (int i = lane; i < nv; i += 64) gs_sc_store(tag + i, 0);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            serial = 1;
+    for (;;) {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(P.long_count + 1, 1u);
+        c = (uint32_t)gs_rfl((int)c);
+        if ((u64)c * GS_LONG_CHUNK >= (u64)n_long) break;
+        const uint32_t mine = P.long_list[(size_t)c * GS_LONG_CHUNK + (size_t)lane];
+        for (u64 todo = __ballot(mine != GS_LONG_NONE); todo; todo &= todo - 1) {
+            serial++;
+            if (serial == 0) {  // wrap after 2^32 - 1 long reads on this wave: old tags could alias, so the wave's tag row starts over
+                for (int i = lane; i < nv; i += 64) gs_sc_store(tag + i, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                serial = 1;
+            }
+            const int64_t r = (int64_t)(uint32_t)gs_readlane((int)mine, __builtin_ctzll(todo));
+            const uint64_t *po = P.off + r * P.off_stride;
+            const u64 off = po[0];
+            const uint32_t none[3] = {0, 0, 0};
+            gs_process_read<true, FROM_NODES, KC, WIDE, false, STRIPED>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag,
+                                                       cnt, (int)serial, none, s_g[wave_in_block], nullptr);
         }
-        const int64_t r = (int64_t)P.long_list[i];
-        const uint64_t *po = P.off + r * P.off_stride;
-        const u64 off = po[0];
-        const uint32_t none[3] = {0, 0, 0};
-        gs_process_read<true, FROM_NODES, 0, WIDE, false, STRIPED>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag, cnt,
-                                                   (int)serial, none, s_g[wave_in_block], nullptr);
     }
     if (lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
@@ -1976,7 +1997,12 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
         return hipGetLastError();
     }
     if (P->nodes == nullptr) {
-        if (lds_stats)
+        if (P->db.k == 31) {  // (as gs_match_kernel: k folded in at compile time)
+            if (lds_stats)
+                hipLaunchKernelGGL((gs_match_long_kernel<true, false, false, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+            else
+                hipLaunchKernelGGL((gs_match_long_kernel<false, false, false, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
+        } else if (lds_stats)
             hipLaunchKernelGGL((gs_match_long_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
         else
             hipLaunchKernelGGL((gs_match_long_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
@@ -1994,6 +2020,15 @@ extern "C" int gs_match_occupancy(int n_values) {
     hipError_t e = n_values <= GS_NV_LDS
                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<true, false, 31>, GS_BLOCK, gs_stats_lds_bytes(n_values))
                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_kernel<false, false, 31>, GS_BLOCK, gs_stats_lds_bytes(n_values));
+    return e == hipSuccess ? n : 0;
+}
+
+// workgroups of the long-read kernel a CU holds at once (the plain variant stands for all of them)
+extern "C" int gs_match_long_occupancy(int n_values) {
+    int n = 0;
+    hipError_t e = n_values <= GS_NV_LDS
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_long_kernel<true, false, true, true>, GS_BLOCK, gs_stats_lds_bytes(n_values))
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gs_match_long_kernel<false, false, true, true>, GS_BLOCK, gs_stats_lds_bytes(n_values));
     return e == hipSuccess ? n : 0;
 }
 

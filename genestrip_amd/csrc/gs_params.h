@@ -43,7 +43,7 @@ struct GsMatchParams {
     uint32_t *hit_counts;  // per table slot, or nullptr (maxKMerResCounts == 0)
     int32_t *class_vi;     // optional per read
     uint8_t *flags;        // optional per read
-    unsigned int *long_count;  // reads with more than 128 k-mer positions are queued for the long-read kernel
+    unsigned int *long_count;  // [0] entries of the queue of reads with more than 128 k-mer positions (chunks of 64 per wave), [1] the long-read kernel's chunk cursor
     uint32_t *long_list;
     // DB-partitioned mode only: node of every k-mer position, looked up by the owning rank (nullptr: probe locally)
     const int32_t *nodes;

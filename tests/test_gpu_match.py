@@ -348,3 +348,48 @@ def test_max_contig_reads_captured_per_batch_equal_the_final_answer(sdb):
     assert np.array_equal(orun.finish()[0], table)
     m.close()
     store.close()
+
+
+@pytest.mark.parametrize("blocks_per_cu", [None, "1"])
+def test_many_long_reads_between_short_ones(sdb, monkeypatch, blocks_per_cu):
+    """the long-read queue: gs_match_kernel files reads with more than 128 k-mer positions in chunks of 64 per wave (the rest of
+    a wave's last chunk is padding), gs_match_long_kernel draws chunks from a shared cursor.  20 000 reads of 20 .. 3000 bases in
+    random order -- far more long reads than waves, so chunks fill up and are reused across two submits of one run --, read by
+    read against the oracle; the same with one workgroup per CU (GS_LONG_BLOCKS_PER_CU)"""
+    if blocks_per_cu:
+        monkeypatch.setenv("GS_LONG_BLOCKS_PER_CU", blocks_per_cu)
+    rng = np.random.default_rng(77)
+    g0 = sdb.genomes
+    reads = []
+    for i in range(20000):
+        L = int(rng.choice([int(rng.integers(20, 158)), 158, 159, 160, int(rng.integers(161, 700)), int(rng.integers(700, 3000))],
+                           p=[0.4, 0.02, 0.02, 0.02, 0.44, 0.1]))
+        parts, left = [], L
+        while left > 0:  # chimeras: several species in one read -> several distinct nodes per iteration and across iterations
+            s = int(rng.integers(0, g0.shape[0]))
+            n = min(left, int(rng.integers(40, 900)))
+            p = int(rng.integers(0, g0.shape[1] - n))
+            parts.append(g0[s][p:p + n].tobytes())
+            left -= n
+        r = bytearray(b"".join(parts))
+        if i % 9 == 0:
+            r[int(rng.integers(0, L))] = ord("N")
+        reads.append(bytes(r))
+    seq, off = orc.pack_reads(reads)
+    for cfg in (dict(), dict(threshold=4, max_paths=3)):
+        o, g = _both(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, (seq, off), **cfg)
+        _assert_same(o, g)
+    # two submits of one run (the queue starts over with each), short-only batch in between
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    orun = orc.MatchRun(odb)
+    orun.submit(seq, off)
+    ot, _ = orun.finish()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    cut = 9000
+    m.match_reads(seq[:int(off[cut])], off[:cut + 1], 0)
+    m.match_reads(seq[int(off[cut]):], off[cut:] - off[cut], cut)
+    gt, _ = m.finish()
+    assert np.array_equal(ot, gt)
+    m.close()
+    store.close()
