@@ -1062,8 +1062,19 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     GS_STATS_EPILOGUE()
 }
 
+// waves per SIMD of the long-read kernel: left alone the compiler takes 80-90 VGPRs (5 waves); at 8 waves (64 VGPRs, 8 of them
+// spilled) reads of 1000 bp run at 162 instead of 134 Gbp/s, at 6 waves (77 VGPRs, no spills) at 140 (tools/long_read_rate.py)
+#ifndef GS_LONG_WAVES
+#define GS_LONG_WAVES GS_WAVES
+#endif
+#if GS_LONG_WAVES
+#define GS_LONG_ATTR __attribute__((amdgpu_waves_per_eu(GS_LONG_WAVES, GS_LONG_WAVES)))
+#else
+#define GS_LONG_ATTR
+#endif
 template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false, bool STRIPED = false, int KC = 0>
-__global__ __launch_bounds__(GS_BLOCK) void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
+__global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
+    if (P.long_count[0] == 0) return;  // (a batch of short reads: nothing queued, no counters to set up and flush)
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
