@@ -1,5 +1,5 @@
 """match rate by read length at a constant number of bases (developer tool): reads of 150 bp take gs_match_kernel, longer ones
-gs_match_long_kernel (one wave per read, 128 k-mer positions per iteration).   python tools/long_read_rate.py [total_Mbases]"""
+gs_match_long_kernel (one wave per read, 128 k-mer positions per iteration).   python tools/long_read_rate.py [total_Mbases [lengths ...]]"""
 import os
 import sys
 import time
@@ -11,11 +11,12 @@ import genestrip_amd as ga  # noqa: E402
 from genestrip_amd import synth  # noqa: E402
 
 total = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 1_500_000_000
+lengths = [int(x) for x in sys.argv[2:]] or [150, 300, 1000, 5000, 20000, 90000]
 db = synth.SynthDB()
 gen = torch.from_numpy(db.genomes).cuda()
 store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
 m = ga.FastqKMerMatcher(store)
-for L in (150, 300, 1000, 5000, 20000, 90000):
+for L in lengths:
     n = total // L
     dseq = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     doff = torch.empty(n + 1, dtype=torch.int64, device="cuda")
