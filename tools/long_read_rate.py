@@ -12,9 +12,10 @@ from genestrip_amd import synth  # noqa: E402
 
 total = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 1_500_000_000
 lengths = [int(x) for x in sys.argv[2:]] or [150, 300, 1000, 5000, 20000, 90000]
-db = synth.SynthDB()
+K = int(os.environ.get("GS_RATE_K", "31"))  # GS_RATE_K=25: the kernels with k as a run-time value
+db = synth.SynthDB(k=K)
 gen = torch.from_numpy(db.genomes).cuda()
-store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
 m = ga.FastqKMerMatcher(store)
 for L in lengths:
     n = total // L
