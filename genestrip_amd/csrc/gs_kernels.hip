@@ -1766,7 +1766,7 @@ __device__ __forceinline__ bool gs_filter_bit(const GsFilterParams &P, const uin
 
 #define GS_FILTER_MAX_HASHES 128
 
-__global__ __launch_bounds__(GS_BLOCK) void gs_filter_kernel(GsFilterParams P) {
+__global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAVES, GS_WAVES))) void gs_filter_kernel(GsFilterParams P) {
     __shared__ u64 s_fkey[GS_BLOCK / 64][16];
     __shared__ u64 s_fcand[GS_BLOCK / 64][64];
     __shared__ int64_t s_factors[GS_FILTER_MAX_HASHES];
