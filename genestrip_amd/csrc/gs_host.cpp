@@ -1347,20 +1347,27 @@ int filter_parsed_source(FilterCtx &c, const std::string &path, int64_t offset, 
     return err;
 }
 
+// block size and reader / inflating threads of the filter goal's text pipelines (GS_HOST_BLOCK_BYTES, GS_HOST_READERS)
+void filter_reader_shape(bool gzip, size_t *block, int *readers) {
+    *block = (size_t)8 << 20;
+    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 64 && v <= ((long long)1 << 29)) *block = (size_t)v;
+    }
+    *readers = (int)std::min<unsigned>(gzip ? 16 : 8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("GS_HOST_READERS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) *readers = v;
+    }
+}
+
 int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool fasta);
 
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
 int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
-    size_t block = (size_t)8 << 20;
-    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
-        const long long v = atoll(e);
-        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
-    }
-    int readers = (int)std::min<unsigned>(gzip ? 16 : 8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
-    if (const char *e = getenv("GS_HOST_READERS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 32) readers = v;
-    }
+    size_t block;
+    int readers;
+    filter_reader_shape(gzip, &block, &readers);
     TextReader tr;
     int err = tr.open(path, block, readers, gzip);
     if (err) {
@@ -1476,16 +1483,9 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
 // device (gs_filter_submit_fasta / gs_filter_submit_fastq_ml); every record is written as four-line FASTQ.  What the device
 // refuses and the tail of the file go through the reference-exact parser.
 int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool fasta) {
-    size_t block = (size_t)8 << 20;
-    if (const char *e = getenv("GS_HOST_BLOCK_BYTES")) {
-        const long long v = atoll(e);
-        if (v >= 64 && v <= ((long long)1 << 29)) block = (size_t)v;
-    }
-    int readers = (int)std::min<unsigned>(gzip ? 16 : 8, std::max<unsigned>(2, std::thread::hardware_concurrency() / 2));
-    if (const char *e = getenv("GS_HOST_READERS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 32) readers = v;
-    }
+    size_t block;
+    int readers;
+    filter_reader_shape(gzip, &block, &readers);
     TextReader tr;
     int err = tr.open(path, block, readers, gzip);
     if (err) {
