@@ -9,7 +9,7 @@ import genestrip_amd as ga  # noqa: E402
 from genestrip_amd import synth  # noqa: E402
 
 n = 10_000_000
-for genera, spg, glen in ((4, 5, 100_000), (10, 20, 10_000), (25, 20, 4_000), (50, 40, 1_000)):
+for genera, spg, glen in ((4, 5, 100_000), (8, 9, 25_000), (10, 9, 20_000), (11, 10, 18_000), (12, 10, 16_000), (10, 20, 10_000), (25, 20, 4_000), (50, 40, 1_000)):
     db = synth.SynthDB(genera=genera, species_per_genus=spg, genome_len=glen)
     store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     gen = torch.from_numpy(db.genomes).cuda()
