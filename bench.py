@@ -306,13 +306,17 @@ def main():
             ns = int(min(n, max(nchk, rate * args.cpu_seconds)))
             seq, off = synth.reads_host(db.genomes, ns, read_len=READ_LEN, first=first)
             orun = orc.MatchRun(odb)
-            t1 = time.perf_counter()
-            orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
-            dt = time.perf_counter() - t1
+            dt, passes = 0.0, 0
+            while passes == 0 or (dt < 0.6 * args.cpu_seconds and passes < 8):  # (the estimate above comes from a cold, short run)
+                t1 = time.perf_counter()
+                orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+                dt += time.perf_counter() - t1
+                passes += 1
             out["cpu_baseline"] = {
-                "value": round(ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
-                "sample": "first %d reads of the same stream, C restatement of the Java path (sorted array + "
-                          "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s" % (ns, cores, dt)}
+                "value": round(passes * ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
+                "sample": "first %d reads of the same stream%s, C restatement of the Java path (sorted array + "
+                          "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s"
+                          % (ns, " x %d passes" % passes if passes > 1 else "", cores, dt)}
             del seq, off
         odb.close()
         if world == 1 and not partitioned and not striped and not args.genera:
