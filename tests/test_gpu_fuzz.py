@@ -2,6 +2,8 @@
 purpose -- low-complexity sequence (homopolymers, short tandem repeats), where many k-mers share a minimizer, the same
 15-mer occurs twice inside a k-mer and a k-mer can equal its own reverse complement.  Everything is compared with the
 oracle bit for bit.  Needs an MI355X: run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,8 @@ def _tree(rng, n_values):
     return parent
 
 
-@pytest.mark.parametrize("seed", range(24))
+# GS_FUZZ_EXTRA=n: n more scenarios (seeds 24 ..), which also draw maxClassificationPaths = 128 (a campaign, not part of the suite)
+@pytest.mark.parametrize("seed", range(24 + int(os.environ.get("GS_FUZZ_EXTRA", "0"))))
 def test_random_scenario(seed):
     rng = np.random.default_rng(1000 + seed)
     k = int(rng.choice([19, 21, 25, 31, 31, 31, 12, 17]))
@@ -62,7 +65,7 @@ def test_random_scenario(seed):
     keys = np.array(sorted(d), dtype=np.int64)
     vidx = np.array([d[x] for x in keys.tolist()], dtype=np.int32)
     cfg = dict(classify=bool(rng.random() < 0.85), count_unique=bool(rng.random() < 0.8),
-               max_paths=int(rng.choice([1, 2, 4, 10, 64])), threshold=int(rng.choice([1, 1, 2, 5, 30])),
+               max_paths=int(rng.choice([1, 2, 4, 10, 64] + ([128] if seed >= 24 else []))), threshold=int(rng.choice([1, 1, 2, 5, 30])),
                max_read_tax_err=float(rng.choice([-1.0, 0.0, 0.2, 3.0])),
                max_read_class_err=float(rng.choice([-1.0, 0.1, 0.6, 25.0])))
     reads = []
