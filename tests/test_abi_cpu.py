@@ -32,6 +32,17 @@ def test_host_layer_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md maps each entry point of both headers to the reference interface it replaces (or says that there is
+    none): by its full name, or as a `_suffix` inside a `gs_family_a / _b / _c` group"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = set()
+    for h in ("gsgpu.h", "gshost.h"):
+        names |= set(re.findall(r"\b(gs_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
+    missing = [n for n in sorted(names) if n not in doc and ("_" + n.rsplit("_", 1)[1]) not in doc]
+    assert not missing, missing
+
+
 def test_header_enums_match_binding():
     header = open(os.path.join(ROOT, "include", "gsgpu.h")).read()
     cols = re.search(r"enum \{\s*GS_C_READS = 0,(.*?)GS_N_COLS", header, re.S).group(1)
