@@ -1086,9 +1086,19 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
     // (long_count[1]) until the queue is empty: reads of very different lengths spread over the waves by themselves, and
     // every wave leaves the loop with the first chunk index beyond the end.
     const unsigned int n_long = P.long_count[0];
-    int32_t *tag = scratch + (size_t)wave_id * 2 * (size_t)nv;
-    int32_t *cnt = tag + nv;
-    uint32_t serial = serials[wave_id];
+    // per-wave vote rows (tag = serial of the read that last touched a node, cnt = its votes in that read): in LDS for the
+    // taxonomies whose counters are in LDS as well (every distinct node of every iteration reads and writes them: two
+    // dependent round trips to HBM otherwise), else this wave's rows of `scratch`, which persist from launch to launch
+    __shared__ int32_t s_votes[LDS_STATS ? GS_BLOCK / 64 : 1][LDS_STATS ? 2 * GS_NV_LDS : 1];
+    int32_t *tag = LDS_STATS ? s_votes[wave_in_block] : scratch + (size_t)wave_id * 2 * (size_t)nv;
+    int32_t *cnt = tag + (LDS_STATS ? GS_NV_LDS : nv);
+    uint32_t serial = LDS_STATS ? 0u : serials[wave_id];
+    if (LDS_STATS) {
+        for (int i = lane; i < GS_NV_LDS; i += 64) tag[i] = 0;  // (serials start at 1)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     for (;;) {
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(P.long_count + 1, 1u);
@@ -1110,7 +1120,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
                                                        cnt, (int)serial, none, s_g[wave_in_block], nullptr);
         }
     }
-    if (lane == 0) serials[wave_id] = serial;
+    if (!LDS_STATS && lane == 0) serials[wave_id] = serial;
     GS_STATS_EPILOGUE()
 }
 

@@ -115,14 +115,22 @@ def test_long_read_serial_wrap(monkeypatch):
     pass for the new read's.  GS_TEST_LONG_SERIAL starts the serials three reads below the wrap and pre-fills the rows
     with the values the serials take right after it."""
     monkeypatch.setenv("GS_TEST_LONG_SERIAL", "0xFFFFFFFD")
+    monkeypatch.setenv("GS_LONG_BLOCKS_PER_CU", "1")  # 1024 waves for 6000 long reads: every wave gets past the wrap
     db = synth.SynthDB(k=31, genera=3, species_per_genus=3, genome_len=20000, seed=11)
     seq, off = synth.reads_host(db.genomes, 6000, read_len=900, seed=3)
     off = off.astype(np.uint64)
+    # (more than GS_NV_LDS = 128 value indices: smaller taxonomies keep the rows in LDS, fresh with every launch)
+    n_values = 300
+    parent = np.zeros(n_values, dtype=np.int32)
+    parent[:db.n_values] = db.parent_vi
+    vidx = db.value_idx.copy()
+    moved = np.flatnonzero(vidx == db.species_vi[0])[::3]
+    vidx[moved] = 150 + (np.arange(len(moved)) % 150)  # leaves under the root that share reads with a species
     for cfg in (dict(), dict(threshold=3, max_paths=128)):
-        orun = orc.MatchRun(orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi), **cfg)
+        orun = orc.MatchRun(orc.DB(31, db.kmers, vidx, n_values, parent), **cfg)
         ocv, ofl = orun.submit(seq, off, threads=8)
         ot, _ = orun.finish()
-        store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        store = ga.DeviceKMerStore(31, db.kmers, vidx, n_values, parent)
         m = ga.FastqKMerMatcher(store, ga.MatchConfig(**cfg))
         gcv, gfl = m.match_reads(seq, off)
         gt, _ = m.finish()
