@@ -13,7 +13,9 @@ from genestrip_amd import synth  # noqa: E402
 total = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 1_500_000_000
 lengths = [int(x) for x in sys.argv[2:]] or [150, 300, 1000, 5000, 20000, 90000]
 K = int(os.environ.get("GS_RATE_K", "31"))  # GS_RATE_K=25: the kernels with k as a run-time value
-db = synth.SynthDB(k=K)
+shape = [int(x) for x in os.environ.get("GS_RATE_SHAPE", "4,5,100000").split(",")]  # genera, species per genus, genome length
+db = synth.SynthDB(k=K, genera=shape[0], species_per_genus=shape[1], genome_len=shape[2])
+print("store: %d k-mers, %d values" % (db.n_entries, db.n_values), flush=True)
 gen = torch.from_numpy(db.genomes).cuda()
 store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
 m = ga.FastqKMerMatcher(store)
