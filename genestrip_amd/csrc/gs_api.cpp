@@ -1840,6 +1840,7 @@ struct gs_run {
     gs_match_cfg cfg{};
     hipStream_t stream = nullptr;
     int64_t *d_sums = nullptr;   // [stat_copies][n_values][GS_N_SUMS]; copy 0 is the one everything outside the kernels sees
+    u64 *h_result = nullptr;     // page-locked landing area of gs_match_finish: sums | max keys | unique counts | double sums
     int64_t *d_max = nullptr;
     double *d_dsums = nullptr;
     u64 *d_route_cursors = nullptr;    // gs_match_encode_route: slots handed out per owner + overflow flag
@@ -2118,9 +2119,8 @@ static int text_status(TextScan &t, hipStream_t stream, int64_t *failed_ticket, 
 static int run_clear(gs_run *run) {
     const size_t nv = (size_t)run->db->info.n_values;
     const size_t cp = (size_t)run->stat_copies;
-    HIP_TRY(hipMemsetAsync(run->d_sums, 0, sizeof(int64_t) * nv * GS_N_SUMS * cp, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_max, 0, sizeof(int64_t) * nv * cp, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_dsums, 0, sizeof(double) * nv * GS_N_DCOLS * cp, run->stream));
+    // (sums, max keys, double sums and the long-read queue counters [queue length, consumer cursor] are one block)
+    HIP_TRY(hipMemsetAsync(run->d_sums, 0, sizeof(int64_t) * nv * (GS_N_SUMS + 1 + GS_N_DCOLS) * cp + 2 * sizeof(unsigned int), run->stream));
     run->stats_spread = false;
     HIP_TRY(hipMemsetAsync(run->d_bitmap, 0, sizeof(uint32_t) * (size_t)run->bitmap_words, run->stream));
     if (run->d_hit_counts)
@@ -2129,7 +2129,6 @@ static int run_clear(gs_run *run) {
         HIP_TRY(gs_launch_clear_seen(run->db->d_table, run->db->n_slots(), run->db->d_rec, run->db->n_rec, run->stream));
     run->seen_dirty = false;
     run->bitmap_merged = false;
-    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 2 * sizeof(unsigned int), run->stream));
     return GS_OK;
 }
 
@@ -2140,16 +2139,14 @@ static void run_free(gs_run *run) {
         hipEventDestroy(p.first);
         hipEventDestroy(p.second);
     }
-    hipFree(run->d_sums);
-    hipFree(run->d_max);
-    hipFree(run->d_dsums);
+    hipHostFree(run->h_result);
+    hipFree(run->d_sums);  // (d_max, d_dsums, d_long_count lie inside)
     hipFree(run->d_stat_recs);
     hipFree(run->d_stat_rec_count);
     hipFree(run->d_route_cursors);
     hipFree(run->d_bitmap);
     hipFree(run->d_hit_counts);
     hipFree(run->d_unique);
-    hipFree(run->d_long_count);
     hipFree(run->d_long_list);
     hipFree(run->d_scratch);
     hipFree(run->d_serial);
@@ -2210,14 +2207,17 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         if (const char *ev = getenv("GS_STAT_RECS")) run->use_stat_recs = run->use_stat_recs && atoi(ev) != 0;
     }
     const size_t cp = (size_t)run->stat_copies;
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS * cp);
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_max, sizeof(int64_t) * nv * cp);
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_dsums, sizeof(double) * nv * GS_N_DCOLS * cp);
+    // sums | max keys | double sums | long-read queue counters in ONE allocation: one memset clears them (gs_match_reset)
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * (GS_N_SUMS + 1 + GS_N_DCOLS) * cp + 2 * sizeof(unsigned int));
+    if (e == hipSuccess) {
+        run->d_max = run->d_sums + nv * GS_N_SUMS * cp;
+        run->d_dsums = reinterpret_cast<double *>(run->d_max + nv * cp);
+        run->d_long_count = reinterpret_cast<unsigned int *>(run->d_dsums + nv * GS_N_DCOLS * cp);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_bitmap, sizeof(uint32_t) * (size_t)run->bitmap_words);
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_unique, sizeof(u64) * nv);
     if (e == hipSuccess && cfg->max_kmer_res_counts > 0)
         e = hipMalloc((void **)&run->d_hit_counts, sizeof(uint32_t) * (size_t)(db->n_slots() + db->n_rec * GS_REC_SLOTS));
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_long_count, 2 * sizeof(unsigned int));  // queue length, consumer cursor
     if (e != hipSuccess) {
         run_free(run);
         return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("run alloc: ") + hipGetErrorString(e));
@@ -2664,8 +2664,13 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
     if (!run || !table) return fail(GS_E_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(run->db->device));
     const size_t nv = (size_t)run->db->info.n_values;
-    std::vector<int64_t> sums(nv * GS_N_SUMS), maxk(nv);
-    std::vector<u64> uniq(nv, 0);
+    // the four result arrays land in page-locked memory (a copy into pageable memory is staged by the runtime: ~20 us each,
+    // one after the other -- a third of the time between two batches of the bench)
+    if (!run->h_result) HIP_TRY(hipHostMalloc((void **)&run->h_result, sizeof(u64) * nv * (GS_N_SUMS + 2 + GS_N_DCOLS), hipHostMallocDefault));
+    int64_t *sums = reinterpret_cast<int64_t *>(run->h_result);
+    int64_t *maxk = sums + nv * GS_N_SUMS;
+    u64 *uniq = reinterpret_cast<u64 *>(maxk + nv);
+    double *dsums = reinterpret_cast<double *>(uniq + nv);
     {
         const int frc = fold_stats(run);
         if (frc) return frc;
@@ -2679,18 +2684,18 @@ extern "C" int gs_match_finish(gs_run *run, int64_t *table, double *dtable) {
             const int urc = run_unique_counts(run);
             if (urc) return urc;
         }
-        HIP_TRY(hipMemcpyAsync(uniq.data(), run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
+        HIP_TRY(hipMemcpyAsync(uniq, run->d_unique, sizeof(u64) * nv, hipMemcpyDeviceToHost, run->stream));
     }
-    HIP_TRY(hipMemcpyAsync(sums.data(), run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToHost, run->stream));
-    HIP_TRY(hipMemcpyAsync(maxk.data(), run->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToHost, run->stream));
-    if (dtable)
-        HIP_TRY(hipMemcpyAsync(dtable, run->d_dsums, sizeof(double) * nv * GS_N_DCOLS, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipMemcpyAsync(sums, run->d_sums, sizeof(int64_t) * nv * GS_N_SUMS, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipMemcpyAsync(maxk, run->d_max, sizeof(int64_t) * nv, hipMemcpyDeviceToHost, run->stream));
+    if (dtable) HIP_TRY(hipMemcpyAsync(dsums, run->d_dsums, sizeof(double) * nv * GS_N_DCOLS, hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
+    if (dtable) memcpy(dtable, dsums, sizeof(double) * nv * GS_N_DCOLS);
     int rc = collect_events(run);
     if (rc) return rc;
     for (size_t v = 0; v < nv; v++) {
         int64_t *row = table + v * GS_N_COLS;
-        const int64_t *s = sums.data() + v * GS_N_SUMS;
+        const int64_t *s = sums + v * GS_N_SUMS;
         row[GS_C_READS] = s[GS_S_READS];
         row[GS_C_READS_KMERS] = s[GS_S_READS_KMERS];
         row[GS_C_KMERS] = s[GS_S_KMERS];
