@@ -1669,24 +1669,49 @@ __global__ __launch_bounds__(256) void gs_rec_unique_count_kernel(const u64 *rec
     }
     const int g = (int)(threadIdx.x & 7);
     const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 3;
-    for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; b0 < n_rec + 7; b0 += groups) {  // (whole waves stay in the loop)
-        const bool in = b0 < n_rec;
-        uint32_t bits = in ? bitmap_rec[b0] : 0u;
-        u64 w = 0;
-        if (bits) w = rec[b0 * GS_REC_WORDS + g];
-        const u64 w1 = __shfl(w, 1, 8);
-        bits &= (uint32_t)(w1 >> GS_REC_WIN_BITS);  // only offsets that hold a k-mer (a merged bitmap comes from other ranks)
-        if (g >= 2 && bits) {
+    // eight lanes per bucket; four buckets per group and iteration with their loads in flight together (the loop is bound by
+    // the latency of bitmap word -> record line, not by bytes)
+    for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; b0 < n_rec; b0 += 4 * groups) {
+        uint32_t bits[4];
+        u64 w[4];
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int j = 3 * (g - 2) + i;
-                if ((bits >> j) & 1u) {
-                    const int vi = (int)((w >> (GS_REC_VAL_BITS * i)) & (GS_REC_MAX_VALUES - 1));
-                    if (vi < n_values) {
+        for (int u = 0; u < 4; u++) {
+            const int64_t bb = b0 + u * groups;
+            bits[u] = bb < n_rec ? bitmap_rec[bb] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = bits[u] ? rec[(b0 + u * groups) * GS_REC_WORDS + g] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 w1 = __shfl(w[u], 1, 8);
+            const uint32_t bt = bits[u] & (uint32_t)(w1 >> GS_REC_WIN_BITS);  // only offsets that hold a k-mer (a merged bitmap comes from other ranks)
+            if (g >= 2 && bt) {
+                // the three k-mers of a value word usually carry the same value index: one atomic for them together
+                int v[3], c[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int vi = (int)((w[u] >> (GS_REC_VAL_BITS * i)) & (GS_REC_MAX_VALUES - 1));
+                    v[i] = (((bt >> (3 * (g - 2) + i)) & 1u) && vi < n_values) ? vi : -1;
+                    c[i] = 1;
+                }
+                if (v[1] >= 0 && v[1] == v[0]) {
+                    c[0]++;
+                    v[1] = -1;
+                }
+                if (v[2] >= 0 && v[2] == v[0]) {
+                    c[0]++;
+                    v[2] = -1;
+                } else if (v[2] >= 0 && v[2] == v[1]) {
+                    c[1]++;
+                    v[2] = -1;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    if (v[i] >= 0) {
                         if (lds)
-                            atomicAdd(&s_cnt[vi], 1u);
+                            atomicAdd(&s_cnt[v[i]], (unsigned int)c[i]);
                         else
-                            atomicAdd(&unique[vi], 1ULL);
+                            atomicAdd(&unique[v[i]], (u64)c[i]);
                     }
                 }
             }
