@@ -66,6 +66,21 @@ def _pmc_traffic(name):
     return None, None
 
 
+def _pmc_issue_bound(name, kern_ms, n_simd=1024, clock_ghz=2.4):
+    """the kernel's instruction-issue floor from the same committed summary: a SIMD issues one wave64 VALU instruction
+    per four cycles; SQ_INSTS_VALU per launch over the device's 1024 SIMDs at 2.4 GHz (GRBM_GUI_ACTIVE of the summary: 2.38)"""
+    for rnd in PROFILE_ROUNDS[name]:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.csv")
+        if os.path.exists(path):
+            vals = dict(l.strip().split(",")[:2] for l in open(path) if l[0] not in "#c" and "," in l)
+            if "SQ_INSTS_VALU" in vals:
+                ms = float(vals["SQ_INSTS_VALU"]) * 4 / n_simd / (clock_ghz * 1e9) * 1e3
+                return {"valu_instructions_per_launch": float(vals["SQ_INSTS_VALU"]), "ms": round(ms, 3),
+                        "frac": round(ms / kern_ms, 4), "note": "VALU issue floor (one wave64 instruction per SIMD and 4 cycles) over the "
+                        "measured kernel time; counters of %s, not measured in this run" % os.path.relpath(path, ROOT)}
+    return None
+
+
 def _kernel_ms(obj, launch, reps, warm=2):
     """average device time of one launch: HIP events recorded by the library on its own stream (cfg.profile)"""
     for _ in range(warm):
@@ -250,7 +265,8 @@ def main():
                      "traffic_note": None if traffic is None else
                      "bytes per launch through the fabric (rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, %s), not measured in this run" % traffic_src,
                      "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_READ},
+                     "algorithmic_bytes_per_launch": n * BYTES_PER_READ,
+                     "issue_bound": None if traffic is None else _pmc_issue_bound("match", kern_ms)},
     }
 
     # ---- parity gate.  N = 1: the first --check-reads reads against the CPU oracle (bit-exact integer table).
