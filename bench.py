@@ -4,22 +4,39 @@
 A step = one pass of the hot path over one batch: gs_match_reset + gs_match_submit (reads already resident
 in HBM) + the per-taxid table merge (RCCL all-reduce / bitmap all-gather when N > 1) + gs_match_finish.
 Weak scaling: every rank classifies `--reads` reads of its own slice of the global read stream against a
-full replica of the store.  Rank 0 prints ONE JSON line: `value` is configs[1]; at N = 1 the same line carries
-extra objects for the workloads the headline does not show:
+full replica of the store.  Rank 0 prints ONE JSON line: `value` is configs[1].
 
-  large_store   match against a 47 M-k-mer / 526-value store (1 GiB table: HBM resident, not Infinity-Cache resident)
-  filter        the `filter` goal's kernel against the XOR index filter of the same store (~47 M keys, 27 hashes)
-  end_to_end    configs[1] again with the reads in page-locked HOST memory (gs_match_submit_async: PCIe included)
+What the line carries besides the contract's fields (N = 1):
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--cpu-seconds S] [--legs main,large,filter,e2e,striped,dbbuild,long]
+  roofline      resource fractions of the dominant kernel, every CEILING measured in this run (gs_calibrate: VALU / SALU
+                issue at the kernel's occupancy, random-line rate at the store's footprint) and every COUNTER collected in
+                this run (rocprofv3 --pmc child passes of this same script, started before the parent touches the GPU;
+                committed profiles/ summaries only when rocprofv3 is unavailable, and then tagged as such);
+                `frac` = the largest resource fraction, `bound` names it (or says "latency" when none reaches 0.6);
+                the SURVEY 8(d) convention figure is kept as `frac_survey_convention`
+  parity        the table of the TIMED steps (all reads of all ranks) against the CPU oracle, bit-exact
+  cpu_baseline  the oracle ("port") on the host cores, timed on that same pass
+  large_store, huge_store, filter, table_only, reads_250bp, long_reads, end_to_end, striped_store, file_pipeline, db_build
+                the workloads the headline does not show, each with its own parity gate
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--legs ...] [--pmc auto|off]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-GS_BENCH_FORCE_MERGE=1 runs the RCCL merge path even at N = 1 (rehearsal of the multi-GPU code on one GPU).
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, before any GPU call, and exits non-zero when
+fewer than N devices are visible.  GS_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box (ranks share GPU 0, merge
+over gloo).  GS_BENCH_FORCE_MERGE=1 runs the RCCL merge path even at N = 1.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,8 +48,19 @@ READ_LEN = 150
 K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
-# committed rocprofv3 --pmc summaries per workload, newest first (r01's large-store passes ran on a smaller store)
-PROFILE_ROUNDS = {"match": ("r02", "r01"), "large_store": ("r02",), "filter": ("r02",)}
+XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8            # per GPU: 7 links x 153.6 GB/s bidirectional
+ALL_LEGS = "main,large,huge,filter,tableonly,e2e,striped,dbbuild,long,r250,files"
+# committed rocprofv3 --pmc summaries per workload, newest first: the fallback when the in-run passes cannot be taken
+PROFILE_ROUNDS = {"match": ("r03", "r02"), "large_store": ("r03", "r02"), "filter": ("r03", "r02")}
+PMC_GROUPS = (
+    "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE",
+    "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
+)
+PMC_KERNELS = {"match": r"gs_match_kernel<true", "large_store": r"gs_match_kernel<false", "filter": r"gs_filter_kernel",
+               "cal_lines": r"cal_random_lines"}
+CAL_LINES_BYTES = 1 << 30
 
 
 def _usable_cores():
@@ -54,33 +82,224 @@ class _DevArray:
         self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": typestr, "version": 2}
 
 
-def _pmc_traffic(name):
-    """(bytes per launch through the fabric, file) from a committed rocprofv3 --pmc summary of the same command
-    (FETCH_SIZE + WRITE_SIZE, KiB units; 64-byte requests are counted exactly), or (None, None)"""
+# ---------------------------------------------------------------------------------------------------------------
+# counters: in-run rocprofv3 --pmc passes (children of this script), committed summaries as the fallback
+# ---------------------------------------------------------------------------------------------------------------
+def _pmc_child():
+    """what the PMC passes profile: two full-size launches each of the configs[1] match kernel, the large-store match kernel
+    and the filter kernel, plus one random-line calibration launch with a known line count (calibrates FETCH_SIZE for
+    64-byte random lines, MI355X_MICROARCH.md 'HBM')"""
+    import torch
+
+    import genestrip_amd as ga
+    from genestrip_amd import synth
+    n = int(os.environ.get("GS_BENCH_PMC_READS", "10000000"))
+    dev = torch.device("cuda", 0)
+    for genera in (0, 25):
+        db = synth.SynthDB(k=K, genera=genera, species_per_genus=20) if genera else synth.SynthDB(k=K)
+        gen = torch.from_numpy(db.genomes).to(dev)
+        dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+        doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN)
+        torch.cuda.synchronize()
+        store = ga.DeviceKMerStore(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        m = ga.FastqKMerMatcher(store)
+        for _ in range(2):
+            m.reset()
+            m.submit(dseq, doff, 0, n_reads=n)
+        m.sync()
+        m.close()
+        store.close()
+        if genera:
+            bloom, _ = _index_filter(ga, synth, torch, dev, db)
+            flt = ga.FastqBloomFilter(K, bloom, 1, 0.2)
+            acc = torch.empty(n, dtype=torch.uint8, device=dev)
+            for _ in range(2):
+                flt.submit(dseq, doff, acc, n_reads=n)
+            _sync_filter(ga, bloom)
+            bloom.close()
+        del gen, dseq, doff
+        torch.cuda.empty_cache()
+    r = ga.calibrate(ga.CAL_RANDOM_LINES, CAL_LINES_BYTES)
+    print("pmc-child done; cal lines per timed launch %d" % int(r["count"]), flush=True)
+
+
+def _sync_filter(ga, bloom):
+    import ctypes as C
+    ga.lib().gs_filter_sync(bloom.h)
+
+
+def _index_filter(ga, synth, torch, dev, db):
+    """BloomIndexGoal: the XOR index filter over the k-mers of the requested taxa (all species), built on the device"""
+    keys = db.kmers[np.isin(db.value_idx, db.species_vi)]
+    bits, hashes, factors = synth.xor_bloom_geometry(len(keys), 1e-8)
+    dwords = torch.zeros((bits + 63) // 64, dtype=torch.int64, device=dev)
+    synth.xor_bloom_device(torch.from_numpy(keys).to(dev), len(keys), bits, torch.from_numpy(factors).to(dev), hashes, dwords)
+    words = dwords.cpu().numpy().view(np.uint64)
+    del dwords
+    return ga.DeviceBloomFilter(ga.BLOOM_XOR, bits, factors, words), (keys, bits, hashes, factors, words)
+
+
+def _pmc_collect(timeout_s, reads):
+    """run the PMC passes; -> ({workload: {counter: value per launch}}, note).  Every pass is its own rocprofv3 process
+    (counters only, no trace domain) with this script as the program behind `--`."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="gsbench_pmc_")
+    env = dict(os.environ, GS_BENCH_PMC_READS=str(reads), TMPDIR=tempfile.gettempdir())
+    res = {w: {} for w in PMC_KERNELS}
+    t_start = time.perf_counter()
+    try:
+        for gi, grp in enumerate(PMC_GROUPS):
+            left = timeout_s - (time.perf_counter() - t_start)
+            if left < 20:
+                return None, "PMC passes ran out of their time budget (%d s)" % timeout_s
+            out = os.path.join(tmp, "g%d" % gi)
+            cmd = [exe, "--pmc"] + grp.split() + ["--output-format", "csv", "-d", out, "-o", "run", "--",
+                                                  sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            try:
+                p = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=min(left, 240))
+            except subprocess.TimeoutExpired:
+                return None, "PMC pass %d timed out" % gi
+            if p.returncode != 0:
+                return None, "PMC pass %d failed (rc %d): %s" % (gi, p.returncode, p.stdout.decode(errors="replace")[-300:])
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            if not rows:
+                return None, "PMC pass %d wrote no counter file" % gi
+            for w, pat in PMC_KERNELS.items():
+                mine = [r for r in rows if re.search(pat, r["Kernel_Name"])]
+                if not mine:
+                    continue
+                dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in mine}
+                longest = max(dur.values())
+                acc = {}
+                for r in mine:  # the full-size launches only (warm-up launches of the calibration kernel are short)
+                    if dur[r["Dispatch_Id"]] >= 0.8 * longest:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                for name, vals in acc.items():
+                    res[w][name] = sum(vals) / len(vals)
+        return res, "rocprofv3 --pmc, %d passes of this script in this run (%.0f s)" % (len(PMC_GROUPS), time.perf_counter() - t_start)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _pmc_committed(name):
+    """counters of a committed rocprofv3 --pmc summary of the same workload: (dict, source) or (None, None)"""
     for rnd in PROFILE_ROUNDS[name]:
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.csv")
         if os.path.exists(path):
-            vals = dict(l.strip().split(",")[:2] for l in open(path) if l[0] not in "#c" and "," in l)
-            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-                return int((float(vals["FETCH_SIZE"]) + float(vals["WRITE_SIZE"])) * 1024), os.path.relpath(path, ROOT)
+            vals = {}
+            for l in open(path):
+                if l[0] in "#c" or "," not in l:
+                    continue
+                f = l.strip().split(",")
+                try:
+                    vals[f[0]] = float(f[1])
+                except ValueError:
+                    pass
+            head = [l for l in open(path) if l.startswith("#")][:1]
+            return vals, "%s (committed summary, NOT measured in this run; %s)" % (os.path.relpath(path, ROOT), head[0][1:].strip() if head else "")
     return None, None
 
 
-def _pmc_issue_bound(name, kern_ms, n_simd=1024, clock_ghz=2.4):
-    """the kernel's instruction-issue floor from the same committed summary: a SIMD issues one wave64 VALU instruction
-    per four cycles; SQ_INSTS_VALU per launch over the device's 1024 SIMDs at 2.4 GHz (GRBM_GUI_ACTIVE of the summary: 2.38)"""
-    for rnd in PROFILE_ROUNDS[name]:
-        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.csv")
-        if os.path.exists(path):
-            vals = dict(l.strip().split(",")[:2] for l in open(path) if l[0] not in "#c" and "," in l)
-            if "SQ_INSTS_VALU" in vals:
-                ms = float(vals["SQ_INSTS_VALU"]) * 4 / n_simd / (clock_ghz * 1e9) * 1e3
-                return {"valu_instructions_per_launch": float(vals["SQ_INSTS_VALU"]), "ms": round(ms, 3),
-                        "frac": round(ms / kern_ms, 4), "note": "VALU issue floor (one wave64 instruction per SIMD and 4 cycles) over the "
-                        "measured kernel time; counters of %s, not measured in this run" % os.path.relpath(path, ROOT)}
-    return None
+def _fetch_correction(pmc):
+    """FETCH_SIZE calibrated on a known byte count of this access pattern (random 64-byte lines, 16 bytes per lane):
+    expected = lines x 64 B over what the counter reported for the calibration kernel of the same pass"""
+    c = (pmc or {}).get("cal_lines") or {}
+    if "FETCH_SIZE" not in c or "lines" not in c or c["FETCH_SIZE"] <= 0:
+        return 1.0, None
+    want = c["lines"] * 64.0
+    got = c["FETCH_SIZE"] * 1024.0
+    return want / got, {"lines": c["lines"], "expected_bytes": want, "fetch_size_bytes": got, "factor": round(want / got, 4)}
 
 
+def _resources(cnt, kern_ms, n_reads, ceil, footprint_key, src):
+    """resource fractions of one kernel launch: counters per launch over the kernel's duration against ceilings measured in
+    this run (gs_calibrate).  -> dict with `frac` (largest), `bound` (its name, or latency), the fractions and the raw rates"""
+    sec = kern_ms * 1e-3
+    out = {"counters_source": src, "kernel_ms": round(kern_ms, 4)}
+    fr = {}
+    if cnt is None:
+        return out, fr
+    fetch_b = cnt.get("FETCH_SIZE", 0.0) * 1024.0 * ceil.get("fetch_correction", 1.0)
+    write_b = cnt.get("WRITE_SIZE", 0.0) * 1024.0
+    if "FETCH_SIZE" in cnt:
+        out["traffic"] = int(fetch_b + write_b)
+        out["fabric_bytes"] = {"GBs": round((fetch_b + write_b) / sec / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                               "frac": round((fetch_b + write_b) / sec / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "FETCH_SIZE + WRITE_SIZE (memory side of L2; Infinity-Cache hits included) over the 8 TB/s HBM peak"}
+        fr["hbm"] = out["fabric_bytes"]["frac"]
+    if "TCC_EA0_RDREQ_sum" in cnt and footprint_key in ceil:
+        rq = cnt["TCC_EA0_RDREQ_sum"] + cnt.get("TCC_EA0_WRREQ_sum", 0.0)
+        out["line_requests"] = {"per_read": round(rq / n_reads, 2), "G_per_s": round(rq / sec / 1e9, 2),
+                                "ceiling_G_per_s": round(ceil[footprint_key] / 1e9, 2),
+                                "frac": round(rq / sec / ceil[footprint_key], 4),
+                                "note": "L2 -> fabric requests over the random 64-byte line rate measured in this run for a table of the store's footprint"}
+        fr["line_requests"] = out["line_requests"]["frac"]
+    if "SQ_INSTS_VALU" in cnt:
+        v = cnt["SQ_INSTS_VALU"]
+        out["valu_issue"] = {"per_read": round(v / n_reads, 1), "G_winst_per_s": round(v / sec / 1e9, 1),
+                             "ceiling_G_winst_per_s": round(ceil["valu_mix"] / 1e9, 1), "frac": round(v / sec / ceil["valu_mix"], 4),
+                             "note": "wave64 VALU instructions over the rate the calibration kernel with the match kernel's instruction mix "
+                                     "sustains at 8 waves per SIMD (measured in this run)"}
+        fr["valu_issue"] = out["valu_issue"]["frac"]
+    if "SQ_INSTS_SALU" in cnt:
+        s = cnt["SQ_INSTS_SALU"] + cnt.get("SQ_INSTS_SMEM", 0.0)
+        out["salu_issue"] = {"per_read": round(s / n_reads, 1), "G_inst_per_s": round(s / sec / 1e9, 1),
+                             "ceiling_G_inst_per_s": round(ceil["salu"] / 1e9, 1), "frac": round(s / sec / ceil["salu"], 4),
+                             "note": "scalar ALU + scalar memory instructions over the measured scalar issue rate"}
+        fr["salu_issue"] = out["salu_issue"]["frac"]
+    if "SQ_WAIT_ANY" in cnt and cnt.get("SQ_WAVE_CYCLES"):
+        out["wait_frac"] = round(cnt["SQ_WAIT_ANY"] / cnt["SQ_WAVE_CYCLES"], 3)
+    if "SQ_INSTS_VMEM_RD" in cnt:
+        out["vmem_loads_per_read"] = round(cnt["SQ_INSTS_VMEM_RD"] / n_reads, 2)
+    if "GRBM_GUI_ACTIVE" in cnt:
+        out["clock_ghz_under_pmc"] = round(cnt["GRBM_GUI_ACTIVE"] / 8 / sec / 1e9, 2)
+    return out, fr
+
+
+def _name_bound(fr):
+    """largest resource fraction and what to call the kernel"""
+    if not fr:
+        return None, None, "unknown (no counters)"
+    top = max(fr, key=fr.get)
+    if fr[top] >= 0.6:
+        return top, fr[top], top
+    return top, fr[top], "latency (no resource reaches 0.6 of its measured ceiling; largest: %s)" % top
+
+
+def _calibrate(ga, footprints):
+    """ceilings of this device, measured now: issue rates at 8 waves per SIMD and random-line rates per footprint"""
+    cal = {}
+    n_cu = None
+    for key, what in (("valu_pure", ga.CAL_VALU_PURE), ("valu_mix", ga.CAL_VALU_MIX), ("salu", ga.CAL_SALU), ("valu_salu", ga.CAL_VALU_SALU),
+                      ("vmem_bytes", ga.CAL_VMEM_BYTES), ("vmem_words", ga.CAL_VMEM_WORDS), ("vmem_shared_lines", ga.CAL_VMEM_SHARED_LINES),
+                      ("vmem_scattered", ga.CAL_VMEM_SCATTERED)):
+        r = ga.calibrate(what)
+        cal[key] = r["rate"]
+        n_cu = r["n_cu"]
+    for key, nbytes in footprints.items():
+        cal[key] = ga.calibrate(ga.CAL_RANDOM_LINES, int(max(1 << 20, nbytes)))["rate"]
+    simds = n_cu * 4
+    rep = {
+        "n_cu": n_cu,
+        "valu_pure_cycles_per_wave64_inst_at_2.4GHz": round(2.4e9 * simds / cal["valu_pure"], 3),
+        "valu_mix_cycles_per_wave64_inst_at_2.4GHz": round(2.4e9 * simds / cal["valu_mix"], 3),
+        "salu_cycles_per_inst_per_cu_at_2.4GHz": round(2.4e9 * n_cu / cal["salu"], 3),
+        "valu_salu_alternating_cycles_per_inst_per_simd": round(2.4e9 * simds / cal["valu_salu"], 3),
+        "vmem_wave_loads_per_s_per_cu": {k[5:]: round(cal[k] / n_cu / 1e6, 1) for k in cal if k.startswith("vmem_")},
+        "vmem_unit": "M wave-level load instructions per second and CU (cache resident)",
+        "random_lines_G_per_s": {k: round(v / 1e9, 2) for k, v in cal.items() if k.startswith("lines_")},
+        "note": "gs_calibrate kernels at 8 waves per SIMD, this run; MI355X_MICROARCH.md lines 54 / 473 give 2 cycles per wave64 VALU "
+                "instruction on the SIMD-32 once a SIMD holds two or more waves (4 for one wave alone)",
+    }
+    return cal, rep
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def _kernel_ms(obj, launch, reps, warm=2):
     """average device time of one launch: HIP events recorded by the library on its own stream (cfg.profile)"""
     for _ in range(warm):
@@ -96,14 +315,38 @@ def _kernel_ms(obj, launch, reps, warm=2):
     return (ms1 - ms0) / max(1, l1 - l0), wall
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(args):
+    """--gpus N without a launcher: start the N ranks (fresh processes), before this process touches the GPU"""
+    import torch
+    rehearsal = os.environ.get("GS_BENCH_BACKEND", "nccl") == "gloo"
+    ndev = torch.cuda.device_count()  # (does not initialise the runtime)
+    if ndev < args.gpus and not rehearsal:
+        sys.stderr.write("bench.py --gpus %d: only %d device(s) visible -- refusing to print a line for fewer GPUs than asked for "
+                         "(GS_BENCH_BACKEND=gloo rehearses the multi-rank flow on one GPU)\n" % (args.gpus, ndev))
+        sys.exit(3)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--check-reads", type=int, default=200_000, help="reads cross-checked against the oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg beyond the parity pass (0 = one pass)")
+    ap.add_argument("--check-reads", type=int, default=0, help="reads per rank cross-checked against the oracle (0 = all timed reads)")
     ap.add_argument("--mode", choices=["sharded", "striped", "partitioned"], default="sharded",
                     help="sharded: store replicated, reads sharded (configs[1]/[3], the default bench line); "
                          "striped: ONE store, its record table split over the GPUs' HBM, foreign record lines loaded over "
@@ -113,10 +356,32 @@ def main():
                     help="--mode striped with ONE rank: stripes of the record table, all in this GPU's HBM (prices the "
                          "stripe arithmetic of the kernel; with N ranks there is one stripe per rank)")
     ap.add_argument("--genera", type=int, default=0, help="size of the synthetic store: genera of 20 species (0: configs[1]'s store)")
-    ap.add_argument("--legs", default="main,large,filter,e2e,striped,dbbuild,long",
-                    help="comma list; large / filter / e2e / striped are the extra N = 1 objects (main always runs)")
+    ap.add_argument("--legs", default=ALL_LEGS, help="comma list of the extra N = 1 objects (main always runs)")
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
+                    help="auto: collect the roofline's counters in this run (rocprofv3 --pmc child passes); off: committed summaries")
+    ap.add_argument("--pmc-seconds", type=int, default=420, help="time budget of the in-run PMC passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return _pmc_child()
     legs = set(args.legs.split(","))
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    partitioned = args.mode == "partitioned"
+    striped = args.mode == "striped"
+    default_workload = args.reads == 10_000_000 and not partitioned and not striped and not args.genera
+
+    # ---- counters first: the PMC passes are child processes and must start before this process initialises the GPU
+    pmc, pmc_note = None, "off (--pmc off)"
+    if world == 1 and args.pmc == "auto" and default_workload:
+        import torch  # noqa: F401  (pages the libraries in before the children time out on a cold box)
+        pmc, pmc_note = _pmc_collect(args.pmc_seconds, args.reads)
 
     import torch
     import torch.distributed as dist
@@ -125,11 +390,6 @@ def main():
     from genestrip_amd import synth
     from genestrip_amd.distributed import merge_run_state, partitioned_finish, partitioned_match_batch, striped_store
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (genestrip_amd has no CPU fallback)")
     # GS_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: several ranks share GPU 0 and the merge runs over
@@ -139,11 +399,11 @@ def main():
     rehearsal = backend == "gloo"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d devices" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearsal else dev  # where the small control tensors of the collectives live
-    partitioned = args.mode == "partitioned"
-    striped = args.mode == "striped"
     force_merge = os.environ.get("GS_BENCH_FORCE_MERGE", "") == "1" or partitioned
     use_dist = world > 1 or force_merge
     if use_dist:
@@ -230,13 +490,7 @@ def main():
 
     total_bases = float(world) * n * READ_LEN * args.steps
     gbps = total_bases / elapsed / 1e9
-    achieved = n * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9  # GB/s, algorithmic bytes of one launch / its duration
-
-    # measured memory-side traffic of one launch: rocprofv3 --pmc passes of this same command (only valid for the
-    # default workload the profile was taken on)
-    traffic, traffic_src = (None, None)
-    if n == 10_000_000 and not partitioned and not striped and not args.genera:
-        traffic, traffic_src = _pmc_traffic("match")
+    conv = n * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9  # GB/s by the SURVEY 8d convention
 
     out = {
         "metric": "Gbp/s classified (match goal), k=31, 150bp reads; bit-exact CSV counts",
@@ -245,7 +499,8 @@ def main():
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "match: %d synthetic 150 bp reads per GPU, k=31, %d-k-mer / %d-taxid store resident in HBM "
                                "(BASELINE.json %s)" % (n, db.n_entries, len(db.species_vi),
-                                                       "configs[4]: a store spread over the GPUs' HBM" if striped else "configs[1]"),
+                                                       "configs[4]: a store spread over the GPUs' HBM; link-bound estimate in striped_store.xgmi_budget"
+                                                       if striped else "configs[1]"),
                    "reads_per_gpu": n, "read_len": READ_LEN, "k": K, "store_kmers": int(db.n_entries),
                    "store_record_bytes": int(info.rec_bytes), "store_table_bytes": int(info.table_bytes),
                    "gate_bytes": int(info.mgate_bytes or info.gate_bytes),
@@ -253,33 +508,69 @@ def main():
                    else ("reads sharded x%d, ONE store with its record table in %d stripes (%s)"
                          % (world, info.n_stripes, "one per GPU, foreign lines over xGMI" if world > 1 else "all in this GPU's HBM")) if striped
                    else ("read-sharded x%d, store replicated" % world)},
-        # `frac` follows SURVEY 8(d)'s convention (one 64-byte line per k-mer position over the HBM peak).  For this
-        # store it is NOT an HBM measurement: the 64 MiB table sits in the 256 MiB Infinity Cache and the minimizer gate
-        # removes the lines of most misses, so the kernel is bound by the fabric's rate of random 64-byte requests
-        # (~59 G/s, tools/probe_bw.hip).  `measured_frac` is what the counters saw; `large_store` below is the
-        # HBM-resident case.
-        "roofline": {"bound": "fabric random 64-byte line rate (table Infinity-Cache resident; HBM peak is the SURVEY 8d convention's denominator)",
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "measured_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic_note": None if traffic is None else
-                     "bytes per launch through the fabric (rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE, %s), not measured in this run" % traffic_src,
-                     "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
-                     "algorithmic_bytes_per_launch": n * BYTES_PER_READ,
-                     "issue_bound": None if traffic is None else _pmc_issue_bound("match", kern_ms)},
     }
 
-    # ---- parity gate.  N = 1: the first --check-reads reads against the CPU oracle (bit-exact integer table).
-    # N > 1 sharded: every rank must hold the same merged table, and rank 0 re-checks its own slice against the oracle.
-    # N > 1 partitioned: the first check_reads / N reads of EVERY rank's slice go through the collective pipeline once
-    # more and rank 0 compares the merged table with the oracle over exactly those reads.
-    nchk = min(args.check_reads, n)
+    # ---- ceilings measured now, on this device (rank 0 of a one-GPU run: the roofline is a single-GPU statement)
+    cal, cal_rep = (None, None)
+    foot_main = int(info.rec_bytes + info.table_bytes + (info.mgate_bytes or info.gate_bytes))
+    if world == 1:
+        cal, cal_rep = _calibrate(ga, {"lines_main": foot_main, "lines_1GiB": 1 << 30, "lines_filter": 226 << 20,
+                                       "lines_cal": CAL_LINES_BYTES})
+        if pmc and pmc.get("cal_lines"):
+            pmc["cal_lines"]["lines"] = ga.calibrate(ga.CAL_RANDOM_LINES, CAL_LINES_BYTES)["count"]
+        corr, corr_rep = _fetch_correction(pmc)
+        cal["fetch_correction"] = corr
+        cal_rep["fetch_size_calibration"] = corr_rep or "not taken (no in-run PMC pass): FETCH_SIZE used as reported (64-byte requests)"
+    cnt, src = (None, None)
+    if world == 1 and default_workload:
+        if pmc and pmc.get("match"):
+            cnt, src = pmc["match"], pmc_note
+        else:
+            cnt, src = _pmc_committed("match")
+            if src:
+                src += "; in-run passes: " + pmc_note
+    roof = {"kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
+            "algorithmic_bytes_per_launch": n * BYTES_PER_READ,
+            "frac_survey_convention": round(conv / HBM_PEAK_GBS, 4),
+            "survey_convention_note": "SURVEY 8(d): one 64-byte line per k-mer position + the sequence bytes, over the 8 TB/s HBM peak; above 1 "
+                                      "because the kernel no longer requests those lines (minimizer gate, super-k-mer records) -- kept for "
+                                      "continuity, NOT a resource fraction"}
+    if cal is not None:
+        res, fr = _resources(cnt, kern_ms, n, cal, "lines_main", src)
+        top, frac, bound = _name_bound(fr)
+        roof.update(res)
+        roof["resource_fracs"] = fr
+        roof["bound"] = "hbm" if top == "hbm" and frac >= 0.6 else bound
+        roof["frac"] = frac
+        if top == "hbm" or top is None:
+            roof.update({"achieved": res.get("fabric_bytes", {}).get("GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        elif top == "line_requests":
+            roof.update({"achieved": res["line_requests"]["G_per_s"], "peak": res["line_requests"]["ceiling_G_per_s"], "unit": "G lines/s"})
+        elif top == "valu_issue":
+            roof.update({"achieved": res["valu_issue"]["G_winst_per_s"], "peak": res["valu_issue"]["ceiling_G_winst_per_s"], "unit": "G wave-instructions/s"})
+        else:
+            roof.update({"achieved": res["salu_issue"]["G_inst_per_s"], "peak": res["salu_issue"]["ceiling_G_inst_per_s"], "unit": "G instructions/s"})
+        roof.setdefault("traffic", None)
+        roof["calibration"] = cal_rep
+    else:
+        roof.update({"bound": "not priced at N > 1 (the roofline is the N = 1 line's)", "achieved": None, "peak": None, "unit": None,
+                     "frac": None, "traffic": None})
+    out["roofline"] = roof
+
+    # ---- parity gate: the table of the TIMED steps against the CPU oracle over the same reads.
+    # N > 1: every rank must hold the same merged table and rank 0 checks it against the oracle over ALL ranks' slices
+    # (partitioned mode: a smaller re-run through the collective pipeline, the reads of every rank's slice head).
+    nchk = n if args.check_reads <= 0 else min(args.check_reads, n)
+    full = nchk == n
     ptable = None
-    if partitioned and world > 1:
-        per = max(1, nchk // world)
+    if (partitioned and world > 1) or (use_dist and world > 1 and not full):
+        # a shorter pass of every rank through the same collective path, merged: what rank 0 compares
         m.reset()
-        partitioned_match_batch(m, K, dseq, doff, per, first)
-        ptable, _ = partitioned_finish(m, t_sums, t_max, t_dsum)
+        if partitioned:
+            partitioned_match_batch(m, K, dseq, doff, nchk, first)
+            ptable, _ = partitioned_finish(m, t_sums, t_max, t_dsum)
+        else:
+            ptable, _ = step(nchk)
     if use_dist and world > 1:
         digest = torch.tensor([int(np.asarray(table, dtype=np.int64).sum() % (1 << 62))], dtype=torch.int64, device=cdev)
         lo, hi = digest.clone(), digest.clone()
@@ -291,74 +582,83 @@ def main():
         cores = _usable_cores()
         odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
         orun = orc.MatchRun(odb)
-        t1 = time.perf_counter()
-        if ptable is not None:
-            per = max(1, nchk // world)
-            for r in range(world):
-                seq, off = synth.reads_host(db.genomes, per, read_len=READ_LEN, first=r * n)
-                orun.submit(seq, off, first_read_no=r * n, threads=cores, per_read=False)
-            nchk = per * world
-        else:
-            seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=first)
-            orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
-        dt_chk = time.perf_counter() - t1
+        dt_chk = 0.0
+        for r in range(world):  # the slices of all ranks, one after the other (host memory: one slice at a time)
+            seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN, first=r * n)
+            t1 = time.perf_counter()
+            orun.submit(seq, off, first_read_no=r * n, threads=cores, per_read=False)
+            dt_chk += time.perf_counter() - t1
+            if world > 1:
+                del seq, off
         otable, _ = orun.finish()
         if ptable is not None:
             gtable = ptable
-        elif world > 1:
-            # rank 0 alone re-checks its own slice: no collectives here (the other ranks are already at the barrier)
-            m.reset()
-            m.submit(dseq, doff, first, n_reads=nchk)
-            gtable, _ = m.finish()
+        elif full:
+            gtable = table  # the table the last timed step returned
         else:
             gtable, _ = step(nchk)
         par = out.setdefault("parity", {})
-        par["reads_checked"] = nchk
+        par["reads_checked"] = nchk * world
+        par["reads_timed_per_step"] = n * world
+        par["what"] = ("the table of the last timed step" if full and ptable is None else "a shorter pass through the same path") + \
+                      " against the CPU oracle over the same reads (integer columns bit-exact)"
         par["bit_exact"] = bool(np.array_equal(otable, gtable))
         if not par["bit_exact"] or par.get("merged_table_identical_on_all_ranks") is False:
             out["value"] = None  # a throughput without parity does not count
-        if world == 1 and args.cpu_seconds > 0:
-            rate = nchk / dt_chk
-            ns = int(min(n, max(nchk, rate * args.cpu_seconds)))
-            seq, off = synth.reads_host(db.genomes, ns, read_len=READ_LEN, first=first)
-            orun = orc.MatchRun(odb)
-            dt, passes = 0.0, 0
-            while passes == 0 or (dt < 0.6 * args.cpu_seconds and passes < 8):  # (the estimate above comes from a cold, short run)
+        if world == 1:
+            # the CPU baseline is the parity pass itself (timed), repeated while the budget lasts
+            dt, passes = dt_chk, 1
+            while dt < 0.6 * args.cpu_seconds and passes < 8:
+                orun2 = orc.MatchRun(odb)
                 t1 = time.perf_counter()
-                orun.submit(seq, off, first_read_no=first, threads=cores, per_read=False)
+                orun2.submit(seq, off, first_read_no=0, threads=cores, per_read=False)
                 dt += time.perf_counter() - t1
                 passes += 1
+                del orun2
             out["cpu_baseline"] = {
-                "value": round(passes * ns * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
-                "sample": "first %d reads of the same stream%s, C restatement of the Java path (sorted array + "
+                "value": round(passes * nchk * READ_LEN / dt / 1e9, 5), "unit": "Gbp/s", "cores": cores, "kind": "port",
+                "sample": "%s %d reads of the same stream%s, C restatement of the Java path (sorted array + "
                           "Blocked-Bloom gate + binary search), %d OpenMP threads, %.1f s"
-                          % (ns, " x %d passes" % passes if passes > 1 else "", cores, dt)}
+                          % ("all" if full else "the first", nchk, " x %d passes" % passes if passes > 1 else "", cores, dt)}
             del seq, off
         odb.close()
-        if world == 1 and not partitioned and not striped and not args.genera:
+        if world == 1 and default_workload:
+            extra = {}
+            lps = roof.get("line_requests", {}).get("per_read")
             if "striped" in legs:
-                out["striped_store"] = leg_striped(ga, db, local_rank, dseq, doff, n, nchk, otable, kern_ms)
+                extra["striped_store"] = leg_striped(ga, db, local_rank, dseq, doff, n, otable, kern_ms, lps)
             if "e2e" in legs:
-                out["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
+                extra["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
             if "long" in legs:
-                out["long_reads"] = leg_long_reads(ga, synth, orc, torch, db, gen, m, dev, cores)
+                extra["long_reads"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 1000, 1_500_000, 200_000,
+                                                   "gs_match_kernel (queues) + gs_match_long_kernel")
+            if "r250" in legs:
+                extra["reads_250bp"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 250, 6_000_000, 1_000_000,
+                                                    "gs_match_kernel (220 k-mer positions per read)")
+            if "files" in legs:  # (last: it closes the matcher)
+                extra["file_pipeline"] = leg_files(ga, synth, orc, torch, dev, db, store, m, cores)
             m.close()
             store.close()
             del dseq, doff
             torch.cuda.empty_cache()
-            if "large" in legs or "filter" in legs or "dbbuild" in legs:
-                out.update(legs_large(ga, synth, orc, torch, dev, legs, cores))
+            if "tableonly" in legs:
+                extra["table_only"] = leg_table_only(ga, synth, orc, torch, dev, cores)
+            if legs & {"large", "filter", "dbbuild"}:
+                extra.update(legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note))
+            if "huge" in legs:
+                extra["huge_store"] = leg_huge(ga, synth, orc, torch, dev, cores)
+            out.update(extra)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def leg_striped(ga, db, device, dseq, doff, n, nchk, otable, plain_ms, stripes=8):
+def leg_striped(ga, db, device, dseq, doff, n, otable, plain_ms, lines_per_read, stripes=8):
     """BASELINE.json configs[4] (a store spread over 8 GPUs) as far as ONE GPU can show it: the same store with its record
     and overflow tables in 8 stripes (gs_db_create_striped, all stripes in this GPU's HBM), the same 10 M reads through the
     striped instantiation of the fused kernel -- stripe pointer per bucket from LDS, seen bits in the run's bitmap.  What
-    is not in this number is the xGMI hop of a foreign line.  Parity: the first nchk reads against the oracle table."""
+    is not in this number is the xGMI hop of a foreign line: `xgmi_budget` prices it.  Parity: all n reads."""
     stores = ga.DeviceKMerStore.striped(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, devices=(device,) * stripes)
     ms = ga.FastqKMerMatcher(stores[stripes // 2], ga.MatchConfig(profile=True))
     info = stores[0].info
@@ -369,22 +669,36 @@ def leg_striped(ga, db, device, dseq, doff, n, nchk, otable, plain_ms, stripes=8
 
     kms, _ = _kernel_ms(ms, launch, 5)
     ms.reset()
-    ms.submit(dseq, doff, 0, n_reads=nchk)
+    ms.submit(dseq, doff, 0, n_reads=n)
     table, _ = ms.finish()
     ms.close()
     for s in stores:
         s.close()
-    return {"stripes": stripes, "stripe_bytes": int(info.stripe_bytes), "kernel_ms": round(kms, 4),
-            "gbps": round(n * READ_LEN / kms / 1e6, 2), "kernel_ms_plain_store": round(plain_ms, 4),
-            "over_plain": round(kms / plain_ms, 4), "where": "all stripes in this GPU's HBM (no xGMI hop in this number)",
-            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
+    res = {"stripes": stripes, "stripe_bytes": int(info.stripe_bytes), "kernel_ms": round(kms, 4),
+           "gbps": round(n * READ_LEN / kms / 1e6, 2), "kernel_ms_plain_store": round(plain_ms, 4),
+           "over_plain": round(kms / plain_ms, 4), "where": "all stripes in this GPU's HBM (no xGMI hop in this number)",
+           "parity": {"reads_checked": n, "bit_exact": bool(np.array_equal(table, otable))}}
+    if lines_per_read:
+        # record / table lines per read = fabric requests minus the read's own sequence bytes (150 B = 2.34 lines), (N-1)/N of them foreign
+        store_lines = max(0.0, lines_per_read - READ_LEN / 64.0)
+        foreign = store_lines * 64.0 * (stripes - 1) / stripes
+        link = XGMI_LINKS * XGMI_GBS_PER_LINK_DIR * 1e9
+        reads_s = n / (kms * 1e-3)
+        res["xgmi_budget"] = {
+            "foreign_bytes_per_read": round(foreign, 1), "reads_per_s_kernel": round(reads_s / 1e9, 3),
+            "inbound_GBs_needed_at_kernel_rate": round(foreign * reads_s / 1e9, 1),
+            "inbound_GBs_available": round(link / 1e9, 1), "links": "%d x %.1f GB/s per direction" % (XGMI_LINKS, XGMI_GBS_PER_LINK_DIR),
+            "link_bound_gbps_per_gpu": round(min(reads_s, link / max(foreign, 1e-9)) * READ_LEN / 1e9, 1),
+            "verdict": "LINK-BOUND ESTIMATE: at N = 8 the striped mode is limited by inbound xGMI before small-packet overhead; a "
+                       "store that fits one GPU's HBM (a 473 M-k-mer store takes 9 GiB of 288 GB) is REPLICATED instead (the default "
+                       "--mode sharded), striping is for stores beyond one GPU"}
+    return res
 
 
-def leg_long_reads(ga, synth, orc, torch, db, gen, m, dev, cores, read_len=1000, n=1_500_000, nchk=20_000):
-    """The same store and the same number of bases as configs[1], as reads of 1000 bp: more than 128 k-mer positions, so they
-    take gs_match_long_kernel (one wave per read, 128 positions per iteration, contig / vote state carried from iteration to
-    iteration; queued by gs_match_kernel in chunks, drawn from a shared cursor).  Whole step (reset, submit, sync) by the
-    host clock, best of 3.  Parity: the first nchk reads against the oracle table."""
+def leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, read_len, n, nchk, kernel):
+    """The configs[1] store and about the same number of bases as reads of another length (250 bp: 220 k-mer positions, the
+    paired-end length; 1000 bp: the long-read kernel).  Whole step (reset, submit, sync) by the host clock, best of 4.
+    Parity: the first nchk reads against the oracle table."""
     dseq = torch.empty(n * read_len, dtype=torch.uint8, device=dev)
     doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
     synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=read_len)
@@ -408,7 +722,7 @@ def leg_long_reads(ga, synth, orc, torch, db, gen, m, dev, cores, read_len=1000,
     otable, _ = orun.finish()
     odb.close()
     del dseq, doff
-    return {"workload": "match: %d reads x %d bp, k=%d, the configs[1] store" % (n, read_len, K), "kernel": "gs_match_kernel (queues) + gs_match_long_kernel",
+    return {"workload": "match: %d reads x %d bp, k=%d, the configs[1] store" % (n, read_len, K), "kernel": kernel,
             "ms_per_step": round(best * 1e3, 3), "gbps": round(n * read_len / best / 1e9, 2),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
 
@@ -454,6 +768,273 @@ def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):
             "table_equals_device_resident_run": bool(np.array_equal(host_table, dev_table))}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# file pipeline: FASTQ files written in this run -> gs_host_match_files / gs_host_filter_files
+# ---------------------------------------------------------------------------------------------------------------
+def _fastq_text(seq, n, read_len=READ_LEN):
+    """four-line FASTQ of n fixed-length reads as one uint8 array (fixed-width descriptors '@r0001234')"""
+    width = 2 + 8 + 1
+    rec = width + read_len + 3 + read_len + 1
+    a = np.empty((n, rec), dtype=np.uint8)
+    a[:, 0] = ord("@")
+    a[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        a[:, 2 + 7 - d] = (idx % 10 + 48).astype(np.uint8)
+        idx //= 10
+    a[:, width - 1] = 10
+    a[:, width:width + read_len] = seq.reshape(n, read_len)
+    a[:, width + read_len:width + read_len + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    a[:, width + read_len + 3:rec - 1] = ord("I")
+    a[:, rec - 1] = 10
+    return a.reshape(-1)
+
+
+def _deflate_piece(job):
+    import zlib
+    path, start, size, last, bgzf = job
+    with open(path, "rb") as f:
+        f.seek(start)
+        c = f.read(size)
+    if bgzf:  # members of <= 64 KiB that state their size, as bgzip writes them
+        import struct
+        parts = []
+        for a in range(0, len(c), 65280):
+            blk = c[a:a + 65280]
+            z = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = z.compress(blk) + z.flush()
+            parts.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(body) + 8 - 1) + body +
+                         struct.pack("<II", zlib.crc32(blk), len(blk)))
+        return b"".join(parts), 0, len(c)
+    z = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = z.compress(c) + (z.flush(zlib.Z_FINISH) if last else z.flush(zlib.Z_FULL_FLUSH))
+    return body, zlib.crc32(c), len(c)
+
+
+def _write_gz(plain, out, bgzf, procs):
+    """compress `plain` on a process pool: ONE gzip member made of independently deflated 8 MiB pieces joined by full flushes
+    (what pigz writes), or BGZF blocks"""
+    import multiprocessing as mp
+    import struct
+    import zlib
+    size = os.path.getsize(plain)
+    piece = 8 << 20
+    jobs = [(plain, a, min(piece, size - a), a + piece >= size, bgzf) for a in range(0, size, piece)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_deflate_piece, jobs)
+    with open(out, "wb") as f:
+        if bgzf:
+            for body, _, _ in parts:
+                f.write(body)
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")  # the empty end-of-file block
+        else:
+            f.write(b"\x1f\x8b\x08\0\0\0\0\0\0\xff")
+            crc = 0
+            for body, c, ln in parts:
+                f.write(body)
+                crc = _crc32_combine(crc, c, ln)
+            f.write(struct.pack("<II", crc & 0xffffffff, size & 0xffffffff))
+
+
+def _crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (GF(2) matrix form), in Python"""
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[i]) for i in range(32)]
+
+    if len2 <= 0:
+        return crc1
+    odd = [0xedb88320] + [1 << i for i in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
+    """SURVEY 8(f2) as the driver sees it: a four-line FASTQ of n reads written in this run (plain, .gz as pigz writes it, BGZF)
+    -> gs_host_match_files (raw text blocks to the device, records found there; own parallel inflate) -> table, which must equal
+    the table of the same reads resident in HBM; and the `filter` goal over the plain file with the accepted reads written
+    (BASELINE.json configs[2]'s filtered-FASTQ writeback) against the resident filter run.  Files in the page cache."""
+    from genestrip_amd import host
+    seq, off = synth.reads_host(db.genomes, n, read_len=READ_LEN)
+    tmp = tempfile.mkdtemp(prefix="gsbench_files_")
+    res = {"reads": n, "tmp": tempfile.gettempdir()}
+    try:
+        plain = os.path.join(tmp, "reads.fastq")
+        t0 = time.perf_counter()
+        _fastq_text(seq, n).tofile(plain)
+        gz, bz = plain + ".gz", os.path.join(tmp, "reads.bgzf.fastq.gz")
+        _write_gz(plain, gz, False, cores)
+        _write_gz(plain, bz, True, cores)
+        res["inputs_written_s"] = round(time.perf_counter() - t0, 1)
+        m.reset()
+        m.submit(seq, off, 0)
+        want, _ = m.finish()
+        m.close()  # (one unique-counting run per store: gs_host_match_files begins its own)
+        for label, path in (("plain", plain), ("gz", gz), ("bgzf", bz)):
+            best, table = None, None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                table, _, tot = host.match_files(store, [path])[:3]
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            res[label] = {"file_bytes": os.path.getsize(path), "seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2),
+                          "file_GBs": round(os.path.getsize(path) / best / 1e9, 2),
+                          "table_equals_resident_run": bool(np.array_equal(table, want)), "reads_seen": int(tot.reads)}
+        # the filter goal with writeback
+        bloom, (keys, bits, hashes, factors, words) = _index_filter(ga, synth, torch, dev, db)
+        flt = ga.FastqBloomFilter(K, bloom, 1, 0.2)
+        acc = flt.accept_reads(seq, off)
+        outp = os.path.join(tmp, "filtered.fastq")
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tot = host.filter_files(bloom, K, [plain], 1, 0.2, filtered_path=outp)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rec_len = (2 + 8 + 1) + READ_LEN + 3 + READ_LEN + 1
+        res["filter_writeback"] = {"seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2),
+                                   "accepted_reads": int(tot.filtered_reads), "accepted_equals_resident_filter": bool(int(acc.sum()) == int(tot.filtered_reads)),
+                                   "output_bytes": os.path.getsize(outp),
+                                   "output_size_as_expected": bool(os.path.getsize(outp) == int(acc.sum()) * rec_len)}
+        bloom.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def leg_table_only(ga, synth, orc, torch, dev, cores, k=16, n=10_000_000, nchk=1_000_000):
+    """A store without super-k-mer records (k < 19; the reference allows k = 15..31, C/GSConfigKey.java:70, and its own
+    ComprehensiveMatchTest runs k = 16): every k-mer is a slot of the bucket table, gated by the word gate.  150-bp reads have
+    135 k-mer positions at k = 16 -- more than 128.  Parity: the first nchk reads."""
+    db = synth.SynthDB(k=k)
+    gen = torch.from_numpy(db.genomes).to(dev)
+    dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN)
+    torch.cuda.synchronize()
+    store = ga.DeviceKMerStore(k, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    info = store.info
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
+    best = None
+    for _ in range(4):
+        m.reset()
+        m.sync()
+        t0 = time.perf_counter()
+        m.submit(dseq, doff, 0, n_reads=n)
+        m.sync()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    m.reset()
+    m.submit(dseq, doff, 0, n_reads=nchk)
+    gt, _ = m.finish()
+    seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN)
+    odb = orc.DB(k, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    orun = orc.MatchRun(odb)
+    orun.submit(seq, off, threads=cores, per_read=False)
+    ot, _ = orun.finish()
+    odb.close()
+    m.close()
+    store.close()
+    return {"workload": "match: %d reads x 150 bp, k=%d, %d-k-mer store WITHOUT records (bucket table only)" % (n, k, db.n_entries),
+            "table_bytes": int(info.table_bytes), "record_bytes": int(info.rec_bytes), "ms_per_step": round(best * 1e3, 3),
+            "gbps": round(n * READ_LEN / best / 1e9, 2), "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))}}
+
+
+def leg_huge(ga, synth, orc, torch, dev, cores, genera=250, n=10_000_000, nchk=200_000):
+    """BASELINE.json configs[4]'s store size on ONE GPU: ~473 M k-mers / 5 251 values built ON THE DEVICE from 5 000 synthetic
+    genomes (gs_dbbuild: FillDBGoal + DBGoal, then the device layout builder), 10 M reads through the fused kernel -- plain and as
+    8 stripes in this GPU's HBM --, oracle spot check over the first nchk reads against the arrays the builder returned."""
+    t0 = time.perf_counter()
+    db = synth.SynthDB(k=K, genera=genera, species_per_genus=20, build=False)
+    t_gen = time.perf_counter() - t0
+    g = db.genomes
+    gen = torch.from_numpy(g).to(dev)
+    goff = torch.arange(g.shape[0] + 1, dtype=torch.int64, device=dev) * g.shape[1]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = ga.DeviceDbBuilder(K, db.n_values, db.parent_vi)
+    b.add(gen.reshape(-1), goff, db.species_vi, update=False)
+    b.add(gen.reshape(-1), goff, db.species_vi, update=True)
+    kmers, vals = b.finish()
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    store = b.to_store()
+    t_layout = time.perf_counter() - t0
+    b.close()
+    info = store.info
+    dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+    doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    synth.reads_device(gen, g.shape[0], g.shape[1], n, dseq, doff, read_len=READ_LEN)
+    torch.cuda.synchronize()
+    m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
+
+    def launch():
+        m.reset()
+        m.submit(dseq, doff, 0, n_reads=n)
+
+    kms, wall = _kernel_ms(m, launch, 4)
+    m.reset()
+    m.submit(dseq, doff, 0, n_reads=nchk)
+    gt, _ = m.finish()
+    m.close()
+    seq, off = synth.reads_host(g, nchk, read_len=READ_LEN)
+    odb = orc.DB(K, kmers, vals, db.n_values, db.parent_vi)
+    orun = orc.MatchRun(odb)
+    orun.submit(seq, off, threads=cores, per_read=False)
+    ot, _ = orun.finish()
+    odb.close()
+    res = {"workload": "match: %d reads x 150 bp, k=31, %d-k-mer / %d-value store built on the device from %d genomes" % (n, len(kmers), db.n_values, g.shape[0]),
+           "store_kmers": int(len(kmers)), "n_values": int(db.n_values), "record_bytes": int(info.rec_bytes), "table_bytes": int(info.table_bytes),
+           "mgate_bytes": int(info.mgate_bytes), "in_records_frac": round(info.n_in_records / max(1, info.n_stored), 4),
+           "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3), "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2),
+           "build_s": {"genomes_host": round(t_gen, 1), "gs_dbbuild_incl_fetch": round(t_build, 2), "layout_on_device": round(t_layout, 2)},
+           "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))}}
+    store.close()
+    torch.cuda.empty_cache()
+    # the same store as 8 stripes in this GPU's HBM (what every GPU of configs[4] would run, minus the xGMI hop)
+    stores = ga.DeviceKMerStore.striped(K, kmers, vals, db.n_values, db.parent_vi, devices=(dev.index or 0,) * 8)
+    ms = ga.FastqKMerMatcher(stores[3], ga.MatchConfig(profile=True))
+
+    def launch_s():
+        ms.reset()
+        ms.submit(dseq, doff, 0, n_reads=n)
+
+    kms_s, _ = _kernel_ms(ms, launch_s, 4)
+    ms.reset()
+    ms.submit(dseq, doff, 0, n_reads=nchk)
+    gts, _ = ms.finish()
+    ms.close()
+    for s in stores:
+        s.close()
+    res["striped_8"] = {"kernel_ms": round(kms_s, 3), "gbps": round(n * READ_LEN / (kms_s * 1e-3) / 1e9, 2),
+                        "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gts))}}
+    del gen, dseq, doff
+    torch.cuda.empty_cache()
+    return res
+
+
 def leg_db_build(ga, orc, torch, db, gen):
     """the compute core of FillDBGoal + DBGoal on the device (gs_dbbuild): the 47 M-k-mer store of the large-store
     leg from its 500 genomes -- every genome as a fill region and again as an update region (DBGoal walks the whole
@@ -496,11 +1077,22 @@ def leg_db_build(ga, orc, torch, db, gen):
                              "sample": "the first %d genomes through orc_build_* (fill, sort, update)" % ns}}
 
 
-def legs_large(ga, synth, orc, torch, dev, legs, cores):
+def _priced(cal, cnt, src, kms, n, footprint_key):
+    """roofline fields of an extra leg (same pricing as the headline)"""
+    if cal is None:
+        return {}
+    res, fr = _resources(cnt, kms, n, cal, footprint_key, src)
+    top, frac, bound = _name_bound(fr)
+    res.update({"resource_fracs": fr, "bound": "hbm" if top == "hbm" and frac is not None and frac >= 0.6 else bound, "frac": frac})
+    return res
+
+
+def legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note):
     """BASELINE.json configs[2] / configs[3] per GPU: a 47 M-k-mer / 526-value store (1 GiB table, four times the
-    Infinity Cache) and the XOR index filter over its species k-mers (~47 M keys, 1.8 G bits, 27 hashes)."""
+    Infinity Cache) and the XOR index filter over its species k-mers (~47 M keys, 1.8 G bits, 27 hashes).  Parity over the
+    first 2 M reads of the timed stream; the filter also at configs[2]'s own read count (100 M reads resident in HBM)."""
     res = {}
-    n, nchk = 10_000_000, 100_000
+    n, nchk = 10_000_000, 2_000_000
     t0 = time.perf_counter()
     db = synth.SynthDB(k=K, genera=25, species_per_genus=20)
     t_db = time.perf_counter() - t0
@@ -510,6 +1102,13 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores):
     synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=READ_LEN)
     torch.cuda.synchronize()
     seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN)
+
+    def counters(name):
+        if pmc and pmc.get(name):
+            return pmc[name], pmc_note
+        c, s = _pmc_committed(name)
+        return c, (s + "; in-run passes: " + pmc_note) if s else None
+
     if "dbbuild" in legs:
         res["db_build"] = leg_db_build(ga, orc, torch, db, gen)
     if "large" in legs:
@@ -532,28 +1131,22 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores):
         m.reset()
         m.submit(dseq, doff, 0, n_reads=nchk)
         gt, _ = m.finish()
-        traffic, src = _pmc_traffic("large_store")
+        cnt, src = counters("large_store")
         ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9
-        res["large_store"] = {
+        obj = {
             "workload": "match: %d reads x 150 bp, k=31, %d-k-mer / %d-value store" % (n, db.n_entries, db.n_values),
             "store_kmers": int(db.n_entries), "n_values": int(db.n_values), "record_bytes": int(info.rec_bytes), "table_bytes": int(info.table_bytes),
             "mgate_bytes": int(info.mgate_bytes), "kernel": "gs_match_kernel<global counters, k=31>",
             "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3), "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2),
-            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "measured_frac": None if traffic is None else round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic_note": None if traffic is None else "rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE per launch, %s" % src,
+            "frac_survey_convention": round(ach / HBM_PEAK_GBS, 4),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))},
             "build_s": {"synthetic_arrays": round(t_db, 1), "gs_db_create": round(t_store, 1)}}
+        obj.update(_priced(cal, cnt, src, kms, n, "lines_1GiB"))
+        res["large_store"] = obj
         m.close()
         store.close()
     if "filter" in legs:
-        keys = db.kmers[np.isin(db.value_idx, db.species_vi)]  # BloomIndexGoal: k-mers of the requested taxa
-        bits, hashes, factors = synth.xor_bloom_geometry(len(keys), 1e-8)
-        dwords = torch.zeros((bits + 63) // 64, dtype=torch.int64, device=dev)
-        synth.xor_bloom_device(torch.from_numpy(keys).to(dev), len(keys), bits, torch.from_numpy(factors).to(dev), hashes, dwords)
-        words = dwords.cpu().numpy().view(np.uint64)
-        del dwords
-        bloom = ga.DeviceBloomFilter(ga.BLOOM_XOR, bits, factors, words)
+        bloom, (keys, bits, hashes, factors, words) = _index_filter(ga, synth, torch, dev, db)
         flt = ga.FastqBloomFilter(K, bloom, 1, 0.2, profile=True)
         acc = torch.empty(n, dtype=torch.uint8, device=dev)
         kms, wall = _kernel_ms(flt, lambda: flt.submit(dseq, doff, acc, n_reads=n), 5)
@@ -562,20 +1155,35 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores):
         same_filter = bool(ob.bits == bits and np.array_equal(ob.words, words))
         want = ob.filter_batch(K, 1, 0.2, seq, off, threads=cores)
         got = acc[:nchk].cpu().numpy()
-        traffic, src = _pmc_traffic("filter")
+        cnt, src = counters("filter")
         ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9
-        res["filter"] = {
+        obj = {
             "workload": "filter: %d reads x 150 bp, k=31, XOR index filter of %d keys (%d bits, %d hashes), minPosCount 1" % (n, len(keys), bits, hashes),
             "filter_keys": int(len(keys)), "filter_bytes": int(len(words) * 8), "n_hashes": int(hashes),
             "kernel": "gs_filter_kernel", "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3),
             "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2), "accepted_frac": round(float(acc.float().mean()), 4),
-            "bound": "fabric random 64-byte line rate (every filter bit is a random line of the bit array; members need 27)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "lines_per_read": None if traffic is None else round(traffic / 64 / n, 1),
-            "measured_frac": None if traffic is None else round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic_note": None if traffic is None else "rocprofv3 --pmc FETCH_SIZE+WRITE_SIZE per launch, %s" % src,
+            "frac_survey_convention": round(ach / HBM_PEAK_GBS, 4),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(want, got)), "filter_bits_equal_oracle": same_filter}}
+        obj.update(_priced(cal, cnt, src, kms, n, "lines_filter"))
+        # configs[2] at its own read count: 100 M reads resident in HBM (15 GB), one launch; the accept flags of the first
+        # 10 M reads must be the ones the 10 M-read launch produced (same stream, same read numbers)
+        n2 = 100_000_000
+        del dseq, doff
+        torch.cuda.empty_cache()
+        dseq2 = torch.empty(n2 * READ_LEN, dtype=torch.uint8, device=dev)
+        doff2 = torch.empty(n2 + 1, dtype=torch.int64, device=dev)
+        synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n2, dseq2, doff2, read_len=READ_LEN)
+        acc2 = torch.empty(n2, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        kms2, _ = _kernel_ms(flt, lambda: flt.submit(dseq2, doff2, acc2, n_reads=n2), 2, warm=1)
+        obj["configs2_100M_reads"] = {"reads": n2, "kernel_ms": round(kms2, 2), "gbps": round(n2 * READ_LEN / (kms2 * 1e-3) / 1e9, 2),
+                                      "accepted_frac": round(float(acc2.float().mean()), 4),
+                                      "first_10M_flags_equal_the_10M_launch": bool(torch.equal(acc2[:n], acc)),
+                                      "first_2M_flags_equal_oracle": bool(np.array_equal(want, acc2[:nchk].cpu().numpy()))}
+        res["filter"] = obj
         bloom.close()
+        del dseq2, doff2, acc2
+        torch.cuda.empty_cache()
     return res
 
 

@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "gs_filter_submit_text", "gs_filter_text_wait_copy", "gs_filter_text_status", "gs_filter_text_reset",
     "gs_filter_submit_fasta", "gs_filter_submit_fastq_ml", "gs_filter_text_read_bounds", "gs_filter_text_line_classes",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
+    "gs_calibrate",
 )
 
 
@@ -153,6 +154,7 @@ def lib():
         "gs_bloom_get": (ci, [vp, vp, vp, vp, vp, i64]), "gs_bloom_destroy": (ci, [vp]),
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
         "gs_filter_kernel_time": (ci, [vp, vp, vp]),
+        "gs_calibrate": (ci, [ci, ci, i64, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -174,6 +176,17 @@ def device_count():
     n = C.c_int(0)
     rc = lib().gs_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+CAL_VALU_PURE, CAL_VALU_MIX, CAL_SALU, CAL_VALU_SALU = 0, 1, 2, 3
+CAL_VMEM_BYTES, CAL_VMEM_WORDS, CAL_VMEM_SHARED_LINES, CAL_VMEM_SCATTERED, CAL_RANDOM_LINES = 4, 5, 6, 7, 8
+
+
+def calibrate(what, arg=0, device=0):
+    """gs_calibrate: a measured ceiling of the device (include/gsgpu.h) -> dict(rate, ms, count, n_cu)"""
+    out = (C.c_double * 4)()
+    _check(lib().gs_calibrate(device, what, arg, out))
+    return {"rate": out[0], "ms": out[1], "count": out[2], "n_cu": int(out[3])}
 
 
 def _ptr(a):

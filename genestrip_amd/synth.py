@@ -51,7 +51,8 @@ def canonical_kmers(seq, k):
 class SynthDB:
     """arrays of a synthetic store: kmers (sorted int64), value_idx, parent_vi, genomes (S_total x genome_len)"""
 
-    def __init__(self, k=31, genera=4, species_per_genus=5, genome_len=100_000, seed=42, native=True):
+    def __init__(self, k=31, genera=4, species_per_genus=5, genome_len=100_000, seed=42, native=True, build=True):
+        """build=False: tree and genomes only (the store is then built from the genomes on the device, gs_dbbuild)"""
         self.k, self.genome_len = k, genome_len
         n_species = genera * species_per_genus
         # value indices in pre-order: root 0, genus, its species, next genus ...
@@ -77,19 +78,21 @@ class SynthDB:
         n_seg = genome_len // seg
         # the shared segments are the same for every member of a genus (5 %) / for every species (1 %)
         root_pick = (_splitmix64(seed * 7 + 1, n_seg) % np.uint64(100)) < np.uint64(1)
+        covered = n_seg * seg
+        root_rep = np.repeat(root_pick, seg)
         for g in range(genera):
             genus_core = _random_dna(seed * 1000003 + 100 + g, genome_len)
             genus_pick = (_splitmix64(seed * 7 + 100 + g, n_seg) % np.uint64(100)) < np.uint64(5)
+            # (a root segment wins over a genus segment)
+            shared = np.where(root_rep, root_core[:covered], genus_core[:covered])
+            is_shared = root_rep | np.repeat(genus_pick, seg)
             for s in range(species_per_genus):
                 i = g * species_per_genus + s
-                gen = _random_dna(seed * 1000003 + 10000 + i, genome_len).copy()
-                for b in range(n_seg):
-                    src = root_core if root_pick[b] else genus_core if genus_pick[b] else None
-                    if src is not None:
-                        gen[b * seg:(b + 1) * seg] = src[b * seg:(b + 1) * seg]
+                gen = _random_dna(seed * 1000003 + 10000 + i, genome_len)
                 genomes[i] = gen
+                genomes[i, :covered] = np.where(is_shared, shared, gen[:covered])
         self.genomes = genomes
-        self.kmers, self.value_idx = (_build_native if native else _build_numpy)(genomes, k, self.species_vi, self.parent_vi)
+        self.kmers, self.value_idx = (_build_native if native else _build_numpy)(genomes, k, self.species_vi, self.parent_vi) if build else (None, None)
 
     @property
     def n_entries(self):

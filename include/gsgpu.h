@@ -459,6 +459,23 @@ int gs_filter_text_read_bounds(gs_bloom *bloom, uint64_t *bounds);
 int gs_filter_text_line_classes(gs_bloom *bloom, uint8_t *classes);
 int gs_filter_kernel_time(gs_bloom *bloom, int64_t *launches, double *total_ms);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement support (no reference counterpart; not on the data path): the ceilings of the device the kernels run on,
+ * measured with small calibration kernels at the match kernel's occupancy (8 waves per SIMD), so that a benchmark prices
+ * its kernels against numbers taken in the same process on the same chip (bench.py `roofline`).
+ *   out[0] = rate: wave64 instructions per second over the whole device (VALU_PURE: full-rate 32-bit ops; VALU_MIX: the
+ *            match kernel's instruction mix; SALU; VALU_SALU: an alternating stream, both kinds counted), wave-level load
+ *            instructions per second (VMEM_*: byte loads of 64 consecutive bytes / dword loads of 8 distinct words /
+ *            16-byte loads with 8 lanes per 64-byte line / 16-byte loads with a line per lane, all cache resident), or
+ *            random 64-byte lines per second from a table of `arg` bytes (RANDOM_LINES)
+ *   out[1] = milliseconds of the timed launch, out[2] = instructions / loads / lines it issued, out[3] = compute units */
+enum {
+    GS_CAL_VALU_PURE = 0, GS_CAL_VALU_MIX = 1, GS_CAL_SALU = 2, GS_CAL_VALU_SALU = 3,
+    GS_CAL_VMEM_BYTES = 4, GS_CAL_VMEM_WORDS = 5, GS_CAL_VMEM_SHARED_LINES = 6, GS_CAL_VMEM_SCATTERED = 7,
+    GS_CAL_RANDOM_LINES = 8
+};
+int gs_calibrate(int device, int what, int64_t arg, double out[4]);
+
 #ifdef __cplusplus
 }
 #endif
