@@ -45,43 +45,65 @@ __device__ __forceinline__ int gs_lane() { return (int)__lane_id(); }
 __device__ __forceinline__ int gs_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int gs_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// developer instrumentation (tools/phase_times.sh: -DGS_PHASE=1): wave cycles per phase of the short-read path, summed over all
+// waves (s_memtime at the phase boundaries; `dep` is a value the phase produces, so the stamp sits behind the wait for it)
+#ifndef GS_PHASE
+#define GS_PHASE 0
+#endif
+#if GS_PHASE
+__device__ unsigned long long gs_phase_acc[16];
+__device__ __forceinline__ unsigned long long *gs_phase_row() {
+    __shared__ unsigned long long ph[4][16];
+    return ph[threadIdx.x >> 6];
+}
+__device__ __forceinline__ void gs_stamp(int i) {
+    const unsigned long long t = __builtin_readcyclecounter();
+    if (gs_lane() == 0) {
+        unsigned long long *p = gs_phase_row();
+        const unsigned long long last = p[15];
+        p[15] = t;
+        if (i >= 0) p[i] += t - last;
+    }
+}
+#define GS_STAMP(i, dep)                \
+    {                                   \
+        asm volatile("" ::"v"(dep));    \
+        gs_stamp(i);                    \
+    }
+extern "C" int gs_debug_phase(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_phase_acc), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gs_phase_acc), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define GS_STAMP(i, dep) {}
+#endif
+
 // bits [s, s+64) of the 128-bit string (b:a), s in 0..63
 __device__ __forceinline__ u64 gs_funnel(u64 a, u64 b, int s) { return (a >> s) | ((b << 1) << (63 - s)); }
 
-// ASCII base -> reference 2-bit code (C0 G1 A2 T3); valid only for upper-case ACGT (CGAT.java:66-69)
-__device__ __forceinline__ void gs_base_code(uint32_t c, uint32_t &code, bool &ok) {
-    uint32_t x = (c >> 1) & 3u;  // A->0 C->1 T->2 G->3
-    code = (0x72u >> (2 * x)) & 3u;
-    ok = c == ((0x47544341u >> (8 * x)) & 0xffu);
+// ASCII bases -> ballot planes of the reference's 2-bit codes (C0 G1 A2 T3, upper case only: CGAT.java:66-69), from a byte that was
+// loaded earlier (0 for the lanes beyond the read).  Straight-line: x = bits 1..2 of the
+// byte (A 0, C 1, T 2, G 3), the one upper-case letter with that x from a byte permute, code-hi = x even, code-lo = x >= 2
+// (C0 G1 A2 T3); a byte that is not its letter (N, lower case, CR, NUL, the 0 of a lane beyond the read) has planes 0 --
+// every window that holds such a byte is INVALID whatever its planes say -- and counts as bad inside the read.
+__device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64 &hi, u64 &lo, u64 &bad) {
+    const uint32_t x = (c >> 1) & 3u;
+    const uint32_t want = __builtin_amdgcn_perm(0u, 0x47544341u, x | 0x0c0c0c00u);
+    const bool ok = c == want;
+    hi = __ballot(ok & ((x & 1u) == 0u));
+    lo = __ballot(ok & (x >= 2u));
+    bad = __ballot(in_range & !ok);
 }
 
 // one 64-base word of a read -> ballot planes
 __device__ __forceinline__ void gs_load_word(const uint8_t *rd, int L, int w, int lane, u64 &hi, u64 &lo, u64 &bad) {
     const int j = 64 * w + lane;
-    uint32_t code = 0;
-    bool b = false;
-    if (j < L) {
-        bool ok;
-        gs_base_code(rd[j], code, ok);
-        b = !ok;
-    }
-    hi = __ballot((code & 2u) != 0);
-    lo = __ballot((code & 1u) != 0);
-    bad = __ballot(b);
-}
-
-// the same planes from a byte that was loaded earlier (software prefetch of the next read)
-__device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64 &hi, u64 &lo, u64 &bad) {
-    uint32_t code = 0;
-    bool b = false;
-    if (in_range) {
-        bool ok;
-        gs_base_code(c, code, ok);
-        b = !ok;
-    }
-    hi = __ballot((code & 2u) != 0);
-    lo = __ballot((code & 1u) != 0);
-    bad = __ballot(b);
+    const uint32_t c = j < L ? rd[j] : 0u;
+    gs_word_from_byte(c, j < L, hi, lo, bad);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -326,11 +348,15 @@ __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, 
 // which the lane that picks a position reads back instead of recomputing it.  cf[s] = that word for the lane's minimizer.
 template <int KC>
 __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u64 (&Blo)[3], const uint32_t (&fhi)[2],
-                                                   const uint32_t (&flo)[2], int k, int lane, uint32_t *wave_g, int (&p)[2],
-                                                   uint32_t (&cf)[2]) {
+                                                   const uint32_t (&flo)[2], const uint32_t (&rhi)[2], const uint32_t (&rlo)[2], int k,
+                                                   int lane, uint32_t *wave_g, int (&p)[2], uint32_t (&cf)[2]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const uint32_t c = gs_lmer_canon(fhi[s] & 0x7fffu, flo[s] & 0x7fffu);
+        // gs_lmer_canon of the k-mer's first 15-mer; its reverse complement is the top 15 bases of the k-mer's (rhi, rlo: the
+        // orientation step needs them anyway), and "the smaller of f and r, low bit = f was it" is min(2f + 1, 2r)
+        const uint32_t f = ((fhi[s] & 0x7fffu) << GS_MIN_L) | (flo[s] & 0x7fffu);
+        const uint32_t rr = ((rhi[s] >> (k - GS_MIN_L)) << GS_MIN_L) | (rlo[s] >> (k - GS_MIN_L));
+        const uint32_t c = min((f << 1) | 1u, rr << 1);
         wave_g[64 * s + lane] = gs_lmer_rank(gs_canon_hash(c >> 1), (uint32_t)(64 * s + lane));
         wave_g[GS_ROW + 64 * s + lane] = c;
     }
@@ -343,16 +369,20 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int w = k - GS_MIN_L + 1;
+    // The ranks of a lane's k - 14 positions are read in ONE batch per sub-round (the loads are independent; left to itself the
+    // compiler waits after every ds_read2 because of the 64-register budget: nine LDS round trips in a row per sub-round), then
+    // folded with min3.
+    constexpr int ND = KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        uint32_t mn = 0xffffffffu;
+        uint32_t g[ND];
 #pragma unroll
-        for (int d = 0; d < (KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L); d++) {
-            if (KC || d < w) {
-                const uint32_t g = wave_g[64 * s + lane + d];
-                mn = g < mn ? g : mn;
-            }
-        }
+        for (int d = 0; d < ND; d++) g[d] = (KC || d < w) ? wave_g[64 * s + lane + d] : 0xffffffffu;
+        __builtin_amdgcn_sched_group_barrier(0x100, (ND + 1) / 2, 0);  // the DS reads first ...
+        uint32_t mn = g[0];
+#pragma unroll
+        for (int d = 1; d < ND; d++) mn = g[d] < mn ? g[d] : mn;
+        __builtin_amdgcn_sched_group_barrier(0x002, ND, 0);            // ... then the min chain
         const int idx = (int)(mn & 0xffu);
         cf[s] = wave_g[GS_ROW + idx];
         p[s] = idx - (64 * s + lane);
@@ -387,21 +417,31 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         // minimizer gate: lanes that share a minimizer read the same gate word -> one request
         int mp[2];
         uint32_t cf[2];
-        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
+        GS_STAMP(2, fhi[1] ^ flo[1])
+        uint32_t rhi[2], rlo[2];  // reverse complement of the k-mer
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            rhi[s] = __brev(fhi[s]) >> (32 - k);
+            rlo[s] = (__brev(flo[s]) >> (32 - k)) ^ kmask;
+        }
+        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, rhi, rlo, k, lane, wave_g, mp, cf);
+        GS_STAMP(3, cf[0] ^ cf[1])
         uint32_t gh[2], ohi[2], olo[2];
         int j[2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const uint32_t rhi = __brev(fhi[s]) >> (32 - k);
-            const uint32_t rlo = (__brev(flo[s]) >> (32 - k)) ^ kmask;
-            gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi, rlo, k, mp[s], gh[s], ohi[s], olo[s], j[s]);
-        }
+        for (int s = 0; s < 2; s++) gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi[s], rlo[s], k, mp[s], gh[s], ohi[s], olo[s], j[s]);
+        if ((GS_ABLATE & 4) == 0) {
+            // the gate words of both sub-rounds are requested together (lanes without a live k-mer read word 0): one round
+            // trip, no exec-mask regions
+            uint32_t gw[2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            if ((GS_ABLATE & 4) == 0 && act[s]) {
+            for (int s = 0; s < 2; s++) gw[s] = db.mgate[act[s] ? gs_mgate_word(gh[s], db.mgate_bits) : 0u];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
                 const uint32_t bits = gs_mgate_bits(gh[s]);
-                act[s] = (db.mgate[gs_mgate_word(gh[s], db.mgate_bits)] & bits) == bits;  // no false negatives
+                act[s] = act[s] & ((gw[s] & bits) == bits);  // no false negatives
             }
+            GS_STAMP(4, gw[0] ^ gw[1])
         }
         if (GS_ABLATE & 6) {  // keep the values alive, look nothing up
 #pragma unroll
@@ -411,14 +451,17 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         }
         if (STRIPED || db.rec != nullptr) {
             // ---- super-k-mer records: both candidate buckets of the minimizer at once -- per bucket one 16-byte load of
-            // the window planes + the 8-byte word that holds this offset's value
-            const u64 M47 = (1ULL << GS_REC_WIN_BITS) - 1;
+            // the window planes + the 8-byte word that holds this offset's value; the loads of BOTH sub-rounds are issued
+            // before the first compare (one round trip), and the compares are straight-line code (bitwise, no short-circuit
+            // branches: every branch is an exec-mask save / restore on the scalar unit, which this kernel keeps as busy as the
+            // vector unit)
+            if (__ballot(act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
                 if (act[s]) {
-                    const int jj = j[s];
-                    const int jw = (jj * 11) >> 5;  // j / 3 for j <= 16
+                    const uint32_t jj = (uint32_t)j[s];
+                    const int jw = (int)(jj * 11u) >> 5;  // j / 3 for j <= 16
                     const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
                     const u64 *r0, *r1;
                     if (STRIPED) {  // the stripe's (biased) base pointer from the wave's copy of the table, behind the hash rows
@@ -430,22 +473,30 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     }
                     const gs_u64x2 A0 = *reinterpret_cast<const gs_u64x2 *>(r0), A1 = *reinterpret_cast<const gs_u64x2 *>(r1);
                     const u64 V0 = r0[2 + jw], V1 = r1[2 + jw];
-                    const bool ok0 = ((uint32_t)((A0.x & M47) >> jj) & kmask) == ohi[s] && ((uint32_t)((A0.y & M47) >> jj) & kmask) == olo[s] &&
-                                     ((A0.y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
-                    const bool ok1 = ((uint32_t)((A1.x & M47) >> jj) & kmask) == ohi[s] && ((uint32_t)((A1.y & M47) >> jj) & kmask) == olo[s] &&
-                                     ((A1.y >> (GS_REC_WIN_BITS + jj)) & 1ULL);
-                    if (ok0 || ok1) {  // (an eligible k-mer is filed in exactly one window)
-                        const u64 V = ok0 ? V0 : V1, Ax = ok0 ? A0.x : A1.x;
-                        const uint32_t rb = ok0 ? b0 : b1;
-                        node[s] = (int)((V >> (GS_REC_VAL_BITS * (jj - 3 * jw))) & (GS_REC_MAX_VALUES - 1));
+                    // window bits [j, j + k) of a plane: j + k <= 2k - 15, so the seen / valid bits above the window stay out
+                    // of the low k bits of the shifted word; one 32-bit funnel shift (j <= 16) per plane
+                    const uint32_t x0 = __builtin_amdgcn_alignbit((uint32_t)(A0.x >> 32), (uint32_t)A0.x, jj);
+                    const uint32_t y0 = __builtin_amdgcn_alignbit((uint32_t)(A0.y >> 32), (uint32_t)A0.y, jj);
+                    const uint32_t x1 = __builtin_amdgcn_alignbit((uint32_t)(A1.x >> 32), (uint32_t)A1.x, jj);
+                    const uint32_t y1 = __builtin_amdgcn_alignbit((uint32_t)(A1.y >> 32), (uint32_t)A1.y, jj);
+                    const uint32_t fbit = 1u << (GS_REC_WIN_BITS - 32 + jj);  // seen (w0) / valid (w1) bit of offset j, high dword
+                    const bool ok0 = ((((x0 ^ ohi[s]) | (y0 ^ olo[s])) & kmask) == 0) & (((uint32_t)(A0.y >> 32) & fbit) != 0);
+                    const bool ok1 = ((((x1 ^ ohi[s]) | (y1 ^ olo[s])) & kmask) == 0) & (((uint32_t)(A1.y >> 32) & fbit) != 0);
+                    const bool hit = ok0 | ok1;  // (an eligible k-mer is filed in exactly one window)
+                    const u64 V = ok0 ? V0 : V1;
+                    const uint32_t seen_hi = ok0 ? (uint32_t)(A0.x >> 32) : (uint32_t)(A1.x >> 32);
+                    const uint32_t rb = ok0 ? b0 : b1;
+                    const int val = (int)((V >> (GS_REC_VAL_BITS * ((int)jj - 3 * jw))) & (GS_REC_MAX_VALUES - 1));
+                    node[s] = hit ? val : node[s];
+                    if (hit) {
                         if (STRIPED) {
                             if (mk.count_unique && ((mk.rec_seen[rb] >> jj) & 1u) == 0) atomicOr(mk.rec_seen + rb, 1u << jj);
-                        } else if (mk.count_unique && ((Ax >> (GS_REC_WIN_BITS + jj)) & 1ULL) == 0)
+                        } else if (mk.count_unique && (seen_hi & fbit) == 0)
                             atomicOr(const_cast<u64 *>(db.rec) + (u64)rb * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
                         if (mk.hit_counts != nullptr)
                             atomicAdd(mk.hit_counts + ((u64)(bmask + 1u) * GS_SLOTS_PER_BUCKET + (u64)rb * GS_REC_SLOTS + (u64)jj), 1u);
                     }
-                    pending = !(ok0 || ok1) && ((V0 | V1) & GS_REC_MORE) != 0;
+                    pending = !hit & (((V0 | V1) & GS_REC_MORE) != 0);
                 }
                 // a k-mer whose window found no bucket (or that has two strand views) lives in the table
                 if (__ballot(pending) != 0) {
@@ -550,6 +601,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     }
                 }
             }
+            if (!LONG) GS_STAMP(1, (uint32_t)(Bhi[0] ^ Bhi[2]))
             // ---- 2/3. k-mers + probe, both sub-rounds in flight
             int node[2];
             if (FROM_NODES) {
@@ -571,6 +623,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 gs_probe_planes<KC, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
+            if (!LONG) GS_STAMP(5, node[0] ^ node[1])
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
             found = found || ((hit0 | hit1) != 0);
             n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
@@ -732,6 +785,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     }
                 }
             }
+            if (!LONG) GS_STAMP(6, node[0])
             {   // carry: node of the last valid position of this iteration
                 const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
                 const int ls = (last_p - base) >> 6, ll = (last_p - base) & 63;
@@ -928,6 +982,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         if (P.class_vi) P.class_vi[r] = out_class;
         if (P.flags) P.flags[r] = (uint8_t)out_flags;
     }
+    if (!LONG) GS_STAMP(7, out_class)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1028,14 +1083,28 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         s_cur[wave_in_block][1] = 64;
     }
     GS_STRIPE_TABLE((const GsMatchParams *)kp0)
+#if GS_PHASE
+    if (lane < 16) gs_phase_row()[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    gs_stamp(-1);
+#endif
     uint32_t lq_base = 0, lq_used = GS_LONG_CHUNK;  // this wave's chunk of the long-read queue
-    for (int64_t r = wave_id; r < n_reads; r += n_waves) {
+    // (Software pipelines over the wave's reads were measured again in round 3, after the LDS and gate round trips had been batched:
+    // (1) the bases of the next read into a second LDS buffer by LDS-DMA and the offsets two reads ahead, requested at the top of
+    // the iteration: 7.59 -> 7.77 ms on configs[1] -- requests OLDER than the gate loads are waited for with them (in-order
+    // counter), the latency only moves; (2) the same requests issued behind the gate loads, the youngest at every later wait: the
+    // waits for offsets and bases shrink from 3 250 to 1 650 wave cycles per read (tools/phase_times.sh) and every other phase
+    // grows by as much: 7.62 ms, 47 M-k-mer store 9.22 -> 9.41 ms.  The SIMD is short of issue slots, not of overlap.)
+    const int64_t po_step = n_waves * P.off_stride;        // stride 1: running offsets; 2: (start, end) pairs
+    const uint64_t *po = P.off + wave_id * P.off_stride;   // offsets of the current read
+    for (int64_t r = wave_id; r < n_reads; r += n_waves, po += po_step) {
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
         const GsMatchParams &Q = *(const GsMatchParams *)kp;
-        const uint64_t *po = Q.off + r * Q.off_stride;  // stride 1: running offsets; 2: (start, end) pairs
         const u64 off = po[0];
         const int L = (int)(po[1] - off);
+        GS_STAMP(0, L)
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
             if (lq_used == GS_LONG_CHUNK) {  // a fresh chunk of the queue for this wave
                 uint32_t b = 0;
@@ -1053,6 +1122,10 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
                                                      s_g[wave_in_block], s_cur[wave_in_block]);
     }
+#if GS_PHASE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 15) atomicAdd(&gs_phase_acc[lane], gs_phase_row()[lane]);
+#endif
     if (lq_used < GS_LONG_CHUNK && (uint32_t)lane >= lq_used) P.long_list[lq_base + (uint32_t)lane] = GS_LONG_NONE;  // (rest of the last chunk)
     if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1256,7 +1329,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
                 // it rules out are not routed at all
                 int mp[2];
                 uint32_t cf[2];
-                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
+                uint32_t rhi[2], rlo[2];
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    rhi[s] = __brev(fhi[s]) >> (32 - k);
+                    rlo[s] = (__brev(flo[s]) >> (32 - k)) ^ kmask;
+                }
+                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, rhi, rlo, k, lane, wave_g, mp, cf);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
@@ -1326,7 +1405,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_route_kernel(GsEncodeParam
             if (P.mgate != nullptr) {
                 int mp[2];
                 uint32_t cf[2];
-                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, k, lane, wave_g, mp, cf);
+                uint32_t rhi[2], rlo[2];
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    rhi[s] = __brev(fhi[s]) >> (32 - k);
+                    rlo[s] = (__brev(flo[s]) >> (32 - k)) ^ kmask;
+                }
+                gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, rhi, rlo, k, lane, wave_g, mp, cf);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     if (base + 64 * s + lane < max && key[s] != GS_KEY_INVALID) {
