@@ -86,24 +86,24 @@ extern "C" int gs_debug_phase(unsigned long long *out, int reset) {
 __device__ __forceinline__ u64 gs_funnel(u64 a, u64 b, int s) { return (a >> s) | ((b << 1) << (63 - s)); }
 
 // ASCII bases -> ballot planes of the reference's 2-bit codes (C0 G1 A2 T3, upper case only: CGAT.java:66-69), from a byte that was
-// loaded earlier (0 for the lanes beyond the read).  Straight-line: x = bits 1..2 of the
-// byte (A 0, C 1, T 2, G 3), the one upper-case letter with that x from a byte permute, code-hi = x even, code-lo = x >= 2
-// (C0 G1 A2 T3); a byte that is not its letter (N, lower case, CR, NUL, the 0 of a lane beyond the read) has planes 0 --
-// every window that holds such a byte is INVALID whatever its planes say -- and counts as bad inside the read.
-__device__ __forceinline__ void gs_word_from_byte(uint32_t c, bool in_range, u64 &hi, u64 &lo, u64 &bad) {
+// loaded earlier; lanes beyond the read hold GS_FILL ('C': code 0, valid -- planes 0 and not bad, without a range test).
+// Straight-line, every ballot one integer compare: x = bits 1..2 of the byte (A 0, C 1, T 2, G 3), d = byte ^ the one upper-case
+// letter with that x (a byte permute), code-hi = x even, code-lo = bit 2 of the byte; a byte that is not its letter (N, lower
+// case, CR, NUL) has d != 0: planes 0 -- every window that holds such a byte is INVALID whatever its planes say -- and bad.
+#define GS_FILL 0x43u
+__device__ __forceinline__ void gs_word_from_byte(uint32_t c, u64 &hi, u64 &lo, u64 &bad) {
     const uint32_t x = (c >> 1) & 3u;
-    const uint32_t want = __builtin_amdgcn_perm(0u, 0x47544341u, x | 0x0c0c0c00u);
-    const bool ok = c == want;
-    hi = __ballot(ok & ((x & 1u) == 0u));
-    lo = __ballot(ok & (x >= 2u));
-    bad = __ballot(in_range & !ok);
+    const uint32_t d = c ^ __builtin_amdgcn_perm(0u, 0x47544341u, x | 0x0c0c0c00u);
+    hi = __ballot(((x & 1u) | d) == 0u);
+    lo = __ballot((((c ^ 4u) & 4u) | d) == 0u);
+    bad = __ballot(d != 0u);
 }
 
 // one 64-base word of a read -> ballot planes
 __device__ __forceinline__ void gs_load_word(const uint8_t *rd, int L, int w, int lane, u64 &hi, u64 &lo, u64 &bad) {
     const int j = 64 * w + lane;
-    const uint32_t c = j < L ? rd[j] : 0u;
-    gs_word_from_byte(c, j < L, hi, lo, bad);
+    const uint32_t c = j < L ? rd[j] : GS_FILL;
+    gs_word_from_byte(c, hi, lo, bad);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -586,7 +586,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 if (LONG)
                     gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
                 else
-                    gs_word_from_byte(pre[w], 64 * w + lane < L, Bhi[w], Blo[w], Bbad[w]);
+                    gs_word_from_byte(pre[w], Bhi[w], Blo[w], Bbad[w]);
             }
             {   // bad-base census for the INVALID-iteration closed form; word 2 belongs to the next iteration
                 const int q = max - 1;
@@ -1117,8 +1117,9 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
             continue;
         }
         uint32_t pre[3];
+        const uint8_t *rd = Q.seq + off;
 #pragma unroll
-        for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? Q.seq[off + 64 * w + lane] : 0u;
+        for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? rd[64 * w + lane] : GS_FILL;
         gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
                                                      s_g[wave_in_block], s_cur[wave_in_block]);
     }
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
         L = (int)(P.off[wave_id + 1] - off);
         pb = P.pos_off[wave_id];
 #pragma unroll
-        for (int i = 0; i < 3; i++) c[i] = 64 * i + lane < L ? P.seq[off + 64 * i + lane] : 0u;
+        for (int i = 0; i < 3; i++) c[i] = 64 * i + lane < L ? P.seq[off + 64 * i + lane] : GS_FILL;
     }
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
         const int max = L - k + 1;
@@ -1306,13 +1307,13 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_encode_kernel(GsEncodeParams P) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 if (base == 0)
-                    gs_word_from_byte(c[i], 64 * i + lane < L, Bhi[i], Blo[i], Bbad[i]);
+                    gs_word_from_byte(c[i], Bhi[i], Blo[i], Bbad[i]);
                 else
                     gs_load_word(rd, L, (base >> 6) + i, lane, Bhi[i], Blo[i], Bbad[i]);
             }
             if (base == 0 && rn < P.n_reads) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) cN[i] = 64 * i + lane < LN ? P.seq[offN + 64 * i + lane] : 0u;
+                for (int i = 0; i < 3; i++) cN[i] = 64 * i + lane < LN ? P.seq[offN + 64 * i + lane] : GS_FILL;
             }
             if (max <= 0) break;
             u64 key[2];
