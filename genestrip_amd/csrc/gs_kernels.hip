@@ -390,6 +390,7 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
     __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next iteration / read
 }
 
+#define GS_ACT(m) __builtin_amdgcn_inverse_ballot_w64(m)  // a wave-level mask as a per-lane condition
 template <int KC, bool STRIPED>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
@@ -401,17 +402,24 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
     const uint32_t bmask = (uint32_t)db.bucket_mask;  // n_buckets <= 2^29
     const bool any_bad = (Bbad[0] | Bbad[1] | Bbad[2]) != 0;
     uint32_t fhi[2], flo[2];
-    bool act[2];
+    // Which lanes hold a live k-mer is kept as a wave-level MASK (a scalar register pair), not as a per-lane flag: "position < max"
+    // is a mask the scalar unit builds from the read length, every later condition is one vector compare whose result is a
+    // mask already, and a mask conditions a lane directly (inverse ballot) -- no flag is materialised in a vector register and
+    // compared again.
+    u64 act[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const int p = base + 64 * s + lane;
-        const bool valid = p < max;
+        const int nv = max - base - 64 * s;  // valid positions of this sub-round
+        const u64 vm = nv >= 64 ? ~0ULL : (nv <= 0 ? 0ULL : ((1ULL << nv) - 1ULL));
         fhi[s] = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
         flo[s] = (uint32_t)gs_funnel(Blo[s], Blo[s + 1], lane) & kmask;
-        // almost every read is clean: the per-lane window test is skipped on a wave-uniform branch
-        const uint32_t wbad = any_bad ? (uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask : 0u;
-        act[s] = valid && (wbad == 0);
-        node[s] = valid ? (wbad ? GS_NODE_INVALID : GS_NODE_MISS) : GS_NODE_NONE;
+        act[s] = vm;
+        node[s] = GS_ACT(vm) ? GS_NODE_MISS : GS_NODE_NONE;
+        if (any_bad) {  // almost every read is clean: the per-lane window test sits behind a wave-uniform branch
+            const u64 wb = __ballot(((uint32_t)gs_funnel(Bbad[s], Bbad[s + 1], lane) & kmask) != 0u) & vm;
+            act[s] = vm & ~wb;
+            node[s] = GS_ACT(wb) ? GS_NODE_INVALID : node[s];
+        }
     }
     if (db.mgate != nullptr) {
         // minimizer gate: lanes that share a minimizer read the same gate word -> one request
@@ -435,18 +443,18 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // trip, no exec-mask regions
             uint32_t gw[2];
 #pragma unroll
-            for (int s = 0; s < 2; s++) gw[s] = db.mgate[act[s] ? gs_mgate_word(gh[s], db.mgate_bits) : 0u];
+            for (int s = 0; s < 2; s++) gw[s] = db.mgate[GS_ACT(act[s]) ? gs_mgate_word(gh[s], db.mgate_bits) : 0u];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const uint32_t bits = gs_mgate_bits(gh[s]);
-                act[s] = act[s] & ((gw[s] & bits) == bits);  // no false negatives
+                act[s] &= __ballot((gw[s] & bits) == bits);  // no false negatives
             }
             GS_STAMP(4, gw[0] ^ gw[1])
         }
         if (GS_ABLATE & 6) {  // keep the values alive, look nothing up
 #pragma unroll
             for (int s = 0; s < 2; s++)
-                if (act[s] && (gh[s] ^ ohi[s] ^ olo[s] ^ (uint32_t)j[s]) == 0x12345u) node[s] = 0;
+                if (GS_ACT(act[s]) && (gh[s] ^ ohi[s] ^ olo[s] ^ (uint32_t)j[s]) == 0x12345u) node[s] = 0;
             return;
         }
         if (STRIPED || db.rec != nullptr) {
@@ -455,11 +463,11 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // before the first compare (one round trip), and the compares are straight-line code (bitwise, no short-circuit
             // branches: every branch is an exec-mask save / restore on the scalar unit, which this kernel keeps as busy as the
             // vector unit)
-            if (__ballot(act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
+            if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
-                if (act[s]) {
+                if (GS_ACT(act[s])) {
                     const uint32_t jj = (uint32_t)j[s];
                     const int jw = (int)(jj * 11u) >> 5;  // j / 3 for j <= 16
                     const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
@@ -516,16 +524,20 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         const u64 h = gs_kmer_hash(fhi[s], flo[s], k, kmask);
         bkt[s] = (uint32_t)h & bmask;
         want[s] = (h >> db.bucket_bits) << shift_rem;
-        if (db.mgate == nullptr && db.gate != nullptr && act[s]) {  // word gate (L2-resident), no false negatives
-            const u64 gbits = gs_gate_field_bits((uint32_t)(h >> GS_GATE_FIELD_SHIFT));
-            act[s] = (db.gate[(h >> db.bucket_bits) & db.gate_mask] & gbits) == gbits;
+        if (db.mgate == nullptr && db.gate != nullptr) {  // word gate (L2-resident), no false negatives
+            bool pass = false;
+            if (GS_ACT(act[s])) {
+                const u64 gbits = gs_gate_field_bits((uint32_t)(h >> GS_GATE_FIELD_SHIFT));
+                pass = (db.gate[(h >> db.bucket_bits) & db.gate_mask] & gbits) == gbits;
+            }
+            act[s] = __ballot(pass);
         }
-        if (act[s]) gs_load_half(db.table, bkt[s], 0, bk[s]);  // both sub-rounds' loads in flight together
+        if (GS_ACT(act[s])) gs_load_half(db.table, bkt[s], 0, bk[s]);  // both sub-rounds' loads in flight together
     }
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         bool pending = false;
-        if (act[s]) {
+        if (GS_ACT(act[s])) {
             int vs = -1, sl = 0;
             const bool done = gs_match_half(bk[s], want[s], vmask2, vs, sl);
             if (vs >= 0) gs_take_hit<false>(db, bkt[s] * GS_SLOTS_PER_BUCKET + sl, vs, node[s], mk);
