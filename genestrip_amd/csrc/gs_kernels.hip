@@ -672,8 +672,13 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     prev[0] = lane == 0 ? carry_last : up0;
                     prev[1] = lane == 0 ? last0 : up1;
                 }
-                const u64 chg0 = __ballot(node[0] != GS_NODE_NONE && node[0] != prev[0]);
-                const u64 chg1 = __ballot(node[1] != GS_NODE_NONE && node[1] != prev[1]);
+                // (positions >= max hold NONE: the first of them differs from its predecessor and is masked away; wave-level masks
+                // throughout, as in gs_probe_planes)
+                const int nv0 = max - base, nv1 = max - base - 64;
+                const u64 vm0 = nv0 >= 64 ? ~0ULL : (nv0 <= 0 ? 0ULL : ((1ULL << nv0) - 1ULL));
+                const u64 vm1 = nv1 >= 64 ? ~0ULL : (nv1 <= 0 ? 0ULL : ((1ULL << nv1) - 1ULL));
+                const u64 chg0 = __ballot(node[0] != prev[0]) & vm0;
+                const u64 chg1 = __ballot(node[1] != prev[1]) & vm1;
                 // a hit contig left open by the previous iteration ends at the first change of this one
                 if (LONG && carry_last >= 0 && (chg0 | chg1) != 0) {
                     const int q = chg0 ? __builtin_ctzll(chg0) : 64 + __builtin_ctzll(chg1);
@@ -684,17 +689,20 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                     const int e1 = chg1 ? 64 + __builtin_ctzll(chg1) : -1;
                     const int end0 = a0 ? lane + 1 + __builtin_ctzll(a0) : e1;
                     const int end1 = a1 ? 64 + lane + 1 + __builtin_ctzll(a1) : -1;
-                    const bool c0 = node[0] >= 0 && node[0] != prev[0] && end0 >= 0;
-                    const bool c1 = node[1] >= 0 && node[1] != prev[1] && end1 >= 0;
+                    // a lane books a contig if it starts a hit contig (hit and change) and a later change closes it: in word 0
+                    // any change of word 1 or a change above the lane, in word 1 a change above the lane
+                    const u64 c0m = hit0 & chg0 & (chg1 ? ~0ULL : (chg0 ? (1ULL << (63 - __builtin_clzll(chg0))) - 1ULL : 0ULL));
+                    const u64 c1m = hit1 & chg1 & (chg1 ? (1ULL << (63 - __builtin_clzll(chg1))) - 1ULL : 0ULL);
+                    const bool c0 = GS_ACT(c0m), c1 = GS_ACT(c1m);
                     if (REC && deferred) {  // every contig belongs to one_vi: add them up in scalar registers
                         const int len0 = c0 ? end0 - lane : 0, len1 = c1 ? end1 - 64 - lane : 0;
-                        for (u64 sm = __ballot(c0); sm; sm &= sm - 1) {
+                        for (u64 sm = c0m; sm; sm &= sm - 1) {
                             const int l = gs_readlane(len0, __builtin_ctzll(sm));
                             def_contigs++;
                             def_sq += l * l;
                             def_max = l > def_max ? l : def_max;
                         }
-                        for (u64 sm = __ballot(c1); sm; sm &= sm - 1) {
+                        for (u64 sm = c1m; sm; sm &= sm - 1) {
                             const int l = gs_readlane(len1, __builtin_ctzll(sm));
                             def_contigs++;
                             def_sq += l * l;
