@@ -3225,6 +3225,13 @@ extern "C" int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint
     *overflow = 0;
     if (n_reads <= 0) return GS_OK;
     HIP_TRY(hipSetDevice(run->db->device));
+    {   // a routed key carries its position in the batch as 32 bits (send_idx, ~0 = unused slot): as gs_route_keys, refuse a batch
+        // whose positions do not fit instead of scattering the answers to truncated positions
+        u64 n_pos = 0;
+        HIP_TRY(hipMemcpyAsync(&n_pos, pos_off + n_reads, sizeof(u64), hipMemcpyDeviceToHost, run->stream));
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        if (n_pos >= 0xffffffffULL) return fail(GS_E_INVALID, "more than 2^32-2 k-mer positions in one batch: split the batch");
+    }
     if (!run->d_route_cursors) HIP_TRY(hipMalloc((void **)&run->d_route_cursors, sizeof(u64) * 65));
     HIP_TRY(hipMemsetAsync(run->d_route_cursors, 0, sizeof(u64) * 65, run->stream));
     GsEncodeParams P{};

@@ -108,6 +108,21 @@ def _attach_all(store, rank, world, group):
     return store
 
 
+def striped_store_close(store, matchers=(), group=None):
+    """Collective.  Takes a striped store down in the only safe order: every rank finishes (closes) its runs, ALL ranks meet,
+    then every rank frees its handle -- which unmaps the foreign stripes and frees its own.  Without the barrier a rank could
+    free its stripe while a kernel of another rank still reads record lines from it through the IPC mapping (a GPU memory fault
+    in that process)."""
+    for m in matchers:
+        m.sync()
+        m.close()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group)
+    store.close()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group)
+
+
 def striped_store_from_file(path, device=0, group=None):
     """Collective.  As striped_store, from a store file (DeviceKMerStore.save of the store built once): every rank reads the
     image, keeps its stripe and attaches the others; nobody rebuilds the layout."""
@@ -216,6 +231,18 @@ def _all_to_all_views(recv, recv_counts, send_views, send_counts, group):
         dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
 
 
+MAX_BATCH_POSITIONS = 0xfffffffe  # a routed key carries its position in the batch as 32 bits, ~0 marks an unused slot
+
+
+def check_batch_positions(n_keys):
+    """the k-mer positions of one DB-partitioned batch must fit the 32-bit routing index (gs_match_encode_route and gs_route_keys
+    refuse more as well): ~35.8 M reads of 150 bp at k = 31 -- split larger batches"""
+    if n_keys > MAX_BATCH_POSITIONS:
+        raise ValueError("a DB-partitioned batch holds %d k-mer positions; at most %d fit the routing index: split the batch"
+                         % (n_keys, MAX_BATCH_POSITIONS))
+    return n_keys
+
+
 def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, group=None, class_vi=None, flags=None,
                             cap=None):
     """One batch in DB-partitioned mode on this rank (matcher's store = this rank's partition).
@@ -229,7 +256,7 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
     world = dist.get_world_size(group)
     dev = seq.device
     pos_off = position_offsets(offsets[:n_reads + 1], k)
-    n_keys = int(pos_off[-1].item())
+    n_keys = check_batch_positions(int(pos_off[-1].item()))
     if n_keys == 0:
         nodes = torch.empty(1, dtype=torch.int32, device=dev)
         matcher.reduce(seq, offsets, pos_off, nodes, n_reads, first_read_no, class_vi, flags)
@@ -276,7 +303,7 @@ def partitioned_match_batch_unfused(matcher, k, seq, offsets, n_reads, first_rea
     seq / offsets: device tensors (uint8 / int64).  Collective: every rank of the group must call it."""
     world = dist.get_world_size(group)
     pos_off = position_offsets(offsets[:n_reads + 1], k)
-    n_keys = int(pos_off[-1].item())
+    n_keys = check_batch_positions(int(pos_off[-1].item()))
     keys = torch.empty(max(n_keys, 1), dtype=torch.int64, device=seq.device)
     matcher.encode(seq, offsets, pos_off, keys, n_reads)
     matcher.sync()

@@ -118,3 +118,30 @@ def test_position_offsets():
     off = torch.tensor([0, 10, 40, 41, 200], dtype=torch.int64)
     assert gd.position_offsets(off, 31).tolist() == [0, 0, 0, 0, 129]
     assert gd.position_offsets(off, 2).tolist() == [0, 9, 38, 38, 196]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """bench.py --gpus N without a launcher starts its ranks itself -- and exits non-zero, before any GPU call and without
+    printing a line, when fewer than N devices are visible (a SCALE run must never record N copies of the N = 1
+    number)"""
+    import subprocess
+    import sys
+
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GS_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, n))], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert "device(s) visible" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
+
+
+def test_partitioned_batch_refuses_positions_beyond_the_routing_index():
+    """a routed key carries its batch position as 32 bits; a batch with more positions must be refused, not truncated"""
+    from genestrip_amd import distributed as gd
+    assert gd.check_batch_positions(0) == 0 and gd.check_batch_positions(gd.MAX_BATCH_POSITIONS) == gd.MAX_BATCH_POSITIONS
+    with pytest.raises(ValueError):
+        gd.check_batch_positions(gd.MAX_BATCH_POSITIONS + 1)
+    with pytest.raises(ValueError):
+        gd.check_batch_positions(1 << 33)

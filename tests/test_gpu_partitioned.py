@@ -222,6 +222,32 @@ def test_fused_encode_route_equals_encode_plus_route(sdb, world):
     store.close()
 
 
+def test_encode_route_refuses_a_batch_whose_positions_overflow_the_routing_index(sdb):
+    """gs_match_encode_route stores a routed key's batch position as 32 bits (~0 = unused slot); pos_off[n_reads] >=
+    2^32 - 1 must come back as GS_E_INVALID before anything is launched (gs_route_keys refuses the same)"""
+    dev = torch.device("cuda", 0)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, n_parts=1, part=0, partition=True)
+    m = ga.FastqKMerMatcher(store)
+    seq, off = _reads(sdb, 4)
+    dseq = torch.from_numpy(seq).to(dev)
+    doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+    for total, ok in ((480, True), (0xfffffffe, True), (0xffffffff, False), (1 << 33, False)):
+        pos = torch.tensor([0, 120, 240, 360, total], dtype=torch.int64, device=dev)
+        keys = torch.empty(2048, dtype=torch.int64, device=dev)
+        idx = torch.empty(2048, dtype=torch.int32, device=dev)
+        nodes = torch.empty(600, dtype=torch.int32, device=dev)
+        if ok and total > 480:
+            continue  # (a legal size this large would need 16 GB of nodes; the boundary itself is checked from the refusing side)
+        if ok:
+            m.encode_route(dseq, doff, pos, 4, 1, 2048, keys, idx, nodes)
+        else:
+            with pytest.raises(ga.GsError) as e:
+                m.encode_route(dseq, doff, pos, 4, 1, 2048, keys, idx, nodes)
+            assert e.value.code == -1
+    m.close()
+    store.close()
+
+
 def test_partitioned_batch_fused_unfused_and_overflow_fallback(sdb):
     """partitioned_match_batch under a 1-rank RCCL group: the fused route, the explicit unfused route and the fallback
     when a region is too small all end in the oracle's table"""
