@@ -290,6 +290,7 @@ struct StoreImage {
     size_t gate_words = 0;
     const uint32_t *mgate = nullptr;
     size_t mgate_words = 0;
+    uint32_t mgate_ctx = 0;  // the gate is keyed by gs_gate_ctx_key
     const u64 *rec = nullptr;
     size_t rec_words = 0;
     const int32_t *parent = nullptr, *depth = nullptr, *tin = nullptr, *tout = nullptr;
@@ -364,6 +365,7 @@ static int store_upload(const StoreImage &im, int dev_no, int stripes, int part,
     db->dev.mgate = db->d_mgate;
     db->dev.mgate_bits = 0;
     while (((size_t)1 << db->dev.mgate_bits) < im.mgate_words) db->dev.mgate_bits++;
+    db->dev.mgate_ctx = im.mgate_ctx;
     db->info.mgate_bytes = (int64_t)(im.mgate_words * sizeof(uint32_t));
     db->dev.bucket_bits = (uint32_t)im.b;
     db->dev.vbits = (uint32_t)im.vbits;
@@ -550,9 +552,9 @@ static int tree_arrays(int32_t n_values, const int32_t *parent_vi, std::vector<i
 // ---------------------------------------------------------------------------------------------------
 // the layout built on the device (gs_layout_build.hip): same rules as the host builder below
 // ---------------------------------------------------------------------------------------------------
-enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_COUNTERS };
+enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_COUNTERS };
 extern "C" hipError_t gs_lb_perkey(const int64_t *kmers, const int32_t *vidx, int64_t n, int k, const int32_t *parent, uint32_t *e_gh, uint32_t *e_ohi,
-                                   uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort, u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh,
+                                   uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort, u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh, uint32_t *h_ctx,
                                    u64 *cnt, hipStream_t stream);
 extern "C" hipError_t gs_lb_sort_entries(u64 *e_sort, u64 *e_sort2, u64 *sort_alt, uint32_t *perm, uint32_t *perm_alt, int64_t n, const uint32_t *e_gh,
                                          const uint32_t *e_ohi, const uint32_t *e_olo, const uint32_t *e_vj, uint32_t *s_gh, uint32_t *s_ohi,
@@ -631,6 +633,11 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     u64 *t_key = pool.get<u64>(sn);
     int32_t *t_val = pool.get<int32_t>(sn);
     uint32_t *m_gh = pool.get<uint32_t>(2 * sn), *h_gh = pool.get<uint32_t>(2 * sn);
+    // context keys of the gate (gs_gate_ctx_key): collected for stores big enough to possibly need them
+    int64_t ctx_min_distinct = 12000000;  // ~20 % of the 15-mer minimizer space: a filter over the minimizers alone starts to leak
+    if (const char *e = getenv("GS_GATE_CTX_MIN_DISTINCT")) ctx_min_distinct = std::max<int64_t>(0, atoll(e));
+    const bool ctx_possible = k >= GS_CTX_MIN_K && n >= ctx_min_distinct;
+    uint32_t *h_ctx = ctx_possible ? pool.get<uint32_t>(2 * sn) : nullptr;
     u64 *cnt = pool.get<u64>(GS_LB_COUNTERS);
     LB_TRY(pool.err, "buffers");
     if (!on_dev) {
@@ -640,14 +647,14 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     LB_TRY(hipMemcpy(d_parent, parent.data(), (size_t)n_values * sizeof(int32_t), hipMemcpyHostToDevice), "upload");
     LB_TRY(hipMemset(cnt, 0, GS_LB_COUNTERS * sizeof(u64)), "counters");
     trace.mark("device: upload");
-    LB_TRY(gs_lb_perkey(d_k, d_v, n, k, d_parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, cnt, stream), "per key");
+    LB_TRY(gs_lb_perkey(d_k, d_v, n, k, d_parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, h_ctx, cnt, stream), "per key");
     u64 c[GS_LB_COUNTERS];
     LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "per key");
     if (!on_dev) {
         pool.drop(d_k);
         pool.drop(d_v);
     }
-    const int64_t n_e = (int64_t)c[GS_LB_N_E], n_h = (int64_t)c[GS_LB_N_H];
+    const int64_t n_e = (int64_t)c[GS_LB_N_E], n_h = (int64_t)c[GS_LB_N_H], n_ctx = (int64_t)c[GS_LB_N_CTX];
     trace.mark("device: per key");
     if (n_e == 0) return 0;  // nothing for records: the host builder's table-only store
     // ---- entries sorted by minimizer, minimizers -> windows
@@ -758,13 +765,24 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     int64_t distinct = 0;
     uint32_t *h_sorted = h_gh;
     LB_TRY(gs_lb_distinct(h_gh, h_alt, n_h, cnt, &distinct, &h_sorted, stream), "distinct minimizers");
+    // a store whose minimizers fill a good part of the minimizer space gets the gate keyed by minimizer + context instead
+    int64_t n_gate = n_h;
+    uint32_t mgate_ctx = 0;
+    if (h_ctx != nullptr && distinct >= ctx_min_distinct) {
+        pool.drop(h_alt);
+        h_alt = pool.get<uint32_t>((size_t)std::max<int64_t>(n_ctx, 1));
+        LB_TRY(pool.err, "gate buffers");
+        LB_TRY(gs_lb_distinct(h_ctx, h_alt, n_ctx, cnt, &distinct, &h_sorted, stream), "distinct context keys");
+        n_gate = n_ctx;
+        mgate_ctx = 1;
+    }
     double bits_per_min = 16.0;
     if (const char *e = getenv("GS_MGATE_BITS_PER_MIN")) bits_per_min = std::max(1.0, atof(e));
     int mgate_bits = 6;
     while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < (double)distinct * bits_per_min) mgate_bits++;
     uint32_t *d_mgate = pool.get<uint32_t>((size_t)1 << mgate_bits);
     LB_TRY(pool.err, "gate");
-    LB_TRY(gs_lb_gate(h_sorted, n_h, (uint32_t)mgate_bits, d_mgate, stream), "gate");
+    LB_TRY(gs_lb_gate(h_sorted, n_gate, (uint32_t)mgate_bits, d_mgate, stream), "gate");
     int32_t *d_tree = pool.get<int32_t>(4 * (size_t)n_values);
     LB_TRY(pool.err, "tree");
     LB_TRY(hipMemcpy(d_tree, parent.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
@@ -800,6 +818,7 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     db->dev.gate_mask = 0;
     db->dev.mgate = db->d_mgate;
     db->dev.mgate_bits = (uint32_t)mgate_bits;
+    db->dev.mgate_ctx = mgate_ctx;
     db->dev.rec = db->d_rec;
     db->dev.rec_bits = (uint32_t)rec_bits;
     db->dev.bucket_bits = (uint32_t)b;
@@ -890,6 +909,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 im.table_words = (size_t)whole->info.n_buckets * GS_SLOTS_PER_BUCKET;
                 im.mgate = whole->d_mgate;
                 im.mgate_words = (size_t)1 << whole->dev.mgate_bits;
+                im.mgate_ctx = whole->dev.mgate_ctx;
                 im.rec = whole->d_rec;
                 im.rec_words = (size_t)whole->n_rec * GS_REC_WORDS;
                 im.parent = parent.data();
@@ -1421,7 +1441,7 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 struct GsStoreFileHeader {
     char magic[8];  // "GSSTORE7"
     gs_db_info info;
-    uint32_t bucket_bits, vbits;
+    uint32_t bucket_bits, vbits;  // (bit 31 of vbits: the minimizer gate is keyed by gs_gate_ctx_key, GsDbDev::mgate_ctx)
     uint64_t gate_words;
     uint64_t mgate_words;  // 32-bit words, a power of two
     uint64_t rec_buckets;  // super-k-mer record buckets (GS_REC_WORDS words each), a power of two or 0
@@ -1605,6 +1625,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     }
     FILE *f = fopen(path, "wb");
     if (!f) return fail(GS_E_IO, std::string("cannot open ") + path);
+    if (db->dev.mgate_ctx) h.vbits |= 0x80000000u;  // (the flag travels in bit 31 of the header's vbits word)
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fflush(f) == 0;
     // the payload with several threads (pwrite), as gs_db_load reads it
     const int fd = fileno(f);
@@ -1654,7 +1675,13 @@ static int db_load_impl(gs_db **out, int device, const char *path, int stripes, 
     FILE *f = fopen(path, "rb");
     if (!f) return fail(GS_E_INVALID, std::string("cannot open ") + path);
     GsStoreFileHeader h{};
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "GSSTORE7", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+    uint32_t file_mgate_ctx = 0;
+    const bool got_header = fread(&h, sizeof(h), 1, f) == 1;
+    if (got_header) {
+        file_mgate_ctx = h.vbits >> 31;
+        h.vbits &= 0x7fffffffu;
+    }
+    if (!got_header || memcmp(h.magic, "GSSTORE7", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
         h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
         h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30) || h.rec_buckets > ((uint64_t)1 << 29)) {
         fclose(f);
@@ -1735,6 +1762,7 @@ static int db_load_impl(gs_db **out, int device, const char *path, int stripes, 
     im.gate_words = gate.size();
     im.mgate = mgate.data();
     im.mgate_words = mgate.size();
+    im.mgate_ctx = (file_mgate_ctx && h.info.k >= GS_CTX_MIN_K && !mgate.empty()) ? 1u : 0u;
     im.rec = rec.data();
     im.rec_words = rec.size();
     im.parent = tree.data();

@@ -391,7 +391,8 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
 }
 
 #define GS_ACT(m) __builtin_amdgcn_inverse_ballot_w64(m)  // a wave-level mask as a per-lane condition
-template <int KC, bool STRIPED>
+// CTX: is the gate keyed by gs_gate_ctx_key?  0 never (the launcher has looked), 1 always, 2 ask the store (GsDbDev::mgate_ctx)
+template <int KC, bool STRIPED, int CTX = 2>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
                                                 uint32_t *wave_g, const GsMark &mk) {
@@ -442,11 +443,14 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // the gate words of both sub-rounds are requested together (lanes without a live k-mer read word 0): one round
             // trip, no exec-mask regions
             uint32_t gw[2];
+            uint32_t gk[2];  // what the gate is keyed by: the minimizer, or (big stores) the minimizer + four bases next to it
 #pragma unroll
-            for (int s = 0; s < 2; s++) gw[s] = db.mgate[GS_ACT(act[s]) ? gs_mgate_word(gh[s], db.mgate_bits) : 0u];
+            for (int s = 0; s < 2; s++) gk[s] = (CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_gate_ctx_key(gh[s], ohi[s], olo[s], j[s], k) : gh[s];
+#pragma unroll
+            for (int s = 0; s < 2; s++) gw[s] = db.mgate[GS_ACT(act[s]) ? gs_mgate_word(gk[s], db.mgate_bits) : 0u];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                const uint32_t bits = gs_mgate_bits(gh[s]);
+                const uint32_t bits = gs_mgate_bits(gk[s]);
                 act[s] &= __ballot((gw[s] & bits) == bits);  // no false negatives
             }
             GS_STAMP(4, gw[0] ^ gw[1])
@@ -553,7 +557,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 // WIDE = true: maxClassificationPaths in 65..128 (C/GSConfigKey.java:350 allows 1..128): candidate path i lives in
 // lane i & 63 of register set i >> 6; with WIDE = false there is one set and lane = path.
 // ---------------------------------------------------------------------------------------------------
-template <bool LONG, bool FROM_NODES, int KC, bool WIDE, bool REC, bool STRIPED>
+template <bool LONG, bool FROM_NODES, int KC, bool WIDE, bool REC, bool STRIPED, int CTX = 2>
 __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L,
                                                 int lane, int (*s_dvi)[128], int (*s_dcnt)[128], int wave_in_block,
                                                 int32_t *tag, int32_t *cnt, int serial, const uint32_t (&pre)[3],
@@ -632,7 +636,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 // (4a. unique k-mers and per-k-mer hit counters are marked by the probe itself)
                 const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap : nullptr,
                                    STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
-                gs_probe_planes<KC, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
+                gs_probe_planes<KC, STRIPED, CTX>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
             if (!LONG) GS_STAMP(5, node[0] ^ node[1])
@@ -1077,7 +1081,7 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         __builtin_amdgcn_wave_barrier();                                                                                 \
     }
 
-template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false, bool STRIPED = false>
+template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false, bool STRIPED = false, int CTX = 0>
 __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAVES, GS_WAVES))) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
     __shared__ int s_dvi[GS_BLOCK / 64][128];  // distinct-node list copy, threshold > 1 only
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         const uint8_t *rd = Q.seq + off;
 #pragma unroll
         for (int w = 0; w < 3; w++) pre[w] = 64 * w + lane < L ? rd[64 * w + lane] : GS_FILL;
-        gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
+        gs_process_read<false, FROM_NODES, KC, WIDE, !LDS_STATS, STRIPED, CTX>(Q, st, r, off, L, lane, s_dvi, s_dcnt, wave_in_block, nullptr, nullptr, 0, pre,
                                                      s_g[wave_in_block], s_cur[wave_in_block]);
     }
 #if GS_PHASE
@@ -2056,62 +2060,48 @@ static size_t gs_stats_lds_bytes(int n_values) {
     return n_values <= GS_NV_TREE_LDS ? (size_t)n_values * 3 * 4 : 0;  // the tree alone
 }
 
+template <bool FROM_NODES, int KC, bool WIDE, bool STRIPED, int CTX>
+static void gs_launch_match_t(const GsMatchParams *P, int grid, size_t lds, bool lds_stats, hipStream_t stream) {
+    if (lds_stats)
+        hipLaunchKernelGGL((gs_match_kernel<true, FROM_NODES, KC, WIDE, STRIPED, CTX>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+    else
+        hipLaunchKernelGGL((gs_match_kernel<false, FROM_NODES, KC, WIDE, STRIPED, CTX>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+}
+
+// k = 31 (the reference's default and maximum) runs kernels with k folded in at compile time; whether the gate is keyed by
+// minimizer + context (big stores, GsDbDev::mgate_ctx) is folded in as well -- the branch alone costs the common kernels 3 % --
+// except in the 128-path variants, which ask the store
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
     const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    const bool ctx = P->db.mgate_ctx != 0;
     if (P->db.n_parts > 1) {  // striped store (always probed locally: nodes == nullptr)
         if (P->nodes != nullptr) return hipErrorInvalidValue;
-        if (P->max_paths > 64) {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        } else if (P->db.k == 31) {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 31, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 31, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        } else {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        }
-        return hipGetLastError();
-    }
-    if (P->max_paths > 64) {  // two candidate paths per lane (the reference allows up to 128, C/GSConfigKey.java:350)
-        if (P->nodes == nullptr) {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        } else {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, true, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, true, 0, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        }
-        return hipGetLastError();
-    }
-    // k = 31 (the reference's default and maximum) runs a kernel with k folded in at compile time
-    if (P->nodes == nullptr) {
-        if (P->db.k == 31) {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        } else {
-            if (lds_stats)
-                hipLaunchKernelGGL((gs_match_kernel<true, false, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-            else
-                hipLaunchKernelGGL((gs_match_kernel<false, false, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
-        }
-    } else {
-        if (lds_stats)
-            hipLaunchKernelGGL((gs_match_kernel<true, true, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        if (P->max_paths > 64)
+            gs_launch_match_t<false, 0, true, true, 2>(P, grid, lds, lds_stats, stream);
+        else if (P->db.k == 31)
+            ctx ? gs_launch_match_t<false, 31, false, true, 1>(P, grid, lds, lds_stats, stream)
+                : gs_launch_match_t<false, 31, false, true, 0>(P, grid, lds, lds_stats, stream);
         else
-            hipLaunchKernelGGL((gs_match_kernel<false, true, 0>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+            ctx ? gs_launch_match_t<false, 0, false, true, 1>(P, grid, lds, lds_stats, stream)
+                : gs_launch_match_t<false, 0, false, true, 0>(P, grid, lds, lds_stats, stream);
+        return hipGetLastError();
     }
+    if (P->nodes != nullptr) {  // DB-partitioned mode: the nodes come from the owners, nothing is probed here
+        if (P->max_paths > 64)
+            gs_launch_match_t<true, 0, true, false, 0>(P, grid, lds, lds_stats, stream);
+        else
+            gs_launch_match_t<true, 0, false, false, 0>(P, grid, lds, lds_stats, stream);
+        return hipGetLastError();
+    }
+    if (P->max_paths > 64)  // two candidate paths per lane (the reference allows up to 128, C/GSConfigKey.java:350)
+        gs_launch_match_t<false, 0, true, false, 2>(P, grid, lds, lds_stats, stream);
+    else if (P->db.k == 31)
+        ctx ? gs_launch_match_t<false, 31, false, false, 1>(P, grid, lds, lds_stats, stream)
+            : gs_launch_match_t<false, 31, false, false, 0>(P, grid, lds, lds_stats, stream);
+    else
+        ctx ? gs_launch_match_t<false, 0, false, false, 1>(P, grid, lds, lds_stats, stream)
+            : gs_launch_match_t<false, 0, false, false, 0>(P, grid, lds, lds_stats, stream);
     return hipGetLastError();
 }
 

@@ -175,6 +175,24 @@ GS_HD uint32_t gs_mgate_bits(uint32_t m) {
     return (1u << (y >> 27)) | (1u << ((y >> 22) & 31));
 }
 
+// Context-keyed gate (big stores).  The 15-mer minimizer space is ~60 M; a store of several hundred million k-mers uses most of
+// it (473 M k-mers: 40 M distinct minimizers), so that a filter over the minimizers alone lets 68 % of the positions of a read
+// that is NOT from the store through -- every one of them then fetches two record lines from HBM.  For such stores the gate is
+// keyed by the minimizer AND four bases next to it: a k-mer at window offset j holds the four bases behind its minimizer when
+// j >= 4, else (k >= 22) the four bases in front of it -- which side is a function of j alone, so store and probe agree -- and a
+// window has ONE such quadruple per side, so the gate holds <= 2 entries per window instead of 1 per minimizer, while a random
+// k-mer that shares a stored minimizer matches its quadruple with probability 2^-8.  No false negatives as before (results do
+// not depend on the gate); record buckets stay keyed by the minimizer alone.
+//   ohi / olo: the k-mer in the orientation in which its minimizer is canonical (gs_min_oriented), minimizer at base (k-15) - j
+#define GS_CTX_MIN_K 22
+GS_HD uint32_t gs_gate_ctx_key(uint32_t gh, uint32_t ohi, uint32_t olo, int j, int k) {
+    const int m = (k - GS_MIN_L) - j;  // first base of the minimizer inside the oriented k-mer
+    const bool behind = j >= 4;
+    const int pos = behind ? m + GS_MIN_L : m - 4;
+    const uint32_t ctx = ((ohi >> pos) & 15u) | (((olo >> pos) & 15u) << 4) | (behind ? 256u : 0u);
+    return gh ^ ((ctx + 1u) * 0x9E3779B1u);
+}
+
 struct GsDbDev {
     const unsigned long long *table;  // n_buckets * 8 slots
     const unsigned long long *gate;   // gate_mask+1 words, or nullptr
@@ -202,7 +220,7 @@ struct GsDbDev {
     // bitmap): bucket b belongs to stripe ((b >> 2) * n_parts) >> (bucket_bits - 2), its line is at tab_biased[p] +
     // b * GS_SLOTS_PER_BUCKET; `table` is nullptr then.
     uint32_t n_parts;
-    uint32_t pad_;
+    uint32_t mgate_ctx;  // 1: the minimizer gate is keyed by gs_gate_ctx_key (minimizer + four neighbouring bases), 0: by the minimizer
     const unsigned long long *rec_biased[GS_MAX_STRIPES];
     const unsigned long long *tab_biased[GS_MAX_STRIPES];
 };

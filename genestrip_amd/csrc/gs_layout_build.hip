@@ -27,7 +27,7 @@ typedef unsigned long long u64;
 #define GS_LB_EMPTY 0xffffffffu
 #define GS_LB_MAXWIN 8  // windows a minimizer's entries are clustered into; what fits none of them goes to the table
 
-enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_COUNTERS };
+enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_COUNTERS };
 
 // every lane of the wave calls this; returns the slot of the lanes with `have` in a list that grows by one atomic per wave
 __device__ __forceinline__ u64 gs_lb_append(bool have, u64 *counter, int lane) {
@@ -44,14 +44,15 @@ __device__ __forceinline__ u64 gs_lb_append(bool have, u64 *counter, int lane) {
 // views' minimizer; one view = one record entry, two views = a table key reachable from both minimizers' buckets
 __global__ __launch_bounds__(256) void gs_lb_perkey_kernel(const int64_t *kmers, const int32_t *vidx, int64_t n, int k, const int32_t *parent,
                                                            uint32_t *e_gh, uint32_t *e_ohi, uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort,
-                                                           u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh, u64 *cnt) {
+                                                           u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh, uint32_t *h_ctx,
+                                                           u64 *cnt) {
     const int lane = (int)(threadIdx.x & 63);
     const uint32_t kmask = (1u << k) - 1u;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; i0 < n; i0 += stride) {
         const int64_t i = i0 + lane;
         bool ok = false, same = false;
-        uint32_t gh1 = 0, gh2 = 0, ohi1 = 0, olo1 = 0, fhi = 0, flo = 0;
+        uint32_t gh1 = 0, gh2 = 0, ohi1 = 0, olo1 = 0, fhi = 0, flo = 0, ck1 = 0, ck2 = 0;
         int j1 = 0;
         int32_t v = 0;
         if (i < n) {
@@ -81,11 +82,21 @@ __global__ __launch_bounds__(256) void gs_lb_perkey_kernel(const int64_t *kmers,
             gs_min_oriented(fhi, flo, rhi, rlo, k, (int)(best1 & 0xffu), gh1, ohi1, olo1, j1);
             gs_min_oriented(rhi, rlo, fhi, flo, k, (int)(best2 & 0xffu), gh2, ohi2, olo2, j2);
             same = gh1 == gh2 && j1 == j2 && ohi1 == ohi2 && olo1 == olo2;
+            if (h_ctx != nullptr) {  // the context keys of both strand views (gs_gate_ctx_key), k >= GS_CTX_MIN_K
+                ck1 = gs_gate_ctx_key(gh1, ohi1, olo1, j1, k);
+                ck2 = gs_gate_ctx_key(gh2, ohi2, olo2, j2, k);
+            }
         }
         const u64 he = gs_lb_append(ok, cnt + GS_LB_N_H, lane);
         if (ok) h_gh[he] = gh1;
         const u64 he2 = gs_lb_append(ok && gh2 != gh1, cnt + GS_LB_N_H, lane);
         if (ok && gh2 != gh1) h_gh[he2] = gh2;
+        if (h_ctx != nullptr) {
+            const u64 ce = gs_lb_append(ok, cnt + GS_LB_N_CTX, lane);
+            if (ok) h_ctx[ce] = ck1;
+            const u64 ce2 = gs_lb_append(ok && ck2 != ck1, cnt + GS_LB_N_CTX, lane);
+            if (ok && ck2 != ck1) h_ctx[ce2] = ck2;
+        }
         const u64 ee = gs_lb_append(ok && same, cnt + GS_LB_N_E, lane);
         if (ok && same) {
             e_gh[ee] = gh1;
@@ -425,8 +436,8 @@ static int lb_grid(int64_t n, int block = 256) {
 
 extern "C" hipError_t gs_lb_perkey(const int64_t *kmers, const int32_t *vidx, int64_t n, int k, const int32_t *parent, uint32_t *e_gh, uint32_t *e_ohi,
                                    uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort, u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh,
-                                   u64 *cnt, hipStream_t stream) {
-    LB_LAUNCH(gs_lb_perkey_kernel, n, kmers, vidx, n, k, parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, cnt);
+                                   uint32_t *h_ctx, u64 *cnt, hipStream_t stream) {
+    LB_LAUNCH(gs_lb_perkey_kernel, n, kmers, vidx, n, k, parent, e_gh, e_ohi, e_olo, e_vj, e_sort, e_sort2, t_key, t_val, m_gh, h_gh, h_ctx, cnt);
     return hipGetLastError();
 }
 
