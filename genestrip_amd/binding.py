@@ -41,6 +41,7 @@ ABI_SYMBOLS = (
     "gs_filter_submit_fasta", "gs_filter_submit_fastq_ml", "gs_filter_text_read_bounds", "gs_filter_text_line_classes",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
     "gs_calibrate",
+    "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
 )
 
 
@@ -155,6 +156,14 @@ def lib():
         "gs_filter_submit": (ci, [vp, ci, ci, dbl, vp, vp, i64, ci, vp, ci]), "gs_filter_sync": (ci, [vp]),
         "gs_filter_kernel_time": (ci, [vp, vp, vp]),
         "gs_calibrate": (ci, [ci, ci, i64, vp]),
+        "gs_match_get_device": (ci, [vp, vp]),
+        "gs_inflate_members": (ci, [ci, vp, vp, i64, vp, i64, vp]),
+        "gs_inflater_create": (ci, [vp, ci]),
+        "gs_inflater_feed": (ci, [vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp]),
+        "gs_inflater_tail": (ci, [vp, vp, i64, vp]),
+        "gs_inflater_reset": (ci, [vp]),
+        "gs_inflater_destroy": (ci, [vp]),
+        "gs_inflate_last_error": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -176,6 +185,57 @@ def device_count():
     n = C.c_int(0)
     rc = lib().gs_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+class InflateMember(C.Structure):
+    _fields_ = [("payload_offset", C.c_int64), ("payload_len", C.c_uint32), ("isize", C.c_uint32), ("crc32", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+def bgzf_members(data):
+    """the members of a BGZF buffer (bytes / numpy uint8), found from their headers alone: list of (payload_offset,
+    payload_len, isize, crc32); stops at the first thing that is not a BGZF member -> (members, offset reached)"""
+    import struct
+    b = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    out, o, n = [], 0, len(b)
+    while o + 28 <= n and b[o] == 0x1f and b[o + 1] == 0x8b and b[o + 2] == 8 and (b[o + 3] & 4):
+        if b[o + 3] & ~4:  # name / comment / header CRC: not what bgzip writes
+            break
+        xlen = struct.unpack_from("<H", b, o + 10)[0]
+        q, bsize = o + 12, None
+        while q + 4 <= o + 12 + xlen:
+            slen = struct.unpack_from("<H", b, q + 2)[0]
+            if b[q:q + 2] == b"BC" and slen == 2:
+                bsize = struct.unpack_from("<H", b, q + 4)[0]
+            q += 4 + slen
+        if bsize is None or o + bsize + 1 > n or bsize + 1 < 12 + xlen + 8:
+            break
+        end = o + bsize + 1
+        crc, isize = struct.unpack_from("<II", b, end - 8)
+        if isize > 65536:
+            break
+        out.append((o + 12 + xlen, end - 8 - (o + 12 + xlen), isize, crc))
+        o = end
+    return out, o
+
+
+def inflate_members(data, members, device=0):
+    """gs_inflate_members: -> (text bytes as numpy uint8, status int32[]); raises GsError when a member is corrupt"""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    arr = (InflateMember * max(1, len(members)))()
+    total = 0
+    for i, (po, pl, isz, crc) in enumerate(members):
+        arr[i] = InflateMember(po, pl, isz, crc, 0)
+        total += isz
+    out = np.zeros(max(total, 1), dtype=np.uint8)
+    st = np.full(max(len(members), 1), -1, dtype=np.int32)
+    rc = lib().gs_inflate_members(device, buf.ctypes.data_as(C.c_void_p), arr, len(members), out.ctypes.data_as(C.c_void_p), total,
+                                  st.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        e = GsError(rc, (lib().gs_inflate_last_error() or b"").decode(errors="replace"))
+        e.status = st[:len(members)].copy()
+        raise e
+    return out[:total], st[:len(members)]
 
 
 CAL_VALU_PURE, CAL_VALU_MIX, CAL_SALU, CAL_VALU_SALU = 0, 1, 2, 3

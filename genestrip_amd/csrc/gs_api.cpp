@@ -2681,6 +2681,12 @@ static int fold_stats(gs_run *run) {
     return GS_OK;
 }
 
+extern "C" int gs_match_get_device(gs_run *run, int *device) {
+    if (!run || !device) return fail(GS_E_INVALID, "NULL argument");
+    *device = run->db->device;
+    return GS_OK;
+}
+
 extern "C" int gs_match_sync(gs_run *run) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));

@@ -200,7 +200,8 @@ CAL_ATTR void cal_vmem(const uint8_t *buf, uint32_t *out, int iters) {
 #define CAL_VMEM_PER_ITER 8
 
 // ---- 6. random 64-byte lines from a table of a given footprint (the store probe's memory-side ceiling): every lane reads
-// 16 bytes of its own random line, 4 independent lines in flight per lane
+// 16 bytes of its own random line; the best of three shapes (4 or 8 independent lines in flight per lane, 8 or 16 workgroups
+// per CU) is the ceiling
 __device__ __forceinline__ u64 cal_mix(u64 x) {
     x ^= x >> 31;
     x *= 0x7fb5d329728ea185ULL;
@@ -209,18 +210,19 @@ __device__ __forceinline__ u64 cal_mix(u64 x) {
     x ^= x >> 33;
     return x;
 }
+template <int INFLIGHT>
 __global__ __launch_bounds__(256) void cal_random_lines(const u64 *table, u64 n_lines, int iters, u64 *out) {
     const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 acc = 0, state = cal_mix(tid + 12345);
     for (int it = 0; it < iters; it++) {
-        u64 idx[4];
+        u64 idx[INFLIGHT];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < INFLIGHT; j++) {
             state = cal_mix(state + j + 1);
             idx[j] = (u64)(((unsigned __int128)state * n_lines) >> 64);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < INFLIGHT; j++) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(table + idx[j] * 8);
             acc += v.x ^ v.y;
         }
@@ -339,11 +341,26 @@ extern "C" int gs_calibrate(int device, int what, int64_t arg, double out[4]) {
             return GS_E_NOMEM;
         }
         CAL_TRY(hipMemset(table, 1, n_lines * 64));
-        const int iters = 100;
-        rc = cal_time(
-            [&](bool warm) { hipLaunchKernelGGL(cal_random_lines, dim3(n_cu * 8), dim3(256), 0, 0, table, n_lines, warm ? 2 : iters, (u64 *)d_out); },
-            &ms);
-        count = (double)n_cu * 8 * 256 * iters * 4;
+        double best_rate = 0;
+        for (int shape = 0; shape < 3 && rc == GS_OK; shape++) {
+            // (every shape requests the same number of lines: n_cu * 8 * 256 * 400)
+            const int inflight = shape == 1 ? 8 : 4, blocks = n_cu * (shape == 2 ? 16 : 8), iters = (shape == 2 ? 200 : 400) / inflight;
+            double t = 0;
+            rc = cal_time(
+                [&](bool warm) {
+                    if (inflight == 8)
+                        hipLaunchKernelGGL(cal_random_lines<8>, dim3(blocks), dim3(256), 0, 0, table, n_lines, warm ? 2 : iters, (u64 *)d_out);
+                    else
+                        hipLaunchKernelGGL(cal_random_lines<4>, dim3(blocks), dim3(256), 0, 0, table, n_lines, warm ? 2 : iters, (u64 *)d_out);
+                },
+                &t);
+            const double c = (double)blocks * 256 * iters * inflight;
+            if (rc == GS_OK && c / t > best_rate) {
+                best_rate = c / t;
+                ms = t;
+                count = c;
+            }
+        }
         hipFree(table);
         break;
     }

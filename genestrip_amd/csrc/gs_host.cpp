@@ -538,6 +538,38 @@ FastaCut fasta_cut(const uint8_t *blk, int64_t n, bool last, const std::vector<u
     return fc;
 }
 
+// device inflaters are kept for the life of the process, per device: their buffers (two text buffers, two staging buffers, page-locked
+// mirrors) take longer to allocate and free than a file takes to inflate
+struct InflaterPool {
+    std::mutex m;
+    std::vector<std::pair<int, gs_inflater *>> idle;
+    gs_inflater *get(int device) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == device) {
+                    gs_inflater *g = idle[i].second;
+                    idle.erase(idle.begin() + (long)i);
+                    return g;
+                }
+        }
+        gs_inflater *g = nullptr;
+        return gs_inflater_create(&g, device) == GS_OK ? g : nullptr;
+    }
+    void put(int device, gs_inflater *g) {
+        if (gs_inflater_reset(g) != GS_OK) {
+            gs_inflater_destroy(g);
+            return;
+        }
+        std::lock_guard<std::mutex> l(m);
+        idle.emplace_back(device, g);
+    }
+};
+inline InflaterPool &inflater_pool() {
+    static InflaterPool *p = new InflaterPool();  // (never destroyed: the runtime may be gone by the time statics are torn down)
+    return *p;
+}
+
 struct TextJob {
     MatchCtx &c;
     std::string path;
@@ -563,15 +595,56 @@ struct TextJob {
     bool general = false;
     bool gz_ = false;
     int readers_ = 2;
+    // block-gzip (BGZF) input without per-read outputs: the members are listed from their headers, the COMPRESSED bytes go to the
+    // device and are inflated there (gs_inflater_feed, one wave per member); the text never exists on the host.  What the device
+    // path cannot take (a chunk the record scan refuses, the unterminated tail of the file) goes the usual way.
+    bool dev_bgzf = false;
+    gs_inflater *inf_ = nullptr;
+    int inf_device_ = 0;
+    std::vector<gs_inflate_member> members_;
+    size_t next_member_ = 0;
+    int64_t dev_tickets_[2] = {-1, -1};
+    int64_t n_feeds_ = 0;
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
     ~TextJob() { abort(); }
     // stops the readers (after the writers of the last chunk are through with its block)
     void abort() {
+        const double ta = now_s();
         drain();
         release_held();
+        const double tb = now_s();
         tr.close();
+        const double tc = now_s();
+        if (inf_) {
+            inflater_pool().put(inf_device_, inf_);
+            inf_ = nullptr;
+        }
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] abort: drain %.2f ms, close %.2f ms, pool %.2f ms\n", fmod(now_s() * 1e3, 1e6), (tb - ta) * 1e3, (tc - tb) * 1e3, (now_s() - tc) * 1e3);
+    }
+
+    // every byte of the mapped file belongs to a BGZF member: list them (payload, ISIZE, CRC-32); false: not (only) BGZF
+    bool list_bgzf_members() {
+        members_.clear();
+        size_t o = 0;
+        while (o < tr.map_len) {
+            size_t len = 0;
+            uint32_t isize = 0;
+            if (!GsBgzfReader::block_at(tr.map, tr.map_len, o, &len, &isize)) return false;
+            const uint8_t *p = tr.map + o;
+            if (p[3] != 4) return false;  // (name / comment / header CRC: not what bgzip writes -- the general decoder knows them)
+            const size_t hdr = 12 + ((size_t)p[10] | ((size_t)p[11] << 8));
+            const uint8_t *t = p + len - 8;
+            gs_inflate_member m{};
+            m.payload_offset = (int64_t)(o + hdr);
+            m.payload_len = (uint32_t)(len - hdr - 8);
+            m.isize = isize;
+            m.crc32 = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            if (isize > 0) members_.push_back(m);
+            o += len;
+        }
+        return !members_.empty();
     }
 
     int open(bool gzip, int readers) {
@@ -594,12 +667,101 @@ struct TextJob {
         if (!err) err = gs_match_text_select(c.run, bank);
         int64_t failed = -1, bad = -1;
         if (!err) err = gs_match_text_status(c.run, &failed, &bad, base_tot);  // totals this bank has seen before
-        if (!err) tr.start();
+        if (!err && gzip && !fasta && !general && !c.filtered.active() && !c.kraken.active()) {
+            bool want = true;
+            if (const char *e = getenv("GS_DEVICE_INFLATE")) want = atoi(e) != 0;
+            if (want && tr.map_len >= 28 && list_bgzf_members()) {
+                int device = 0;
+                if (gs_match_get_device(c.run, &device) == GS_OK && (inf_ = inflater_pool().get(device)) != nullptr) {
+                    inf_device_ = device;
+                    dev_bgzf = true;
+                }
+            }
+        }
+        if (!err && !dev_bgzf) tr.start();
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] open %s: %.2f ms (device inflate %d, %zu members)\n", fmod(now_s() * 1e3, 1e6), path.c_str(), (now_s() - t0) * 1e3, (int)dev_bgzf, members_.size());
         return err;
+    }
+
+    // one run of members: inflate on the device, submit the whole records, carry the rest (on the device)
+    int step_bgzf(int *err_out) {
+        int err = GS_OK;
+        // text per feed: a wave inflates a member in ~6 ms whatever else runs, so the rate is the number of members under way --
+        // 512 MiB are ~8000 members, two rounds over the device's wave slots
+        int64_t text_target = (int64_t)512 << 20;
+        if (const char *e = getenv("GS_HOST_BGZF_TEXT")) {
+            const long long v = atoll(e);
+            if (v >= 65536 && v <= ((long long)1 << 29)) text_target = v;
+        }
+        auto run_end = [&](size_t from) {
+            int64_t sum = 0;
+            size_t e = from;
+            while (e < members_.size() && (e == from || sum + members_[e].isize <= text_target)) sum += members_[e++].isize;
+            return e;
+        };
+        const size_t a = next_member_, b = run_end(a), b2 = run_end(b);
+        const bool last = b == members_.size();
+        int64_t next_lo = 0, next_hi = 0;
+        if (b2 > b) {
+            next_lo = members_[b].payload_offset;
+            next_hi = members_[b2 - 1].payload_offset + (int64_t)members_[b2 - 1].payload_len;
+        }
+        // The previous feed's text went to the device scan, which takes its own copy (device to device, a fraction of a
+        // millisecond): that copy must be through before this feed runs -- the feed ends by moving its leftover into the OTHER
+        // text buffer, which is the one the scan is copying from.
+        const int slot = 0;
+        if (dev_tickets_[slot] >= 0) {
+            err = gs_match_text_wait_copy(c.run, dev_tickets_[slot]);
+            dev_tickets_[slot] = -1;
+        }
+        const uint8_t *text = nullptr;
+        int64_t n_bytes = 0, n_lines = 0, tail = 0;
+        int64_t fallback_off = -1, fallback_reads = 0;
+        static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
+        const double tt0 = now_s();
+        if (!err && gs_inflater_feed(inf_, tr.map, members_.data() + a, (int64_t)(b - a), next_lo, next_hi, last ? 1 : 0, &text, &n_bytes, &n_lines, &tail) != GS_OK)
+            err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
+        n_feeds_++;
+        next_member_ = b;
+        const double tt1 = now_s();
+        if (!err) err = gs_match_text_select(c.run, bank);
+        if (!err && n_lines > 0) {
+            int64_t ticket = -1;
+            err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
+            if (!err) {
+                dev_tickets_[slot] = ticket;
+                if (first_ticket < 0) first_ticket = ticket;
+                chunks.push_back({carry_file_off, reads_in_file, ticket});
+                reads_in_file += n_lines >> 2;
+                carry_file_off += n_bytes;
+                if (chunks.size() == 1 || (chunks.size() & 15) == 0) err = check_refusal(&fallback_off, &fallback_reads);
+            }
+            if (trace) fprintf(stderr, "bgzf feed %lld: members %zu, feed %.2f ms, submit+check %.2f ms, %lld bytes %lld lines tail %lld\n", (long long)n_feeds_, b - a, (tt1 - tt0) * 1e3, (now_s() - tt1) * 1e3, (long long)n_bytes, (long long)n_lines, (long long)tail);
+        } else if (!err && tail > ((int64_t)256 << 20) && !last) {  // no record boundary in a quarter of a gigabyte: the general parser
+            fallback_off = carry_file_off;
+            fallback_reads = reads_in_file;
+        }
+        if (err || last || fallback_off >= 0) {
+            if (!err && fallback_off < 0) {  // what is left behind the last whole record
+                int64_t n = 0;
+                carry.resize((size_t)tail);
+                if (tail > 0 && gs_inflater_tail(inf_, carry.data(), tail, &n) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            }
+            for (int q = 0; q < 2; q++)
+                if (dev_tickets_[q] >= 0) {
+                    const int e2 = gs_match_text_wait_copy(c.run, dev_tickets_[q]);
+                    if (!err) err = e2;
+                    dev_tickets_[q] = -1;
+                }
+            err = finish(err, fallback_off, fallback_reads);
+        }
+        *err_out = err;
+        return 1;
     }
 
     // 1: a block was handled, 0: none ready (blocking = false only); `done` is set when the file is through
     int step(bool blocking, int *err_out) {
+        if (dev_bgzf) return step_bgzf(err_out);
         if (general) return step_general(blocking, err_out);
         if (fasta) return step_fasta(blocking, err_out);
         int err = GS_OK;
@@ -968,14 +1130,17 @@ private:
 
     int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
         done = true;
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] finish at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         drain();
         const int held_err = release_held();  // (the blocks return to the pool in close(): no copy may still read them)
         if (!err) err = held_err;
         tr.close();
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f]   closed at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         c.t_parse += now_s() - t0;
         if (err) return err;
         err = gs_match_text_select(c.run, bank);
         if (!err && fallback_off < 0) err = check_refusal(&fallback_off, &fallback_reads);  // also fetches the final totals
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f]   status at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         if (err) return err;
         if (fallback_off >= 0) {  // `tot` was read after the refusal: it holds exactly the accepted chunks
             int64_t failed = -1, bad = -1;
@@ -1019,6 +1184,7 @@ namespace {
 // max-contig read numbers of the run are in that (file, read) form.
 int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t *file_index, std::vector<int64_t> &reads_of_file_out,
               bool *composite) {
+    if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] run_files enter\n", fmod(now_s() * 1e3, 1e6));
     bool fast = true;
     if (const char *e = getenv("GS_HOST_FAST")) fast = atoi(e) != 0;
     int err = GS_OK;
@@ -1126,13 +1292,16 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         }
     }
     if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    const double t_enter = now_s();
     rc = gs_match_begin(&c.run, db, cfg);
     if (rc) return rc;
     const double t_start = now_s();
     std::vector<int64_t> reads_of_file;
     bool side_by_side = false;
     int err = run_files(c, paths, n_paths, nullptr, reads_of_file, &side_by_side);
+    const double t_files = now_s();
     if (!err) err = gs_match_finish(c.run, table, dtable);
+    if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] match_files: begin %.2f ms, files %.2f ms, finish %.2f ms\n", fmod(now_s() * 1e3, 1e6), (t_start - t_enter) * 1e3, (t_files - t_start) * 1e3, (now_s() - t_files) * 1e3);
     if (!err && side_by_side) {  // (file << 32 | read in file) -> running read number over the files in order
         std::vector<int64_t> before((size_t)n_paths + 1, 0);
         for (int i = 0; i < n_paths; i++) before[(size_t)i + 1] = before[(size_t)i] + reads_of_file[(size_t)i];
@@ -1141,7 +1310,11 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
             if (x >= 0) x = before[(size_t)(x >> 32)] + (x & 0xffffffffLL);
         }
     }
-    gs_match_destroy(c.run);
+    {
+        const double td = now_s();
+        gs_match_destroy(c.run);
+        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] match_files: destroy %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - td) * 1e3);
+    }
     const bool wrote = c.filtered.close() & c.kraken.close();  // (both are flushed before the clock stops)
     if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {

@@ -1,0 +1,929 @@
+// gs_inflate_dev.hip -- DEFLATE on the device for block-gzip input (BGZF: bgzip / htslib, and this library's own .gz outputs).
+//
+// The reference reads every .fastq.gz through java.util.zip.GZIPInputStream (B/io/StreamProvider.java:92-100): one thread, ~0.2 GB/s
+// of text.  A BGZF file is a chain of gzip members of at most 64 KiB of text that state their compressed size (the 'BC' extra
+// subfield), so the host finds every member by hopping from header to header without inflating anything, the COMPRESSED bytes go
+// over PCIe (a fifth of the text), and the members are inflated side by side on the GPU straight into the text buffer the record
+// scan reads (gs_match_submit_text with GS_MEM_DEVICE): ONE WAVE PER MEMBER.
+//
+// A wave decodes its member in lock step -- every lane holds the same bit buffer and walks the same Huffman tables (LDS) --, which
+// costs nothing (a wave instruction is a wave instruction) and lets the lanes share the work that is parallel:
+//   * the compressed bytes are fetched 256 at a time, lane i holding dword i of the piece; the bit buffer is refilled with a
+//     v_readlane from that register: no memory latency on the decode chain (the next piece is already in a second register);
+//   * literals are collected in a register, lane j holding the j-th pending byte, and leave as one coalesced store of up to 64;
+//   * a match is copied by all lanes at once, out[p + i] = out[p - dist + i % dist] (every source byte lies in front of p);
+//   * the Huffman tables of a dynamic block are built with the lanes filling the replicated entries of each code in parallel.
+// The text written earlier is read back through the same CU's L1 / L2; a wave waits for its own stores only when a match reaches
+// into the bytes stored since its last wait.  Behind the last block: the member's ISIZE must be met exactly, and its CRC-32 is
+// recomputed from the text (64 lanes x slicing-by-1 over equal slices, combined with x^(8 n) mod P).
+//
+// gs_inflater_feed turns a run of members into "whole four-line records": the text is appended behind the tail the previous call
+// left over, a second pair of kernels counts the newlines and finds the last one that closes a record (count a multiple of four),
+// and the caller hands exactly that much to gs_match_submit_text / gs_filter_submit_text.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gsgpu.h"
+
+typedef unsigned long long u64;
+
+#define GI_WAVES 4                 // waves per workgroup
+#define GI_LROOT 10                // root bits of the literal / length table
+#define GI_DROOT 9                 // root bits of the distance table
+#define GI_LSIZE 1408              // entries: 2^10 root + sub-tables (zlib's bound for 286 symbols, root 10, 15 bits: 1332)
+#define GI_DSIZE 640               // 2^9 root + sub-tables (bound for 30 symbols, root 9, 15 bits: < 640)
+#define GI_MAXSYM 320              // 288 literal / length + 32 distance code lengths
+
+// table entry: bits 0-3 code bits to drop, bits 4-6 kind, bits 8.. payload
+enum { GI_BAD = 0, GI_LIT = 1, GI_LEN = 2, GI_EOB = 3, GI_SUB = 4, GI_DIST = 5 };
+#define GI_ENTRY(bits, kind, payload) ((uint32_t)(bits) | ((uint32_t)(kind) << 4) | ((uint32_t)(payload) << 8))
+
+// status of a member (0 = inflated, ISIZE and CRC-32 as announced)
+enum { GI_OK = 0, GI_E_HEADER = 1, GI_E_TABLE = 2, GI_E_CODE = 3, GI_E_DIST = 4, GI_E_OVERRUN = 5, GI_E_SIZE = 6, GI_E_CRC = 7, GI_E_INPUT = 8 };
+
+struct GiWave {
+    uint32_t ltab[GI_LSIZE];
+    uint32_t dtab[GI_DSIZE];
+    uint16_t count[16], offs[16];
+    uint16_t work[GI_MAXSYM];
+    uint8_t lens[GI_MAXSYM + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+};
+
+__constant__ uint16_t gi_len_base[31] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0};
+__constant__ uint8_t gi_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
+__constant__ uint16_t gi_dist_base[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+                                          4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
+__constant__ uint8_t gi_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+__constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+__constant__ uint32_t gi_crc_table[256];
+
+__device__ __forceinline__ int gi_lane() { return (int)__lane_id(); }
+__device__ __forceinline__ uint32_t gi_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void gi_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- the bit reader: 64-bit buffer, refilled 32 bits at a time from the wave's current 256-byte piece of the input
+struct GiBits {
+    const uint8_t *in;    // the member's deflate payload
+    uint32_t in_len;      // its length
+    uint32_t piece_at;    // byte offset of the piece in `cur`
+    uint32_t idx;         // next dword of the piece (0..64)
+    uint32_t cur, nxt;    // lane i: dword i of the current / the following piece
+    u64 bb;               // bit buffer (low bits first)
+    int bc;               // valid bits in it
+    uint32_t taken;       // dwords handed to the bit buffer so far
+    __device__ __forceinline__ uint32_t load_piece(uint32_t at, int lane) const {
+        // dword `lane` of the piece at byte offset `at`: bytes beyond the payload read as 0 (an overrun is caught by `taken`)
+        const uint32_t o = at + 4u * (uint32_t)lane;
+        uint32_t v = 0;
+        if (o + 4u <= in_len) {
+            memcpy(&v, in + o, 4);
+        } else if (o < in_len) {
+            for (uint32_t b = 0; o + b < in_len; b++) v |= (uint32_t)in[o + b] << (8 * b);
+        }
+        return v;
+    }
+    __device__ __forceinline__ void start(const uint8_t *p, uint32_t n, int lane) {
+        in = p;
+        in_len = n;
+        piece_at = 0;
+        idx = 0;
+        taken = 0;
+        bb = 0;
+        bc = 0;
+        cur = load_piece(0, lane);
+        nxt = load_piece(256, lane);
+    }
+    __device__ __forceinline__ void refill(int lane) {
+        while (bc <= 32) {
+            if (idx == 64) {
+                cur = nxt;
+                piece_at += 256;
+                nxt = load_piece(piece_at + 256, lane);
+                idx = 0;
+            }
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx);
+            bb |= (u64)w << bc;
+            bc += 32;
+            idx++;
+            taken++;
+        }
+    }
+    // continue at byte `at` of the payload (behind a stored block)
+    __device__ __forceinline__ void seek(uint32_t at, int lane) {
+        piece_at = at & ~3u;
+        cur = load_piece(piece_at, lane);
+        nxt = load_piece(piece_at + 256, lane);
+        idx = 0;
+        bb = 0;
+        bc = 0;
+        taken = piece_at / 4;
+        refill(lane);
+        const int skip = 8 * (int)(at & 3u);
+        bb >>= skip;
+        bc -= skip;
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(int n) {
+        bb >>= n;
+        bc -= n;
+    }
+    __device__ __forceinline__ uint32_t get(int n) {
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+    // bits consumed so far; a stream that ran beyond its payload has consumed more than 8 * in_len
+    __device__ __forceinline__ u64 consumed() const { return (u64)taken * 32u - (u64)bc; }
+};
+
+// ---- Huffman decoding table from code lengths (canonical codes, deflate bit order), root table + sub-tables.
+// type 0: literal / length codes (n <= 288), 1: distance codes (n <= 32), 2: code length codes (n = 19, root 7, no sub-tables).
+// All lanes run the same statements; only the replication of an entry over its copies is spread over the lanes.
+// Returns false for an over-subscribed or (where deflate forbids it) incomplete set of lengths, or when the sub-tables outgrow cap.
+__device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint32_t *tab, int root, int cap, int lane) {
+    for (int i = lane; i < 16; i += 64) w.count[i] = 0;
+    for (int i = lane; i < (1 << root); i += 64) tab[i] = 0;
+    gi_lds_sync();
+    if (lane == 0)
+        for (int s = 0; s < n; s++) w.count[w.lens[lens_at + s]]++;
+    gi_lds_sync();
+    int max = 15;
+    while (max >= 1 && w.count[max] == 0) max--;
+    if (max == 0) return true;  // no code at all (the distance code of a block of literals): every lookup ends in an invalid entry
+    int left = 1;
+    for (int len = 1; len <= 15; len++) {
+        left <<= 1;
+        left -= (int)w.count[len];
+        if (left < 0) return false;  // over-subscribed
+    }
+    if (left > 0 && (type == 2 || max != 1)) return false;  // incomplete: only a single code of one bit may stand alone
+    if (lane == 0) {
+        w.offs[1] = 0;
+        for (int len = 1; len < 15; len++) w.offs[len + 1] = (uint16_t)(w.offs[len] + w.count[len]);
+        for (int s = 0; s < n; s++) {
+            const int l = w.lens[lens_at + s];
+            if (l) w.work[w.offs[l]++] = (uint16_t)s;
+        }
+    }
+    gi_lds_sync();
+    // codes in canonical order; `huff` is the bit-reversed code (the stream delivers codes low bit first)
+    uint32_t huff = 0;
+    int len = 1;
+    while (w.count[len] == 0) len++;
+    int remaining = (int)w.count[len];
+    int used = 1 << root;   // entries in use (root table first)
+    int sub_base = 0, sub_bits = 0;
+    uint32_t sub_prefix = 0xffffffffu;
+    int n_codes = 0;
+    for (int l = 1; l <= 15; l++) n_codes += (int)w.count[l];
+    for (int i = 0; i < n_codes; i++) {
+        const int sym = (int)w.work[i];
+        uint32_t e;
+        if (type == 0) {
+            if (sym < 256)
+                e = GI_ENTRY(0, GI_LIT, sym);
+            else if (sym == 256)
+                e = GI_ENTRY(0, GI_EOB, 0);
+            else if (sym <= 285)
+                e = GI_ENTRY(0, GI_LEN, (uint32_t)gi_len_base[sym - 257] | ((uint32_t)gi_len_extra[sym - 257] << 9));
+            else
+                e = GI_ENTRY(0, GI_BAD, 0);  // 286, 287 never appear in a valid stream
+        } else if (type == 1) {
+            e = sym <= 29 ? GI_ENTRY(0, GI_DIST, (uint32_t)gi_dist_base[sym] | ((uint32_t)gi_dist_extra[sym] << 15)) : GI_ENTRY(0, GI_BAD, 0);
+        } else {
+            e = GI_ENTRY(0, GI_LIT, sym);
+        }
+        if (len <= root) {
+            e |= (uint32_t)len;
+            const int reps = 1 << (root - len);
+            for (int r = lane; r < reps; r += 64) tab[huff + ((uint32_t)r << len)] = e;
+        } else {
+            const uint32_t prefix = huff & ((1u << root) - 1u);
+            if (prefix != sub_prefix) {  // a new sub-table: as many bits as the longest code under this prefix needs
+                sub_prefix = prefix;
+                int curr = len - root, room = 1 << curr, l2 = len, cnt = remaining;
+                while (l2 < max) {
+                    room -= cnt;
+                    if (room <= 0) break;
+                    curr++;
+                    l2++;
+                    room <<= 1;
+                    cnt = (int)w.count[l2];
+                }
+                sub_bits = curr;
+                sub_base = used;
+                used += 1 << curr;
+                if (used > cap) return false;
+                for (int r = lane; r < (1 << curr); r += 64) tab[sub_base + r] = 0;
+                if (lane == 0) tab[prefix] = GI_ENTRY(root, GI_SUB, (uint32_t)sub_base | ((uint32_t)sub_bits << 12));
+            }
+            e |= (uint32_t)(len - root);
+            const int reps = 1 << (sub_bits - (len - root));
+            for (int r = lane; r < reps; r += 64) tab[sub_base + (huff >> root) + ((uint32_t)r << (len - root))] = e;
+        }
+        // next code of this length in bit-reversed form
+        uint32_t incr = 1u << (len - 1);
+        while (huff & incr) incr >>= 1;
+        huff = incr ? (huff & (incr - 1)) + incr : 0;
+        if (--remaining == 0 && i + 1 < n_codes) {
+            len++;
+            while (w.count[len] == 0) len++;
+            remaining = (int)w.count[len];
+        }
+    }
+    gi_lds_sync();
+    return true;
+}
+
+__device__ __forceinline__ uint32_t gi_lookup(const uint32_t *tab, int root, const GiBits &b) {
+    uint32_t e = gi_uni(tab[b.peek(root)]);
+    if (((e >> 4) & 7u) == GI_SUB) {
+        const uint32_t base = (e >> 8) & 0xfffu, bits = (e >> 20) & 0xfu;
+        e = gi_uni(tab[base + (((uint32_t)(b.bb >> root)) & ((1u << bits) - 1u))]);
+        e += (uint32_t)root;  // (code bits = root + bits inside the sub-table; the low nibble cannot overflow: <= 15)
+    }
+    return e;
+}
+
+// x^(8 n) mod P (reflected CRC-32 polynomial arithmetic), and a * b mod P
+__device__ uint32_t gi_gf_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? 0xedb88320u : 0u);
+    }
+    return p;
+}
+__device__ uint32_t gi_x_pow_8n(uint32_t n) {
+    uint32_t r = 0x80000000u, sq = 0x00800000u;  // x^0, x^8 (bit 31 = x^0 in the reflected representation)
+    while (n) {
+        if (n & 1u) r = gi_gf_mul(r, sq);
+        sq = gi_gf_mul(sq, sq);
+        n >>= 1;
+    }
+    return r;
+}
+
+struct GiBlock {
+    u64 in_off;        // deflate payload of the member inside the compressed buffer
+    uint32_t in_len;
+    uint32_t out_len;  // ISIZE
+    u64 out_off;       // where its text goes
+    uint32_t crc;
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
+                                                                    int32_t *status) {
+    __shared__ GiWave s_w[GI_WAVES];
+    const int lane = gi_lane();
+    const int wib = (int)gi_uni(threadIdx.x >> 6);
+    GiWave &w = s_w[wib];
+    const int64_t n_waves = (int64_t)gridDim.x * GI_WAVES;
+    for (int64_t bi = (int64_t)blockIdx.x * GI_WAVES + wib; bi < n_blocks; bi += n_waves) {
+        const GiBlock blk = blocks[bi];
+        uint8_t *const dst = out + blk.out_off;
+        const uint32_t cap = blk.out_len;
+        GiBits b;
+        b.start(comp + blk.in_off, blk.in_len, lane);
+        uint32_t pos = 0;          // bytes of text produced (stored or pending)
+        uint32_t npend = 0;        // pending literals (lane j < npend holds byte pos - npend + j)
+        uint32_t pbyte = 0;
+        uint32_t visible = 0;      // every byte below this offset is known to have reached memory
+        int err = GI_OK;
+        bool last = false;
+        auto flush = [&]() {
+            if (npend) {
+                if ((uint32_t)lane < npend) dst[pos - npend + (uint32_t)lane] = (uint8_t)pbyte;
+                npend = 0;
+            }
+        };
+        while (!last && err == GI_OK) {
+            b.refill(lane);
+            last = b.get(1) != 0;
+            const uint32_t btype = b.get(2);
+            if (btype == 0) {  // stored: to the byte boundary, LEN, ~LEN, bytes
+                b.drop(b.bc & 7);
+                b.refill(lane);
+                const uint32_t len = b.get(16), nlen = b.get(16);
+                if ((len ^ nlen) != 0xffffu) {
+                    err = GI_E_HEADER;
+                    break;
+                }
+                flush();
+                if (pos + len > cap) {
+                    err = GI_E_OVERRUN;
+                    break;
+                }
+                // the reader stands on a byte boundary: the bytes are copied straight from the payload, the reader re-seated behind them
+                const uint32_t src = (uint32_t)(b.consumed() >> 3);
+                if ((u64)src + len > blk.in_len) {
+                    err = GI_E_INPUT;
+                    break;
+                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = b.in[src + i];
+                b.seek(src + len, lane);
+                pos += len;
+                continue;
+            }
+            if (btype == 3) {
+                err = GI_E_HEADER;
+                break;
+            }
+            if (btype == 1) {  // fixed codes
+                for (int s = lane; s < 288; s += 64) w.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+                for (int s = lane; s < 32; s += 64) w.lens[288 + s] = 5;
+                gi_lds_sync();
+                if (!gi_build(w, 0, 288, 0, w.ltab, GI_LROOT, GI_LSIZE, lane) || !gi_build(w, 1, 32, 288, w.dtab, GI_DROOT, GI_DSIZE, lane)) {
+                    err = GI_E_TABLE;
+                    break;
+                }
+            } else {  // dynamic codes
+                b.refill(lane);
+                const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+                if (hlit > 286 || hdist > 30) {
+                    err = GI_E_HEADER;
+                    break;
+                }
+                for (int s = lane; s < 19; s += 64) w.lens[s] = 0;
+                gi_lds_sync();
+                for (int i = 0; i < hclen; i++) {
+                    b.refill(lane);
+                    const uint32_t v = b.get(3);
+                    if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
+                }
+                gi_lds_sync();
+                if (!gi_build(w, 2, 19, 0, w.dtab, 7, GI_DSIZE, lane)) {  // (the code length code lives in dtab for a moment)
+                    err = GI_E_TABLE;
+                    break;
+                }
+                int at = 0, prev = 0;
+                const int total = hlit + hdist;
+                // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
+                while (at < total && err == GI_OK) {
+                    b.refill(lane);
+                    const uint32_t e = gi_lookup(w.dtab, 7, b);
+                    if (((e >> 4) & 7u) != GI_LIT) {
+                        err = GI_E_CODE;
+                        break;
+                    }
+                    b.drop((int)(e & 15u));
+                    const int sym = (int)((e >> 8) & 0xffu);
+                    int rep = 1, val = sym;
+                    if (sym == 16) {
+                        if (at == 0) {
+                            err = GI_E_CODE;
+                            break;
+                        }
+                        rep = 3 + (int)b.get(2);
+                        val = prev;
+                    } else if (sym == 17) {
+                        rep = 3 + (int)b.get(3);
+                        val = 0;
+                    } else if (sym == 18) {
+                        rep = 11 + (int)b.get(7);
+                        val = 0;
+                    }
+                    if (at + rep > total) {
+                        err = GI_E_CODE;
+                        break;
+                    }
+                    // literal / length lengths at lens[24 + i] for now, distance lengths behind them
+                    for (int r = lane; r < rep; r += 64) w.lens[24 + at + r] = (uint8_t)val;
+                    at += rep;
+                    prev = val;
+                }
+                if (err != GI_OK) break;
+                gi_lds_sync();
+                {   // into place: lens[0 .. 288) literal / length (unused ones 0), lens[288 .. 320) distances
+                    uint8_t mine[5];
+                    for (int q = 0; q < 5; q++) {
+                        const int s = lane + 64 * q;  // 0 .. 319
+                        uint8_t v = 0;
+                        if (s < 288) {
+                            if (s < hlit) v = w.lens[24 + s];
+                        } else if (s - 288 < hdist)
+                            v = w.lens[24 + hlit + (s - 288)];
+                        mine[q] = v;
+                    }
+                    gi_lds_sync();
+                    for (int q = 0; q < 5; q++) w.lens[lane + 64 * q] = mine[q];
+                    gi_lds_sync();
+                }
+                if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
+                    err = GI_E_TABLE;
+                    break;
+                }
+                if (!gi_build(w, 0, 288, 0, w.ltab, GI_LROOT, GI_LSIZE, lane) || !gi_build(w, 1, 32, 288, w.dtab, GI_DROOT, GI_DSIZE, lane)) {
+                    err = GI_E_TABLE;
+                    break;
+                }
+            }
+            // ---- the symbols of the block
+            for (;;) {
+                b.refill(lane);
+                if (b.consumed() > (u64)blk.in_len * 8u + 64u) {
+                    err = GI_E_INPUT;
+                    break;
+                }
+                uint32_t e = gi_lookup(w.ltab, GI_LROOT, b);
+                const uint32_t kind = (e >> 4) & 7u;
+                b.drop((int)(e & 15u));
+                if (kind == GI_LIT) {
+                    if (pos >= cap) {
+                        err = GI_E_OVERRUN;
+                        break;
+                    }
+                    if ((uint32_t)lane == npend) pbyte = (e >> 8) & 0xffu;
+                    npend++;
+                    pos++;
+                    if (npend == 64) flush();
+                    continue;
+                }
+                if (kind == GI_EOB) break;
+                if (kind != GI_LEN) {
+                    err = GI_E_CODE;
+                    break;
+                }
+                const uint32_t len = ((e >> 8) & 0x1ffu) + b.get((int)((e >> 17) & 7u));
+                b.refill(lane);
+                const uint32_t d = gi_lookup(w.dtab, GI_DROOT, b);
+                if (((d >> 4) & 7u) != GI_DIST) {
+                    err = GI_E_CODE;
+                    break;
+                }
+                b.drop((int)(d & 15u));
+                const uint32_t dist = ((d >> 8) & 0x7fffu) + b.get((int)((d >> 23) & 15u));
+                if (dist > pos) {
+                    err = GI_E_DIST;
+                    break;
+                }
+                if (pos + len > cap) {
+                    err = GI_E_OVERRUN;
+                    break;
+                }
+                flush();
+                const uint32_t from = pos - dist;
+                if (from + (len < dist ? len : dist) > visible) {  // the source reaches into bytes this wave stored since its last wait
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    visible = pos;
+                }
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + (dist >= len ? i : i % dist)];
+                pos += len;
+            }
+        }
+        flush();
+        if (err == GI_OK && pos != cap) err = GI_E_SIZE;
+        if (err == GI_OK && b.consumed() > (u64)blk.in_len * 8u) err = GI_E_INPUT;
+        if (err == GI_OK && cap > 0) {  // CRC-32 of the text: 64 equal slices, then crc = crc_0 * x^(8 (n - s)) + crc_1 * x^(8 (n - 2s)) + ...
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t slice = (cap + 63u) / 64u;
+            const uint32_t lo = (uint32_t)lane * slice, hi = lo + slice < cap ? lo + slice : cap;
+            uint32_t c = 0;  // (raw register: the pre / post inversion is applied once, on the combined value)
+            if (lane == 0) c = 0xffffffffu;
+            for (uint32_t i = lo; i < hi && lo < cap; i++) c = gi_crc_table[(c ^ dst[i]) & 0xffu] ^ (c >> 8);
+            // combine: the register after slice j is R_j; the whole register = sum_j R_j * x^(8 * bytes behind slice j)
+            const uint32_t behind = hi < cap ? cap - hi : 0;
+            uint32_t part = (lo < cap) ? gi_gf_mul(c, gi_x_pow_8n(behind)) : 0u;
+            for (int o = 32; o >= 1; o >>= 1) part ^= (uint32_t)__shfl_xor((int)part, o);
+            if ((part ^ 0xffffffffu) != blk.crc) err = GI_E_CRC;
+        }
+        if (lane == 0) status[bi] = err;
+    }
+}
+
+// ---- the four-line cut: newlines per 4 KiB tile, then (one workgroup) the offset of the last newline whose count is a multiple of 4
+__global__ __launch_bounds__(256) void gi_count_kernel(const uint8_t *text, int64_t n, uint32_t *tile_count) {
+    const int64_t tile = blockIdx.x;
+    const int64_t at = tile * 4096 + (int64_t)threadIdx.x * 16;
+    uint32_t c = 0;
+    if (at + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + at);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        for (int q = 0; q < 4; q++) {
+            const uint32_t x = wds[q] ^ 0x0a0a0a0au;
+            c += __popc(((x - 0x01010101u) & ~x & 0x80808080u));
+        }
+    } else {
+        for (int64_t i = at; i < n && i < at + 16; i++) c += text[i] == '\n';
+    }
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_count[tile] = s[0];
+}
+
+// out[0] = newlines in [0, n), out[1] = bytes up to and including the newline number (out[0] & ~3) (0 if that is 0)
+__global__ __launch_bounds__(1024) void gi_cut_kernel(const uint8_t *text, int64_t n, const uint32_t *tile_count, int64_t n_tiles, u64 *out) {
+    __shared__ u64 s_part[1024];
+    __shared__ u64 s_total, s_tile, s_before;
+    const int t = (int)threadIdx.x;
+    // totals per thread over a contiguous range of tiles
+    const int64_t per = (n_tiles + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    u64 mine = 0;
+    for (int64_t i = lo; i < hi; i++) mine += tile_count[i];
+    s_part[t] = mine;
+    __syncthreads();
+    if (t == 0) {
+        u64 tot = 0;
+        for (int i = 0; i < 1024; i++) tot += s_part[i];
+        s_total = tot;
+        const u64 target = tot & ~3ULL;  // the newline with this number (1-based) ends the last whole record
+        u64 acc = 0;
+        int64_t tile = -1;
+        if (target > 0) {
+            int i = 0;
+            while (acc + s_part[i] < target) acc += s_part[i++];
+            for (int64_t j = (int64_t)i * per;; j++) {
+                if (acc + tile_count[j] >= target) {
+                    tile = j;
+                    break;
+                }
+                acc += tile_count[j];
+            }
+        }
+        s_tile = (u64)tile;
+        s_before = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const u64 target = s_total & ~3ULL;
+        u64 cut = 0;
+        if (target > 0) {
+            u64 seen = s_before;
+            const int64_t base = (int64_t)s_tile * 4096;
+            for (int64_t i = base; i < n && i < base + 4096; i++)
+                if (text[i] == '\n' && ++seen == target) {
+                    cut = (u64)i + 1;
+                    break;
+                }
+        }
+        out[0] = s_total;
+        out[1] = cut;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string gi_err;
+extern "C" const char *gs_inflate_last_error(void) { return gi_err.c_str(); }
+static int gi_fail(int code, const std::string &m) {
+    gi_err = m;
+    return code;
+}
+#define GI_TRY(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) return gi_fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static int gi_upload_crc_table() {
+    static bool done[64] = {false};
+    int dev = 0;
+    GI_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && done[dev]) return GS_OK;
+    uint32_t t[256];
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xedb88320u : 0u);
+        t[i] = c;
+    }
+    GI_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gi_crc_table), t, sizeof(t)));
+    if (dev >= 0 && dev < 64) done[dev] = true;
+    return GS_OK;
+}
+
+struct gs_inflater {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    uint8_t *d_comp[2] = {nullptr, nullptr};
+    size_t comp_cap[2] = {0, 0};
+    uint8_t *h_comp[2] = {nullptr, nullptr};  // page-locked staging: the file is a page-cache mapping, which the runtime copies at ~0.1 GB/s
+    size_t h_comp_cap[2] = {0, 0};
+    int64_t comp_lo[2] = {-1, -1}, comp_hi[2] = {-1, -1};  // the range of the file each staging buffer holds
+    hipEvent_t comp_ready[2] = {nullptr, nullptr};
+    uint8_t *d_text[2] = {nullptr, nullptr};
+    size_t text_cap[2] = {0, 0};
+    int cur = 0;            // text buffer of the current call
+    int64_t tail = 0;       // bytes carried into d_text[cur] by the previous call
+    GiBlock *d_blocks = nullptr;
+    size_t blocks_cap = 0;
+    int32_t *d_status = nullptr;
+    size_t status_cap = 0;
+    uint32_t *d_tiles = nullptr;
+    size_t tiles_cap = 0;
+    u64 *d_cut = nullptr;
+    // pinned host mirrors
+    GiBlock *h_blocks = nullptr;
+    int32_t *h_status = nullptr;
+    size_t h_cap = 0;
+    u64 *h_cut = nullptr;
+    double kernel_ms = 0;
+    int64_t launches = 0;
+};
+
+extern "C" int gs_inflater_create(gs_inflater **out, int device) {
+    if (!out) return gi_fail(GS_E_INVALID, "NULL argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
+    if (device < 0 || device >= n) return gi_fail(GS_E_INVALID, "bad device");
+    GI_TRY(hipSetDevice(device));
+    int rc = gi_upload_crc_table();
+    if (rc) return rc;
+    gs_inflater *g = new gs_inflater();
+    g->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->comp_ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_cut, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g->h_cut, 2 * sizeof(u64));
+    if (e != hipSuccess) {
+        delete g;
+        return gi_fail(GS_E_HIP, std::string("inflater: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return GS_OK;
+}
+
+// forget the carried tail and the staged ranges: the inflater is ready for another file (its buffers stay)
+extern "C" int gs_inflater_reset(gs_inflater *g) {
+    if (!g) return gi_fail(GS_E_INVALID, "NULL argument");
+    hipSetDevice(g->device);
+    if (g->stream) hipStreamSynchronize(g->stream);
+    g->tail = 0;
+    g->cur = 0;
+    for (int i = 0; i < 2; i++) g->comp_lo[i] = g->comp_hi[i] = -1;
+    return GS_OK;
+}
+
+extern "C" int gs_inflater_destroy(gs_inflater *g) {
+    if (!g) return GS_OK;
+    hipSetDevice(g->device);
+    if (g->stream) hipStreamSynchronize(g->stream);
+    for (int i = 0; i < 2; i++) {
+        hipFree(g->d_comp[i]);
+        hipHostFree(g->h_comp[i]);
+        hipFree(g->d_text[i]);
+        if (g->comp_ready[i]) hipEventDestroy(g->comp_ready[i]);
+    }
+    hipFree(g->d_blocks);
+    hipFree(g->d_status);
+    hipFree(g->d_tiles);
+    hipFree(g->d_cut);
+    hipHostFree(g->h_blocks);
+    hipHostFree(g->h_status);
+    hipHostFree(g->h_cut);
+    if (g->stream) hipStreamDestroy(g->stream);
+    delete g;
+    return GS_OK;
+}
+
+template <typename T>
+static int gi_grow(T **p, size_t *cap, size_t need, hipStream_t s) {
+    if (*cap >= need) return GS_OK;
+    GI_TRY(hipStreamSynchronize(s));
+    hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    GI_TRY(hipMalloc((void **)p, want * sizeof(T)));
+    *cap = want;
+    return GS_OK;
+}
+
+// the same for a buffer whose first `keep` bytes matter (the carried tail of the text)
+static int gi_grow_keep(uint8_t **p, size_t *cap, size_t need, size_t keep, hipStream_t s) {
+    if (*cap >= need) return GS_OK;
+    GI_TRY(hipStreamSynchronize(s));
+    uint8_t *q = nullptr;
+    const size_t want = need + need / 4 + 4096;
+    GI_TRY(hipMalloc((void **)&q, want));
+    if (keep > 0 && *p) {
+        hipError_t e = hipMemcpy(q, *p, keep, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            hipFree(q);
+            return gi_fail(GS_E_HIP, std::string("text buffer: ") + hipGetErrorString(e));
+        }
+    }
+    hipFree(*p);
+    *p = q;
+    *cap = want;
+    return GS_OK;
+}
+
+// copy file[lo, hi) into staging buffer `which` (asynchronous on the inflater's stream)
+static int gi_stage(gs_inflater *g, int which, const uint8_t *file, int64_t lo, int64_t hi) {
+    if (g->comp_lo[which] == lo && g->comp_hi[which] == hi) return GS_OK;  // prefetched by the previous call
+    int rc = gi_grow(&g->d_comp[which], &g->comp_cap[which], (size_t)(hi - lo) + 1024, g->stream);
+    if (rc) return rc;
+    if (g->h_comp_cap[which] < (size_t)(hi - lo)) {
+        GI_TRY(hipStreamSynchronize(g->stream));
+        hipHostFree(g->h_comp[which]);
+        g->h_comp[which] = nullptr;
+        g->h_comp_cap[which] = 0;
+        const size_t want = (size_t)(hi - lo) + (size_t)(hi - lo) / 4 + 4096;
+        GI_TRY(hipHostMalloc((void **)&g->h_comp[which], want));
+        g->h_comp_cap[which] = want;
+    }
+    {   // the page-cache mapping into the page-locked buffer, on several threads (one thread moves ~5 GB/s: less than the device inflates)
+        const size_t n = (size_t)(hi - lo);
+        int n_thr = (int)std::min<size_t>(8, n >> 22);
+        if (const char *e = getenv("GS_INFLATE_COPY_THREADS")) n_thr = std::max(1, std::min(32, atoi(e)));
+        if (n_thr <= 1) {
+            memcpy(g->h_comp[which], file + lo, n);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) {
+                const size_t a = n * (size_t)t / (size_t)n_thr, b = n * ((size_t)t + 1) / (size_t)n_thr;
+                th.emplace_back([=] { memcpy(g->h_comp[which] + a, file + lo + a, b - a); });
+            }
+            for (auto &x : th) x.join();
+        }
+    }
+    GI_TRY(hipMemcpyAsync(g->d_comp[which], g->h_comp[which], (size_t)(hi - lo), hipMemcpyHostToDevice, g->stream));
+    GI_TRY(hipMemsetAsync(g->d_comp[which] + (hi - lo), 0, 1024, g->stream));
+    g->comp_lo[which] = lo;
+    g->comp_hi[which] = hi;
+    return GS_OK;
+}
+
+extern "C" int gs_inflater_feed(gs_inflater *g, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, int64_t next_lo,
+                                int64_t next_hi, int last, const uint8_t **text, int64_t *n_bytes, int64_t *n_lines, int64_t *tail_bytes) {
+    if (!g || !text || !n_bytes || !n_lines || n_members < 0 || (n_members > 0 && (!file || !members)))
+        return gi_fail(GS_E_INVALID, "bad argument");
+    GI_TRY(hipSetDevice(g->device));
+    *text = nullptr;
+    *n_bytes = *n_lines = 0;
+    int64_t lo = 0, hi = 0, total_out = 0;
+    for (int64_t i = 0; i < n_members; i++) {
+        const gs_inflate_member &m = members[i];
+        if (m.payload_len > (1u << 20) || m.isize > (1u << 16) || m.payload_offset < 0)
+            return gi_fail(GS_E_INVALID, "a BGZF member holds at most 64 KiB of text");
+        if (i == 0) lo = m.payload_offset;
+        if (m.payload_offset < hi && i > 0) return gi_fail(GS_E_INVALID, "members must be in file order");
+        hi = m.payload_offset + (int64_t)m.payload_len;
+        total_out += m.isize;
+    }
+    lo &= ~(int64_t)3;  // (the payloads are read as aligned dwords)
+    const int cb = g->cur;
+    int rc;
+    if ((rc = gi_grow_keep(&g->d_text[cb], &g->text_cap[cb], (size_t)(g->tail + total_out) + 8192, (size_t)g->tail, g->stream))) return rc;
+    if ((rc = gi_grow(&g->d_blocks, &g->blocks_cap, (size_t)n_members + 1, g->stream))) return rc;
+    if ((rc = gi_grow(&g->d_status, &g->status_cap, (size_t)n_members + 1, g->stream))) return rc;
+    if (g->h_cap < (size_t)n_members + 1) {
+        GI_TRY(hipStreamSynchronize(g->stream));
+        hipHostFree(g->h_blocks);
+        hipHostFree(g->h_status);
+        g->h_blocks = nullptr;
+        g->h_status = nullptr;
+        g->h_cap = 0;
+        const size_t want = (size_t)n_members * 2 + 1024;
+        GI_TRY(hipHostMalloc((void **)&g->h_blocks, want * sizeof(GiBlock)));
+        GI_TRY(hipHostMalloc((void **)&g->h_status, want * sizeof(int32_t)));
+        g->h_cap = want;
+    }
+    if (n_members > 0) {
+        if ((rc = gi_stage(g, cb, file, lo, hi))) return rc;
+        int64_t at = g->tail;
+        for (int64_t i = 0; i < n_members; i++) {
+            GiBlock &b = g->h_blocks[i];
+            b.in_off = (u64)(members[i].payload_offset - lo);
+            b.in_len = members[i].payload_len;
+            b.out_len = members[i].isize;
+            b.out_off = (u64)at;
+            b.crc = members[i].crc32;
+            b.pad = 0;
+            at += members[i].isize;
+        }
+        GI_TRY(hipMemcpyAsync(g->d_blocks, g->h_blocks, sizeof(GiBlock) * (size_t)n_members, hipMemcpyHostToDevice, g->stream));
+        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * 4);
+        hipLaunchKernelGGL(gi_inflate_kernel, dim3(grid), dim3(64 * GI_WAVES), 0, g->stream, g->d_comp[cb], g->d_blocks, n_members, g->d_text[cb],
+                           g->d_status);
+        GI_TRY(hipGetLastError());
+        GI_TRY(hipMemcpyAsync(g->h_status, g->d_status, sizeof(int32_t) * (size_t)n_members, hipMemcpyDeviceToHost, g->stream));
+    }
+    const int64_t have = g->tail + total_out;
+    const int64_t n_tiles = (have + 4095) / 4096;
+    if ((rc = gi_grow(&g->d_tiles, &g->tiles_cap, (size_t)n_tiles + 1, g->stream))) return rc;
+    if (have > 0) {
+        hipLaunchKernelGGL(gi_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, g->stream, g->d_text[cb], have, g->d_tiles);
+        hipLaunchKernelGGL(gi_cut_kernel, dim3(1), dim3(1024), 0, g->stream, g->d_text[cb], have, g->d_tiles, n_tiles, g->d_cut);
+        GI_TRY(hipGetLastError());
+        GI_TRY(hipMemcpyAsync(g->h_cut, g->d_cut, 2 * sizeof(u64), hipMemcpyDeviceToHost, g->stream));
+    } else {
+        g->h_cut[0] = g->h_cut[1] = 0;
+    }
+    // the compressed bytes of the NEXT call travel while this call's kernels run
+    if (next_hi > next_lo && file) {
+        if ((rc = gi_stage(g, cb ^ 1, file, next_lo & ~(int64_t)3, next_hi))) return rc;
+    }
+    GI_TRY(hipStreamSynchronize(g->stream));
+    for (int64_t i = 0; i < n_members; i++)
+        if (g->h_status[i] != GI_OK)
+            return gi_fail(GS_E_INVALID, "corrupt BGZF member " + std::to_string(i) + " of this run (inflate status " + std::to_string(g->h_status[i]) + ")");
+    int64_t lines = (int64_t)g->h_cut[0], cut = (int64_t)g->h_cut[1];
+    int64_t whole_lines = lines & ~(int64_t)3;
+    if (last && (lines & 3) == 0 && cut < have) {
+        // (the file ends without a final newline behind whole records: the tail is an unterminated line the caller must deal with)
+    }
+    *text = g->d_text[cb];
+    *n_bytes = cut;
+    *n_lines = whole_lines;
+    const int64_t tail = have - cut;
+    if (tail_bytes) *tail_bytes = tail;
+    // the rest opens the other buffer for the next call
+    const int nb = cb ^ 1;
+    if ((rc = gi_grow(&g->d_text[nb], &g->text_cap[nb], (size_t)tail + 8192, g->stream))) return rc;
+    if (tail > 0) GI_TRY(hipMemcpyAsync(g->d_text[nb], g->d_text[cb] + cut, (size_t)tail, hipMemcpyDeviceToDevice, g->stream));
+    GI_TRY(hipStreamSynchronize(g->stream));
+    g->tail = tail;
+    g->cur = nb;
+    return GS_OK;
+}
+
+// the tail the last call left over (an unterminated last line, or fewer than four lines): copied to the host for the caller's parser
+extern "C" int gs_inflater_tail(gs_inflater *g, uint8_t *out, int64_t cap, int64_t *n) {
+    if (!g || !n) return gi_fail(GS_E_INVALID, "NULL argument");
+    *n = g->tail;
+    if (g->tail == 0) return GS_OK;
+    if (!out || cap < g->tail) return gi_fail(GS_E_INVALID, "tail buffer too small");
+    GI_TRY(hipSetDevice(g->device));
+    GI_TRY(hipMemcpy(out, g->d_text[g->cur], (size_t)g->tail, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+// one-shot form (tests, tools): inflate the members of a compressed buffer on the host into a host buffer
+extern "C" int gs_inflate_members(int device, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, uint8_t *out,
+                                  int64_t out_cap, int32_t *status) {
+    if (n_members < 0 || (n_members > 0 && (!file || !members || !out))) return gi_fail(GS_E_INVALID, "bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
+    if (n_members == 0) return GS_OK;
+    GI_TRY(hipSetDevice(device));
+    int rc = gi_upload_crc_table();
+    if (rc) return rc;
+    int64_t lo = members[0].payload_offset & ~(int64_t)3, hi = 0, total = 0;
+    std::vector<GiBlock> hb((size_t)n_members);
+    for (int64_t i = 0; i < n_members; i++) {
+        if (members[i].payload_len > (1u << 20) || members[i].isize > (1u << 16) || members[i].payload_offset < lo)
+            return gi_fail(GS_E_INVALID, "a BGZF member holds at most 64 KiB of text; members in file order");
+        hb[(size_t)i] = GiBlock{(u64)(members[i].payload_offset - lo), members[i].payload_len, members[i].isize, (u64)total, members[i].crc32, 0};
+        total += members[i].isize;
+        hi = std::max<int64_t>(hi, members[i].payload_offset + (int64_t)members[i].payload_len);
+    }
+    if (total > out_cap) return gi_fail(GS_E_INVALID, "output buffer too small");
+    uint8_t *d_comp = nullptr, *d_out = nullptr;
+    GiBlock *d_b = nullptr;
+    int32_t *d_s = nullptr;
+    hipError_t e = hipMalloc((void **)&d_comp, (size_t)(hi - lo) + 1024);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)total + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, sizeof(GiBlock) * (size_t)n_members);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_s, sizeof(int32_t) * (size_t)n_members);
+    if (e == hipSuccess) e = hipMemset(d_comp, 0, (size_t)(hi - lo) + 1024);
+    if (e == hipSuccess) e = hipMemcpy(d_comp, file + lo, (size_t)(hi - lo), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_b, hb.data(), sizeof(GiBlock) * (size_t)n_members, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)n_cu * 4);
+        hipLaunchKernelGGL(gi_inflate_kernel, dim3(grid), dim3(64 * GI_WAVES), 0, 0, d_comp, d_b, n_members, d_out, d_s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    std::vector<int32_t> st((size_t)n_members, -1);
+    if (e == hipSuccess) e = hipMemcpy(st.data(), d_s, sizeof(int32_t) * (size_t)n_members, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total > 0) e = hipMemcpy(out, d_out, (size_t)total, hipMemcpyDeviceToHost);
+    hipFree(d_comp);
+    hipFree(d_out);
+    hipFree(d_b);
+    hipFree(d_s);
+    if (e != hipSuccess) return gi_fail(GS_E_HIP, std::string("gs_inflate_members: ") + hipGetErrorString(e));
+    int bad = 0;
+    for (int64_t i = 0; i < n_members; i++) {
+        if (status) status[i] = st[(size_t)i];
+        bad += st[(size_t)i] != GI_OK;
+    }
+    return bad ? gi_fail(GS_E_INVALID, std::to_string(bad) + " member(s) did not inflate to their ISIZE / CRC-32") : GS_OK;
+}

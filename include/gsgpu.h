@@ -399,6 +399,8 @@ int gs_match_text_read_bounds(gs_run *run, uint64_t *bounds);
 
 /* accumulated device time of the match kernel launches since gs_match_begin (cfg.profile != 0) */
 int gs_match_kernel_time(gs_run *run, int64_t *launches, double *total_ms);
+/* the device the run's store lives on (for helpers that work beside a run: gs_inflater_create) */
+int gs_match_get_device(gs_run *run, int *device);
 
 /* ---------------------------------------------------------------------------------------------------
  * filter
@@ -458,6 +460,45 @@ int gs_filter_submit_fastq_ml(gs_bloom *bloom, int k, int min_pos_count, double 
 int gs_filter_text_read_bounds(gs_bloom *bloom, uint64_t *bounds);
 int gs_filter_text_line_classes(gs_bloom *bloom, uint8_t *classes);
 int gs_filter_kernel_time(gs_bloom *bloom, int64_t *launches, double *total_ms);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Block-gzip input inflated on the device
+ *
+ * Replaces java.util.zip.GZIPInputStream in front of the FASTQ parser (B/io/StreamProvider.java:92-100, 148-150) for BGZF
+ * files (bgzip / htslib; also what this library writes for .gz outputs): gzip members of at most 64 KiB of text that state
+ * their compressed size, so the host lists them without inflating and ships the COMPRESSED bytes; one wave inflates one member
+ * (genestrip_amd/csrc/gs_inflate_dev.hip), ISIZE and CRC-32 are checked as GZIPInputStream checks them.
+ *
+ *   payload_offset / payload_len   the member's DEFLATE stream inside `file` (behind the gzip header, in front of the trailer)
+ *   isize / crc32                  the member's trailer: size and CRC-32 of its text
+ *
+ * gs_inflate_members: one shot, host buffers (status[i]: 0 = ok, else the member's inflate error; may be NULL).
+ * gs_inflater_*: the streaming form in front of gs_match_submit_text / gs_filter_submit_text.  Every feed appends the text of a
+ * run of members behind what the previous feed left over and returns, as DEVICE memory, the longest prefix made of whole
+ * four-line records (n_lines a multiple of 4, n_bytes up to and including that newline); the rest is carried into the next
+ * feed.  next_lo / next_hi: the byte range of `file` the NEXT feed will need (0, 0: none) -- it is copied to the device while
+ * this feed's kernels run.  The returned pointer stays valid until the NEXT feed (hand it to gs_match_submit_text with
+ * GS_MEM_DEVICE and wait for that chunk's copy -- gs_match_text_wait_copy -- before feeding again).  gs_inflater_tail: what is left after the last feed (fewer
+ * than four lines, or a last line without newline), for the caller's parser.  A member that does not inflate to its ISIZE and
+ * CRC-32 fails the feed with GS_E_INVALID (gs_inflate_last_error).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t payload_offset;
+    uint32_t payload_len;
+    uint32_t isize;
+    uint32_t crc32;
+    uint32_t reserved;
+} gs_inflate_member;
+typedef struct gs_inflater gs_inflater;
+int gs_inflate_members(int device, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, uint8_t *out,
+                       int64_t out_cap, int32_t *status);
+int gs_inflater_create(gs_inflater **out, int device);
+int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, int64_t next_lo,
+                     int64_t next_hi, int last, const uint8_t **text, int64_t *n_bytes, int64_t *n_lines, int64_t *tail_bytes);
+int gs_inflater_tail(gs_inflater *inf, uint8_t *out, int64_t cap, int64_t *n);
+int gs_inflater_reset(gs_inflater *inf);  /* ready for another file; its device and page-locked buffers stay (allocating them costs more than inflating a file) */
+int gs_inflater_destroy(gs_inflater *inf);
+const char *gs_inflate_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart; not on the data path): the ceilings of the device the kernels run on,
