@@ -611,17 +611,13 @@ struct TextJob {
     ~TextJob() { abort(); }
     // stops the readers (after the writers of the last chunk are through with its block)
     void abort() {
-        const double ta = now_s();
         drain();
         release_held();
-        const double tb = now_s();
         tr.close();
-        const double tc = now_s();
         if (inf_) {
             inflater_pool().put(inf_device_, inf_);
             inf_ = nullptr;
         }
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] abort: drain %.2f ms, close %.2f ms, pool %.2f ms\n", fmod(now_s() * 1e3, 1e6), (tb - ta) * 1e3, (tc - tb) * 1e3, (now_s() - tc) * 1e3);
     }
 
     // every byte of the mapped file belongs to a BGZF member: list them (payload, ISIZE, CRC-32); false: not (only) BGZF
@@ -679,7 +675,6 @@ struct TextJob {
             }
         }
         if (!err && !dev_bgzf) tr.start();
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] open %s: %.2f ms (device inflate %d, %zu members)\n", fmod(now_s() * 1e3, 1e6), path.c_str(), (now_s() - t0) * 1e3, (int)dev_bgzf, members_.size());
         return err;
     }
 
@@ -1130,17 +1125,14 @@ private:
 
     int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
         done = true;
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] finish at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         drain();
         const int held_err = release_held();  // (the blocks return to the pool in close(): no copy may still read them)
         if (!err) err = held_err;
         tr.close();
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f]   closed at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         c.t_parse += now_s() - t0;
         if (err) return err;
         err = gs_match_text_select(c.run, bank);
         if (!err && fallback_off < 0) err = check_refusal(&fallback_off, &fallback_reads);  // also fetches the final totals
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f]   status at %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - t0) * 1e3);
         if (err) return err;
         if (fallback_off >= 0) {  // `tot` was read after the refusal: it holds exactly the accepted chunks
             int64_t failed = -1, bad = -1;
@@ -1184,7 +1176,6 @@ namespace {
 // max-contig read numbers of the run are in that (file, read) form.
 int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t *file_index, std::vector<int64_t> &reads_of_file_out,
               bool *composite) {
-    if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] run_files enter\n", fmod(now_s() * 1e3, 1e6));
     bool fast = true;
     if (const char *e = getenv("GS_HOST_FAST")) fast = atoi(e) != 0;
     int err = GS_OK;
@@ -1292,16 +1283,13 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         }
     }
     if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
-    const double t_enter = now_s();
     rc = gs_match_begin(&c.run, db, cfg);
     if (rc) return rc;
     const double t_start = now_s();
     std::vector<int64_t> reads_of_file;
     bool side_by_side = false;
     int err = run_files(c, paths, n_paths, nullptr, reads_of_file, &side_by_side);
-    const double t_files = now_s();
     if (!err) err = gs_match_finish(c.run, table, dtable);
-    if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] match_files: begin %.2f ms, files %.2f ms, finish %.2f ms\n", fmod(now_s() * 1e3, 1e6), (t_start - t_enter) * 1e3, (t_files - t_start) * 1e3, (now_s() - t_files) * 1e3);
     if (!err && side_by_side) {  // (file << 32 | read in file) -> running read number over the files in order
         std::vector<int64_t> before((size_t)n_paths + 1, 0);
         for (int i = 0; i < n_paths; i++) before[(size_t)i + 1] = before[(size_t)i] + reads_of_file[(size_t)i];
@@ -1310,11 +1298,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
             if (x >= 0) x = before[(size_t)(x >> 32)] + (x & 0xffffffffLL);
         }
     }
-    {
-        const double td = now_s();
-        gs_match_destroy(c.run);
-        if (getenv("GS_HOST_TRACE")) fprintf(stderr, "[%.1f] match_files: destroy %.2f ms\n", fmod(now_s() * 1e3, 1e6), (now_s() - td) * 1e3);
-    }
+    gs_match_destroy(c.run);
     const bool wrote = c.filtered.close() & c.kraken.close();  // (both are flushed before the clock stops)
     if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {

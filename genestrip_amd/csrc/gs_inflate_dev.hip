@@ -34,32 +34,37 @@
 typedef unsigned long long u64;
 
 #define GI_WAVES 4                 // waves per workgroup
-#define GI_LROOT 10                // root bits of the literal / length table
-#define GI_DROOT 9                 // root bits of the distance table
-#define GI_LSIZE 1408              // entries: 2^10 root + sub-tables (zlib's bound for 286 symbols, root 10, 15 bits: 1332)
-#define GI_DSIZE 640               // 2^9 root + sub-tables (bound for 30 symbols, root 9, 15 bits: < 640)
-#define GI_MAXSYM 320              // 288 literal / length + 32 distance code lengths
+#define GI_LROOT 9                 // root bits of the literal / length table
+#define GI_DROOT 8                 // root bits of the distance table
+#define GI_LSIZE 864               // entries: 2^9 root + sub-tables (zlib's proven bound for 286 symbols, root 9, 15 bits: 852)
+#define GI_DSIZE 592               // 2^8 root + sub-tables; a code that needs more is decoded the canonical way (gi_slow)
+#define GI_LDESC ((GI_LSIZE - 512) / 2)
+#define GI_DDESC ((GI_DSIZE - 256) / 2)
 
-// table entry: bits 0-3 code bits to drop, bits 4-6 kind, bits 8.. payload
+// table entry (16 bits -- the tables of a wave take 4.7 KB of LDS, so that 32 waves fit a CU): bits 0-3 code bits to drop (in a
+// sub-table: the bits beyond the root), bits 4-6 kind, bits 7-15 value: the literal, the length / distance SYMBOL (base and extra
+// bits are arithmetic), or the number of the sub-table's descriptor (offset << 3 | index bits)
 enum { GI_BAD = 0, GI_LIT = 1, GI_LEN = 2, GI_EOB = 3, GI_SUB = 4, GI_DIST = 5 };
-#define GI_ENTRY(bits, kind, payload) ((uint32_t)(bits) | ((uint32_t)(kind) << 4) | ((uint32_t)(payload) << 8))
+#define GI_ENTRY(bits, kind, value) ((uint16_t)((uint32_t)(bits) | ((uint32_t)(kind) << 4) | ((uint32_t)(value) << 7)))
 
 // status of a member (0 = inflated, ISIZE and CRC-32 as announced)
 enum { GI_OK = 0, GI_E_HEADER = 1, GI_E_TABLE = 2, GI_E_CODE = 3, GI_E_DIST = 4, GI_E_OVERRUN = 5, GI_E_SIZE = 6, GI_E_CRC = 7, GI_E_INPUT = 8 };
 
-struct GiWave {
-    uint32_t ltab[GI_LSIZE];
-    uint32_t dtab[GI_DSIZE];
-    uint16_t count[16], offs[16];
-    uint16_t work[GI_MAXSYM];
-    uint8_t lens[GI_MAXSYM + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+struct GiCode {            // what the canonical decoder needs (and the table builder starts from)
+    uint16_t count[16];    // codes per length
+    uint16_t *work;        // symbols ordered by (length, symbol)
 };
 
-__constant__ uint16_t gi_len_base[31] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0};
-__constant__ uint8_t gi_len_extra[31] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0};
-__constant__ uint16_t gi_dist_base[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
-                                          4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
-__constant__ uint8_t gi_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+struct GiWave {
+    uint32_t lroot[1 << GI_LROOT];  // the literal / length root table again, 32-bit entries that can hold TWO literals (gi_pair_literals)
+    uint16_t ltab[GI_LSIZE];
+    uint16_t dtab[GI_DSIZE];
+    uint16_t ldesc[GI_LDESC], ddesc[GI_DDESC];
+    uint16_t lwork[288], dwork[32];
+    uint16_t lcount[16], dcount[16], offs[16];
+    uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+};
+
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 __constant__ uint32_t gi_crc_table[256];
 
@@ -69,6 +74,29 @@ __device__ __forceinline__ void gi_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// base and extra bits of a length symbol s = code - 257 (0..28) and of a distance symbol d (0..29): RFC 1951 3.2.5 in closed form
+__device__ __forceinline__ void gi_len_sym(uint32_t s, uint32_t &base, uint32_t &extra) {
+    if (s < 8) {
+        base = 3 + s;
+        extra = 0;
+    } else if (s == 28) {
+        base = 258;
+        extra = 0;
+    } else {
+        extra = (s >> 2) - 1;
+        base = 3 + ((4 + (s & 3)) << extra);
+    }
+}
+__device__ __forceinline__ void gi_dist_sym(uint32_t d, uint32_t &base, uint32_t &extra) {
+    if (d < 4) {
+        base = 1 + d;
+        extra = 0;
+    } else {
+        extra = (d >> 1) - 1;
+        base = 1 + ((2 + (d & 1)) << extra);
+    }
 }
 
 // ---- the bit reader: 64-bit buffer, refilled 32 bits at a time from the wave's current 256-byte piece of the input
@@ -146,65 +174,65 @@ struct GiBits {
     __device__ __forceinline__ u64 consumed() const { return (u64)taken * 32u - (u64)bc; }
 };
 
-// ---- Huffman decoding table from code lengths (canonical codes, deflate bit order), root table + sub-tables.
-// type 0: literal / length codes (n <= 288), 1: distance codes (n <= 32), 2: code length codes (n = 19, root 7, no sub-tables).
+// ---- Huffman code from code lengths (canonical codes, deflate bit order): counts + symbols in canonical order (always), and the
+// root table + sub-tables for the fast path (*fast = false when the sub-tables do not fit `cap`: the block is then decoded the
+// canonical way, gi_slow -- correct for every code, an order of magnitude slower, and not needed by any stream zlib writes).
+// type 0: literal / length codes (n = 288), 1: distance codes (n = 32), 2: code length codes (n = 19, root 7, no sub-tables).
 // All lanes run the same statements; only the replication of an entry over its copies is spread over the lanes.
-// Returns false for an over-subscribed or (where deflate forbids it) incomplete set of lengths, or when the sub-tables outgrow cap.
-__device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint32_t *tab, int root, int cap, int lane) {
-    for (int i = lane; i < 16; i += 64) w.count[i] = 0;
+// Returns false for an over-subscribed or (where deflate forbids it) incomplete set of lengths.
+__device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab, uint16_t *desc, int n_desc, uint16_t *count, uint16_t *work,
+                         int root, int cap, int lane, bool *fast) {
+    *fast = true;
+    for (int i = lane; i < 16; i += 64) count[i] = 0;
     for (int i = lane; i < (1 << root); i += 64) tab[i] = 0;
     gi_lds_sync();
     if (lane == 0)
-        for (int s = 0; s < n; s++) w.count[w.lens[lens_at + s]]++;
+        for (int s = 0; s < n; s++) count[w.lens[lens_at + s]]++;
     gi_lds_sync();
     int max = 15;
-    while (max >= 1 && w.count[max] == 0) max--;
+    while (max >= 1 && count[max] == 0) max--;
     if (max == 0) return true;  // no code at all (the distance code of a block of literals): every lookup ends in an invalid entry
     int left = 1;
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
-        left -= (int)w.count[len];
+        left -= (int)count[len];
         if (left < 0) return false;  // over-subscribed
     }
     if (left > 0 && (type == 2 || max != 1)) return false;  // incomplete: only a single code of one bit may stand alone
     if (lane == 0) {
         w.offs[1] = 0;
-        for (int len = 1; len < 15; len++) w.offs[len + 1] = (uint16_t)(w.offs[len] + w.count[len]);
+        for (int len = 1; len < 15; len++) w.offs[len + 1] = (uint16_t)(w.offs[len] + count[len]);
         for (int s = 0; s < n; s++) {
             const int l = w.lens[lens_at + s];
-            if (l) w.work[w.offs[l]++] = (uint16_t)s;
+            if (l) work[w.offs[l]++] = (uint16_t)s;
         }
     }
     gi_lds_sync();
     // codes in canonical order; `huff` is the bit-reversed code (the stream delivers codes low bit first)
     uint32_t huff = 0;
     int len = 1;
-    while (w.count[len] == 0) len++;
-    int remaining = (int)w.count[len];
+    while (count[len] == 0) len++;
+    int remaining = (int)count[len];
     int used = 1 << root;   // entries in use (root table first)
-    int sub_base = 0, sub_bits = 0;
+    int sub_base = 0, sub_bits = 0, n_sub = 0;
     uint32_t sub_prefix = 0xffffffffu;
     int n_codes = 0;
-    for (int l = 1; l <= 15; l++) n_codes += (int)w.count[l];
+    for (int l = 1; l <= 15; l++) n_codes += (int)count[l];
     for (int i = 0; i < n_codes; i++) {
-        const int sym = (int)w.work[i];
-        uint32_t e;
+        const int sym = (int)work[i];
+        uint32_t kind, value;
         if (type == 0) {
-            if (sym < 256)
-                e = GI_ENTRY(0, GI_LIT, sym);
-            else if (sym == 256)
-                e = GI_ENTRY(0, GI_EOB, 0);
-            else if (sym <= 285)
-                e = GI_ENTRY(0, GI_LEN, (uint32_t)gi_len_base[sym - 257] | ((uint32_t)gi_len_extra[sym - 257] << 9));
-            else
-                e = GI_ENTRY(0, GI_BAD, 0);  // 286, 287 never appear in a valid stream
+            kind = sym < 256 ? GI_LIT : (sym == 256 ? GI_EOB : (sym <= 285 ? GI_LEN : GI_BAD));  // 286, 287 never appear in a valid stream
+            value = sym < 256 ? (uint32_t)sym : (sym <= 285 ? (uint32_t)(sym - 257) & 31u : 0u);
         } else if (type == 1) {
-            e = sym <= 29 ? GI_ENTRY(0, GI_DIST, (uint32_t)gi_dist_base[sym] | ((uint32_t)gi_dist_extra[sym] << 15)) : GI_ENTRY(0, GI_BAD, 0);
+            kind = sym <= 29 ? GI_DIST : GI_BAD;
+            value = (uint32_t)sym;
         } else {
-            e = GI_ENTRY(0, GI_LIT, sym);
+            kind = GI_LIT;
+            value = (uint32_t)sym;
         }
         if (len <= root) {
-            e |= (uint32_t)len;
+            const uint16_t e = GI_ENTRY(len, kind, value);
             const int reps = 1 << (root - len);
             for (int r = lane; r < reps; r += 64) tab[huff + ((uint32_t)r << len)] = e;
         } else {
@@ -218,16 +246,24 @@ __device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint32_t *tab,
                     curr++;
                     l2++;
                     room <<= 1;
-                    cnt = (int)w.count[l2];
+                    cnt = (int)count[l2];
                 }
                 sub_bits = curr;
                 sub_base = used;
                 used += 1 << curr;
-                if (used > cap) return false;
+                if (used > cap || n_sub >= n_desc) {
+                    *fast = false;
+                    gi_lds_sync();
+                    return true;
+                }
                 for (int r = lane; r < (1 << curr); r += 64) tab[sub_base + r] = 0;
-                if (lane == 0) tab[prefix] = GI_ENTRY(root, GI_SUB, (uint32_t)sub_base | ((uint32_t)sub_bits << 12));
+                if (lane == 0) {
+                    desc[n_sub] = (uint16_t)(((uint32_t)sub_base << 3) | (uint32_t)sub_bits);
+                    tab[prefix] = GI_ENTRY(root, GI_SUB, n_sub);
+                }
+                n_sub++;
             }
-            e |= (uint32_t)(len - root);
+            const uint16_t e = GI_ENTRY(len - root, kind, value);
             const int reps = 1 << (sub_bits - (len - root));
             for (int r = lane; r < reps; r += 64) tab[sub_base + (huff >> root) + ((uint32_t)r << (len - root))] = e;
         }
@@ -237,22 +273,75 @@ __device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint32_t *tab,
         huff = incr ? (huff & (incr - 1)) + incr : 0;
         if (--remaining == 0 && i + 1 < n_codes) {
             len++;
-            while (w.count[len] == 0) len++;
-            remaining = (int)w.count[len];
+            while (count[len] == 0) len++;
+            remaining = (int)count[len];
         }
     }
     gi_lds_sync();
     return true;
 }
 
-__device__ __forceinline__ uint32_t gi_lookup(const uint32_t *tab, int root, const GiBits &b) {
-    uint32_t e = gi_uni(tab[b.peek(root)]);
-    if (((e >> 4) & 7u) == GI_SUB) {
-        const uint32_t base = (e >> 8) & 0xfffu, bits = (e >> 20) & 0xfu;
-        e = gi_uni(tab[base + (((uint32_t)(b.bb >> root)) & ((1u << bits) - 1u))]);
-        e += (uint32_t)root;  // (code bits = root + bits inside the sub-table; the low nibble cannot overflow: <= 15)
+// The hot loop's first lookup goes to `lroot`: entry = bits 0-3 code bits, bits 4-6 kind, bits 8-15 value (literal, length symbol,
+// sub-table number), and -- kind GI_LIT2 -- a SECOND literal in bits 16-23 when the bits behind a short literal code decode to
+// another literal inside the same root index (sequence and quality lines are runs of literals: two per table walk).  The decode
+// loop runs on the scalar unit, which the four SIMDs of a CU share: every symbol it does not have to walk for counts twice.
+#define GI_LIT2 6
+__device__ void gi_pair_literals(GiWave &w, int lane) {
+    uint32_t mine[(1 << GI_LROOT) / 64];
+#pragma unroll
+    for (int q = 0; q < (1 << GI_LROOT) / 64; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * (uint32_t)q;
+        const uint32_t e = w.ltab[i];
+        const uint32_t bits = e & 15u, kind = (e >> 4) & 7u, val = e >> 7;
+        uint32_t r = bits | (kind << 4) | ((val & 0xffu) << 8);
+        if (kind == GI_LIT && bits < GI_LROOT) {
+            const uint32_t e2 = w.ltab[i >> bits];  // (only its low GI_LROOT - bits index bits are real: usable iff its code is that short)
+            const uint32_t bits2 = e2 & 15u;
+            if (((e2 >> 4) & 7u) == GI_LIT && bits2 != 0 && bits + bits2 <= GI_LROOT) r = (bits + bits2) | ((uint32_t)GI_LIT2 << 4) | ((val & 0xffu) << 8) | (((e2 >> 7) & 0xffu) << 16);
+        }
+        mine[q] = r;
     }
-    return e;
+#pragma unroll
+    for (int q = 0; q < (1 << GI_LROOT) / 64; q++) w.lroot[lane + 64 * q] = mine[q];
+    gi_lds_sync();
+}
+
+// fast path: (kind << 16 | value << 4 | bits) of the next code; bits = 0: no such code
+__device__ __forceinline__ uint32_t gi_lookup(const uint16_t *tab, const uint16_t *desc, int root, const GiBits &b) {
+    uint32_t e = gi_uni(tab[b.peek(root)]);
+    uint32_t bits = e & 15u;
+    if (((e >> 4) & 7u) == GI_SUB) {
+        const uint32_t d = gi_uni(desc[e >> 7]);
+        e = gi_uni(tab[(d >> 3) + (((uint32_t)(b.bb >> root)) & ((1u << (d & 7u)) - 1u))]);
+        bits = (e & 15u) ? (e & 15u) + (uint32_t)root : 0u;
+    }
+    return (((e >> 4) & 7u) << 16) | ((e >> 7) << 4) | bits;
+}
+
+// the canonical decoder (no table): walks the lengths, one bit at a time; same result format.  type as in gi_build.
+__device__ uint32_t gi_slow(const uint16_t *count, const uint16_t *work, int type, const GiBits &b) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; len++) {
+        code |= (int)((b.bb >> (len - 1)) & 1u);
+        const int cnt = (int)count[len];
+        if (code - cnt < first) {
+            const int sym = (int)gi_uni(work[index + (code - first)]);
+            uint32_t kind, value;
+            if (type == 0) {
+                kind = sym < 256 ? GI_LIT : (sym == 256 ? GI_EOB : (sym <= 285 ? GI_LEN : GI_BAD));
+                value = sym < 256 ? (uint32_t)sym : (sym <= 285 ? (uint32_t)(sym - 257) & 31u : 0u);
+            } else {
+                kind = sym <= 29 ? GI_DIST : GI_BAD;
+                value = (uint32_t)sym;
+            }
+            return (kind << 16) | (value << 4) | (uint32_t)len;
+        }
+        index += cnt;
+        first += cnt;
+        first <<= 1;
+        code <<= 1;
+    }
+    return 0;
 }
 
 // x^(8 n) mod P (reflected CRC-32 polynomial arithmetic), and a * b mod P
@@ -285,13 +374,18 @@ struct GiBlock {
 };
 
 __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
-                                                                    int32_t *status) {
+                                                                    int32_t *status, int force_slow, unsigned long long *next_member) {
     __shared__ GiWave s_w[GI_WAVES];
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
-    const int64_t n_waves = (int64_t)gridDim.x * GI_WAVES;
-    for (int64_t bi = (int64_t)blockIdx.x * GI_WAVES + wib; bi < n_blocks; bi += n_waves) {
+    // the waves draw members from a shared counter: a member takes 5 .. 15 ms of a wave, a fixed assignment would leave the waves
+    // with one member fewer idle for that long
+    for (;;) {
+        unsigned long long take = 0;
+        if (lane == 0) take = atomicAdd(next_member, 1ULL);
+        const int64_t bi = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
+        if (bi >= n_blocks) break;
         const GiBlock blk = blocks[bi];
         uint8_t *const dst = out + blk.out_off;
         const uint32_t cap = blk.out_len;
@@ -302,10 +396,11 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
         uint32_t pbyte = 0;
         uint32_t visible = 0;      // every byte below this offset is known to have reached memory
         int err = GI_OK;
-        bool last = false;
+        bool last = false, lfast = true, dfast = true;
         auto flush = [&]() {
             if (npend) {
-                if ((uint32_t)lane < npend) dst[pos - npend + (uint32_t)lane] = (uint8_t)pbyte;
+                const uint32_t at = pos - npend + (uint32_t)lane;
+                if ((uint32_t)lane < npend && at < cap) dst[at] = (uint8_t)pbyte;  // (never beyond the member's own text)
                 npend = 0;
             }
         };
@@ -345,7 +440,8 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                 for (int s = lane; s < 288; s += 64) w.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
                 for (int s = lane; s < 32; s += 64) w.lens[288 + s] = 5;
                 gi_lds_sync();
-                if (!gi_build(w, 0, 288, 0, w.ltab, GI_LROOT, GI_LSIZE, lane) || !gi_build(w, 1, 32, 288, w.dtab, GI_DROOT, GI_DSIZE, lane)) {
+                if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+                    !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
                     err = GI_E_TABLE;
                     break;
                 }
@@ -364,7 +460,8 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
                 }
                 gi_lds_sync();
-                if (!gi_build(w, 2, 19, 0, w.dtab, 7, GI_DSIZE, lane)) {  // (the code length code lives in dtab for a moment)
+                bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
+                if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
                     err = GI_E_TABLE;
                     break;
                 }
@@ -373,13 +470,13 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                 // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
                 while (at < total && err == GI_OK) {
                     b.refill(lane);
-                    const uint32_t e = gi_lookup(w.dtab, 7, b);
-                    if (((e >> 4) & 7u) != GI_LIT) {
+                    const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
+                    if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
                         err = GI_E_CODE;
                         break;
                     }
                     b.drop((int)(e & 15u));
-                    const int sym = (int)((e >> 8) & 0xffu);
+                    const int sym = (int)((e >> 4) & 0xffu);
                     int rep = 1, val = sym;
                     if (sym == 16) {
                         if (at == 0) {
@@ -425,30 +522,70 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     err = GI_E_TABLE;
                     break;
                 }
-                if (!gi_build(w, 0, 288, 0, w.ltab, GI_LROOT, GI_LSIZE, lane) || !gi_build(w, 1, 32, 288, w.dtab, GI_DROOT, GI_DSIZE, lane)) {
+                if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+                    !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
                     err = GI_E_TABLE;
                     break;
                 }
             }
-            // ---- the symbols of the block
+            if (lfast) gi_pair_literals(w, lane);
+            if (force_slow) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
+            // ---- the symbols of the block.  Literals wait in `pbyte` (lane j: the j-th pending byte) and are stored 62..64 at a time;
+            // whether they fit the member's announced size is checked when they are stored (flush), not per literal.
+            const uint32_t tlimit = blk.in_len / 4u + 4u;  // dwords the reader may take before the stream has run off its payload
             for (;;) {
-                b.refill(lane);
-                if (b.consumed() > (u64)blk.in_len * 8u + 64u) {
-                    err = GI_E_INPUT;
-                    break;
-                }
-                uint32_t e = gi_lookup(w.ltab, GI_LROOT, b);
-                const uint32_t kind = (e >> 4) & 7u;
-                b.drop((int)(e & 15u));
-                if (kind == GI_LIT) {
-                    if (pos >= cap) {
-                        err = GI_E_OVERRUN;
+                if (b.bc <= 32) {
+                    b.refill(lane);
+                    if (b.taken > tlimit) {
+                        err = GI_E_INPUT;
                         break;
                     }
-                    if ((uint32_t)lane == npend) pbyte = (e >> 8) & 0xffu;
+                }
+                uint32_t e;
+                if (lfast) {
+                    const uint32_t r = gi_uni(w.lroot[b.peek(GI_LROOT)]);
+                    const uint32_t rk = (r >> 4) & 7u;
+                    if (rk == GI_LIT2) {  // two literals in one walk
+                        b.drop((int)(r & 15u));
+                        if ((uint32_t)lane == npend) pbyte = (r >> 8) & 0xffu;
+                        if ((uint32_t)lane == npend + 1u) pbyte = (r >> 16) & 0xffu;
+                        npend += 2;
+                        pos += 2;
+                        if (npend >= 63) {
+                            if (pos > cap) {
+                                err = GI_E_OVERRUN;
+                                break;
+                            }
+                            flush();
+                        }
+                        continue;
+                    }
+                    if (rk == GI_SUB) {
+                        const uint32_t d = gi_uni(w.ldesc[(r >> 8) & 0xffu]);
+                        const uint32_t e2 = gi_uni(w.ltab[(d >> 3) + (((uint32_t)(b.bb >> GI_LROOT)) & ((1u << (d & 7u)) - 1u))]);
+                        const uint32_t bits = (e2 & 15u) ? (e2 & 15u) + GI_LROOT : 0u;
+                        e = (((e2 >> 4) & 7u) << 16) | ((e2 >> 7) << 4) | bits;
+                    } else
+                        e = (rk << 16) | (((r >> 8) & 0xffu) << 4) | (r & 15u);
+                } else
+                    e = gi_slow(w.lcount, w.lwork, 0, b);
+                const uint32_t kind = e >> 16;
+                if ((e & 15u) == 0) {
+                    err = GI_E_CODE;
+                    break;
+                }
+                b.drop((int)(e & 15u));
+                if (kind == GI_LIT) {
+                    if ((uint32_t)lane == npend) pbyte = (e >> 4) & 0xffu;
                     npend++;
                     pos++;
-                    if (npend == 64) flush();
+                    if (npend >= 63) {
+                        if (pos > cap) {
+                            err = GI_E_OVERRUN;
+                            break;
+                        }
+                        flush();
+                    }
                     continue;
                 }
                 if (kind == GI_EOB) break;
@@ -456,15 +593,18 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     err = GI_E_CODE;
                     break;
                 }
-                const uint32_t len = ((e >> 8) & 0x1ffu) + b.get((int)((e >> 17) & 7u));
+                uint32_t lbase, lextra, dbase, dextra;
+                gi_len_sym((e >> 4) & 31u, lbase, lextra);
+                const uint32_t len = lbase + b.get((int)lextra);
                 b.refill(lane);
-                const uint32_t d = gi_lookup(w.dtab, GI_DROOT, b);
-                if (((d >> 4) & 7u) != GI_DIST) {
+                const uint32_t d = dfast ? gi_lookup(w.dtab, w.ddesc, GI_DROOT, b) : gi_slow(w.dcount, w.dwork, 1, b);
+                if ((d >> 16) != GI_DIST || (d & 15u) == 0) {
                     err = GI_E_CODE;
                     break;
                 }
                 b.drop((int)(d & 15u));
-                const uint32_t dist = ((d >> 8) & 0x7fffu) + b.get((int)((d >> 23) & 15u));
+                gi_dist_sym((d >> 4) & 31u, dbase, dextra);
+                const uint32_t dist = dbase + b.get((int)dextra);
                 if (dist > pos) {
                     err = GI_E_DIST;
                     break;
@@ -480,11 +620,19 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     visible = pos;
                 }
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + (dist >= len ? i : i % dist)];
+                if (dist >= len) {  // the usual case: source and destination do not overlap
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + i];
+                } else if (dist == 1) {  // a run of one byte
+                    const uint8_t c = dst[from];
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = c;
+                } else {  // the pattern of `dist` bytes repeats
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + i % dist];
+                }
                 pos += len;
             }
         }
-        flush();
+        if (err == GI_OK && pos > cap) err = GI_E_OVERRUN;
+        if (err == GI_OK) flush();
         if (err == GI_OK && pos != cap) err = GI_E_SIZE;
         if (err == GI_OK && b.consumed() > (u64)blk.in_len * 8u) err = GI_E_INPUT;
         if (err == GI_OK && cap > 0) {  // CRC-32 of the text: 64 equal slices, then crc = crc_0 * x^(8 (n - s)) + crc_1 * x^(8 (n - 2s)) + ...
@@ -596,6 +744,17 @@ static int gi_fail(int code, const std::string &m) {
         if (e_ != hipSuccess) return gi_fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+static int gi_wgs_per_cu() {  // workgroups of four waves per CU: more waves do NOT mean more text (their history windows share the caches)
+    int v = 4;
+    if (const char *e = getenv("GS_INFLATE_WGS")) v = std::max(1, std::min(8, atoi(e)));
+    return v;
+}
+
+static int gi_force_slow() {  // GS_INFLATE_FORCE_SLOW=1: every Huffman code through the canonical decoder (tests)
+    const char *e = getenv("GS_INFLATE_FORCE_SLOW");
+    return e && atoi(e) != 0;
+}
+
 static int gi_upload_crc_table() {
     static bool done[64] = {false};
     int dev = 0;
@@ -657,7 +816,7 @@ extern "C" int gs_inflater_create(gs_inflater **out, int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g->n_cu = prop.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->comp_ready[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&g->d_cut, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_cut, 4 * sizeof(u64));  // [0..1] the cut, [2] the member queue's cursor
     if (e == hipSuccess) e = hipHostMalloc((void **)&g->h_cut, 2 * sizeof(u64));
     if (e != hipSuccess) {
         delete g;
@@ -818,9 +977,10 @@ extern "C" int gs_inflater_feed(gs_inflater *g, const uint8_t *file, const gs_in
             at += members[i].isize;
         }
         GI_TRY(hipMemcpyAsync(g->d_blocks, g->h_blocks, sizeof(GiBlock) * (size_t)n_members, hipMemcpyHostToDevice, g->stream));
-        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * 4);
+        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * gi_wgs_per_cu());
+        GI_TRY(hipMemsetAsync(g->d_cut + 2, 0, sizeof(u64), g->stream));
         hipLaunchKernelGGL(gi_inflate_kernel, dim3(grid), dim3(64 * GI_WAVES), 0, g->stream, g->d_comp[cb], g->d_blocks, n_members, g->d_text[cb],
-                           g->d_status);
+                           g->d_status, gi_force_slow(), g->d_cut + 2);
         GI_TRY(hipGetLastError());
         GI_TRY(hipMemcpyAsync(g->h_status, g->d_status, sizeof(int32_t) * (size_t)n_members, hipMemcpyDeviceToHost, g->stream));
     }
@@ -897,7 +1057,10 @@ extern "C" int gs_inflate_members(int device, const uint8_t *file, const gs_infl
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     GiBlock *d_b = nullptr;
     int32_t *d_s = nullptr;
+    unsigned long long *d_q = nullptr;
     hipError_t e = hipMalloc((void **)&d_comp, (size_t)(hi - lo) + 1024);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_q, sizeof(u64));
+    if (e == hipSuccess) e = hipMemset(d_q, 0, sizeof(u64));
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)total + 64);
     if (e == hipSuccess) e = hipMalloc((void **)&d_b, sizeof(GiBlock) * (size_t)n_members);
     if (e == hipSuccess) e = hipMalloc((void **)&d_s, sizeof(int32_t) * (size_t)n_members);
@@ -907,8 +1070,8 @@ extern "C" int gs_inflate_members(int device, const uint8_t *file, const gs_infl
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)n_cu * 4);
-        hipLaunchKernelGGL(gi_inflate_kernel, dim3(grid), dim3(64 * GI_WAVES), 0, 0, d_comp, d_b, n_members, d_out, d_s);
+        const int grid = (int)std::min<int64_t>((n_members + GI_WAVES - 1) / GI_WAVES, (int64_t)n_cu * gi_wgs_per_cu());
+        hipLaunchKernelGGL(gi_inflate_kernel, dim3(grid), dim3(64 * GI_WAVES), 0, 0, d_comp, d_b, n_members, d_out, d_s, gi_force_slow(), d_q);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -919,6 +1082,7 @@ extern "C" int gs_inflate_members(int device, const uint8_t *file, const gs_infl
     hipFree(d_out);
     hipFree(d_b);
     hipFree(d_s);
+    hipFree(d_q);
     if (e != hipSuccess) return gi_fail(GS_E_HIP, std::string("gs_inflate_members: ") + hipGetErrorString(e));
     int bad = 0;
     for (int64_t i = 0; i < n_members; i++) {

@@ -113,3 +113,76 @@ def test_damaged_members_are_reported():
     with pytest.raises(ga.GsError) as e:
         ga.inflate_members(three, mem3)
     assert list(e.value.status != 0) == [False, True, False]
+
+
+def test_canonical_decoder_gives_the_same_text(monkeypatch):
+    """the table-free decoder that takes over when a Huffman code needs more sub-table room than a wave has (no stream zlib writes
+    does), forced onto everything"""
+    monkeypatch.setenv("GS_INFLATE_FORCE_SLOW", "1")
+    text = gzip.open(os.path.join(GOLDEN, "human_virus", "sample.fastq.gz")).read()
+    _roundtrip(bgzf(text, level=6), text)
+    _roundtrip(bgzf(text[:200000], level=9, block=20000), text[:200000])
+    test_block_kinds_and_shapes()
+
+
+def _fastq(seq, off, start=0, multiline=False, final_newline=True):
+    out = []
+    for i in range(len(off) - 1):
+        s = seq[int(off[i]):int(off[i + 1])].tobytes()
+        q = b"F" * len(s)
+        if multiline:
+            h = len(s) // 2
+            out.append(b"@r%d\n%s\n%s\n+\n%s\n%s\n" % (start + i, s[:h], s[h:], q[:h], q[h:]))
+        else:
+            out.append(b"@r%d some text\n%s\n+\n%s\n" % (start + i, s, q))
+    t = b"".join(out)
+    return t if final_newline else t[:-1]
+
+
+@pytest.mark.parametrize("shape", ["plain", "no_final_newline", "truncated", "multiline", "small_feeds"])
+def test_bgzf_files_through_the_device_inflater(tmp_path, monkeypatch, shape):
+    """gs_host_match_files on BGZF input: the members are inflated on the device (no per-read outputs asked for); the table and
+    the totals must equal the host decoder's and the oracle's -- also when the file ends in the middle of a record or without a
+    newline (the leftover goes to the reference-exact parser) and when it is not four-line FASTQ (the device scan refuses, the
+    general path takes over)"""
+    from genestrip_amd import host, synth
+    from oracle import gs_oracle as orc
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
+    seq, off = synth.reads_host(db.genomes, 30000, read_len=150, seed=9)
+    text = _fastq(seq, off, multiline=shape == "multiline", final_newline=shape != "no_final_newline")
+    if shape == "truncated":
+        text = text[:-200]
+    if shape == "small_feeds":
+        monkeypatch.setenv("GS_HOST_BGZF_TEXT", "300000")  # many feeds: tails carried from feed to feed on the device
+    path = tmp_path / "reads.fastq.gz"
+    path.write_bytes(bgzf(text, level=4))
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    monkeypatch.setenv("GS_DEVICE_INFLATE", "1")
+    t_dev, _, tot_dev = host.match_files(store, [str(path)])
+    monkeypatch.setenv("GS_DEVICE_INFLATE", "0")
+    t_host, _, tot_host = host.match_files(store, [str(path)])
+    assert np.array_equal(t_dev, t_host)
+    assert (tot_dev.reads, tot_dev.kmers, tot_dev.bps) == (tot_host.reads, tot_host.kmers, tot_host.bps)
+    if shape in ("plain", "small_feeds"):
+        orun = orc.MatchRun(orc.DB(31, db.kmers, db.value_idx, db.n_values, db.parent_vi))
+        orun.submit(seq, off, threads=8, per_read=False)
+        assert np.array_equal(t_dev, orun.finish()[0]) and tot_dev.reads == 30000
+    store.close()
+
+
+def test_a_corrupt_bgzf_member_fails_the_file(tmp_path, monkeypatch):
+    from genestrip_amd import host, synth
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
+    seq, off = synth.reads_host(db.genomes, 5000, read_len=150, seed=9)
+    data = bytearray(bgzf(_fastq(seq, off), level=6))
+    members, _ = ga.bgzf_members(bytes(data))
+    po, pl, _, _ = members[len(members) // 2]
+    data[po + pl // 2] ^= 0x55
+    path = tmp_path / "bad.fastq.gz"
+    path.write_bytes(bytes(data))
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    monkeypatch.setenv("GS_DEVICE_INFLATE", "1")
+    with pytest.raises(Exception) as e:
+        host.match_files(store, [str(path)])
+    assert "corrupt" in str(e.value)
+    store.close()
