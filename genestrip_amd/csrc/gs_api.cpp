@@ -2978,6 +2978,7 @@ struct gs_dbbuild {
     int32_t *d_out_vals = nullptr;
     int64_t n_out = 0, n_kmers_seen = 0;
     bool finished = false;
+    bool failed = false;  // gs_dbbuild_finish failed half-way: the pairs are gone, nothing can be fetched (sticky GS_E_STATE)
 };
 
 static void dbbuild_free(gs_dbbuild *b) {
@@ -3126,6 +3127,7 @@ extern "C" int gs_dbbuild_set_range(gs_dbbuild *b, uint64_t lo, uint64_t hi) {
 
 extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
     if (!b || !n_kmers) return fail(GS_E_INVALID, "NULL argument");
+    if (b->failed) return fail(GS_E_STATE, "this builder's gs_dbbuild_finish failed: its pairs are gone (start over with gs_dbbuild_begin)");
     if (b->finished) {
         *n_kmers = b->n_out;
         return GS_OK;
@@ -3183,7 +3185,15 @@ extern "C" int gs_dbbuild_finish(gs_dbbuild *b, int64_t *n_kmers) try {
     b->d_keys = nullptr;
     b->d_vals = nullptr;
     b->cap = b->n_pairs = 0;
-    if (rc != GS_OK) return rc;
+    if (rc != GS_OK) {  // nothing half-built may be handed out later: no results, no second finish
+        hipFree(b->d_out_keys);
+        hipFree(b->d_out_vals);
+        b->d_out_keys = nullptr;
+        b->d_out_vals = nullptr;
+        b->n_out = 0;
+        b->failed = true;
+        return rc;
+    }
     b->finished = true;
     *n_kmers = b->n_out;
     return GS_OK;

@@ -1650,11 +1650,17 @@ int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool f
         return err;
     }
     err = gs_filter_text_reset(c.bloom, 1);
-    PinnedVec<uint8_t> acc;
-    PinnedVec<uint32_t> nls;
-    std::vector<uint64_t> bounds;
-    std::vector<uint8_t> cls;
-    std::vector<int64_t> head;
+    // two result sets: the records of chunk i are formatted and handed to the writers on a thread of their own while chunk i + 1 is
+    // on the device (as the four-line path does; the chunk's block goes back to its reader when the formatting is through)
+    struct Res {
+        PinnedVec<uint8_t> acc;
+        PinnedVec<uint32_t> nls;
+        std::vector<uint64_t> bounds;
+        std::vector<uint8_t> cls;
+        std::vector<int64_t> head;
+    } res[2];
+    std::future<void> formatting;
+    int64_t n_chunks = 0;
     std::vector<uint8_t> carry;
     int64_t carry_lines = 0, carry_headers = 0, carry_file_off = 0, fallback_off = -1;
     int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
@@ -1685,6 +1691,13 @@ int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool f
         } else {
             uint8_t *start = blk - carry.size();
             if (!carry.empty()) memcpy(start, carry.data(), carry.size());
+            Res &rs = res[n_chunks & 1];
+            PinnedVec<uint8_t> &acc = rs.acc;
+            PinnedVec<uint32_t> &nls = rs.nls;
+            std::vector<uint64_t> &bounds = rs.bounds;
+            std::vector<uint8_t> &cls = rs.cls;
+            std::vector<int64_t> &head = rs.head;
+            std::function<void()> format_job;
             const int64_t bytes = (int64_t)carry.size() + fc.cut;
             int64_t lines = carry_lines + sl.newlines - fc.tail_lines, records = carry_headers + fc.cut_headers, used = bytes, ticket = -1;
             if (fasta && records >= ((int64_t)1 << 24)) {  // (more records than one chunk may hold)
@@ -1727,24 +1740,29 @@ int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool f
                         break;
                     }
                     head.push_back(lines);
-                    std::vector<FilterPart> parts((size_t)c.pool.threads());
                     const bool probs = c.with_probs && !fasta;
-                    c.pool.run(records, [&](int t, int64_t lo, int64_t hi) {
-                        FilterPart &p = parts[(size_t)t];
-                        p.acc = c.acc_out.take();
-                        p.rest = c.rest_out.take();
-                        for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-                            const int64_t L = (int64_t)(bounds[(size_t)r + 1] - bounds[(size_t)r]);
-                            if (acc[(size_t)r]) {
-                                p.n_accepted++;
-                                if (c.acc_out.active())
-                                    append_general_record(p.acc, start, nl, cls.data(), head[(size_t)r], head[(size_t)r + 1], L, fasta, probs);
-                            } else if (c.rest_out.active())
-                                append_general_record(p.rest, start, nl, cls.data(), head[(size_t)r], head[(size_t)r + 1], L, fasta, probs);
-                        }
-                        p.pack(c.acc_out, c.rest_out);
-                    });
-                    write_filter_parts(c, parts);
+                    const int64_t n_rec = records;
+                    Res *rp = &rs;
+                    format_job = [&c, rp, start, nl, n_rec, fasta, probs] {
+                        std::vector<FilterPart> parts((size_t)c.pool.threads());
+                        const Res &r_ = *rp;
+                        c.pool.run(n_rec, [&](int t, int64_t lo, int64_t hi) {
+                            FilterPart &p = parts[(size_t)t];
+                            p.acc = c.acc_out.take();
+                            p.rest = c.rest_out.take();
+                            for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
+                                const int64_t L = (int64_t)(r_.bounds[(size_t)r + 1] - r_.bounds[(size_t)r]);
+                                if (r_.acc[(size_t)r]) {
+                                    p.n_accepted++;
+                                    if (c.acc_out.active())
+                                        append_general_record(p.acc, start, nl, r_.cls.data(), r_.head[(size_t)r], r_.head[(size_t)r + 1], L, fasta, probs);
+                                } else if (c.rest_out.active())
+                                    append_general_record(p.rest, start, nl, r_.cls.data(), r_.head[(size_t)r], r_.head[(size_t)r + 1], L, fasta, probs);
+                            }
+                            p.pack(c.acc_out, c.rest_out);
+                        });
+                        write_filter_parts(c, parts);
+                    };
                 }
             }
             if (fallback_off < 0) {
@@ -1758,10 +1776,26 @@ int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool f
                     carry_headers = fc.headers - fc.cut_headers;
                 }
             }
+            if (format_job) {  // (the carry has been taken out of the block: the formatting thread may hand it back)
+                if (formatting.valid()) formatting.get();  // one chunk at a time: output order, and the other result set is free again
+                n_chunks++;
+                try {
+                    formatting = std::async(std::launch::async, [format_job, &tr, i] {
+                        format_job();
+                        tr.release(i);
+                    });
+                } catch (const std::system_error &) {  // no thread to be had: on this one
+                    format_job();
+                    tr.release(i);
+                }
+                if (eof || fallback_off >= 0) break;
+                continue;
+            }
         }
         tr.release(i);
         if (eof || fallback_off >= 0) break;
     }
+    if (formatting.valid()) formatting.get();
     tr.close();
     c.t_parse += now_s() - t0;
     if (err) return err;
