@@ -360,6 +360,7 @@ def main():
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
                     help="auto: collect the roofline's counters in this run (rocprofv3 --pmc child passes); off: committed summaries")
     ap.add_argument("--pmc-seconds", type=int, default=420, help="time budget of the in-run PMC passes")
+    ap.add_argument("--pmc-save", default="", help="directory for <workload>_pmc_summary.csv files of the in-run PMC passes (the format of profiles/rNN_*_pmc_summary.csv)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -382,6 +383,16 @@ def main():
     if world == 1 and args.pmc == "auto" and default_workload:
         import torch  # noqa: F401  (pages the libraries in before the children time out on a cold box)
         pmc, pmc_note = _pmc_collect(args.pmc_seconds, args.reads)
+        if pmc is not None and args.pmc_save:
+            os.makedirs(args.pmc_save, exist_ok=True)
+            for w, vals in pmc.items():
+                if vals:
+                    with open(os.path.join(args.pmc_save, w + "_pmc_summary.csv"), "w") as f:
+                        f.write("# PMC counters of the kernel matching /%s/ per launch, mean over the full-size launches of `bench.py --pmc-child` (%d reads x 150 bp, k=31):\n"
+                                "# %s; groups: %s\n" % (PMC_KERNELS[w], args.reads, pmc_note, " | ".join(PMC_GROUPS)))
+                        f.write("counter,value_per_launch\n")
+                        for name in sorted(vals):
+                            f.write("%s,%.6g\n" % (name, vals[name]))
 
     import torch
     import torch.distributed as dist

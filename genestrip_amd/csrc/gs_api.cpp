@@ -552,7 +552,7 @@ static int tree_arrays(int32_t n_values, const int32_t *parent_vi, std::vector<i
 // ---------------------------------------------------------------------------------------------------
 // the layout built on the device (gs_layout_build.hip): same rules as the host builder below
 // ---------------------------------------------------------------------------------------------------
-enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_COUNTERS };
+enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_N_HINT, GS_LB_COUNTERS };
 extern "C" hipError_t gs_lb_perkey(const int64_t *kmers, const int32_t *vidx, int64_t n, int k, const int32_t *parent, uint32_t *e_gh, uint32_t *e_ohi,
                                    uint32_t *e_olo, uint32_t *e_vj, u64 *e_sort, u64 *e_sort2, u64 *t_key, int32_t *t_val, uint32_t *m_gh, uint32_t *h_gh, uint32_t *h_ctx,
                                    u64 *cnt, hipStream_t stream);
@@ -578,6 +578,10 @@ extern "C" hipError_t gs_lb_table(const u64 *t_key, const int32_t *t_val, int64_
 extern "C" hipError_t gs_lb_distinct(uint32_t *h_gh, uint32_t *h_alt, int64_t n_h, u64 *d_scratch, int64_t *distinct, uint32_t **sorted,
                                      hipStream_t stream);
 extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream);
+extern "C" hipError_t gs_lb_hint_collect(const uint32_t *w_valid, const uint32_t *w_gh, const u64 *w_hi, const u64 *w_lo, const uint32_t *win_bucket,
+                                         int64_t n_w, uint32_t rec_bits, int k, uint32_t *hint_gh, uint32_t *hint_cx, u64 *cnt, hipStream_t stream);
+extern "C" hipError_t gs_lb_hint(const uint32_t *hint_gh, const uint32_t *hint_cx, int64_t n, int ctx, uint32_t mgate_bits, uint32_t *mgate,
+                                 hipStream_t stream);
 
 // device scratch that goes when the build is over (or fails)
 struct DevPool {
@@ -714,6 +718,12 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "lines");
     const int64_t n_t = (int64_t)c[GS_LB_N_T], n_m = (int64_t)c[GS_LB_N_M], n_in_records = (int64_t)c[GS_LB_IN_REC];
     LB_TRY(gs_lb_more(m_gh, n_m, (uint32_t)rec_bits, d_rec, stream), "more bits");
+    // the windows in their second bucket (gs_mgate_hint); at most every window
+    uint32_t *hint_gh = pool.get<uint32_t>(std::max<size_t>(sw, 1)), *hint_cx = pool.get<uint32_t>(std::max<size_t>(sw, 1));
+    LB_TRY(pool.err, "hint buffers");
+    LB_TRY(gs_lb_hint_collect(w_valid, w_gh, w_hi, w_lo, win_bucket, (int64_t)sw, (uint32_t)rec_bits, k, hint_gh, hint_cx, cnt, stream), "hints");
+    LB_TRY(hipMemcpy(c, cnt, sizeof(c), hipMemcpyDeviceToHost), "hints");
+    const int64_t n_hint = (int64_t)c[GS_LB_N_HINT];
     LB_TRY(hipDeviceSynchronize(), "more bits");
     for (void *p : {(void *)slot, (void *)win_bucket, (void *)assign, (void *)w_hi, (void *)w_lo, (void *)w_valid, (void *)w_gh, (void *)s_gh, (void *)s_ohi,
                     (void *)s_olo, (void *)s_vj, (void *)group, (void *)m_gh})
@@ -783,6 +793,7 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     uint32_t *d_mgate = pool.get<uint32_t>((size_t)1 << mgate_bits);
     LB_TRY(pool.err, "gate");
     LB_TRY(gs_lb_gate(h_sorted, n_gate, (uint32_t)mgate_bits, d_mgate, stream), "gate");
+    LB_TRY(gs_lb_hint(hint_gh, hint_cx, n_hint, (int)mgate_ctx, (uint32_t)mgate_bits, d_mgate, stream), "gate hints");
     int32_t *d_tree = pool.get<int32_t>(4 * (size_t)n_values);
     LB_TRY(pool.err, "tree");
     LB_TRY(hipMemcpy(d_tree, parent.data(), sizeof(int32_t) * (size_t)n_values, hipMemcpyHostToDevice), "tree");
@@ -934,6 +945,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
     std::vector<int32_t> hval;
     std::vector<uint32_t> hmin;   // order hash of the minimizer(s) of every reachable key of ANY partition (k >= GS_MIN_K)
     std::vector<uint32_t> hmore;  // minimizers whose record bucket must send mismatching probes on to the table
+    std::vector<uint32_t> hint_min;  // minimizers with a window in their second candidate bucket (gs_mgate_hint)
     std::vector<RecEntry> rents;
     hkey.reserve((size_t)n);
     hval.reserve((size_t)n);
@@ -1289,12 +1301,14 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
         rec.reset(n_rec * GS_REC_WORDS);
         {
             std::vector<int64_t> cnt((size_t)n_thr, 0);
+            std::vector<std::vector<uint32_t>> hint_of((size_t)n_thr);
             parallel_slices(n_thr, (int64_t)n_rec, [&](int t, int64_t lo, int64_t hi) {
                 int64_t mine = 0;
                 for (int64_t b = lo; b < hi; b++) {
                     if (b + 8 < hi && slot[(size_t)b + 8] != EMPTY) __builtin_prefetch(order[slot[(size_t)b + 8]]);
                     if (slot[(size_t)b] == EMPTY) continue;
                     const Win *W = order[slot[(size_t)b]];
+                    if ((uint32_t)b != gs_rec_bucket(W->gh, (uint32_t)rec_bits, 0)) hint_of[(size_t)t].push_back(W->gh);  // gs_mgate_hint
                     u64 *rp = rec.data() + (size_t)b * GS_REC_WORDS;
                     rp[0] = W->whi;
                     rp[1] = W->wlo | ((u64)W->valid << GS_REC_WIN_BITS);
@@ -1307,6 +1321,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 cnt[(size_t)t] = mine;
             });
             for (int64_t x : cnt) n_in_records += x;
+            for (const auto &h : hint_of) hint_min.insert(hint_min.end(), h.begin(), h.end());
         }
         for (const Win *W : homeless) {  // their k-mers become table keys, reachable through both buckets' `more` bit
             for (uint32_t m = W->valid; m; m &= m - 1) {
@@ -1400,6 +1415,7 @@ static int db_create_impl(gs_db **out, int device, int k, int64_t n, const int64
                 if ((__atomic_load_n(w, __ATOMIC_RELAXED) & bits) != bits) __atomic_fetch_or(w, bits, __ATOMIC_RELAXED);
             }
         });
+        for (uint32_t h : hint_min) mgate.data()[gs_mgate_word(h, (uint32_t)mgate_bits)] |= gs_mgate_hint(h);  // windows in their second bucket
     }
     trace.mark("gates");
     StoreImage im{};
@@ -1439,7 +1455,7 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE7"
+    char magic[8];  // "GSSTORE8"
     gs_db_info info;
     uint32_t bucket_bits, vbits;  // (bit 31 of vbits: the minimizer gate is keyed by gs_gate_ctx_key, GsDbDev::mgate_ctx)
     uint64_t gate_words;
@@ -1595,7 +1611,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     if (db->striped()) return fail(GS_E_UNSUPPORTED, "a striped store is not saved as such: save the store built by gs_db_create");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE7", 8);
+    memcpy(h.magic, "GSSTORE8", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
@@ -1681,7 +1697,7 @@ static int db_load_impl(gs_db **out, int device, const char *path, int stripes, 
         file_mgate_ctx = h.vbits >> 31;
         h.vbits &= 0x7fffffffu;
     }
-    if (!got_header || memcmp(h.magic, "GSSTORE7", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+    if (!got_header || memcmp(h.magic, "GSSTORE8", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
         h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
         h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30) || h.rec_buckets > ((uint64_t)1 << 29)) {
         fclose(f);

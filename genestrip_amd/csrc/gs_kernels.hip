@@ -439,6 +439,12 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         int j[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi[s], rlo[s], k, mp[s], gh[s], ohi[s], olo[s], j[s]);
+        // Lanes that look into their minimizer's second bucket as well.  Every store carries the hint bits (gs_mgate_hint); they
+        // are USED where a record line is dear -- a context-keyed store (hundreds of millions of k-mers, lines from HBM) and a
+        // striped one (lines over xGMI) --: on a store whose records sit in the caches the second line costs less than the
+        // test (measured on configs[1]: 6.74 ms without, 6.94 ms with it; 47 M store 8.66 / 8.68; 473 M store 15.39 / 15.03).
+        const bool use_hint = STRIPED || CTX == 1 || (CTX == 2 && db.mgate_ctx);
+        u64 two[2] = {~0ULL, ~0ULL};
         if ((GS_ABLATE & 4) == 0) {
             // the gate words of both sub-rounds are requested together (lanes without a live k-mer read word 0): one round
             // trip, no exec-mask regions
@@ -452,6 +458,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             for (int s = 0; s < 2; s++) {
                 const uint32_t bits = gs_mgate_bits(gk[s]);
                 act[s] &= __ballot((gw[s] & bits) == bits);  // no false negatives
+                if (use_hint) two[s] = __ballot((gw[s] & gs_mgate_hint(gk[s])) != 0u);  // a window of this key may sit in the second bucket
             }
             GS_STAMP(4, gw[0] ^ gw[1])
         }
@@ -462,11 +469,12 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             return;
         }
         if (STRIPED || db.rec != nullptr) {
-            // ---- super-k-mer records: both candidate buckets of the minimizer at once -- per bucket one 16-byte load of
-            // the window planes + the 8-byte word that holds this offset's value; the loads of BOTH sub-rounds are issued
-            // before the first compare (one round trip), and the compares are straight-line code (bitwise, no short-circuit
-            // branches: every branch is an exec-mask save / restore on the scalar unit, which this kernel keeps as busy as the
-            // vector unit)
+            // ---- super-k-mer records: per candidate bucket of the minimizer one 16-byte load of the window planes + the
+            // 8-byte word that holds this offset's value.  The first bucket always; the second one only where the gate word
+            // carries the key's hint bit (two windows in three sit in their first bucket: a third fewer line requests, which
+            // is what bounds a store that does not fit the caches).  Both loads of a sub-round are in flight together and the
+            // compares are straight-line code (bitwise, no short-circuit branches: every branch is an exec-mask save /
+            // restore on the scalar unit, which this kernel keeps as busy as the vector unit)
             if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
 #pragma unroll
             for (int s = 0; s < 2; s++) {
@@ -475,16 +483,17 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     const uint32_t jj = (uint32_t)j[s];
                     const int jw = (int)(jj * 11u) >> 5;  // j / 3 for j <= 16
                     const uint32_t b0 = gs_rec_bucket(gh[s], db.rec_bits, 0), b1 = gs_rec_bucket(gh[s], db.rec_bits, 1);
-                    const u64 *r0, *r1;
-                    if (STRIPED) {  // the stripe's (biased) base pointer from the wave's copy of the table, behind the hash rows
-                        r0 = gs_rec_stripe(db, wave_g, b0) + (u64)b0 * GS_REC_WORDS;
-                        r1 = gs_rec_stripe(db, wave_g, b1) + (u64)b1 * GS_REC_WORDS;
-                    } else {
-                        r0 = db.rec + (u64)b0 * GS_REC_WORDS;
-                        r1 = db.rec + (u64)b1 * GS_REC_WORDS;
+                    // the stripe's (biased) base pointer from the wave's copy of the table, behind the hash rows
+                    const u64 *r0 = (STRIPED ? gs_rec_stripe(db, wave_g, b0) : db.rec) + (u64)b0 * GS_REC_WORDS;
+                    gs_u64x2 A1 = {0, 0};  // (no valid bit: matches nothing)
+                    u64 V1 = 0;
+                    if (!use_hint || GS_ACT(two[s])) {
+                        const u64 *r1 = (STRIPED ? gs_rec_stripe(db, wave_g, b1) : db.rec) + (u64)b1 * GS_REC_WORDS;
+                        A1 = *reinterpret_cast<const gs_u64x2 *>(r1);
+                        V1 = r1[2 + jw];
                     }
-                    const gs_u64x2 A0 = *reinterpret_cast<const gs_u64x2 *>(r0), A1 = *reinterpret_cast<const gs_u64x2 *>(r1);
-                    const u64 V0 = r0[2 + jw], V1 = r1[2 + jw];
+                    const gs_u64x2 A0 = *reinterpret_cast<const gs_u64x2 *>(r0);
+                    const u64 V0 = r0[2 + jw];
                     // window bits [j, j + k) of a plane: j + k <= 2k - 15, so the seen / valid bits above the window stay out
                     // of the low k bits of the shifted word; one 32-bit funnel shift (j <= 16) per plane
                     const uint32_t x0 = __builtin_amdgcn_alignbit((uint32_t)(A0.x >> 32), (uint32_t)A0.x, jj);

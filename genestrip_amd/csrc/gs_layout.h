@@ -174,6 +174,18 @@ GS_HD uint32_t gs_mgate_bits(uint32_t m) {
     const uint32_t y = m * 0xC2B2AE3Du;  // a second product: independent of the word index at any gate size
     return (1u << (y >> 27)) | (1u << ((y >> 22) & 31));
 }
+// A third bit of the same word, the "second bucket" hint: set for a gate key iff a window of its minimizer was placed in the
+// minimizer's SECOND candidate bucket (gs_rec_bucket(gh, 1)).  A probe whose hint is clear loads the first bucket's line only --
+// cuckoo placement tries the first choice first, so about two windows in three sit there --; a hint set by a neighbour of the
+// word costs the second line, nothing else.  (Windows without a bucket need no hint: their k-mers are in the table, which the
+// `more` bit of EITHER bucket line announces.)
+GS_HD uint32_t gs_mgate_hint(uint32_t m) { return 1u << (((m * 0xC2B2AE3Du) >> 17) & 31); }
+// the two context keys of a window (gs_gate_ctx_key of its k-mers with j >= 4 / j <= 3) from the window planes; c = k - 15
+GS_HD uint32_t gs_gate_ctx_key_raw(uint32_t gh, uint32_t ctx) { return gh ^ ((ctx + 1u) * 0x9E3779B1u); }
+GS_HD uint32_t gs_window_ctx(uint64_t w_hi, uint64_t w_lo, int k, bool behind) {
+    const int pos = behind ? (k - GS_MIN_L) + GS_MIN_L : (k - GS_MIN_L) - 4;
+    return ((uint32_t)(w_hi >> pos) & 15u) | (((uint32_t)(w_lo >> pos) & 15u) << 4) | (behind ? 256u : 0u);
+}
 
 // Context-keyed gate (big stores).  The 15-mer minimizer space is ~60 M; a store of several hundred million k-mers uses most of
 // it (473 M k-mers: 40 M distinct minimizers), so that a filter over the minimizers alone lets 68 % of the positions of a read
@@ -190,7 +202,7 @@ GS_HD uint32_t gs_gate_ctx_key(uint32_t gh, uint32_t ohi, uint32_t olo, int j, i
     const bool behind = j >= 4;
     const int pos = behind ? m + GS_MIN_L : m - 4;
     const uint32_t ctx = ((ohi >> pos) & 15u) | (((olo >> pos) & 15u) << 4) | (behind ? 256u : 0u);
-    return gh ^ ((ctx + 1u) * 0x9E3779B1u);
+    return gs_gate_ctx_key_raw(gh, ctx);
 }
 
 struct GsDbDev {

@@ -27,7 +27,7 @@ typedef unsigned long long u64;
 #define GS_LB_EMPTY 0xffffffffu
 #define GS_LB_MAXWIN 8  // windows a minimizer's entries are clustered into; what fits none of them goes to the table
 
-enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_COUNTERS };
+enum { GS_LB_N_E = 0, GS_LB_N_T, GS_LB_N_M, GS_LB_N_H, GS_LB_IN_REC, GS_LB_OVERFLOW, GS_LB_MAX_DISP, GS_LB_N_WIN, GS_LB_N_CTX, GS_LB_N_HINT, GS_LB_COUNTERS };
 
 // every lane of the wave calls this; returns the slot of the lanes with `have` in a list that grows by one atomic per wave
 __device__ __forceinline__ u64 gs_lb_append(bool have, u64 *counter, int lane) {
@@ -416,6 +416,41 @@ __global__ __launch_bounds__(256) void gs_lb_gate_kernel(const uint32_t *h_gh, i
     }
 }
 
+// windows that sit in their minimizer's SECOND candidate bucket: (minimizer, the window's two context values) on the hint list
+__global__ __launch_bounds__(256) void gs_lb_hint_collect_kernel(const uint32_t *w_valid, const uint32_t *w_gh, const u64 *w_hi, const u64 *w_lo,
+                                                                 const uint32_t *win_bucket, int64_t n_w, uint32_t rec_bits, int k, uint32_t *hint_gh,
+                                                                 uint32_t *hint_cx, u64 *cnt) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; i0 < n_w; i0 += stride) {
+        const int64_t w = i0 + lane;
+        bool second = false;
+        if (w < n_w && w_valid[w] != 0) {
+            const uint32_t bkt = win_bucket[w];
+            second = bkt != GS_LB_EMPTY && bkt != gs_rec_bucket(w_gh[w], rec_bits, 0);
+        }
+        const u64 at = gs_lb_append(second, cnt + GS_LB_N_HINT, lane);
+        if (second) {
+            hint_gh[at] = w_gh[w];
+            hint_cx[at] = k >= GS_CTX_MIN_K ? gs_window_ctx(w_hi[w], w_lo[w], k, true) | (gs_window_ctx(w_hi[w], w_lo[w], k, false) << 16) : 0u;
+        }
+    }
+}
+
+// ... and their hint bits into the finished gate (keyed by the minimizer, or by both context keys of the window)
+__global__ __launch_bounds__(256) void gs_lb_hint_kernel(const uint32_t *hint_gh, const uint32_t *hint_cx, int64_t n, int ctx, uint32_t mgate_bits,
+                                                         uint32_t *mgate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t gh = hint_gh[i];
+        for (int side = 0; side < (ctx ? 2 : 1); side++) {
+            const uint32_t key = ctx ? gs_gate_ctx_key_raw(gh, (hint_cx[i] >> (16 * side)) & 0xffffu) : gh;
+            uint32_t *w = mgate + gs_mgate_word(key, mgate_bits);
+            const uint32_t bit = gs_mgate_hint(key);
+            if ((*w & bit) == 0) atomicOr(w, bit);
+        }
+    }
+}
+
 // number of distinct values in a SORTED array
 __global__ __launch_bounds__(256) void gs_lb_distinct_kernel(const uint32_t *a, int64_t n, u64 *out) {
     u64 mine = 0;
@@ -685,6 +720,18 @@ extern "C" hipError_t gs_lb_distinct(uint32_t *h_gh, uint32_t *h_alt, int64_t n_
     *distinct = (int64_t)d;
     *sorted = dk.current();
     return e;
+}
+
+extern "C" hipError_t gs_lb_hint_collect(const uint32_t *w_valid, const uint32_t *w_gh, const u64 *w_hi, const u64 *w_lo, const uint32_t *win_bucket,
+                                         int64_t n_w, uint32_t rec_bits, int k, uint32_t *hint_gh, uint32_t *hint_cx, u64 *cnt, hipStream_t stream) {
+    LB_LAUNCH(gs_lb_hint_collect_kernel, n_w, w_valid, w_gh, w_hi, w_lo, win_bucket, n_w, rec_bits, k, hint_gh, hint_cx, cnt);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t gs_lb_hint(const uint32_t *hint_gh, const uint32_t *hint_cx, int64_t n, int ctx, uint32_t mgate_bits, uint32_t *mgate,
+                                 hipStream_t stream) {
+    LB_LAUNCH(gs_lb_hint_kernel, n, hint_gh, hint_cx, n, ctx, mgate_bits, mgate);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream) {
