@@ -2240,7 +2240,8 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     // Counters that do not fit the LDS are global atomics: 12 bytes x 8 per tax id in three cache lines that every CU
     // hits.  Measured on the 47 M-k-mer / 526-value store: they cost 8 of 16.7 ms on reads from the store; spread over
     // 16 copies (one per group of workgroups) the lines are 16 times colder.
-    if (nv > GS_NV_LDS) {
+    const char *force_global = getenv("GS_FORCE_GLOBAL_STATS");  // (developer knob, see gs_launch_match)
+    if (nv > GS_NV_LDS || (force_global != nullptr && atoi(force_global) != 0)) {
         int copies = 16;
         if (const char *ev = getenv("GS_STAT_COPIES")) copies = std::max(1, std::min(64, atoi(ev)));
         while (copies > 1 && (size_t)copies * nv * 96 > ((size_t)64 << 20)) copies /= 2;

@@ -6,16 +6,24 @@
 // over PCIe (a fifth of the text), and the members are inflated side by side on the GPU straight into the text buffer the record
 // scan reads (gs_match_submit_text with GS_MEM_DEVICE): ONE WAVE PER MEMBER.
 //
-// A wave decodes its member in lock step -- every lane holds the same bit buffer and walks the same Huffman tables (LDS) --, which
-// costs nothing (a wave instruction is a wave instruction) and lets the lanes share the work that is parallel:
-//   * the compressed bytes are fetched 256 at a time, lane i holding dword i of the piece; the bit buffer is refilled with a
-//     v_readlane from that register: no memory latency on the decode chain (the next piece is already in a second register);
-//   * literals are collected in a register, lane j holding the j-th pending byte, and leave as one coalesced store of up to 64;
-//   * a match is copied by all lanes at once, out[p + i] = out[p - dist + i % dist] (every source byte lies in front of p);
-//   * the Huffman tables of a dynamic block are built with the lanes filling the replicated entries of each code in parallel.
-// The text written earlier is read back through the same CU's L1 / L2; a wave waits for its own stores only when a match reaches
-// into the bytes stored since its last wait.  Behind the last block: the member's ISIZE must be met exactly, and its CRC-32 is
-// recomputed from the text (64 lanes x slicing-by-1 over equal slices, combined with x^(8 n) mod P).
+// Block headers and Huffman tables are handled in lock step (every lane holds the same bit buffer; the replicated entries of a
+// code are filled by the lanes in parallel).  The SYMBOLS of a block are decoded 64 bit offsets at a time (gi_token): lane l
+// decodes the complete token -- literal, or length + extra bits + distance + extra bits, two table reads each from LDS -- that
+// WOULD start l bits behind the reader; a short scalar walk (offset += token bits, one v_readlane per token) then picks the
+// lanes that really are token starts, a prefix sum over their output lengths gives every token its place in the text, and
+//   * the literals of the group leave in one store,
+//   * the short matches whose source lies in front of the group are copied side by side, one lane per match,
+//   * the remaining matches (runs, overlapping or long ones) are copied in order by all lanes at once,
+//     out[p + i] = out[p - dist + i % dist].
+// The first version decoded one symbol per walk of the scalar unit: 19 scalar instructions per byte of text, the CU's one scalar
+// issue port 80 % busy (rocprofv3 --pmc) -- the port, not memory, was the limit.  Here the per-token work is vector work.
+// A block whose code does not fit the tables takes the one-symbol-at-a-time loop with the canonical decoder (gi_slow).
+// The last GI_RING bytes of a wave's text are kept in LDS as well (a ring): a match whose distance fits the ring -- the header and
+// quality lines of FASTQ always, and whatever a fast compression level finds in the bases -- is copied from there, a hundred
+// cycles instead of a trip through L2 behind the wave's own stores (which was 90 % of the kernel's time).  A longer distance reads
+// the text back through the same CU's L1 / L2, and the wave waits for its own stores only when such a match reaches into the
+// bytes stored since its last wait.  Behind the last block: the member's ISIZE must be met exactly, and its CRC-32 is recomputed
+// from the text (64 lanes x slicing-by-4 over equal slices, tables in LDS, combined with x^(8 n) mod P).
 //
 // gs_inflater_feed turns a run of members into "whole four-line records": the text is appended behind the tail the previous call
 // left over, a second pair of kernels counts the newlines and finds the last one that closes a record (count a multiple of four),
@@ -38,6 +46,11 @@ typedef unsigned long long u64;
 #define GI_DROOT 8                 // root bits of the distance table
 #define GI_LSIZE 864               // entries: 2^9 root + sub-tables (zlib's proven bound for 286 symbols, root 9, 15 bits: 852)
 #define GI_DSIZE 592               // 2^8 root + sub-tables; a code that needs more is decoded the canonical way (gi_slow)
+#ifndef GI_RING
+#define GI_RING 2048               // bytes of recent text per wave in LDS (a power of two); with it a wave takes 8.6 KB: 16 waves per CU
+#endif
+#define GI_PAR_MAX 16u             // matches of at most this length are copied one lane per match (gi_inflate_kernel)
+#define GI_ON(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 #define GI_LDESC ((GI_LSIZE - 512) / 2)
 #define GI_DDESC ((GI_DSIZE - 256) / 2)
 
@@ -56,17 +69,18 @@ struct GiCode {            // what the canonical decoder needs (and the table bu
 };
 
 struct GiWave {
-    uint32_t lroot[1 << GI_LROOT];  // the literal / length root table again, 32-bit entries that can hold TWO literals (gi_pair_literals)
+    uint32_t cbuf[128];      // two 256-byte pieces of the compressed payload (piece j in half j & 1) for the token decoder
     uint16_t ltab[GI_LSIZE];
     uint16_t dtab[GI_DSIZE];
     uint16_t ldesc[GI_LDESC], ddesc[GI_DDESC];
     uint16_t lwork[288], dwork[32];
     uint16_t lcount[16], dcount[16], offs[16];
     uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+    uint8_t ring[GI_RING];   // text byte p at ring[p % GI_RING]
 };
 
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-__constant__ uint32_t gi_crc_table[256];
+__constant__ uint32_t gi_crc_table[4 * 256];  // slicing-by-4 tables of the reflected CRC-32
 
 __device__ __forceinline__ int gi_lane() { return (int)__lane_id(); }
 __device__ __forceinline__ uint32_t gi_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -157,6 +171,12 @@ struct GiBits {
         taken = piece_at / 4;
         refill(lane);
         const int skip = 8 * (int)(at & 3u);
+        bb >>= skip;
+        bc -= skip;
+    }
+    __device__ __forceinline__ void seek_bit(u64 bit, int lane) {  // continue at bit `bit` of the payload
+        seek((uint32_t)(bit >> 3), lane);
+        const int skip = (int)(bit & 7u);
         bb >>= skip;
         bc -= skip;
     }
@@ -281,31 +301,6 @@ __device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab,
     return true;
 }
 
-// The hot loop's first lookup goes to `lroot`: entry = bits 0-3 code bits, bits 4-6 kind, bits 8-15 value (literal, length symbol,
-// sub-table number), and -- kind GI_LIT2 -- a SECOND literal in bits 16-23 when the bits behind a short literal code decode to
-// another literal inside the same root index (sequence and quality lines are runs of literals: two per table walk).  The decode
-// loop runs on the scalar unit, which the four SIMDs of a CU share: every symbol it does not have to walk for counts twice.
-#define GI_LIT2 6
-__device__ void gi_pair_literals(GiWave &w, int lane) {
-    uint32_t mine[(1 << GI_LROOT) / 64];
-#pragma unroll
-    for (int q = 0; q < (1 << GI_LROOT) / 64; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * (uint32_t)q;
-        const uint32_t e = w.ltab[i];
-        const uint32_t bits = e & 15u, kind = (e >> 4) & 7u, val = e >> 7;
-        uint32_t r = bits | (kind << 4) | ((val & 0xffu) << 8);
-        if (kind == GI_LIT && bits < GI_LROOT) {
-            const uint32_t e2 = w.ltab[i >> bits];  // (only its low GI_LROOT - bits index bits are real: usable iff its code is that short)
-            const uint32_t bits2 = e2 & 15u;
-            if (((e2 >> 4) & 7u) == GI_LIT && bits2 != 0 && bits + bits2 <= GI_LROOT) r = (bits + bits2) | ((uint32_t)GI_LIT2 << 4) | ((val & 0xffu) << 8) | (((e2 >> 7) & 0xffu) << 16);
-        }
-        mine[q] = r;
-    }
-#pragma unroll
-    for (int q = 0; q < (1 << GI_LROOT) / 64; q++) w.lroot[lane + 64 * q] = mine[q];
-    gi_lds_sync();
-}
-
 // fast path: (kind << 16 | value << 4 | bits) of the next code; bits = 0: no such code
 __device__ __forceinline__ uint32_t gi_lookup(const uint16_t *tab, const uint16_t *desc, int root, const GiBits &b) {
     uint32_t e = gi_uni(tab[b.peek(root)]);
@@ -344,6 +339,58 @@ __device__ uint32_t gi_slow(const uint16_t *count, const uint16_t *work, int typ
     return 0;
 }
 
+// ---- the token decoder: what starts at this lane's bit offset (w0 = the next 32 bits, w1 = the 32 behind them)
+//   kind: GI_LIT / GI_LEN / GI_EOB / GI_BAD; t: bits of the whole token (a match: length code + extra + distance code + extra,
+//   at most 48); olen: bytes of text it produces; dist: the distance of a match; lit: the byte of a literal
+__device__ __forceinline__ void gi_token(const GiWave &w, uint32_t w0, uint32_t w1, uint32_t &kind, uint32_t &t, uint32_t &olen, uint32_t &dist,
+                                         uint32_t &lit) {
+    const u64 bits = ((u64)w1 << 32) | w0;
+    uint32_t e = w.ltab[w0 & ((1u << GI_LROOT) - 1u)];
+    uint32_t n = e & 15u;
+    kind = (e >> 4) & 7u;
+    if (kind == GI_SUB) {
+        const uint32_t d = w.ldesc[e >> 7];
+        e = w.ltab[(d >> 3) + ((w0 >> GI_LROOT) & ((1u << (d & 7u)) - 1u))];
+        n = (e & 15u) ? (e & 15u) + GI_LROOT : 0u;
+        kind = (e >> 4) & 7u;
+    }
+    const uint32_t val = e >> 7;
+    if (n == 0 || (kind != GI_LIT && kind != GI_LEN && kind != GI_EOB)) kind = GI_BAD;
+    lit = val & 0xffu;
+    t = n;
+    olen = kind == GI_LIT ? 1u : 0u;
+    dist = 0;
+    if (kind == GI_LEN) {
+        uint32_t lbase, lextra, dbase, dextra;
+        gi_len_sym(val & 31u, lbase, lextra);
+        olen = lbase + ((uint32_t)(bits >> n) & ((1u << lextra) - 1u));
+        const uint32_t u = (uint32_t)(bits >> (n + lextra));  // (n + lextra <= 20: 44 bits are left, a distance takes at most 28)
+        uint32_t de = w.dtab[u & ((1u << GI_DROOT) - 1u)];
+        uint32_t dn = de & 15u, dk = (de >> 4) & 7u;
+        if (dk == GI_SUB) {
+            const uint32_t d = w.ddesc[de >> 7];
+            de = w.dtab[(d >> 3) + ((u >> GI_DROOT) & ((1u << (d & 7u)) - 1u))];
+            dn = (de & 15u) ? (de & 15u) + GI_DROOT : 0u;
+            dk = (de >> 4) & 7u;
+        }
+        gi_dist_sym((de >> 7) & 31u, dbase, dextra);
+        dist = dbase + ((u >> dn) & ((1u << dextra) - 1u));
+        t = n + lextra + dn + dextra;
+        if (dk != GI_DIST || dn == 0) kind = GI_BAD;
+    }
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: four shifts inside the rows of 16, two row broadcasts)
+__device__ __forceinline__ uint32_t gi_scan_incl(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // x^(8 n) mod P (reflected CRC-32 polynomial arithmetic), and a * b mod P
 __device__ uint32_t gi_gf_mul(uint32_t a, uint32_t b) {
     uint32_t p = 0;
@@ -373,15 +420,20 @@ struct GiBlock {
     uint32_t pad;
 };
 
-__global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
                                                                     int32_t *status, int force_slow, unsigned long long *next_member) {
     __shared__ GiWave s_w[GI_WAVES];
+    __shared__ uint32_t s_crc[4 * 256];
+    for (int i = (int)threadIdx.x; i < 4 * 256; i += 64 * GI_WAVES) s_crc[i] = gi_crc_table[i];
+    __syncthreads();
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
+    constexpr uint32_t RM = GI_RING - 1u;
     // the waves draw members from a shared counter: a member takes 5 .. 15 ms of a wave, a fixed assignment would leave the waves
     // with one member fewer idle for that long
     for (;;) {
+        __builtin_amdgcn_wave_barrier();
         unsigned long long take = 0;
         if (lane == 0) take = atomicAdd(next_member, 1ULL);
         const int64_t bi = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
@@ -400,7 +452,10 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
         auto flush = [&]() {
             if (npend) {
                 const uint32_t at = pos - npend + (uint32_t)lane;
-                if ((uint32_t)lane < npend && at < cap) dst[at] = (uint8_t)pbyte;  // (never beyond the member's own text)
+                if ((uint32_t)lane < npend && at < cap) {  // (never beyond the member's own text)
+                    dst[at] = (uint8_t)pbyte;
+                    w.ring[at & RM] = (uint8_t)pbyte;
+                }
                 npend = 0;
             }
         };
@@ -427,7 +482,11 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     err = GI_E_INPUT;
                     break;
                 }
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = b.in[src + i];
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                    const uint8_t c = b.in[src + i];
+                    dst[pos + i] = c;
+                    if (len - i <= GI_RING) w.ring[(pos + i) & RM] = c;  // (the last GI_RING bytes of the block)
+                }
                 b.seek(src + len, lane);
                 pos += len;
                 continue;
@@ -528,10 +587,140 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                     break;
                 }
             }
-            if (lfast) gi_pair_literals(w, lane);
-            if (force_slow) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
-            // ---- the symbols of the block.  Literals wait in `pbyte` (lane j: the j-th pending byte) and are stored 62..64 at a time;
-            // whether they fit the member's announced size is checked when they are stored (flush), not per literal.
+            if (force_slow & 1) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
+            if (lfast && dfast) {
+                // ---- the symbols of the block, 64 bit offsets at a time (see the head of the file)
+                flush();
+                u64 P = b.consumed();                         // the reader's position, bits from the start of the payload
+                const u64 plimit = (u64)blk.in_len * 8u;      // a token that starts behind it: the stream has run off its payload
+                uint32_t k = (uint32_t)(P >> 11);             // pieces k and k + 1 are in w.cbuf, piece k + 2 is on its way
+                {
+                    const uint32_t p0 = b.load_piece(k * 256u, lane), p1 = b.load_piece((k + 1u) * 256u, lane);
+                    w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = p0;
+                    w.cbuf[((k + 1u) & 1u) * 64u + (uint32_t)lane] = p1;
+                }
+                uint32_t ahead = b.load_piece((k + 2u) * 256u, lane);
+                gi_lds_sync();
+                bool eob = false;
+                uint32_t guard = 0;
+                while (!eob) {
+                    if (P > plimit || ++guard > 8u * blk.in_len + 64u) {  // (every group takes at least one bit: the second test cannot fire)
+                        err = GI_E_INPUT;
+                        break;
+                    }
+                    if ((uint32_t)(P >> 11) != k) {  // one piece further: piece k + 2 takes the place of piece k
+                        w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = ahead;
+                        k++;
+                        ahead = b.load_piece((k + 2u) * 256u, lane);
+                        gi_lds_sync();
+                    }
+                    const uint32_t q = (uint32_t)(P & 4095u) + (uint32_t)lane;  // this lane's bit offset inside the 512 staged bytes
+                    const uint32_t d0 = q >> 5, sh = q & 31u;
+                    const uint32_t x0 = w.cbuf[d0 & 127u], x1 = w.cbuf[(d0 + 1u) & 127u], x2 = w.cbuf[(d0 + 2u) & 127u];
+                    uint32_t kind, t, olen, dist, lit;
+                    gi_token(w, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), kind, t, olen, dist, lit);
+                    // which lanes are token starts: lane 0 is one, and every token names the next
+                    const bool stop = kind == GI_EOB || kind == GI_BAD;
+                    const uint32_t step = stop ? 64u : t;  // (an end marker ends the walk)
+                    u64 chain = 0;
+                    uint32_t at = 0;
+                    for (int hop = 0; hop < 64 && at < 64u; hop++) {  // (a token has at least one bit)
+                        chain |= 1ULL << at;
+                        at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
+                    }
+                    uint32_t adv = at;  // bits of this group
+                    if ((__ballot(stop) & chain) != 0) {  // the chain's last token is an end marker
+                        const int el = 63 - __builtin_clzll(chain);
+                        if ((uint32_t)__builtin_amdgcn_readlane((int)kind, el) == GI_BAD) {
+                            err = GI_E_CODE;
+                            break;
+                        }
+                        eob = true;
+                        adv = (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)t, el);
+                    }
+                    const bool on = GI_ON(chain);
+                    const uint32_t ol = on ? olen : 0u;
+                    const uint32_t incl = gi_scan_incl(ol);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    const uint32_t mpos = pos + (incl - ol);  // where this lane's token writes
+                    if (pos + total > cap) {
+                        err = GI_E_OVERRUN;
+                        break;
+                    }
+                    const bool is_match = on && kind == GI_LEN;
+                    const u64 mm = __ballot(is_match);
+                    if (mm != 0 && __ballot(is_match && dist > mpos) != 0) {
+                        err = GI_E_DIST;
+                        break;
+                    }
+                    if (on && kind == GI_LIT) {
+                        dst[mpos] = (uint8_t)lit;
+                        w.ring[mpos & RM] = (uint8_t)lit;
+                    }
+                    if (mm != 0) {
+                        gi_lds_sync();
+                        // Nothing this group writes lands on a ring slot whose old byte a match with dist + total + 64 <= GI_RING
+                        // still reads (the slot of byte p is reused by byte p + GI_RING).
+                        const uint32_t from = mpos - dist;
+                        // side by side: short, not overlapping, source in the ring and in front of the group's first byte
+                        const bool par = is_match && olen <= GI_PAR_MAX && dist >= olen && dist + total + 64u <= GI_RING && (mpos - pos) + olen <= dist;
+                        const u64 pm = __ballot(par);
+                        if (pm != 0) {
+                            for (uint32_t i = 0; i < GI_PAR_MAX; i++) {
+                                const bool go = par && i < olen;
+                                if (__ballot(go) == 0) break;
+                                if (go) {
+                                    const uint8_t c = w.ring[(from + i) & RM];
+                                    dst[mpos + i] = c;
+                                    w.ring[(mpos + i) & RM] = c;
+                                }
+                            }
+                            gi_lds_sync();
+                        }
+                        for (u64 sm = mm & ~pm; sm != 0; sm &= sm - 1) {  // the others in order, all lanes on one match
+                            const int ml = __builtin_ctzll(sm);
+                            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)olen, ml), dd = (uint32_t)__builtin_amdgcn_readlane((int)dist, ml);
+                            const uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)mpos, ml), fr = mp - dd;
+                            if (dd + total + 64u <= GI_RING) {
+                                if (dd == 1) {  // a run of one byte
+                                    const uint8_t c = w.ring[fr & RM];
+                                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                        dst[mp + i] = c;
+                                        w.ring[(mp + i) & RM] = c;
+                                    }
+                                } else {
+                                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                        const uint8_t c = w.ring[(fr + (dd >= len ? i : i % dd)) & RM];
+                                        dst[mp + i] = c;
+                                        w.ring[(mp + i) & RM] = c;
+                                    }
+                                }
+                                gi_lds_sync();
+                            } else {
+                                if (fr + (len < dd ? len : dd) > visible) {  // the source reaches into bytes this wave stored since its last wait
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                    visible = mp;
+                                }
+                                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                    const uint8_t c = dst[fr + (dd >= len ? i : i % dd)];
+                                    dst[mp + i] = c;
+                                    w.ring[(mp + i) & RM] = c;
+                                }
+                                gi_lds_sync();
+                            }
+                        }
+                    }
+                    pos += total;
+                    P += adv;
+                }
+                if (err != GI_OK) break;
+                b.seek_bit(P, lane);
+                continue;  // the next block
+            }
+            // ---- one symbol at a time (a code that did not fit the tables; GS_INFLATE_FORCE_SLOW).  Literals wait in `pbyte` (lane j:
+            // the j-th pending byte) and are stored 62..64 at a time; whether they fit the member's announced size is checked when
+            // they are stored (flush), not per literal.
             const uint32_t tlimit = blk.in_len / 4u + 4u;  // dwords the reader may take before the stream has run off its payload
             for (;;) {
                 if (b.bc <= 32) {
@@ -541,34 +730,7 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                         break;
                     }
                 }
-                uint32_t e;
-                if (lfast) {
-                    const uint32_t r = gi_uni(w.lroot[b.peek(GI_LROOT)]);
-                    const uint32_t rk = (r >> 4) & 7u;
-                    if (rk == GI_LIT2) {  // two literals in one walk
-                        b.drop((int)(r & 15u));
-                        if ((uint32_t)lane == npend) pbyte = (r >> 8) & 0xffu;
-                        if ((uint32_t)lane == npend + 1u) pbyte = (r >> 16) & 0xffu;
-                        npend += 2;
-                        pos += 2;
-                        if (npend >= 63) {
-                            if (pos > cap) {
-                                err = GI_E_OVERRUN;
-                                break;
-                            }
-                            flush();
-                        }
-                        continue;
-                    }
-                    if (rk == GI_SUB) {
-                        const uint32_t d = gi_uni(w.ldesc[(r >> 8) & 0xffu]);
-                        const uint32_t e2 = gi_uni(w.ltab[(d >> 3) + (((uint32_t)(b.bb >> GI_LROOT)) & ((1u << (d & 7u)) - 1u))]);
-                        const uint32_t bits = (e2 & 15u) ? (e2 & 15u) + GI_LROOT : 0u;
-                        e = (((e2 >> 4) & 7u) << 16) | ((e2 >> 7) << 4) | bits;
-                    } else
-                        e = (rk << 16) | (((r >> 8) & 0xffu) << 4) | (r & 15u);
-                } else
-                    e = gi_slow(w.lcount, w.lwork, 0, b);
+                const uint32_t e = lfast ? gi_lookup(w.ltab, w.ldesc, GI_LROOT, b) : gi_slow(w.lcount, w.lwork, 0, b);
                 const uint32_t kind = e >> 16;
                 if ((e & 15u) == 0) {
                     err = GI_E_CODE;
@@ -615,18 +777,42 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
                 }
                 flush();
                 const uint32_t from = pos - dist;
-                if (from + (len < dist ? len : dist) > visible) {  // the source reaches into bytes this wave stored since its last wait
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    visible = pos;
-                }
-                if (dist >= len) {  // the usual case: source and destination do not overlap
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + i];
-                } else if (dist == 1) {  // a run of one byte
-                    const uint8_t c = dst[from];
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = c;
-                } else {  // the pattern of `dist` bytes repeats
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = dst[from + i % dist];
+                if (dist <= GI_RING - 64u) {
+                    // the source lies in the ring (every source byte is in front of `pos`, and a byte is overwritten GI_RING
+                    // bytes later: not by this copy).  LDS operations of a wave execute in order: the barrier is for the compiler.
+                    gi_lds_sync();
+                    if (dist >= len) {  // the usual case: source and destination do not overlap
+                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                            const uint8_t c = w.ring[(from + i) & RM];
+                            dst[pos + i] = c;
+                            w.ring[(pos + i) & RM] = c;
+                        }
+                    } else if (dist == 1) {  // a run of one byte
+                        const uint8_t c = w.ring[from & RM];
+                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                            dst[pos + i] = c;
+                            w.ring[(pos + i) & RM] = c;
+                        }
+                    } else {  // the pattern of `dist` bytes repeats
+                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                            const uint8_t c = w.ring[(from + i % dist) & RM];
+                            dst[pos + i] = c;
+                            w.ring[(pos + i) & RM] = c;
+                        }
+                    }
+                    gi_lds_sync();
+                } else {
+                    if (from + (len < dist ? len : dist) > visible) {  // the source reaches into bytes this wave stored since its last wait
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        visible = pos;
+                    }
+                    // (dist > GI_RING - 64 >= len is not guaranteed for a small ring: keep the general form)
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        const uint8_t c = dst[from + (dist >= len ? i : i % dist)];
+                        dst[pos + i] = c;
+                        w.ring[(pos + i) & RM] = c;
+                    }
                 }
                 pos += len;
             }
@@ -638,18 +824,29 @@ __global__ __launch_bounds__(64 * GI_WAVES) void gi_inflate_kernel(const uint8_t
         if (err == GI_OK && cap > 0) {  // CRC-32 of the text: 64 equal slices, then crc = crc_0 * x^(8 (n - s)) + crc_1 * x^(8 (n - 2s)) + ...
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t slice = (cap + 63u) / 64u;
+            const uint32_t slice = ((cap + 63u) / 64u + 3u) & ~3u;
             const uint32_t lo = (uint32_t)lane * slice, hi = lo + slice < cap ? lo + slice : cap;
             uint32_t c = 0;  // (raw register: the pre / post inversion is applied once, on the combined value)
             if (lane == 0) c = 0xffffffffu;
-            for (uint32_t i = lo; i < hi && lo < cap; i++) c = gi_crc_table[(c ^ dst[i]) & 0xffu] ^ (c >> 8);
+            uint32_t i = lo;
+            for (; i + 4u <= hi && lo < cap; i += 4) {  // slicing-by-4: four independent table reads per dword of text
+                uint32_t v;
+                memcpy(&v, dst + i, 4);
+                c ^= v;
+                c = s_crc[768 + (c & 0xffu)] ^ s_crc[512 + ((c >> 8) & 0xffu)] ^ s_crc[256 + ((c >> 16) & 0xffu)] ^ s_crc[c >> 24];
+            }
+            for (; i < hi && lo < cap; i++) c = s_crc[(c ^ dst[i]) & 0xffu] ^ (c >> 8);
             // combine: the register after slice j is R_j; the whole register = sum_j R_j * x^(8 * bytes behind slice j)
             const uint32_t behind = hi < cap ? cap - hi : 0;
             uint32_t part = (lo < cap) ? gi_gf_mul(c, gi_x_pow_8n(behind)) : 0u;
             for (int o = 32; o >= 1; o >>= 1) part ^= (uint32_t)__shfl_xor((int)part, o);
             if ((part ^ 0xffffffffu) != blk.crc) err = GI_E_CRC;
         }
-        if (lane == 0) status[bi] = err;
+        // (every lane stores the same word.  With `if (lane == 0)` here AND around the atomic at the top of the loop, clang -O2 threads
+        // the two tests through the back edge: lane 0 and the other 63 lanes then go around the loop separately, the 63 read
+        // their own -- zero -- `take` with readfirstlane and inflate member 0 for ever.  Seen with ROCm 7.2 once the loop body
+        // changed; the barrier at the top is there for the same reason.)
+        status[bi] = err;
     }
 }
 
@@ -744,7 +941,7 @@ static int gi_fail(int code, const std::string &m) {
         if (e_ != hipSuccess) return gi_fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static int gi_wgs_per_cu() {  // workgroups of four waves per CU: more waves do NOT mean more text (their history windows share the caches)
+static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a CU holds four: tables + ring of 16 waves)
     int v = 4;
     if (const char *e = getenv("GS_INFLATE_WGS")) v = std::max(1, std::min(8, atoi(e)));
     return v;
@@ -760,12 +957,14 @@ static int gi_upload_crc_table() {
     int dev = 0;
     GI_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && done[dev]) return GS_OK;
-    uint32_t t[256];
+    uint32_t t[4 * 256];
     for (uint32_t i = 0; i < 256; i++) {
         uint32_t c = i;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xedb88320u : 0u);
         t[i] = c;
     }
+    for (int q = 1; q < 4; q++)  // t[q][i]: the register after byte i and q zero bytes
+        for (uint32_t i = 0; i < 256; i++) t[256 * q + i] = (t[256 * (q - 1) + i] >> 8) ^ t[t[256 * (q - 1) + i] & 0xffu];
     GI_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gi_crc_table), t, sizeof(t)));
     if (dev >= 0 && dev < 64) done[dev] = true;
     return GS_OK;

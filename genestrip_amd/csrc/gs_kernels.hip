@@ -476,6 +476,9 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // compares are straight-line code (bitwise, no short-circuit branches: every branch is an exec-mask save /
             // restore on the scalar unit, which this kernel keeps as busy as the vector unit)
             if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
+            // (Tried in round 3 and dropped: touching sub-round 1's lines -- one dword each -- before sub-round 0's loads go out, to
+            // turn the second round trip into an L2 hit.  configs[1] 6.80 -> 7.05 ms, 47 M store 8.72 -> 9.08 ms, 473 M store
+            // 15.0 -> 15.2 ms: the kernel pays for the extra instructions and gains nothing from the shorter chain.)
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
@@ -2069,6 +2072,15 @@ static size_t gs_stats_lds_bytes(int n_values) {
     return n_values <= GS_NV_TREE_LDS ? (size_t)n_values * 3 * 4 : 0;  // the tree alone
 }
 
+// GS_FORCE_GLOBAL_STATS=1 (developer knob): the kernels for stores with more values than the LDS counters hold, on any store
+static bool gs_force_global_stats() {
+    static const bool on = [] {
+        const char *e = getenv("GS_FORCE_GLOBAL_STATS");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    return on;
+}
+
 template <bool FROM_NODES, int KC, bool WIDE, bool STRIPED, int CTX>
 static void gs_launch_match_t(const GsMatchParams *P, int grid, size_t lds, bool lds_stats, hipStream_t stream) {
     if (lds_stats)
@@ -2082,7 +2094,7 @@ static void gs_launch_match_t(const GsMatchParams *P, int grid, size_t lds, bool
 // except in the 128-path variants, which ask the store
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
-    const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    const bool lds_stats = P->db.n_values <= GS_NV_LDS && !gs_force_global_stats();
     const bool ctx = P->db.mgate_ctx != 0;
     if (P->db.n_parts > 1) {  // striped store (always probed locally: nodes == nullptr)
         if (P->nodes != nullptr) return hipErrorInvalidValue;
@@ -2117,7 +2129,7 @@ extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStrea
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream) {
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
-    const bool lds_stats = P->db.n_values <= GS_NV_LDS;
+    const bool lds_stats = P->db.n_values <= GS_NV_LDS && !gs_force_global_stats();
     if (P->db.n_parts > 1) {
         if (P->nodes != nullptr) return hipErrorInvalidValue;
         if (P->max_paths > 64) {

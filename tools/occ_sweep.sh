@@ -3,8 +3,8 @@
 # (developer tool; run on the GPU box from the repo root): how much of the time is latency that more waves would hide
 mkdir -p gpurun_out
 for b in 8 7 6 5 4; do
-  GS_MATCH_BLOCKS_PER_CU=$b python bench.py --legs main --cpu-seconds 0 --check-reads 20000 2>/dev/null > gpurun_out/occ_$b.json
+  GS_MATCH_BLOCKS_PER_CU=$b python bench.py --pmc off --legs main,large --cpu-seconds 0 --check-reads 20000 2>/dev/null > gpurun_out/occ_$b.json
   python3 -c "
 import json
-d=json.loads(open('gpurun_out/occ_$b.json').read().strip().splitlines()[-1]); print('blocks/CU $b', d['roofline']['kernel_ms'])"
+d=json.loads(open('gpurun_out/occ_$b.json').read().strip().splitlines()[-1]); print('blocks/CU $b', 'configs[1]', d['roofline']['kernel_ms'], 'ms; 47 M store', d['large_store']['kernel_ms'], 'ms')"
 done
