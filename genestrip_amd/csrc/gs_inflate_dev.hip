@@ -128,7 +128,8 @@ struct GiBits {
         const uint32_t o = at + 4u * (uint32_t)lane;
         uint32_t v = 0;
         if (o + 4u <= in_len) {
-            memcpy(&v, in + o, 4);
+            typedef uint32_t __attribute__((aligned(1))) u32_any;  // (the payload starts at any byte; the hardware reads unaligned dwords)
+            v = *reinterpret_cast<const u32_any *>(in + o);
         } else if (o < in_len) {
             for (uint32_t b = 0; o + b < in_len; b++) v |= (uint32_t)in[o + b] << (8 * b);
         }

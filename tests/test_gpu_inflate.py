@@ -84,6 +84,36 @@ def test_fuzzed_texts():
     _roundtrip(b"".join(parts), want)
 
 
+def test_distances_around_the_ring_and_groups_of_short_matches():
+    """The token decoder keeps the last 2 KiB of text in LDS and copies short matches side by side: distances on both sides of the
+    ring limit, sources that end inside the group they belong to, matches of every length, groups that end in an end-of-block."""
+    rng = np.random.default_rng(77)
+    parts, want = [], b""
+    for dist0 in (1500, 1800, 1900, 1984, 2000, 2047, 2048, 2049, 2100, 2500, 4096, 9000):
+        text = bytearray(rng.integers(0, 256, dist0 + 300, dtype=np.uint8).tobytes())
+        at = len(text)
+        for k in range(400):  # copies of 3..258 bytes from `dist0 +- a little` back, separated by a few fresh bytes
+            ln = int(rng.integers(3, 259)) if k % 7 == 0 else int(rng.integers(3, 12))
+            d = dist0 + int(rng.integers(-40, 41))
+            if d > at or at + ln > 65000:
+                break
+            text += text[at - d:at - d + ln] if d >= ln else (text[at - d:at] * (ln // d + 1))[:ln]
+            text += rng.integers(0, 256, int(rng.integers(0, 4)), dtype=np.uint8).tobytes()
+            at = len(text)
+        data = bytes(text[:65000])
+        for level in (1, 9):
+            parts.append(_member(data, level=level))
+            want += data
+    acgt = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 64000))  # level 1 on four letters: almost only matches of 3..8 bytes
+    for level in (1, 2, 3):
+        parts.append(_member(acgt, level=level))
+        want += acgt
+    tiny = b"".join(_member(acgt[a:a + n], level=6) for a, n in ((0, 1), (1, 2), (3, 3), (6, 7), (13, 64), (77, 65), (142, 300)))  # short last groups
+    parts.append(tiny)
+    want += acgt[0:1] + acgt[1:3] + acgt[3:6] + acgt[6:13] + acgt[13:77] + acgt[77:142] + acgt[142:442]
+    _roundtrip(b"".join(parts), want)
+
+
 def test_damaged_members_are_reported():
     text = (b"@r1\nACGTACGTAGCTAGCTAGCATCGATCGATCAGCTAGCTAGCTAGCTACGATCGATCGATCGATCGATCAGC\n+\n" + b"I" * 70 + b"\n") * 300
     good = _member(text)
