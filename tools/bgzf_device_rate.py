@@ -1,5 +1,5 @@
 import os, sys, time, tempfile, shutil
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import genestrip_amd as ga
 from genestrip_amd import synth, host
