@@ -700,6 +700,9 @@ def leg_striped(ga, db, device, dseq, doff, n, otable, plain_ms, lines_per_read,
             "inbound_GBs_needed_at_kernel_rate": round(foreign * reads_s / 1e9, 1),
             "inbound_GBs_available": round(link / 1e9, 1), "links": "%d x %.1f GB/s per direction" % (XGMI_LINKS, XGMI_GBS_PER_LINK_DIR),
             "link_bound_gbps_per_gpu": round(min(reads_s, link / max(foreign, 1e-9)) * READ_LEN / 1e9, 1),
+            "basis": "fabric read requests per read of the PLAIN kernel on this store (PMC, this run) minus the read's own bases; the "
+                     "striped kernel skips the second record line where the gate word's hint bit is clear (about a third fewer "
+                     "record lines), which this estimate does not credit",
             "verdict": "LINK-BOUND ESTIMATE: at N = 8 the striped mode is limited by inbound xGMI before small-packet overhead; a "
                        "store that fits one GPU's HBM (a 473 M-k-mer store takes 9 GiB of 288 GB) is REPLICATED instead (the default "
                        "--mode sharded), striping is for stores beyond one GPU"}
