@@ -476,9 +476,12 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // compares are straight-line code (bitwise, no short-circuit branches: every branch is an exec-mask save /
             // restore on the scalar unit, which this kernel keeps as busy as the vector unit)
             if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
-            // (Tried in round 3 and dropped: touching sub-round 1's lines -- one dword each -- before sub-round 0's loads go out, to
-            // turn the second round trip into an L2 hit.  configs[1] 6.80 -> 7.05 ms, 47 M store 8.72 -> 9.08 ms, 473 M store
-            // 15.0 -> 15.2 ms: the kernel pays for the extra instructions and gains nothing from the shorter chain.)
+            // (Tried in round 3 and dropped, twice: touching sub-round 1's lines -- one dword each -- before sub-round 0's loads go
+            // out, so that the second record round trip (3 400 + 3 200 of 24 900 wave cycles per read on the 473 M-k-mer store,
+            // tools/phase_times.sh huge) is an L2 hit.  With plain loads, which the compiler is free to sink: configs[1] 6.80 ->
+            // 7.05 ms, 47 M store 8.72 -> 9.08, 473 M store 15.0 -> 15.2.  With loads the compiler does not see (inline asm, issued
+            // first for certain; big stores only): 473 M store 15.0 -> 15.2 ms, striped 7.24 -> 7.40.  The round trip that was
+            // taken out does not come off the kernel's time.)
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 bool pending = false;
@@ -522,11 +525,13 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     }
                     pending = !hit & (((V0 | V1) & GS_REC_MORE) != 0);
                 }
+                GS_STAMP(8 + 2 * s, node[s])  // (phase 8 / 10: the record lines of sub-round 0 / 1)
                 // a k-mer whose window found no bucket (or that has two strand views) lives in the table
                 if (__ballot(pending) != 0) {
                     const u64 h = gs_kmer_hash(ohi[s], olo[s], k, kmask);
                     gs_lookup_rest<true, STRIPED>(db, (uint32_t)h & bmask, (h >> db.bucket_bits) << shift_rem, vmask2, pending, node[s], mk, wave_g);
                 }
+                GS_STAMP(9 + 2 * s, node[s])  // (phase 9 / 11: its walk of the overflow table)
             }
             return;
         }

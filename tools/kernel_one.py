@@ -1,7 +1,8 @@
 """a few full-size launches of ONE kernel for profiling (developer tool; tools/pmc_passes.sh runs it under rocprofv3):
-    python tools/kernel_one.py [bench|miss|large|filter]
+    python tools/kernel_one.py [bench|miss|large|huge|filter]
 bench: gs_match_kernel on the config-2 workload; miss: the same store, reads from genomes that are not in it;
-large: gs_match_kernel on the 47 M-k-mer / 526-value store; filter: gs_filter_kernel on the XOR index filter of that store"""
+large: gs_match_kernel on the 47 M-k-mer / 526-value store; huge: the 473 M-k-mer / 5 251-value store built on the device
+(context-keyed gate); filter: gs_filter_kernel on the XOR index filter of the 47 M store"""
 import os
 import sys
 
@@ -14,7 +15,10 @@ from genestrip_amd import synth  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "bench"
 n = 10_000_000
-db = synth.SynthDB(genera=25, species_per_genus=20) if what in ("large", "filter") else synth.SynthDB()
+if what == "huge":
+    db = synth.SynthDB(k=31, genera=250, species_per_genus=20, build=False)
+else:
+    db = synth.SynthDB(genera=25, species_per_genus=20) if what in ("large", "filter") else synth.SynthDB()
 src = synth.SynthDB(seed=43) if what == "miss" else db
 gen = torch.from_numpy(src.genomes).cuda()
 dseq = torch.empty(n * 150, dtype=torch.uint8, device="cuda")
@@ -32,7 +36,16 @@ if what == "filter":
     for _ in range(3):
         m.submit(dseq, doff, acc, n_reads=n)
 else:
-    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    if what == "huge":
+        goff = torch.arange(db.genomes.shape[0] + 1, dtype=torch.int64, device="cuda") * db.genomes.shape[1]
+        b = ga.DeviceDbBuilder(31, db.n_values, db.parent_vi)
+        b.add(gen.reshape(-1), goff, db.species_vi, update=False)
+        b.add(gen.reshape(-1), goff, db.species_vi, update=True)
+        b.finish()
+        store = b.to_store()
+        b.close()
+    else:
+        store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
     for _ in range(3):
         m.reset()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # wave cycles per phase of the short-read match path (developer tool; run on the GPU box from the repo root):
-#   tools/phase_times.sh [bench|miss|large]
+#   tools/phase_times.sh [bench|miss|large|huge]
 # builds a copy of libgsgpu.so with -DGS_PHASE=1 (s_memtime stamps at the phase boundaries, accumulated per wave in LDS),
 # runs tools/kernel_one.py against it and prints the share of every phase
 set -e
@@ -21,8 +21,9 @@ L = ga.lib()
 out = (ctypes.c_ulonglong * 16)()
 runpy.run_path("/tmp/gs_phase/tools/kernel_one.py", run_name="__main__")
 L.gs_debug_phase(out, 0)
-names = ["0 offsets", "1 bases -> planes", "2 funnel / act", "3 minimizers (LDS)", "4 orient + gate word", "5 records / table", "6 contigs + nodes", "7 classify + stats + loop"]
-tot = sum(out[i] for i in range(8))
+names = ["0 offsets", "1 bases -> planes", "2 funnel / act", "3 minimizers (LDS)", "4 orient + gate word", "5 (end of the record path)", "6 contigs + nodes", "7 classify + stats + loop"]
+names += ["8 records, sub-round 0", "9 table walk, sub-round 0", "10 records, sub-round 1", "11 table walk, sub-round 1"]
+tot = sum(out[i] for i in range(12))
 for i, n in enumerate(names):
     print("%-28s %6.2f %%   %8.0f cycles / read" % (n, 100.0 * out[i] / tot, out[i] / 3.0 / 10e6))
 print("total wave cycles per read: %.0f (3 launches of 10 M reads)" % (tot / 3.0 / 10e6))
