@@ -57,6 +57,7 @@ PMC_GROUPS = (
     "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum",
     "FETCH_SIZE",
     "WRITE_SIZE",
+    "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE",
 )
 PMC_KERNELS = {"match": r"gs_match_kernel<true", "large_store": r"gs_match_kernel<false", "filter": r"gs_filter_kernel",
                "cal_lines": r"cal_random_lines"}
@@ -258,6 +259,14 @@ def _resources(cnt, kern_ms, n_reads, ceil, footprint_key, src):
         out["vmem_loads_per_read"] = round(cnt["SQ_INSTS_VMEM_RD"] / n_reads, 2)
     if "GRBM_GUI_ACTIVE" in cnt:
         out["clock_ghz_under_pmc"] = round(cnt["GRBM_GUI_ACTIVE"] / 8 / sec / 1e9, 2)
+    if "TA_TA_BUSY_sum" in cnt and cnt.get("GRBM_GUI_ACTIVE") and ceil.get("n_cu"):
+        # one texture-address unit per CU takes the wave's vector-memory instructions apart into cache-line accesses; its busy
+        # cycles (summed over the CUs) over the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        f = cnt["TA_TA_BUSY_sum"] / (ceil["n_cu"] * cnt["GRBM_GUI_ACTIVE"] / 8.0)
+        out["vmem_address"] = {"frac": round(f, 4), "l1_line_accesses_per_read": round(cnt.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n_reads, 1),
+                               "note": "TA_TA_BUSY_sum over CUs x kernel cycles: the share of the time a CU's vector-memory address unit is busy "
+                                       "(scattered loads cost it up to 78 cycles per wave instruction, calibration.vmem_wave_loads_per_s_per_cu)"}
+        fr["vmem_address"] = out["vmem_address"]["frac"]
     return out, fr
 
 
@@ -284,6 +293,7 @@ def _calibrate(ga, footprints):
     for key, nbytes in footprints.items():
         cal[key] = ga.calibrate(ga.CAL_RANDOM_LINES, int(max(1 << 20, nbytes)))["rate"]
     simds = n_cu * 4
+    cal["n_cu"] = n_cu
     rep = {
         "n_cu": n_cu,
         "valu_pure_cycles_per_wave64_inst_at_2.4GHz": round(2.4e9 * simds / cal["valu_pure"], 3),
