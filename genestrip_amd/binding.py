@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
-    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_to_db", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
+    "gs_match_segments_fetch", "gs_match_max_counts", "gs_db_create_striped", "gs_db_create_stripe", "gs_db_stripe_export", "gs_db_stripe_attach", "gs_db_load_striped", "gs_db_load_stripe", "gs_dbbuild_begin", "gs_dbbuild_set_range", "gs_dbbuild_add", "gs_dbbuild_finish", "gs_dbbuild_fetch", "gs_dbbuild_to_db", "gs_dbbuild_destroy", "gs_db_create_part", "gs_match_encode", "gs_match_probe_keys", "gs_match_encode_route", "gs_match_route_geometry", "gs_unroute_region", "gs_match_reduce", "gs_route_keys",
     "gs_unroute_nodes",
     "gs_match_submit_text", "gs_match_submit_fasta", "gs_match_submit_fastq_ml", "gs_match_text_wait_copy", "gs_match_text_status", "gs_match_text_clear_error",
     "gs_match_text_select", "gs_match_segments_text", "gs_match_text_newlines", "gs_match_text_read_bounds", "gs_match_text_line_classes",
@@ -130,6 +130,7 @@ def lib():
         "gs_dbbuild_destroy": (ci, [vp]),
         "gs_match_encode": (ci, [vp, vp, vp, i64, vp, vp]), "gs_match_probe_keys": (ci, [vp, vp, i64, vp]),
         "gs_match_encode_route": (ci, [vp, vp, vp, i64, vp, ci, i64, vp, vp, vp, vp, vp]),
+        "gs_match_route_geometry": (ci, [vp, i64, vp, vp]),
         "gs_unroute_region": (ci, [vp, vp, vp, i64, vp]),
         "gs_match_reduce": (ci, [vp, vp, vp, i64, i64, vp, vp, vp, vp]),
         "gs_route_keys": (ci, [vp, vp, i64, ci, vp, vp, vp, vp]), "gs_unroute_nodes": (ci, [vp, vp, vp, vp, i64, vp, i64]),
@@ -638,6 +639,12 @@ class FastqKMerMatcher:
                                            C.c_void_p(pos_off.data_ptr()), n_parts, cap, C.c_void_p(send_keys.data_ptr()),
                                            C.c_void_p(send_idx.data_ptr()), C.c_void_p(nodes.data_ptr()), counts, C.byref(over)))
         return list(counts), bool(over.value)
+
+    def route_geometry(self, n_reads):
+        """gs_match_route_geometry: (waves gs_match_encode_route launches for n_reads reads, slots per chunk)"""
+        w, c = C.c_int32(0), C.c_int32(0)
+        _check(lib().gs_match_route_geometry(self.h, n_reads, C.byref(w), C.byref(c)))
+        return int(w.value), int(c.value)
 
     def unroute_region(self, idx, back, n, nodes):
         _ready(idx, back, nodes)

@@ -3275,6 +3275,17 @@ extern "C" int gs_match_encode(gs_run *run, const uint8_t *seq, const uint64_t *
 extern "C" hipError_t gs_launch_encode_route(const GsEncodeParams *P, const GsRouteParams *R, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_unroute_region(const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes, hipStream_t stream);
 
+static int route_grid(const gs_run *run, int64_t n_reads) {  // workgroups of GS_BLOCK / 64 waves (one read per wave at a time)
+    return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4));
+}
+
+extern "C" int gs_match_route_geometry(const gs_run *run, int64_t n_reads, int32_t *n_waves, int32_t *chunk) {
+    if (!run || n_reads < 0) return fail(GS_E_INVALID, "bad argument");
+    if (n_waves) *n_waves = route_grid(run, n_reads) * (GS_BLOCK / 64);
+    if (chunk) *chunk = GS_ROUTE_CHUNK;
+    return GS_OK;
+}
+
 extern "C" int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
                                      int n_parts, int64_t cap, uint64_t *send_keys, uint32_t *send_idx, int32_t *nodes,
                                      int64_t *counts, int *overflow) {
@@ -3311,9 +3322,7 @@ extern "C" int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint
     R.send_keys = (unsigned long long *)send_keys;
     R.send_idx = send_idx;
     R.nodes = nodes;
-    int grid = (int)std::min<int64_t>((int64_t)run->db->n_cu * 8, (n_reads + 3) / 4);
-    if (grid < 1) grid = 1;
-    HIP_TRY(gs_launch_encode_route(&P, &R, grid, run->stream));
+    HIP_TRY(gs_launch_encode_route(&P, &R, route_grid(run, n_reads), run->stream));
     u64 h[65];
     HIP_TRY(hipMemcpyAsync(h, run->d_route_cursors, sizeof(h), hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));

@@ -218,7 +218,8 @@ def exchange_all_to_all(send, send_counts, group=None):
     return recv, rc
 
 
-ROUTE_CHUNK = 2048  # genestrip_amd/csrc/gs_params.h: GS_ROUTE_CHUNK
+ROUTE_CHUNK = 2048  # genestrip_amd/csrc/gs_params.h: GS_ROUTE_CHUNK (the library reports it: FastqKMerMatcher.route_geometry)
+ROUTE_OVERFLOWS = [0]  # batches of partitioned_match_batch that fell back to the unfused steps
 
 
 def _all_to_all_views(recv, recv_counts, send_views, send_counts, group):
@@ -264,10 +265,10 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
         return
     # room per owner: its fair share of ALL positions with a quarter on top (only gate-passing k-mers are routed, and a
     # chunk is given up when it cannot take the keys of a sub-round) + one chunk per wave that may stay partly used
+    n_waves, chunk = matcher.route_geometry(n_reads)  # (the library's launch geometry on this device, not a copy of it)
     if cap is None:
-        n_waves = min(256 * 8 * 4, (n_reads + 3) // 4 * 4)
-        cap = n_keys // world + n_keys // (4 * world) + (n_waves + 2) * ROUTE_CHUNK
-    cap = (cap + ROUTE_CHUNK - 1) // ROUTE_CHUNK * ROUTE_CHUNK
+        cap = n_keys // world + n_keys // (4 * world) + (n_waves + 2) * chunk
+    cap = (cap + chunk - 1) // chunk * chunk
     send_keys = torch.empty(world * cap, dtype=torch.int64, device=dev)
     send_idx = torch.empty(world * cap, dtype=torch.int32, device=dev)
     nodes = torch.empty(n_keys, dtype=torch.int32, device=dev)
@@ -275,6 +276,7 @@ def partitioned_match_batch(matcher, k, seq, offsets, n_reads, first_read_no=0, 
     flag = torch.tensor([int(overflow)], dtype=torch.int64, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)  # every rank takes the same route
     if int(flag.item()):
+        ROUTE_OVERFLOWS[0] += 1  # (a batch whose regions were too small pays for the fused encode AND the unfused steps: worth noticing)
         return partitioned_match_batch_unfused(matcher, k, seq, offsets, n_reads, first_read_no, group, class_vi, flags)
     sc = torch.tensor(counts, dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)

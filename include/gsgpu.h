@@ -362,6 +362,9 @@ int gs_match_probe_keys(gs_run *run, const uint64_t *keys, int64_t n_keys, int32
 int gs_match_encode_route(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, const uint64_t *pos_off,
                           int n_parts, int64_t cap, uint64_t *send_keys, uint32_t *send_idx, int32_t *nodes, int64_t *counts,
                           int *overflow);
+/* What a caller needs to size `cap`: the waves gs_match_encode_route launches for a batch of n_reads reads on this run's device
+ * (each may leave one chunk partly used per owner) and the chunk size in slots (2048).  No device work. */
+int gs_match_route_geometry(const gs_run *run, int64_t n_reads, int32_t *n_waves, int32_t *chunk);
 /* nodes[idx[i]] = back[i] for the n answers of one owner region (idx ~0 skipped); asynchronous on the run's stream */
 int gs_unroute_region(gs_run *run, const uint32_t *idx, const int32_t *back, int64_t n, int32_t *nodes);
 int gs_match_reduce(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads, int64_t first_read_no,

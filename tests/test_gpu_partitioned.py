@@ -267,10 +267,15 @@ def test_partitioned_batch_fused_unfused_and_overflow_fallback(sdb):
             m = ga.FastqKMerMatcher(store)
             cv = torch.full((n,), -1, dtype=torch.int32, device=dev)
             fl = torch.zeros(n, dtype=torch.uint8, device=dev)
+            fell_back = gd.ROUTE_OVERFLOWS[0]
             if how == "unfused":
                 gd.partitioned_match_batch_unfused(m, 31, dseq, doff, n, 0, class_vi=cv, flags=fl)
             else:
                 gd.partitioned_match_batch(m, 31, dseq, doff, n, 0, class_vi=cv, flags=fl, cap=None if how == "fused" else gd.ROUTE_CHUNK)
+            # the default region size comes from the library's own launch geometry: it never overflows; a region of one chunk does
+            assert gd.ROUTE_OVERFLOWS[0] - fell_back == (1 if how == "overflow" else 0), how
+            waves, chunk = m.route_geometry(n)
+            assert chunk == gd.ROUTE_CHUNK and waves % 4 == 0 and 4 <= waves <= torch.cuda.get_device_properties(dev).multi_processor_count * 32
             table, _ = m.finish()
             assert np.array_equal(table, want), how
             assert np.array_equal(cv.cpu().numpy(), wcv) and np.array_equal(fl.cpu().numpy(), wfl), how
