@@ -41,7 +41,7 @@ extern "C" hipError_t gs_launch_probe_keys(const GsDbDev *db, const u64 *keys, i
                                             hipStream_t stream);
 extern "C" hipError_t gs_launch_filter(const struct GsFilterParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_stat_reduce(const GsStatRec *recs, const void *count, int64_t n_max, int n_values, void *sums, void *maxk,
-                                             void *dsums, hipStream_t stream);
+                                             void *dsums, int32_t *vi_scratch, hipStream_t stream);
 extern "C" int gs_match_occupancy(int n_values);
 extern "C" int gs_match_long_occupancy(int n_values);
 extern "C" int gs_filter_occupancy();
@@ -1891,6 +1891,8 @@ struct gs_run {
     GsStatRec *d_stat_recs = nullptr;  // deferred statistics of the current batch (global-atomic counters only)
     u64 *d_stat_rec_count = nullptr;
     size_t stat_recs_cap = 0;
+    int32_t *d_stat_vi = nullptr;      // the records' value indices as an array (stores with more values than one reduce pass takes)
+    size_t stat_vi_cap = 0;
     bool use_stat_recs = false;
     int stat_copies = 1;         // > 1: global-atomic counters spread over several copies (GsMatchParams::stat_copies)
     bool stats_spread = false;   // some copy other than 0 may be non-zero: fold_stats() before reading
@@ -2186,6 +2188,7 @@ static void run_free(gs_run *run) {
     hipHostFree(run->h_result);
     hipFree(run->d_sums);  // (d_max, d_dsums, d_long_count lie inside)
     hipFree(run->d_stat_recs);
+    hipFree(run->d_stat_vi);
     hipFree(run->d_stat_rec_count);
     hipFree(run->d_route_cursors);
     hipFree(run->d_bitmap);
@@ -2380,6 +2383,8 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     const int64_t rec_room = n_reads + (int64_t)grid * (GS_BLOCK / 64) * 64;  // every wave may leave one chunk of 64 partly used
     if (run->use_stat_recs) {
         if ((rc = grow(&run->d_stat_recs, &run->stat_recs_cap, (size_t)rec_room, run->stream))) return rc;
+        /* (640 = GS_REDUCE_VALUES, the values one pass of gs_stat_reduce_kernel takes) */
+        if (run->db->info.n_values > 640 && (rc = grow(&run->d_stat_vi, &run->stat_vi_cap, (size_t)rec_room, run->stream))) return rc;
         if (!run->d_stat_rec_count) HIP_TRY(hipMalloc((void **)&run->d_stat_rec_count, sizeof(u64)));
         HIP_TRY(hipMemsetAsync(run->d_stat_rec_count, 0, sizeof(u64), run->stream));
         P.stat_recs = run->d_stat_recs;
@@ -2399,7 +2404,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     HIP_TRY(gs_launch_match(&P, grid, run->stream));
     if (P.stat_recs)  // (into copy 0 of the counters; part of the timed region)
         HIP_TRY(gs_launch_stat_reduce(P.stat_recs, run->d_stat_rec_count, rec_room, run->db->info.n_values, run->d_sums, run->d_max,
-                                      run->d_dsums, run->stream));
+                                      run->d_dsums, run->d_stat_vi, run->stream));
     if (run->cfg.profile) {
         HIP_TRY(hipEventRecord(e1, run->stream));
         run->pending.push_back({e0, e1});
