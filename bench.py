@@ -933,6 +933,8 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
         outp = os.path.join(tmp, "filtered.fastq")
         best = None
         for _ in range(2):
+            if os.path.exists(outp):
+                os.remove(outp)  # (truncating 0.6 GB of page cache is not part of the pipeline)
             t0 = time.perf_counter()
             tot = host.filter_files(bloom, K, [plain], 1, 0.2, filtered_path=outp)
             dt = time.perf_counter() - t0
@@ -942,6 +944,17 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
                                    "accepted_reads": int(tot.filtered_reads), "accepted_equals_resident_filter": bool(int(acc.sum()) == int(tot.filtered_reads)),
                                    "output_bytes": os.path.getsize(outp),
                                    "output_size_as_expected": bool(os.path.getsize(outp) == int(acc.sum()) * rec_len)}
+        # ... and from the BGZF file: members inflated on the device, the filter on the device text, the text back once for the writers
+        plain_out = open(outp, "rb").read() if os.path.getsize(outp) < (2 << 30) else None
+        best = None
+        for _ in range(2):
+            os.remove(outp)
+            t0 = time.perf_counter()
+            tot = host.filter_files(bloom, K, [bz], 1, 0.2, filtered_path=outp)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        res["filter_writeback_bgzf"] = {"seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2), "accepted_reads": int(tot.filtered_reads),
+                                        "output_equals_plain_input_run": bool(plain_out is not None and open(outp, "rb").read() == plain_out)}
         bloom.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

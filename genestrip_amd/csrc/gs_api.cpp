@@ -3966,11 +3966,12 @@ static int filter_submit_text(gs_bloom *b, int k, int min_pos_count, double posi
     if (n_lines > 0 && !accept) return fail(GS_E_INVALID, "accept is NULL");
     HIP_TRY(hipSetDevice(b->device));
     const bool fasta = fasta_records >= 0 || ml_out != nullptr;  // the reads are gathered, not in place
-    int rc = text_submit(b->text, b->stream, text, n_bytes, n_lines, mem, k, ticket, fasta_records, ml_out);
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE && mem != GS_MEM_DEVICE_TEXT) return fail(GS_E_INVALID, "bad mem");
+    int rc = text_submit(b->text, b->stream, text, n_bytes, n_lines, mem == GS_MEM_HOST ? GS_MEM_HOST : GS_MEM_DEVICE, k, ticket, fasta_records, ml_out);
     if (rc) return rc;
     const int64_t n_reads = ml_out ? std::max<int64_t>(ml_out[0], 0) : (fasta ? fasta_records : (n_lines >> 2));
     if (n_reads == 0) return GS_OK;
-    const bool dev_out = mem == GS_MEM_DEVICE;
+    const bool dev_out = mem == GS_MEM_DEVICE;  // (GS_MEM_DEVICE_TEXT: the text is in HBM, accept / newlines are host arrays)
     if (!dev_out && b->reads_cap < (size_t)n_reads) {
         HIP_TRY(hipStreamSynchronize(b->stream));
         hipFree(b->d_off);
@@ -4038,6 +4039,12 @@ extern "C" int gs_filter_text_line_classes(gs_bloom *b, uint8_t *classes) {
         HIP_TRY(hipMemcpyAsync(classes, b->text.d_ml_class, (size_t)b->text.last_lines, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return bloom_collect(b);
+}
+
+extern "C" int gs_filter_get_device(gs_bloom *b, int *device) {
+    if (!b || !device) return fail(GS_E_INVALID, "NULL argument");
+    *device = b->device;
+    return GS_OK;
 }
 
 extern "C" int gs_filter_text_wait_copy(gs_bloom *b, int64_t ticket) {

@@ -258,6 +258,61 @@ struct PinnedVec {
     ~PinnedVec() { gs_pinned_free(p); }
 };
 
+// Big page-locked buffers kept from call to call (locking half a gigabyte of pages costs ~0.1 s -- more than a file of four million
+// reads takes to filter): get() hands out an idle buffer of at least `bytes` (or allocates), put() takes it back.  Never freed.
+struct PinnedPool {
+    std::mutex m;
+    std::vector<std::pair<void *, size_t>> idle;
+    void *get(size_t bytes, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].second >= bytes) {
+                    void *q = idle[i].first;
+                    *cap = idle[i].second;
+                    idle.erase(idle.begin() + (long)i);
+                    return q;
+                }
+            if (!idle.empty()) {  // too small: give the pages back before asking for more
+                gs_pinned_free(idle.back().first);
+                idle.pop_back();
+            }
+        }
+        void *q = nullptr;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (gs_pinned_alloc(&q, want) != GS_OK) return nullptr;
+        *cap = want;
+        return q;
+    }
+    void put(void *q, size_t cap) {
+        if (!q) return;
+        std::lock_guard<std::mutex> l(m);
+        idle.emplace_back(q, cap);
+    }
+};
+inline PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool();  // (never destroyed: the runtime may be gone by the time statics are torn down)
+    return *p;
+}
+struct PooledBuf {  // one buffer of the pool, returned when it goes out of scope
+    void *p = nullptr;
+    size_t cap = 0;
+    int need(size_t bytes) {
+        if (bytes <= cap) return GS_OK;
+        pinned_pool().put(p, cap);
+        p = pinned_pool().get(bytes, &cap);
+        if (!p) {
+            cap = 0;
+            return hfail(GS_E_NOMEM, "page-locked memory for a text chunk");
+        }
+        return GS_OK;
+    }
+    PooledBuf() = default;
+    PooledBuf(const PooledBuf &) = delete;
+    PooledBuf &operator=(const PooledBuf &) = delete;
+    ~PooledBuf() { pinned_pool().put(p, cap); }
+};
+
 struct MatchCtx {
     gs_run *run = nullptr;
     gs_db_info info{};
@@ -570,6 +625,39 @@ inline InflaterPool &inflater_pool() {
     return *p;
 }
 
+// every byte of the mapped file belongs to a BGZF member: list them (payload, ISIZE, CRC-32); false: not (only) BGZF
+inline bool bgzf_member_list(const uint8_t *map, size_t map_len, std::vector<gs_inflate_member> &members) {
+    members.clear();
+    size_t o = 0;
+    while (o < map_len) {
+        size_t len = 0;
+        uint32_t isize = 0;
+        if (!GsBgzfReader::block_at(map, map_len, o, &len, &isize)) return false;
+        const uint8_t *p = map + o;
+        if (p[3] != 4) return false;  // (name / comment / header CRC: not what bgzip writes -- the general decoder knows them)
+        const size_t hdr = 12 + ((size_t)p[10] | ((size_t)p[11] << 8));
+        const uint8_t *t = p + len - 8;
+        gs_inflate_member m{};
+        m.payload_offset = (int64_t)(o + hdr);
+        m.payload_len = (uint32_t)(len - hdr - 8);
+        m.isize = isize;
+        m.crc32 = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (isize > 0) members.push_back(m);
+        o += len;
+    }
+    return !members.empty();
+}
+
+// text per feed of the device inflater (GS_HOST_BGZF_TEXT): a feed is ~8000 members at 512 MiB, two rounds over the device's wave slots
+inline int64_t bgzf_text_target() {
+    int64_t t = (int64_t)512 << 20;
+    if (const char *e = getenv("GS_HOST_BGZF_TEXT")) {
+        const long long v = atoll(e);
+        if (v >= 65536 && v <= ((long long)1 << 29)) t = v;
+    }
+    return t;
+}
+
 struct TextJob {
     MatchCtx &c;
     std::string path;
@@ -620,28 +708,7 @@ struct TextJob {
         }
     }
 
-    // every byte of the mapped file belongs to a BGZF member: list them (payload, ISIZE, CRC-32); false: not (only) BGZF
-    bool list_bgzf_members() {
-        members_.clear();
-        size_t o = 0;
-        while (o < tr.map_len) {
-            size_t len = 0;
-            uint32_t isize = 0;
-            if (!GsBgzfReader::block_at(tr.map, tr.map_len, o, &len, &isize)) return false;
-            const uint8_t *p = tr.map + o;
-            if (p[3] != 4) return false;  // (name / comment / header CRC: not what bgzip writes -- the general decoder knows them)
-            const size_t hdr = 12 + ((size_t)p[10] | ((size_t)p[11] << 8));
-            const uint8_t *t = p + len - 8;
-            gs_inflate_member m{};
-            m.payload_offset = (int64_t)(o + hdr);
-            m.payload_len = (uint32_t)(len - hdr - 8);
-            m.isize = isize;
-            m.crc32 = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-            if (isize > 0) members_.push_back(m);
-            o += len;
-        }
-        return !members_.empty();
-    }
+    bool list_bgzf_members() { return bgzf_member_list(tr.map, tr.map_len, members_); }
 
     int open(bool gzip, int readers) {
         // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
@@ -683,11 +750,7 @@ struct TextJob {
         int err = GS_OK;
         // text per feed: a wave inflates a member in ~6 ms whatever else runs, so the rate is the number of members under way --
         // 512 MiB are ~8000 members, two rounds over the device's wave slots
-        int64_t text_target = (int64_t)512 << 20;
-        if (const char *e = getenv("GS_HOST_BGZF_TEXT")) {
-            const long long v = atoll(e);
-            if (v >= 65536 && v <= ((long long)1 << 29)) text_target = v;
-        }
+        const int64_t text_target = bgzf_text_target();
         auto run_end = [&](size_t from) {
             int64_t sum = 0;
             size_t e = from;
@@ -1520,6 +1583,144 @@ void filter_reader_shape(bool gzip, size_t *block, int *readers) {
 
 int filter_general_file(FilterCtx &c, const std::string &path, bool gzip, bool fasta);
 
+// the records of one chunk of four-line FASTQ to the writers: nextEntry (FastqBloomFilter.java:92-105), input order
+void format_text_chunk(FilterCtx &c, const uint8_t *start, const uint8_t *h_acc, const uint32_t *h_nl, int64_t n_reads) {
+    std::vector<FilterPart> parts((size_t)c.pool.threads());
+    c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
+        FilterPart &p = parts[(size_t)t];
+        p.acc = c.acc_out.take();
+        p.rest = c.rest_out.take();
+        for (int64_t r = lo; r < hi; r++) {
+            if (h_acc[r]) {
+                p.n_accepted++;
+                if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r, c.with_probs);
+            } else if (c.rest_out.active())
+                append_text_record(p.rest, start, h_nl, r, c.with_probs);
+        }
+        p.pack(c.acc_out, c.rest_out);
+    });
+    write_filter_parts(c, parts);
+}
+
+// Block-gzip (BGZF) FASTQ: the members are listed from their headers, the COMPRESSED bytes go to the device and are inflated there
+// (gs_inflater_feed), the filter runs on the text where it lies (GS_MEM_DEVICE_TEXT), and the text comes back ONCE, page-locked, for
+// the writers -- while the filter kernel runs.  *handled = false: not (only) BGZF, or no inflater: the caller takes its usual path.
+int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
+    *handled = false;
+    if (const char *e = getenv("GS_DEVICE_INFLATE"))
+        if (atoi(e) == 0) return GS_OK;
+    size_t block;
+    int readers;
+    filter_reader_shape(true, &block, &readers);
+    TextReader tr;  // (for the mapping only: its readers are never started)
+    int err = tr.open(path, block, readers, true);
+    std::vector<gs_inflate_member> members;
+    int device = 0;
+    gs_inflater *inf = nullptr;
+    if (err || tr.map_len < 28 || !bgzf_member_list(tr.map, tr.map_len, members) || gs_filter_get_device(c.bloom, &device) != GS_OK ||
+        (inf = inflater_pool().get(device)) == nullptr) {
+        tr.close();
+        return GS_OK;
+    }
+    *handled = true;
+    err = gs_filter_text_reset(c.bloom, 1);
+    PooledBuf text_sets[2], nl_sets[2];
+    PinnedVec<uint8_t> acc_sets[2];
+    std::future<void> formatting;
+    int64_t n_formatted = 0, text_off = 0, fallback_off = -1;
+    int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
+    std::vector<uint8_t> carry;
+    const double t0 = now_s();
+    // (feeds of 128 MiB here, not 512: the writers get their first chunk four times earlier, and what they have not written when
+    // the last feed is through is what the file waits for in the end -- 4 M reads: 285 ms with 512 MiB feeds, 175 ms with 128)
+    const int64_t text_target = getenv("GS_HOST_BGZF_TEXT") ? bgzf_text_target() : ((int64_t)128 << 20);
+    auto run_end = [&](size_t from) {
+        int64_t sum = 0;
+        size_t e = from;
+        while (e < members.size() && (e == from || sum + members[e].isize <= text_target)) sum += members[e++].isize;
+        return e;
+    };
+    for (size_t a = 0; !err && a < members.size();) {
+        const size_t b = run_end(a), b2 = run_end(b);
+        const bool last = b == members.size();
+        int64_t next_lo = 0, next_hi = 0;
+        if (b2 > b) {
+            next_lo = members[b].payload_offset;
+            next_hi = members[b2 - 1].payload_offset + (int64_t)members[b2 - 1].payload_len;
+        }
+        const uint8_t *text = nullptr;
+        int64_t n_bytes = 0, n_lines = 0, tail = 0;
+        const double tg = now_s();
+        if (gs_inflater_feed(inf, tr.map, members.data() + a, (int64_t)(b - a), next_lo, next_hi, last ? 1 : 0, &text, &n_bytes, &n_lines, &tail) != GS_OK) {
+            err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
+            break;
+        }
+        a = b;
+        if (n_lines > 0) {
+            const int64_t n_reads = n_lines >> 2;
+            const int set = (int)(n_formatted & 1);  // (the set of the chunk before last: its writers are through)
+            if ((err = acc_sets[set].resize((size_t)n_reads)) || (err = nl_sets[set].need(sizeof(uint32_t) * (size_t)n_lines)) || (err = text_sets[set].need((size_t)n_bytes)))
+                break;
+            uint8_t *h_acc = acc_sets[set].data(), *h_text = static_cast<uint8_t *>(text_sets[set].p);
+            uint32_t *h_nl = static_cast<uint32_t *>(nl_sets[set].p);
+            int64_t ticket = -1;
+            static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
+            const double t1 = now_s();
+            err = gs_filter_submit_text(c.bloom, c.k, c.min_pos_count, c.positive_ratio, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, h_acc, h_nl, 0, &ticket);
+            const double t2 = now_s();
+            if (!err && gs_inflater_fetch(inf, h_text, n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());  // (while the kernel runs)
+            const double t3 = now_s();
+            if (!err) err = gs_filter_text_status(c.bloom, &failed, &bad, tot);  // synchronises: results are needed now
+            const double t4 = now_s();
+            c.t_gpu += t4 - tg;
+            if (err) break;
+            if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
+                fallback_off = text_off;
+                break;
+            }
+            if (formatting.valid()) formatting.get();  // one chunk at a time: output order, the other set is free
+            if (trace)
+                fprintf(stderr, "filter bgzf feed: %lld bytes, inflate + buffers %.2f ms, submit %.2f, text back %.2f, status %.2f, writers of the chunk before %.2f\n",
+                        (long long)n_bytes, (t1 - tg) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now_s() - t4) * 1e3);
+            n_formatted++;
+            auto write_chunk = [&c, h_text, h_acc, h_nl, n_reads] { format_text_chunk(c, h_text, h_acc, h_nl, n_reads); };
+            try {
+                formatting = std::async(std::launch::async, write_chunk);
+            } catch (const std::system_error &) {  // no thread to be had: on this one
+                write_chunk();
+            }
+            text_off += n_bytes;
+        } else if (tail > ((int64_t)256 << 20) && !last) {  // no record boundary in a quarter of a gigabyte: the general parser
+            fallback_off = text_off;
+            break;
+        }
+        if (last) {  // what is left behind the last whole record
+            int64_t n = 0;
+            carry.resize((size_t)tail);
+            if (tail > 0 && gs_inflater_tail(inf, carry.data(), tail, &n) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+        }
+    }
+    const double te0 = now_s();
+    if (formatting.valid()) formatting.get();
+    const double te1 = now_s();
+    inflater_pool().put(device, inf);
+    tr.close();
+    if (getenv("GS_HOST_TRACE") != nullptr)
+        fprintf(stderr, "filter bgzf: loop %.2f ms (from open), last writers %.2f, inflater back + unmap %.2f\n", (te0 - t0) * 1e3, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);
+    c.t_parse += now_s() - t0;
+    if (err) return err;
+    c.reads += tot[0];
+    c.kmers += tot[1];
+    c.bps += tot[2];
+    if (fallback_off >= 0) {
+        err = gs_filter_text_reset(c.bloom, 1);
+        if (err) return err;
+        return filter_parsed_source(c, path, fallback_off, nullptr, 0);
+    }
+    if (!carry.empty()) return filter_parsed_source(c, std::string(), 0, carry.data(), carry.size());
+    return GS_OK;
+}
+
 // plain FASTQ: raw text blocks to the device (gs_filter_submit_text); accept flags and record geometry come back
 int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     size_t block;
@@ -1587,21 +1788,7 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
                 n_formatted++;
                 keep_block = true;
                 auto write_chunk = [&c, &tr, h_acc, h_nl, start, n_reads, i] {
-                    std::vector<FilterPart> parts((size_t)c.pool.threads());
-                    c.pool.run(n_reads, [&](int t, int64_t lo, int64_t hi) {
-                        FilterPart &p = parts[(size_t)t];
-                        p.acc = c.acc_out.take();
-                        p.rest = c.rest_out.take();
-                        for (int64_t r = lo; r < hi; r++) {  // nextEntry (FastqBloomFilter.java:92-105), input order
-                            if (h_acc[r]) {
-                                p.n_accepted++;
-                                if (c.acc_out.active()) append_text_record(p.acc, start, h_nl, r, c.with_probs);
-                            } else if (c.rest_out.active())
-                                append_text_record(p.rest, start, h_nl, r, c.with_probs);
-                        }
-                        p.pack(c.acc_out, c.rest_out);
-                    });
-                    write_filter_parts(c, parts);
+                    format_text_chunk(c, start, h_acc, h_nl, n_reads);
                     tr.release(i);  // the block goes back to its reader
                 };
                 try {
@@ -1833,12 +2020,17 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
         const int kind = fast ? text_path_kind(path) : 0;
         if (kind >= 3)
             err = filter_general_file(c, path, kind == 4, true);
-        else if (kind)
-            err = filter_text_file(c, path, kind == 2);
+        else if (kind) {
+            bool handled = false;
+            if (kind == 2) err = filter_bgzf_file(c, path, &handled);  // (block-gzip: inflated on the device)
+            if (!err && !handled) err = filter_text_file(c, path, kind == 2);
+        }
         else
             err = filter_parsed_source(c, path, 0, nullptr, 0);
     }
+    const double tc0 = now_s();
     const bool wrote = c.acc_out.close() & c.rest_out.close();
+    if (getenv("GS_HOST_TRACE") != nullptr) fprintf(stderr, "filter files: %.2f ms before the outputs were closed, closing %.2f ms\n", (tc0 - t_start) * 1e3, (now_s() - tc0) * 1e3);
     if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {
         totals->reads = c.reads;

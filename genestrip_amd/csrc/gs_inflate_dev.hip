@@ -984,6 +984,8 @@ struct gs_inflater {
     uint8_t *d_text[2] = {nullptr, nullptr};
     size_t text_cap[2] = {0, 0};
     int cur = 0;            // text buffer of the current call
+    const uint8_t *last_text = nullptr;  // what the last feed returned (gs_inflater_fetch)
+    int64_t last_bytes = 0;
     int64_t tail = 0;       // bytes carried into d_text[cur] by the previous call
     GiBlock *d_blocks = nullptr;
     size_t blocks_cap = 0;
@@ -1033,6 +1035,8 @@ extern "C" int gs_inflater_reset(gs_inflater *g) {
     if (g->stream) hipStreamSynchronize(g->stream);
     g->tail = 0;
     g->cur = 0;
+    g->last_text = nullptr;
+    g->last_bytes = 0;
     for (int i = 0; i < 2; i++) g->comp_lo[i] = g->comp_hi[i] = -1;
     return GS_OK;
 }
@@ -1209,6 +1213,8 @@ extern "C" int gs_inflater_feed(gs_inflater *g, const uint8_t *file, const gs_in
         // (the file ends without a final newline behind whole records: the tail is an unterminated line the caller must deal with)
     }
     *text = g->d_text[cb];
+    g->last_text = g->d_text[cb];
+    g->last_bytes = cut;
     *n_bytes = cut;
     *n_lines = whole_lines;
     const int64_t tail = have - cut;
@@ -1231,6 +1237,15 @@ extern "C" int gs_inflater_tail(gs_inflater *g, uint8_t *out, int64_t cap, int64
     if (!out || cap < g->tail) return gi_fail(GS_E_INVALID, "tail buffer too small");
     GI_TRY(hipSetDevice(g->device));
     GI_TRY(hipMemcpy(out, g->d_text[g->cur], (size_t)g->tail, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+extern "C" int gs_inflater_fetch(gs_inflater *g, uint8_t *out, int64_t n_bytes) {
+    if (!g || n_bytes < 0 || (n_bytes > 0 && !out)) return gi_fail(GS_E_INVALID, "bad argument");
+    if (n_bytes == 0) return GS_OK;
+    if (g->last_text == nullptr || n_bytes > g->last_bytes) return gi_fail(GS_E_STATE, "more bytes than the last feed returned");
+    GI_TRY(hipSetDevice(g->device));
+    GI_TRY(hipMemcpy(out, g->last_text, (size_t)n_bytes, hipMemcpyDeviceToHost));
     return GS_OK;
 }
 

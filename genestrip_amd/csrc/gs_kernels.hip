@@ -1215,6 +1215,9 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     for (;;) {
+        // (keeps the compiler from threading a lane-0 test at the end of an iteration into this one through the back edge: lane 0
+        // and the other lanes would go around the loop separately and read their own `c` -- seen in gs_inflate_dev.hip)
+        __builtin_amdgcn_wave_barrier();
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(P.long_count + 1, 1u);
         c = (uint32_t)gs_rfl((int)c);

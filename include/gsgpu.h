@@ -42,7 +42,7 @@ enum {
     GS_E_IO = -7         /* reading or writing a file failed (host layer)  */
 };
 
-enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1 };
+enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1, GS_MEM_DEVICE_TEXT = 2 /* gs_filter_submit_text only: the text in HBM, the results to host memory */ };
 
 const char *gs_last_error(void);
 const char *gs_strerror(int code);
@@ -444,6 +444,7 @@ int gs_filter_submit_text(gs_bloom *bloom, int k, int min_pos_count, double posi
                           int64_t n_bytes, int64_t n_lines, int mem, uint8_t *accept, uint32_t *newlines, int profile,
                           int64_t *ticket);
 int gs_filter_text_wait_copy(gs_bloom *bloom, int64_t ticket);
+int gs_filter_get_device(gs_bloom *bloom, int *device);
 int gs_filter_text_status(gs_bloom *bloom, int64_t *failed_ticket, int64_t *first_bad_record, int64_t totals[3]);
 int gs_filter_text_reset(gs_bloom *bloom, int clear_totals);
 
@@ -499,6 +500,9 @@ int gs_inflater_create(gs_inflater **out, int device);
 int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, int64_t next_lo,
                      int64_t next_hi, int last, const uint8_t **text, int64_t *n_bytes, int64_t *n_lines, int64_t *tail_bytes);
 int gs_inflater_tail(gs_inflater *inf, uint8_t *out, int64_t cap, int64_t *n);
+/* the first n_bytes of the text the LAST gs_inflater_feed returned, copied to host memory (page-locked for speed); synchronous.
+ * For callers that need the text on the host as well -- the filter goal's writers (C/bloom/FastqBloomFilter.java:92-105 rewriteInput). */
+int gs_inflater_fetch(gs_inflater *inf, uint8_t *out, int64_t n_bytes);
 int gs_inflater_reset(gs_inflater *inf);  /* ready for another file; its device and page-locked buffers stay (allocating them costs more than inflating a file) */
 int gs_inflater_destroy(gs_inflater *inf);
 const char *gs_inflate_last_error(void);

@@ -245,6 +245,48 @@ def test_filter_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypat
     gb.close()
 
 
+@pytest.mark.parametrize("text_target", [0, 70000])
+@pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "multi-line first"])
+def test_filter_files_bgzf_input_inflated_on_the_device(sdb, tmp_path, monkeypatch, shape, text_target):
+    """gs_host_filter_files over block-gzip FASTQ: members inflated on the device, the filter on the device text, the text back once
+    for the writers (filter_bgzf_file) -- output files and totals byte-identical to the host-decoder path (GS_DEVICE_INFLATE=0)
+    and to the oracle, whatever the file shape; small feeds (GS_HOST_BGZF_TEXT) put record and member boundaries everywhere"""
+    from conftest import bgzf
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    recs = _fastq_bytes(sdb, 1500, seed=41, nl=b"\r\n" if shape == "crlf" else b"\n")
+    for at in ([900] if shape == "multi-line record" else [0] if shape == "multi-line first" else []):
+        s = recs[at].split(b"\n")
+        recs[at] = s[0] + b"\n" + s[1][:50] + b"\n" + s[1][50:] + b"\n+\n" + s[3] + b"\n"
+    data = b"".join(recs)
+    if shape == "no final newline":
+        data = data[:-1]
+    path = str(tmp_path / "in.fastq.gz")
+    open(path, "wb").write(bgzf(data, block=20000, level=1))
+    p = orc.parse_fastq(data, k=31)
+    want = ob.filter_batch(31, 1, 0.2, p["seq"], p["seq_off"])
+    if text_target:
+        monkeypatch.setenv("GS_HOST_BGZF_TEXT", str(text_target))
+    outs = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("GS_DEVICE_INFLATE", dev)
+        a, r = str(tmp_path / f"acc{dev}.fastq"), str(tmp_path / f"rest{dev}.fastq")
+        tot = host.filter_files(gb, 31, [path], filtered_path=a, rest_path=r)
+        assert (tot.reads, tot.kmers, tot.bps) == (int(p["n_reads"]), int(p["total_kmers"]), int(p["total_bps"])), dev
+        assert tot.filtered_reads == int(want.sum()), dev
+        outs[dev] = (open(a, "rb").read(), open(r, "rb").read())
+    assert outs["1"] == outs["0"]
+    exp = b""
+    for i in np.flatnonzero(want):
+        d = bytes(p["desc"][int(p["desc_off"][i]):int(p["desc_off"][i + 1])])
+        s = bytes(p["seq"][int(p["seq_off"][i]):int(p["seq_off"][i + 1])])
+        exp += d + b"\n" + s + b"\n+\n" + b"~" * len(s) + b"\n"
+    assert outs["1"][0] == exp
+    gb.close()
+
+
 @pytest.mark.parametrize("odd", [False, True])
 def test_match_files_gzip_files_side_by_side(sdb, tmp_path, monkeypatch, odd):
     """two or more gzip files are inflated side by side (each behind its own thread, own status bank on the device,
