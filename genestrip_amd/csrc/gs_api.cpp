@@ -2592,11 +2592,13 @@ static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, 
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));
     const bool fasta = fasta_records >= 0 || ml_out != nullptr;
-    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem, run->db->info.k, ticket, fasta_records, ml_out);
+    if (mem != GS_MEM_HOST && mem != GS_MEM_DEVICE && mem != GS_MEM_DEVICE_TEXT) return fail(GS_E_INVALID, "bad mem");
+    int rc = text_submit(run->text, run->stream, text, n_bytes, n_lines, mem == GS_MEM_HOST ? GS_MEM_HOST : GS_MEM_DEVICE, run->db->info.k, ticket,
+                         fasta_records, ml_out);
     if (rc) return rc;
     const int64_t n_reads = ml_out ? std::max<int64_t>(ml_out[0], 0) : (fasta ? fasta_records : (n_lines >> 2));
     if (n_reads == 0) return GS_OK;
-    const bool dev_out = mem == GS_MEM_DEVICE;
+    const bool dev_out = mem == GS_MEM_DEVICE;  // (GS_MEM_DEVICE_TEXT: the text is in HBM, class_vi / flags are host arrays)
     if ((class_vi || flags) && !dev_out && run->reads_cap < (size_t)n_reads) {
         HIP_TRY(hipStreamSynchronize(run->stream));
         hipFree(run->d_off);

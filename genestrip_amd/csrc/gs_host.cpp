@@ -683,9 +683,10 @@ struct TextJob {
     bool general = false;
     bool gz_ = false;
     int readers_ = 2;
-    // block-gzip (BGZF) input without per-read outputs: the members are listed from their headers, the COMPRESSED bytes go to the
-    // device and are inflated there (gs_inflater_feed, one wave per member); the text never exists on the host.  What the device
-    // path cannot take (a chunk the record scan refuses, the unterminated tail of the file) goes the usual way.
+    // block-gzip (BGZF) input: the members are listed from their headers, the COMPRESSED bytes go to the device and are inflated
+    // there (gs_inflater_feed, one wave per member); without per-read outputs the text never exists on the host, with them
+    // (Kraken-style lines, filtered FASTQ) it comes back once per feed, page-locked, for the writers.  What the device path cannot
+    // take (a chunk the record scan refuses, the unterminated tail of the file) goes the usual way.
     bool dev_bgzf = false;
     gs_inflater *inf_ = nullptr;
     int inf_device_ = 0;
@@ -693,6 +694,7 @@ struct TextJob {
     size_t next_member_ = 0;
     int64_t dev_tickets_[2] = {-1, -1};
     int64_t n_feeds_ = 0;
+    PooledBuf dev_text_[2];  // the text of a feed on the host, for the per-read writers
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
@@ -730,7 +732,7 @@ struct TextJob {
         if (!err) err = gs_match_text_select(c.run, bank);
         int64_t failed = -1, bad = -1;
         if (!err) err = gs_match_text_status(c.run, &failed, &bad, base_tot);  // totals this bank has seen before
-        if (!err && gzip && !fasta && !general && !c.filtered.active() && !c.kraken.active()) {
+        if (!err && gzip && !fasta && !general) {
             bool want = true;
             if (const char *e = getenv("GS_DEVICE_INFLATE")) want = atoi(e) != 0;
             if (want && tr.map_len >= 28 && list_bgzf_members()) {
@@ -750,7 +752,9 @@ struct TextJob {
         int err = GS_OK;
         // text per feed: a wave inflates a member in ~6 ms whatever else runs, so the rate is the number of members under way --
         // 512 MiB are ~8000 members, two rounds over the device's wave slots
-        const int64_t text_target = bgzf_text_target();
+        const bool per_read = c.filtered.active() || c.kraken.active();
+        // (with writers behind it a feed is 128 MiB of text, not 512: they start four times earlier -- as filter_bgzf_file)
+        const int64_t text_target = per_read && !getenv("GS_HOST_BGZF_TEXT") ? ((int64_t)128 << 20) : bgzf_text_target();
         auto run_end = [&](size_t from) {
             int64_t sum = 0;
             size_t e = from;
@@ -783,7 +787,38 @@ struct TextJob {
         next_member_ = b;
         const double tt1 = now_s();
         if (!err) err = gs_match_text_select(c.run, bank);
-        if (!err && n_lines > 0) {
+        if (!err && n_lines > 0 && per_read) {
+            // the writers need the chunk's results and its text: class / flags come to host arrays (GS_MEM_DEVICE_TEXT), the text of
+            // the feed is fetched while the match kernel runs, then the chunk is formatted on a thread of its own
+            const int64_t n_chunk = n_lines >> 2;
+            MatchCtx::Results &rs = c.res[n_formatted & 1];  // (the set of the chunk before last: its writers are done)
+            PooledBuf &tb = dev_text_[n_formatted & 1];
+            int64_t ticket = -1;
+            err = rs.cls.resize((size_t)n_chunk);
+            if (!err) err = rs.flags.resize((size_t)n_chunk);
+            if (!err) err = tb.need((size_t)n_bytes);
+            if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
+            if (!err && gs_inflater_fetch(inf_, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (!err) {
+                chunks.push_back({carry_file_off, reads_in_file, ticket});
+                err = check_refusal(&fallback_off, &fallback_reads);  // (synchronises: the results are needed now)
+                if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
+                if (err || fallback_off >= 0) chunks.pop_back();
+            }
+            if (!err && fallback_off < 0) {
+                if (first_ticket < 0) first_ticket = ticket;
+                reads_in_file += n_chunk;
+                carry_file_off += n_bytes;
+                drain();  // one chunk at a time: output order, and the other result set becomes free
+                n_formatted++;
+                const uint8_t *h_text = static_cast<const uint8_t *>(tb.p);
+                try {
+                    formatting = std::async(std::launch::async, [this, &rs, h_text, n_chunk] { format_chunk(rs, h_text, n_chunk, -1); });
+                } catch (const std::system_error &) {  // no thread to be had: on this one
+                    format_chunk(rs, h_text, n_chunk, -1);
+                }
+            }
+        } else if (!err && n_lines > 0) {
             int64_t ticket = -1;
             err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
             if (!err) {
@@ -1158,7 +1193,7 @@ private:
             p.pack(cc.kraken, cc.filtered);
         });
         write_parts(c, parts);
-        tr.release(block);
+        if (block >= 0) tr.release(block);  // (-1: the text was not a reader's block -- device-inflated input)
     }
 
     // waits for the chunk that is being formatted (its result set and its block are free afterwards)

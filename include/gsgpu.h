@@ -42,7 +42,7 @@ enum {
     GS_E_IO = -7         /* reading or writing a file failed (host layer)  */
 };
 
-enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1, GS_MEM_DEVICE_TEXT = 2 /* gs_filter_submit_text only: the text in HBM, the results to host memory */ };
+enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1, GS_MEM_DEVICE_TEXT = 2 /* gs_match_submit_text / gs_filter_submit_text: the text in HBM, the per-read results to host memory */ };
 
 const char *gs_last_error(void);
 const char *gs_strerror(int code);

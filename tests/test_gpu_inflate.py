@@ -200,6 +200,33 @@ def test_bgzf_files_through_the_device_inflater(tmp_path, monkeypatch, shape):
     store.close()
 
 
+@pytest.mark.parametrize("shape", ["plain", "no_final_newline", "multiline", "small_feeds"])
+def test_bgzf_files_with_per_read_outputs_through_the_device_inflater(tmp_path, monkeypatch, shape):
+    """gs_host_match_files on BGZF input WITH per-read outputs (Kraken-style lines, the filtered FASTQ): the text of a feed comes back
+    once for the writers; both files, the table and the totals must equal the host-decoder run byte for byte"""
+    from genestrip_amd import host, synth
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
+    seq, off = synth.reads_host(db.genomes, 20000, read_len=150, seed=19)
+    text = _fastq(seq, off, multiline=shape == "multiline", final_newline=shape != "no_final_newline")
+    if shape == "small_feeds":
+        monkeypatch.setenv("GS_HOST_BGZF_TEXT", "300000")
+    path = tmp_path / "reads.fastq.gz"
+    path.write_bytes(bgzf(text, level=1))
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    cfg = ga.MatchConfig(classify=True)
+    taxids = [f"t{i}" for i in range(db.n_values)]
+    got = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("GS_DEVICE_INFLATE", dev)
+        fo, ko = tmp_path / f"filtered{dev}.fastq", tmp_path / f"kraken{dev}.txt"
+        t, _, tot = host.match_files(store, [str(path)], config=cfg, filtered_path=fo, kraken_out_path=ko, taxids=taxids)
+        got[dev] = (t, (tot.reads, tot.kmers, tot.bps), fo.read_bytes(), ko.read_bytes())
+    assert np.array_equal(got["1"][0], got["0"][0]) and got["1"][1] == got["0"][1]
+    assert got["1"][2] == got["0"][2] and got["1"][3] == got["0"][3]
+    assert len(got["1"][3].splitlines()) == 20000 and len(got["1"][2]) > 0
+    store.close()
+
+
 def test_a_corrupt_bgzf_member_fails_the_file(tmp_path, monkeypatch):
     from genestrip_amd import host, synth
     db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)

@@ -16,6 +16,14 @@ bench._write_gz(plain, bz, True, 16)
 for rep in range(3):
     t0 = time.perf_counter(); t, _, tot = host.match_files(store, [bz]); dt = time.perf_counter() - t0
     print(f"device inflate: {dt*1e3:.1f} ms = {n*150/dt/1e9:.2f} Gbp/s reads {tot.reads}", flush=True)
+ko = os.path.join(tmp, "kraken.txt")
+for env, label in (("1", "device inflate"), ("0", "host decoders")):  # with Kraken-style per-read lines: the text comes back once per feed
+    os.environ["GS_DEVICE_INFLATE"] = env
+    for rep in range(2):
+        if os.path.exists(ko):
+            os.remove(ko)
+        t0 = time.perf_counter(); host.match_files(store, [bz], kraken_out_path=ko, taxids=[f"t{i}" for i in range(db.n_values)]); dt = time.perf_counter() - t0
+        print(f"{label}, per-read lines written: {dt*1e3:.1f} ms = {n*150/dt/1e9:.2f} Gbp/s ({os.path.getsize(ko) / 1e6:.0f} MB)", flush=True)
 os.environ["GS_DEVICE_INFLATE"] = "0"
 t0 = time.perf_counter(); t2, _, tot = host.match_files(store, [bz]); dt = time.perf_counter() - t0
 print(f"host inflate: {dt*1e3:.1f} ms = {n*150/dt/1e9:.2f} Gbp/s", np.array_equal(t, t2), flush=True)
