@@ -1,0 +1,42 @@
+"""bench.py's roofline arithmetic on made-up counters (no GPU): every fraction is counter / time / ceiling, the bound is the
+largest one, a kernel that reaches 0.6 of nothing is called latency-bound, and a fraction can never be read above its ceiling
+by construction (VERDICT r02 "weak 2": frac 1.27)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def _ceil():
+    return {"valu_mix": 690e9, "salu": 585e9, "lines_main": 59.5e9, "n_cu": 256, "fetch_correction": 1.0}
+
+
+def test_resource_fractions_from_counters():
+    n = 10_000_000
+    cnt = {"SQ_INSTS_VALU": 299.0 * n, "SQ_INSTS_SALU": 212.0 * n, "SQ_INSTS_SMEM": 14.0 * n, "TCC_EA0_RDREQ_sum": 14.0 * n,
+           "FETCH_SIZE": 8.7e6, "WRITE_SIZE": 6.9e4, "SQ_WAIT_ANY": 4.6, "SQ_WAVE_CYCLES": 10.0, "SQ_INSTS_VMEM_RD": 10.5 * n,
+           "GRBM_GUI_ACTIVE": 8 * 1.62e7, "TA_TA_BUSY_sum": 0.54 * 256 * 1.62e7, "TCP_TOTAL_CACHE_ACCESSES_sum": 159.0 * n}
+    out, fr = bench._resources(cnt, 6.8, n, _ceil(), "lines_main", "test")
+    sec = 6.8e-3
+    assert abs(fr["valu_issue"] - 299.0 * n / sec / 690e9) < 1e-3
+    assert abs(fr["salu_issue"] - 226.0 * n / sec / 585e9) < 1e-3
+    assert abs(fr["line_requests"] - 14.0 * n / sec / 59.5e9) < 1e-3
+    assert abs(fr["hbm"] - (8.7e6 + 6.9e4) * 1024 / sec / 8e12) < 1e-3
+    assert abs(fr["vmem_address"] - 0.54) < 1e-3 and out["vmem_address"]["l1_line_accesses_per_read"] == 159.0
+    assert out["wait_frac"] == 0.46 and out["vmem_loads_per_read"] == 10.5
+    top, frac, name = bench._name_bound(fr)
+    assert top == "valu_issue" and name == "valu_issue" and 0.6 < frac < 1.0
+
+
+def test_no_counters_and_latency_bound():
+    out, fr = bench._resources(None, 6.8, 10, _ceil(), "lines_main", "none")
+    assert fr == {} and bench._name_bound(fr)[2].startswith("unknown")
+    top, frac, name = bench._name_bound({"hbm": 0.2, "valu_issue": 0.4})
+    assert top == "valu_issue" and name.startswith("latency")
+
+
+def test_fetch_correction_from_the_calibration_kernel():
+    f, rec = bench._fetch_correction({"cal_lines": {"FETCH_SIZE": 1000.0, "lines": 16000.0}})
+    assert abs(f - 16000.0 * 64 / (1000.0 * 1024)) < 1e-9 and rec["factor"] == 1.0
+    assert bench._fetch_correction(None) == (1.0, None)
