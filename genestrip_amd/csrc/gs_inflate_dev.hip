@@ -76,7 +76,6 @@ struct GiWave {
     uint16_t lwork[288], dwork[32];
     uint16_t lcount[16], dcount[16], offs[16];
     uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
-    uint8_t ring[GI_RING];   // text byte p at ring[p % GI_RING]
 };
 
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -421,16 +420,423 @@ struct GiBlock {
     uint32_t pad;
 };
 
+// ---- the blocks of one unit of work, from the reader's position: a BGZF member to its final block (MARK = false: bytes), or a
+// SEGMENT of a single-member stream from one block boundary to the next one that was found (MARK = true, gi_segment_kernel:
+// 16-bit symbols; what a match copies from in front of the segment is a MARKER 0x8000 | window position, resolved later --
+// dst[-GI_WINDOW .. 0) and the ring hold those markers when the call starts, so that no copy has to know).
+template <bool MARK>
+struct GiOut {
+    typedef uint8_t T;
+};
+template <>
+struct GiOut<true> {
+    typedef uint16_t T;
+};
+#define GI_WINDOW 32768u
+enum { GI_E_SYNC = 9 };  // a segment did not end on the block boundary the next segment starts at (or the stream ended inside it)
+
+template <bool MARK>
+__device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits &b, uint32_t in_len, u64 stop_bit, bool to_final,
+                                typename GiOut<MARK>::T *dst, uint32_t cap, int force_slow, int lane, uint32_t *produced) {
+    typedef typename GiOut<MARK>::T OutT;
+    constexpr uint32_t RM = GI_RING - 1u;
+    constexpr uint32_t BACK = MARK ? GI_WINDOW : 0u;  // how far in front of the unit's first symbol a match may reach
+    uint32_t pos = 0;          // bytes of text produced (stored or pending)
+    uint32_t npend = 0;        // pending literals (lane j < npend holds byte pos - npend + j)
+    uint32_t pbyte = 0;
+    uint32_t visible = 0;      // every byte below this offset is known to have reached memory
+    int err = GI_OK;
+    bool last = false, lfast = true, dfast = true;
+    auto flush = [&]() {
+        if (npend) {
+            const uint32_t at = pos - npend + (uint32_t)lane;
+            if ((uint32_t)lane < npend && at < cap) {  // (never beyond the member's own text)
+                dst[at] = (OutT)pbyte;
+                ring[at & RM] = (OutT)pbyte;
+            }
+            npend = 0;
+        }
+    };
+    while (!last && err == GI_OK) {
+        if (MARK && !to_final && b.consumed() >= stop_bit) break;  // the next segment's first block (checked behind the loop)
+        b.refill(lane);
+        last = b.get(1) != 0;
+        if (MARK && last && !to_final) {  // the stream ends inside a segment that is not the last one
+            err = GI_E_SYNC;
+            break;
+        }
+        const uint32_t btype = b.get(2);
+        if (btype == 0) {  // stored: to the byte boundary, LEN, ~LEN, bytes
+            b.drop(b.bc & 7);
+            b.refill(lane);
+            const uint32_t len = b.get(16), nlen = b.get(16);
+            if ((len ^ nlen) != 0xffffu) {
+                err = GI_E_HEADER;
+                break;
+            }
+            flush();
+            if (pos + len > cap) {
+                err = GI_E_OVERRUN;
+                break;
+            }
+            // the reader stands on a byte boundary: the bytes are copied straight from the payload, the reader re-seated behind them
+            const uint32_t src = (uint32_t)(b.consumed() >> 3);
+            if ((u64)src + len > in_len) {
+                err = GI_E_INPUT;
+                break;
+            }
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const OutT c = (OutT)b.in[src + i];
+                dst[pos + i] = c;
+                if (len - i <= GI_RING) ring[(pos + i) & RM] = c;  // (the last GI_RING bytes of the block)
+            }
+            b.seek(src + len, lane);
+            pos += len;
+            continue;
+        }
+        if (btype == 3) {
+            err = GI_E_HEADER;
+            break;
+        }
+        if (btype == 1) {  // fixed codes
+            for (int s = lane; s < 288; s += 64) w.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+            for (int s = lane; s < 32; s += 64) w.lens[288 + s] = 5;
+            gi_lds_sync();
+            if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+                !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
+                err = GI_E_TABLE;
+                break;
+            }
+        } else {  // dynamic codes
+            b.refill(lane);
+            const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+            if (hlit > 286 || hdist > 30) {
+                err = GI_E_HEADER;
+                break;
+            }
+            for (int s = lane; s < 19; s += 64) w.lens[s] = 0;
+            gi_lds_sync();
+            for (int i = 0; i < hclen; i++) {
+                b.refill(lane);
+                const uint32_t v = b.get(3);
+                if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
+            }
+            gi_lds_sync();
+            bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
+            if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
+                err = GI_E_TABLE;
+                break;
+            }
+            int at = 0, prev = 0;
+            const int total = hlit + hdist;
+            // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
+            while (at < total && err == GI_OK) {
+                b.refill(lane);
+                const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
+                if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
+                    err = GI_E_CODE;
+                    break;
+                }
+                b.drop((int)(e & 15u));
+                const int sym = (int)((e >> 4) & 0xffu);
+                int rep = 1, val = sym;
+                if (sym == 16) {
+                    if (at == 0) {
+                        err = GI_E_CODE;
+                        break;
+                    }
+                    rep = 3 + (int)b.get(2);
+                    val = prev;
+                } else if (sym == 17) {
+                    rep = 3 + (int)b.get(3);
+                    val = 0;
+                } else if (sym == 18) {
+                    rep = 11 + (int)b.get(7);
+                    val = 0;
+                }
+                if (at + rep > total) {
+                    err = GI_E_CODE;
+                    break;
+                }
+                // literal / length lengths at lens[24 + i] for now, distance lengths behind them
+                for (int r = lane; r < rep; r += 64) w.lens[24 + at + r] = (uint8_t)val;
+                at += rep;
+                prev = val;
+            }
+            if (err != GI_OK) break;
+            gi_lds_sync();
+            {   // into place: lens[0 .. 288) literal / length (unused ones 0), lens[288 .. 320) distances
+                uint8_t mine[5];
+                for (int q = 0; q < 5; q++) {
+                    const int s = lane + 64 * q;  // 0 .. 319
+                    uint8_t v = 0;
+                    if (s < 288) {
+                        if (s < hlit) v = w.lens[24 + s];
+                    } else if (s - 288 < hdist)
+                        v = w.lens[24 + hlit + (s - 288)];
+                    mine[q] = v;
+                }
+                gi_lds_sync();
+                for (int q = 0; q < 5; q++) w.lens[lane + 64 * q] = mine[q];
+                gi_lds_sync();
+            }
+            if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
+                err = GI_E_TABLE;
+                break;
+            }
+            if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+                !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
+                err = GI_E_TABLE;
+                break;
+            }
+        }
+        if (force_slow & 1) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
+        if (lfast && dfast) {
+            // ---- the symbols of the block, 64 bit offsets at a time (see the head of the file)
+            flush();
+            u64 P = b.consumed();                         // the reader's position, bits from the start of the payload
+            const u64 plimit = (u64)in_len * 8u;      // a token that starts behind it: the stream has run off its payload
+            uint32_t k = (uint32_t)(P >> 11);             // pieces k and k + 1 are in w.cbuf, piece k + 2 is on its way
+            {
+                const uint32_t p0 = b.load_piece(k * 256u, lane), p1 = b.load_piece((k + 1u) * 256u, lane);
+                w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = p0;
+                w.cbuf[((k + 1u) & 1u) * 64u + (uint32_t)lane] = p1;
+            }
+            uint32_t ahead = b.load_piece((k + 2u) * 256u, lane);
+            gi_lds_sync();
+            bool eob = false;
+            uint32_t guard = 0;
+            while (!eob) {
+                if (P > plimit || (u64)++guard > plimit + 64u) {  // (every group takes at least one bit: the second test cannot fire)
+                    err = GI_E_INPUT;
+                    break;
+                }
+                if ((uint32_t)(P >> 11) != k) {  // one piece further: piece k + 2 takes the place of piece k
+                    w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = ahead;
+                    k++;
+                    ahead = b.load_piece((k + 2u) * 256u, lane);
+                    gi_lds_sync();
+                }
+                const uint32_t q = (uint32_t)(P & 4095u) + (uint32_t)lane;  // this lane's bit offset inside the 512 staged bytes
+                const uint32_t d0 = q >> 5, sh = q & 31u;
+                const uint32_t x0 = w.cbuf[d0 & 127u], x1 = w.cbuf[(d0 + 1u) & 127u], x2 = w.cbuf[(d0 + 2u) & 127u];
+                uint32_t kind, t, olen, dist, lit;
+                gi_token(w, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), kind, t, olen, dist, lit);
+                // which lanes are token starts: lane 0 is one, and every token names the next
+                const bool stop = kind == GI_EOB || kind == GI_BAD;
+                const uint32_t step = stop ? 64u : t;  // (an end marker ends the walk)
+                u64 chain = 0;
+                uint32_t at = 0;
+                for (int hop = 0; hop < 64 && at < 64u; hop++) {  // (a token has at least one bit)
+                    chain |= 1ULL << at;
+                    at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
+                }
+                uint32_t adv = at;  // bits of this group
+                if ((__ballot(stop) & chain) != 0) {  // the chain's last token is an end marker
+                    const int el = 63 - __builtin_clzll(chain);
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)kind, el) == GI_BAD) {
+                        err = GI_E_CODE;
+                        break;
+                    }
+                    eob = true;
+                    adv = (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)t, el);
+                }
+                const bool on = GI_ON(chain);
+                const uint32_t ol = on ? olen : 0u;
+                const uint32_t incl = gi_scan_incl(ol);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t mpos = pos + (incl - ol);  // where this lane's token writes
+                if (pos + total > cap) {
+                    err = GI_E_OVERRUN;
+                    break;
+                }
+                const bool is_match = on && kind == GI_LEN;
+                const u64 mm = __ballot(is_match);
+                if (mm != 0 && __ballot(is_match && dist > mpos + BACK) != 0) {
+                    err = GI_E_DIST;
+                    break;
+                }
+                if (on && kind == GI_LIT) {
+                    dst[mpos] = (OutT)lit;
+                    ring[mpos & RM] = (OutT)lit;
+                }
+                if (mm != 0) {
+                    gi_lds_sync();
+                    // Nothing this group writes lands on a ring slot whose old byte a match with dist + total + 64 <= GI_RING
+                    // still reads (the slot of byte p is reused by byte p + GI_RING).
+                    const uint32_t from = mpos - dist;
+                    // side by side: short, not overlapping, source in the ring and in front of the group's first byte
+                    const bool par = is_match && olen <= GI_PAR_MAX && dist >= olen && dist + total + 64u <= GI_RING && (mpos - pos) + olen <= dist;
+                    const u64 pm = __ballot(par);
+                    if (pm != 0) {
+                        for (uint32_t i = 0; i < GI_PAR_MAX; i++) {
+                            const bool go = par && i < olen;
+                            if (__ballot(go) == 0) break;
+                            if (go) {
+                                const OutT c = ring[(from + i) & RM];
+                                dst[mpos + i] = c;
+                                ring[(mpos + i) & RM] = c;
+                            }
+                        }
+                        gi_lds_sync();
+                    }
+                    for (u64 sm = mm & ~pm; sm != 0; sm &= sm - 1) {  // the others in order, all lanes on one match
+                        const int ml = __builtin_ctzll(sm);
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)olen, ml), dd = (uint32_t)__builtin_amdgcn_readlane((int)dist, ml);
+                        const uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)mpos, ml), fr = mp - dd;
+                        if (dd + total + 64u <= GI_RING) {
+                            if (dd == 1) {  // a run of one byte
+                                const OutT c = ring[fr & RM];
+                                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                    dst[mp + i] = c;
+                                    ring[(mp + i) & RM] = c;
+                                }
+                            } else {
+                                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                    const OutT c = ring[(fr + (dd >= len ? i : i % dd)) & RM];
+                                    dst[mp + i] = c;
+                                    ring[(mp + i) & RM] = c;
+                                }
+                            }
+                            gi_lds_sync();
+                        } else {
+                            if ((int32_t)(fr + (len < dd ? len : dd)) > (int32_t)visible) {  // the source reaches into bytes this wave stored since its last wait
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                visible = mp;
+                            }
+                            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                                const OutT c = dst[(int32_t)(fr + (dd >= len ? i : i % dd))];
+                                dst[mp + i] = c;
+                                ring[(mp + i) & RM] = c;
+                            }
+                            gi_lds_sync();
+                        }
+                    }
+                }
+                pos += total;
+                P += adv;
+            }
+            if (err != GI_OK) break;
+            b.seek_bit(P, lane);
+            continue;  // the next block
+        }
+        // ---- one symbol at a time (a code that did not fit the tables; GS_INFLATE_FORCE_SLOW).  Literals wait in `pbyte` (lane j:
+        // the j-th pending byte) and are stored 62..64 at a time; whether they fit the member's announced size is checked when
+        // they are stored (flush), not per literal.
+        const uint32_t tlimit = in_len / 4u + 4u;  // dwords the reader may take before the stream has run off its payload
+        for (;;) {
+            if (b.bc <= 32) {
+                b.refill(lane);
+                if (b.taken > tlimit) {
+                    err = GI_E_INPUT;
+                    break;
+                }
+            }
+            const uint32_t e = lfast ? gi_lookup(w.ltab, w.ldesc, GI_LROOT, b) : gi_slow(w.lcount, w.lwork, 0, b);
+            const uint32_t kind = e >> 16;
+            if ((e & 15u) == 0) {
+                err = GI_E_CODE;
+                break;
+            }
+            b.drop((int)(e & 15u));
+            if (kind == GI_LIT) {
+                if ((uint32_t)lane == npend) pbyte = (e >> 4) & 0xffu;
+                npend++;
+                pos++;
+                if (npend >= 63) {
+                    if (pos > cap) {
+                        err = GI_E_OVERRUN;
+                        break;
+                    }
+                    flush();
+                }
+                continue;
+            }
+            if (kind == GI_EOB) break;
+            if (kind != GI_LEN) {
+                err = GI_E_CODE;
+                break;
+            }
+            uint32_t lbase, lextra, dbase, dextra;
+            gi_len_sym((e >> 4) & 31u, lbase, lextra);
+            const uint32_t len = lbase + b.get((int)lextra);
+            b.refill(lane);
+            const uint32_t d = dfast ? gi_lookup(w.dtab, w.ddesc, GI_DROOT, b) : gi_slow(w.dcount, w.dwork, 1, b);
+            if ((d >> 16) != GI_DIST || (d & 15u) == 0) {
+                err = GI_E_CODE;
+                break;
+            }
+            b.drop((int)(d & 15u));
+            gi_dist_sym((d >> 4) & 31u, dbase, dextra);
+            const uint32_t dist = dbase + b.get((int)dextra);
+            if (dist > pos + BACK) {
+                err = GI_E_DIST;
+                break;
+            }
+            if (pos + len > cap) {
+                err = GI_E_OVERRUN;
+                break;
+            }
+            flush();
+            const uint32_t from = pos - dist;
+            if (dist <= GI_RING - 64u) {
+                // the source lies in the ring (every source byte is in front of `pos`, and a byte is overwritten GI_RING
+                // bytes later: not by this copy).  LDS operations of a wave execute in order: the barrier is for the compiler.
+                gi_lds_sync();
+                if (dist >= len) {  // the usual case: source and destination do not overlap
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        const OutT c = ring[(from + i) & RM];
+                        dst[pos + i] = c;
+                        ring[(pos + i) & RM] = c;
+                    }
+                } else if (dist == 1) {  // a run of one byte
+                    const OutT c = ring[from & RM];
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        dst[pos + i] = c;
+                        ring[(pos + i) & RM] = c;
+                    }
+                } else {  // the pattern of `dist` bytes repeats
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                        const OutT c = ring[(from + i % dist) & RM];
+                        dst[pos + i] = c;
+                        ring[(pos + i) & RM] = c;
+                    }
+                }
+                gi_lds_sync();
+            } else {
+                if ((int32_t)(from + (len < dist ? len : dist)) > (int32_t)visible) {  // the source reaches into bytes this wave stored since its last wait
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    visible = pos;
+                }
+                // (dist > GI_RING - 64 >= len is not guaranteed for a small ring: keep the general form)
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                    const OutT c = dst[(int32_t)(from + (dist >= len ? i : i % dist))];
+                    dst[pos + i] = c;
+                    ring[(pos + i) & RM] = c;
+                }
+            }
+            pos += len;
+        }
+    }
+    if (err == GI_OK && pos > cap) err = GI_E_OVERRUN;
+    if (err == GI_OK) flush();
+    if (MARK && err == GI_OK && !to_final && b.consumed() != stop_bit) err = GI_E_SYNC;
+    *produced = pos;
+    return err;
+}
+
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
                                                                     int32_t *status, int force_slow, unsigned long long *next_member) {
     __shared__ GiWave s_w[GI_WAVES];
+    __shared__ uint8_t s_ring[GI_WAVES][GI_RING];  // text byte p of a wave's member at [p % GI_RING]
     __shared__ uint32_t s_crc[4 * 256];
     for (int i = (int)threadIdx.x; i < 4 * 256; i += 64 * GI_WAVES) s_crc[i] = gi_crc_table[i];
     __syncthreads();
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
-    constexpr uint32_t RM = GI_RING - 1u;
     // the waves draw members from a shared counter: a member takes 5 .. 15 ms of a wave, a fixed assignment would leave the waves
     // with one member fewer idle for that long
     for (;;) {
@@ -444,382 +850,9 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const uint32_t cap = blk.out_len;
         GiBits b;
         b.start(comp + blk.in_off, blk.in_len, lane);
-        uint32_t pos = 0;          // bytes of text produced (stored or pending)
-        uint32_t npend = 0;        // pending literals (lane j < npend holds byte pos - npend + j)
-        uint32_t pbyte = 0;
-        uint32_t visible = 0;      // every byte below this offset is known to have reached memory
         int err = GI_OK;
-        bool last = false, lfast = true, dfast = true;
-        auto flush = [&]() {
-            if (npend) {
-                const uint32_t at = pos - npend + (uint32_t)lane;
-                if ((uint32_t)lane < npend && at < cap) {  // (never beyond the member's own text)
-                    dst[at] = (uint8_t)pbyte;
-                    w.ring[at & RM] = (uint8_t)pbyte;
-                }
-                npend = 0;
-            }
-        };
-        while (!last && err == GI_OK) {
-            b.refill(lane);
-            last = b.get(1) != 0;
-            const uint32_t btype = b.get(2);
-            if (btype == 0) {  // stored: to the byte boundary, LEN, ~LEN, bytes
-                b.drop(b.bc & 7);
-                b.refill(lane);
-                const uint32_t len = b.get(16), nlen = b.get(16);
-                if ((len ^ nlen) != 0xffffu) {
-                    err = GI_E_HEADER;
-                    break;
-                }
-                flush();
-                if (pos + len > cap) {
-                    err = GI_E_OVERRUN;
-                    break;
-                }
-                // the reader stands on a byte boundary: the bytes are copied straight from the payload, the reader re-seated behind them
-                const uint32_t src = (uint32_t)(b.consumed() >> 3);
-                if ((u64)src + len > blk.in_len) {
-                    err = GI_E_INPUT;
-                    break;
-                }
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                    const uint8_t c = b.in[src + i];
-                    dst[pos + i] = c;
-                    if (len - i <= GI_RING) w.ring[(pos + i) & RM] = c;  // (the last GI_RING bytes of the block)
-                }
-                b.seek(src + len, lane);
-                pos += len;
-                continue;
-            }
-            if (btype == 3) {
-                err = GI_E_HEADER;
-                break;
-            }
-            if (btype == 1) {  // fixed codes
-                for (int s = lane; s < 288; s += 64) w.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
-                for (int s = lane; s < 32; s += 64) w.lens[288 + s] = 5;
-                gi_lds_sync();
-                if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
-                    !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
-                    err = GI_E_TABLE;
-                    break;
-                }
-            } else {  // dynamic codes
-                b.refill(lane);
-                const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
-                if (hlit > 286 || hdist > 30) {
-                    err = GI_E_HEADER;
-                    break;
-                }
-                for (int s = lane; s < 19; s += 64) w.lens[s] = 0;
-                gi_lds_sync();
-                for (int i = 0; i < hclen; i++) {
-                    b.refill(lane);
-                    const uint32_t v = b.get(3);
-                    if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
-                }
-                gi_lds_sync();
-                bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
-                if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
-                    err = GI_E_TABLE;
-                    break;
-                }
-                int at = 0, prev = 0;
-                const int total = hlit + hdist;
-                // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
-                while (at < total && err == GI_OK) {
-                    b.refill(lane);
-                    const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
-                    if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
-                        err = GI_E_CODE;
-                        break;
-                    }
-                    b.drop((int)(e & 15u));
-                    const int sym = (int)((e >> 4) & 0xffu);
-                    int rep = 1, val = sym;
-                    if (sym == 16) {
-                        if (at == 0) {
-                            err = GI_E_CODE;
-                            break;
-                        }
-                        rep = 3 + (int)b.get(2);
-                        val = prev;
-                    } else if (sym == 17) {
-                        rep = 3 + (int)b.get(3);
-                        val = 0;
-                    } else if (sym == 18) {
-                        rep = 11 + (int)b.get(7);
-                        val = 0;
-                    }
-                    if (at + rep > total) {
-                        err = GI_E_CODE;
-                        break;
-                    }
-                    // literal / length lengths at lens[24 + i] for now, distance lengths behind them
-                    for (int r = lane; r < rep; r += 64) w.lens[24 + at + r] = (uint8_t)val;
-                    at += rep;
-                    prev = val;
-                }
-                if (err != GI_OK) break;
-                gi_lds_sync();
-                {   // into place: lens[0 .. 288) literal / length (unused ones 0), lens[288 .. 320) distances
-                    uint8_t mine[5];
-                    for (int q = 0; q < 5; q++) {
-                        const int s = lane + 64 * q;  // 0 .. 319
-                        uint8_t v = 0;
-                        if (s < 288) {
-                            if (s < hlit) v = w.lens[24 + s];
-                        } else if (s - 288 < hdist)
-                            v = w.lens[24 + hlit + (s - 288)];
-                        mine[q] = v;
-                    }
-                    gi_lds_sync();
-                    for (int q = 0; q < 5; q++) w.lens[lane + 64 * q] = mine[q];
-                    gi_lds_sync();
-                }
-                if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
-                    err = GI_E_TABLE;
-                    break;
-                }
-                if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
-                    !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
-                    err = GI_E_TABLE;
-                    break;
-                }
-            }
-            if (force_slow & 1) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
-            if (lfast && dfast) {
-                // ---- the symbols of the block, 64 bit offsets at a time (see the head of the file)
-                flush();
-                u64 P = b.consumed();                         // the reader's position, bits from the start of the payload
-                const u64 plimit = (u64)blk.in_len * 8u;      // a token that starts behind it: the stream has run off its payload
-                uint32_t k = (uint32_t)(P >> 11);             // pieces k and k + 1 are in w.cbuf, piece k + 2 is on its way
-                {
-                    const uint32_t p0 = b.load_piece(k * 256u, lane), p1 = b.load_piece((k + 1u) * 256u, lane);
-                    w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = p0;
-                    w.cbuf[((k + 1u) & 1u) * 64u + (uint32_t)lane] = p1;
-                }
-                uint32_t ahead = b.load_piece((k + 2u) * 256u, lane);
-                gi_lds_sync();
-                bool eob = false;
-                uint32_t guard = 0;
-                while (!eob) {
-                    if (P > plimit || ++guard > 8u * blk.in_len + 64u) {  // (every group takes at least one bit: the second test cannot fire)
-                        err = GI_E_INPUT;
-                        break;
-                    }
-                    if ((uint32_t)(P >> 11) != k) {  // one piece further: piece k + 2 takes the place of piece k
-                        w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = ahead;
-                        k++;
-                        ahead = b.load_piece((k + 2u) * 256u, lane);
-                        gi_lds_sync();
-                    }
-                    const uint32_t q = (uint32_t)(P & 4095u) + (uint32_t)lane;  // this lane's bit offset inside the 512 staged bytes
-                    const uint32_t d0 = q >> 5, sh = q & 31u;
-                    const uint32_t x0 = w.cbuf[d0 & 127u], x1 = w.cbuf[(d0 + 1u) & 127u], x2 = w.cbuf[(d0 + 2u) & 127u];
-                    uint32_t kind, t, olen, dist, lit;
-                    gi_token(w, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), kind, t, olen, dist, lit);
-                    // which lanes are token starts: lane 0 is one, and every token names the next
-                    const bool stop = kind == GI_EOB || kind == GI_BAD;
-                    const uint32_t step = stop ? 64u : t;  // (an end marker ends the walk)
-                    u64 chain = 0;
-                    uint32_t at = 0;
-                    for (int hop = 0; hop < 64 && at < 64u; hop++) {  // (a token has at least one bit)
-                        chain |= 1ULL << at;
-                        at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
-                    }
-                    uint32_t adv = at;  // bits of this group
-                    if ((__ballot(stop) & chain) != 0) {  // the chain's last token is an end marker
-                        const int el = 63 - __builtin_clzll(chain);
-                        if ((uint32_t)__builtin_amdgcn_readlane((int)kind, el) == GI_BAD) {
-                            err = GI_E_CODE;
-                            break;
-                        }
-                        eob = true;
-                        adv = (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)t, el);
-                    }
-                    const bool on = GI_ON(chain);
-                    const uint32_t ol = on ? olen : 0u;
-                    const uint32_t incl = gi_scan_incl(ol);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    const uint32_t mpos = pos + (incl - ol);  // where this lane's token writes
-                    if (pos + total > cap) {
-                        err = GI_E_OVERRUN;
-                        break;
-                    }
-                    const bool is_match = on && kind == GI_LEN;
-                    const u64 mm = __ballot(is_match);
-                    if (mm != 0 && __ballot(is_match && dist > mpos) != 0) {
-                        err = GI_E_DIST;
-                        break;
-                    }
-                    if (on && kind == GI_LIT) {
-                        dst[mpos] = (uint8_t)lit;
-                        w.ring[mpos & RM] = (uint8_t)lit;
-                    }
-                    if (mm != 0) {
-                        gi_lds_sync();
-                        // Nothing this group writes lands on a ring slot whose old byte a match with dist + total + 64 <= GI_RING
-                        // still reads (the slot of byte p is reused by byte p + GI_RING).
-                        const uint32_t from = mpos - dist;
-                        // side by side: short, not overlapping, source in the ring and in front of the group's first byte
-                        const bool par = is_match && olen <= GI_PAR_MAX && dist >= olen && dist + total + 64u <= GI_RING && (mpos - pos) + olen <= dist;
-                        const u64 pm = __ballot(par);
-                        if (pm != 0) {
-                            for (uint32_t i = 0; i < GI_PAR_MAX; i++) {
-                                const bool go = par && i < olen;
-                                if (__ballot(go) == 0) break;
-                                if (go) {
-                                    const uint8_t c = w.ring[(from + i) & RM];
-                                    dst[mpos + i] = c;
-                                    w.ring[(mpos + i) & RM] = c;
-                                }
-                            }
-                            gi_lds_sync();
-                        }
-                        for (u64 sm = mm & ~pm; sm != 0; sm &= sm - 1) {  // the others in order, all lanes on one match
-                            const int ml = __builtin_ctzll(sm);
-                            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)olen, ml), dd = (uint32_t)__builtin_amdgcn_readlane((int)dist, ml);
-                            const uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)mpos, ml), fr = mp - dd;
-                            if (dd + total + 64u <= GI_RING) {
-                                if (dd == 1) {  // a run of one byte
-                                    const uint8_t c = w.ring[fr & RM];
-                                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                                        dst[mp + i] = c;
-                                        w.ring[(mp + i) & RM] = c;
-                                    }
-                                } else {
-                                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                                        const uint8_t c = w.ring[(fr + (dd >= len ? i : i % dd)) & RM];
-                                        dst[mp + i] = c;
-                                        w.ring[(mp + i) & RM] = c;
-                                    }
-                                }
-                                gi_lds_sync();
-                            } else {
-                                if (fr + (len < dd ? len : dd) > visible) {  // the source reaches into bytes this wave stored since its last wait
-                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                    visible = mp;
-                                }
-                                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                                    const uint8_t c = dst[fr + (dd >= len ? i : i % dd)];
-                                    dst[mp + i] = c;
-                                    w.ring[(mp + i) & RM] = c;
-                                }
-                                gi_lds_sync();
-                            }
-                        }
-                    }
-                    pos += total;
-                    P += adv;
-                }
-                if (err != GI_OK) break;
-                b.seek_bit(P, lane);
-                continue;  // the next block
-            }
-            // ---- one symbol at a time (a code that did not fit the tables; GS_INFLATE_FORCE_SLOW).  Literals wait in `pbyte` (lane j:
-            // the j-th pending byte) and are stored 62..64 at a time; whether they fit the member's announced size is checked when
-            // they are stored (flush), not per literal.
-            const uint32_t tlimit = blk.in_len / 4u + 4u;  // dwords the reader may take before the stream has run off its payload
-            for (;;) {
-                if (b.bc <= 32) {
-                    b.refill(lane);
-                    if (b.taken > tlimit) {
-                        err = GI_E_INPUT;
-                        break;
-                    }
-                }
-                const uint32_t e = lfast ? gi_lookup(w.ltab, w.ldesc, GI_LROOT, b) : gi_slow(w.lcount, w.lwork, 0, b);
-                const uint32_t kind = e >> 16;
-                if ((e & 15u) == 0) {
-                    err = GI_E_CODE;
-                    break;
-                }
-                b.drop((int)(e & 15u));
-                if (kind == GI_LIT) {
-                    if ((uint32_t)lane == npend) pbyte = (e >> 4) & 0xffu;
-                    npend++;
-                    pos++;
-                    if (npend >= 63) {
-                        if (pos > cap) {
-                            err = GI_E_OVERRUN;
-                            break;
-                        }
-                        flush();
-                    }
-                    continue;
-                }
-                if (kind == GI_EOB) break;
-                if (kind != GI_LEN) {
-                    err = GI_E_CODE;
-                    break;
-                }
-                uint32_t lbase, lextra, dbase, dextra;
-                gi_len_sym((e >> 4) & 31u, lbase, lextra);
-                const uint32_t len = lbase + b.get((int)lextra);
-                b.refill(lane);
-                const uint32_t d = dfast ? gi_lookup(w.dtab, w.ddesc, GI_DROOT, b) : gi_slow(w.dcount, w.dwork, 1, b);
-                if ((d >> 16) != GI_DIST || (d & 15u) == 0) {
-                    err = GI_E_CODE;
-                    break;
-                }
-                b.drop((int)(d & 15u));
-                gi_dist_sym((d >> 4) & 31u, dbase, dextra);
-                const uint32_t dist = dbase + b.get((int)dextra);
-                if (dist > pos) {
-                    err = GI_E_DIST;
-                    break;
-                }
-                if (pos + len > cap) {
-                    err = GI_E_OVERRUN;
-                    break;
-                }
-                flush();
-                const uint32_t from = pos - dist;
-                if (dist <= GI_RING - 64u) {
-                    // the source lies in the ring (every source byte is in front of `pos`, and a byte is overwritten GI_RING
-                    // bytes later: not by this copy).  LDS operations of a wave execute in order: the barrier is for the compiler.
-                    gi_lds_sync();
-                    if (dist >= len) {  // the usual case: source and destination do not overlap
-                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                            const uint8_t c = w.ring[(from + i) & RM];
-                            dst[pos + i] = c;
-                            w.ring[(pos + i) & RM] = c;
-                        }
-                    } else if (dist == 1) {  // a run of one byte
-                        const uint8_t c = w.ring[from & RM];
-                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                            dst[pos + i] = c;
-                            w.ring[(pos + i) & RM] = c;
-                        }
-                    } else {  // the pattern of `dist` bytes repeats
-                        for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                            const uint8_t c = w.ring[(from + i % dist) & RM];
-                            dst[pos + i] = c;
-                            w.ring[(pos + i) & RM] = c;
-                        }
-                    }
-                    gi_lds_sync();
-                } else {
-                    if (from + (len < dist ? len : dist) > visible) {  // the source reaches into bytes this wave stored since its last wait
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        visible = pos;
-                    }
-                    // (dist > GI_RING - 64 >= len is not guaranteed for a small ring: keep the general form)
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                        const uint8_t c = dst[from + (dist >= len ? i : i % dist)];
-                        dst[pos + i] = c;
-                        w.ring[(pos + i) & RM] = c;
-                    }
-                }
-                pos += len;
-            }
-        }
-        if (err == GI_OK && pos > cap) err = GI_E_OVERRUN;
-        if (err == GI_OK) flush();
+        uint32_t pos = 0;
+        err = gi_decode_blocks<false>(w, s_ring[wib], b, blk.in_len, 0, true, dst, cap, force_slow, lane, &pos);
         if (err == GI_OK && pos != cap) err = GI_E_SIZE;
         if (err == GI_OK && b.consumed() > (u64)blk.in_len * 8u) err = GI_E_INPUT;
         if (err == GI_OK && cap > 0) {  // CRC-32 of the text: 64 equal slices, then crc = crc_0 * x^(8 (n - s)) + crc_1 * x^(8 (n - 2s)) + ...
