@@ -420,6 +420,86 @@ struct GiBlock {
     uint32_t pad;
 };
 
+// the header of a dynamic block behind its three type bits: code length code, the lengths of the two codes, their tables
+// (GI_OK, or what is wrong with it -- the block finder of a single-member stream lives off the second answer)
+__device__ int gi_dynamic_header(GiWave &w, GiBits &b, int lane, bool *lfast_out, bool *dfast_out) {
+    bool lfast = true, dfast = true;
+    b.refill(lane);
+    const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+    if (hlit > 286 || hdist > 30) {
+        return GI_E_HEADER;
+    }
+    for (int s = lane; s < 19; s += 64) w.lens[s] = 0;
+    gi_lds_sync();
+    for (int i = 0; i < hclen; i++) {
+        b.refill(lane);
+        const uint32_t v = b.get(3);
+        if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
+    }
+    gi_lds_sync();
+    bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
+    if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
+        return GI_E_TABLE;
+    }
+    int at = 0, prev = 0;
+    const int total = hlit + hdist;
+    // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
+    while (at < total) {
+        b.refill(lane);
+        const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
+        if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
+            return GI_E_CODE;
+        }
+        b.drop((int)(e & 15u));
+        const int sym = (int)((e >> 4) & 0xffu);
+        int rep = 1, val = sym;
+        if (sym == 16) {
+            if (at == 0) return GI_E_CODE;
+            rep = 3 + (int)b.get(2);
+            val = prev;
+        } else if (sym == 17) {
+            rep = 3 + (int)b.get(3);
+            val = 0;
+        } else if (sym == 18) {
+            rep = 11 + (int)b.get(7);
+            val = 0;
+        }
+        if (at + rep > total) {
+            return GI_E_CODE;
+        }
+        // literal / length lengths at lens[24 + i] for now, distance lengths behind them
+        for (int r = lane; r < rep; r += 64) w.lens[24 + at + r] = (uint8_t)val;
+        at += rep;
+        prev = val;
+    }
+    gi_lds_sync();
+    {   // into place: lens[0 .. 288) literal / length (unused ones 0), lens[288 .. 320) distances
+        uint8_t mine[5];
+        for (int q = 0; q < 5; q++) {
+            const int s = lane + 64 * q;  // 0 .. 319
+            uint8_t v = 0;
+            if (s < 288) {
+                if (s < hlit) v = w.lens[24 + s];
+            } else if (s - 288 < hdist)
+                v = w.lens[24 + hlit + (s - 288)];
+            mine[q] = v;
+        }
+        gi_lds_sync();
+        for (int q = 0; q < 5; q++) w.lens[lane + 64 * q] = mine[q];
+        gi_lds_sync();
+    }
+    if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
+        return GI_E_TABLE;
+    }
+    if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+        !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
+        return GI_E_TABLE;
+    }
+    *lfast_out = lfast;
+    *dfast_out = dfast;
+    return GI_OK;
+}
+
 // ---- the blocks of one unit of work, from the reader's position: a BGZF member to its final block (MARK = false: bytes), or a
 // SEGMENT of a single-member stream from one block boundary to the next one that was found (MARK = true, gi_segment_kernel:
 // 16-bit symbols; what a match copies from in front of the segment is a MARKER 0x8000 | window position, resolved later --
@@ -508,87 +588,8 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                 break;
             }
         } else {  // dynamic codes
-            b.refill(lane);
-            const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
-            if (hlit > 286 || hdist > 30) {
-                err = GI_E_HEADER;
-                break;
-            }
-            for (int s = lane; s < 19; s += 64) w.lens[s] = 0;
-            gi_lds_sync();
-            for (int i = 0; i < hclen; i++) {
-                b.refill(lane);
-                const uint32_t v = b.get(3);
-                if (lane == 0) w.lens[gi_cl_order[i]] = (uint8_t)v;
-            }
-            gi_lds_sync();
-            bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
-            if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
-                err = GI_E_TABLE;
-                break;
-            }
-            int at = 0, prev = 0;
-            const int total = hlit + hdist;
-            // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
-            while (at < total && err == GI_OK) {
-                b.refill(lane);
-                const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
-                if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
-                    err = GI_E_CODE;
-                    break;
-                }
-                b.drop((int)(e & 15u));
-                const int sym = (int)((e >> 4) & 0xffu);
-                int rep = 1, val = sym;
-                if (sym == 16) {
-                    if (at == 0) {
-                        err = GI_E_CODE;
-                        break;
-                    }
-                    rep = 3 + (int)b.get(2);
-                    val = prev;
-                } else if (sym == 17) {
-                    rep = 3 + (int)b.get(3);
-                    val = 0;
-                } else if (sym == 18) {
-                    rep = 11 + (int)b.get(7);
-                    val = 0;
-                }
-                if (at + rep > total) {
-                    err = GI_E_CODE;
-                    break;
-                }
-                // literal / length lengths at lens[24 + i] for now, distance lengths behind them
-                for (int r = lane; r < rep; r += 64) w.lens[24 + at + r] = (uint8_t)val;
-                at += rep;
-                prev = val;
-            }
+            err = gi_dynamic_header(w, b, lane, &lfast, &dfast);
             if (err != GI_OK) break;
-            gi_lds_sync();
-            {   // into place: lens[0 .. 288) literal / length (unused ones 0), lens[288 .. 320) distances
-                uint8_t mine[5];
-                for (int q = 0; q < 5; q++) {
-                    const int s = lane + 64 * q;  // 0 .. 319
-                    uint8_t v = 0;
-                    if (s < 288) {
-                        if (s < hlit) v = w.lens[24 + s];
-                    } else if (s - 288 < hdist)
-                        v = w.lens[24 + hlit + (s - 288)];
-                    mine[q] = v;
-                }
-                gi_lds_sync();
-                for (int q = 0; q < 5; q++) w.lens[lane + 64 * q] = mine[q];
-                gi_lds_sync();
-            }
-            if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
-                err = GI_E_TABLE;
-                break;
-            }
-            if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
-                !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
-                err = GI_E_TABLE;
-                break;
-            }
         }
         if (force_slow & 1) lfast = dfast = false;  // (test hook: every code through the canonical decoder)
         if (lfast && dfast) {
@@ -882,6 +883,169 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         // changed; the barrier at the top is there for the same reason.)
         status[bi] = err;
     }
+}
+
+// =====================================================================================================================
+// A single-member gzip stream (gzip, pigz: what every sequencer pipeline writes) on the device.  Its deflate blocks follow each other
+// at arbitrary BIT positions and every match may reach 32 KiB back, so the stream is taken apart the way pugz / rapidgzip do it on
+// CPU threads:
+//   1. gi_find_kernel: one wave per 64 KiB of the compressed stream looks for the first bit offset at which a non-final DYNAMIC
+//      block starts -- 64 offsets at a time through the cheap tests (type bits, code counts, a complete code-length code: one offset
+//      in ~2 000 passes), the survivors through the whole header (gi_dynamic_header: both codes must be complete);
+//   2. gi_segment_kernel: one wave per SEGMENT (from one found block to the next) decodes to 16-bit symbols; what a match takes from in
+//      front of the segment is a marker 0x8000 | window position; a segment must END exactly where the next one starts (else the
+//      finder was fooled: the whole stream goes back to the host decoders);
+//   3. gi_windows_kernel: the last 32 KiB of every segment, markers replaced through the window of the segment before -- the one
+//      sequential step, one workgroup walking the segments;
+//   4. gi_resolve_kernel: every segment's symbols to bytes (markers through the window in front of it), at its place in the text;
+//   5. the CRC-32 of the text per 64 KiB tile (gi_crc_kernel), combined on the host, against the member's trailer.
+// =====================================================================================================================
+struct GiSeg {
+    u64 start_bit;     // of the segment's first block, from the first byte of the deflate stream
+    u64 stop_bit;      // where the next segment starts (unused for the last one)
+    u64 out_off;       // first symbol of the segment in the symbol buffer (GI_WINDOW marker symbols lie in front of it)
+    uint32_t out_cap;  // symbols it may produce
+    uint32_t to_final; // the last segment: to the stream's final block
+};
+
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
+                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk) {
+    __shared__ GiWave s_w[GI_WAVES];
+    const int lane = gi_lane();
+    const int wib = (int)gi_uni(threadIdx.x >> 6);
+    GiWave &w = s_w[wib];
+    typedef uint32_t __attribute__((aligned(1))) u32_any;
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long take = 0;
+        if (lane == 0) take = atomicAdd(next_chunk, 1ULL);
+        const int64_t ci = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
+        if (ci >= n_chunks) break;
+        u64 found = ~0ULL;
+        const u64 lo = (u64)ci * chunk_bytes * 8u;
+        u64 hi = lo + (u64)chunk_bytes * 8u;
+        if (hi > (u64)in_len * 8u) hi = (u64)in_len * 8u;
+        for (u64 o0 = lo; o0 < hi && found == ~0ULL; o0 += 64) {
+            const u64 o = o0 + (u64)lane;
+            // the 96 bits at this lane's offset (the buffer has slack behind the stream)
+            const uint8_t *p = in + ((o >> 5) << 2);
+            const uint32_t d0 = *reinterpret_cast<const u32_any *>(p), d1 = *reinterpret_cast<const u32_any *>(p + 4);
+            const uint32_t d2 = *reinterpret_cast<const u32_any *>(p + 8), d3 = *reinterpret_cast<const u32_any *>(p + 12);
+            const uint32_t sh = (uint32_t)o & 31u;
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+            // not final, dynamic, at most 286 / 30 codes, and the code length code is complete (Kraft sum exactly one)
+            bool ok = o < hi && (w0 & 7u) == 4u && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u;
+            const uint32_t hclen = ((w0 >> 13) & 15u) + 4u;
+            const u64 a = ((u64)w1 << 32 | w0) >> 17;   // 47 bits: 15 lengths
+            const u64 c = ((u64)w2 << 32 | w1) >> 30;   // from bit 62: lengths 15 .. 18
+            uint32_t kraft = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 19; i++) {
+                const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
+                kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
+            }
+            ok = ok && kraft == 128u;
+            for (u64 cand = __ballot(ok); cand != 0 && found == ~0ULL; cand &= cand - 1) {  // the whole header, in offset order
+                const u64 oc = o0 + (u64)__builtin_ctzll(cand);
+                GiBits b;
+                b.in = in;
+                b.in_len = in_len;
+                b.seek_bit(oc + 3, lane);
+                bool lf, df;
+                if (gi_dynamic_header(w, b, lane, &lf, &df) == GI_OK && lf && df) found = oc;
+            }
+        }
+        start_bit[ci] = found;  // (every lane the same word)
+    }
+}
+
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
+                                                                                                           uint16_t *sym, int32_t *status, uint32_t *out_len,
+                                                                                                           unsigned long long *next_seg) {
+    __shared__ GiWave s_w[GI_WAVES];
+    __shared__ uint16_t s_ring[GI_WAVES][GI_RING];
+    const int lane = gi_lane();
+    const int wib = (int)gi_uni(threadIdx.x >> 6);
+    GiWave &w = s_w[wib];
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long take = 0;
+        if (lane == 0) take = atomicAdd(next_seg, 1ULL);
+        const int64_t si = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
+        if (si >= n_segs) break;
+        const GiSeg seg = segs[si];
+        uint16_t *const dst = sym + seg.out_off;
+        // the unknown window in front of the segment: markers, in memory and in the ring
+        for (uint32_t j = (uint32_t)lane; j < GI_WINDOW; j += 64) dst[(int32_t)j - (int32_t)GI_WINDOW] = (uint16_t)(0x8000u | j);
+        for (uint32_t j = (uint32_t)lane; j < GI_RING; j += 64) s_ring[wib][j] = (uint16_t)(0x8000u | (GI_WINDOW - GI_RING + j));
+        gi_lds_sync();
+        GiBits b;
+        b.in = in;
+        b.in_len = in_len;
+        b.seek_bit(seg.start_bit, lane);
+        uint32_t pos = 0;
+        const int err = gi_decode_blocks<true>(w, s_ring[wib], b, in_len, seg.stop_bit, seg.to_final != 0, dst, seg.out_cap, 0, lane, &pos);
+        status[si] = err;
+        out_len[si] = pos;
+    }
+}
+
+// win[i]: the last GI_WINDOW bytes of the text up to the end of segment i
+__global__ __launch_bounds__(1024) void gi_windows_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, int64_t n_segs, uint8_t *win) {
+    for (int64_t i = 0; i < n_segs; i++) {
+        const uint16_t *dst = sym + segs[i].out_off;
+        const int64_t n = (int64_t)out_len[i];
+        const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : nullptr;
+        uint8_t *cur = win + (size_t)i * GI_WINDOW;
+        for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 1024) {
+            const uint16_t v = dst[n - (int64_t)GI_WINDOW + (int64_t)j];  // (in front of the segment: its marker prefix)
+            cur[j] = v < 0x8000u ? (uint8_t)v : (prev ? prev[v & 0x7fffu] : (uint8_t)0);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gi_resolve_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, const u64 *text_off, int64_t n_segs,
+                                                         const uint8_t *win, uint8_t *text) {
+    for (int64_t i = blockIdx.y; i < n_segs; i += gridDim.y) {
+        const uint16_t *dst = sym + segs[i].out_off;
+        const uint32_t n = out_len[i];
+        const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : nullptr;
+        uint8_t *out = text + text_off[i];
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+            const uint16_t v = dst[j];
+            out[j] = v < 0x8000u ? (uint8_t)v : (prev ? prev[v & 0x7fffu] : (uint8_t)0);
+        }
+    }
+}
+
+// raw CRC-32 register (no pre / post inversion) over tile t of `tile` bytes: the host combines them
+__global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t *text, int64_t n, uint32_t tile, uint32_t *crc) {
+    __shared__ uint32_t s_crc[4 * 256];
+    for (int i = (int)threadIdx.x; i < 4 * 256; i += 256) s_crc[i] = gi_crc_table[i];
+    __syncthreads();
+    const int lane = gi_lane();
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t base = t * (int64_t)tile;
+    if (base >= n) return;
+    const uint32_t cap = (uint32_t)(n - base < (int64_t)tile ? n - base : (int64_t)tile);
+    const uint8_t *dst = text + base;
+    const uint32_t slice = ((cap + 63u) / 64u + 3u) & ~3u;
+    const uint32_t lo = (uint32_t)lane * slice, hi = lo + slice < cap ? lo + slice : cap;
+    uint32_t c = 0;
+    uint32_t i = lo;
+    for (; i + 4u <= hi && lo < cap; i += 4) {
+        uint32_t v;
+        memcpy(&v, dst + i, 4);
+        c ^= v;
+        c = s_crc[768 + (c & 0xffu)] ^ s_crc[512 + ((c >> 8) & 0xffu)] ^ s_crc[256 + ((c >> 16) & 0xffu)] ^ s_crc[c >> 24];
+    }
+    for (; i < hi && lo < cap; i++) c = s_crc[(c ^ dst[i]) & 0xffu] ^ (c >> 8);
+    const uint32_t behind = hi < cap ? cap - hi : 0;
+    uint32_t part = (lo < cap) ? gi_gf_mul(c, gi_x_pow_8n(behind)) : 0u;
+    for (int o = 32; o >= 1; o >>= 1) part ^= (uint32_t)__shfl_xor((int)part, o);
+    if (lane == 0) crc[t] = part;
 }
 
 // ---- the four-line cut: newlines per 4 KiB tile, then (one workgroup) the offset of the last newline whose count is a multiple of 4
@@ -1279,6 +1443,235 @@ extern "C" int gs_inflater_fetch(gs_inflater *g, uint8_t *out, int64_t n_bytes) 
     if (g->last_text == nullptr || n_bytes > g->last_bytes) return gi_fail(GS_E_STATE, "more bytes than the last feed returned");
     GI_TRY(hipSetDevice(g->device));
     GI_TRY(hipMemcpy(out, g->last_text, (size_t)n_bytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+// ---- single-member gzip on the device (kernels above: gi_find_kernel .. gi_crc_kernel)
+static uint32_t gi_h_gf_mul(uint32_t a, uint32_t b) {  // (the device functions gi_gf_mul / gi_x_pow_8n again, for the host)
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? 0xedb88320u : 0u);
+    }
+    return p;
+}
+static uint32_t gi_h_x_pow_8n(uint64_t n) {
+    uint32_t r = 0x80000000u, sq = 0x00800000u;
+    while (n) {
+        if (n & 1u) r = gi_h_gf_mul(r, sq);
+        sq = gi_h_gf_mul(sq, sq);
+        n >>= 1;
+    }
+    return r;
+}
+
+struct GiDevBufs {  // freed on every way out
+    std::vector<void *> p;
+    template <typename T>
+    hipError_t get(T **q, size_t bytes) {
+        void *v = nullptr;
+        const hipError_t e = hipMalloc(&v, bytes ? bytes : 1);
+        if (e == hipSuccess) p.push_back(v);
+        *q = static_cast<T *>(v);
+        return e;
+    }
+    void keep(void *v) { p.erase(std::remove(p.begin(), p.end(), v), p.end()); }
+    ~GiDevBufs() {
+        for (void *v : p) hipFree(v);
+    }
+};
+
+extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text_out, int64_t *n_text, int64_t info[4]) {
+    if (!gz || !d_text_out || !n_text || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
+    *d_text_out = nullptr;
+    *n_text = 0;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
+    // the member's header (RFC 1952)
+    if (gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) return gi_fail(GS_E_INVALID, "not a gzip stream");
+    const int flg = gz[3];
+    int64_t hdr = 10;
+    if (flg & 4) {
+        if (hdr + 2 > n) return gi_fail(GS_E_INVALID, "truncated gzip header");
+        hdr += 2 + ((int64_t)gz[hdr] | ((int64_t)gz[hdr + 1] << 8));
+    }
+    for (int bit : {8, 16})
+        if (flg & bit) {
+            while (hdr < n && gz[hdr] != 0) hdr++;
+            hdr++;
+        }
+    if (flg & 2) hdr += 2;
+    if (hdr + 8 >= n) return gi_fail(GS_E_INVALID, "truncated gzip stream");
+    const int64_t in_len64 = n - hdr - 8;
+    if (in_len64 > ((int64_t)1 << 30)) return gi_fail(GS_E_UNSUPPORTED, "more than 1 GiB of compressed data: host decoders");
+    const uint32_t in_len = (uint32_t)in_len64;
+    const uint8_t *trailer = gz + n - 8;
+    const uint32_t want_crc = (uint32_t)trailer[0] | ((uint32_t)trailer[1] << 8) | ((uint32_t)trailer[2] << 16) | ((uint32_t)trailer[3] << 24);
+    const uint32_t want_isize = (uint32_t)trailer[4] | ((uint32_t)trailer[5] << 8) | ((uint32_t)trailer[6] << 16) | ((uint32_t)trailer[7] << 24);
+    GI_TRY(hipSetDevice(device));
+    int rc = gi_upload_crc_table();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    uint32_t chunk = 65536;
+    if (const char *e = getenv("GS_GUNZIP_CHUNK")) chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
+    uint32_t ratio = 16;
+    if (const char *e = getenv("GS_GUNZIP_RATIO")) ratio = (uint32_t)std::max(2, std::min(1024, atoi(e)));
+    const int64_t n_chunks = ((int64_t)in_len + chunk - 1) / chunk;
+    GiDevBufs bufs;
+    uint8_t *d_in = nullptr;
+    u64 *d_start = nullptr;
+    unsigned long long *d_q = nullptr;
+    hipError_t e = bufs.get(&d_in, (size_t)in_len + 1024);
+    if (e == hipSuccess) e = bufs.get(&d_start, sizeof(u64) * (size_t)n_chunks);
+    if (e == hipSuccess) e = bufs.get(&d_q, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMemset(d_in + in_len, 0, 1024);
+    if (e == hipSuccess) e = hipMemcpy(d_in, gz + hdr, in_len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_q, 0, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMemset(d_start, 0xff, sizeof(u64) * (size_t)n_chunks);
+    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
+    const int wgs = n_cu * gi_wgs_per_cu();
+    // 1. block starts (chunk 0 starts with the stream)
+    if (n_chunks > 1) {
+        unsigned long long one = 1;
+        GI_TRY(hipMemcpy(d_q, &one, sizeof(one), hipMemcpyHostToDevice));  // (the counter starts at chunk 1)
+        hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len,
+                           chunk, n_chunks, d_start, d_q);
+        GI_TRY(hipGetLastError());
+    }
+    std::vector<u64> starts((size_t)n_chunks);
+    GI_TRY(hipMemcpy(starts.data(), d_start, sizeof(u64) * (size_t)n_chunks, hipMemcpyDeviceToHost));
+    starts[0] = 0;
+    std::vector<GiSeg> segs;
+    u64 sym_total = 0;
+    for (int64_t c = 0; c < n_chunks; c++) {
+        if (starts[(size_t)c] == ~0ULL) continue;
+        if (!segs.empty()) segs.back().stop_bit = starts[(size_t)c];
+        GiSeg sg{};
+        sg.start_bit = starts[(size_t)c];
+        segs.push_back(sg);
+    }
+    for (size_t i = 0; i < segs.size(); i++) {
+        const u64 end = i + 1 < segs.size() ? segs[i].stop_bit : (u64)in_len * 8u;
+        const u64 span = (end - segs[i].start_bit) / 8u + 1u;
+        const u64 cap = span * ratio + 65536u;
+        if (cap > 0xffff0000ull) return gi_fail(GS_E_UNSUPPORTED, "a segment of more than 4 G symbols");
+        segs[i].to_final = i + 1 == segs.size();
+        segs[i].out_cap = (uint32_t)cap;
+        sym_total += GI_WINDOW;
+        segs[i].out_off = sym_total;
+        sym_total += cap;
+    }
+    const int64_t n_segs = (int64_t)segs.size();
+    // 2. segments
+    GiSeg *d_segs = nullptr;
+    uint16_t *d_sym = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_len = nullptr;
+    e = bufs.get(&d_segs, sizeof(GiSeg) * (size_t)n_segs);
+    if (e == hipSuccess) e = bufs.get(&d_sym, sizeof(uint16_t) * (size_t)sym_total + 64);
+    if (e == hipSuccess) e = bufs.get(&d_status, sizeof(int32_t) * (size_t)n_segs);
+    if (e == hipSuccess) e = bufs.get(&d_len, sizeof(uint32_t) * (size_t)n_segs);
+    if (e == hipSuccess) e = hipMemcpy(d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_segs + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, d_segs,
+                       n_segs, d_sym, d_status, d_len, d_q + 1);
+    GI_TRY(hipGetLastError());
+    std::vector<int32_t> st((size_t)n_segs);
+    std::vector<uint32_t> len((size_t)n_segs);
+    GI_TRY(hipMemcpy(st.data(), d_status, sizeof(int32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    GI_TRY(hipMemcpy(len.data(), d_len, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    std::vector<u64> off((size_t)n_segs + 1, 0);
+    for (int64_t i = 0; i < n_segs; i++) {
+        if (st[(size_t)i] == GI_E_SYNC || st[(size_t)i] == GI_E_OVERRUN)
+            return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + " of " + std::to_string(n_segs) + (st[(size_t)i] == GI_E_SYNC ? " does not end where the next one starts" : " outgrows its buffer") + ": host decoders");
+        if (st[(size_t)i] != GI_OK && i == 0) return gi_fail(GS_E_INVALID, "corrupt gzip stream (inflate status " + std::to_string(st[(size_t)i]) + " in the first segment)");
+        if (st[(size_t)i] != GI_OK) return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + ": inflate status " + std::to_string(st[(size_t)i]) + " (a damaged stream or a false block start): host decoders");
+        off[(size_t)i + 1] = off[(size_t)i] + len[(size_t)i];
+    }
+    const int64_t total = (int64_t)off[(size_t)n_segs];
+    if ((uint32_t)total != want_isize) return gi_fail(GS_E_UNSUPPORTED, "ISIZE does not match (several members, or a damaged stream): host decoders");
+    // 3. windows, 4. text
+    uint8_t *d_win = nullptr, *d_text = nullptr;
+    u64 *d_off = nullptr;
+    uint32_t *d_crc = nullptr;
+    const uint32_t tile = 65536;
+    const int64_t n_tiles = (total + tile - 1) / tile;
+    e = bufs.get(&d_win, (size_t)n_segs * GI_WINDOW);
+    if (e == hipSuccess) e = bufs.get(&d_text, (size_t)total + 8192);
+    if (e == hipSuccess) e = bufs.get(&d_off, sizeof(u64) * (size_t)n_segs);
+    if (e == hipSuccess) e = bufs.get(&d_crc, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_tiles, 1));
+    if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(u64) * (size_t)n_segs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
+    hipLaunchKernelGGL(gi_windows_kernel, dim3(1), dim3(1024), 0, 0, d_sym, d_segs, d_len, n_segs, d_win);
+    hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_segs, 16384)), dim3(256), 0, 0, d_sym, d_segs, d_len, d_off, n_segs, d_win, d_text);
+    if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, d_text, total, tile, d_crc);
+    GI_TRY(hipGetLastError());
+    std::vector<uint32_t> crc((size_t)std::max<int64_t>(n_tiles, 1), 0);
+    GI_TRY(hipMemcpy(crc.data(), d_crc, sizeof(uint32_t) * (size_t)n_tiles, hipMemcpyDeviceToHost));
+    // 5. the tiles' registers behind one another: R = 0xffffffff x^(8 n) + sum_t R_t x^(8 bytes behind tile t)
+    uint32_t reg = gi_h_gf_mul(0xffffffffu, gi_h_x_pow_8n((uint64_t)total));
+    const uint32_t x_tile = gi_h_x_pow_8n(tile);
+    uint32_t xp = 0x80000000u;  // x^0: the last tile has nothing behind it
+    for (int64_t t = n_tiles - 1; t >= 0; t--) {
+        reg ^= gi_h_gf_mul(crc[(size_t)t], xp);
+        xp = gi_h_gf_mul(xp, t == n_tiles - 1 ? gi_h_x_pow_8n((uint64_t)(total - t * (int64_t)tile)) : x_tile);  // (the tile's own bytes join what lies behind the next one)
+    }
+    if ((reg ^ 0xffffffffu) != want_crc) return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
+    bufs.keep(d_text);
+    *d_text_out = d_text;
+    *n_text = total;
+    if (info) {
+        info[0] = n_segs;
+        info[1] = n_chunks;
+        info[2] = (int64_t)sym_total;
+        info[3] = 0;
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_gunzip_free(int device, uint8_t *d_text) {
+    if (!d_text) return GS_OK;
+    GI_TRY(hipSetDevice(device));
+    GI_TRY(hipFree(d_text));
+    return GS_OK;
+}
+
+extern "C" int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_text, int64_t info[4]) {
+    if (!n_text) return gi_fail(GS_E_INVALID, "NULL argument");
+    uint8_t *d_text = nullptr;
+    int rc = gs_gunzip_plan_device(device, gz, n, &d_text, n_text, info);
+    if (rc) return rc;
+    if (*n_text > out_cap || (*n_text > 0 && !out)) {
+        hipFree(d_text);
+        return gi_fail(GS_E_INVALID, "output buffer too small");
+    }
+    const hipError_t e = *n_text > 0 ? hipMemcpy(out, d_text, (size_t)*n_text, hipMemcpyDeviceToHost) : hipSuccess;
+    hipFree(d_text);
+    if (e != hipSuccess) return gi_fail(GS_E_HIP, std::string("gs_gunzip_device: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+
+extern "C" int gs_text_cut_device(int device, const uint8_t *d_text, int64_t n, int64_t *n_lines, int64_t *cut) {
+    if (!n_lines || !cut || n < 0 || (n > 0 && !d_text)) return gi_fail(GS_E_INVALID, "bad argument");
+    *n_lines = 0;
+    *cut = 0;
+    if (n == 0) return GS_OK;
+    GI_TRY(hipSetDevice(device));
+    const int64_t n_tiles = (n + 4095) / 4096;
+    GiDevBufs bufs;
+    uint32_t *d_tiles = nullptr;
+    u64 *d_cut = nullptr;
+    hipError_t e = bufs.get(&d_tiles, sizeof(uint32_t) * (size_t)n_tiles);
+    if (e == hipSuccess) e = bufs.get(&d_cut, 4 * sizeof(u64));
+    if (e != hipSuccess) return gi_fail(GS_E_NOMEM, "gs_text_cut_device");
+    hipLaunchKernelGGL(gi_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, 0, d_text, n, d_tiles);
+    hipLaunchKernelGGL(gi_cut_kernel, dim3(1), dim3(1024), 0, 0, d_text, n, d_tiles, n_tiles, d_cut);
+    u64 h[2] = {0, 0};
+    GI_TRY(hipMemcpy(h, d_cut, sizeof(h), hipMemcpyDeviceToHost));
+    *n_lines = (int64_t)h[0] & ~(int64_t)3;
+    *cut = (int64_t)h[1];
     return GS_OK;
 }
 

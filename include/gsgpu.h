@@ -499,6 +499,18 @@ int gs_inflate_members(int device, const uint8_t *file, const gs_inflate_member 
 int gs_inflater_create(gs_inflater **out, int device);
 int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_member *members, int64_t n_members, int64_t next_lo,
                      int64_t next_hi, int last, const uint8_t **text, int64_t *n_bytes, int64_t *n_lines, int64_t *tail_bytes);
+/* A SINGLE-MEMBER gzip stream (gzip, pigz) inflated on the device: block boundaries found speculatively, segments decoded side by
+ * side with markers for the unknown 32 KiB window, windows resolved in a second pass (gs_inflate_dev.hip), CRC-32 and ISIZE checked
+ * as java.util.zip.GZIPInputStream does (B/io/StreamProvider.java:92-100).  gs_gunzip_plan_device leaves the text in device memory
+ * (*d_text, released with gs_gunzip_free); gs_gunzip_device copies it to `out` (tests, tools).  GS_E_UNSUPPORTED: not a stream this
+ * path takes (several members, a segment that outgrows its buffer, a block boundary that was a mirage, > 1 GiB compressed) -- the
+ * caller inflates on the host instead; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).
+ * info (may be NULL): [0] segments, [1] chunks searched, [2] symbols, [3] reserved. */
+int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text, int64_t *n_text, int64_t info[4]);
+int gs_gunzip_free(int device, uint8_t *d_text);
+int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_text, int64_t info[4]);
+/* lines and the offset behind the last newline that closes a four-line record (count a multiple of four) in n bytes of device text */
+int gs_text_cut_device(int device, const uint8_t *d_text, int64_t n, int64_t *n_lines, int64_t *cut);
 int gs_inflater_tail(gs_inflater *inf, uint8_t *out, int64_t cap, int64_t *n);
 /* the first n_bytes of the text the LAST gs_inflater_feed returned, copied to host memory (page-locked for speed); synchronous.
  * For callers that need the text on the host as well -- the filter goal's writers (C/bloom/FastqBloomFilter.java:92-105 rewriteInput). */
