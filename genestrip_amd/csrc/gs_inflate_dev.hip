@@ -40,6 +40,9 @@
 #include "../../include/gsgpu.h"
 
 typedef unsigned long long u64;
+struct __attribute__((aligned(16))) gs_u16x8 {
+    uint16_t v[8];
+};
 
 #define GI_WAVES 4                 // waves per workgroup
 #define GI_LROOT 9                 // root bits of the literal / length table
@@ -909,7 +912,7 @@ struct GiSeg {
 };
 
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
-                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk) {
+                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk, int text_only) {
     __shared__ GiWave s_w[GI_WAVES];
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
@@ -952,7 +955,15 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 b.in_len = in_len;
                 b.seek_bit(oc + 3, lane);
                 bool lf, df;
-                if (gi_dynamic_header(w, b, lane, &lf, &df) == GI_OK && lf && df) found = oc;
+                if (gi_dynamic_header(w, b, lane, &lf, &df) == GI_OK && lf && df) {
+                    // FASTQ / FASTA are text: a block whose code gives a length to a byte >= 128 is not taken for a start (a bit pattern
+                    // that parses as a header by chance -- about one per 100 MB -- does so with all but certainty; a real block
+                    // with such bytes is then simply not a segment boundary)
+                    bool high = false;
+                    if (text_only)
+                        for (int sidx = 128 + lane; sidx < 256; sidx += 64) high |= w.lens[sidx] != 0;
+                    if (__ballot(high) == 0) found = oc;
+                }
             }
         }
         start_bit[ci] = found;  // (every lane the same word)
@@ -990,19 +1001,53 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-// win[i]: the last GI_WINDOW bytes of the text up to the end of segment i
-__global__ __launch_bounds__(1024) void gi_windows_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, int64_t n_segs, uint8_t *win) {
+// win[i]: the last GI_WINDOW bytes of the text up to the end of segment i.  gi_window_prep_kernel copies every segment's last GI_WINDOW
+// symbols into an array of their own (side by side); then ONE workgroup walks the segments in order -- the only sequential step of the
+// whole decoder --, the window before in LDS, the symbols of the next segment already on their way: about a microsecond per segment.
+// (Repetitive text keeps its markers to the end of a segment -- every quality line is a copy of the one before --, so the walk has
+// to look at every slot; a list of the few slots that still hold markers was no faster.)
+__global__ __launch_bounds__(256) void gi_window_prep_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, int64_t n_segs, uint16_t *win16) {
+    const int64_t i = blockIdx.x;
+    if (i >= n_segs) return;
+    const uint16_t *dst = sym + segs[i].out_off;
+    const int64_t n = (int64_t)out_len[i];
+    uint16_t *cur = win16 + (size_t)i * GI_WINDOW;
+    for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 256) cur[j] = dst[n - (int64_t)GI_WINDOW + (int64_t)j];  // (in front of the segment: its marker prefix)
+}
+
+__global__ __launch_bounds__(1024) void gi_windows_kernel(const uint16_t *win16, int64_t n_segs, uint8_t *win) {
+    __shared__ uint8_t s_win[2][GI_WINDOW];
+    const uint32_t t = threadIdx.x;
+    // thread t owns the slots 8 t + 8192 q .. + 8 (q < 4): four 16-byte loads per segment
+    gs_u16x8 nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + 8u * t + 8192u * (uint32_t)q);
+    int p = 0;
     for (int64_t i = 0; i < n_segs; i++) {
-        const uint16_t *dst = sym + segs[i].out_off;
-        const int64_t n = (int64_t)out_len[i];
-        const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : nullptr;
-        uint8_t *cur = win + (size_t)i * GI_WINDOW;
-        for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 1024) {
-            const uint16_t v = dst[n - (int64_t)GI_WINDOW + (int64_t)j];  // (in front of the segment: its marker prefix)
-            cur[j] = v < 0x8000u ? (uint8_t)v : (prev ? prev[v & 0x7fffu] : (uint8_t)0);
+        gs_u16x8 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        if (i + 1 < n_segs) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)(i + 1) * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
         }
-        __threadfence_block();
+        uint8_t *out = win + (size_t)i * GI_WINDOW;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint8_t bytes[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint16_t v = cur[q].v[e];
+                bytes[e] = v < 0x8000u ? (uint8_t)v : (i ? s_win[p][v & 0x7fffu] : (uint8_t)0);  // (segment 0 starts the stream)
+            }
+            const uint32_t slot = 8u * t + 8192u * (uint32_t)q;
+            uint64_t pack;
+            memcpy(&pack, bytes, 8);
+            *reinterpret_cast<uint64_t *>(&s_win[p ^ 1][slot]) = pack;
+            *reinterpret_cast<uint64_t *>(out + slot) = pack;
+        }
         __syncthreads();
+        p ^= 1;
     }
 }
 
@@ -1514,8 +1559,10 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     if (rc) return rc;
     hipDeviceProp_t prop;
     const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    uint32_t chunk = 65536;
+    uint32_t chunk = 16384;  // (about one deflate block of zlib's at its usual levels: a segment is then ~100 KB of text, a few ms of a wave)
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
+    int text_only = 1;  // GS_GUNZIP_ANY_BYTES=1: block starts whose literal code covers bytes >= 128 count as well
+    if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) text_only = atoi(e) == 0;
     uint32_t ratio = 16;
     if (const char *e = getenv("GS_GUNZIP_RATIO")) ratio = (uint32_t)std::max(2, std::min(1024, atoi(e)));
     const int64_t n_chunks = ((int64_t)in_len + chunk - 1) / chunk;
@@ -1537,7 +1584,7 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
         unsigned long long one = 1;
         GI_TRY(hipMemcpy(d_q, &one, sizeof(one), hipMemcpyHostToDevice));  // (the counter starts at chunk 1)
         hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len,
-                           chunk, n_chunks, d_start, d_q);
+                           chunk, n_chunks, d_start, d_q, text_only);
         GI_TRY(hipGetLastError());
     }
     std::vector<u64> starts((size_t)n_chunks);
@@ -1570,7 +1617,9 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     int32_t *d_status = nullptr;
     uint32_t *d_len = nullptr;
     e = bufs.get(&d_segs, sizeof(GiSeg) * (size_t)n_segs);
-    if (e == hipSuccess) e = bufs.get(&d_sym, sizeof(uint16_t) * (size_t)sym_total + 64);
+    u64 sym_used = sym_total;
+    const u64 sym_room = sym_total + sym_total / 8 + ((u64)64 << 20);  // slack for segments that are decoded again (mirages, below)
+    if (e == hipSuccess) e = bufs.get(&d_sym, sizeof(uint16_t) * (size_t)sym_room + 64);
     if (e == hipSuccess) e = bufs.get(&d_status, sizeof(int32_t) * (size_t)n_segs);
     if (e == hipSuccess) e = bufs.get(&d_len, sizeof(uint32_t) * (size_t)n_segs);
     if (e == hipSuccess) e = hipMemcpy(d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs, hipMemcpyHostToDevice);
@@ -1582,15 +1631,72 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     std::vector<uint32_t> len((size_t)n_segs);
     GI_TRY(hipMemcpy(st.data(), d_status, sizeof(int32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
     GI_TRY(hipMemcpy(len.data(), d_len, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
-    std::vector<u64> off((size_t)n_segs + 1, 0);
-    for (int64_t i = 0; i < n_segs; i++) {
+    // A block start that was a mirage (a bit pattern that parses as a complete dynamic header: about one per 100 MB of compressed
+    // data) shows as the segment IN FRONT of it running past it: that segment is decoded again up to the start after the mirage,
+    // into the slack behind the symbols (the mirage's own segment is dropped).  A few rounds: two mirages may follow each other.
+    int64_t n_mirages = 0;
+    for (int round = 0; round < 4; round++) {
+        std::vector<GiSeg> redo;
+        std::vector<size_t> redo_at;
+        std::vector<GiSeg> kept;
+        std::vector<int32_t> kst;
+        std::vector<uint32_t> klen;
+        for (size_t i = 0; i < segs.size(); i++) {
+            if (st[i] == GI_E_SYNC && i + 1 < segs.size()) {
+                GiSeg m = segs[i];
+                const GiSeg &gone = segs[i + 1];
+                m.stop_bit = gone.stop_bit;
+                m.to_final = gone.to_final;
+                const u64 cap = (u64)m.out_cap + gone.out_cap;
+                if (cap > 0xffff0000ull || sym_used + GI_WINDOW + cap > sym_room) return gi_fail(GS_E_UNSUPPORTED, "no room to decode a segment again: host decoders");
+                m.out_cap = (uint32_t)cap;
+                sym_used += GI_WINDOW;
+                m.out_off = sym_used;
+                sym_used += cap;
+                redo.push_back(m);
+                redo_at.push_back(kept.size());
+                kept.push_back(m);
+                kst.push_back(GI_OK);
+                klen.push_back(0);
+                n_mirages++;
+                i++;  // (the segment behind the mirage is gone)
+            } else {
+                kept.push_back(segs[i]);
+                kst.push_back(st[i]);
+                klen.push_back(len[i]);
+            }
+        }
+        if (redo.empty()) break;
+        const int64_t n_redo = (int64_t)redo.size();
+        GI_TRY(hipMemcpy(d_segs, redo.data(), sizeof(GiSeg) * (size_t)n_redo, hipMemcpyHostToDevice));  // (the master copy goes back below)
+        GI_TRY(hipMemset(d_q + 1, 0, sizeof(u64)));
+        hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_redo + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, d_segs,
+                           n_redo, d_sym, d_status, d_len, d_q + 1);
+        GI_TRY(hipGetLastError());
+        std::vector<int32_t> rst((size_t)n_redo);
+        std::vector<uint32_t> rlen((size_t)n_redo);
+        GI_TRY(hipMemcpy(rst.data(), d_status, sizeof(int32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
+        GI_TRY(hipMemcpy(rlen.data(), d_len, sizeof(uint32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < redo.size(); r++) {
+            kst[redo_at[r]] = rst[r];
+            klen[redo_at[r]] = rlen[r];
+        }
+        segs.swap(kept);
+        st.swap(kst);
+        len.swap(klen);
+    }
+    const int64_t n_segs_final = (int64_t)segs.size();
+    GI_TRY(hipMemcpy(d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs_final, hipMemcpyHostToDevice));
+    GI_TRY(hipMemcpy(d_len, len.data(), sizeof(uint32_t) * (size_t)n_segs_final, hipMemcpyHostToDevice));
+    std::vector<u64> off((size_t)n_segs_final + 1, 0);
+    for (int64_t i = 0; i < n_segs_final; i++) {
         if (st[(size_t)i] == GI_E_SYNC || st[(size_t)i] == GI_E_OVERRUN)
-            return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + " of " + std::to_string(n_segs) + (st[(size_t)i] == GI_E_SYNC ? " does not end where the next one starts" : " outgrows its buffer") + ": host decoders");
+            return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + " of " + std::to_string(n_segs_final) + (st[(size_t)i] == GI_E_SYNC ? " does not end where the next one starts" : " outgrows its buffer") + ": host decoders");
         if (st[(size_t)i] != GI_OK && i == 0) return gi_fail(GS_E_INVALID, "corrupt gzip stream (inflate status " + std::to_string(st[(size_t)i]) + " in the first segment)");
         if (st[(size_t)i] != GI_OK) return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + ": inflate status " + std::to_string(st[(size_t)i]) + " (a damaged stream or a false block start): host decoders");
         off[(size_t)i + 1] = off[(size_t)i] + len[(size_t)i];
     }
-    const int64_t total = (int64_t)off[(size_t)n_segs];
+    const int64_t total = (int64_t)off[(size_t)n_segs_final];
     if ((uint32_t)total != want_isize) return gi_fail(GS_E_UNSUPPORTED, "ISIZE does not match (several members, or a damaged stream): host decoders");
     // 3. windows, 4. text
     uint8_t *d_win = nullptr, *d_text = nullptr;
@@ -1598,14 +1704,17 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     uint32_t *d_crc = nullptr;
     const uint32_t tile = 65536;
     const int64_t n_tiles = (total + tile - 1) / tile;
-    e = bufs.get(&d_win, (size_t)n_segs * GI_WINDOW);
+    uint16_t *d_win16 = nullptr;
+    e = bufs.get(&d_win, (size_t)n_segs_final * GI_WINDOW);
+    if (e == hipSuccess) e = bufs.get(&d_win16, sizeof(uint16_t) * (size_t)n_segs_final * GI_WINDOW);
     if (e == hipSuccess) e = bufs.get(&d_text, (size_t)total + 8192);
-    if (e == hipSuccess) e = bufs.get(&d_off, sizeof(u64) * (size_t)n_segs);
+    if (e == hipSuccess) e = bufs.get(&d_off, sizeof(u64) * (size_t)n_segs_final);
     if (e == hipSuccess) e = bufs.get(&d_crc, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_tiles, 1));
-    if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(u64) * (size_t)n_segs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(u64) * (size_t)n_segs_final, hipMemcpyHostToDevice);
     if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(gi_windows_kernel, dim3(1), dim3(1024), 0, 0, d_sym, d_segs, d_len, n_segs, d_win);
-    hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_segs, 16384)), dim3(256), 0, 0, d_sym, d_segs, d_len, d_off, n_segs, d_win, d_text);
+    hipLaunchKernelGGL(gi_window_prep_kernel, dim3((unsigned)n_segs_final), dim3(256), 0, 0, d_sym, d_segs, d_len, n_segs_final, d_win16);
+    hipLaunchKernelGGL(gi_windows_kernel, dim3(1), dim3(1024), 0, 0, d_win16, n_segs_final, d_win);
+    hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_segs_final, 16384)), dim3(256), 0, 0, d_sym, d_segs, d_len, d_off, n_segs_final, d_win, d_text);
     if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, d_text, total, tile, d_crc);
     GI_TRY(hipGetLastError());
     std::vector<uint32_t> crc((size_t)std::max<int64_t>(n_tiles, 1), 0);
@@ -1623,10 +1732,10 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     *d_text_out = d_text;
     *n_text = total;
     if (info) {
-        info[0] = n_segs;
+        info[0] = n_segs_final;
         info[1] = n_chunks;
         info[2] = (int64_t)sym_total;
-        info[3] = 0;
+        info[3] = n_mirages;
     }
     return GS_OK;
 }

@@ -505,7 +505,7 @@ int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_mem
  * (*d_text, released with gs_gunzip_free); gs_gunzip_device copies it to `out` (tests, tools).  GS_E_UNSUPPORTED: not a stream this
  * path takes (several members, a segment that outgrows its buffer, a block boundary that was a mirage, > 1 GiB compressed) -- the
  * caller inflates on the host instead; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).
- * info (may be NULL): [0] segments, [1] chunks searched, [2] symbols, [3] reserved. */
+ * info (may be NULL): [0] segments, [1] chunks searched, [2] symbols, [3] block starts that were mirages (decoded again). */
 int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text, int64_t *n_text, int64_t info[4]);
 int gs_gunzip_free(int device, uint8_t *d_text);
 int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_text, int64_t info[4]);
