@@ -695,6 +695,11 @@ struct TextJob {
     int64_t dev_tickets_[2] = {-1, -1};
     int64_t n_feeds_ = 0;
     PooledBuf dev_text_[2];  // the text of a feed on the host, for the per-read writers
+    // a single-member gzip file inflated on the device as a whole (gs_gunzip_plan_device): its text lies in HBM, step_gunzip hands it
+    // to the record scan in slices of whole records
+    bool dev_gz = false;
+    uint8_t *gz_text_ = nullptr;
+    int64_t gz_n_ = 0, gz_off_ = 0;
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
@@ -707,6 +712,11 @@ struct TextJob {
         if (inf_) {
             inflater_pool().put(inf_device_, inf_);
             inf_ = nullptr;
+        }
+        if (gz_text_) {
+            gs_match_sync(c.run);  // (the record scan may still be copying out of it)
+            gs_gunzip_free(inf_device_, gz_text_);
+            gz_text_ = nullptr;
         }
     }
 
@@ -743,8 +753,98 @@ struct TextJob {
                 }
             }
         }
-        if (!err && !dev_bgzf) tr.start();
+        if (!err && gzip && !fasta && !general && !dev_bgzf && tr.map_len >= 18) {
+            // not block-gzip: a single-member stream (gzip, pigz) is inflated on the device as a whole -- block starts found speculatively,
+            // segments decoded side by side, windows resolved in a second pass.  Whatever that path does not take (several members, a
+            // damaged stream: the host decoders report it) is inflated on the host as before.
+            bool want = true;
+            if (const char *e = getenv("GS_DEVICE_INFLATE")) want = atoi(e) != 0;
+            if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = want && atoi(e) != 0;
+            int device = 0;
+            if (want && gs_match_get_device(c.run, &device) == GS_OK) {
+                uint8_t *d = nullptr;
+                int64_t nt = 0;
+                static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
+                const double tg = now_s();
+                const int grc = gs_gunzip_plan_device(device, tr.map, (int64_t)tr.map_len, &d, &nt, nullptr);
+                if (trace) fprintf(stderr, "gunzip on the device: rc %d, %lld bytes of text, %.2f ms%s%s\n", grc, (long long)nt, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
+                if (grc == GS_OK) {
+                    dev_gz = true;
+                    gz_text_ = d;
+                    gz_n_ = nt;
+                    inf_device_ = device;
+                }
+            }
+        }
+        if (!err && !dev_bgzf && !dev_gz) tr.start();
         return err;
+    }
+
+    // the next slice of the device text: whole four-line records up to the feed size, the leftover of the last slice to the host
+    int step_gunzip(int *err_out) {
+        int err = GS_OK;
+        const bool per_read = c.filtered.active() || c.kraken.active();
+        const int64_t text_target = per_read && !getenv("GS_HOST_BGZF_TEXT") ? ((int64_t)128 << 20) : bgzf_text_target();
+        const int64_t rest = gz_n_ - gz_off_, look = std::min(rest, text_target);
+        const bool last = look == rest;
+        const uint8_t *text = gz_text_ + gz_off_;
+        int64_t n_lines = 0, n_bytes = 0;
+        int64_t fallback_off = -1, fallback_reads = 0;
+        if (look > 0 && gs_text_cut_device(inf_device_, text, look, &n_lines, &n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+        if (!err) err = gs_match_text_select(c.run, bank);
+        if (!err && n_lines > 0 && per_read) {
+            const int64_t n_chunk = n_lines >> 2;
+            MatchCtx::Results &rs = c.res[n_formatted & 1];  // (the set of the chunk before last: its writers are done)
+            PooledBuf &tb = dev_text_[n_formatted & 1];
+            int64_t ticket = -1;
+            err = rs.cls.resize((size_t)n_chunk);
+            if (!err) err = rs.flags.resize((size_t)n_chunk);
+            if (!err) err = tb.need((size_t)n_bytes);
+            if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
+            if (!err && gs_device_fetch(inf_device_, text, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (!err) {
+                chunks.push_back({carry_file_off, reads_in_file, ticket});
+                err = check_refusal(&fallback_off, &fallback_reads);  // (synchronises: the results are needed now)
+                if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
+                if (err || fallback_off >= 0) chunks.pop_back();
+            }
+            if (!err && fallback_off < 0) {
+                if (first_ticket < 0) first_ticket = ticket;
+                reads_in_file += n_chunk;
+                carry_file_off += n_bytes;
+                drain();  // one chunk at a time: output order, and the other result set becomes free
+                n_formatted++;
+                const uint8_t *h_text = static_cast<const uint8_t *>(tb.p);
+                try {
+                    formatting = std::async(std::launch::async, [this, &rs, h_text, n_chunk] { format_chunk(rs, h_text, n_chunk, -1); });
+                } catch (const std::system_error &) {  // no thread to be had: on this one
+                    format_chunk(rs, h_text, n_chunk, -1);
+                }
+            }
+        } else if (!err && n_lines > 0) {
+            int64_t ticket = -1;
+            err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
+            if (!err) {
+                if (first_ticket < 0) first_ticket = ticket;
+                chunks.push_back({carry_file_off, reads_in_file, ticket});
+                reads_in_file += n_lines >> 2;
+                carry_file_off += n_bytes;
+                if (chunks.size() == 1 || (chunks.size() & 15) == 0) err = check_refusal(&fallback_off, &fallback_reads);
+            }
+        } else if (!err && !last) {  // not one whole record in a full slice: the general parser
+            fallback_off = carry_file_off;
+            fallback_reads = reads_in_file;
+        }
+        if (!err && fallback_off < 0) gz_off_ += n_bytes;
+        if (err || last || fallback_off >= 0) {
+            if (!err && fallback_off < 0 && gz_off_ < gz_n_) {  // what is left behind the last whole record
+                carry.resize((size_t)(gz_n_ - gz_off_));
+                if (gs_device_fetch(inf_device_, gz_text_ + gz_off_, carry.data(), gz_n_ - gz_off_) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            }
+            err = finish(err, fallback_off, fallback_reads);
+        }
+        *err_out = err;
+        return 1;
     }
 
     // one run of members: inflate on the device, submit the whole records, carry the rest (on the device)
@@ -855,6 +955,7 @@ struct TextJob {
     // 1: a block was handled, 0: none ready (blocking = false only); `done` is set when the file is through
     int step(bool blocking, int *err_out) {
         if (dev_bgzf) return step_bgzf(err_out);
+        if (dev_gz) return step_gunzip(err_out);
         if (general) return step_general(blocking, err_out);
         if (fasta) return step_fasta(blocking, err_out);
         int err = GS_OK;

@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1511,6 +1512,41 @@ static uint32_t gi_h_x_pow_8n(uint64_t n) {
     return r;
 }
 
+// host memory of any kind (a page-cache mapping is copied by the runtime at a crawl) to the device through two page-locked buffers,
+// filled by several threads while the other one is on its way
+static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n) {
+    static std::mutex m;
+    static uint8_t *h[2] = {nullptr, nullptr};
+    static hipEvent_t done[2] = {nullptr, nullptr};
+    const size_t piece = (size_t)32 << 20;
+    std::lock_guard<std::mutex> l(m);
+    for (int i = 0; i < 2; i++) {
+        if (!h[i]) GI_TRY(hipHostMalloc((void **)&h[i], piece));
+        if (!done[i]) GI_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    int which = 0;
+    bool used[2] = {false, false};
+    for (size_t at = 0; at < n; at += piece, which ^= 1) {
+        const size_t len = std::min(piece, n - at);
+        if (used[which]) GI_TRY(hipEventSynchronize(done[which]));
+        int n_thr = (int)std::min<size_t>(8, std::max<size_t>(1, len >> 22));
+        if (const char *e = getenv("GS_INFLATE_COPY_THREADS")) n_thr = std::max(1, std::min(32, atoi(e)));
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_thr; t++) {
+            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * ((size_t)t + 1) / (size_t)n_thr;
+            uint8_t *dst = h[which];
+            th.emplace_back([=] { memcpy(dst + a, src + at + a, b - a); });
+        }
+        memcpy(h[which], src + at, len / (size_t)n_thr);
+        for (auto &x : th) x.join();
+        GI_TRY(hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, 0));
+        GI_TRY(hipEventRecord(done[which], 0));
+        used[which] = true;
+    }
+    GI_TRY(hipStreamSynchronize(0));
+    return GS_OK;
+}
+
 struct GiDevBufs {  // freed on every way out
     std::vector<void *> p;
     template <typename T>
@@ -1574,7 +1610,7 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     if (e == hipSuccess) e = bufs.get(&d_start, sizeof(u64) * (size_t)n_chunks);
     if (e == hipSuccess) e = bufs.get(&d_q, 2 * sizeof(u64));
     if (e == hipSuccess) e = hipMemset(d_in + in_len, 0, 1024);
-    if (e == hipSuccess) e = hipMemcpy(d_in, gz + hdr, in_len, hipMemcpyHostToDevice);
+    if (e == hipSuccess && (rc = gi_h2d_staged(d_in, gz + hdr, in_len))) return rc;
     if (e == hipSuccess) e = hipMemset(d_q, 0, 2 * sizeof(u64));
     if (e == hipSuccess) e = hipMemset(d_start, 0xff, sizeof(u64) * (size_t)n_chunks);
     if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
@@ -1759,6 +1795,14 @@ extern "C" int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_
     const hipError_t e = *n_text > 0 ? hipMemcpy(out, d_text, (size_t)*n_text, hipMemcpyDeviceToHost) : hipSuccess;
     hipFree(d_text);
     if (e != hipSuccess) return gi_fail(GS_E_HIP, std::string("gs_gunzip_device: ") + hipGetErrorString(e));
+    return GS_OK;
+}
+
+extern "C" int gs_device_fetch(int device, const uint8_t *d_src, uint8_t *out, int64_t n) {
+    if (n < 0 || (n > 0 && (!d_src || !out))) return gi_fail(GS_E_INVALID, "bad argument");
+    if (n == 0) return GS_OK;
+    GI_TRY(hipSetDevice(device));
+    GI_TRY(hipMemcpy(out, d_src, (size_t)n, hipMemcpyDeviceToHost));
     return GS_OK;
 }
 

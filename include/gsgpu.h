@@ -511,6 +511,8 @@ int gs_gunzip_free(int device, uint8_t *d_text);
 int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_text, int64_t info[4]);
 /* lines and the offset behind the last newline that closes a four-line record (count a multiple of four) in n bytes of device text */
 int gs_text_cut_device(int device, const uint8_t *d_text, int64_t n, int64_t *n_lines, int64_t *cut);
+/* n bytes of device memory to host memory (page-locked for speed); synchronous */
+int gs_device_fetch(int device, const uint8_t *d_src, uint8_t *out, int64_t n);
 int gs_inflater_tail(gs_inflater *inf, uint8_t *out, int64_t cap, int64_t *n);
 /* the first n_bytes of the text the LAST gs_inflater_feed returned, copied to host memory (page-locked for speed); synchronous.
  * For callers that need the text on the host as well -- the filter goal's writers (C/bloom/FastqBloomFilter.java:92-105 rewriteInput). */
