@@ -1599,8 +1599,12 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
     int text_only = 1;  // GS_GUNZIP_ANY_BYTES=1: block starts whose literal code covers bytes >= 128 count as well
     if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) text_only = atoi(e) == 0;
-    uint32_t ratio = 16;
-    if (const char *e = getenv("GS_GUNZIP_RATIO")) ratio = (uint32_t)std::max(2, std::min(1024, atoi(e)));
+    // symbols a segment may produce per byte of its compressed span: four times the stream's own ratio (ISIZE is known modulo 2^32:
+    // the smallest size that is not smaller than the compressed stream), at least 16; deflate's limit is 1032
+    uint64_t text_est = want_isize;
+    while (text_est < in_len) text_est += (uint64_t)1 << 32;
+    uint32_t ratio = (uint32_t)std::min<uint64_t>(1040, std::max<uint64_t>(16, 4 * (text_est / std::max<uint32_t>(in_len, 1)) + 4));
+    if (const char *e = getenv("GS_GUNZIP_RATIO")) ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
     const int64_t n_chunks = ((int64_t)in_len + chunk - 1) / chunk;
     GiDevBufs bufs;
     uint8_t *d_in = nullptr;

@@ -243,3 +243,108 @@ def test_a_corrupt_bgzf_member_fails_the_file(tmp_path, monkeypatch):
         host.match_files(store, [str(path)])
     assert "corrupt" in str(e.value)
     store.close()
+
+
+# ---- single-member gzip streams (gzip, pigz) on the device: gs_gunzip_device
+def _gz(data, level=6, **kw):
+    return gzip.compress(data, compresslevel=level, mtime=0)
+
+
+def _fastq_like(n, seed):
+    rng = np.random.default_rng(seed)
+    acgt = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n * 150).tobytes()
+    qual = rng.choice(np.frombuffer(b"FFFFFFF:,#", dtype=np.uint8), n * 150).tobytes()
+    return b"".join(b"@read%07d/1\n" % i + acgt[i * 150:(i + 1) * 150] + b"\n+\n" + qual[i * 150:(i + 1) * 150] + b"\n" for i in range(n))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_single_member_gzip_equals_zlib(level):
+    """block starts found speculatively, segments decoded side by side with window markers, windows resolved in a second pass: the text
+    must be what zlib gives, for every level, with many segments (small chunks) and with one"""
+    text = _fastq_like(20000, 7 + level)
+    z = _gz(text, level)
+    for chunk in ("4096", "16384", "1048576"):
+        os.environ["GS_GUNZIP_CHUNK"] = chunk
+        try:
+            got, info = ga.gunzip_device(z, len(text))
+        finally:
+            del os.environ["GS_GUNZIP_CHUNK"]
+        assert got.tobytes() == text, (level, chunk)
+        assert info[0] >= 1 and (chunk != "4096" or info[0] > 10), info
+
+
+def test_single_member_gzip_shapes():
+    rng = np.random.default_rng(3)
+    for name, data in (("empty", b""), ("one byte", b"x"), ("runs", (b"A" * 1000 + b"\n") * 3000),
+                       ("far copies", bytes(rng.integers(65, 91, 40000, dtype=np.uint8)) * 30),
+                       ("header fields", _fastq_like(3000, 5))):
+        z = _gz(data)
+        if name == "header fields":  # FNAME + FCOMMENT + FEXTRA in front of the deflate stream
+            body = z[10:]
+            z = z[:3] + bytes([4 | 8 | 16]) + z[4:10] + struct.pack("<H", 5) + b"extra" + b"name.fastq\0" + b"a comment\0" + body
+        got, info = ga.gunzip_device(z, len(data))
+        assert got.tobytes() == data, name
+
+
+def test_single_member_gzip_what_the_device_path_refuses_or_reports():
+    text = _fastq_like(5000, 11)
+    z = _gz(text)
+    with pytest.raises(ga.GsError) as e:  # two members behind one another: ISIZE of the last one does not cover the text -> host decoders
+        ga.gunzip_device(z + z, 2 * len(text))
+    assert e.value.code == -4
+    bad = bytearray(z)
+    bad[-6] ^= 1  # the CRC-32 of the trailer
+    with pytest.raises(ga.GsError) as e:
+        ga.gunzip_device(bytes(bad), len(text))
+    assert e.value.code == -1 and "CRC" in str(e.value)
+    rng = np.random.default_rng(5)
+    n_bad = 0
+    for _ in range(20):  # a flipped payload bit: never a silent success with other text
+        d = bytearray(z)
+        d[20 + int(rng.integers(0, len(z) - 40))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            got, _ = ga.gunzip_device(bytes(d), len(text) + 100000)
+            assert got.tobytes() == text
+        except ga.GsError as ex:
+            assert ex.code in (-1, -4)
+            n_bad += 1
+    assert n_bad >= 18
+
+
+def test_binary_data_and_mirages(monkeypatch):
+    """random bytes compress to stored / near-flat blocks, and with GS_GUNZIP_ANY_BYTES=1 every parsable header counts as a block start:
+    a start that was a mirage makes the segment in front of it run past it, which is decoded again"""
+    rng = np.random.default_rng(9)
+    data = bytes(rng.integers(0, 256, 300000, dtype=np.uint8)) + _fastq_like(4000, 2) + bytes(rng.integers(0, 64, 500000, dtype=np.uint8))
+    z = _gz(data)
+    for any_bytes in ("0", "1"):
+        monkeypatch.setenv("GS_GUNZIP_ANY_BYTES", any_bytes)
+        monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+        got, info = ga.gunzip_device(z, len(data))
+        assert got.tobytes() == data, any_bytes
+
+
+@pytest.mark.parametrize("outputs", [False, True])
+def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs):
+    """gs_host_match_files on a plain (single-member) .gz: inflated on the device as a whole; table, totals and per-read files must
+    equal the host-decoder run, also when the file ends in the middle of a record"""
+    from genestrip_amd import host, synth
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
+    seq, off = synth.reads_host(db.genomes, 20000, read_len=150, seed=29)
+    text = _fastq(seq, off)[:-77]
+    path = tmp_path / "reads.fastq.gz"
+    path.write_bytes(_gz(text, 6))
+    monkeypatch.setenv("GS_HOST_BGZF_TEXT", "700000")  # several slices
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    got = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("GS_DEVICE_GUNZIP", dev)
+        kw = {}
+        if outputs:
+            kw = dict(filtered_path=tmp_path / f"f{dev}.fastq", kraken_out_path=tmp_path / f"k{dev}.txt", taxids=[f"t{i}" for i in range(db.n_values)])
+        t, _, tot = host.match_files(store, [str(path)], **kw)
+        files = tuple(open(p, "rb").read() for p in (kw.get("filtered_path"), kw.get("kraken_out_path")) if p)
+        got[dev] = (t, (tot.reads, tot.kmers, tot.bps), files)
+    assert np.array_equal(got["1"][0], got["0"][0]) and got["1"][1] == got["0"][1] and got["1"][2] == got["0"][2]
+    assert got["1"][1][0] in (19999, 20000)  # (the last record is cut short: what becomes of it is the reference parser's business)
+    store.close()
