@@ -1753,11 +1753,28 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     std::vector<gs_inflate_member> members;
     int device = 0;
     gs_inflater *inf = nullptr;
-    if (err || tr.map_len < 28 || !bgzf_member_list(tr.map, tr.map_len, members) || gs_filter_get_device(c.bloom, &device) != GS_OK ||
-        (inf = inflater_pool().get(device)) == nullptr) {
+    // (not block-gzip: a single-member stream is inflated on the device as a whole, gs_gunzip_plan_device, and handed on in slices)
+    uint8_t *gz_text = nullptr;
+    int64_t gz_n = 0, gz_off = 0;
+    if (err || tr.map_len < 18 || gs_filter_get_device(c.bloom, &device) != GS_OK) {
         tr.close();
         return GS_OK;
     }
+    if (tr.map_len >= 28 && bgzf_member_list(tr.map, tr.map_len, members)) {
+        if ((inf = inflater_pool().get(device)) == nullptr) {
+            tr.close();
+            return GS_OK;
+        }
+    } else {
+        members.clear();
+        bool want = true;
+        if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = atoi(e) != 0;
+        if (!want || gs_gunzip_plan_device(device, tr.map, (int64_t)tr.map_len, &gz_text, &gz_n, nullptr) != GS_OK) {
+            tr.close();
+            return GS_OK;  // (several members, a damaged stream, ...: the host decoders take it -- and report it)
+        }
+    }
+    const bool whole = inf == nullptr;
     *handled = true;
     err = gs_filter_text_reset(c.bloom, 1);
     PooledBuf text_sets[2], nl_sets[2];
@@ -1776,22 +1793,35 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         while (e < members.size() && (e == from || sum + members[e].isize <= text_target)) sum += members[e++].isize;
         return e;
     };
-    for (size_t a = 0; !err && a < members.size();) {
-        const size_t b = run_end(a), b2 = run_end(b);
-        const bool last = b == members.size();
-        int64_t next_lo = 0, next_hi = 0;
-        if (b2 > b) {
-            next_lo = members[b].payload_offset;
-            next_hi = members[b2 - 1].payload_offset + (int64_t)members[b2 - 1].payload_len;
-        }
+    for (size_t a = 0; !err && (whole || a < members.size());) {
+        bool last = false;
         const uint8_t *text = nullptr;
         int64_t n_bytes = 0, n_lines = 0, tail = 0;
         const double tg = now_s();
-        if (gs_inflater_feed(inf, tr.map, members.data() + a, (int64_t)(b - a), next_lo, next_hi, last ? 1 : 0, &text, &n_bytes, &n_lines, &tail) != GS_OK) {
-            err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
-            break;
+        if (whole) {  // the next slice of the device text: whole records up to the feed size
+            const int64_t rest = gz_n - gz_off, look = std::min(rest, text_target);
+            last = look == rest;
+            text = gz_text + gz_off;
+            if (look > 0 && gs_text_cut_device(device, text, look, &n_lines, &n_bytes) != GS_OK) {
+                err = hfail(GS_E_HIP, gs_inflate_last_error());
+                break;
+            }
+            tail = last ? rest - n_bytes : (n_lines > 0 ? 0 : ((int64_t)1 << 40));  // (no record in a full slice: the general parser, below)
+            gz_off += n_bytes;
+        } else {
+            const size_t b = run_end(a), b2 = run_end(b);
+            last = b == members.size();
+            int64_t next_lo = 0, next_hi = 0;
+            if (b2 > b) {
+                next_lo = members[b].payload_offset;
+                next_hi = members[b2 - 1].payload_offset + (int64_t)members[b2 - 1].payload_len;
+            }
+            if (gs_inflater_feed(inf, tr.map, members.data() + a, (int64_t)(b - a), next_lo, next_hi, last ? 1 : 0, &text, &n_bytes, &n_lines, &tail) != GS_OK) {
+                err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
+                break;
+            }
+            a = b;
         }
-        a = b;
         if (n_lines > 0) {
             const int64_t n_reads = n_lines >> 2;
             const int set = (int)(n_formatted & 1);  // (the set of the chunk before last: its writers are through)
@@ -1804,7 +1834,8 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
             const double t1 = now_s();
             err = gs_filter_submit_text(c.bloom, c.k, c.min_pos_count, c.positive_ratio, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, h_acc, h_nl, 0, &ticket);
             const double t2 = now_s();
-            if (!err && gs_inflater_fetch(inf, h_text, n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());  // (while the kernel runs)
+            if (!err && (whole ? gs_device_fetch(device, text, h_text, n_bytes) : gs_inflater_fetch(inf, h_text, n_bytes)) != GS_OK)
+                err = hfail(GS_E_HIP, gs_inflate_last_error());  // (while the kernel runs)
             const double t3 = now_s();
             if (!err) err = gs_filter_text_status(c.bloom, &failed, &bad, tot);  // synchronises: results are needed now
             const double t4 = now_s();
@@ -1833,13 +1864,16 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         if (last) {  // what is left behind the last whole record
             int64_t n = 0;
             carry.resize((size_t)tail);
-            if (tail > 0 && gs_inflater_tail(inf, carry.data(), tail, &n) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (tail > 0 && (whole ? gs_device_fetch(device, gz_text + gz_off, carry.data(), tail) : gs_inflater_tail(inf, carry.data(), tail, &n)) != GS_OK)
+                err = hfail(GS_E_HIP, gs_inflate_last_error());
+            break;
         }
     }
     const double te0 = now_s();
     if (formatting.valid()) formatting.get();
     const double te1 = now_s();
-    inflater_pool().put(device, inf);
+    if (inf) inflater_pool().put(device, inf);
+    if (gz_text) gs_gunzip_free(device, gz_text);  // (every slice's filter run has been waited for: gs_filter_text_status)
     tr.close();
     if (getenv("GS_HOST_TRACE") != nullptr)
         fprintf(stderr, "filter bgzf: loop %.2f ms (from open), last writers %.2f, inflater back + unmap %.2f\n", (te0 - t0) * 1e3, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);

@@ -245,9 +245,10 @@ def test_filter_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypat
     gb.close()
 
 
+@pytest.mark.parametrize("container", ["bgzf", "gzip"])
 @pytest.mark.parametrize("text_target", [0, 70000])
 @pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "multi-line first"])
-def test_filter_files_bgzf_input_inflated_on_the_device(sdb, tmp_path, monkeypatch, shape, text_target):
+def test_filter_files_bgzf_input_inflated_on_the_device(sdb, tmp_path, monkeypatch, shape, text_target, container):
     """gs_host_filter_files over block-gzip FASTQ: members inflated on the device, the filter on the device text, the text back once
     for the writers (filter_bgzf_file) -- output files and totals byte-identical to the host-decoder path (GS_DEVICE_INFLATE=0)
     and to the oracle, whatever the file shape; small feeds (GS_HOST_BGZF_TEXT) put record and member boundaries everywhere"""
@@ -264,7 +265,12 @@ def test_filter_files_bgzf_input_inflated_on_the_device(sdb, tmp_path, monkeypat
     if shape == "no final newline":
         data = data[:-1]
     path = str(tmp_path / "in.fastq.gz")
-    open(path, "wb").write(bgzf(data, block=20000, level=1))
+    if container == "bgzf":
+        open(path, "wb").write(bgzf(data, block=20000, level=1))
+    else:  # one gzip member: inflated on the device as a whole (gs_gunzip_plan_device), handed on in slices
+        import gzip
+        open(path, "wb").write(gzip.compress(data, compresslevel=6, mtime=0))
+        monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
     p = orc.parse_fastq(data, k=31)
     want = ob.filter_batch(31, 1, 0.2, p["seq"], p["seq_off"])
     if text_target:
