@@ -1595,7 +1595,10 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     if (rc) return rc;
     hipDeviceProp_t prop;
     const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    uint32_t chunk = 16384;  // (about one deflate block of zlib's at its usual levels: a segment is then ~100 KB of text, a few ms of a wave)
+    // One segment per wave slot of the device, but not less than 16 KiB of compressed data (about one deflate block of zlib's): the
+    // finder reads a chunk only up to its first block start, the sequential window pass takes 2 us per segment, and a segment is
+    // decoded by one wave -- more segments than slots only add rounds.
+    uint32_t chunk = (uint32_t)std::max<int64_t>(16384, (int64_t)in_len / ((int64_t)n_cu * 4 * gi_wgs_per_cu()));
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
     int text_only = 1;  // GS_GUNZIP_ANY_BYTES=1: block starts whose literal code covers bytes >= 128 count as well
     if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) text_only = atoi(e) == 0;
