@@ -1003,10 +1003,10 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
 }
 
 // win[i]: the last GI_WINDOW bytes of the text up to the end of segment i.  gi_window_prep_kernel copies every segment's last GI_WINDOW
-// symbols into an array of their own (side by side); then ONE workgroup walks the segments in order -- the only sequential step of the
-// whole decoder --, the window before in LDS, the symbols of the next segment already on their way: about a microsecond per segment.
-// (Repetitive text keeps its markers to the end of a segment -- every quality line is a copy of the one before --, so the walk has
-// to look at every slot; a list of the few slots that still hold markers was no faster.)
+// symbols into an array of their own (side by side); the markers in them are then replaced through the window before -- the only
+// sequential dependence of the whole decoder.  (Repetitive text keeps its markers to the end of a segment -- every quality line is a
+// copy of the one before --, so every slot has to be looked at; one workgroup walking all segments, the window in LDS, takes 2.2 us
+// per segment: 9 ms for 4 096.)
 __global__ __launch_bounds__(256) void gi_window_prep_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, int64_t n_segs, uint16_t *win16) {
     const int64_t i = blockIdx.x;
     if (i >= n_segs) return;
@@ -1016,39 +1016,91 @@ __global__ __launch_bounds__(256) void gi_window_prep_kernel(const uint16_t *sym
     for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 256) cur[j] = dst[n - (int64_t)GI_WINDOW + (int64_t)j];  // (in front of the segment: its marker prefix)
 }
 
-__global__ __launch_bounds__(1024) void gi_windows_kernel(const uint16_t *win16, int64_t n_segs, uint8_t *win) {
-    __shared__ uint8_t s_win[2][GI_WINDOW];
+// The walk in two levels.  A segment's window symbols are a MAP from the window before it (slot -> a byte, or "slot p of the window
+// before"), and maps compose: gi_win_compose_kernel walks the segments of a GROUP in order (the groups side by side, one workgroup
+// each, the composed map in LDS) and leaves every segment's map relative to the window before its group; gi_win_groups_kernel walks
+// the groups' last segments in order (one workgroup, the window bytes in LDS); gi_win_apply_kernel fills in all other windows side by
+// side from the end of the group before.  4 096 segments: 32 + 128 sequential steps instead of 4 096.
+// Thread t owns the slots 8 t + 8192 q .. + 8 (q < 4); the LDS copy is updated in place between two barriers.
+__global__ __launch_bounds__(1024) void gi_win_compose_kernel(uint16_t *win16, int64_t n_segs, int64_t per_group) {
+    __shared__ uint16_t s_c[GI_WINDOW];
     const uint32_t t = threadIdx.x;
-    // thread t owns the slots 8 t + 8192 q .. + 8 (q < 4): four 16-byte loads per segment
+    const int64_t a = (int64_t)blockIdx.x * per_group, b = a + per_group < n_segs ? a + per_group : n_segs;
+    if (a >= b) return;
     gs_u16x8 nxt[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + 8u * t + 8192u * (uint32_t)q);
-    int p = 0;
-    for (int64_t i = 0; i < n_segs; i++) {
+    for (int q = 0; q < 4; q++) {
+        nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)a * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
+        *reinterpret_cast<gs_u16x8 *>(&s_c[8u * t + 8192u * (uint32_t)q]) = nxt[q];
+    }
+    if (a + 1 < b) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)(a + 1) * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
+    }
+    __syncthreads();
+    for (int64_t i = a + 1; i < b; i++) {
         gs_u16x8 cur[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) cur[q] = nxt[q];
-        if (i + 1 < n_segs) {
+        if (i + 1 < b) {
 #pragma unroll
             for (int q = 0; q < 4; q++) nxt[q] = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)(i + 1) * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
         }
-        uint8_t *out = win + (size_t)i * GI_WINDOW;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint8_t bytes[8];
+        for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint16_t v = cur[q].v[e];
-                bytes[e] = v < 0x8000u ? (uint8_t)v : (i ? s_win[p][v & 0x7fffu] : (uint8_t)0);  // (segment 0 starts the stream)
+                cur[q].v[e] = v < 0x8000u ? v : s_c[v & 0x7fffu];
             }
-            const uint32_t slot = 8u * t + 8192u * (uint32_t)q;
-            uint64_t pack;
-            memcpy(&pack, bytes, 8);
-            *reinterpret_cast<uint64_t *>(&s_win[p ^ 1][slot]) = pack;
-            *reinterpret_cast<uint64_t *>(out + slot) = pack;
+        __syncthreads();  // (every read of the map before is through)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            *reinterpret_cast<gs_u16x8 *>(&s_c[8u * t + 8192u * (uint32_t)q]) = cur[q];
+            *reinterpret_cast<gs_u16x8 *>(win16 + (size_t)i * GI_WINDOW + 8u * t + 8192u * (uint32_t)q) = cur[q];
         }
         __syncthreads();
-        p ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void gi_win_groups_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win) {
+    __shared__ uint8_t s_w[GI_WINDOW];
+    const uint32_t t = threadIdx.x;
+    const int64_t n_groups = (n_segs + per_group - 1) / per_group;
+    for (int64_t g = 0; g < n_groups; g++) {
+        const int64_t last = ((g + 1) * per_group < n_segs ? (g + 1) * per_group : n_segs) - 1;
+        uint64_t pack[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const gs_u16x8 c = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)last * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
+            uint8_t bytes[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) bytes[e] = c.v[e] < 0x8000u ? (uint8_t)c.v[e] : (g ? s_w[c.v[e] & 0x7fffu] : (uint8_t)0);  // (group 0 starts the stream)
+            memcpy(&pack[q], bytes, 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t slot = 8u * t + 8192u * (uint32_t)q;
+            *reinterpret_cast<uint64_t *>(&s_w[slot]) = pack[q];
+            *reinterpret_cast<uint64_t *>(win + (size_t)last * GI_WINDOW + slot) = pack[q];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gi_win_apply_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win) {
+    const int64_t i = blockIdx.x;
+    if (i >= n_segs) return;
+    const int64_t g = i / per_group;
+    const int64_t last = ((g + 1) * per_group < n_segs ? (g + 1) * per_group : n_segs) - 1;
+    if (i == last) return;  // (gi_win_groups_kernel has written it)
+    const uint8_t *prev = g ? win + (size_t)(g * per_group - 1) * GI_WINDOW : nullptr;
+    const uint16_t *c = win16 + (size_t)i * GI_WINDOW;
+    uint8_t *out = win + (size_t)i * GI_WINDOW;
+    for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 256) {
+        const uint16_t v = c[j];
+        out[j] = v < 0x8000u ? (uint8_t)v : (prev ? prev[v & 0x7fffu] : (uint8_t)0);
     }
 }
 
@@ -1756,7 +1808,12 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(u64) * (size_t)n_segs_final, hipMemcpyHostToDevice);
     if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
     hipLaunchKernelGGL(gi_window_prep_kernel, dim3((unsigned)n_segs_final), dim3(256), 0, 0, d_sym, d_segs, d_len, n_segs_final, d_win16);
-    hipLaunchKernelGGL(gi_windows_kernel, dim3(1), dim3(1024), 0, 0, d_win16, n_segs_final, d_win);
+    {
+        const int64_t per_group = std::max<int64_t>(1, (n_segs_final + 127) / 128), n_groups = (n_segs_final + per_group - 1) / per_group;
+        if (per_group > 1) hipLaunchKernelGGL(gi_win_compose_kernel, dim3((unsigned)n_groups), dim3(1024), 0, 0, d_win16, n_segs_final, per_group);
+        hipLaunchKernelGGL(gi_win_groups_kernel, dim3(1), dim3(1024), 0, 0, d_win16, n_segs_final, per_group, d_win);
+        if (per_group > 1) hipLaunchKernelGGL(gi_win_apply_kernel, dim3((unsigned)n_segs_final), dim3(256), 0, 0, d_win16, n_segs_final, per_group, d_win);
+    }
     hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_segs_final, 16384)), dim3(256), 0, 0, d_sym, d_segs, d_len, d_off, n_segs_final, d_win, d_text);
     if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, d_text, total, tile, d_crc);
     GI_TRY(hipGetLastError());
