@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "gs_filter_submit_fasta", "gs_filter_submit_fastq_ml", "gs_filter_text_read_bounds", "gs_filter_text_line_classes",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
     "gs_calibrate",
-    "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
+    "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
 )
 
 
@@ -163,6 +163,10 @@ def lib():
         "gs_inflater_feed": (ci, [vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp]),
         "gs_inflater_tail": (ci, [vp, vp, i64, vp]),
         "gs_inflater_fetch": (ci, [vp, vp, i64]),
+        "gs_gunzipper_open": (ci, [vp, ci, vp, i64]),
+        "gs_gunzipper_next": (ci, [vp, i64, vp, vp, vp]),
+        "gs_gunzipper_info": (ci, [vp, vp]),
+        "gs_gunzipper_close": (ci, [vp]),
         "gs_gunzip_plan_device": (ci, [ci, vp, i64, vp, vp, vp]),
         "gs_gunzip_free": (ci, [ci, vp]),
         "gs_gunzip_device": (ci, [ci, vp, i64, vp, i64, vp, vp]),
@@ -247,8 +251,8 @@ def inflate_members(data, members, device=0):
 
 
 def gunzip_device(data, expect_bytes, device=0):
-    """gs_gunzip_device: a single-member gzip stream inflated on the device -> (text as numpy uint8, info[4] = segments, chunks,
-    symbols, 0); raises GsError (code -4: a stream this path does not take -- the host decoders do; -1: a damaged stream)"""
+    """gs_gunzip_device: a single-member gzip stream inflated on the device -> (text as numpy uint8, info[4] = segments, chunks searched,
+    batches, mirages); raises GsError (code -4: a stream this path does not take -- the host decoders do; -1: a damaged stream)"""
     buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
     out = np.zeros(max(int(expect_bytes), 1), dtype=np.uint8)
     n = C.c_int64(0)

@@ -698,8 +698,10 @@ struct TextJob {
     // a single-member gzip file inflated on the device as a whole (gs_gunzip_plan_device): its text lies in HBM, step_gunzip hands it
     // to the record scan in slices of whole records
     bool dev_gz = false;
-    uint8_t *gz_text_ = nullptr;
-    int64_t gz_n_ = 0, gz_off_ = 0;
+    gs_gunzipper *gzr_ = nullptr;
+    const uint8_t *gz_text_ = nullptr;  // the current batch (gs_gunzipper_next)
+    int64_t gz_n_ = 0, gz_off_ = 0, gz_ticket_ = -1;
+    int gz_last_ = 0;                   // 1: the member is through, 2: and more data follows it (the host decoders take the rest)
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
@@ -713,9 +715,10 @@ struct TextJob {
             inflater_pool().put(inf_device_, inf_);
             inf_ = nullptr;
         }
-        if (gz_text_) {
-            gs_match_sync(c.run);  // (the record scan may still be copying out of it)
-            gs_gunzip_free(inf_device_, gz_text_);
+        if (gzr_) {
+            gs_match_sync(c.run);  // (the record scan may still be copying out of its text)
+            gs_gunzipper_close(gzr_);
+            gzr_ = nullptr;
             gz_text_ = nullptr;
         }
     }
@@ -762,17 +765,19 @@ struct TextJob {
             if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = want && atoi(e) != 0;
             int device = 0;
             if (want && gs_match_get_device(c.run, &device) == GS_OK) {
-                uint8_t *d = nullptr;
-                int64_t nt = 0;
                 static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
                 const double tg = now_s();
-                const int grc = gs_gunzip_plan_device(device, tr.map, (int64_t)tr.map_len, &d, &nt, nullptr);
-                if (trace) fprintf(stderr, "gunzip on the device: rc %d, %lld bytes of text, %.2f ms%s%s\n", grc, (long long)nt, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
+                int grc = gs_gunzipper_open(&gzr_, device, tr.map, (int64_t)tr.map_len);
+                if (grc == GS_OK) grc = gs_gunzipper_next(gzr_, 0, &gz_text_, &gz_n_, &gz_last_);  // (the first batch now: a stream this path does not take shows here)
+                if (trace) fprintf(stderr, "gunzip on the device: rc %d, first batch %lld bytes of text, %.2f ms%s%s\n", grc, (long long)gz_n_, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
                 if (grc == GS_OK) {
                     dev_gz = true;
-                    gz_text_ = d;
-                    gz_n_ = nt;
                     inf_device_ = device;
+                } else if (gzr_) {
+                    gs_gunzipper_close(gzr_);
+                    gzr_ = nullptr;
+                    gz_text_ = nullptr;
+                    gz_n_ = 0;
                 }
             }
         }
@@ -785,12 +790,34 @@ struct TextJob {
         int err = GS_OK;
         const bool per_read = c.filtered.active() || c.kraken.active();
         const int64_t text_target = per_read && !getenv("GS_HOST_BGZF_TEXT") ? ((int64_t)128 << 20) : bgzf_text_target();
-        const int64_t rest = gz_n_ - gz_off_, look = std::min(rest, text_target);
-        const bool last = look == rest;
-        const uint8_t *text = gz_text_ + gz_off_;
-        int64_t n_lines = 0, n_bytes = 0;
         int64_t fallback_off = -1, fallback_reads = 0;
-        if (look > 0 && gs_text_cut_device(inf_device_, text, look, &n_lines, &n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+        int64_t n_lines = 0, n_bytes = 0;
+        for (;;) {  // a slice with a whole record in it: from this batch, or with the next one behind what is left of this
+            const int64_t rest = gz_n_ - gz_off_, look = std::min(rest, text_target);
+            n_lines = n_bytes = 0;
+            if (look > 0 && gs_text_cut_device(inf_device_, gz_text_ + gz_off_, look, &n_lines, &n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (err || n_lines > 0 || gz_last_ || look < rest) break;  // (look < rest: a full slice without a record -- the general parser, below)
+            if (gz_ticket_ >= 0) {  // the scan's copy out of this batch's text must be through before the text is replaced
+                err = gs_match_text_wait_copy(c.run, gz_ticket_);
+                gz_ticket_ = -1;
+                if (err) break;
+            }
+            const int grc = gs_gunzipper_next(gzr_, rest, &gz_text_, &gz_n_, &gz_last_);
+            gz_off_ = 0;
+            if (grc == GS_E_UNSUPPORTED) {  // from here on the host decoders (the tail that was kept belongs to them as well)
+                fallback_off = carry_file_off;
+                fallback_reads = reads_in_file;
+                gz_n_ = 0;
+                break;
+            }
+            if (grc != GS_OK) {
+                err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
+                break;
+            }
+        }
+        const int64_t rest = gz_n_ - gz_off_;
+        const bool last = gz_last_ != 0 && std::min(rest, text_target) == rest;
+        const uint8_t *text = gz_text_ + gz_off_;
         if (!err) err = gs_match_text_select(c.run, bank);
         if (!err && n_lines > 0 && per_read) {
             const int64_t n_chunk = n_lines >> 2;
@@ -825,17 +852,22 @@ struct TextJob {
             int64_t ticket = -1;
             err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
             if (!err) {
+                gz_ticket_ = ticket;
                 if (first_ticket < 0) first_ticket = ticket;
                 chunks.push_back({carry_file_off, reads_in_file, ticket});
                 reads_in_file += n_lines >> 2;
                 carry_file_off += n_bytes;
                 if (chunks.size() == 1 || (chunks.size() & 15) == 0) err = check_refusal(&fallback_off, &fallback_reads);
             }
-        } else if (!err && !last) {  // not one whole record in a full slice: the general parser
+        } else if (!err && fallback_off < 0 && !last) {  // not one whole record in a full slice: the general parser
             fallback_off = carry_file_off;
             fallback_reads = reads_in_file;
         }
         if (!err && fallback_off < 0) gz_off_ += n_bytes;
+        if (!err && fallback_off < 0 && last && gz_last_ == 2) {  // another member follows: the host decoders, from behind the last whole record
+            fallback_off = carry_file_off;
+            fallback_reads = reads_in_file;
+        }
         if (err || last || fallback_off >= 0) {
             if (!err && fallback_off < 0 && gz_off_ < gz_n_) {  // what is left behind the last whole record
                 carry.resize((size_t)(gz_n_ - gz_off_));
@@ -1754,8 +1786,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     int device = 0;
     gs_inflater *inf = nullptr;
     // (not block-gzip: a single-member stream is inflated on the device as a whole, gs_gunzip_plan_device, and handed on in slices)
-    uint8_t *gz_text = nullptr;
+    gs_gunzipper *gzr = nullptr;
+    const uint8_t *gz_text = nullptr;  // the current batch
     int64_t gz_n = 0, gz_off = 0;
+    int gz_last = 0;
     if (err || tr.map_len < 18 || gs_filter_get_device(c.bloom, &device) != GS_OK) {
         tr.close();
         return GS_OK;
@@ -1769,9 +1803,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         members.clear();
         bool want = true;
         if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = atoi(e) != 0;
-        if (!want || gs_gunzip_plan_device(device, tr.map, (int64_t)tr.map_len, &gz_text, &gz_n, nullptr) != GS_OK) {
+        if (!want || gs_gunzipper_open(&gzr, device, tr.map, (int64_t)tr.map_len) != GS_OK || gs_gunzipper_next(gzr, 0, &gz_text, &gz_n, &gz_last) != GS_OK) {
+            gs_gunzipper_close(gzr);
             tr.close();
-            return GS_OK;  // (several members, a damaged stream, ...: the host decoders take it -- and report it)
+            return GS_OK;  // (a stream this path does not take, a damaged one: the host decoders take it -- and report it)
         }
     }
     const bool whole = inf == nullptr;
@@ -1799,14 +1834,36 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         int64_t n_bytes = 0, n_lines = 0, tail = 0;
         const double tg = now_s();
         if (whole) {  // the next slice of the device text: whole records up to the feed size
-            const int64_t rest = gz_n - gz_off, look = std::min(rest, text_target);
-            last = look == rest;
+            bool refused = false;
+            for (;;) {  // (a slice with a whole record in it: from this batch, or with the next one behind what is left of this)
+                const int64_t rest = gz_n - gz_off, look = std::min(rest, text_target);
+                n_lines = n_bytes = 0;
+                if (look > 0 && gs_text_cut_device(device, gz_text + gz_off, look, &n_lines, &n_bytes) != GS_OK) {
+                    err = hfail(GS_E_HIP, gs_inflate_last_error());
+                    break;
+                }
+                if (n_lines > 0 || gz_last || look < rest) break;
+                const int grc = gs_gunzipper_next(gzr, rest, &gz_text, &gz_n, &gz_last);  // (every earlier slice has been waited for: gs_filter_text_status)
+                gz_off = 0;
+                if (grc == GS_E_UNSUPPORTED) {
+                    refused = true;
+                    gz_n = 0;
+                    break;
+                }
+                if (grc != GS_OK) {
+                    err = hfail(GS_E_INVALID, std::string("corrupt gzip stream in ") + path + ": " + gs_inflate_last_error());
+                    break;
+                }
+            }
+            if (err) break;
+            const int64_t rest = gz_n - gz_off;
+            last = gz_last != 0 && std::min(rest, text_target) == rest;
             text = gz_text + gz_off;
-            if (look > 0 && gs_text_cut_device(device, text, look, &n_lines, &n_bytes) != GS_OK) {
-                err = hfail(GS_E_HIP, gs_inflate_last_error());
+            tail = last ? rest - n_bytes : (n_lines > 0 ? 0 : ((int64_t)1 << 40));  // (no record in a full slice: the general parser, below)
+            if (refused || (last && gz_last == 2 && n_lines == 0)) {  // the host decoders from here: a batch the device path does not take, or another member
+                fallback_off = text_off;
                 break;
             }
-            tail = last ? rest - n_bytes : (n_lines > 0 ? 0 : ((int64_t)1 << 40));  // (no record in a full slice: the general parser, below)
             gz_off += n_bytes;
         } else {
             const size_t b = run_end(a), b2 = run_end(b);
@@ -1864,6 +1921,11 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         if (last) {  // what is left behind the last whole record
             int64_t n = 0;
             carry.resize((size_t)tail);
+            if (whole && gz_last == 2) {  // another member follows: the host decoders, from behind the last whole record
+                carry.clear();
+                fallback_off = text_off;
+                break;
+            }
             if (tail > 0 && (whole ? gs_device_fetch(device, gz_text + gz_off, carry.data(), tail) : gs_inflater_tail(inf, carry.data(), tail, &n)) != GS_OK)
                 err = hfail(GS_E_HIP, gs_inflate_last_error());
             break;
@@ -1873,7 +1935,7 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     if (formatting.valid()) formatting.get();
     const double te1 = now_s();
     if (inf) inflater_pool().put(device, inf);
-    if (gz_text) gs_gunzip_free(device, gz_text);  // (every slice's filter run has been waited for: gs_filter_text_status)
+    if (gzr) gs_gunzipper_close(gzr);  // (every slice's filter run has been waited for: gs_filter_text_status)
     tr.close();
     if (getenv("GS_HOST_TRACE") != nullptr)
         fprintf(stderr, "filter bgzf: loop %.2f ms (from open), last writers %.2f, inflater back + unmap %.2f\n", (te0 - t0) * 1e3, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);

@@ -973,7 +973,7 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
 
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
                                                                                                            uint16_t *sym, int32_t *status, uint32_t *out_len,
-                                                                                                           unsigned long long *next_seg) {
+                                                                                                           u64 *end_bit, unsigned long long *next_seg) {
     __shared__ GiWave s_w[GI_WAVES];
     __shared__ uint16_t s_ring[GI_WAVES][GI_RING];
     const int lane = gi_lane();
@@ -999,6 +999,7 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const int err = gi_decode_blocks<true>(w, s_ring[wib], b, in_len, seg.stop_bit, seg.to_final != 0, dst, seg.out_cap, 0, lane, &pos);
         status[si] = err;
         out_len[si] = pos;
+        end_bit[si] = b.consumed();
     }
 }
 
@@ -1063,10 +1064,17 @@ __global__ __launch_bounds__(1024) void gi_win_compose_kernel(uint16_t *win16, i
     }
 }
 
-__global__ __launch_bounds__(1024) void gi_win_groups_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win) {
+__global__ __launch_bounds__(1024) void gi_win_groups_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win, const uint8_t *win0) {
     __shared__ uint8_t s_w[GI_WINDOW];
     const uint32_t t = threadIdx.x;
     const int64_t n_groups = (n_segs + per_group - 1) / per_group;
+    // win0: the text in front of the first segment (a later batch of the stream), or nullptr (the stream starts here: zeros)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t slot = 8u * t + 8192u * (uint32_t)q;
+        *reinterpret_cast<uint64_t *>(&s_w[slot]) = win0 ? *reinterpret_cast<const uint64_t *>(win0 + slot) : 0ULL;
+    }
+    __syncthreads();
     for (int64_t g = 0; g < n_groups; g++) {
         const int64_t last = ((g + 1) * per_group < n_segs ? (g + 1) * per_group : n_segs) - 1;
         uint64_t pack[4];
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(1024) void gi_win_groups_kernel(const uint16_t *win
             const gs_u16x8 c = *reinterpret_cast<const gs_u16x8 *>(win16 + (size_t)last * GI_WINDOW + 8u * t + 8192u * (uint32_t)q);
             uint8_t bytes[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) bytes[e] = c.v[e] < 0x8000u ? (uint8_t)c.v[e] : (g ? s_w[c.v[e] & 0x7fffu] : (uint8_t)0);  // (group 0 starts the stream)
+            for (int e = 0; e < 8; e++) bytes[e] = c.v[e] < 0x8000u ? (uint8_t)c.v[e] : s_w[c.v[e] & 0x7fffu];
             memcpy(&pack[q], bytes, 8);
         }
         __syncthreads();
@@ -1089,13 +1097,13 @@ __global__ __launch_bounds__(1024) void gi_win_groups_kernel(const uint16_t *win
     }
 }
 
-__global__ __launch_bounds__(256) void gi_win_apply_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win) {
+__global__ __launch_bounds__(256) void gi_win_apply_kernel(const uint16_t *win16, int64_t n_segs, int64_t per_group, uint8_t *win, const uint8_t *win0) {
     const int64_t i = blockIdx.x;
     if (i >= n_segs) return;
     const int64_t g = i / per_group;
     const int64_t last = ((g + 1) * per_group < n_segs ? (g + 1) * per_group : n_segs) - 1;
     if (i == last) return;  // (gi_win_groups_kernel has written it)
-    const uint8_t *prev = g ? win + (size_t)(g * per_group - 1) * GI_WINDOW : nullptr;
+    const uint8_t *prev = g ? win + (size_t)(g * per_group - 1) * GI_WINDOW : win0;
     const uint16_t *c = win16 + (size_t)i * GI_WINDOW;
     uint8_t *out = win + (size_t)i * GI_WINDOW;
     for (uint32_t j = threadIdx.x; j < GI_WINDOW; j += 256) {
@@ -1105,11 +1113,11 @@ __global__ __launch_bounds__(256) void gi_win_apply_kernel(const uint16_t *win16
 }
 
 __global__ __launch_bounds__(256) void gi_resolve_kernel(const uint16_t *sym, const GiSeg *segs, const uint32_t *out_len, const u64 *text_off, int64_t n_segs,
-                                                         const uint8_t *win, uint8_t *text) {
+                                                         const uint8_t *win, const uint8_t *win0, uint8_t *text) {
     for (int64_t i = blockIdx.y; i < n_segs; i += gridDim.y) {
         const uint16_t *dst = sym + segs[i].out_off;
         const uint32_t n = out_len[i];
-        const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : nullptr;
+        const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : win0;
         uint8_t *out = text + text_off[i];
         for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
             const uint16_t v = dst[j];
@@ -1615,10 +1623,66 @@ struct GiDevBufs {  // freed on every way out
     }
 };
 
-extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text_out, int64_t *n_text, int64_t info[4]) {
-    if (!gz || !d_text_out || !n_text || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
-    *d_text_out = nullptr;
-    *n_text = 0;
+// ---- the streaming form: the stream is taken in BATCHES of about one segment per wave slot of the device (its compressed bytes, the
+// finder, the segments, the window pass chained to the window the batch before left, the text, the CRC-32 folded into a running
+// register), so that a file of any size goes through buffers of a few gigabytes.
+struct gs_gunzipper {
+    int device = 0, n_cu = 256;
+    const uint8_t *gz = nullptr;  // the mapped file (stays the caller's)
+    int64_t n = 0, hdr = 0, in_len = 0;
+    uint32_t want_crc = 0, want_isize = 0;
+    u64 bit = 0;          // of the next batch's first block, from the first byte of the deflate stream
+    bool done = false, more_members = false;
+    uint32_t raw = 0xffffffffu;  // running CRC-32 register (before the final inversion)
+    u64 total = 0;               // text bytes so far
+    uint32_t chunk = 65536, ratio = 16;
+    int text_only = 1;
+    int64_t n_batches = 0, n_segments = 0, n_mirages = 0, n_chunks = 0;
+    // device buffers, grown as needed
+    uint8_t *d_in = nullptr, *d_win = nullptr, *d_prev = nullptr, *d_text = nullptr, *d_tail = nullptr;
+    u64 *d_start = nullptr, *d_end = nullptr, *d_off = nullptr;
+    unsigned long long *d_q = nullptr;
+    GiSeg *d_segs = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_len = nullptr, *d_crc = nullptr;
+    uint16_t *d_sym = nullptr, *d_win16 = nullptr;
+    size_t in_cap = 0, start_cap = 0, seg_cap = 0, sym_cap = 0, win_cap = 0, win16_cap = 0, text_cap = 0, tail_cap = 0, crc_cap = 0;
+    bool have_prev = false;
+    int64_t last_n_text = 0;
+};
+
+template <typename T>
+static int gu_grow(T **p, size_t *cap, size_t need, size_t slack_pct = 12) {
+    if (*cap >= need && *p) return GS_OK;
+    hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need * slack_pct / 100 + 256;
+    const hipError_t e = hipMalloc((void **)p, want * sizeof(T));
+    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzipper: ") + hipGetErrorString(e));
+    *cap = want;
+    return GS_OK;
+}
+
+static int64_t gu_slots(int n_cu) {  // chunks per batch: the device's wave slots (GS_GUNZIP_SLOTS: tests force many small batches)
+    if (const char *e = getenv("GS_GUNZIP_SLOTS")) return std::max(1, std::min(1 << 20, atoi(e)));
+    return (int64_t)n_cu * 4 * gi_wgs_per_cu();
+}
+
+extern "C" int gs_gunzipper_close(gs_gunzipper *g) {
+    if (!g) return GS_OK;
+    hipSetDevice(g->device);
+    hipDeviceSynchronize();
+    for (void *p : {(void *)g->d_in, (void *)g->d_win, (void *)g->d_prev, (void *)g->d_text, (void *)g->d_tail, (void *)g->d_start, (void *)g->d_end, (void *)g->d_off,
+                    (void *)g->d_q, (void *)g->d_segs, (void *)g->d_status, (void *)g->d_len, (void *)g->d_crc, (void *)g->d_sym, (void *)g->d_win16})
+        hipFree(p);
+    delete g;
+    return GS_OK;
+}
+
+extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n) {
+    if (!out || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
+    *out = nullptr;
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
     // the member's header (RFC 1952)
@@ -1636,70 +1700,113 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
         }
     if (flg & 2) hdr += 2;
     if (hdr + 8 >= n) return gi_fail(GS_E_INVALID, "truncated gzip stream");
-    const int64_t in_len64 = n - hdr - 8;
-    if (in_len64 > ((int64_t)1 << 30)) return gi_fail(GS_E_UNSUPPORTED, "more than 1 GiB of compressed data: host decoders");
-    const uint32_t in_len = (uint32_t)in_len64;
-    const uint8_t *trailer = gz + n - 8;
-    const uint32_t want_crc = (uint32_t)trailer[0] | ((uint32_t)trailer[1] << 8) | ((uint32_t)trailer[2] << 16) | ((uint32_t)trailer[3] << 24);
-    const uint32_t want_isize = (uint32_t)trailer[4] | ((uint32_t)trailer[5] << 8) | ((uint32_t)trailer[6] << 16) | ((uint32_t)trailer[7] << 24);
     GI_TRY(hipSetDevice(device));
     int rc = gi_upload_crc_table();
     if (rc) return rc;
+    gs_gunzipper *g = new gs_gunzipper();
+    g->device = device;
     hipDeviceProp_t prop;
-    const int n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    // One segment per wave slot of the device, but not less than 16 KiB of compressed data (about one deflate block of zlib's): the
-    // finder reads a chunk only up to its first block start, the sequential window pass takes 2 us per segment, and a segment is
-    // decoded by one wave -- more segments than slots only add rounds.
-    uint32_t chunk = (uint32_t)std::max<int64_t>(16384, (int64_t)in_len / ((int64_t)n_cu * 4 * gi_wgs_per_cu()));
-    if (const char *e = getenv("GS_GUNZIP_CHUNK")) chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
-    int text_only = 1;  // GS_GUNZIP_ANY_BYTES=1: block starts whose literal code covers bytes >= 128 count as well
-    if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) text_only = atoi(e) == 0;
-    // symbols a segment may produce per byte of its compressed span: four times the stream's own ratio (ISIZE is known modulo 2^32:
-    // the smallest size that is not smaller than the compressed stream), at least 16; deflate's limit is 1032
-    uint64_t text_est = want_isize;
-    while (text_est < in_len) text_est += (uint64_t)1 << 32;
-    uint32_t ratio = (uint32_t)std::min<uint64_t>(1040, std::max<uint64_t>(16, 4 * (text_est / std::max<uint32_t>(in_len, 1)) + 4));
-    if (const char *e = getenv("GS_GUNZIP_RATIO")) ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
-    const int64_t n_chunks = ((int64_t)in_len + chunk - 1) / chunk;
-    GiDevBufs bufs;
-    uint8_t *d_in = nullptr;
-    u64 *d_start = nullptr;
-    unsigned long long *d_q = nullptr;
-    hipError_t e = bufs.get(&d_in, (size_t)in_len + 1024);
-    if (e == hipSuccess) e = bufs.get(&d_start, sizeof(u64) * (size_t)n_chunks);
-    if (e == hipSuccess) e = bufs.get(&d_q, 2 * sizeof(u64));
-    if (e == hipSuccess) e = hipMemset(d_in + in_len, 0, 1024);
-    if (e == hipSuccess && (rc = gi_h2d_staged(d_in, gz + hdr, in_len))) return rc;
-    if (e == hipSuccess) e = hipMemset(d_q, 0, 2 * sizeof(u64));
-    if (e == hipSuccess) e = hipMemset(d_start, 0xff, sizeof(u64) * (size_t)n_chunks);
-    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
-    const int wgs = n_cu * gi_wgs_per_cu();
-    // 1. block starts (chunk 0 starts with the stream)
+    g->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    g->gz = gz;
+    g->n = n;
+    g->hdr = hdr;
+    g->in_len = n - hdr;  // (what lies behind the deflate stream -- the trailer, further members -- is found when the final block is)
+    const int64_t slots = gu_slots(g->n_cu);
+    // One segment per wave slot, but not less than 16 KiB of compressed data (about one deflate block of zlib's) nor more than 64 KiB
+    // (then the stream takes several batches): the finder reads a chunk only up to its first block start, and more segments than
+    // slots only add rounds.
+    g->chunk = (uint32_t)std::min<int64_t>(65536, std::max<int64_t>(16384, g->in_len / slots));
+    if (const char *e = getenv("GS_GUNZIP_CHUNK")) g->chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
+    if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) g->text_only = atoi(e) == 0;  // block starts whose literal code covers bytes >= 128 count as well
+    // symbols a segment may produce per byte of its compressed span: generous for text (a FASTQ stream is 4 .. 6 : 1), deflate's
+    // limit is 1032 : 1; a segment that outgrows its room sends the rest of the file to the host decoders
+    g->ratio = 24;
+    if (g->in_len < ((int64_t)64 << 20)) {  // a small stream says how far it expands (ISIZE, modulo 2^32)
+        const uint8_t *t = gz + n - 8;
+        u64 est = (u64)t[4] | ((u64)t[5] << 8) | ((u64)t[6] << 16) | ((u64)t[7] << 24);
+        g->ratio = (uint32_t)std::min<u64>(1040, std::max<u64>(24, 4 * (est / (u64)std::max<int64_t>(g->in_len, 1)) + 4));
+    }
+    if (const char *e = getenv("GS_GUNZIP_RATIO")) g->ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
+    hipError_t e = hipMalloc((void **)&g->d_q, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_prev, GI_WINDOW);
+    if (e != hipSuccess) {
+        gs_gunzipper_close(g);
+        return gi_fail(GS_E_NOMEM, "gs_gunzipper_open");
+    }
+    *out = g;
+    return GS_OK;
+}
+
+// One batch.  keep_tail: the last `keep_tail` bytes of the text the call before returned stay in front of the new text (what lay behind
+// the caller's last whole record).  *last: 0 = more batches follow, 1 = the member's final block is through (CRC-32 and ISIZE were
+// right), 2 = as 1, and more data follows the member (another member: the caller's host decoders take over at *this* text offset).
+// The pointer is valid until the next call.
+extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text_out, int64_t *n_text, int *last) {
+    if (!g || !d_text_out || !n_text || !last || keep_tail < 0 || keep_tail > g->last_n_text) return gi_fail(GS_E_INVALID, "bad argument");
+    *d_text_out = nullptr;
+    *n_text = 0;
+    *last = 0;
+    if (g->done) return gi_fail(GS_E_STATE, "the stream is through");
+    GI_TRY(hipSetDevice(g->device));
+    int rc;
+    // the tail of the batch before, out of the way
+    if (keep_tail > 0) {
+        if ((rc = gu_grow(&g->d_tail, &g->tail_cap, (size_t)keep_tail))) return rc;
+        GI_TRY(hipMemcpy(g->d_tail, g->d_text + (g->last_n_text - keep_tail), (size_t)keep_tail, hipMemcpyDeviceToDevice));
+    }
+    const int64_t slots = gu_slots(g->n_cu);
+    const int wgs = g->n_cu * gi_wgs_per_cu();
+    const u64 base = (g->bit / 8u) & ~(u64)3;  // of the device copy, in the deflate stream
+    const u64 rel0 = g->bit - base * 8u;
+    const int64_t remain = g->in_len - (int64_t)base;
+    const int64_t nb_chunks = std::min<int64_t>(slots, (remain + g->chunk - 1) / g->chunk);
+    const int64_t span = std::min<int64_t>(remain, (nb_chunks + 64) * (int64_t)g->chunk);
+    const bool to_end = span == remain;
+    const int64_t n_chunks = (span + g->chunk - 1) / g->chunk;
+    if (span >= ((int64_t)1 << 31)) return gi_fail(GS_E_UNSUPPORTED, "a batch of more than 2 GiB");
+    const uint32_t in_len = (uint32_t)span;
+    if ((rc = gu_grow(&g->d_in, &g->in_cap, (size_t)span + 1024))) return rc;
+    if ((rc = gu_grow(&g->d_start, &g->start_cap, (size_t)n_chunks))) return rc;
+    if ((rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span))) return rc;
+    GI_TRY(hipMemset(g->d_in + span, 0, 1024));
+    GI_TRY(hipMemset(g->d_start, 0xff, sizeof(u64) * (size_t)n_chunks));
+    // 1. block starts (chunk 0 starts with the batch's first block)
     if (n_chunks > 1) {
-        unsigned long long one = 1;
-        GI_TRY(hipMemcpy(d_q, &one, sizeof(one), hipMemcpyHostToDevice));  // (the counter starts at chunk 1)
-        hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len,
-                           chunk, n_chunks, d_start, d_q, text_only);
+        unsigned long long one[2] = {1, 0};
+        GI_TRY(hipMemcpy(g->d_q, one, sizeof(one), hipMemcpyHostToDevice));  // (the counter starts at chunk 1)
+        hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len,
+                           g->chunk, n_chunks, g->d_start, g->d_q, g->text_only);
         GI_TRY(hipGetLastError());
     }
     std::vector<u64> starts((size_t)n_chunks);
-    GI_TRY(hipMemcpy(starts.data(), d_start, sizeof(u64) * (size_t)n_chunks, hipMemcpyDeviceToHost));
-    starts[0] = 0;
+    GI_TRY(hipMemcpy(starts.data(), g->d_start, sizeof(u64) * (size_t)n_chunks, hipMemcpyDeviceToHost));
+    starts[0] = rel0;
     std::vector<GiSeg> segs;
-    u64 sym_total = 0;
+    std::vector<u64> stops;  // found starts behind the batch's chunks: where its last segment may end
     for (int64_t c = 0; c < n_chunks; c++) {
-        if (starts[(size_t)c] == ~0ULL) continue;
+        if (starts[(size_t)c] == ~0ULL || (c > 0 && starts[(size_t)c] <= rel0)) continue;
+        if (c >= nb_chunks) {
+            stops.push_back(starts[(size_t)c]);
+            continue;
+        }
         if (!segs.empty()) segs.back().stop_bit = starts[(size_t)c];
         GiSeg sg{};
         sg.start_bit = starts[(size_t)c];
         segs.push_back(sg);
     }
+    size_t stop_at = 0;
+    if (stops.empty() && !to_end) return gi_fail(GS_E_UNSUPPORTED, "no block start in 64 chunks behind a batch: host decoders");
+    u64 sym_total = 0;
     for (size_t i = 0; i < segs.size(); i++) {
-        const u64 end = i + 1 < segs.size() ? segs[i].stop_bit : (u64)in_len * 8u;
-        const u64 span = (end - segs[i].start_bit) / 8u + 1u;
-        const u64 cap = span * ratio + 65536u;
+        const bool is_last = i + 1 == segs.size();
+        if (is_last) {
+            segs[i].to_final = stops.empty();
+            segs[i].stop_bit = stops.empty() ? 0 : stops[0];
+        }
+        const u64 end = is_last ? (stops.empty() ? (u64)in_len * 8u : stops.back()) : segs[i].stop_bit;  // (room up to the farthest stop: it may have to run on)
+        const u64 span_b = (end - segs[i].start_bit) / 8u + 1u;
+        const u64 cap = span_b * g->ratio + 65536u;
         if (cap > 0xffff0000ull) return gi_fail(GS_E_UNSUPPORTED, "a segment of more than 4 G symbols");
-        segs[i].to_final = i + 1 == segs.size();
         segs[i].out_cap = (uint32_t)cap;
         sym_total += GI_WINDOW;
         segs[i].out_off = sym_total;
@@ -1707,42 +1814,52 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
     }
     const int64_t n_segs = (int64_t)segs.size();
     // 2. segments
-    GiSeg *d_segs = nullptr;
-    uint16_t *d_sym = nullptr;
-    int32_t *d_status = nullptr;
-    uint32_t *d_len = nullptr;
-    e = bufs.get(&d_segs, sizeof(GiSeg) * (size_t)n_segs);
     u64 sym_used = sym_total;
     const u64 sym_room = sym_total + sym_total / 8 + ((u64)64 << 20);  // slack for segments that are decoded again (mirages, below)
-    if (e == hipSuccess) e = bufs.get(&d_sym, sizeof(uint16_t) * (size_t)sym_room + 64);
-    if (e == hipSuccess) e = bufs.get(&d_status, sizeof(int32_t) * (size_t)n_segs);
-    if (e == hipSuccess) e = bufs.get(&d_len, sizeof(uint32_t) * (size_t)n_segs);
-    if (e == hipSuccess) e = hipMemcpy(d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_segs + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, d_segs,
-                       n_segs, d_sym, d_status, d_len, d_q + 1);
+    if ((rc = gu_grow(&g->d_sym, &g->sym_cap, (size_t)sym_room + 64, 0))) return rc;
+    if (g->seg_cap < (size_t)n_segs) {
+        size_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        if ((rc = gu_grow(&g->d_segs, &c1, (size_t)n_segs)) || (rc = gu_grow(&g->d_status, &c2, (size_t)n_segs)) || (rc = gu_grow(&g->d_len, &c3, (size_t)n_segs)) ||
+            (rc = gu_grow(&g->d_end, &c4, (size_t)n_segs)) || (rc = gu_grow(&g->d_off, &c5, (size_t)n_segs)))
+            return rc;
+        g->seg_cap = std::min(std::min(c1, c2), std::min(std::min(c3, c4), c5));
+    }
+    GI_TRY(hipMemcpy(g->d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs, hipMemcpyHostToDevice));
+    GI_TRY(hipMemset(g->d_q + 1, 0, sizeof(u64)));
+    hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_segs + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len, g->d_segs,
+                       n_segs, g->d_sym, g->d_status, g->d_len, g->d_end, g->d_q + 1);
     GI_TRY(hipGetLastError());
     std::vector<int32_t> st((size_t)n_segs);
     std::vector<uint32_t> len((size_t)n_segs);
-    GI_TRY(hipMemcpy(st.data(), d_status, sizeof(int32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
-    GI_TRY(hipMemcpy(len.data(), d_len, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    std::vector<u64> endb((size_t)n_segs);
+    GI_TRY(hipMemcpy(st.data(), g->d_status, sizeof(int32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    GI_TRY(hipMemcpy(len.data(), g->d_len, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    GI_TRY(hipMemcpy(endb.data(), g->d_end, sizeof(u64) * (size_t)n_segs, hipMemcpyDeviceToHost));
     // A block start that was a mirage (a bit pattern that parses as a complete dynamic header: about one per 100 MB of compressed
-    // data) shows as the segment IN FRONT of it running past it: that segment is decoded again up to the start after the mirage,
-    // into the slack behind the symbols (the mirage's own segment is dropped).  A few rounds: two mirages may follow each other.
-    int64_t n_mirages = 0;
-    for (int round = 0; round < 4; round++) {
-        std::vector<GiSeg> redo;
+    // data without the text test) shows as the segment IN FRONT of it running past it: that segment is decoded again up to the start
+    // after the mirage, into the slack behind the symbols (the mirage's own segment is dropped); for the batch's last segment the
+    // next of the starts behind the batch takes the mirage's place.  A few rounds: two mirages may follow each other.
+    for (int round = 0; round < 6; round++) {
+        std::vector<GiSeg> redo, kept;
         std::vector<size_t> redo_at;
-        std::vector<GiSeg> kept;
         std::vector<int32_t> kst;
         std::vector<uint32_t> klen;
+        std::vector<u64> kend;
         for (size_t i = 0; i < segs.size(); i++) {
-            if (st[i] == GI_E_SYNC && i + 1 < segs.size()) {
+            const bool is_last = i + 1 == segs.size();
+            if (st[i] == GI_E_SYNC && (!is_last || (!segs[i].to_final && (stop_at + 1 < stops.size() || to_end)))) {
                 GiSeg m = segs[i];
-                const GiSeg &gone = segs[i + 1];
-                m.stop_bit = gone.stop_bit;
-                m.to_final = gone.to_final;
-                const u64 cap = (u64)m.out_cap + gone.out_cap;
+                u64 cap = m.out_cap;
+                if (!is_last) {
+                    const GiSeg &gone = segs[i + 1];
+                    m.stop_bit = gone.stop_bit;
+                    m.to_final = gone.to_final;
+                    cap += gone.out_cap;
+                } else {
+                    stop_at++;
+                    m.to_final = stop_at >= stops.size();
+                    m.stop_bit = m.to_final ? 0 : stops[stop_at];
+                }
                 if (cap > 0xffff0000ull || sym_used + GI_WINDOW + cap > sym_room) return gi_fail(GS_E_UNSUPPORTED, "no room to decode a segment again: host decoders");
                 m.out_cap = (uint32_t)cap;
                 sym_used += GI_WINDOW;
@@ -1753,90 +1870,163 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
                 kept.push_back(m);
                 kst.push_back(GI_OK);
                 klen.push_back(0);
-                n_mirages++;
-                i++;  // (the segment behind the mirage is gone)
+                kend.push_back(0);
+                g->n_mirages++;
+                if (!is_last) i++;  // (the segment behind the mirage is gone)
             } else {
                 kept.push_back(segs[i]);
                 kst.push_back(st[i]);
                 klen.push_back(len[i]);
+                kend.push_back(endb[i]);
             }
         }
         if (redo.empty()) break;
         const int64_t n_redo = (int64_t)redo.size();
-        GI_TRY(hipMemcpy(d_segs, redo.data(), sizeof(GiSeg) * (size_t)n_redo, hipMemcpyHostToDevice));  // (the master copy goes back below)
-        GI_TRY(hipMemset(d_q + 1, 0, sizeof(u64)));
-        hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_redo + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, d_segs,
-                           n_redo, d_sym, d_status, d_len, d_q + 1);
+        GI_TRY(hipMemcpy(g->d_segs, redo.data(), sizeof(GiSeg) * (size_t)n_redo, hipMemcpyHostToDevice));  // (the master copy goes back below)
+        GI_TRY(hipMemset(g->d_q + 1, 0, sizeof(u64)));
+        hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_redo + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len, g->d_segs,
+                           n_redo, g->d_sym, g->d_status, g->d_len, g->d_end, g->d_q + 1);
         GI_TRY(hipGetLastError());
         std::vector<int32_t> rst((size_t)n_redo);
         std::vector<uint32_t> rlen((size_t)n_redo);
-        GI_TRY(hipMemcpy(rst.data(), d_status, sizeof(int32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
-        GI_TRY(hipMemcpy(rlen.data(), d_len, sizeof(uint32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
+        std::vector<u64> rend((size_t)n_redo);
+        GI_TRY(hipMemcpy(rst.data(), g->d_status, sizeof(int32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
+        GI_TRY(hipMemcpy(rlen.data(), g->d_len, sizeof(uint32_t) * (size_t)n_redo, hipMemcpyDeviceToHost));
+        GI_TRY(hipMemcpy(rend.data(), g->d_end, sizeof(u64) * (size_t)n_redo, hipMemcpyDeviceToHost));
         for (size_t r = 0; r < redo.size(); r++) {
             kst[redo_at[r]] = rst[r];
             klen[redo_at[r]] = rlen[r];
+            kend[redo_at[r]] = rend[r];
         }
         segs.swap(kept);
         st.swap(kst);
         len.swap(klen);
+        endb.swap(kend);
     }
-    const int64_t n_segs_final = (int64_t)segs.size();
-    GI_TRY(hipMemcpy(d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs_final, hipMemcpyHostToDevice));
-    GI_TRY(hipMemcpy(d_len, len.data(), sizeof(uint32_t) * (size_t)n_segs_final, hipMemcpyHostToDevice));
-    std::vector<u64> off((size_t)n_segs_final + 1, 0);
-    for (int64_t i = 0; i < n_segs_final; i++) {
-        if (st[(size_t)i] == GI_E_SYNC || st[(size_t)i] == GI_E_OVERRUN)
-            return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + " of " + std::to_string(n_segs_final) + (st[(size_t)i] == GI_E_SYNC ? " does not end where the next one starts" : " outgrows its buffer") + ": host decoders");
-        if (st[(size_t)i] != GI_OK && i == 0) return gi_fail(GS_E_INVALID, "corrupt gzip stream (inflate status " + std::to_string(st[(size_t)i]) + " in the first segment)");
-        if (st[(size_t)i] != GI_OK) return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + ": inflate status " + std::to_string(st[(size_t)i]) + " (a damaged stream or a false block start): host decoders");
+    const int64_t n_fin = (int64_t)segs.size();
+    GI_TRY(hipMemcpy(g->d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_fin, hipMemcpyHostToDevice));
+    GI_TRY(hipMemcpy(g->d_len, len.data(), sizeof(uint32_t) * (size_t)n_fin, hipMemcpyHostToDevice));
+    std::vector<u64> off((size_t)n_fin + 1, 0);
+    for (int64_t i = 0; i < n_fin; i++) {
+        const int e = st[(size_t)i];
+        if (e == GI_E_SYNC || e == GI_E_OVERRUN)
+            return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + " of " + std::to_string(n_fin) + (e == GI_E_SYNC ? " does not end where the next one starts" : " outgrows its buffer") + ": host decoders");
+        if (e != GI_OK && i == 0 && g->n_batches == 0) return gi_fail(GS_E_INVALID, "corrupt gzip stream (inflate status " + std::to_string(e) + " in the first segment)");
+        if (e != GI_OK) return gi_fail(GS_E_UNSUPPORTED, "segment " + std::to_string(i) + ": inflate status " + std::to_string(e) + " (a damaged stream or a false block start): host decoders");
         off[(size_t)i + 1] = off[(size_t)i] + len[(size_t)i];
     }
-    const int64_t total = (int64_t)off[(size_t)n_segs_final];
-    if ((uint32_t)total != want_isize) return gi_fail(GS_E_UNSUPPORTED, "ISIZE does not match (several members, or a damaged stream): host decoders");
-    // 3. windows, 4. text
-    uint8_t *d_win = nullptr, *d_text = nullptr;
-    u64 *d_off = nullptr;
-    uint32_t *d_crc = nullptr;
+    const int64_t n_new = (int64_t)off[(size_t)n_fin];
+    const bool final_batch = segs.back().to_final != 0;
+    // 3. windows (chained to the batch before), 4. text behind the kept tail, 5. CRC-32 of the new text
     const uint32_t tile = 65536;
-    const int64_t n_tiles = (total + tile - 1) / tile;
-    uint16_t *d_win16 = nullptr;
-    e = bufs.get(&d_win, (size_t)n_segs_final * GI_WINDOW);
-    if (e == hipSuccess) e = bufs.get(&d_win16, sizeof(uint16_t) * (size_t)n_segs_final * GI_WINDOW);
-    if (e == hipSuccess) e = bufs.get(&d_text, (size_t)total + 8192);
-    if (e == hipSuccess) e = bufs.get(&d_off, sizeof(u64) * (size_t)n_segs_final);
-    if (e == hipSuccess) e = bufs.get(&d_crc, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_tiles, 1));
-    if (e == hipSuccess) e = hipMemcpy(d_off, off.data(), sizeof(u64) * (size_t)n_segs_final, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return gi_fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_gunzip: ") + hipGetErrorString(e));
-    hipLaunchKernelGGL(gi_window_prep_kernel, dim3((unsigned)n_segs_final), dim3(256), 0, 0, d_sym, d_segs, d_len, n_segs_final, d_win16);
+    const int64_t n_tiles = (n_new + tile - 1) / tile;
+    if ((rc = gu_grow(&g->d_win, &g->win_cap, (size_t)n_fin * GI_WINDOW))) return rc;
+    if ((rc = gu_grow(&g->d_win16, &g->win16_cap, (size_t)n_fin * GI_WINDOW))) return rc;
+    if ((rc = gu_grow(&g->d_text, &g->text_cap, (size_t)(keep_tail + n_new) + 8192))) return rc;
+    if ((rc = gu_grow(&g->d_crc, &g->crc_cap, (size_t)std::max<int64_t>(n_tiles, 1)))) return rc;
+    GI_TRY(hipMemcpy(g->d_off, off.data(), sizeof(u64) * (size_t)n_fin, hipMemcpyHostToDevice));
+    if (keep_tail > 0) GI_TRY(hipMemcpy(g->d_text, g->d_tail, (size_t)keep_tail, hipMemcpyDeviceToDevice));
+    const uint8_t *win0 = g->have_prev ? g->d_prev : nullptr;
+    hipLaunchKernelGGL(gi_window_prep_kernel, dim3((unsigned)n_fin), dim3(256), 0, 0, g->d_sym, g->d_segs, g->d_len, n_fin, g->d_win16);
     {
-        const int64_t per_group = std::max<int64_t>(1, (n_segs_final + 127) / 128), n_groups = (n_segs_final + per_group - 1) / per_group;
-        if (per_group > 1) hipLaunchKernelGGL(gi_win_compose_kernel, dim3((unsigned)n_groups), dim3(1024), 0, 0, d_win16, n_segs_final, per_group);
-        hipLaunchKernelGGL(gi_win_groups_kernel, dim3(1), dim3(1024), 0, 0, d_win16, n_segs_final, per_group, d_win);
-        if (per_group > 1) hipLaunchKernelGGL(gi_win_apply_kernel, dim3((unsigned)n_segs_final), dim3(256), 0, 0, d_win16, n_segs_final, per_group, d_win);
+        const int64_t per_group = std::max<int64_t>(1, (n_fin + 127) / 128), n_groups = (n_fin + per_group - 1) / per_group;
+        if (per_group > 1) hipLaunchKernelGGL(gi_win_compose_kernel, dim3((unsigned)n_groups), dim3(1024), 0, 0, g->d_win16, n_fin, per_group);
+        hipLaunchKernelGGL(gi_win_groups_kernel, dim3(1), dim3(1024), 0, 0, g->d_win16, n_fin, per_group, g->d_win, win0);
+        if (per_group > 1) hipLaunchKernelGGL(gi_win_apply_kernel, dim3((unsigned)n_fin), dim3(256), 0, 0, g->d_win16, n_fin, per_group, g->d_win, win0);
     }
-    hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_segs_final, 16384)), dim3(256), 0, 0, d_sym, d_segs, d_len, d_off, n_segs_final, d_win, d_text);
-    if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, d_text, total, tile, d_crc);
+    hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_fin, 16384)), dim3(256), 0, 0, g->d_sym, g->d_segs, g->d_len, g->d_off, n_fin, g->d_win, win0,
+                       g->d_text + keep_tail);
+    if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, g->d_text + keep_tail, n_new, tile, g->d_crc);
     GI_TRY(hipGetLastError());
+    GI_TRY(hipMemcpy(g->d_prev, g->d_win + (size_t)(n_fin - 1) * GI_WINDOW, GI_WINDOW, hipMemcpyDeviceToDevice));  // (a short batch's window reaches into the one before: gi_win_* took it from win0)
+    g->have_prev = true;
     std::vector<uint32_t> crc((size_t)std::max<int64_t>(n_tiles, 1), 0);
-    GI_TRY(hipMemcpy(crc.data(), d_crc, sizeof(uint32_t) * (size_t)n_tiles, hipMemcpyDeviceToHost));
-    // 5. the tiles' registers behind one another: R = 0xffffffff x^(8 n) + sum_t R_t x^(8 bytes behind tile t)
-    uint32_t reg = gi_h_gf_mul(0xffffffffu, gi_h_x_pow_8n((uint64_t)total));
-    const uint32_t x_tile = gi_h_x_pow_8n(tile);
-    uint32_t xp = 0x80000000u;  // x^0: the last tile has nothing behind it
-    for (int64_t t = n_tiles - 1; t >= 0; t--) {
-        reg ^= gi_h_gf_mul(crc[(size_t)t], xp);
-        xp = gi_h_gf_mul(xp, t == n_tiles - 1 ? gi_h_x_pow_8n((uint64_t)(total - t * (int64_t)tile)) : x_tile);  // (the tile's own bytes join what lies behind the next one)
+    if (n_tiles > 0) GI_TRY(hipMemcpy(crc.data(), g->d_crc, sizeof(uint32_t) * (size_t)n_tiles, hipMemcpyDeviceToHost));
+    {   // the tiles' registers behind one another, then behind the register so far: R = R_before x^(8 n) + sum_t R_t x^(8 bytes behind tile t)
+        uint32_t add = 0;
+        const uint32_t x_tile = gi_h_x_pow_8n(tile);
+        uint32_t xp = 0x80000000u;  // x^0: the last tile has nothing behind it
+        for (int64_t t = n_tiles - 1; t >= 0; t--) {
+            add ^= gi_h_gf_mul(crc[(size_t)t], xp);
+            xp = gi_h_gf_mul(xp, t == n_tiles - 1 ? gi_h_x_pow_8n((uint64_t)(n_new - t * (int64_t)tile)) : x_tile);
+        }
+        g->raw = gi_h_gf_mul(g->raw, gi_h_x_pow_8n((uint64_t)n_new)) ^ add;
     }
-    if ((reg ^ 0xffffffffu) != want_crc) return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
-    bufs.keep(d_text);
-    *d_text_out = d_text;
-    *n_text = total;
-    if (info) {
-        info[0] = n_segs_final;
-        info[1] = n_chunks;
-        info[2] = (int64_t)sym_total;
-        info[3] = n_mirages;
+    g->total += (u64)n_new;
+    g->n_batches++;
+    g->n_segments += n_fin;
+    g->n_chunks += n_chunks;
+    g->last_n_text = keep_tail + n_new;
+    *d_text_out = g->d_text;
+    *n_text = keep_tail + n_new;
+    if (final_batch) {
+        g->done = true;
+        // the trailer behind the final block's last byte; whatever follows it is another member
+        const u64 end_byte = base + (endb.back() + 7u) / 8u;
+        if ((int64_t)end_byte + 8 > g->in_len) return gi_fail(GS_E_INVALID, "corrupt gzip stream: no trailer behind the final block");
+        const uint8_t *t = g->gz + g->hdr + end_byte;
+        const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t want_isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if ((uint32_t)g->total != want_isize) return gi_fail(GS_E_INVALID, "corrupt gzip stream: ISIZE does not match the inflated text");
+        if ((g->raw ^ 0xffffffffu) != want_crc) return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
+        g->more_members = (int64_t)end_byte + 8 < g->in_len;
+        *last = g->more_members ? 2 : 1;
+    } else {
+        g->bit = base * 8u + segs.back().stop_bit;
     }
+    return GS_OK;
+}
+
+extern "C" int gs_gunzipper_info(const gs_gunzipper *g, int64_t info[4]) {
+    if (!g || !info) return gi_fail(GS_E_INVALID, "NULL argument");
+    info[0] = g->n_segments;
+    info[1] = g->n_chunks;
+    info[2] = g->n_batches;
+    info[3] = g->n_mirages;
+    return GS_OK;
+}
+
+// the whole stream into one device buffer (tests, tools; a file the host pipeline takes goes batch by batch)
+extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text_out, int64_t *n_text, int64_t info[4]) {
+    if (!d_text_out || !n_text) return gi_fail(GS_E_INVALID, "bad argument");
+    *d_text_out = nullptr;
+    *n_text = 0;
+    gs_gunzipper *g = nullptr;
+    int rc = gs_gunzipper_open(&g, device, gz, n);
+    if (rc) return rc;
+    uint8_t *all = nullptr;
+    size_t cap = 0, have = 0;
+    for (;;) {
+        const uint8_t *t = nullptr;
+        int64_t nt = 0;
+        int last = 0;
+        rc = gs_gunzipper_next(g, 0, &t, &nt, &last);
+        if (!rc && last == 2) rc = gi_fail(GS_E_UNSUPPORTED, "several members in one file: host decoders");
+        if (!rc && have + (size_t)nt + 8192 > cap) {
+            uint8_t *bigger = nullptr;
+            const size_t want = (have + (size_t)nt) * (last ? 1 : 2) + 8192;
+            if (hipMalloc((void **)&bigger, want) != hipSuccess) rc = gi_fail(GS_E_NOMEM, "gs_gunzip_plan_device");
+            if (!rc && have && hipMemcpy(bigger, all, have, hipMemcpyDeviceToDevice) != hipSuccess) rc = gi_fail(GS_E_HIP, "gs_gunzip_plan_device");
+            if (!rc) {
+                hipFree(all);
+                all = bigger;
+                cap = want;
+            } else
+                hipFree(bigger);
+        }
+        if (!rc && nt > 0 && hipMemcpy(all + have, t, (size_t)nt, hipMemcpyDeviceToDevice) != hipSuccess) rc = gi_fail(GS_E_HIP, "gs_gunzip_plan_device");
+        if (rc) break;
+        have += (size_t)nt;
+        if (last) break;
+    }
+    if (!rc && info) gs_gunzipper_info(g, info);
+    gs_gunzipper_close(g);
+    if (rc) {
+        hipFree(all);
+        return rc;
+    }
+    *d_text_out = all;
+    *n_text = (int64_t)have;
     return GS_OK;
 }
 

@@ -501,11 +501,23 @@ int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_mem
                      int64_t next_hi, int last, const uint8_t **text, int64_t *n_bytes, int64_t *n_lines, int64_t *tail_bytes);
 /* A SINGLE-MEMBER gzip stream (gzip, pigz) inflated on the device: block boundaries found speculatively, segments decoded side by
  * side with markers for the unknown 32 KiB window, windows resolved in a second pass (gs_inflate_dev.hip), CRC-32 and ISIZE checked
- * as java.util.zip.GZIPInputStream does (B/io/StreamProvider.java:92-100).  gs_gunzip_plan_device leaves the text in device memory
- * (*d_text, released with gs_gunzip_free); gs_gunzip_device copies it to `out` (tests, tools).  GS_E_UNSUPPORTED: not a stream this
- * path takes (several members, a segment that outgrows its buffer, a block boundary that was a mirage, > 1 GiB compressed) -- the
- * caller inflates on the host instead; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).
- * info (may be NULL): [0] segments, [1] chunks searched, [2] symbols, [3] block starts that were mirages (decoded again). */
+ * as java.util.zip.GZIPInputStream does (B/io/StreamProvider.java:92-100).
+ * gs_gunzipper_*: the stream in BATCHES of about one segment per wave slot of the device (a file of any size through buffers of a few
+ * gigabytes).  gs_gunzipper_next: the text of the next batch in device memory, behind the last `keep_tail` bytes of the text the call
+ * before returned (what lay behind the caller's last whole record); the pointer is valid until the next call.  *last: 0 = more
+ * batches follow, 1 = the member is through (CRC-32 and ISIZE were right), 2 = as 1 and more data follows the member (another
+ * member: inflate the rest on the host, from this text offset).  GS_E_UNSUPPORTED (from open or from any batch): not a stream this
+ * path takes from here on (a segment that outgrows its buffer, a block boundary that was a mirage and could not be repaired) -- the
+ * caller inflates the rest on the host; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).  `gz` must stay
+ * readable until gs_gunzipper_close.  gs_gunzipper_info: [0] segments, [1] chunks searched, [2] batches, [3] block starts that were
+ * mirages (decoded again).
+ * gs_gunzip_plan_device: the whole stream into ONE device buffer (released with gs_gunzip_free; several members: GS_E_UNSUPPORTED);
+ * gs_gunzip_device copies it to `out` (tests, tools).  info as gs_gunzipper_info. */
+typedef struct gs_gunzipper gs_gunzipper;
+int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n);
+int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text, int64_t *n_text, int *last);
+int gs_gunzipper_info(const gs_gunzipper *g, int64_t info[4]);
+int gs_gunzipper_close(gs_gunzipper *g);
 int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text, int64_t *n_text, int64_t info[4]);
 int gs_gunzip_free(int device, uint8_t *d_text);
 int gs_gunzip_device(int device, const uint8_t *gz, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_text, int64_t info[4]);

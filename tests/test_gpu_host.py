@@ -271,6 +271,8 @@ def test_filter_files_bgzf_input_inflated_on_the_device(sdb, tmp_path, monkeypat
         import gzip
         open(path, "wb").write(gzip.compress(data, compresslevel=6, mtime=0))
         monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+        if text_target:
+            monkeypatch.setenv("GS_GUNZIP_SLOTS", "5")  # (the stream in many batches)
     p = orc.parse_fastq(data, k=31)
     want = ob.filter_batch(31, 1, 0.2, p["seq"], p["seq_off"])
     if text_target:

@@ -273,6 +273,19 @@ def test_single_member_gzip_equals_zlib(level):
         assert info[0] >= 1 and (chunk != "4096" or info[0] > 10), info
 
 
+@pytest.mark.parametrize("slots", ["3", "17"])
+def test_single_member_gzip_in_many_batches(monkeypatch, slots):
+    """the stream in batches of a few chunks: every batch starts at the block the one before stopped at, its windows are resolved through
+    the window the batch before left, the CRC-32 is folded into a running register"""
+    monkeypatch.setenv("GS_GUNZIP_SLOTS", slots)
+    monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+    for level in (1, 6):
+        text = _fastq_like(12000, 40 + level)
+        got, info = ga.gunzip_device(_gz(text, level), len(text))
+        assert got.tobytes() == text
+        assert info[2] > 5, info  # batches
+
+
 def test_single_member_gzip_shapes():
     rng = np.random.default_rng(3)
     for name, data in (("empty", b""), ("one byte", b"x"), ("runs", (b"A" * 1000 + b"\n") * 3000),
@@ -324,8 +337,9 @@ def test_binary_data_and_mirages(monkeypatch):
         assert got.tobytes() == data, any_bytes
 
 
+@pytest.mark.parametrize("batches", [False, True])
 @pytest.mark.parametrize("outputs", [False, True])
-def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs):
+def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs, batches):
     """gs_host_match_files on a plain (single-member) .gz: inflated on the device as a whole; table, totals and per-read files must
     equal the host-decoder run, also when the file ends in the middle of a record"""
     from genestrip_amd import host, synth
@@ -335,6 +349,9 @@ def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs):
     path = tmp_path / "reads.fastq.gz"
     path.write_bytes(_gz(text, 6))
     monkeypatch.setenv("GS_HOST_BGZF_TEXT", "700000")  # several slices
+    if batches:  # ... and several batches of the stream: records that straddle a batch are carried on the device
+        monkeypatch.setenv("GS_GUNZIP_SLOTS", "7")
+        monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
     store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     got = {}
     for dev in ("1", "0"):
@@ -347,4 +364,24 @@ def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs):
         got[dev] = (t, (tot.reads, tot.kmers, tot.bps), files)
     assert np.array_equal(got["1"][0], got["0"][0]) and got["1"][1] == got["0"][1] and got["1"][2] == got["0"][2]
     assert got["1"][1][0] in (19999, 20000)  # (the last record is cut short: what becomes of it is the reference parser's business)
+    store.close()
+
+
+def test_two_gzip_members_in_one_file(tmp_path, monkeypatch):
+    """`cat a.gz b.gz`: the device path inflates the first member (CRC-32 checked), says that more follows, and the host decoders take the
+    rest from that text offset -- table and totals as the host-decoder run over the whole file"""
+    from genestrip_amd import host, synth
+    db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
+    seq, off = synth.reads_host(db.genomes, 9000, read_len=150, seed=31)
+    text = _fastq(seq, off)
+    cut = text.index(b"\n@", len(text) // 2) + 1
+    path = tmp_path / "two.fastq.gz"
+    path.write_bytes(_gz(text[:cut], 6) + _gz(text[cut:], 1))
+    store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+    got = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("GS_DEVICE_GUNZIP", dev)
+        t, _, tot = host.match_files(store, [str(path)])
+        got[dev] = (t, (tot.reads, tot.kmers, tot.bps))
+    assert np.array_equal(got["1"][0], got["0"][0]) and got["1"][1] == got["0"][1] and got["1"][1][0] == 9000
     store.close()
