@@ -1947,6 +1947,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     if (fallback_off >= 0) {
         err = gs_filter_text_reset(c.bloom, 1);
         if (err) return err;
+        // not four lines per record from the very first chunk: once more with the records found on the device, as filter_text_file
+        bool ml = fallback_off == 0;
+        if (const char *e = getenv("GS_HOST_ML")) ml = ml && atoi(e) != 0;
+        if (ml) return filter_general_file(c, path, true, false);
         return filter_parsed_source(c, path, fallback_off, nullptr, 0);
     }
     if (!carry.empty()) return filter_parsed_source(c, std::string(), 0, carry.data(), carry.size());
