@@ -804,7 +804,7 @@ struct TextJob {
             }
             const int grc = gs_gunzipper_next(gzr_, rest, &gz_text_, &gz_n_, &gz_last_);
             gz_off_ = 0;
-            if (grc == GS_E_UNSUPPORTED) {  // from here on the host decoders (the tail that was kept belongs to them as well)
+            if (grc == GS_E_UNSUPPORTED || grc == GS_E_NOMEM) {  // from here on the host decoders (the tail that was kept belongs to them as well)
                 fallback_off = carry_file_off;
                 fallback_reads = reads_in_file;
                 gz_n_ = 0;
@@ -1845,7 +1845,7 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
                 if (n_lines > 0 || gz_last || look < rest) break;
                 const int grc = gs_gunzipper_next(gzr, rest, &gz_text, &gz_n, &gz_last);  // (every earlier slice has been waited for: gs_filter_text_status)
                 gz_off = 0;
-                if (grc == GS_E_UNSUPPORTED) {
+                if (grc == GS_E_UNSUPPORTED || grc == GS_E_NOMEM) {
                     refused = true;
                     gz_n = 0;
                     break;
