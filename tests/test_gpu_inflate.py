@@ -273,6 +273,19 @@ def test_single_member_gzip_equals_zlib(level):
         assert info[0] >= 1 and (chunk != "4096" or info[0] > 10), info
 
 
+def test_golden_sample_fastq_gz_on_the_device(monkeypatch):
+    """the reference's own fixture (sample.fastq.gz of the human_virus project) as it lies on disk -- whatever wrote it -- through the device
+    decoder, whole and in small batches"""
+    raw = open(os.path.join(GOLDEN, "human_virus", "sample.fastq.gz"), "rb").read()
+    text = gzip.decompress(raw)
+    got, info = ga.gunzip_device(raw, len(text))
+    assert got.tobytes() == text
+    monkeypatch.setenv("GS_GUNZIP_SLOTS", "4")
+    monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+    got, info = ga.gunzip_device(raw, len(text))
+    assert got.tobytes() == text
+
+
 @pytest.mark.parametrize("slots", ["3", "17"])
 def test_single_member_gzip_in_many_batches(monkeypatch, slots):
     """the stream in batches of a few chunks: every batch starts at the block the one before stopped at, its windows are resolved through
