@@ -517,7 +517,8 @@ struct GiOut<true> {
     typedef uint16_t T;
 };
 #define GI_WINDOW 32768u
-enum { GI_E_SYNC = 9 };  // a segment did not end on the block boundary the next segment starts at (or the stream ended inside it)
+enum { GI_E_SYNC = 9,     // a segment did not end on the block boundary the next segment starts at
+       GI_FINAL = 10 };    // (not an error) the member's final block lay inside the segment: it is the member's last, its text is good
 
 template <bool MARK>
 __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits &b, uint32_t in_len, u64 stop_bit, bool to_final,
@@ -525,6 +526,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
     typedef typename GiOut<MARK>::T OutT;
     constexpr uint32_t RM = GI_RING - 1u;
     constexpr uint32_t BACK = MARK ? GI_WINDOW : 0u;  // how far in front of the unit's first symbol a match may reach
+    bool final_inside = false;
     uint32_t pos = 0;          // bytes of text produced (stored or pending)
     uint32_t npend = 0;        // pending literals (lane j < npend holds byte pos - npend + j)
     uint32_t pbyte = 0;
@@ -545,10 +547,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
         if (MARK && !to_final && b.consumed() >= stop_bit) break;  // the next segment's first block (checked behind the loop)
         b.refill(lane);
         last = b.get(1) != 0;
-        if (MARK && last && !to_final) {  // the stream ends inside a segment that is not the last one
-            err = GI_E_SYNC;
-            break;
-        }
+        if (MARK && last && !to_final) final_inside = true;  // the member ends inside this segment (another member follows: GI_FINAL)
         const uint32_t btype = b.get(2);
         if (btype == 0) {  // stored: to the byte boundary, LEN, ~LEN, bytes
             b.drop(b.bc & 7);
@@ -827,6 +826,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
     }
     if (err == GI_OK && pos > cap) err = GI_E_OVERRUN;
     if (err == GI_OK) flush();
+    if (MARK && err == GI_OK && final_inside) err = GI_FINAL;
     if (MARK && err == GI_OK && !to_final && b.consumed() != stop_bit) err = GI_E_SYNC;
     *produced = pos;
     return err;
@@ -1643,7 +1643,7 @@ struct gs_gunzipper {
     u64 total = 0;               // text bytes so far
     uint32_t chunk = 65536, ratio = 16;
     int text_only = 1;
-    int64_t n_batches = 0, n_segments = 0, n_mirages = 0, n_chunks = 0;
+    int64_t n_batches = 0, n_segments = 0, n_mirages = 0, n_chunks = 0, n_members = 1;
     // device buffers, grown as needed
     uint8_t *d_in = nullptr, *d_win = nullptr, *d_prev = nullptr, *d_text = nullptr, *d_tail = nullptr;
     u64 *d_start = nullptr, *d_end = nullptr, *d_off = nullptr;
@@ -1686,17 +1686,13 @@ extern "C" int gs_gunzipper_close(gs_gunzipper *g) {
     return GS_OK;
 }
 
-extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n) {
-    if (!out || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
-    *out = nullptr;
-    int nd = 0;
-    if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
-    // the member's header (RFC 1952)
-    if (gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) return gi_fail(GS_E_INVALID, "not a gzip stream");
+// length of the member header at p (RFC 1952), or -1: not a gzip member / truncated
+static int64_t gi_gzip_header(const uint8_t *gz, int64_t n) {
+    if (n < 18 || gz[0] != 0x1f || gz[1] != 0x8b || gz[2] != 8 || (gz[3] & 0xe0)) return -1;
     const int flg = gz[3];
     int64_t hdr = 10;
     if (flg & 4) {
-        if (hdr + 2 > n) return gi_fail(GS_E_INVALID, "truncated gzip header");
+        if (hdr + 2 > n) return -1;
         hdr += 2 + ((int64_t)gz[hdr] | ((int64_t)gz[hdr + 1] << 8));
     }
     for (int bit : {8, 16})
@@ -1705,7 +1701,16 @@ extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *
             hdr++;
         }
     if (flg & 2) hdr += 2;
-    if (hdr + 8 >= n) return gi_fail(GS_E_INVALID, "truncated gzip stream");
+    return hdr + 8 >= n ? -1 : hdr;
+}
+
+extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n) {
+    if (!out || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
+    *out = nullptr;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return gi_fail(GS_E_NODEVICE, "no usable gfx950 device");
+    const int64_t hdr = gi_gzip_header(gz, n);
+    if (hdr < 0) return gi_fail(GS_E_INVALID, "not a gzip stream, or a truncated one");
     GI_TRY(hipSetDevice(device));
     int rc = gi_upload_crc_table();
     if (rc) return rc;
@@ -1845,7 +1850,25 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     // data without the text test) shows as the segment IN FRONT of it running past it: that segment is decoded again up to the start
     // after the mirage, into the slack behind the symbols (the mirage's own segment is dropped); for the batch's last segment the
     // next of the starts behind the batch takes the mirage's place.  A few rounds: two mirages may follow each other.
+    bool member_end = false;
     for (int round = 0; round < 6; round++) {
+        {   // the member's final block inside a segment (another member follows): that segment is the last one -- once nothing in front
+            // of it is in doubt; what the batch decoded behind it belongs to the next member and is decoded again from its first block
+            size_t f = segs.size(), y = segs.size();
+            for (size_t i = 0; i < segs.size(); i++) {
+                if (st[i] == GI_FINAL && f == segs.size()) f = i;
+                if (st[i] == GI_E_SYNC && y == segs.size()) y = i;
+            }
+            if (f < segs.size() && y > f) {
+                segs.resize(f + 1);
+                st.resize(f + 1);
+                len.resize(f + 1);
+                endb.resize(f + 1);
+                segs[f].to_final = 1;
+                st[f] = GI_OK;
+                member_end = true;
+            }
+        }
         std::vector<GiSeg> redo, kept;
         std::vector<size_t> redo_at;
         std::vector<int32_t> kst;
@@ -1853,7 +1876,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         std::vector<u64> kend;
         for (size_t i = 0; i < segs.size(); i++) {
             const bool is_last = i + 1 == segs.size();
-            if (st[i] == GI_E_SYNC && (!is_last || (!segs[i].to_final && (stop_at + 1 < stops.size() || to_end)))) {
+            if (st[i] == GI_E_SYNC && !member_end && (!is_last || (!segs[i].to_final && (stop_at + 1 < stops.size() || to_end)))) {
                 GiSeg m = segs[i];
                 u64 cap = m.out_cap;
                 if (!is_last) {
@@ -1975,8 +1998,20 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         const uint32_t want_isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
         if ((uint32_t)g->total != want_isize) return gi_fail(GS_E_INVALID, "corrupt gzip stream: ISIZE does not match the inflated text");
         if ((g->raw ^ 0xffffffffu) != want_crc) return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
-        g->more_members = (int64_t)end_byte + 8 < g->in_len;
-        *last = g->more_members ? 2 : 1;
+        // what follows the trailer: another member (cat a.gz b.gz: its text simply follows), or nothing a gzip reader takes (ignored,
+        // as java.util.zip.GZIPInputStream does)
+        const int64_t nxt = (int64_t)end_byte + 8;
+        const int64_t h2 = nxt < g->in_len ? gi_gzip_header(g->gz + g->hdr + nxt, g->in_len - nxt) : -1;
+        if (h2 >= 0) {
+            g->done = false;
+            g->bit = (u64)(nxt + h2) * 8u;
+            g->have_prev = false;
+            g->raw = 0xffffffffu;
+            g->total = 0;
+            g->n_members++;
+            *last = 0;
+        } else
+            *last = 1;
     } else {
         g->bit = base * 8u + segs.back().stop_bit;
     }

@@ -505,8 +505,9 @@ int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_mem
  * gs_gunzipper_*: the stream in BATCHES of about one segment per wave slot of the device (a file of any size through buffers of a few
  * gigabytes).  gs_gunzipper_next: the text of the next batch in device memory, behind the last `keep_tail` bytes of the text the call
  * before returned (what lay behind the caller's last whole record); the pointer is valid until the next call.  *last: 0 = more
- * batches follow, 1 = the member is through (CRC-32 and ISIZE were right), 2 = as 1 and more data follows the member (another
- * member: inflate the rest on the host, from this text offset).  GS_E_UNSUPPORTED (from open or from any batch): not a stream this
+ * batches follow, 1 = the file is through (every member's CRC-32 and ISIZE were right; members behind one another -- cat a.gz b.gz --
+ * give their texts behind one another, what is not a member behind the last trailer is ignored as GZIPInputStream ignores it).
+ * GS_E_UNSUPPORTED (from open or from any batch): not a stream this
  * path takes from here on (a segment that outgrows its buffer, a block boundary that was a mirage and could not be repaired) -- the
  * caller inflates the rest on the host; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).  `gz` must stay
  * readable until gs_gunzipper_close.  gs_gunzipper_info: [0] segments, [1] chunks searched, [2] batches, [3] block starts that were

@@ -315,9 +315,18 @@ def test_single_member_gzip_shapes():
 def test_single_member_gzip_what_the_device_path_refuses_or_reports():
     text = _fastq_like(5000, 11)
     z = _gz(text)
-    with pytest.raises(ga.GsError) as e:  # two members behind one another: ISIZE of the last one does not cover the text -> host decoders
-        ga.gunzip_device(z + z, 2 * len(text))
-    assert e.value.code == -4
+    # members behind one another (cat a.gz b.gz): the text of one behind the other, every member's CRC-32 and ISIZE checked; what is
+    # not a member behind the last trailer is ignored, as java.util.zip.GZIPInputStream does
+    other = _fastq_like(3000, 12)
+    got, info = ga.gunzip_device(z + _gz(other, 1) + _gz(b"") + z, 2 * len(text) + len(other))
+    assert got.tobytes() == text + other + text
+    got, _ = ga.gunzip_device(z + b"\0" * 100, len(text))
+    assert got.tobytes() == text
+    two = bytearray(z + z)
+    two[-6] ^= 1  # the second member's CRC-32
+    with pytest.raises(ga.GsError) as e:
+        ga.gunzip_device(bytes(two), 2 * len(text))
+    assert e.value.code == -1 and "CRC" in str(e.value)
     bad = bytearray(z)
     bad[-6] ^= 1  # the CRC-32 of the trailer
     with pytest.raises(ga.GsError) as e:
@@ -381,8 +390,8 @@ def test_gzip_files_through_the_device_gunzip(tmp_path, monkeypatch, outputs, ba
 
 
 def test_two_gzip_members_in_one_file(tmp_path, monkeypatch):
-    """`cat a.gz b.gz`: the device path inflates the first member (CRC-32 checked), says that more follows, and the host decoders take the
-    rest from that text offset -- table and totals as the host-decoder run over the whole file"""
+    """`cat a.gz b.gz`: member behind member on the device (each with its own CRC-32 and ISIZE, no window across the seam) -- table and
+    totals as the host-decoder run over the whole file"""
     from genestrip_amd import host, synth
     db = synth.SynthDB(k=31, genera=2, species_per_genus=3, genome_len=20000, seed=3)
     seq, off = synth.reads_host(db.genomes, 9000, read_len=150, seed=31)
