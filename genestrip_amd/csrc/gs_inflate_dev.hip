@@ -53,6 +53,7 @@ struct __attribute__((aligned(16))) gs_u16x8 {
 #ifndef GI_RING
 #define GI_RING 2048               // bytes of recent text per wave in LDS (a power of two); with it a wave takes 8.6 KB: 16 waves per CU
 #endif
+#define GI_FIND_GROUPS 4            // groups of 64 bit offsets per trip of the block finder (gi_find_kernel)
 #define GI_PAR_MAX 16u             // matches of at most this length are copied one lane per match (gi_inflate_kernel)
 #define GI_ON(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 #define GI_LDESC ((GI_LSIZE - 512) / 2)
@@ -932,41 +933,53 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         const u64 lo = (u64)ci * chunk_bytes * 8u;
         u64 hi = lo + (u64)chunk_bytes * 8u;
         if (hi > (u64)in_len * 8u) hi = (u64)in_len * 8u;
-        for (u64 o0 = lo; o0 < hi && found == ~0ULL; o0 += 64) {
-            const u64 o = o0 + (u64)lane;
-            // the 96 bits at this lane's offset (the buffer has slack behind the stream)
-            const uint8_t *p = in + ((o >> 5) << 2);
-            const uint32_t d0 = *reinterpret_cast<const u32_any *>(p), d1 = *reinterpret_cast<const u32_any *>(p + 4);
-            const uint32_t d2 = *reinterpret_cast<const u32_any *>(p + 8), d3 = *reinterpret_cast<const u32_any *>(p + 12);
-            const uint32_t sh = (uint32_t)o & 31u;
-            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
-            // not final, dynamic, at most 286 / 30 codes, and the code length code is complete (Kraft sum exactly one)
-            bool ok = o < hi && (w0 & 7u) == 4u && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u;
-            const uint32_t hclen = ((w0 >> 13) & 15u) + 4u;
-            const u64 a = ((u64)w1 << 32 | w0) >> 17;   // 47 bits: 15 lengths
-            const u64 c = ((u64)w2 << 32 | w1) >> 30;   // from bit 62: lengths 15 .. 18
-            uint32_t kraft = 0;
+        for (u64 o00 = lo; o00 < hi && found == ~0ULL; o00 += 64 * GI_FIND_GROUPS) {
+            // GI_FIND_GROUPS groups of 64 offsets per trip: all their loads first (a trip is otherwise one memory latency per 64 offsets)
+            uint32_t w0[GI_FIND_GROUPS], w1[GI_FIND_GROUPS], w2[GI_FIND_GROUPS];
 #pragma unroll
-            for (uint32_t i = 0; i < 19; i++) {
-                const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
-                kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
+            for (int u = 0; u < GI_FIND_GROUPS; u++) {
+                const u64 o = o00 + 64u * (u64)u + (u64)lane;
+                // the 96 bits at this lane's offset (the buffer has slack behind the stream)
+                const uint8_t *p = in + ((o >> 5) << 2);
+                const uint32_t d0 = *reinterpret_cast<const u32_any *>(p), d1 = *reinterpret_cast<const u32_any *>(p + 4);
+                const uint32_t d2 = *reinterpret_cast<const u32_any *>(p + 8), d3 = *reinterpret_cast<const u32_any *>(p + 12);
+                const uint32_t sh = (uint32_t)o & 31u;
+                w0[u] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                w1[u] = __builtin_amdgcn_alignbit(d2, d1, sh);
+                w2[u] = __builtin_amdgcn_alignbit(d3, d2, sh);
             }
-            ok = ok && kraft == 128u;
-            for (u64 cand = __ballot(ok); cand != 0 && found == ~0ULL; cand &= cand - 1) {  // the whole header, in offset order
-                const u64 oc = o0 + (u64)__builtin_ctzll(cand);
-                GiBits b;
-                b.in = in;
-                b.in_len = in_len;
-                b.seek_bit(oc + 3, lane);
-                bool lf, df;
-                if (gi_dynamic_header(w, b, lane, &lf, &df) == GI_OK && lf && df) {
-                    // FASTQ / FASTA are text: a block whose code gives a length to a byte >= 128 is not taken for a start (a bit pattern
-                    // that parses as a header by chance -- about one per 100 MB -- does so with all but certainty; a real block
-                    // with such bytes is then simply not a segment boundary)
-                    bool high = false;
-                    if (text_only)
-                        for (int sidx = 128 + lane; sidx < 256; sidx += 64) high |= w.lens[sidx] != 0;
-                    if (__ballot(high) == 0) found = oc;
+#pragma unroll
+            for (int u = 0; u < GI_FIND_GROUPS; u++) {
+                const u64 o0 = o00 + 64u * (u64)u;
+                const u64 o = o0 + (u64)lane;
+                // not final, dynamic, at most 286 / 30 codes, and the code length code is complete (Kraft sum exactly one)
+                bool ok = o < hi && (w0[u] & 7u) == 4u && ((w0[u] >> 3) & 31u) <= 29u && ((w0[u] >> 8) & 31u) <= 29u;
+                const uint32_t hclen = ((w0[u] >> 13) & 15u) + 4u;
+                const u64 a = ((u64)w1[u] << 32 | w0[u]) >> 17;   // 47 bits: 15 lengths
+                const u64 c = ((u64)w2[u] << 32 | w1[u]) >> 30;   // from bit 62: lengths 15 .. 18
+                uint32_t kraft = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 19; i++) {
+                    const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
+                    kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
+                }
+                ok = ok && kraft == 128u;
+                for (u64 cand = found == ~0ULL ? __ballot(ok) : 0; cand != 0 && found == ~0ULL; cand &= cand - 1) {  // the whole header, in offset order
+                    const u64 oc = o0 + (u64)__builtin_ctzll(cand);
+                    GiBits b;
+                    b.in = in;
+                    b.in_len = in_len;
+                    b.seek_bit(oc + 3, lane);
+                    bool lf, df;
+                    if (gi_dynamic_header(w, b, lane, &lf, &df) == GI_OK && lf && df) {
+                        // FASTQ / FASTA are text: a block whose code gives a length to a byte >= 128 is not taken for a start (a bit pattern
+                        // that parses as a header by chance -- about one per 100 MB -- does so with all but certainty; a real block
+                        // with such bytes is then simply not a segment boundary)
+                        bool high = false;
+                        if (text_only)
+                            for (int sidx = 128 + lane; sidx < 256; sidx += 64) high |= w.lens[sidx] != 0;
+                        if (__ballot(high) == 0) found = oc;
+                    }
                 }
             }
         }
