@@ -918,7 +918,7 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
         m.close()  # (one unique-counting run per store: gs_host_match_files begins its own)
         for label, path in (("plain", plain), ("gz", gz), ("bgzf", bz)):
             best, table = None, None
-            for _ in range(2):
+            for _ in range(3):  # (best of three: the files were written a moment ago, and their write-back now and then stalls a reader)
                 t0 = time.perf_counter()
                 table, _, tot = host.match_files(store, [path])[:3]
                 dt = time.perf_counter() - t0
