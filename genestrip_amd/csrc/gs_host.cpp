@@ -620,6 +620,52 @@ struct InflaterPool {
         idle.emplace_back(device, g);
     }
 };
+// ... and the decoders of single-member streams, whose device buffers are gigabytes (one idle object per device is kept)
+struct GunzipperPool {
+    std::mutex m;
+    std::vector<std::pair<int, gs_gunzipper *>> idle;
+    int open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n) {
+        gs_gunzipper *g = nullptr;
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == device) {
+                    g = idle[i].second;
+                    idle.erase(idle.begin() + (long)i);
+                    break;
+                }
+        }
+        if (g) {
+            const int rc = gs_gunzipper_reopen(g, gz, n);
+            if (rc == GS_OK) {
+                *out = g;
+                return GS_OK;
+            }
+            gs_gunzipper_close(g);
+            *out = nullptr;
+            return rc;
+        }
+        return gs_gunzipper_open(out, device, gz, n);
+    }
+    void put(int device, gs_gunzipper *g) {
+        if (!g) return;
+        {
+            std::lock_guard<std::mutex> l(m);
+            bool have = false;
+            for (auto &x : idle) have = have || x.first == device;
+            if (!have) {
+                idle.emplace_back(device, g);
+                return;
+            }
+        }
+        gs_gunzipper_close(g);
+    }
+};
+inline GunzipperPool &gunzipper_pool() {
+    static GunzipperPool *p = new GunzipperPool();  // (never destroyed, as the inflaters)
+    return *p;
+}
+
 inline InflaterPool &inflater_pool() {
     static InflaterPool *p = new InflaterPool();  // (never destroyed: the runtime may be gone by the time statics are torn down)
     return *p;
@@ -717,7 +763,7 @@ struct TextJob {
         }
         if (gzr_) {
             gs_match_sync(c.run);  // (the record scan may still be copying out of its text)
-            gs_gunzipper_close(gzr_);
+            gunzipper_pool().put(inf_device_, gzr_);
             gzr_ = nullptr;
             gz_text_ = nullptr;
         }
@@ -767,14 +813,14 @@ struct TextJob {
             if (want && gs_match_get_device(c.run, &device) == GS_OK) {
                 static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
                 const double tg = now_s();
-                int grc = gs_gunzipper_open(&gzr_, device, tr.map, (int64_t)tr.map_len);
+                int grc = gunzipper_pool().open(&gzr_, device, tr.map, (int64_t)tr.map_len);
                 if (grc == GS_OK) grc = gs_gunzipper_next(gzr_, 0, &gz_text_, &gz_n_, &gz_last_);  // (the first batch now: a stream this path does not take shows here)
                 if (trace) fprintf(stderr, "gunzip on the device: rc %d, first batch %lld bytes of text, %.2f ms%s%s\n", grc, (long long)gz_n_, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
                 if (grc == GS_OK) {
                     dev_gz = true;
                     inf_device_ = device;
                 } else if (gzr_) {
-                    gs_gunzipper_close(gzr_);
+                    gunzipper_pool().put(device, gzr_);
                     gzr_ = nullptr;
                     gz_text_ = nullptr;
                     gz_n_ = 0;
@@ -1803,8 +1849,8 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         members.clear();
         bool want = true;
         if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = atoi(e) != 0;
-        if (!want || gs_gunzipper_open(&gzr, device, tr.map, (int64_t)tr.map_len) != GS_OK || gs_gunzipper_next(gzr, 0, &gz_text, &gz_n, &gz_last) != GS_OK) {
-            gs_gunzipper_close(gzr);
+        if (!want || gunzipper_pool().open(&gzr, device, tr.map, (int64_t)tr.map_len) != GS_OK || gs_gunzipper_next(gzr, 0, &gz_text, &gz_n, &gz_last) != GS_OK) {
+            gunzipper_pool().put(device, gzr);
             tr.close();
             return GS_OK;  // (a stream this path does not take, a damaged one: the host decoders take it -- and report it)
         }
@@ -1935,7 +1981,7 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     if (formatting.valid()) formatting.get();
     const double te1 = now_s();
     if (inf) inflater_pool().put(device, inf);
-    if (gzr) gs_gunzipper_close(gzr);  // (every slice's filter run has been waited for: gs_filter_text_status)
+    if (gzr) gunzipper_pool().put(device, gzr);  // (every slice's filter run has been waited for: gs_filter_text_status)
     tr.close();
     if (getenv("GS_HOST_TRACE") != nullptr)
         fprintf(stderr, "filter bgzf: loop %.2f ms (from open), last writers %.2f, inflater back + unmap %.2f\n", (te0 - t0) * 1e3, (te1 - te0) * 1e3, (now_s() - te1) * 1e3);

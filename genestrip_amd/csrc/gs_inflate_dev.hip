@@ -1717,6 +1717,8 @@ static int64_t gi_gzip_header(const uint8_t *gz, int64_t n) {
     return hdr + 8 >= n ? -1 : hdr;
 }
 
+extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n);
+
 extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n) {
     if (!out || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
     *out = nullptr;
@@ -1731,10 +1733,40 @@ extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *
     g->device = device;
     hipDeviceProp_t prop;
     g->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    hipError_t e = hipMalloc((void **)&g->d_q, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_prev, GI_WINDOW);
+    if (e != hipSuccess) {
+        gs_gunzipper_close(g);
+        return gi_fail(GS_E_NOMEM, "gs_gunzipper_open");
+    }
+    rc = gs_gunzipper_reopen(g, gz, n);
+    if (rc) {
+        gs_gunzipper_close(g);
+        return rc;
+    }
+    *out = g;
+    return GS_OK;
+}
+
+// the same object (and its device buffers: a batch's symbols alone are gigabytes) on another file
+extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n) {
+    if (!g || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
+    const int64_t hdr = gi_gzip_header(gz, n);
+    if (hdr < 0) return gi_fail(GS_E_INVALID, "not a gzip stream, or a truncated one");
+    GI_TRY(hipSetDevice(g->device));
+    GI_TRY(hipDeviceSynchronize());  // (nobody reads the last file's text any more)
     g->gz = gz;
     g->n = n;
     g->hdr = hdr;
     g->in_len = n - hdr;  // (what lies behind the deflate stream -- the trailer, further members -- is found when the final block is)
+    g->bit = 0;
+    g->done = g->more_members = g->have_prev = false;
+    g->raw = 0xffffffffu;
+    g->total = 0;
+    g->n_batches = g->n_segments = g->n_mirages = g->n_chunks = 0;
+    g->n_members = 1;
+    g->last_n_text = 0;
+    g->text_only = 1;
     const int64_t slots = gu_slots(g->n_cu);
     // One segment per wave slot, but not less than 16 KiB of compressed data (about one deflate block of zlib's) nor more than 64 KiB
     // (then the stream takes several batches): the finder reads a chunk only up to its first block start, and more segments than
@@ -1751,20 +1783,12 @@ extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *
         g->ratio = (uint32_t)std::min<u64>(1040, std::max<u64>(24, 4 * (est / (u64)std::max<int64_t>(g->in_len, 1)) + 4));
     }
     if (const char *e = getenv("GS_GUNZIP_RATIO")) g->ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
-    hipError_t e = hipMalloc((void **)&g->d_q, 2 * sizeof(u64));
-    if (e == hipSuccess) e = hipMalloc((void **)&g->d_prev, GI_WINDOW);
-    if (e != hipSuccess) {
-        gs_gunzipper_close(g);
-        return gi_fail(GS_E_NOMEM, "gs_gunzipper_open");
-    }
-    *out = g;
     return GS_OK;
 }
 
 // One batch.  keep_tail: the last `keep_tail` bytes of the text the call before returned stay in front of the new text (what lay behind
-// the caller's last whole record).  *last: 0 = more batches follow, 1 = the member's final block is through (CRC-32 and ISIZE were
-// right), 2 = as 1, and more data follows the member (another member: the caller's host decoders take over at *this* text offset).
-// The pointer is valid until the next call.
+// the caller's last whole record).  *last: 0 = more batches follow (of this member, or of the member behind it), 1 = the file is through
+// (every member's CRC-32 and ISIZE were right).  The pointer is valid until the next call.
 extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text_out, int64_t *n_text, int *last) {
     if (!g || !d_text_out || !n_text || !last || keep_tail < 0 || keep_tail > g->last_n_text) return gi_fail(GS_E_INVALID, "bad argument");
     *d_text_out = nullptr;

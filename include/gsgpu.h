@@ -516,6 +516,7 @@ int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_mem
  * gs_gunzip_device copies it to `out` (tests, tools).  info as gs_gunzipper_info. */
 typedef struct gs_gunzipper gs_gunzipper;
 int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t n);
+int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n); /* the same object and its device buffers on another file */
 int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text, int64_t *n_text, int *last);
 int gs_gunzipper_info(const gs_gunzipper *g, int64_t info[4]);
 int gs_gunzipper_close(gs_gunzipper *g);
