@@ -1774,13 +1774,14 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     g->chunk = (uint32_t)std::min<int64_t>(65536, std::max<int64_t>(16384, g->in_len / slots));
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) g->chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
     if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) g->text_only = atoi(e) == 0;  // block starts whose literal code covers bytes >= 128 count as well
-    // symbols a segment may produce per byte of its compressed span: generous for text (a FASTQ stream is 4 .. 6 : 1), deflate's
-    // limit is 1032 : 1; a segment that outgrows its room sends the rest of the file to the host decoders
-    g->ratio = 24;
+    // symbols a segment may produce per byte of its compressed span: twice what FASTQ does (4 .. 6 : 1); a segment that outgrows its
+    // room is decoded again with eight times as much (deflate's limit is 1032 : 1), and when the slack for that is used up the rest
+    // of the file goes to the host decoders
+    g->ratio = 12;
     if (g->in_len < ((int64_t)64 << 20)) {  // a small stream says how far it expands (ISIZE, modulo 2^32)
         const uint8_t *t = gz + n - 8;
         u64 est = (u64)t[4] | ((u64)t[5] << 8) | ((u64)t[6] << 16) | ((u64)t[7] << 24);
-        g->ratio = (uint32_t)std::min<u64>(1040, std::max<u64>(24, 4 * (est / (u64)std::max<int64_t>(g->in_len, 1)) + 4));
+        g->ratio = (uint32_t)std::min<u64>(1040, std::max<u64>(12, 4 * (est / (u64)std::max<int64_t>(g->in_len, 1)) + 4));
     }
     if (const char *e = getenv("GS_GUNZIP_RATIO")) g->ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
     return GS_OK;
@@ -1939,6 +1940,19 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
                 kend.push_back(0);
                 g->n_mirages++;
                 if (!is_last) i++;  // (the segment behind the mirage is gone)
+            } else if (st[i] == GI_E_OVERRUN && (u64)segs[i].out_cap * 8u <= 0xffff0000ull && sym_used + GI_WINDOW + (u64)segs[i].out_cap * 8u <= sym_room) {
+                // a segment that expands more than the room it was given (a run of one base, of one quality): once more with eight times the room
+                GiSeg m = segs[i];
+                m.out_cap *= 8u;
+                sym_used += GI_WINDOW;
+                m.out_off = sym_used;
+                sym_used += m.out_cap;
+                redo.push_back(m);
+                redo_at.push_back(kept.size());
+                kept.push_back(m);
+                kst.push_back(GI_OK);
+                klen.push_back(0);
+                kend.push_back(0);
             } else {
                 kept.push_back(segs[i]);
                 kst.push_back(st[i]);

@@ -346,6 +346,17 @@ def test_single_member_gzip_what_the_device_path_refuses_or_reports():
     assert n_bad >= 18
 
 
+def test_a_segment_that_outgrows_its_room_is_decoded_again(monkeypatch):
+    """long runs inside ordinary FASTQ: the segments that hold them expand a hundred times more than their neighbours"""
+    monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+    monkeypatch.setenv("GS_GUNZIP_RATIO", "6")
+    body = _fastq_like(6000, 21)
+    data = body[:700000] + b"@poly\n" + b"A" * 3_000_000 + b"\n+\n" + b"#" * 3_000_000 + b"\n" + body[700000:]
+    z = _gz(data, 6)
+    got, info = ga.gunzip_device(z, len(data))
+    assert got.tobytes() == data and info[0] > 10
+
+
 def test_binary_data_and_mirages(monkeypatch):
     """random bytes compress to stored / near-flat blocks, and with GS_GUNZIP_ANY_BYTES=1 every parsable header counts as a block start:
     a start that was a mirage makes the segment in front of it run past it, which is decoded again"""
