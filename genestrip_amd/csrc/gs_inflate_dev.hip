@@ -1594,11 +1594,19 @@ static uint32_t gi_h_x_pow_8n(uint64_t n) {
 // host memory of any kind (a page-cache mapping is copied by the runtime at a crawl) to the device through two page-locked buffers,
 // filled by several threads while the other one is on its way
 static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n) {
-    static std::mutex m;
-    static uint8_t *h[2] = {nullptr, nullptr};
-    static hipEvent_t done[2] = {nullptr, nullptr};
+    struct Staging {  // per device: events belong to the device they were created on, and two devices should not wait for each other
+        std::mutex m;
+        uint8_t *h[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+    };
+    static Staging per_device[64];
+    int dev = 0;
+    GI_TRY(hipGetDevice(&dev));
+    Staging &st = per_device[(dev >= 0 && dev < 64) ? dev : 0];
+    uint8_t **h = st.h;
+    hipEvent_t *done = st.done;
     const size_t piece = (size_t)32 << 20;
-    std::lock_guard<std::mutex> l(m);
+    std::lock_guard<std::mutex> l(st.m);
     for (int i = 0; i < 2; i++) {
         if (!h[i]) GI_TRY(hipHostMalloc((void **)&h[i], piece));
         if (!done[i]) GI_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
