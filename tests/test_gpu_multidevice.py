@@ -64,8 +64,12 @@ def _write_fastq(path, seq, off, start):
             f.write(b"@r%d\n%s\n+\n%s\n" % (start + i, s, b"F" * len(s)))
 
 
-def test_files_dealt_to_replicas_on_distinct_devices(sdb, tmp_path):
-    """gs_host_match_files_multi over one replica per device"""
+@pytest.mark.parametrize("container", ["plain", "gzip", "bgzf"])
+def test_files_dealt_to_replicas_on_distinct_devices(sdb, tmp_path, container):
+    """gs_host_match_files_multi over one replica per device; gzip / BGZF files are inflated on the device each replica lives on (every
+    device its own inflater, staging buffers and events)"""
+    import gzip
+    from conftest import bgzf
     devs = _devices()
     seq, off = synth.reads_host(sdb.genomes, 15000, read_len=150, seed=23)
     off = off.astype(np.uint64)
@@ -74,6 +78,10 @@ def test_files_dealt_to_replicas_on_distinct_devices(sdb, tmp_path):
     for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
         p = str(tmp_path / f"s{i}.fastq")
         _write_fastq(p, seq[int(off[a]):int(off[b])], off[a:b + 1] - off[a], a)
+        if container != "plain":
+            raw = open(p, "rb").read()
+            p += ".gz"
+            open(p, "wb").write(gzip.compress(raw, 6, mtime=0) if container == "gzip" else bgzf(raw, block=30000, level=1))
         paths.append(p)
     want = _oracle(sdb, seq, off)
     stores = [ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, device=d) for d in devs]
