@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -53,7 +54,7 @@ struct __attribute__((aligned(16))) gs_u16x8 {
 #ifndef GI_RING
 #define GI_RING 2048               // bytes of recent text per wave in LDS (a power of two); with it a wave takes 8.6 KB: 16 waves per CU
 #endif
-#define GI_FIND_GROUPS 4            // groups of 64 bit offsets per trip of the block finder (gi_find_kernel)
+#define GI_RING_SYM 1024           // symbols of recent text per wave of gi_segment_kernel (2 KB: with it five workgroups fit a CU)
 #define GI_PAR_MAX 16u             // matches of at most this length are copied one lane per match (gi_inflate_kernel)
 #define GI_ON(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 #define GI_LDESC ((GI_LSIZE - 512) / 2)
@@ -525,7 +526,8 @@ template <bool MARK>
 __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits &b, uint32_t in_len, u64 stop_bit, bool to_final,
                                 typename GiOut<MARK>::T *dst, uint32_t cap, int force_slow, int lane, uint32_t *produced) {
     typedef typename GiOut<MARK>::T OutT;
-    constexpr uint32_t RM = GI_RING - 1u;
+    constexpr uint32_t RING = MARK ? GI_RING_SYM : GI_RING;
+    constexpr uint32_t RM = RING - 1u;
     constexpr uint32_t BACK = MARK ? GI_WINDOW : 0u;  // how far in front of the unit's first symbol a match may reach
     bool final_inside = false;
     uint32_t pos = 0;          // bytes of text produced (stored or pending)
@@ -572,7 +574,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
             for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
                 const OutT c = (OutT)b.in[src + i];
                 dst[pos + i] = c;
-                if (len - i <= GI_RING) ring[(pos + i) & RM] = c;  // (the last GI_RING bytes of the block)
+                if (len - i <= RING) ring[(pos + i) & RM] = c;  // (the last GI_RING bytes of the block)
             }
             b.seek(src + len, lane);
             pos += len;
@@ -632,10 +634,10 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                 const uint32_t step = stop ? 64u : t;  // (an end marker ends the walk)
                 u64 chain = 0;
                 uint32_t at = 0;
-                for (int hop = 0; hop < 64 && at < 64u; hop++) {  // (a token has at least one bit)
+                do {  // (a token has at least one bit: at most 64 trips)
                     chain |= 1ULL << at;
                     at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
-                }
+                } while (at < 64u);
                 uint32_t adv = at;  // bits of this group
                 if ((__ballot(stop) & chain) != 0) {  // the chain's last token is an end marker
                     const int el = 63 - __builtin_clzll(chain);
@@ -661,8 +663,11 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                     err = GI_E_DIST;
                     break;
                 }
+                // A group of at most RING / 4 symbols is put together in the ring and stored from there in whole lines (below); a
+                // larger one (long matches) is stored piece by piece as it is produced.
+                const bool big = total > RING / 4u;
                 if (on && kind == GI_LIT) {
-                    dst[mpos] = (OutT)lit;
+                    if (big) dst[mpos] = (OutT)lit;
                     ring[mpos & RM] = (OutT)lit;
                 }
                 if (mm != 0) {
@@ -671,7 +676,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                     // still reads (the slot of byte p is reused by byte p + GI_RING).
                     const uint32_t from = mpos - dist;
                     // side by side: short, not overlapping, source in the ring and in front of the group's first byte
-                    const bool par = is_match && olen <= GI_PAR_MAX && dist >= olen && dist + total + 64u <= GI_RING && (mpos - pos) + olen <= dist;
+                    const bool par = is_match && olen <= GI_PAR_MAX && dist >= olen && dist + total + 64u <= RING && (mpos - pos) + olen <= dist;
                     const u64 pm = __ballot(par);
                     if (pm != 0) {
                         for (uint32_t i = 0; i < GI_PAR_MAX; i++) {
@@ -679,7 +684,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                             if (__ballot(go) == 0) break;
                             if (go) {
                                 const OutT c = ring[(from + i) & RM];
-                                dst[mpos + i] = c;
+                                if (big) dst[mpos + i] = c;
                                 ring[(mpos + i) & RM] = c;
                             }
                         }
@@ -689,35 +694,41 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                         const int ml = __builtin_ctzll(sm);
                         const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)olen, ml), dd = (uint32_t)__builtin_amdgcn_readlane((int)dist, ml);
                         const uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)mpos, ml), fr = mp - dd;
-                        if (dd + total + 64u <= GI_RING) {
+                        if (dd + total + 64u <= RING) {
                             if (dd == 1) {  // a run of one byte
                                 const OutT c = ring[fr & RM];
                                 for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                                    dst[mp + i] = c;
+                                    if (big) dst[mp + i] = c;
                                     ring[(mp + i) & RM] = c;
                                 }
                             } else {
                                 for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
                                     const OutT c = ring[(fr + (dd >= len ? i : i % dd)) & RM];
-                                    dst[mp + i] = c;
+                                    if (big) dst[mp + i] = c;
                                     ring[(mp + i) & RM] = c;
                                 }
                             }
                             gi_lds_sync();
                         } else {
+                            // (a small group: dd > RING - 64 - RING / 4 > the group's length + 258 -- the source ends in front of `pos`,
+                            // in symbols that were stored by the groups before)
                             if ((int32_t)(fr + (len < dd ? len : dd)) > (int32_t)visible) {  // the source reaches into bytes this wave stored since its last wait
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                visible = mp;
+                                visible = big ? mp : pos;
                             }
                             for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
                                 const OutT c = dst[(int32_t)(fr + (dd >= len ? i : i % dd))];
-                                dst[mp + i] = c;
+                                if (big) dst[mp + i] = c;
                                 ring[(mp + i) & RM] = c;
                             }
                             gi_lds_sync();
                         }
                     }
+                }
+                if (!big) {
+                    gi_lds_sync();
+                    for (uint32_t i = (uint32_t)lane; i < total; i += 64) dst[pos + i] = ring[(pos + i) & RM];
                 }
                 pos += total;
                 P += adv;
@@ -785,7 +796,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
             }
             flush();
             const uint32_t from = pos - dist;
-            if (dist <= GI_RING - 64u) {
+            if (dist <= RING - 64u) {
                 // the source lies in the ring (every source byte is in front of `pos`, and a byte is overwritten GI_RING
                 // bytes later: not by this copy).  LDS operations of a wave execute in order: the barrier is for the compiler.
                 gi_lds_sync();
@@ -916,56 +927,166 @@ struct GiSeg {
     uint32_t to_final; // the last segment: to the stream's final block
 };
 
+// the bits from bit `p` of the stream on (at least 57 of them; the buffer has slack behind the stream)
+__device__ __forceinline__ u64 gi_bits_at(const uint8_t *in, u64 p) {
+    typedef u64 __attribute__((aligned(1))) u64_any;
+    return *reinterpret_cast<const u64_any *>(in + (p >> 3)) >> (p & 7u);
+}
+
+// The block finder's third test, ONE CANDIDATE PER LANE (the lanes diverge; nothing here is wave-uniform): the code lengths of the
+// dynamic header at bit `o` are decoded the canonical way -- the code length code's counts in a register, its symbols in canonical
+// order in the lane's 20 bytes of LDS -- and only summed up: true when the repeat codes fit, the literal / length code is complete and
+// has an end-of-block code, the distance code is complete (or the one 1-bit code, or none), and -- text_only -- no byte >= 128 has a
+// code.  Stricter than gi_dynamic_header in corners no compressor produces (an incomplete literal code of one symbol); what passes is
+// checked by gi_dynamic_header, what does not is simply not a segment boundary.  A random candidate costs the whole wave ~100 trips
+// of this loop for up to 64 candidates, where gi_dynamic_header took ~30 us for each of them.
+__device__ bool gi_header_plausible(const uint8_t *in, uint32_t in_len, u64 o, uint8_t *sorted, bool text_only) {
+    const u64 end = (u64)in_len * 8u;
+    if (o + 17u + 57u + 64u > end) return false;  // (a block start this close to the end of the stream is of no use as a boundary)
+    const uint32_t head = (uint32_t)gi_bits_at(in, o);
+    const uint32_t hlit = ((head >> 3) & 31u) + 257u, hdist = ((head >> 8) & 31u) + 1u, hclen = ((head >> 13) & 15u) + 4u;
+    u64 pos = o + 17u;
+    const u64 cl = gi_bits_at(in, pos) & ((1ULL << (3u * hclen)) - 1ULL);
+    pos += 3u * hclen;
+    constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    u64 by_sym = 0;  // 3 bits per symbol 0 .. 18
+#pragma unroll
+    for (int i = 0; i < 19; i++) by_sym |= ((cl >> (3 * i)) & 7ULL) << (3 * order[i]);
+    u64 cnts = 0;    // 8 bits per length 0 .. 7
+#pragma unroll
+    for (int sidx = 0; sidx < 19; sidx++) cnts += 1ULL << (8u * (uint32_t)((by_sym >> (3 * sidx)) & 7ULL));
+    cnts &= ~0xffULL;
+    u64 run = cnts * 0x0101010101010101ULL - cnts;  // per length: the codes of all shorter lengths = where its symbols start
+#pragma unroll
+    for (int sidx = 0; sidx < 19; sidx++) {
+        const uint32_t l = (uint32_t)((by_sym >> (3 * sidx)) & 7ULL);
+        if (l) {
+            sorted[(uint32_t)(run >> (8u * l)) & 31u] = (uint8_t)sidx;
+            run += 1ULL << (8u * l);
+        }
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t at = 0, prev = 0, lit_k = 0, dist_k = 0;
+    bool eob = false, high = false;
+    u64 buf = gi_bits_at(in, pos);
+    int have = 57;
+    while (at < total) {
+        if (have < 14) {
+            if (pos + 64u > end) return false;
+            buf = gi_bits_at(in, pos);
+            have = 57;
+        }
+        int code = 0, first = 0, index = 0, used = 0;
+        uint32_t sym = 0;
+#pragma unroll
+        for (int len = 1; len <= 7; len++) {
+            if (used == 0) {
+                code |= (int)((buf >> (len - 1)) & 1u);
+                const int cnt = (int)((cnts >> (8 * len)) & 255u);
+                if (code - cnt < first) {
+                    sym = sorted[index + (code - first)];
+                    used = len;
+                }
+                index += cnt;
+                first += cnt;
+                first <<= 1;
+                code <<= 1;
+            }
+        }
+        if (used == 0) return false;  // (not with a complete code)
+        buf >>= used;
+        uint32_t rep = 1, val = sym, extra = 0;
+        if (sym == 16) {
+            if (at == 0) return false;
+            rep = 3u + ((uint32_t)buf & 3u);
+            val = prev;
+            extra = 2;
+        } else if (sym == 17) {
+            rep = 3u + ((uint32_t)buf & 7u);
+            val = 0;
+            extra = 3;
+        } else if (sym == 18) {
+            rep = 11u + ((uint32_t)buf & 127u);
+            val = 0;
+            extra = 7;
+        }
+        buf >>= extra;
+        have -= used + (int)extra;
+        pos += (u64)(used + (int)extra);
+        if (at + rep > total) return false;
+        if (val) {
+            const uint32_t wgt = 32768u >> val;
+            const uint32_t nl = at < hlit ? (rep < hlit - at ? rep : hlit - at) : 0u;
+            lit_k += nl * wgt;
+            dist_k += (rep - nl) * wgt;
+            if (nl && at <= 256u && at + nl > 256u) eob = true;
+            if (nl && at < 256u && at + nl > 128u) high = true;
+        }
+        at += rep;
+        prev = val;
+    }
+    return eob && !(text_only && high) && lit_k == 32768u && (dist_k == 32768u || dist_k == 16384u || dist_k == 0u);
+}
+
+// The block finder: per chunk of the compressed stream the bit offsets at which a non-final dynamic block starts (the first
+// GI_FIND_MAX of them, in stream order; in the stream's last MiB the final block as well), through three sieves of falling width and
+// rising cost --
+//   1. every offset: the type bits and the two code counts (one offset in nine passes).  The chunk goes through registers in pieces
+//      of 512 bytes (lane i holds dwords i and 64 + i, the next piece is on its way); a group of 64 offsets takes its three dwords
+//      with v_readlane, so a group is ~25 instructions and no memory latency.  The survivors' offsets are queued in LDS;
+//   2. 64 queued offsets at a time: the code length code is complete (Kraft sum exactly one: one in 250 of those);
+//   3. 64 of those at a time, one per lane: gi_header_plausible (above);
+// and what is left -- real block starts, and a mirage per 100 MB -- through gi_dynamic_header by the whole wave.
+// (The first version: sieves 1 + 2 in one step for every offset, from memory, and gi_dynamic_header for each of the ~40 survivors
+// per chunk, up to the chunk's first block start only: 5.9 ms for 4 096 chunks of 58 KB.  This one reads the whole stream.)
+#define GI_FIND_MAX 16
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
-                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk, int text_only) {
+                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk, int text_only,
+                                                                                                        int64_t n_real, int64_t fin_first) {
     __shared__ GiWave s_w[GI_WAVES];
+    __shared__ uint32_t s_q1[GI_WAVES][256];  // sieve 1's survivors (a ring; bit offsets from the chunk's first bit)
+    __shared__ uint32_t s_q2[GI_WAVES][128];  // sieve 2's survivors
+    __shared__ uint8_t s_sorted[GI_WAVES][64 * 20];
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
+    uint32_t *const q1 = s_q1[wib], *const q2 = s_q2[wib];
     typedef uint32_t __attribute__((aligned(1))) u32_any;
+    const bool low_half = lane < 32;
+    const uint32_t sh = (uint32_t)lane & 31u;
     for (;;) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long take = 0;
         if (lane == 0) take = atomicAdd(next_chunk, 1ULL);
         const int64_t ci = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
         if (ci >= n_chunks) break;
-        u64 found = ~0ULL;
-        const u64 lo = (u64)ci * chunk_bytes * 8u;
-        u64 hi = lo + (u64)chunk_bytes * 8u;
-        if (hi > (u64)in_len * 8u) hi = (u64)in_len * 8u;
-        for (u64 o00 = lo; o00 < hi && found == ~0ULL; o00 += 64 * GI_FIND_GROUPS) {
-            // GI_FIND_GROUPS groups of 64 offsets per trip: all their loads first (a trip is otherwise one memory latency per 64 offsets)
-            uint32_t w0[GI_FIND_GROUPS], w1[GI_FIND_GROUPS], w2[GI_FIND_GROUPS];
-#pragma unroll
-            for (int u = 0; u < GI_FIND_GROUPS; u++) {
-                const u64 o = o00 + 64u * (u64)u + (u64)lane;
-                // the 96 bits at this lane's offset (the buffer has slack behind the stream)
-                const uint8_t *p = in + ((o >> 5) << 2);
-                const uint32_t d0 = *reinterpret_cast<const u32_any *>(p), d1 = *reinterpret_cast<const u32_any *>(p + 4);
-                const uint32_t d2 = *reinterpret_cast<const u32_any *>(p + 8), d3 = *reinterpret_cast<const u32_any *>(p + 12);
-                const uint32_t sh = (uint32_t)o & 31u;
-                w0[u] = __builtin_amdgcn_alignbit(d1, d0, sh);
-                w1[u] = __builtin_amdgcn_alignbit(d2, d1, sh);
-                w2[u] = __builtin_amdgcn_alignbit(d3, d2, sh);
-            }
-#pragma unroll
-            for (int u = 0; u < GI_FIND_GROUPS; u++) {
-                const u64 o0 = o00 + 64u * (u64)u;
-                const u64 o = o0 + (u64)lane;
-                // not final, dynamic, at most 286 / 30 codes, and the code length code is complete (Kraft sum exactly one)
-                bool ok = o < hi && (w0[u] & 7u) == 4u && ((w0[u] >> 3) & 31u) <= 29u && ((w0[u] >> 8) & 31u) <= 29u;
-                const uint32_t hclen = ((w0[u] >> 13) & 15u) + 4u;
-                const u64 a = ((u64)w1[u] << 32 | w0[u]) >> 17;   // 47 bits: 15 lengths
-                const u64 c = ((u64)w2[u] << 32 | w1[u]) >> 30;   // from bit 62: lengths 15 .. 18
-                uint32_t kraft = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < 19; i++) {
-                    const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
-                    kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
-                }
-                ok = ok && kraft == 128u;
-                for (u64 cand = found == ~0ULL ? __ballot(ok) : 0; cand != 0 && found == ~0ULL; cand &= cand - 1) {  // the whole header, in offset order
-                    const u64 oc = o0 + (u64)__builtin_ctzll(cand);
+        // Chunks n_real .. n_chunks are the chunks fin_first .. n_real (the stream's last MiB, when the upload reaches its end) once
+        // more, searched for the FINAL block: without it the last segment is the stream's last two blocks, and a batch takes as long
+        // as its longest segment.  (A search of its own: twice the candidates in one chunk would make that wave the kernel's last.)
+        const bool fin = ci >= n_real;
+        const u64 lo_byte = (u64)(fin ? fin_first + (ci - n_real) : ci) * chunk_bytes;
+        const uint32_t type_bits = fin ? 5u : 4u;
+        const u64 lo = lo_byte * 8u;
+        const u64 hi_byte = lo_byte + chunk_bytes < (u64)in_len ? lo_byte + chunk_bytes : (u64)in_len;
+        const uint32_t n_bits = (uint32_t)(hi_byte - lo_byte) * 8u;  // (offsets are kept relative to `lo`: a chunk is less than 512 MiB)
+        uint32_t n1 = 0, h1 = 0, n2 = 0, n_found = 0, grp = 0;      // (wave-uniform; grp: groups of 64 offsets searched so far)
+        const uint8_t *const p0 = in + lo_byte + 4u * (uint32_t)lane;
+        // the piece being searched: dwords 0 .. 63, 64 .. 127 and 128 of it; the one behind it (the buffer is zero for 1 KiB behind the stream)
+        uint32_t r0 = 0, r1 = 0, r2 = 0;
+        uint32_t x0 = *reinterpret_cast<const u32_any *>(p0), x1 = *reinterpret_cast<const u32_any *>(p0 + 256);
+        uint32_t x2 = *reinterpret_cast<const u32_any *>(in + lo_byte + 512);
+        for (;;) {
+            const bool scanned = grp * 64u >= n_bits;
+            if (n2 >= 64u || (scanned && n1 == 0u && n2 > 0u)) {
+                // sieve 3, one candidate per lane; then the whole header for what is left, in offset order
+                gi_lds_sync();
+                const uint32_t cnt = n2 < 64u ? n2 : 64u;
+                const bool act = (uint32_t)lane < cnt;
+                const uint32_t rel = q2[act ? lane : 0];
+                const uint32_t rest = q2[64u + (uint32_t)lane < n2 ? 64u + (uint32_t)lane : 0u];
+                const bool good = act && gi_header_plausible(in, in_len, lo + rel, &s_sorted[wib][20 * lane], text_only != 0);
+                for (u64 cand = __ballot(good); cand != 0; cand &= cand - 1) {
+                    const u64 oc = lo + (u64)(uint32_t)__builtin_amdgcn_readlane((int)rel, __builtin_ctzll(cand));
                     GiBits b;
                     b.in = in;
                     b.in_len = in_len;
@@ -978,20 +1099,89 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                         bool high = false;
                         if (text_only)
                             for (int sidx = 128 + lane; sidx < 256; sidx += 64) high |= w.lens[sidx] != 0;
-                        if (__ballot(high) == 0) found = oc;
+                        if (__ballot(high) == 0) {
+                            if (n_found < GI_FIND_MAX) start_bit[ci * GI_FIND_MAX + n_found] = oc;  // (every lane the same word)
+                            n_found++;
+                        }
                     }
                 }
+                gi_lds_sync();
+                if (64u + (uint32_t)lane < n2) q2[lane] = rest;  // (fewer than 64 are left: one lane each)
+                n2 -= cnt;
+                continue;
+            }
+            if (n1 >= 64u || (scanned && n1 > 0u)) {
+                // sieve 2: the code length code is complete
+                gi_lds_sync();
+                const uint32_t cnt = n1 < 64u ? n1 : 64u;
+                const bool act = (uint32_t)lane < cnt;
+                const uint32_t rel = q1[(h1 + (uint32_t)lane) & 255u];
+                const u64 o = lo + (act ? rel : 0u);
+                const uint8_t *p = in + ((o >> 5) << 2);
+                const uint32_t d0 = *reinterpret_cast<const u32_any *>(p), d1 = *reinterpret_cast<const u32_any *>(p + 4);
+                const uint32_t d2 = *reinterpret_cast<const u32_any *>(p + 8), d3 = *reinterpret_cast<const u32_any *>(p + 12);
+                const uint32_t sh2 = (uint32_t)o & 31u;
+                const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh2), w1 = __builtin_amdgcn_alignbit(d2, d1, sh2), w2 = __builtin_amdgcn_alignbit(d3, d2, sh2);
+                const uint32_t hclen = ((w0 >> 13) & 15u) + 4u;
+                const u64 a = ((u64)w1 << 32 | w0) >> 17;   // 47 bits: 15 lengths
+                const u64 c = ((u64)w2 << 32 | w1) >> 30;   // from bit 62: lengths 15 .. 18
+                uint32_t kraft = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 19; i++) {
+                    const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
+                    kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
+                }
+                const bool ok = act && kraft == 128u;
+                const u64 m = __ballot(ok);
+                if (ok) q2[n2 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rel;
+                n2 += (uint32_t)__builtin_popcountll(m);  // (fewer than 64 before: the queue holds 128)
+                h1 += cnt;
+                n1 -= cnt;
+                continue;
+            }
+            if (scanned) break;
+            // sieve 1 over the next eight groups of 64 offsets: not final, dynamic, at most 286 / 30 codes
+            if ((grp & 63u) == 0u) {
+                r0 = x0;
+                r1 = x1;
+                r2 = x2;
+                const uint32_t next_at = (grp >> 6) * 512u + 512u;
+                if (next_at * 8u < n_bits) {  // the piece behind this one, while this one is searched
+                    x0 = *reinterpret_cast<const u32_any *>(p0 + next_at);
+                    x1 = *reinterpret_cast<const u32_any *>(p0 + next_at + 256);
+                    x2 = *reinterpret_cast<const u32_any *>(in + lo_byte + next_at + 512);
+                }
+            }
+            {
+                const uint32_t oct = (grp >> 3) & 7u;
+                const uint32_t cur = oct < 4u ? r0 : r1, nxt = oct < 4u ? r1 : r2;
+                const uint32_t d = 16u * (oct & 3u);
+                const uint32_t rel0 = grp * 64u + (uint32_t)lane;
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; j++) {
+                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d + 2u * j));
+                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d + 2u * j + 1u));
+                    const uint32_t s2 = (j == 7u && d == 48u) ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0)
+                                                              : (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)((d + 2u * j + 2u) & 63u));
+                    const uint32_t w0 = __builtin_amdgcn_alignbit(low_half ? s1 : s2, low_half ? s0 : s1, sh);
+                    const uint32_t rel = rel0 + 64u * j;
+                    const bool ok = rel < n_bits && (w0 & 7u) == type_bits && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u;
+                    const u64 m = __ballot(ok);
+                    if (ok) q1[(h1 + n1 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 255u] = rel;
+                    n1 += (uint32_t)__builtin_popcountll(m);  // (the type bits 0 0 1 -- 1 0 1 -- fit every third offset at most: 22 per group, 63 + 176 in the ring)
+                }
+                grp += 8u;
             }
         }
-        start_bit[ci] = found;  // (every lane the same word)
     }
 }
 
-__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
+// (96 VGPRs and 7.2 KB of LDS per wave: five waves per SIMD, 20 per CU)
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
                                                                                                            uint16_t *sym, int32_t *status, uint32_t *out_len,
                                                                                                            u64 *end_bit, unsigned long long *next_seg) {
     __shared__ GiWave s_w[GI_WAVES];
-    __shared__ uint16_t s_ring[GI_WAVES][GI_RING];
+    __shared__ uint16_t s_ring[GI_WAVES][GI_RING_SYM];
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
@@ -1005,7 +1195,7 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         uint16_t *const dst = sym + seg.out_off;
         // the unknown window in front of the segment: markers, in memory and in the ring
         for (uint32_t j = (uint32_t)lane; j < GI_WINDOW; j += 64) dst[(int32_t)j - (int32_t)GI_WINDOW] = (uint16_t)(0x8000u | j);
-        for (uint32_t j = (uint32_t)lane; j < GI_RING; j += 64) s_ring[wib][j] = (uint16_t)(0x8000u | (GI_WINDOW - GI_RING + j));
+        for (uint32_t j = (uint32_t)lane; j < GI_RING_SYM; j += 64) s_ring[wib][j] = (uint16_t)(0x8000u | (GI_WINDOW - GI_RING_SYM + j));
         gi_lds_sync();
         GiBits b;
         b.in = in;
@@ -1267,6 +1457,12 @@ static int gi_fail(int code, const std::string &m) {
 static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a CU holds four: tables + ring of 16 waves)
     int v = 4;
     if (const char *e = getenv("GS_INFLATE_WGS")) v = std::max(1, std::min(8, atoi(e)));
+    return v;
+}
+
+static int gi_seg_wgs_per_cu() {  // ... of gi_segment_kernel: five (2 KB of ring per wave, 96 VGPRs)
+    int v = 5;
+    if (const char *e = getenv("GS_GUNZIP_WGS")) v = std::max(1, std::min(8, atoi(e)));
     return v;
 }
 
@@ -1593,6 +1789,12 @@ static uint32_t gi_h_x_pow_8n(uint64_t n) {
 
 // host memory of any kind (a page-cache mapping is copied by the runtime at a crawl) to the device through two page-locked buffers,
 // filled by several threads while the other one is on its way
+static double gi_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool gi_trace() {  // GS_HOST_TRACE: the host layer's timeline on stderr; here the stages of a gunzip batch
+    static const bool on = getenv("GS_HOST_TRACE") != nullptr;
+    return on;
+}
+
 static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n) {
     struct Staging {  // per device: events belong to the device they were created on, and two devices should not wait for each other
         std::mutex m;
@@ -1693,7 +1895,7 @@ static int gu_grow(T **p, size_t *cap, size_t need, size_t slack_pct = 12) {
 
 static int64_t gu_slots(int n_cu) {  // chunks per batch: the device's wave slots (GS_GUNZIP_SLOTS: tests force many small batches)
     if (const char *e = getenv("GS_GUNZIP_SLOTS")) return std::max(1, std::min(1 << 20, atoi(e)));
-    return (int64_t)n_cu * 4 * gi_wgs_per_cu();
+    return (int64_t)n_cu * GI_WAVES * gi_seg_wgs_per_cu();
 }
 
 extern "C" int gs_gunzipper_close(gs_gunzipper *g) {
@@ -1776,9 +1978,8 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     g->last_n_text = 0;
     g->text_only = 1;
     const int64_t slots = gu_slots(g->n_cu);
-    // One segment per wave slot, but not less than 16 KiB of compressed data (about one deflate block of zlib's) nor more than 64 KiB
-    // (then the stream takes several batches): the finder reads a chunk only up to its first block start, and more segments than
-    // slots only add rounds.
+    // The finder's unit of work, and the unit a batch is measured in (one chunk per wave slot): not less than 16 KiB of compressed data
+    // nor more than 64 KiB (320 MiB on 256 CUs: then the stream takes several batches).
     g->chunk = (uint32_t)std::min<int64_t>(65536, std::max<int64_t>(16384, g->in_len / slots));
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) g->chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
     if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) g->text_only = atoi(e) == 0;  // block starts whose literal code covers bytes >= 128 count as well
@@ -1812,7 +2013,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         GI_TRY(hipMemcpy(g->d_tail, g->d_text + (g->last_n_text - keep_tail), (size_t)keep_tail, hipMemcpyDeviceToDevice));
     }
     const int64_t slots = gu_slots(g->n_cu);
-    const int wgs = g->n_cu * gi_wgs_per_cu();
+    const int wgs = g->n_cu * gi_seg_wgs_per_cu();
     const u64 base = (g->bit / 8u) & ~(u64)3;  // of the device copy, in the deflate stream
     const u64 rel0 = g->bit - base * 8u;
     const int64_t remain = g->in_len - (int64_t)base;
@@ -1823,34 +2024,52 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     if (span >= ((int64_t)1 << 31)) return gi_fail(GS_E_UNSUPPORTED, "a batch of more than 2 GiB");
     const uint32_t in_len = (uint32_t)span;
     if ((rc = gu_grow(&g->d_in, &g->in_cap, (size_t)span + 1024))) return rc;
-    if ((rc = gu_grow(&g->d_start, &g->start_cap, (size_t)n_chunks))) return rc;
+    const int64_t fin_first = to_end ? std::max<int64_t>(0, n_chunks - (((int64_t)1 << 20) + g->chunk - 1) / g->chunk) : n_chunks;
+    const int64_t n_search = n_chunks + (n_chunks - fin_first);  // (the last MiB twice: gi_find_kernel)
+    if ((rc = gu_grow(&g->d_start, &g->start_cap, (size_t)n_search * GI_FIND_MAX))) return rc;
+    const double t_0 = gi_now_ms();
     if ((rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span))) return rc;
+    const double t_up = gi_now_ms();
     GI_TRY(hipMemset(g->d_in + span, 0, 1024));
-    GI_TRY(hipMemset(g->d_start, 0xff, sizeof(u64) * (size_t)n_chunks));
-    // 1. block starts (chunk 0 starts with the batch's first block)
-    if (n_chunks > 1) {
-        unsigned long long one[2] = {1, 0};
-        GI_TRY(hipMemcpy(g->d_q, one, sizeof(one), hipMemcpyHostToDevice));  // (the counter starts at chunk 1)
-        hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len,
-                           g->chunk, n_chunks, g->d_start, g->d_q, g->text_only);
-        GI_TRY(hipGetLastError());
-    }
-    std::vector<u64> starts((size_t)n_chunks);
-    GI_TRY(hipMemcpy(starts.data(), g->d_start, sizeof(u64) * (size_t)n_chunks, hipMemcpyDeviceToHost));
-    starts[0] = rel0;
-    std::vector<GiSeg> segs;
-    std::vector<u64> stops;  // found starts behind the batch's chunks: where its last segment may end
-    for (int64_t c = 0; c < n_chunks; c++) {
-        if (starts[(size_t)c] == ~0ULL || (c > 0 && starts[(size_t)c] <= rel0)) continue;
-        if (c >= nb_chunks) {
-            stops.push_back(starts[(size_t)c]);
-            continue;
+    GI_TRY(hipMemset(g->d_start, 0xff, sizeof(u64) * (size_t)n_search * GI_FIND_MAX));
+    // 1. block starts: all of them (the first GI_FIND_MAX of a chunk)
+    GI_TRY(hipMemset(g->d_q, 0, sizeof(u64)));
+    hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_search + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * gi_wgs_per_cu())), dim3(64 * GI_WAVES), 0, 0,
+                       g->d_in, in_len, g->chunk, n_search, g->d_start, g->d_q, g->text_only, n_chunks, fin_first);
+    GI_TRY(hipGetLastError());
+    std::vector<u64> found((size_t)n_search * GI_FIND_MAX);
+    GI_TRY(hipMemcpy(found.data(), g->d_start, sizeof(u64) * found.size(), hipMemcpyDeviceToHost));
+    const double t_find = gi_now_ms();
+    std::vector<u64> cands{rel0}, beyond;  // block starts in the batch's chunks (the batch's first block in front), and behind them
+    for (int64_t c = 0; c < n_search; c++)
+        for (int j = 0; j < GI_FIND_MAX; j++) {
+            const u64 v = found[(size_t)c * GI_FIND_MAX + (size_t)j];
+            if (v == ~0ULL) break;
+            if (v > rel0) ((c < n_chunks ? c : fin_first + (c - n_chunks)) < nb_chunks ? cands : beyond).push_back(v);
         }
-        if (!segs.empty()) segs.back().stop_bit = starts[(size_t)c];
+    if (n_search > n_chunks) {  // (the final block's place among the others)
+        std::sort(cands.begin(), cands.end());
+        std::sort(beyond.begin(), beyond.end());
+    }
+    // One segment per wave slot and ONE ROUND of segments per batch: a segment is a wave's work from beginning to end, so the batch
+    // takes as long as its longest segment whatever the others do -- blocks of the stream (50 KB of gzip -1 .. -6 FASTQ, 300 KB of
+    // text, ~12 ms) are dealt out whole, m = floor(blocks / slots) to a segment, and what is left over when the blocks are not a
+    // multiple of the slots waits for the next batch (found again there) instead of costing this one a second round.  At the end of
+    // the stream nothing follows that the blocks left over could join: m = ceil(blocks / slots) then, and one batch less.
+    const size_t n_cand = cands.size();
+    size_t per_seg = std::max<size_t>(1, n_cand / (size_t)slots);
+    if (to_end && n_cand > (size_t)slots * per_seg) per_seg++;
+    const size_t keep = std::min(n_cand, (size_t)slots * per_seg);
+    std::vector<GiSeg> segs;
+    for (size_t i = 0; i < keep; i += per_seg) {
+        if (!segs.empty()) segs.back().stop_bit = cands[i];
         GiSeg sg{};
-        sg.start_bit = starts[(size_t)c];
+        sg.start_bit = cands[i];
         segs.push_back(sg);
     }
+    std::vector<u64> stops;  // found starts behind the batch's segments: where its last segment may end (the first, or -- mirages -- one of the next)
+    for (size_t i = keep; i < n_cand && stops.size() < 8; i++) stops.push_back(cands[i]);
+    for (size_t i = 0; i < beyond.size() && stops.size() < 8; i++) stops.push_back(beyond[i]);
     size_t stop_at = 0;
     if (stops.empty() && !to_end) return gi_fail(GS_E_UNSUPPORTED, "no block start in 64 chunks behind a batch: host decoders");
     u64 sym_total = 0;
@@ -1892,6 +2111,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     GI_TRY(hipMemcpy(st.data(), g->d_status, sizeof(int32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
     GI_TRY(hipMemcpy(len.data(), g->d_len, sizeof(uint32_t) * (size_t)n_segs, hipMemcpyDeviceToHost));
     GI_TRY(hipMemcpy(endb.data(), g->d_end, sizeof(u64) * (size_t)n_segs, hipMemcpyDeviceToHost));
+    const double t_seg = gi_now_ms();
     // A block start that was a mirage (a bit pattern that parses as a complete dynamic header: about one per 100 MB of compressed
     // data without the text test) shows as the segment IN FRONT of it running past it: that segment is decoded again up to the start
     // after the mirage, into the slack behind the symbols (the mirage's own segment is dropped); for the batch's last segment the
@@ -2042,6 +2262,17 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     }
     g->total += (u64)n_new;
     g->n_batches++;
+    if (gi_trace()) {
+        uint32_t longest = 0;
+        std::vector<uint32_t> sorted_len(len.begin(), len.end());
+        std::sort(sorted_len.begin(), sorted_len.end());
+        for (uint32_t v : len) longest = std::max(longest, v);
+        fprintf(stderr, "  segments' text: shortest %u, 10 %% %u, median %u, 90 %% %u, longest %u bytes\n", sorted_len.front(), sorted_len[sorted_len.size() / 10], sorted_len[sorted_len.size() / 2],
+                sorted_len[sorted_len.size() * 9 / 10], longest);
+    }
+    if (gi_trace())
+        fprintf(stderr, "gunzip batch %lld: %lld bytes up %.2f ms, find %.2f (%zu starts in %lld chunks), %lld segments %.2f, windows + text + CRC %.2f: %lld bytes of text\n",
+                (long long)g->n_batches, (long long)span, t_up - t_0, t_find - t_up, n_cand, (long long)n_chunks, (long long)n_fin, t_seg - t_find, gi_now_ms() - t_seg, (long long)n_new);
     g->n_segments += n_fin;
     g->n_chunks += n_chunks;
     g->last_n_text = keep_tail + n_new;

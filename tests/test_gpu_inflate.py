@@ -299,6 +299,18 @@ def test_single_member_gzip_in_many_batches(monkeypatch, slots):
         assert info[2] > 5, info  # batches
 
 
+def test_single_member_gzip_with_more_blocks_than_wave_slots(monkeypatch):
+    """every block start is found; with more blocks than wave slots a segment takes floor(blocks / slots) of them and the blocks left
+    over wait for the next batch"""
+    monkeypatch.setenv("GS_GUNZIP_SLOTS", "4")
+    monkeypatch.setenv("GS_GUNZIP_CHUNK", "1048576")
+    for level in (1, 6):
+        text = _fastq_like(30000, 50 + level)
+        got, info = ga.gunzip_device(_gz(text, level), len(text))
+        assert got.tobytes() == text
+        assert 4 <= info[0] <= 4 * info[2], info  # at most four segments in each batch
+
+
 def test_single_member_gzip_shapes():
     rng = np.random.default_rng(3)
     for name, data in (("empty", b""), ("one byte", b"x"), ("runs", (b"A" * 1000 + b"\n") * 3000),

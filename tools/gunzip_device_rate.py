@@ -1,4 +1,5 @@
-"""rate of the device decoder for single-member gzip on FASTQ (developer tool): python tools/gunzip_device_rate.py [reads] [level]
+"""rate of the device decoder for single-member gzip on FASTQ (developer tool): python tools/gunzip_device_rate.py [reads] [level] [keep_dir]
+(keep_dir: the generated files stay there and are used again by the next run with the same arguments)
 wall time of gs_gunzip_device (H2D of the compressed bytes + the five kernels + D2H of the text); run under rocprofv3 --kernel-trace --stats
 for the kernels' own times"""
 import os
@@ -15,13 +16,18 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-    db = synth.SynthDB()
-    seq, off = synth.reads_host(db.genomes, n)
-    text = bench._fastq_text(seq, n).tobytes()
+    keep = sys.argv[3] if len(sys.argv) > 3 else None
     with tempfile.TemporaryDirectory() as tmp:  # gzip(1) itself: one member, one thread
-        p = os.path.join(tmp, "r.fastq")
-        open(p, "wb").write(text)
-        subprocess.run(["gzip", "-%d" % level, "-k", p], check=True)
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            tmp = keep
+        p = os.path.join(tmp, "r_%d_%d.fastq" % (n, level))
+        if not os.path.exists(p + ".gz"):
+            db = synth.SynthDB()
+            seq, off = synth.reads_host(db.genomes, n)
+            open(p, "wb").write(bench._fastq_text(seq, n).tobytes())
+            subprocess.run(["gzip", "-%d" % level, "-k", p], check=True)
+        text = open(p, "rb").read()
         data = open(p + ".gz", "rb").read()
     print(f"{len(text) / 1e6:.0f} MB text, {len(data) / 1e6:.0f} MB gzip -{level}", flush=True)
     for _ in range(3):
