@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1040,9 +1041,10 @@ __device__ bool gi_header_plausible(const uint8_t *in, uint32_t in_len, u64 o, u
 // (The first version: sieves 1 + 2 in one step for every offset, from memory, and gi_dynamic_header for each of the ~40 survivors
 // per chunk, up to the chunk's first block start only: 5.9 ms for 4 096 chunks of 58 KB.  This one reads the whole stream.)
 #define GI_FIND_MAX 16
+#define GI_FIND_LAUNCHES 64  // finder launches per batch (one behind every uploaded piece; the last ones share a counter-less tail)
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
-                                                                                                        int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk, int text_only,
-                                                                                                        int64_t n_real, int64_t fin_first) {
+                                                                                                        int64_t first, int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk,
+                                                                                                        int text_only, int64_t n_real, int64_t fin_first) {
     __shared__ GiWave s_w[GI_WAVES];
     __shared__ uint32_t s_q1[GI_WAVES][256];  // sieve 1's survivors (a ring; bit offsets from the chunk's first bit)
     __shared__ uint32_t s_q2[GI_WAVES][128];  // sieve 2's survivors
@@ -1058,8 +1060,8 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         __builtin_amdgcn_wave_barrier();
         unsigned long long take = 0;
         if (lane == 0) take = atomicAdd(next_chunk, 1ULL);
-        const int64_t ci = (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
-        if (ci >= n_chunks) break;
+        const int64_t ci = first + (int64_t)(((u64)gi_uni((uint32_t)(take >> 32)) << 32) | gi_uni((uint32_t)take));
+        if (ci >= n_chunks) break;  // (this launch: the chunks first .. n_chunks, `next_chunk` counts from 0)
         // Chunks n_real .. n_chunks are the chunks fin_first .. n_real (the stream's last MiB, when the upload reaches its end) once
         // more, searched for the FINAL block: without it the last segment is the stream's last two blocks, and a batch takes as long
         // as its longest segment.  (A search of its own: twice the candidates in one chunk would make that wave the kernel's last.)
@@ -1389,53 +1391,79 @@ __global__ __launch_bounds__(256) void gi_count_kernel(const uint8_t *text, int6
 }
 
 // out[0] = newlines in [0, n), out[1] = bytes up to and including the newline number (out[0] & ~3) (0 if that is 0)
+// inclusive prefix sum over the 1024 threads of the block (s: 1024 words of LDS; returns this thread's sum, *total the block's)
+__device__ u64 gi_block_scan(u64 v, u64 *s, int t, u64 *total) {
+    s[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const u64 add = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    const u64 mine = s[t];
+    *total = s[1023];
+    __syncthreads();
+    return mine;
+}
+
+// out[0]: newlines in text[0 .. n); out[1]: the bytes up to and including the last newline whose number is a multiple of four (the
+// whole four-line records).  One block: the tiles' counts summed per thread and scanned, the thread whose range holds the target
+// newline opened up over the block (its tiles, then the 4 096 bytes of the one tile), a scan each time.  (The first version walked
+// the last two levels on one thread, a dependent load per tile and per byte: 0.46 ms for 512 MiB of text.)
 __global__ __launch_bounds__(1024) void gi_cut_kernel(const uint8_t *text, int64_t n, const uint32_t *tile_count, int64_t n_tiles, u64 *out) {
-    __shared__ u64 s_part[1024];
-    __shared__ u64 s_total, s_tile, s_before;
+    __shared__ u64 s_scan[1024];
+    __shared__ u64 s_lo, s_before, s_tile;
     const int t = (int)threadIdx.x;
-    // totals per thread over a contiguous range of tiles
     const int64_t per = (n_tiles + 1023) / 1024;
     const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
     u64 mine = 0;
     for (int64_t i = lo; i < hi; i++) mine += tile_count[i];
-    s_part[t] = mine;
-    __syncthreads();
-    if (t == 0) {
-        u64 tot = 0;
-        for (int i = 0; i < 1024; i++) tot += s_part[i];
-        s_total = tot;
-        const u64 target = tot & ~3ULL;  // the newline with this number (1-based) ends the last whole record
-        u64 acc = 0;
-        int64_t tile = -1;
-        if (target > 0) {
-            int i = 0;
-            while (acc + s_part[i] < target) acc += s_part[i++];
-            for (int64_t j = (int64_t)i * per;; j++) {
-                if (acc + tile_count[j] >= target) {
-                    tile = j;
-                    break;
-                }
-                acc += tile_count[j];
-            }
+    u64 total = 0;
+    const u64 incl = gi_block_scan(mine, s_scan, t, &total);
+    const u64 target = total & ~3ULL;  // the newline with this number (1-based) ends the last whole record
+    if (target == 0) {
+        if (t == 0) {
+            out[0] = total;
+            out[1] = 0;
         }
-        s_tile = (u64)tile;
-        s_before = acc;
+        return;
+    }
+    if (incl - mine < target && target <= incl) {  // (exactly one thread)
+        s_lo = (u64)lo;
+        s_before = incl - mine;
     }
     __syncthreads();
-    if (t == 0) {
-        const u64 target = s_total & ~3ULL;
-        u64 cut = 0;
-        if (target > 0) {
-            u64 seen = s_before;
-            const int64_t base = (int64_t)s_tile * 4096;
-            for (int64_t i = base; i < n && i < base + 4096; i++)
-                if (text[i] == '\n' && ++seen == target) {
-                    cut = (u64)i + 1;
-                    break;
-                }
+    // that thread's tiles, 1024 at a time
+    int64_t tile = -1;
+    u64 before = s_before;
+    const int64_t first = (int64_t)s_lo, behind = first + per < n_tiles ? first + per : n_tiles;
+    for (int64_t base = first; tile < 0 && base < behind; base += 1024) {
+        const int64_t i = base + t;
+        const u64 c = i < behind ? tile_count[i] : 0;
+        u64 sum = 0;
+        const u64 inc = gi_block_scan(c, s_scan, t, &sum);
+        if (before + inc - c < target && target <= before + inc) {
+            s_tile = (u64)i;
+            s_before = before + inc - c;
         }
-        out[0] = s_total;
-        out[1] = cut;
+        __syncthreads();
+        if (before + sum >= target) tile = (int64_t)s_tile;
+        before += sum;
+    }
+    if (tile < 0) return;  // (not reached: the target lies in that thread's tiles)
+    // the tile's bytes, four to a thread
+    before = s_before;
+    const int64_t at = tile * 4096 + 4 * (int64_t)t;
+    uint32_t c = 0;
+    for (int q = 0; q < 4; q++) c += (at + q < n && text[at + q] == '\n') ? 1u : 0u;
+    u64 sum = 0;
+    const u64 inc = gi_block_scan(c, s_scan, t, &sum);
+    if (before + inc - c < target && target <= before + inc) {
+        u64 seen = before + inc - c;
+        for (int q = 0; q < 4; q++)
+            if (at + q < n && text[at + q] == '\n' && ++seen == target) out[1] = (u64)(at + q) + 1;
+        out[0] = total;
     }
 }
 
@@ -1795,7 +1823,8 @@ static bool gi_trace() {  // GS_HOST_TRACE: the host layer's timeline on stderr;
     return on;
 }
 
-static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n) {
+// `after_piece(bytes uploaded so far, the event behind that piece's copy)`: work on other streams that waits for the piece
+static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, const std::function<int(size_t, hipEvent_t)> &after_piece) {
     struct Staging {  // per device: events belong to the device they were created on, and two devices should not wait for each other
         std::mutex m;
         uint8_t *h[2] = {nullptr, nullptr};
@@ -1828,11 +1857,15 @@ static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n) {
         }
         memcpy(h[which], src + at, len / (size_t)n_thr);
         for (auto &x : th) x.join();
-        GI_TRY(hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, 0));
-        GI_TRY(hipEventRecord(done[which], 0));
+        GI_TRY(hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, stream));
+        GI_TRY(hipEventRecord(done[which], stream));
         used[which] = true;
+        if (after_piece) {
+            const int rc = after_piece(at + len, done[which]);
+            if (rc) return rc;
+        }
     }
-    GI_TRY(hipStreamSynchronize(0));
+    GI_TRY(hipStreamSynchronize(stream));
     return GS_OK;
 }
 
@@ -1865,7 +1898,10 @@ struct gs_gunzipper {
     uint32_t raw = 0xffffffffu;  // running CRC-32 register (before the final inversion)
     u64 total = 0;               // text bytes so far
     uint32_t chunk = 65536, ratio = 16;
+    uint32_t fchunk = 8192;   // the finder's unit of work (GS_GUNZIP_FIND_CHUNK)
     int text_only = 1;
+    hipStream_t s_up = nullptr, s_find[2] = {nullptr, nullptr};  // the upload, and the finder launches behind its pieces
+    unsigned long long *d_fq = nullptr;                        // one work counter per finder launch
     int64_t n_batches = 0, n_segments = 0, n_mirages = 0, n_chunks = 0, n_members = 1;
     // device buffers, grown as needed
     uint8_t *d_in = nullptr, *d_win = nullptr, *d_prev = nullptr, *d_text = nullptr, *d_tail = nullptr;
@@ -1902,8 +1938,10 @@ extern "C" int gs_gunzipper_close(gs_gunzipper *g) {
     if (!g) return GS_OK;
     hipSetDevice(g->device);
     hipDeviceSynchronize();
+    for (hipStream_t st : {g->s_up, g->s_find[0], g->s_find[1]})
+        if (st) hipStreamDestroy(st);
     for (void *p : {(void *)g->d_in, (void *)g->d_win, (void *)g->d_prev, (void *)g->d_text, (void *)g->d_tail, (void *)g->d_start, (void *)g->d_end, (void *)g->d_off,
-                    (void *)g->d_q, (void *)g->d_segs, (void *)g->d_status, (void *)g->d_len, (void *)g->d_crc, (void *)g->d_sym, (void *)g->d_win16})
+                    (void *)g->d_fq, (void *)g->d_q, (void *)g->d_segs, (void *)g->d_status, (void *)g->d_len, (void *)g->d_crc, (void *)g->d_sym, (void *)g->d_win16})
         hipFree(p);
     delete g;
     return GS_OK;
@@ -1944,7 +1982,11 @@ extern "C" int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *
     hipDeviceProp_t prop;
     g->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     hipError_t e = hipMalloc((void **)&g->d_q, 2 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_fq, GI_FIND_LAUNCHES * sizeof(u64));
     if (e == hipSuccess) e = hipMalloc((void **)&g->d_prev, GI_WINDOW);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->s_up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->s_find[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->s_find[1], hipStreamNonBlocking);
     if (e != hipSuccess) {
         gs_gunzipper_close(g);
         return gi_fail(GS_E_NOMEM, "gs_gunzipper_open");
@@ -1982,6 +2024,8 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     // nor more than 64 KiB (320 MiB on 256 CUs: then the stream takes several batches).
     g->chunk = (uint32_t)std::min<int64_t>(65536, std::max<int64_t>(16384, g->in_len / slots));
     if (const char *e = getenv("GS_GUNZIP_CHUNK")) g->chunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
+    g->fchunk = std::min<uint32_t>(g->chunk, 8192);
+    if (const char *e = getenv("GS_GUNZIP_FIND_CHUNK")) g->fchunk = (uint32_t)std::max(4096, std::min(1 << 24, atoi(e)));
     if (const char *e = getenv("GS_GUNZIP_ANY_BYTES")) g->text_only = atoi(e) == 0;  // block starts whose literal code covers bytes >= 128 count as well
     // symbols a segment may produce per byte of its compressed span: twice what FASTQ does (4 .. 6 : 1); a segment that outgrows its
     // room is decoded again with eight times as much (deflate's limit is 1032 : 1), and when the slack for that is used up the rest
@@ -2024,30 +2068,59 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     if (span >= ((int64_t)1 << 31)) return gi_fail(GS_E_UNSUPPORTED, "a batch of more than 2 GiB");
     const uint32_t in_len = (uint32_t)span;
     if ((rc = gu_grow(&g->d_in, &g->in_cap, (size_t)span + 1024))) return rc;
-    const int64_t fin_first = to_end ? std::max<int64_t>(0, n_chunks - (((int64_t)1 << 20) + g->chunk - 1) / g->chunk) : n_chunks;
-    const int64_t n_search = n_chunks + (n_chunks - fin_first);  // (the last MiB twice: gi_find_kernel)
+    // 1. the compressed bytes in pieces, and behind every piece the block finder over the chunks that are complete with it (all block
+    // starts: the first GI_FIND_MAX of a chunk): the search runs while the next pieces are copied
+    const int64_t fc = g->fchunk;
+    const int64_t n_fchunks = (span + fc - 1) / fc;
+    const int64_t fin_first = to_end ? std::max<int64_t>(0, n_fchunks - (((int64_t)1 << 20) + fc - 1) / fc) : n_fchunks;
+    const int64_t n_search = n_fchunks + (n_fchunks - fin_first);  // (the last MiB twice: gi_find_kernel)
     if ((rc = gu_grow(&g->d_start, &g->start_cap, (size_t)n_search * GI_FIND_MAX))) return rc;
     const double t_0 = gi_now_ms();
-    if ((rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span))) return rc;
-    const double t_up = gi_now_ms();
     GI_TRY(hipMemset(g->d_in + span, 0, 1024));
     GI_TRY(hipMemset(g->d_start, 0xff, sizeof(u64) * (size_t)n_search * GI_FIND_MAX));
-    // 1. block starts: all of them (the first GI_FIND_MAX of a chunk)
-    GI_TRY(hipMemset(g->d_q, 0, sizeof(u64)));
-    hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_search + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * gi_wgs_per_cu())), dim3(64 * GI_WAVES), 0, 0,
-                       g->d_in, in_len, g->chunk, n_search, g->d_start, g->d_q, g->text_only, n_chunks, fin_first);
-    GI_TRY(hipGetLastError());
+    GI_TRY(hipMemset(g->d_fq, 0, GI_FIND_LAUNCHES * sizeof(u64)));
+    GI_TRY(hipStreamSynchronize(0));  // (the upload and the finder run on streams of their own, which do not wait for the null stream)
+    int64_t searched = 0;
+    int n_launch = 0;
+    auto find_upto = [&](int64_t upto, hipEvent_t ev) -> int {  // the work items searched .. upto
+        if (upto <= searched) return GS_OK;
+        hipStream_t st = g->s_find[n_launch & 1];
+        if (ev) GI_TRY(hipStreamWaitEvent(st, ev, 0));
+        const int64_t n_items = upto - searched;
+        hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_items + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * gi_wgs_per_cu())), dim3(64 * GI_WAVES), 0, st,
+                           g->d_in, in_len, g->fchunk, searched, upto, g->d_start, g->d_fq + n_launch, g->text_only, n_fchunks, fin_first);
+        GI_TRY(hipGetLastError());
+        searched = upto;
+        n_launch++;
+        return GS_OK;
+    };
+    // (A launch behind every second piece of 32 MiB, 8 KiB to a wave: 8 192 chunks, two rounds over the wave slots, about as long as the
+    // two pieces take to arrive.  The launches share one hardware queue -- the process has more streams than queues -- and run one after
+    // the other: smaller launches leave the device half empty, larger ones leave more to do when the last piece is there.
+    // 238 MB: 4.9 ms of upload + 2.2 ms against 4.9 + 4.5 with one launch behind the upload.)
+    int n_pieces = 0, every = 2;
+    if (const char *e = getenv("GS_GUNZIP_FIND_EVERY")) every = std::max(1, atoi(e));
+    rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
+        if (++n_pieces % every != 0 || (int64_t)up >= span || n_launch >= GI_FIND_LAUNCHES - 1) return GS_OK;  // (the rest in one launch, below)
+        return find_upto(((int64_t)up - 4096) / fc, ev);  // (a candidate is looked at up to ~600 bytes behind its chunk)
+    });
+    if (rc) return rc;
+    const double t_up = gi_now_ms();
+    if ((rc = find_upto(n_search, nullptr))) return rc;
+    GI_TRY(hipStreamSynchronize(g->s_find[0]));
+    GI_TRY(hipStreamSynchronize(g->s_find[1]));
     std::vector<u64> found((size_t)n_search * GI_FIND_MAX);
     GI_TRY(hipMemcpy(found.data(), g->d_start, sizeof(u64) * found.size(), hipMemcpyDeviceToHost));
     const double t_find = gi_now_ms();
     std::vector<u64> cands{rel0}, beyond;  // block starts in the batch's chunks (the batch's first block in front), and behind them
+    const u64 batch_bits = (u64)nb_chunks * g->chunk * 8u;
     for (int64_t c = 0; c < n_search; c++)
         for (int j = 0; j < GI_FIND_MAX; j++) {
             const u64 v = found[(size_t)c * GI_FIND_MAX + (size_t)j];
             if (v == ~0ULL) break;
-            if (v > rel0) ((c < n_chunks ? c : fin_first + (c - n_chunks)) < nb_chunks ? cands : beyond).push_back(v);
+            if (v > rel0) (v < batch_bits ? cands : beyond).push_back(v);
         }
-    if (n_search > n_chunks) {  // (the final block's place among the others)
+    if (n_search > n_fchunks) {  // (the final block's place among the others)
         std::sort(cands.begin(), cands.end());
         std::sort(beyond.begin(), beyond.end());
     }
