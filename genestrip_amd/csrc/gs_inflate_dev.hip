@@ -1327,7 +1327,21 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const uint16_t *sym, co
         const uint32_t n = out_len[i];
         const uint8_t *prev = i ? win + (size_t)(i - 1) * GI_WINDOW : win0;
         uint8_t *out = text + text_off[i];
-        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        // eight symbols to a thread (a segment's symbols start on a 16-byte boundary: its room is a multiple of eight), then the rest
+        typedef u64 __attribute__((aligned(1))) u64_any;
+        const uint32_t n8 = n / 8u;
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n8; j += gridDim.x * blockDim.x) {
+            const gs_u16x8 v = *reinterpret_cast<const gs_u16x8 *>(dst + 8u * (size_t)j);
+            u64 o = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint16_t c = v.v[q];
+                const uint8_t b = c < 0x8000u ? (uint8_t)c : (prev ? prev[c & 0x7fffu] : (uint8_t)0);
+                o |= (u64)b << (8 * q);
+            }
+            *reinterpret_cast<u64_any *>(out + 8u * (size_t)j) = o;
+        }
+        for (uint32_t j = 8u * n8 + blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
             const uint16_t v = dst[j];
             out[j] = v < 0x8000u ? (uint8_t)v : (prev ? prev[v & 0x7fffu] : (uint8_t)0);
         }
@@ -2154,7 +2168,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         }
         const u64 end = is_last ? (stops.empty() ? (u64)in_len * 8u : stops.back()) : segs[i].stop_bit;  // (room up to the farthest stop: it may have to run on)
         const u64 span_b = (end - segs[i].start_bit) / 8u + 1u;
-        const u64 cap = span_b * g->ratio + 65536u;
+        const u64 cap = (span_b * g->ratio + 65536u + 7u) & ~(u64)7;  // (a multiple of eight: gi_resolve_kernel reads 16 bytes at a time)
         if (cap > 0xffff0000ull) return gi_fail(GS_E_UNSUPPORTED, "a segment of more than 4 G symbols");
         segs[i].out_cap = (uint32_t)cap;
         sym_total += GI_WINDOW;
