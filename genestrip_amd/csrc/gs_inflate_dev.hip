@@ -1349,7 +1349,11 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const uint16_t *sym, co
 }
 
 // raw CRC-32 register (no pre / post inversion) over tile t of `tile` bytes: the host combines them
-__global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t *text, int64_t n, uint32_t tile, uint32_t *crc) {
+struct GiCrcPow {  // x^(8 * slice * 2^s) mod P for a whole tile's slice (tile / 64 bytes), s = 0 .. 5: computed once on the host
+    uint32_t p[6];
+};
+
+__global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t *text, int64_t n, uint32_t tile, uint32_t *crc, GiCrcPow pw) {
     __shared__ uint32_t s_crc[4 * 256];
     for (int i = (int)threadIdx.x; i < 4 * 256; i += 256) s_crc[i] = gi_crc_table[i];
     __syncthreads();
@@ -1373,6 +1377,18 @@ __global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t *text, int64_
         }
     }
     for (; i < hi && lo < cap; i++) c = s_crc[(c ^ dst[i]) & 0xffu] ^ (c >> 8);
+    if (cap == tile && slice * 64u == tile) {
+        // a whole tile, 64 equal slices: neighbours are joined pairwise, crc(A B) = crc(A) x^(8 |B|) + crc(B), six times (a lane's own
+        // x^(8 * bytes behind it) -- a square-and-multiply per lane -- took longer than the slice itself)
+        uint32_t part = c;
+#pragma unroll
+        for (int sidx = 0; sidx < 6; sidx++) {
+            const uint32_t other = (uint32_t)__shfl_down((int)part, 1 << sidx);
+            if ((lane & ((2 << sidx) - 1)) == 0) part = gi_gf_mul(part, pw.p[sidx]) ^ other;
+        }
+        if (lane == 0) crc[t] = part;
+        return;
+    }
     const uint32_t behind = hi < cap ? cap - hi : 0;
     uint32_t part = (lo < cap) ? gi_gf_mul(c, gi_x_pow_8n(behind)) : 0u;
     for (int o = 32; o >= 1; o >>= 1) part ^= (uint32_t)__shfl_xor((int)part, o);
@@ -2331,7 +2347,9 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     }
     hipLaunchKernelGGL(gi_resolve_kernel, dim3(16, (unsigned)std::min<int64_t>(n_fin, 16384)), dim3(256), 0, 0, g->d_sym, g->d_segs, g->d_len, g->d_off, n_fin, g->d_win, win0,
                        g->d_text + keep_tail);
-    if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, g->d_text + keep_tail, n_new, tile, g->d_crc);
+    GiCrcPow pw;
+    for (int sidx = 0; sidx < 6; sidx++) pw.p[sidx] = gi_h_x_pow_8n((uint64_t)(tile / 64u) << sidx);
+    if (n_tiles > 0) hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, g->d_text + keep_tail, n_new, tile, g->d_crc, pw);
     GI_TRY(hipGetLastError());
     GI_TRY(hipMemcpy(g->d_prev, g->d_win + (size_t)(n_fin - 1) * GI_WINDOW, GI_WINDOW, hipMemcpyDeviceToDevice));  // (a short batch's window reaches into the one before: gi_win_* took it from win0)
     g->have_prev = true;
