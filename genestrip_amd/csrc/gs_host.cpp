@@ -838,6 +838,8 @@ struct TextJob {
         const int64_t text_target = per_read && !getenv("GS_HOST_BGZF_TEXT") ? ((int64_t)128 << 20) : bgzf_text_target();
         int64_t fallback_off = -1, fallback_reads = 0;
         int64_t n_lines = 0, n_bytes = 0;
+        static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
+        const double ts0 = now_s();
         for (;;) {  // a slice with a whole record in it: from this batch, or with the next one behind what is left of this
             const int64_t rest = gz_n_ - gz_off_, look = std::min(rest, text_target);
             n_lines = n_bytes = 0;
@@ -864,6 +866,7 @@ struct TextJob {
         const int64_t rest = gz_n_ - gz_off_;
         const bool last = gz_last_ != 0 && std::min(rest, text_target) == rest;
         const uint8_t *text = gz_text_ + gz_off_;
+        const double ts1 = now_s();
         if (!err) err = gs_match_text_select(c.run, bank);
         if (!err && n_lines > 0 && per_read) {
             const int64_t n_chunk = n_lines >> 2;
@@ -914,6 +917,7 @@ struct TextJob {
             fallback_off = carry_file_off;
             fallback_reads = reads_in_file;
         }
+        const double ts2 = now_s();
         if (err || last || fallback_off >= 0) {
             if (!err && fallback_off < 0 && gz_off_ < gz_n_) {  // what is left behind the last whole record
                 carry.resize((size_t)(gz_n_ - gz_off_));
@@ -921,6 +925,9 @@ struct TextJob {
             }
             err = finish(err, fallback_off, fallback_reads);
         }
+        if (trace)
+            fprintf(stderr, "gunzip slice: %lld bytes, %lld lines: cut (+ next batch) %.2f ms, submit %.2f ms, finish %.2f ms\n", (long long)n_bytes, (long long)n_lines, (ts1 - ts0) * 1e3,
+                    (ts2 - ts1) * 1e3, (now_s() - ts2) * 1e3);
         *err_out = err;
         return 1;
     }
@@ -1560,13 +1567,16 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
         }
     }
     if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    const double t_begin = now_s();
     rc = gs_match_begin(&c.run, db, cfg);
     if (rc) return rc;
     const double t_start = now_s();
     std::vector<int64_t> reads_of_file;
     bool side_by_side = false;
     int err = run_files(c, paths, n_paths, nullptr, reads_of_file, &side_by_side);
+    const double t_files = now_s();
     if (!err) err = gs_match_finish(c.run, table, dtable);
+    const double t_fin = now_s();
     if (!err && side_by_side) {  // (file << 32 | read in file) -> running read number over the files in order
         std::vector<int64_t> before((size_t)n_paths + 1, 0);
         for (int i = 0; i < n_paths; i++) before[(size_t)i + 1] = before[(size_t)i] + reads_of_file[(size_t)i];
@@ -1577,6 +1587,9 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     }
     gs_match_destroy(c.run);
     const bool wrote = c.filtered.close() & c.kraken.close();  // (both are flushed before the clock stops)
+    if (getenv("GS_HOST_TRACE") != nullptr)
+        fprintf(stderr, "match files: begin %.2f ms, files %.2f, finish %.2f, destroy + close %.2f\n", (t_start - t_begin) * 1e3, (t_files - t_start) * 1e3, (t_fin - t_files) * 1e3,
+                (now_s() - t_fin) * 1e3);
     if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
     if (totals) {
         totals->reads = c.reads;

@@ -2355,14 +2355,12 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     g->have_prev = true;
     std::vector<uint32_t> crc((size_t)std::max<int64_t>(n_tiles, 1), 0);
     if (n_tiles > 0) GI_TRY(hipMemcpy(crc.data(), g->d_crc, sizeof(uint32_t) * (size_t)n_tiles, hipMemcpyDeviceToHost));
-    {   // the tiles' registers behind one another, then behind the register so far: R = R_before x^(8 n) + sum_t R_t x^(8 bytes behind tile t)
+    {   // the tiles' registers behind one another (Horner: one multiplication per tile), then behind the register so far:
+        // R = R_before x^(8 n) + sum_t R_t x^(8 bytes behind tile t)
         uint32_t add = 0;
         const uint32_t x_tile = gi_h_x_pow_8n(tile);
-        uint32_t xp = 0x80000000u;  // x^0: the last tile has nothing behind it
-        for (int64_t t = n_tiles - 1; t >= 0; t--) {
-            add ^= gi_h_gf_mul(crc[(size_t)t], xp);
-            xp = gi_h_gf_mul(xp, t == n_tiles - 1 ? gi_h_x_pow_8n((uint64_t)(n_new - t * (int64_t)tile)) : x_tile);
-        }
+        for (int64_t t = 0; t < n_tiles; t++)
+            add = gi_h_gf_mul(add, t == n_tiles - 1 ? gi_h_x_pow_8n((uint64_t)(n_new - t * (int64_t)tile)) : x_tile) ^ crc[(size_t)t];
         g->raw = gi_h_gf_mul(g->raw, gi_h_x_pow_8n((uint64_t)n_new)) ^ add;
     }
     g->total += (u64)n_new;
