@@ -649,6 +649,7 @@ struct GunzipperPool {
     }
     void put(int device, gs_gunzipper *g) {
         if (!g) return;
+        gs_gunzipper_park(g);  // (the file is about to be unmapped: no upload thread may read it any more)
         {
             std::lock_guard<std::mutex> l(m);
             bool have = false;

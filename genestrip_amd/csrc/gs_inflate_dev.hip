@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -1929,6 +1930,18 @@ struct gs_gunzipper {
     u64 total = 0;               // text bytes so far
     uint32_t chunk = 65536, ratio = 16;
     uint32_t fchunk = 8192;   // the finder's unit of work (GS_GUNZIP_FIND_CHUNK)
+    double block_bytes = 0;   // compressed bytes per deflate block, as the batch before found them (0: not known yet)
+    // A stream of up to GS_GUNZIP_WHOLE_MAX bytes (16 GiB) is uploaded WHOLE, by a thread of its own, while the batches are decoded: only
+    // the first batch waits for its bytes, and nothing is uploaded twice.  (Larger streams: every batch uploads its own span, d_in.)
+    bool whole = false;
+    uint8_t *d_all = nullptr;
+    size_t all_cap = 0;
+    std::thread up_thr;
+    std::mutex up_m;
+    std::condition_variable up_cv;
+    int64_t up_done = 0;  // bytes of the deflate stream that have arrived (under up_m)
+    int up_rc = GS_OK;
+    bool up_cancel = false, up_finished = false;
     int text_only = 1;
     hipStream_t s_up = nullptr, s_find[2] = {nullptr, nullptr};  // the upload, and the finder launches behind its pieces
     unsigned long long *d_fq = nullptr;                        // one work counter per finder launch
@@ -1964,14 +1977,70 @@ static int64_t gu_slots(int n_cu) {  // chunks per batch: the device's wave slot
     return (int64_t)n_cu * GI_WAVES * gi_seg_wgs_per_cu();
 }
 
+// the caller is through with the file (or gives up on it): the upload thread is stopped -- `gz` may go away; the buffers stay
+extern "C" int gs_gunzipper_park(gs_gunzipper *g) {
+    if (!g) return GS_OK;
+    if (g->up_thr.joinable()) {
+        {
+            std::lock_guard<std::mutex> l(g->up_m);
+            g->up_cancel = true;
+        }
+        g->up_thr.join();
+    }
+    g->up_cancel = false;
+    return GS_OK;
+}
+
+static void gu_start_upload(gs_gunzipper *g) {
+    g->up_done = 0;
+    g->up_rc = GS_OK;
+    g->up_cancel = g->up_finished = false;
+    g->up_thr = std::thread([g] {
+        int rc = hipSetDevice(g->device) == hipSuccess ? GS_OK : GS_E_HIP;
+        hipEvent_t prev = nullptr;
+        size_t prev_end = 0;
+        auto publish = [g](int64_t done, int rc_now, bool fin) {
+            {
+                std::lock_guard<std::mutex> l(g->up_m);
+                g->up_done = std::max(g->up_done, done);
+                if (rc_now) g->up_rc = rc_now;
+                g->up_finished = g->up_finished || fin;
+            }
+            g->up_cv.notify_all();
+        };
+        if (!rc)
+            rc = gi_h2d_staged(g->d_all, g->gz + g->hdr, (size_t)g->in_len, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
+                if (prev) {  // the piece before this one has arrived when its event has (this one is on its way)
+                    if (hipEventSynchronize(prev) != hipSuccess) return GS_E_HIP;
+                    publish((int64_t)prev_end, GS_OK, false);
+                }
+                prev = ev;
+                prev_end = up;
+                std::lock_guard<std::mutex> l(g->up_m);
+                return g->up_cancel ? GS_E_STATE : GS_OK;
+            });
+        publish(rc ? 0 : g->in_len, rc, true);
+    });
+}
+
+// until `need` bytes of the stream have arrived; *have: how many have
+static int gu_wait_uploaded(gs_gunzipper *g, int64_t need, int64_t *have) {
+    std::unique_lock<std::mutex> l(g->up_m);
+    g->up_cv.wait(l, [&] { return g->up_done >= need || g->up_finished; });
+    *have = g->up_done;
+    if (g->up_done < need) return gi_fail(g->up_rc ? g->up_rc : GS_E_HIP, "gs_gunzipper: the upload of the stream failed");
+    return GS_OK;
+}
+
 extern "C" int gs_gunzipper_close(gs_gunzipper *g) {
     if (!g) return GS_OK;
+    gs_gunzipper_park(g);
     hipSetDevice(g->device);
     hipDeviceSynchronize();
     for (hipStream_t st : {g->s_up, g->s_find[0], g->s_find[1]})
         if (st) hipStreamDestroy(st);
     for (void *p : {(void *)g->d_in, (void *)g->d_win, (void *)g->d_prev, (void *)g->d_text, (void *)g->d_tail, (void *)g->d_start, (void *)g->d_end, (void *)g->d_off,
-                    (void *)g->d_fq, (void *)g->d_q, (void *)g->d_segs, (void *)g->d_status, (void *)g->d_len, (void *)g->d_crc, (void *)g->d_sym, (void *)g->d_win16})
+                    (void *)g->d_all, (void *)g->d_fq, (void *)g->d_q, (void *)g->d_segs, (void *)g->d_status, (void *)g->d_len, (void *)g->d_crc, (void *)g->d_sym, (void *)g->d_win16})
         hipFree(p);
     delete g;
     return GS_OK;
@@ -2035,6 +2104,7 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     if (!g || !gz || n < 18) return gi_fail(GS_E_INVALID, "bad argument");
     const int64_t hdr = gi_gzip_header(gz, n);
     if (hdr < 0) return gi_fail(GS_E_INVALID, "not a gzip stream, or a truncated one");
+    gs_gunzipper_park(g);
     GI_TRY(hipSetDevice(g->device));
     GI_TRY(hipDeviceSynchronize());  // (nobody reads the last file's text any more)
     g->gz = gz;
@@ -2046,6 +2116,7 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     g->raw = 0xffffffffu;
     g->total = 0;
     g->n_batches = g->n_segments = g->n_mirages = g->n_chunks = 0;
+    g->block_bytes = 0;
     g->n_members = 1;
     g->last_n_text = 0;
     g->text_only = 1;
@@ -2067,6 +2138,15 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
         g->ratio = (uint32_t)std::min<u64>(1040, std::max<u64>(12, 4 * (est / (u64)std::max<int64_t>(g->in_len, 1)) + 4));
     }
     if (const char *e = getenv("GS_GUNZIP_RATIO")) g->ratio = (uint32_t)std::max(2, std::min(1040, atoi(e)));
+    int64_t whole_max = (int64_t)16 << 30;
+    if (const char *e = getenv("GS_GUNZIP_WHOLE_MAX")) whole_max = atoll(e);
+    g->whole = g->in_len <= whole_max;
+    if (g->whole && gu_grow(&g->d_all, &g->all_cap, (size_t)g->in_len + 1024) != GS_OK) g->whole = false;  // (no room: batch by batch)
+    if (g->whole) {
+        GI_TRY(hipMemset(g->d_all + g->in_len, 0, 1024));
+        GI_TRY(hipDeviceSynchronize());
+        gu_start_upload(g);
+    }
     return GS_OK;
 }
 
@@ -2091,13 +2171,21 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     const u64 base = (g->bit / 8u) & ~(u64)3;  // of the device copy, in the deflate stream
     const u64 rel0 = g->bit - base * 8u;
     const int64_t remain = g->in_len - (int64_t)base;
-    const int64_t nb_chunks = std::min<int64_t>(slots, (remain + g->chunk - 1) / g->chunk);
+    int64_t nb_chunks = std::min<int64_t>(slots, (remain + g->chunk - 1) / g->chunk);
+    if (g->block_bytes > 0 && (remain + g->chunk - 1) / g->chunk > slots) {  // (what is left fits one batch: all of it, m = ceil below)
+        // as many bytes as hold a whole number of blocks per wave slot (and 3 % more: blocks differ a little): what lies behind the
+        // batch's last segment is uploaded and searched again by the next batch
+        const double room = (double)nb_chunks * g->chunk;
+        const int64_t per_slot = std::max<int64_t>(1, (int64_t)(room / ((double)slots * g->block_bytes)));
+        nb_chunks = std::min<int64_t>(nb_chunks, (int64_t)((double)per_slot * (double)slots * g->block_bytes * 1.03 / g->chunk) + 1);
+    }
     const int64_t span = std::min<int64_t>(remain, (nb_chunks + 64) * (int64_t)g->chunk);
     const bool to_end = span == remain;
     const int64_t n_chunks = (span + g->chunk - 1) / g->chunk;
     if (span >= ((int64_t)1 << 31)) return gi_fail(GS_E_UNSUPPORTED, "a batch of more than 2 GiB");
     const uint32_t in_len = (uint32_t)span;
-    if ((rc = gu_grow(&g->d_in, &g->in_cap, (size_t)span + 1024))) return rc;
+    if (!g->whole && (rc = gu_grow(&g->d_in, &g->in_cap, (size_t)span + 1024))) return rc;
+    const uint8_t *const d_in = g->whole ? g->d_all + base : g->d_in;  // (whole: what lies behind the span is the stream itself, and zeros behind its end)
     // 1. the compressed bytes in pieces, and behind every piece the block finder over the chunks that are complete with it (all block
     // starts: the first GI_FIND_MAX of a chunk): the search runs while the next pieces are copied
     const int64_t fc = g->fchunk;
@@ -2106,7 +2194,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     const int64_t n_search = n_fchunks + (n_fchunks - fin_first);  // (the last MiB twice: gi_find_kernel)
     if ((rc = gu_grow(&g->d_start, &g->start_cap, (size_t)n_search * GI_FIND_MAX))) return rc;
     const double t_0 = gi_now_ms();
-    GI_TRY(hipMemset(g->d_in + span, 0, 1024));
+    if (!g->whole) GI_TRY(hipMemset(g->d_in + span, 0, 1024));
     GI_TRY(hipMemset(g->d_start, 0xff, sizeof(u64) * (size_t)n_search * GI_FIND_MAX));
     GI_TRY(hipMemset(g->d_fq, 0, GI_FIND_LAUNCHES * sizeof(u64)));
     GI_TRY(hipStreamSynchronize(0));  // (the upload and the finder run on streams of their own, which do not wait for the null stream)
@@ -2118,7 +2206,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         if (ev) GI_TRY(hipStreamWaitEvent(st, ev, 0));
         const int64_t n_items = upto - searched;
         hipLaunchKernelGGL(gi_find_kernel, dim3((unsigned)std::min<int64_t>((n_items + GI_WAVES - 1) / GI_WAVES, (int64_t)g->n_cu * gi_wgs_per_cu())), dim3(64 * GI_WAVES), 0, st,
-                           g->d_in, in_len, g->fchunk, searched, upto, g->d_start, g->d_fq + n_launch, g->text_only, n_fchunks, fin_first);
+                           d_in, in_len, g->fchunk, searched, upto, g->d_start, g->d_fq + n_launch, g->text_only, n_fchunks, fin_first);
         GI_TRY(hipGetLastError());
         searched = upto;
         n_launch++;
@@ -2130,11 +2218,23 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     // 238 MB: 4.9 ms of upload + 2.2 ms against 4.9 + 4.5 with one launch behind the upload.)
     int n_pieces = 0, every = 2;
     if (const char *e = getenv("GS_GUNZIP_FIND_EVERY")) every = std::max(1, atoi(e));
-    rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
-        if (++n_pieces % every != 0 || (int64_t)up >= span || n_launch >= GI_FIND_LAUNCHES - 1) return GS_OK;  // (the rest in one launch, below)
-        return find_upto(((int64_t)up - 4096) / fc, ev);  // (a candidate is looked at up to ~600 bytes behind its chunk)
-    });
-    if (rc) return rc;
+    if (g->whole) {
+        // the upload thread is ahead of the batches: the first one follows it in steps of `every` pieces, the later ones find their
+        // bytes in place (one launch, the whole device)
+        int64_t seen = 0;
+        while (seen < span) {
+            int64_t have = 0;
+            if ((rc = gu_wait_uploaded(g, (int64_t)base + std::min<int64_t>(span, seen + (int64_t)every * (32 << 20)), &have))) return rc;
+            seen = std::min<int64_t>(span, have - (int64_t)base);
+            if (seen < span && n_launch < GI_FIND_LAUNCHES - 1 && (rc = find_upto((seen - 4096) / fc, nullptr))) return rc;
+        }
+    } else {
+        rc = gi_h2d_staged(g->d_in, g->gz + g->hdr + base, (size_t)span, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
+            if (++n_pieces % every != 0 || (int64_t)up >= span || n_launch >= GI_FIND_LAUNCHES - 1) return GS_OK;  // (the rest in one launch, below)
+            return find_upto(((int64_t)up - 4096) / fc, ev);  // (a candidate is looked at up to ~600 bytes behind its chunk)
+        });
+        if (rc) return rc;
+    }
     const double t_up = gi_now_ms();
     if ((rc = find_upto(n_search, nullptr))) return rc;
     GI_TRY(hipStreamSynchronize(g->s_find[0]));
@@ -2160,6 +2260,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     // multiple of the slots waits for the next batch (found again there) instead of costing this one a second round.  At the end of
     // the stream nothing follows that the blocks left over could join: m = ceil(blocks / slots) then, and one batch less.
     const size_t n_cand = cands.size();
+    if (n_cand > 16) g->block_bytes = (double)(cands.back() - cands.front()) / 8.0 / (double)(n_cand - 1);
     size_t per_seg = std::max<size_t>(1, n_cand / (size_t)slots);
     if (to_end && n_cand > (size_t)slots * per_seg) per_seg++;
     const size_t keep = std::min(n_cand, (size_t)slots * per_seg);
@@ -2205,7 +2306,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     }
     GI_TRY(hipMemcpy(g->d_segs, segs.data(), sizeof(GiSeg) * (size_t)n_segs, hipMemcpyHostToDevice));
     GI_TRY(hipMemset(g->d_q + 1, 0, sizeof(u64)));
-    hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_segs + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len, g->d_segs,
+    hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_segs + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, g->d_segs,
                        n_segs, g->d_sym, g->d_status, g->d_len, g->d_end, g->d_q + 1);
     GI_TRY(hipGetLastError());
     std::vector<int32_t> st((size_t)n_segs);
@@ -2295,7 +2396,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         const int64_t n_redo = (int64_t)redo.size();
         GI_TRY(hipMemcpy(g->d_segs, redo.data(), sizeof(GiSeg) * (size_t)n_redo, hipMemcpyHostToDevice));  // (the master copy goes back below)
         GI_TRY(hipMemset(g->d_q + 1, 0, sizeof(u64)));
-        hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_redo + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, g->d_in, in_len, g->d_segs,
+        hipLaunchKernelGGL(gi_segment_kernel, dim3((unsigned)std::min<int64_t>((n_redo + GI_WAVES - 1) / GI_WAVES, wgs)), dim3(64 * GI_WAVES), 0, 0, d_in, in_len, g->d_segs,
                            n_redo, g->d_sym, g->d_status, g->d_len, g->d_end, g->d_q + 1);
         GI_TRY(hipGetLastError());
         std::vector<int32_t> rst((size_t)n_redo);

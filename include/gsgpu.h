@@ -510,7 +510,8 @@ int gs_inflater_feed(gs_inflater *inf, const uint8_t *file, const gs_inflate_mem
  * GS_E_UNSUPPORTED (from open or from any batch): not a stream this
  * path takes from here on (a segment that outgrows its buffer, a block boundary that was a mirage and could not be repaired) -- the
  * caller inflates the rest on the host; GS_E_INVALID: the stream is damaged (bad code, CRC-32 or ISIZE mismatch).  `gz` must stay
- * readable until gs_gunzipper_close.  gs_gunzipper_info: [0] segments, [1] chunks searched, [2] batches, [3] block starts that were
+ * readable until gs_gunzipper_close, _reopen or _park (a stream of up to 16 GiB is uploaded by a thread of the object's own while the
+ * batches are decoded).  gs_gunzipper_info: [0] segments, [1] chunks searched, [2] batches, [3] block starts that were
  * mirages (decoded again).
  * gs_gunzip_plan_device: the whole stream into ONE device buffer (released with gs_gunzip_free; several members: GS_E_UNSUPPORTED);
  * gs_gunzip_device copies it to `out` (tests, tools).  info as gs_gunzipper_info. */
@@ -519,6 +520,7 @@ int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t
 int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n); /* the same object and its device buffers on another file */
 int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text, int64_t *n_text, int *last);
 int gs_gunzipper_info(const gs_gunzipper *g, int64_t info[4]);
+int gs_gunzipper_park(gs_gunzipper *g); /* the caller is through with the file: the upload thread is stopped (`gz` may go away), the buffers stay */
 int gs_gunzipper_close(gs_gunzipper *g);
 int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text, int64_t *n_text, int64_t info[4]);
 int gs_gunzip_free(int device, uint8_t *d_text);

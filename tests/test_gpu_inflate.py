@@ -286,10 +286,14 @@ def test_golden_sample_fastq_gz_on_the_device(monkeypatch):
     assert got.tobytes() == text
 
 
+@pytest.mark.parametrize("upload", ["whole", "per_batch"])
 @pytest.mark.parametrize("slots", ["3", "17"])
-def test_single_member_gzip_in_many_batches(monkeypatch, slots):
+def test_single_member_gzip_in_many_batches(monkeypatch, slots, upload):
     """the stream in batches of a few chunks: every batch starts at the block the one before stopped at, its windows are resolved through
-    the window the batch before left, the CRC-32 is folded into a running register"""
+    the window the batch before left, the CRC-32 is folded into a running register.  The compressed bytes: uploaded whole by the
+    decoder's own thread while the batches run (the default up to 16 GiB), or span by span with every batch"""
+    if upload == "per_batch":
+        monkeypatch.setenv("GS_GUNZIP_WHOLE_MAX", "0")
     monkeypatch.setenv("GS_GUNZIP_SLOTS", slots)
     monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
     for level in (1, 6):
@@ -297,6 +301,36 @@ def test_single_member_gzip_in_many_batches(monkeypatch, slots):
         got, info = ga.gunzip_device(_gz(text, level), len(text))
         assert got.tobytes() == text
         assert info[2] > 5, info  # batches
+
+
+def test_a_decoder_given_up_half_way_is_used_again(monkeypatch):
+    """gs_gunzipper_park stops the upload thread of a stream that is not read to its end; the object then takes the next stream"""
+    import ctypes
+    from genestrip_amd import binding
+    lib = binding.lib()
+    monkeypatch.setenv("GS_GUNZIP_SLOTS", "4")
+    monkeypatch.setenv("GS_GUNZIP_CHUNK", "4096")
+    a, b = _fastq_like(20000, 71), _fastq_like(5000, 72)
+    za, zb = _gz(a, 1), _gz(b, 6)
+    buf_a, buf_b = ctypes.create_string_buffer(za, len(za)), ctypes.create_string_buffer(zb, len(zb))
+    g = ctypes.c_void_p()
+    assert lib.gs_gunzipper_open(ctypes.byref(g), 0, buf_a, len(za)) == 0
+    d, n, last = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int()
+    assert lib.gs_gunzipper_next(g, 0, ctypes.byref(d), ctypes.byref(n), ctypes.byref(last)) == 0 and last.value == 0  # (one batch of many)
+    assert lib.gs_gunzipper_park(g) == 0
+    del buf_a  # (the first stream's bytes are gone)
+    assert lib.gs_gunzipper_reopen(g, buf_b, len(zb)) == 0
+    got = bytearray()
+    keep = 0
+    while True:
+        assert lib.gs_gunzipper_next(g, 0, ctypes.byref(d), ctypes.byref(n), ctypes.byref(last)) == 0
+        out = ctypes.create_string_buffer(max(1, n.value))
+        assert lib.gs_device_fetch(0, d, out, n.value) == 0
+        got += out.raw[:n.value]
+        if last.value:
+            break
+    assert bytes(got) == b
+    assert lib.gs_gunzipper_close(g) == 0
 
 
 def test_single_member_gzip_with_more_blocks_than_wave_slots(monkeypatch):
