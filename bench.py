@@ -915,7 +915,31 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
         m.reset()
         m.submit(seq, off, 0)
         want, _ = m.finish()
+        # a .gz of several batches at their natural size (the decoder takes up to 320 MiB of compressed data per batch): 12 M reads
+        n_big = 12_000_000
+        seq_b, off_b = synth.reads_host(db.genomes, n_big, read_len=READ_LEN)
+        m.reset()
+        m.submit(seq_b, off_b, 0)
+        want_b, _ = m.finish()
         m.close()  # (one unique-counting run per store: gs_host_match_files begins its own)
+        t0 = time.perf_counter()
+        plain_b = os.path.join(tmp, "reads_big.fastq")
+        _fastq_text(seq_b, n_big).tofile(plain_b)
+        del seq_b, off_b
+        gz_b = plain_b + ".gz"
+        _write_gz(plain_b, gz_b, False, cores)
+        os.remove(plain_b)
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            table, _, tot = host.match_files(store, [gz_b])[:3]
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        res["gz_large"] = {"reads": n_big, "file_bytes": os.path.getsize(gz_b), "seconds": round(best, 3), "gbps": round(n_big * READ_LEN / best / 1e9, 2),
+                           "table_equals_resident_run": bool(np.array_equal(table, want_b)), "reads_seen": int(tot.reads),
+                           "input_written_s": round(time.perf_counter() - t0 - 2 * best, 1),
+                           "note": "three batches; the compressed bytes are uploaded whole by the decoder's own thread while the batches are decoded"}
+        os.remove(gz_b)
         for label, path in (("plain", plain), ("gz", gz), ("bgzf", bz)):
             best, table = None, None
             for _ in range(3):  # (best of three: the files were written a moment ago, and their write-back now and then stalls a reader)

@@ -1050,6 +1050,16 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t s_q1[GI_WAVES][256];  // sieve 1's survivors (a ring; bit offsets from the chunk's first bit)
     __shared__ uint32_t s_q2[GI_WAVES][128];  // sieve 2's survivors
     __shared__ uint8_t s_sorted[GI_WAVES][64 * 20];
+    __shared__ uint8_t s_kraft[4096];  // four code lengths of 3 bits -> their Kraft sum in 1 / 128 (255: more than one)
+    for (uint32_t i = threadIdx.x; i < 4096u; i += 64 * GI_WAVES) {
+        uint32_t sum = 0;
+        for (uint32_t f = 0; f < 4; f++) {
+            const uint32_t len = (i >> (3 * f)) & 7u;
+            sum += len ? (128u >> len) : 0u;
+        }
+        s_kraft[i] = (uint8_t)(sum < 255u ? sum : 255u);
+    }
+    __syncthreads();
     const int lane = gi_lane();
     const int wib = (int)gi_uni(threadIdx.x >> 6);
     GiWave &w = s_w[wib];
@@ -1126,14 +1136,12 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 const uint32_t sh2 = (uint32_t)o & 31u;
                 const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh2), w1 = __builtin_amdgcn_alignbit(d2, d1, sh2), w2 = __builtin_amdgcn_alignbit(d3, d2, sh2);
                 const uint32_t hclen = ((w0 >> 13) & 15u) + 4u;
-                const u64 a = ((u64)w1 << 32 | w0) >> 17;   // 47 bits: 15 lengths
-                const u64 c = ((u64)w2 << 32 | w1) >> 30;   // from bit 62: lengths 15 .. 18
-                uint32_t kraft = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < 19; i++) {
-                    const uint32_t len = i < 15 ? (uint32_t)(a >> (3 * i)) & 7u : (uint32_t)(c >> (3 * (i - 15))) & 7u;
-                    kraft += (i < hclen && len != 0) ? (128u >> len) : 0u;
-                }
+                const uint32_t na = hclen < 15u ? hclen : 15u, nc = hclen - na;  // the first 15 lengths, and lengths 15 .. 18
+                const u64 a = (((u64)w1 << 32 | w0) >> 17) & ((1ULL << (3u * na)) - 1ULL);
+                const uint32_t c = (uint32_t)(((u64)w2 << 32 | w1) >> 30) & ((1u << (3u * nc)) - 1u);
+                // (the sum by table, four lengths at a time: 19 x shift / mask / compare / select were most of this sieve)
+                const uint32_t kraft = (uint32_t)s_kraft[(uint32_t)a & 0xfffu] + s_kraft[(uint32_t)(a >> 12) & 0xfffu] + s_kraft[(uint32_t)(a >> 24) & 0xfffu] +
+                                       s_kraft[(uint32_t)(a >> 36)] + s_kraft[c];
                 const bool ok = act && kraft == 128u;
                 const u64 m = __ballot(ok);
                 if (ok) q2[n2 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = rel;
