@@ -930,14 +930,14 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
         _write_gz(plain_b, gz_b, False, cores)
         os.remove(plain_b)
         best = None
-        for _ in range(2):
+        for _ in range(3):
             t1 = time.perf_counter()
             table, _, tot = host.match_files(store, [gz_b])[:3]
             dt = time.perf_counter() - t1
             best = dt if best is None else min(best, dt)
         res["gz_large"] = {"reads": n_big, "file_bytes": os.path.getsize(gz_b), "seconds": round(best, 3), "gbps": round(n_big * READ_LEN / best / 1e9, 2),
                            "table_equals_resident_run": bool(np.array_equal(table, want_b)), "reads_seen": int(tot.reads),
-                           "input_written_s": round(time.perf_counter() - t0 - 2 * best, 1),
+                           "input_written_s": round(time.perf_counter() - t0 - 3 * best, 1),
                            "note": "three batches; the compressed bytes are uploaded whole by the decoder's own thread while the batches are decoded"}
         os.remove(gz_b)
         for label, path in (("plain", plain), ("gz", gz), ("bgzf", bz)):
