@@ -10,7 +10,7 @@ import sys
 
 def main():
     path = sys.argv[1]
-    pats = [re.compile(p) for p in sys.argv[2:]] or [re.compile(r"gs_match|gs_filter|gi_inflate")]
+    pats = [re.compile(p) for p in sys.argv[2:]] or [re.compile(r"gs_match|gs_filter|gi_inflate|gi_segment|gi_find|gi_resolve|gi_crc")]
     dur = {}
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
