@@ -41,7 +41,7 @@ ABI_SYMBOLS = (
     "gs_filter_submit_fasta", "gs_filter_submit_fastq_ml", "gs_filter_text_read_bounds", "gs_filter_text_line_classes",
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
     "gs_calibrate",
-    "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
+    "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_first_span", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
 )
 
 
@@ -167,6 +167,7 @@ def lib():
         "gs_gunzipper_reopen": (ci, [vp, vp, i64]),
         "gs_gunzipper_next": (ci, [vp, i64, vp, vp, vp]),
         "gs_gunzipper_info": (ci, [vp, vp]),
+        "gs_gunzipper_first_span": (ci, [vp, i64]),
         "gs_gunzipper_park": (ci, [vp]),
         "gs_gunzipper_close": (ci, [vp]),
         "gs_gunzip_plan_device": (ci, [ci, vp, i64, vp, vp, vp]),

@@ -662,6 +662,12 @@ struct GunzipperPool {
         gs_gunzipper_close(g);
     }
 };
+// compressed bytes of a stream's first batch when writers wait for its text (GS_HOST_GUNZIP_FIRST; 0: a full batch)
+inline int64_t gunzip_first_span() {
+    if (const char *e = getenv("GS_HOST_GUNZIP_FIRST")) return std::max<int64_t>(0, atoll(e));
+    return (int64_t)64 << 20;
+}
+
 inline GunzipperPool &gunzipper_pool() {
     static GunzipperPool *p = new GunzipperPool();  // (never destroyed, as the inflaters)
     return *p;
@@ -815,6 +821,8 @@ struct TextJob {
                 static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
                 const double tg = now_s();
                 int grc = gunzipper_pool().open(&gzr_, device, tr.map, (int64_t)tr.map_len);
+                // (writers behind this job: a small first batch, so that they start after 10 ms and not after the 27 a full batch takes)
+                if (grc == GS_OK && (c.filtered.active() || c.kraken.active())) grc = gs_gunzipper_first_span(gzr_, gunzip_first_span());
                 if (grc == GS_OK) grc = gs_gunzipper_next(gzr_, 0, &gz_text_, &gz_n_, &gz_last_);  // (the first batch now: a stream this path does not take shows here)
                 if (trace) fprintf(stderr, "gunzip on the device: rc %d, first batch %lld bytes of text, %.2f ms%s%s\n", grc, (long long)gz_n_, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
                 if (grc == GS_OK) {
@@ -1863,7 +1871,8 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         members.clear();
         bool want = true;
         if (const char *e = getenv("GS_DEVICE_GUNZIP")) want = atoi(e) != 0;
-        if (!want || gunzipper_pool().open(&gzr, device, tr.map, (int64_t)tr.map_len) != GS_OK || gs_gunzipper_next(gzr, 0, &gz_text, &gz_n, &gz_last) != GS_OK) {
+        if (!want || gunzipper_pool().open(&gzr, device, tr.map, (int64_t)tr.map_len) != GS_OK || gs_gunzipper_first_span(gzr, gunzip_first_span()) != GS_OK ||
+            gs_gunzipper_next(gzr, 0, &gz_text, &gz_n, &gz_last) != GS_OK) {
             gunzipper_pool().put(device, gzr);
             tr.close();
             return GS_OK;  // (a stream this path does not take, a damaged one: the host decoders take it -- and report it)

@@ -1939,6 +1939,7 @@ struct gs_gunzipper {
     uint32_t chunk = 65536, ratio = 16;
     uint32_t fchunk = 8192;   // the finder's unit of work (GS_GUNZIP_FIND_CHUNK)
     double block_bytes = 0;   // compressed bytes per deflate block, as the batch before found them (0: not known yet)
+    int64_t first_span = 0;   // > 0: the first batch takes at most this many compressed bytes (gs_gunzipper_first_span)
     // A stream of up to GS_GUNZIP_WHOLE_MAX bytes (16 GiB) is uploaded WHOLE, by a thread of its own, while the batches are decoded: only
     // the first batch waits for its bytes, and nothing is uploaded twice.  (Larger streams: every batch uploads its own span, d_in.)
     bool whole = false;
@@ -1983,6 +1984,14 @@ static int gu_grow(T **p, size_t *cap, size_t need, size_t slack_pct = 12) {
 static int64_t gu_slots(int n_cu) {  // chunks per batch: the device's wave slots (GS_GUNZIP_SLOTS: tests force many small batches)
     if (const char *e = getenv("GS_GUNZIP_SLOTS")) return std::max(1, std::min(1 << 20, atoi(e)));
     return (int64_t)n_cu * GI_WAVES * gi_seg_wgs_per_cu();
+}
+
+// A caller with writers behind it wants the first text early, not the most text per batch: the FIRST batch of the stream then takes at
+// most `bytes` of compressed data (0: as much as a batch holds).  Call between open / reopen and the first gs_gunzipper_next.
+extern "C" int gs_gunzipper_first_span(gs_gunzipper *g, int64_t bytes) {
+    if (!g || bytes < 0) return gi_fail(GS_E_INVALID, "bad argument");
+    g->first_span = bytes;
+    return GS_OK;
 }
 
 // the caller is through with the file (or gives up on it): the upload thread is stopped -- `gz` may go away; the buffers stay
@@ -2125,6 +2134,7 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     g->total = 0;
     g->n_batches = g->n_segments = g->n_mirages = g->n_chunks = 0;
     g->block_bytes = 0;
+    g->first_span = 0;
     g->n_members = 1;
     g->last_n_text = 0;
     g->text_only = 1;
@@ -2180,6 +2190,7 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
     const u64 rel0 = g->bit - base * 8u;
     const int64_t remain = g->in_len - (int64_t)base;
     int64_t nb_chunks = std::min<int64_t>(slots, (remain + g->chunk - 1) / g->chunk);
+    if (g->n_batches == 0 && g->first_span > 0) nb_chunks = std::min<int64_t>(nb_chunks, std::max<int64_t>(1, g->first_span / g->chunk));
     if (g->block_bytes > 0 && (remain + g->chunk - 1) / g->chunk > slots) {  // (what is left fits one batch: all of it, m = ceil below)
         // as many bytes as hold a whole number of blocks per wave slot (and 3 % more: blocks differ a little): what lies behind the
         // batch's last segment is uploaded and searched again by the next batch

@@ -520,6 +520,7 @@ int gs_gunzipper_open(gs_gunzipper **out, int device, const uint8_t *gz, int64_t
 int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n); /* the same object and its device buffers on another file */
 int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8_t **d_text, int64_t *n_text, int *last);
 int gs_gunzipper_info(const gs_gunzipper *g, int64_t info[4]);
+int gs_gunzipper_first_span(gs_gunzipper *g, int64_t bytes); /* the first batch takes at most `bytes` of compressed data: first text early (callers with writers) */
 int gs_gunzipper_park(gs_gunzipper *g); /* the caller is through with the file: the upload thread is stopped (`gz` may go away), the buffers stay */
 int gs_gunzipper_close(gs_gunzipper *g);
 int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, uint8_t **d_text, int64_t *n_text, int64_t info[4]);

@@ -333,6 +333,32 @@ def test_a_decoder_given_up_half_way_is_used_again(monkeypatch):
     assert lib.gs_gunzipper_close(g) == 0
 
 
+def test_a_small_first_batch_for_callers_with_writers():
+    """gs_gunzipper_first_span: the first batch takes at most that many compressed bytes (first text early), the rest as usual"""
+    import ctypes
+    from genestrip_amd import binding
+    lib = binding.lib()
+    text = _fastq_like(20000, 81)
+    z = _gz(text, 6)
+    buf = ctypes.create_string_buffer(z, len(z))
+    g = ctypes.c_void_p()
+    assert lib.gs_gunzipper_open(ctypes.byref(g), 0, buf, len(z)) == 0
+    assert lib.gs_gunzipper_first_span(g, 65536) == 0
+    d, n, last = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int()
+    got, sizes = bytearray(), []
+    while True:
+        assert lib.gs_gunzipper_next(g, 0, ctypes.byref(d), ctypes.byref(n), ctypes.byref(last)) == 0
+        out = ctypes.create_string_buffer(max(1, n.value))
+        assert lib.gs_device_fetch(0, d, out, n.value) == 0
+        got += out.raw[:n.value]
+        sizes.append(n.value)
+        if last.value:
+            break
+    assert bytes(got) == text
+    assert len(sizes) == 2 and sizes[0] < sizes[1] and sizes[0] < 16 * 65536, sizes
+    assert lib.gs_gunzipper_close(g) == 0
+
+
 def test_single_member_gzip_with_more_blocks_than_wave_slots(monkeypatch):
     """every block start is found; with more blocks than wave slots a segment takes floor(blocks / slots) of them and the blocks left
     over wait for the next batch"""

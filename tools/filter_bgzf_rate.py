@@ -19,9 +19,13 @@ try:
     bz = os.path.join(tmp, "r.bgzf.fastq.gz")
     bench._write_gz(plain, bz, True, 16)
     outp = os.path.join(tmp, "acc.fastq")
-    for label, path, env in (("plain input", plain, "1"), ("bgzf, device inflate", bz, "1"), ("bgzf, host decoders", bz, "0")):
+    gz = os.path.join(tmp, "r.fastq.gz")
+    bench._write_gz(plain, gz, False, 16)
+    for label, path, env in (("plain input", plain, "1"), ("bgzf, device inflate", bz, "1"), ("bgzf, host decoders", bz, "0"), ("one .gz stream, device inflate", gz, "1")):
         os.environ["GS_DEVICE_INFLATE"] = env
         for rep in range(3):
+            if os.path.exists(outp):
+                os.remove(outp)  # (truncating 0.6 GB of page cache is not part of the pipeline)
             t0 = time.perf_counter()
             tot = host.filter_files(bloom, 31, [path], 1, 0.2, filtered_path=outp)
             dt = time.perf_counter() - t0
