@@ -1,4 +1,5 @@
-// gs_inflate_dev.hip -- DEFLATE on the device for block-gzip input (BGZF: bgzip / htslib, and this library's own .gz outputs).
+// gs_inflate_dev.hip -- DEFLATE on the device: block-gzip input (BGZF: bgzip / htslib, and this library's own .gz outputs), and -- in the
+// second half of the file -- single-member gzip streams (gzip, pigz) taken apart into segments.
 //
 // The reference reads every .fastq.gz through java.util.zip.GZIPInputStream (B/io/StreamProvider.java:92-100): one thread, ~0.2 GB/s
 // of text.  A BGZF file is a chain of gzip members of at most 64 KiB of text that state their compressed size (the 'BC' extra
@@ -11,10 +12,11 @@
 // decodes the complete token -- literal, or length + extra bits + distance + extra bits, two table reads each from LDS -- that
 // WOULD start l bits behind the reader; a short scalar walk (offset += token bits, one v_readlane per token) then picks the
 // lanes that really are token starts, a prefix sum over their output lengths gives every token its place in the text, and
-//   * the literals of the group leave in one store,
+//   * the literals of the group go to their places,
 //   * the short matches whose source lies in front of the group are copied side by side, one lane per match,
 //   * the remaining matches (runs, overlapping or long ones) are copied in order by all lanes at once,
-//     out[p + i] = out[p - dist + i % dist].
+//     out[p + i] = out[p - dist + i % dist]
+// -- all of it inside the LDS ring (below) when the group is small, which is then stored to the text in whole lines.
 // The first version decoded one symbol per walk of the scalar unit: 19 scalar instructions per byte of text, the CU's one scalar
 // issue port 80 % busy (rocprofv3 --pmc) -- the port, not memory, was the limit.  Here the per-token work is vector work.
 // A block whose code does not fit the tables takes the one-symbol-at-a-time loop with the canonical decoder (gi_slow).
@@ -910,14 +912,14 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
 // A single-member gzip stream (gzip, pigz: what every sequencer pipeline writes) on the device.  Its deflate blocks follow each other
 // at arbitrary BIT positions and every match may reach 32 KiB back, so the stream is taken apart the way pugz / rapidgzip do it on
 // CPU threads:
-//   1. gi_find_kernel: one wave per 64 KiB of the compressed stream looks for the first bit offset at which a non-final DYNAMIC
-//      block starts -- 64 offsets at a time through the cheap tests (type bits, code counts, a complete code-length code: one offset
-//      in ~2 000 passes), the survivors through the whole header (gi_dynamic_header: both codes must be complete);
-//   2. gi_segment_kernel: one wave per SEGMENT (from one found block to the next) decodes to 16-bit symbols; what a match takes from in
-//      front of the segment is a marker 0x8000 | window position; a segment must END exactly where the next one starts (else the
-//      finder was fooled: the whole stream goes back to the host decoders);
-//   3. gi_windows_kernel: the last 32 KiB of every segment, markers replaced through the window of the segment before -- the one
-//      sequential step, one workgroup walking the segments;
+//   1. gi_find_kernel: one wave per 8 KiB of the compressed stream finds EVERY bit offset at which a non-final DYNAMIC block starts
+//      (and the final one at the stream's end), through three sieves of falling width and rising cost (see the kernel); it runs behind
+//      the upload of the compressed bytes, launch by launch;
+//   2. gi_segment_kernel: one wave per SEGMENT -- a whole number of blocks, one round of segments per batch -- decodes to 16-bit
+//      symbols; what a match takes from in front of the segment is a marker 0x8000 | window position; a segment must END exactly where
+//      the next one starts (else that start was a mirage: the segment is decoded again up to the start after it);
+//   3. gi_window_prep / gi_win_compose / gi_win_groups / gi_win_apply: the last 32 KiB of every segment, markers replaced through the
+//      window of the segment before -- the one sequential dependence, walked in two levels because window maps compose;
 //   4. gi_resolve_kernel: every segment's symbols to bytes (markers through the window in front of it), at its place in the text;
 //   5. the CRC-32 of the text per 64 KiB tile (gi_crc_kernel), combined on the host, against the member's trailer.
 // =====================================================================================================================
@@ -1042,7 +1044,7 @@ __device__ bool gi_header_plausible(const uint8_t *in, uint32_t in_len, u64 o, u
 // (The first version: sieves 1 + 2 in one step for every offset, from memory, and gi_dynamic_header for each of the ~40 survivors
 // per chunk, up to the chunk's first block start only: 5.9 ms for 4 096 chunks of 58 KB.  This one reads the whole stream.)
 #define GI_FIND_MAX 16
-#define GI_FIND_LAUNCHES 64  // finder launches per batch (one behind every uploaded piece; the last ones share a counter-less tail)
+#define GI_FIND_LAUNCHES 64  // finder launches per batch at most (each has a work counter of its own; what is left when they are used up goes into the last one)
 __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
                                                                                                         int64_t first, int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk,
                                                                                                         int text_only, int64_t n_real, int64_t fin_first) {
