@@ -40,6 +40,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -2165,7 +2166,11 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     if (g->whole) {
         GI_TRY(hipMemset(g->d_all + g->in_len, 0, 1024));
         GI_TRY(hipDeviceSynchronize());
-        gu_start_upload(g);
+        try {
+            gu_start_upload(g);
+        } catch (const std::system_error &) {  // no thread to be had: every batch uploads its own span
+            g->whole = false;
+        }
     }
     return GS_OK;
 }
