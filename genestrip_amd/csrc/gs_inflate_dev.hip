@@ -2028,6 +2028,7 @@ static void gu_start_upload(gs_gunzipper *g) {
             }
             g->up_cv.notify_all();
         };
+        try {
         if (!rc)
             rc = gi_h2d_staged(g->d_all, g->gz + g->hdr, (size_t)g->in_len, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
                 if (prev) {  // the piece before this one has arrived when its event has (this one is on its way)
@@ -2039,6 +2040,9 @@ static void gu_start_upload(gs_gunzipper *g) {
                 std::lock_guard<std::mutex> l(g->up_m);
                 return g->up_cancel ? GS_E_STATE : GS_OK;
             });
+        } catch (...) {  // (the copy helpers' threads, memory: the batches then fail with this code)
+            rc = GS_E_NOMEM;
+        }
         publish(rc ? 0 : g->in_len, rc, true);
     });
 }
