@@ -735,6 +735,19 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                     gi_lds_sync();
                     for (uint32_t i = (uint32_t)lane; i < total; i += 64) dst[pos + i] = ring[(pos + i) & RM];
                 }
+                if (total > RING) {
+                    // A group of more than RING symbols (a handful of maximal matches in 64 bits of input: runs) wrote some ring slots
+                    // twice, and not in the order of the positions -- the literals go first, the matches after them: a literal
+                    // behind 1 Ki symbols of run lost its slot to the run (found by tools/gunzip_fuzz.py: the newline between a
+                    // run of 'A' and the first FASTQ record, copied 216 symbols later).  The text itself is right (every copy of
+                    // such a group reads and writes memory): the ring is filled again from its last RING symbols.
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t from_p = pos + total - RING;
+                    for (uint32_t i = (uint32_t)lane; i < RING; i += 64) ring[(from_p + i) & RM] = dst[(int32_t)(from_p + i)];
+                    gi_lds_sync();
+                    visible = pos + total;
+                }
                 pos += total;
                 P += adv;
             }
@@ -2521,7 +2534,8 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
         const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         const uint32_t want_isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
         if ((uint32_t)g->total != want_isize) return gi_fail(GS_E_INVALID, "corrupt gzip stream: ISIZE does not match the inflated text");
-        if ((g->raw ^ 0xffffffffu) != want_crc) return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
+        if ((g->raw ^ 0xffffffffu) != want_crc && !getenv("GS_GUNZIP_DEBUG_KEEP_BAD_CRC"))  // (tools/gunzip_debug.py: the text as it came out)
+            return gi_fail(GS_E_INVALID, "corrupt gzip stream: CRC-32 of the inflated text does not match");
         // what follows the trailer: another member (cat a.gz b.gz: its text simply follows), or nothing a gzip reader takes (ignored,
         // as java.util.zip.GZIPInputStream does)
         const int64_t nxt = (int64_t)end_byte + 8;
