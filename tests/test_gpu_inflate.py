@@ -507,3 +507,24 @@ def test_two_gzip_members_in_one_file(tmp_path, monkeypatch):
         got[dev] = (t, (tot.reads, tot.kmers, tot.bps))
     assert np.array_equal(got["1"][0], got["0"][0]) and got["1"][1] == got["0"][1] and got["1"][1][0] == 9000
     store.close()
+
+
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("mode", ["", "bgzf"])
+def test_randomised_streams_equal_zlib(mode):
+    """a short run of tools/gunzip_fuzz.py (texts of several kinds, every level / strategy, flushes, several members, the decoder's
+    geometry drawn at random): zlib's text, or a refusal to the host decoders -- never other text"""
+    assert _tool("gunzip_fuzz").main(40 if mode == "" else 20, 11, mode) == 0
+
+
+def test_randomised_compressed_files_equal_the_plain_file():
+    """a short run of tools/host_gz_fuzz.py: FASTQ of random shape as one gzip member / several / BGZF through `match` (with and
+    without per-read lines) and `filter` with writeback, random batch / slice / chunk sizes, against the plain file"""
+    assert _tool("host_gz_fuzz").main(4, 5) == 0

@@ -65,9 +65,8 @@ def bgzf(rng, data):
     return bytes(out + b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0\x1b\0\x03\0\0\0\0\0\0\0\0\0")
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+def main(cases=30, seed=1):
+    rng = np.random.default_rng(seed)
     db = synth.SynthDB()
     store = ga.DeviceKMerStore(31, db.kmers, db.value_idx, db.n_values, db.parent_vi)
     bloom, _ = bench._index_filter(ga, synth, torch, torch.device("cuda:0"), db)
@@ -117,9 +116,11 @@ def main():
                 return 1
         if case % 5 == 4:
             print("%d cases" % (case + 1), flush=True)
+    for k in KNOBS:
+        os.environ.pop(k, None)
     print("all %d cases: every compressed variant gives what the plain file gives" % cases)
     return 0
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
