@@ -2179,6 +2179,10 @@ extern "C" int gs_gunzipper_reopen(gs_gunzipper *g, const uint8_t *gz, int64_t n
     int64_t whole_max = (int64_t)16 << 30;
     if (const char *e = getenv("GS_GUNZIP_WHOLE_MAX")) whole_max = atoll(e);
     g->whole = g->in_len <= whole_max;
+    if (g->whole && (size_t)g->in_len + 1024 > g->all_cap) {  // (a buffer that has to grow: at most a quarter of what is free -- the batches need room too)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (size_t)g->in_len > free_b / 4) g->whole = false;
+    }
     if (g->whole && gu_grow(&g->d_all, &g->all_cap, (size_t)g->in_len + 1024) != GS_OK) g->whole = false;  // (no room: batch by batch)
     if (g->whole) {
         GI_TRY(hipMemset(g->d_all + g->in_len, 0, 1024));
