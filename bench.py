@@ -333,12 +333,50 @@ def _free_port():
     return p
 
 
+def _visible_gpus():
+    """GPUs this process's children would see, counted WITHOUT loading or initialising the HIP runtime: the KFD topology nodes that
+    have SIMDs and whose render node exists in /dev/dri, cut down by the *_VISIBLE_DEVICES lists.  -1: cannot tell (the ranks decide).
+    (torch.cuda.device_count() only stays clear of hipInit when amdsmi initialises -- here it does not, error 34 -- and importing
+    torch maps libamdhip64 into the process that is about to fork + exec the launcher.)"""
+    topo = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.exists("/dev/kfd"):
+        return 0
+    try:
+        nodes = sorted(os.listdir(topo))
+    except OSError:
+        return -1
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(topo, node, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            return -1
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1"))
+        if minor >= 0 and not os.path.exists("/dev/dri/renderD%d" % minor):
+            continue  # (not handed to this container)
+        n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def _self_launch(args):
-    """--gpus N without a launcher: start the N ranks (fresh processes), before this process touches the GPU"""
-    import torch
+    """--gpus N without a launcher: start the N ranks (fresh processes).  This process never imports torch and never touches the HIP
+    runtime: a fork + exec out of a process that has initialised the GPU is what must not happen (GS_BENCH_LAUNCH_HOOK=<file>: the
+    parent records what it sees and whether libamdhip64 is mapped, for tests/test_distributed_cpu.py)."""
     rehearsal = os.environ.get("GS_BENCH_BACKEND", "nccl") == "gloo"
-    ndev = torch.cuda.device_count()  # (does not initialise the runtime)
-    if ndev < args.gpus and not rehearsal:
+    ndev = _visible_gpus()
+    hook = os.environ.get("GS_BENCH_LAUNCH_HOOK")
+    if hook:
+        with open("/proc/self/maps") as f:
+            maps = f.read()
+        with open(hook, "w") as f:
+            json.dump({"visible": ndev, "hip_mapped": "libamdhip64" in maps, "torch_imported": "torch" in sys.modules}, f)
+    if 0 <= ndev < args.gpus and not rehearsal:
         sys.stderr.write("bench.py --gpus %d: only %d device(s) visible -- refusing to print a line for fewer GPUs than asked for "
                          "(GS_BENCH_BACKEND=gloo rehearses the multi-rank flow on one GPU)\n" % (args.gpus, ndev))
         sys.exit(3)
@@ -421,7 +459,8 @@ def main():
     if rehearsal:
         local_rank = 0
     elif torch.cuda.device_count() < world:
-        raise SystemExit("bench.py: %d ranks but %d devices" % (world, torch.cuda.device_count()))
+        sys.stderr.write("bench.py: %d ranks but only %d device(s) visible\n" % (world, torch.cuda.device_count()))
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearsal else dev  # where the small control tensors of the collectives live
@@ -598,6 +637,15 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         out["parity"] = {"merged_table_identical_on_all_ranks": bool(lo.item() == hi.item())}
+        # what the collective library itself saw: one contribution per rank summed by an all-reduce on the data-path backend, and the
+        # distinct devices behind the ranks (a SCALE record with N copies of one GPU would show here)
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        devs = [None] * world
+        prop = torch.cuda.get_device_properties(local_rank)
+        dist.all_gather_object(devs, "%s:%s" % (socket.gethostname(), getattr(prop, "uuid", None) or getattr(prop, "pci_bus_id", local_rank)))
+        out["rccl_ranks_seen"] = {"backend": backend, "torch_world_size": dist.get_world_size(), "all_reduce_sum_of_ones": int(ones.item()),
+                                  "distinct_devices": len(set(devs))}
     if rank == 0:
         from oracle import gs_oracle as orc
         cores = _usable_cores()
@@ -836,16 +884,18 @@ def _deflate_piece(job):
 
 
 def _write_gz(plain, out, bgzf, procs):
-    """compress `plain` on a process pool: ONE gzip member made of independently deflated 8 MiB pieces joined by full flushes
+    """compress `plain` on a thread pool: ONE gzip member made of independently deflated 8 MiB pieces joined by full flushes
     (what pigz writes), or BGZF blocks"""
-    import multiprocessing as mp
+    from concurrent.futures import ThreadPoolExecutor
     import struct
-    import zlib
     size = os.path.getsize(plain)
     piece = 8 << 20
     jobs = [(plain, a, min(piece, size - a), a + piece >= size, bgzf) for a in range(0, size, piece)]
-    with mp.get_context("fork").Pool(procs) as pool:
-        parts = pool.map(_deflate_piece, jobs)
+    # THREADS, not processes: this runs after the GPU has been initialised, and a process that holds the HIP runtime must not fork
+    # (round 3's profiled runs showed the forked workers die with SIGSEGV inside the profiler's inherited signal handler when the
+    # pool was torn down).  zlib releases the interpreter lock while it compresses, so the threads run side by side.
+    with ThreadPoolExecutor(max_workers=max(1, procs)) as pool:
+        parts = list(pool.map(_deflate_piece, jobs))
     with open(out, "wb") as f:
         if bgzf:
             for body, _, _ in parts:

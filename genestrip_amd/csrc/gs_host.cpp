@@ -754,7 +754,7 @@ struct TextJob {
     gs_gunzipper *gzr_ = nullptr;
     const uint8_t *gz_text_ = nullptr;  // the current batch (gs_gunzipper_next)
     int64_t gz_n_ = 0, gz_off_ = 0, gz_ticket_ = -1;
-    int gz_last_ = 0;                   // 1: the member is through, 2: and more data follows it (the host decoders take the rest)
+    int gz_last_ = 0;                   // 1: the file is through (members behind one another are decoded on the device, each with its own CRC-32 / ISIZE)
 
     TextJob(MatchCtx &ctx, const std::string &p, int bank_, int64_t first_read_no, bool fasta_ = false)
         : c(ctx), path(p), bank(bank_), read_no(first_read_no), fasta(fasta_) {}
@@ -763,17 +763,23 @@ struct TextJob {
     void abort() {
         drain();
         release_held();
+        release_gunzipper();  // (before the file is unmapped: its upload thread reads the mapping)
         tr.close();
         if (inf_) {
             inflater_pool().put(inf_device_, inf_);
             inf_ = nullptr;
         }
-        if (gzr_) {
-            gs_match_sync(c.run);  // (the record scan may still be copying out of its text)
-            gunzipper_pool().put(inf_device_, gzr_);
-            gzr_ = nullptr;
-            gz_text_ = nullptr;
-        }
+    }
+    // The device gunzipper goes back to its pool -- which parks its upload thread -- BEFORE tr.close() unmaps the file the thread
+    // is copying from (a stream of up to 16 GiB is uploaded whole while the batches run; finish() is reached mid-stream by every
+    // refusal or fallback).  Its device text stays valid until the object is reopened.
+    void release_gunzipper() {
+        if (!gzr_) return;
+        gs_match_sync(c.run);  // (the record scan may still be copying out of its text)
+        gunzipper_pool().put(inf_device_, gzr_);
+        gzr_ = nullptr;
+        gz_text_ = nullptr;
+        gz_n_ = gz_off_ = 0;
     }
 
     bool list_bgzf_members() { return bgzf_member_list(tr.map, tr.map_len, members_); }
@@ -922,10 +928,6 @@ struct TextJob {
             fallback_reads = reads_in_file;
         }
         if (!err && fallback_off < 0) gz_off_ += n_bytes;
-        if (!err && fallback_off < 0 && last && gz_last_ == 2) {  // another member follows: the host decoders, from behind the last whole record
-            fallback_off = carry_file_off;
-            fallback_reads = reads_in_file;
-        }
         const double ts2 = now_s();
         if (err || last || fallback_off >= 0) {
             if (!err && fallback_off < 0 && gz_off_ < gz_n_) {  // what is left behind the last whole record
@@ -1421,6 +1423,7 @@ private:
         drain();
         const int held_err = release_held();  // (the blocks return to the pool in close(): no copy may still read them)
         if (!err) err = held_err;
+        release_gunzipper();  // (parks the upload thread: it reads the mapping that close() removes)
         tr.close();
         c.t_parse += now_s() - t0;
         if (err) return err;
@@ -1929,7 +1932,7 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
             last = gz_last != 0 && std::min(rest, text_target) == rest;
             text = gz_text + gz_off;
             tail = last ? rest - n_bytes : (n_lines > 0 ? 0 : ((int64_t)1 << 40));  // (no record in a full slice: the general parser, below)
-            if (refused || (last && gz_last == 2 && n_lines == 0)) {  // the host decoders from here: a batch the device path does not take, or another member
+            if (refused) {  // the host decoders from here: a batch the device path does not take
                 fallback_off = text_off;
                 break;
             }
@@ -1990,11 +1993,6 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
         if (last) {  // what is left behind the last whole record
             int64_t n = 0;
             carry.resize((size_t)tail);
-            if (whole && gz_last == 2) {  // another member follows: the host decoders, from behind the last whole record
-                carry.clear();
-                fallback_off = text_off;
-                break;
-            }
             if (tail > 0 && (whole ? gs_device_fetch(device, gz_text + gz_off, carry.data(), tail) : gs_inflater_tail(inf, carry.data(), tail, &n)) != GS_OK)
                 err = hfail(GS_E_HIP, gs_inflate_last_error());
             break;
@@ -2349,6 +2347,40 @@ extern "C" int gs_host_filter_files(gs_bloom *bloom, int k, int min_pos_count, d
     return err;
 } catch (const std::bad_alloc &) {
     return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
+
+// The pools above keep page-locked blocks and the device decoders' buffers (a parked gunzipper holds up to a quarter of the free
+// HBM) for the life of the process.  A long-lived host -- a JVM that next loads a big store -- hands them back with this call;
+// nothing may be using the host layer on another thread meanwhile.
+namespace {
+void release_pools_impl() {
+    {
+        PinnedPool &pp = pinned_pool();  // (the big buffers of this file)
+        std::lock_guard<std::mutex> l(pp.m);
+        for (auto &x : pp.idle) gs_pinned_free(x.first);
+        pp.idle.clear();
+    }
+    gs_host::pinned_pool().release_all();  // (the readers' blocks)
+    {
+        InflaterPool &ip = inflater_pool();
+        std::lock_guard<std::mutex> l(ip.m);
+        for (auto &x : ip.idle) gs_inflater_destroy(x.second);
+        ip.idle.clear();
+    }
+    {
+        GunzipperPool &gp = gunzipper_pool();
+        std::lock_guard<std::mutex> l(gp.m);
+        for (auto &x : gp.idle) gs_gunzipper_close(x.second);
+        gp.idle.clear();
+    }
+}
+}  // namespace
+
+extern "C" int gs_host_release_pools(void) try {
+    release_pools_impl();
+    return GS_OK;
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
     return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }

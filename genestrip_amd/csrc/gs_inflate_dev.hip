@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -1555,10 +1556,10 @@ static int gi_force_slow() {  // GS_INFLATE_FORCE_SLOW=1: every Huffman code thr
 }
 
 static int gi_upload_crc_table() {
-    static bool done[64] = {false};
+    static std::atomic<bool> done[64];  // (zero-initialised; two threads may both upload the same table, neither reads a torn flag)
     int dev = 0;
     GI_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && done[dev]) return GS_OK;
+    if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return GS_OK;
     uint32_t t[4 * 256];
     for (uint32_t i = 0; i < 256; i++) {
         uint32_t c = i;
@@ -1568,7 +1569,7 @@ static int gi_upload_crc_table() {
     for (int q = 1; q < 4; q++)  // t[q][i]: the register after byte i and q zero bytes
         for (uint32_t i = 0; i < 256; i++) t[256 * q + i] = (t[256 * (q - 1) + i] >> 8) ^ t[t[256 * (q - 1) + i] & 0xffu];
     GI_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gi_crc_table), t, sizeof(t)));
-    if (dev >= 0 && dev < 64) done[dev] = true;
+    if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     return GS_OK;
 }
 
@@ -1880,19 +1881,40 @@ static bool gi_trace() {  // GS_HOST_TRACE: the host layer's timeline on stderr;
 
 // `after_piece(bytes uploaded so far, the event behind that piece's copy)`: work on other streams that waits for the piece
 static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, const std::function<int(size_t, hipEvent_t)> &after_piece) {
-    struct Staging {  // per device: events belong to the device they were created on, and two devices should not wait for each other
-        std::mutex m;
+    // Two page-locked pieces + their events, taken from a per-device free list for the length of ONE call: a second decoder on the
+    // same device (a filter and a match job, two threads of a JVM) gets a set of its own instead of waiting for a whole stream.
+    struct Staging {
         uint8_t *h[2] = {nullptr, nullptr};
         hipEvent_t done[2] = {nullptr, nullptr};
     };
-    static Staging per_device[64];
+    struct StagingList {
+        std::mutex m;
+        std::vector<Staging *> idle;
+    };
+    static StagingList per_device[64];
     int dev = 0;
     GI_TRY(hipGetDevice(&dev));
-    Staging &st = per_device[(dev >= 0 && dev < 64) ? dev : 0];
-    uint8_t **h = st.h;
-    hipEvent_t *done = st.done;
+    StagingList &sl = per_device[(dev >= 0 && dev < 64) ? dev : 0];
+    Staging *stp = nullptr;
+    {
+        std::lock_guard<std::mutex> l(sl.m);
+        if (!sl.idle.empty()) {
+            stp = sl.idle.back();
+            sl.idle.pop_back();
+        }
+    }
+    if (!stp) stp = new Staging();
+    struct Return {  // (back to the list on every way out; every way out has synchronised the stream first)
+        StagingList &sl;
+        Staging *st;
+        ~Return() {
+            std::lock_guard<std::mutex> l(sl.m);
+            sl.idle.push_back(st);
+        }
+    } give_back{sl, stp};
+    uint8_t **h = stp->h;
+    hipEvent_t *done = stp->done;
     const size_t piece = (size_t)32 << 20;
-    std::lock_guard<std::mutex> l(st.m);
     for (int i = 0; i < 2; i++) {
         if (!h[i]) GI_TRY(hipHostMalloc((void **)&h[i], piece));
         if (!done[i]) GI_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
@@ -1901,7 +1923,10 @@ static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream
     bool used[2] = {false, false};
     for (size_t at = 0; at < n; at += piece, which ^= 1) {
         const size_t len = std::min(piece, n - at);
-        if (used[which]) GI_TRY(hipEventSynchronize(done[which]));
+        if (used[which] && hipEventSynchronize(done[which]) != hipSuccess) {
+            hipStreamSynchronize(stream);
+            return gi_fail(GS_E_HIP, "gi_h2d_staged: waiting for a staging buffer failed");
+        }
         int n_thr = (int)std::min<size_t>(8, std::max<size_t>(1, len >> 22));
         if (const char *e = getenv("GS_INFLATE_COPY_THREADS")) n_thr = std::max(1, std::min(32, atoi(e)));
         std::vector<std::thread> th;
@@ -1912,12 +1937,19 @@ static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream
         }
         memcpy(h[which], src + at, len / (size_t)n_thr);
         for (auto &x : th) x.join();
-        GI_TRY(hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, stream));
-        GI_TRY(hipEventRecord(done[which], stream));
+        hipError_t ce = hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, stream);
+        if (ce == hipSuccess) ce = hipEventRecord(done[which], stream);
+        if (ce != hipSuccess) {
+            hipStreamSynchronize(stream);
+            return gi_fail(ce == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gi_h2d_staged: ") + hipGetErrorString(ce));
+        }
         used[which] = true;
         if (after_piece) {
             const int rc = after_piece(at + len, done[which]);
-            if (rc) return rc;
+            if (rc) {  // (cancelled or failed: the copies under way still read h[], which the next caller fills)
+                hipStreamSynchronize(stream);
+                return rc;
+            }
         }
     }
     GI_TRY(hipStreamSynchronize(stream));
@@ -2584,7 +2616,6 @@ extern "C" int gs_gunzip_plan_device(int device, const uint8_t *gz, int64_t n, u
         int64_t nt = 0;
         int last = 0;
         rc = gs_gunzipper_next(g, 0, &t, &nt, &last);
-        if (!rc && last == 2) rc = gi_fail(GS_E_UNSUPPORTED, "several members in one file: host decoders");
         if (!rc && have + (size_t)nt + 8192 > cap) {
             uint8_t *bigger = nullptr;
             const size_t want = (have + (size_t)nt) * (last ? 1 : 2) + 8192;

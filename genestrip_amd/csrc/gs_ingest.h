@@ -356,6 +356,11 @@ public:
         }
         gs_pinned_free(p);
     }
+    void release_all() {  // gs_host_release_pools
+        std::lock_guard<std::mutex> l(m_);
+        for (auto &x : idle_) gs_pinned_free(x.first);
+        idle_.clear();
+    }
 
 private:
     std::mutex m_;

@@ -50,6 +50,7 @@ def lib():
         "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
         "gs_host_match_files_multi": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
         "gs_host_stat": (C.c_int64, [ci]),
+        "gs_host_release_pools": (ci, []),
         "gs_host_filter_files": (ci, [vp, ci, ci, C.c_double, vp, ci, C.c_char_p, C.c_char_p, ci, vp]),
         "gs_host_write_csv": (ci, [C.c_char_p, vp, vp, vp, vp]),
         "gs_host_last_error": (C.c_char_p, []), "gs_host_java_double": (ci, [C.c_double, vp, ci]),
@@ -118,6 +119,11 @@ class FastqReader:
             self.close()
         except Exception:
             pass
+
+
+def release_pools():
+    """gs_host_release_pools: the page-locked blocks and device decoders the host layer keeps from call to call are freed"""
+    _check(lib().gs_host_release_pools())
 
 
 def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=None, write_all=True, taxids=None,

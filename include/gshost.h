@@ -114,6 +114,10 @@ typedef struct {
 int gs_host_write_csv(const char *path, const gs_host_tax_info *tax, const int64_t *table, const double *dtable,
                       const gs_host_totals *totals);
 
+/* The host layer keeps page-locked blocks and the device decoders of gzip input (gigabytes of HBM) from call to call; this hands
+ * them back (a long-lived JVM host before it loads a big store).  No other thread may be inside the host layer meanwhile. */
+int gs_host_release_pools(void);
+
 /* message of the last failure raised inside the host layer itself (failures of the C ABI: gs_last_error) */
 const char *gs_host_last_error(void);
 

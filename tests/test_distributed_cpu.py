@@ -137,6 +137,24 @@ def test_bench_refuses_more_gpus_than_visible():
     assert "device(s) visible" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
 
 
+def test_bench_parent_never_maps_the_hip_runtime(tmp_path):
+    """the process that starts the ranks of `bench.py --gpus N` must not have initialised the GPU runtime when it
+    forks + execs the launcher.  It does not even import torch: the devices are counted from the KFD topology.  The parent writes
+    what it saw into GS_BENCH_LAUNCH_HOOK just before it decides."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hook = str(tmp_path / "hook.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GS_BENCH_BACKEND")}
+    env["GS_BENCH_LAUNCH_HOOK"] = hook
+    env["ROCR_VISIBLE_DEVICES"] = ""  # (no device for the ranks, wherever this runs: the refusal path)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    seen = json.load(open(hook))
+    assert r.returncode == 3 and seen["visible"] == 0, (r.returncode, seen, r.stderr[-300:])
+    assert seen["hip_mapped"] is False and seen["torch_imported"] is False, seen
+
+
 def test_partitioned_batch_refuses_positions_beyond_the_routing_index():
     """a routed key carries its batch position as 32 bits; a batch with more positions must be refused, not truncated"""
     from genestrip_amd import distributed as gd

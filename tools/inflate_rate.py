@@ -1,7 +1,7 @@
 """rate of the device DEFLATE decoder on BGZF FASTQ (developer tool): python tools/inflate_rate.py [reads] [level]
 wall time of gs_inflate_members (H2D of the compressed bytes + kernel + D2H of the text); run under
 rocprofv3 --kernel-trace --stats for the kernel's own time"""
-import multiprocessing as mp
+from concurrent.futures import ThreadPoolExecutor
 import os
 import struct
 import sys
@@ -29,8 +29,8 @@ if __name__ == "__main__":
     db = synth.SynthDB()
     seq, off = synth.reads_host(db.genomes, n)
     text = bench._fastq_text(seq, n).tobytes()
-    with mp.get_context("fork").Pool(16) as pool:
-        parts = pool.map(_blk, [(text[a:a + 65280], level) for a in range(0, len(text), 65280)], chunksize=64)
+    with ThreadPoolExecutor(16) as pool:  # (threads: zlib releases the interpreter lock; nothing here may fork once HIP is loaded)
+        parts = list(pool.map(_blk, [(text[a:a + 65280], level) for a in range(0, len(text), 65280)], chunksize=64))
     data = b"".join(parts)
     members, reached = ga.bgzf_members(data)
     assert reached == len(data)
