@@ -42,6 +42,8 @@ ABI_SYMBOLS = (
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
     "gs_calibrate",
     "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_first_span", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
+    "gs_filter_compact_text", "gs_match_compact_text", "gs_deflater_create", "gs_deflater_pack", "gs_deflater_info", "gs_deflater_destroy",
+    "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error",
 )
 
 
@@ -179,6 +181,16 @@ def lib():
         "gs_inflater_reset": (ci, [vp]),
         "gs_inflater_destroy": (ci, [vp]),
         "gs_inflate_last_error": (C.c_char_p, []),
+        "gs_filter_compact_text": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+        "gs_match_compact_text": (ci, [vp, ci, ci, vp, vp, vp]),
+        "gs_deflater_create": (ci, [vp, ci]),
+        "gs_deflater_pack": (ci, [vp, vp, i64, vp, i64, vp]),
+        "gs_deflater_info": (ci, [vp, vp]),
+        "gs_deflater_destroy": (ci, [vp]),
+        "gs_deflate_bound": (i64, [i64]),
+        "gs_deflate_host": (ci, [ci, vp, i64, vp, i64, vp]),
+        "gs_deflate_host_reference": (ci, [vp, i64, vp, i64, vp]),
+        "gs_deflate_last_error": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -264,6 +276,75 @@ def gunzip_device(data, expect_bytes, device=0):
     if rc != 0:
         raise GsError(rc, (lib().gs_inflate_last_error() or b"").decode(errors="replace"))
     return out[:n.value], list(info)
+
+
+def _fetch_device(device, p, n):
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    if n:
+        rc = lib().gs_device_fetch(device, p, out.ctypes.data_as(C.c_void_p), n)
+        if rc != 0:
+            raise GsError(rc, (lib().gs_inflate_last_error() or b"").decode(errors="replace"))
+    return out[:n]
+
+
+def _deflate(fn, data, *head):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    cap = int(lib().gs_deflate_bound(len(buf))) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    rc = fn(*head, buf.ctypes.data_as(C.c_void_p) if len(buf) else None, len(buf), out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    if rc != 0:
+        raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
+    return out[:n.value]
+
+
+def deflate_device(data, device=0):
+    """gs_deflate_host: bytes -> BGZF members written on the device (numpy uint8; no end-of-file block)"""
+    return _deflate(lib().gs_deflate_host, data, device)
+
+
+def deflate_reference(data):
+    """gs_deflate_host_reference: the same format from the CPU loop over the same table builder (no device)"""
+    return _deflate(lib().gs_deflate_host_reference, data)
+
+
+class DeviceDeflater:
+    """gs_deflater_*: device text -> BGZF members in a (page-locked) host buffer"""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        self.device = device
+        rc = lib().gs_deflater_create(C.byref(self.h), device)
+        if rc != 0:
+            raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
+
+    def pack(self, d_text, n, out):
+        """d_text: device pointer (int) or tensor with data_ptr(); out: numpy uint8 of at least gs_deflate_bound(n) bytes -> bytes written"""
+        p = C.c_void_p(d_text.data_ptr() if hasattr(d_text, "data_ptr") else int(d_text))
+        _ready(d_text)
+        n_out = C.c_int64(0)
+        rc = lib().gs_deflater_pack(self.h, p, int(n), out.ctypes.data_as(C.c_void_p), int(out.shape[0]), C.byref(n_out))
+        if rc != 0:
+            raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
+        return n_out.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gs_deflater_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def deflate_bound(n):
+    return int(lib().gs_deflate_bound(int(n)))
+
+
+BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
 CAL_VALU_PURE, CAL_VALU_MIX, CAL_SALU, CAL_VALU_SALU = 0, 1, 2, 3
@@ -627,6 +708,14 @@ class FastqKMerMatcher:
                                               None, C.byref(ticket)))
         return max(n_rec.value, 0), used.value
 
+    def compact_text(self, with_probs=False, slot=0):
+        """gs_match_compact_text: the reads of the last four-line chunk that matchRead returned true for, as afterMatch writes them,
+        gathered on the device -> (bytes as numpy uint8, records)"""
+        p, nb, nr, d = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        _check(lib().gs_match_compact_text(self.h, int(with_probs), int(slot), C.byref(p), C.byref(nb), C.byref(nr)))
+        _check(lib().gs_match_get_device(self.h, C.byref(d)))
+        return _fetch_device(d.value, p, nb.value), nr.value
+
     def text_wait_copy(self, ticket):
         _check(lib().gs_match_text_wait_copy(self.h, ticket))
 
@@ -798,6 +887,12 @@ class DeviceBloomFilter:
         _check(lib().gs_bloom_build(C.byref(self.h), device, kind, pk, n, mem, int(expected_insertions or max(n, 1)), float(fpp)))
         return self
 
+    @property
+    def device(self):
+        d = C.c_int(0)
+        _check(lib().gs_filter_get_device(self.h, C.byref(d)))
+        return d.value
+
     def get(self, with_words=True):
         """-> (bits, hash_factors int64[], words uint64[] or None)"""
         bits, nh = C.c_int64(0), C.c_int32(0)
@@ -892,6 +987,13 @@ class FastqBloomFilter:
         tot = (C.c_int64 * 3)()
         _check(lib().gs_filter_text_status(self.bloom.h, C.byref(ft), C.byref(fb), tot))
         return ft.value, fb.value, tuple(tot)
+
+    def compact_text(self, which=1, with_probs=False, slot=0):
+        """gs_filter_compact_text: the accepted (which = 1) / other records of the last four-line chunk as ReadEntry.write writes them,
+        gathered on the device -> (bytes as numpy uint8, records)"""
+        p, nb, nr = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _check(lib().gs_filter_compact_text(self.bloom.h, int(which), int(with_probs), int(slot), C.byref(p), C.byref(nb), C.byref(nr)))
+        return _fetch_device(self.bloom.device, p, nb.value), nr.value
 
     def text_reset(self, clear_totals=False):
         _check(lib().gs_filter_text_reset(self.bloom.h, int(clear_totals)))

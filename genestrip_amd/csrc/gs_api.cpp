@@ -1861,6 +1861,16 @@ struct TextScan {
     int64_t last_reads = 0, last_lines = 0;  // of the most recent chunk (per-read follow-up calls refer to it)
     hipEvent_t copied[8] = {};     // H2D of ticket t has completed: copied[t % 8]
     int64_t tickets = 0;
+    // the writers' gather on the device (gs_*_compact_text, gs_deflate_dev.hip): output buffers [which][slot], per-record lengths,
+    // per-block sums, page-locked totals; d_last_flags = where the last chunk's per-read flags lie on the device
+    uint8_t *d_compact[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    size_t compact_cap[2][2] = {{0, 0}, {0, 0}};
+    uint32_t *d_clen = nullptr;
+    u64 *d_cblocks = nullptr, *h_ctotals = nullptr;
+    size_t clen_cap = 0, cblocks_cap = 0;
+    const uint8_t *d_last_flags = nullptr;
+    int64_t last_bytes = 0;
+    bool last_four_line = false;
 };
 enum { GS_TEXT_BANKS = 16 };
 
@@ -1957,6 +1967,11 @@ static void text_free(TextScan &t) {
     hipFree(t.d_off2);
     hipFree(t.d_status);
     hipFree(t.d_totals);
+    for (auto &w : t.d_compact)
+        for (uint8_t *q : w) hipFree(q);
+    hipFree(t.d_clen);
+    hipFree(t.d_cblocks);
+    if (t.h_ctotals) hipHostFree(t.h_ctotals);
     for (hipEvent_t ev : t.copied)
         if (ev) hipEventDestroy(ev);
     t = TextScan();
@@ -2123,7 +2138,43 @@ static int text_submit(TextScan &t, hipStream_t stream, const uint8_t *text, int
     t.tickets = tk + 1;
     t.last_reads = n_reads;
     t.last_lines = n_lines;
+    t.last_bytes = n_bytes;
+    t.last_four_line = !fasta;
+    t.d_last_flags = nullptr;
     if (ticket) *ticket = tk;
+    return GS_OK;
+}
+
+extern "C" int gs_compact_records_device(hipStream_t stream, const uint8_t *d_text, const uint32_t *d_nl, int64_t n_records, const uint8_t *d_flags, int mask, int want,
+                                         int with_probs, uint8_t *d_out, uint32_t *d_len, u64 *d_blocks, u64 *h_totals);
+extern "C" const char *gs_deflate_last_error(void);
+
+static int text_touched(TextScan &t, hipStream_t stream);
+
+// the records of the last chunk whose flag says so, as ReadEntry.write writes them, into t.d_compact[which][slot]; synchronises
+static int text_compact(TextScan &t, hipStream_t stream, int mask, int want, int which, int slot, int with_probs, const uint8_t **d_out, int64_t *n_bytes,
+                        int64_t *n_records) {
+    if (!d_out || !n_bytes || !n_records) return fail(GS_E_INVALID, "NULL argument");
+    *d_out = nullptr;
+    *n_bytes = *n_records = 0;
+    if (which < 0 || which > 1 || slot < 0 || slot > 1) return fail(GS_E_INVALID, "which and slot must be 0 or 1");
+    if (t.tickets == 0) return fail(GS_E_STATE, "no text chunk has been submitted");
+    if (!t.last_four_line) return fail(GS_E_STATE, "the last chunk was not four-line FASTQ");
+    if (!t.d_last_flags) return fail(GS_E_STATE, "the last chunk was submitted without per-read flags");
+    const int64_t n = t.last_reads;
+    if (n == 0) return GS_OK;
+    int rc;
+    if ((rc = grow(&t.d_compact[which][slot], &t.compact_cap[which][slot], (size_t)t.last_bytes + 64, stream))) return rc;
+    if ((rc = grow(&t.d_clen, &t.clen_cap, (size_t)n, stream))) return rc;
+    if ((rc = grow(&t.d_cblocks, &t.cblocks_cap, 2 * ((size_t)n / 256 + 1) + 2, stream))) return rc;
+    if (!t.h_ctotals) HIP_TRY(hipHostMalloc((void **)&t.h_ctotals, 2 * sizeof(u64)));
+    if (gs_compact_records_device(stream, t.d_text, t.d_nl, n, t.d_last_flags, mask, want, with_probs, t.d_compact[which][slot], t.d_clen, t.d_cblocks, t.h_ctotals) != GS_OK)
+        return fail(GS_E_HIP, std::string("record gather: ") + gs_deflate_last_error());
+    if ((rc = text_touched(t, stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    *d_out = t.d_compact[which][slot];
+    *n_bytes = (int64_t)t.h_ctotals[0];
+    *n_records = (int64_t)t.h_ctotals[1];
     return GS_OK;
 }
 
@@ -2620,11 +2671,19 @@ static int match_submit_text(gs_run *run, const uint8_t *text, int64_t n_bytes, 
                       df, nullptr, nullptr, fasta ? 1 : 2, run->text.d_status + (size_t)run->text.bank * GS_TS_WORDS + GS_TS_SKIP);
     if (rc) return rc;
     if ((rc = text_touched(run->text, run->stream))) return rc;
+    run->text.d_last_flags = df;
     if (!dev_out) {  // complete after gs_match_sync
         if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
     }
     return GS_OK;
+}
+
+// the reads matchRead() returned true for (GS_F_RETURNED), as afterMatch writes them (FastqKMerMatcher.java:304-307)
+extern "C" int gs_match_compact_text(gs_run *run, int with_probs, int slot, const uint8_t **d_out, int64_t *n_bytes, int64_t *n_records) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    HIP_TRY(hipSetDevice(run->db->device));
+    return text_compact(run->text, run->stream, GS_F_RETURNED, 1, 1, slot, with_probs, d_out, n_bytes, n_records);
 }
 
 extern "C" int gs_match_text_wait_copy(gs_run *run, int64_t ticket) {
@@ -3992,6 +4051,7 @@ static int filter_submit_text(gs_bloom *b, int k, int min_pos_count, double posi
                        n_reads, d_acc, fasta ? 1 : 2, b->text.d_status + (size_t)b->text.bank * GS_TS_WORDS + GS_TS_SKIP, profile);
     if (rc) return rc;
     if ((rc = text_touched(b->text, b->stream))) return rc;
+    if (!fasta) b->text.d_last_flags = d_acc;
     const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (!dev_out) HIP_TRY(hipMemcpyAsync(accept, b->d_accept, (size_t)n_reads, kind, b->stream));
     if (newlines) HIP_TRY(hipMemcpyAsync(newlines, b->text.d_nl, sizeof(uint32_t) * (size_t)n_lines, kind, b->stream));
@@ -4021,6 +4081,13 @@ extern "C" int gs_filter_submit_fastq_ml(gs_bloom *b, int k, int min_pos_count, 
     *consumed_bytes = out[1];
     if (consumed_lines) *consumed_lines = out[2];
     return rc;
+}
+
+// nextEntry's rewriteInput on the device (FastqBloomFilter.java:92-105): the accepted (which != 0) or the other records of the last chunk
+extern "C" int gs_filter_compact_text(gs_bloom *b, int which, int with_probs, int slot, const uint8_t **d_out, int64_t *n_bytes, int64_t *n_records) {
+    if (!b) return fail(GS_E_INVALID, "bloom is NULL");
+    HIP_TRY(hipSetDevice(b->device));
+    return text_compact(b->text, b->stream, 0xff, which != 0, which != 0, slot, with_probs, d_out, n_bytes, n_records);
 }
 
 extern "C" int gs_filter_text_read_bounds(gs_bloom *b, uint64_t *bounds) {

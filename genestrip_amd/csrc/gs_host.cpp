@@ -662,6 +662,87 @@ struct GunzipperPool {
         gs_gunzipper_close(g);
     }
 };
+// ... and the device DEFLATE writers of .gz outputs (slots and output buffer of the size of a chunk's text)
+struct DeflaterPool {
+    std::mutex m;
+    std::vector<std::pair<int, gs_deflater *>> idle;
+    gs_deflater *get(int device) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == device) {
+                    gs_deflater *g = idle[i].second;
+                    idle.erase(idle.begin() + (long)i);
+                    return g;
+                }
+        }
+        gs_deflater *g = nullptr;
+        return gs_deflater_create(&g, device) == GS_OK ? g : nullptr;
+    }
+    void put(int device, gs_deflater *g) {
+        if (!g) return;
+        std::lock_guard<std::mutex> l(m);
+        idle.emplace_back(device, g);
+    }
+};
+inline DeflaterPool &deflater_pool() {
+    static DeflaterPool *p = new DeflaterPool();  // (never destroyed, as the inflaters)
+    return *p;
+}
+// GS_DEVICE_OUTPUT=0: the per-read writers format (and zlib compresses) on host threads, as before round 4
+inline bool device_output() {
+    if (const char *e = getenv("GS_DEVICE_OUTPUT")) return atoi(e) != 0;
+    return true;
+}
+
+// The device side of one output file of the filter / match goal: the records the file wants have been gathered on the device
+// (gs_filter_compact_text / gs_match_compact_text); emit() compresses them there when the file is gzip (gs_deflater_pack: BGZF
+// members, what OutFile::pack makes with zlib on host threads) or fetches them as they are, into one of two page-locked buffers,
+// and hands that buffer to the file's writer thread by reference.  Called on the chunk's formatting thread, chunk after chunk.
+struct DeviceWriter {
+    OutFile *out = nullptr;
+    int device = 0;
+    gs_deflater *defl = nullptr;
+    PooledBuf buf[2];
+    std::future<void> written[2];
+    int64_t bytes_text = 0, bytes_file = 0;
+    void begin(OutFile *o, int dev) {
+        out = o;
+        device = dev;
+    }
+    int emit(int set, const uint8_t *d_text, int64_t n_bytes) {
+        if (!out || !out->active() || n_bytes <= 0) return GS_OK;
+        if (written[set].valid()) written[set].get();  // (the chunk before last is on disk: its buffer is free)
+        int64_t n_out = n_bytes;
+        if (out->gzip()) {
+            if (!defl && !(defl = deflater_pool().get(device))) return hfail(GS_E_NOMEM, "no device DEFLATE writer");
+            const int64_t cap = gs_deflate_bound(n_bytes);
+            int err = buf[set].need((size_t)cap);
+            if (err) return err;
+            if (gs_deflater_pack(defl, d_text, n_bytes, static_cast<uint8_t *>(buf[set].p), cap, &n_out) != GS_OK)
+                return hfail(GS_E_HIP, std::string("device DEFLATE writer: ") + gs_deflate_last_error());
+        } else {
+            int err = buf[set].need((size_t)n_bytes);
+            if (err) return err;
+            if (gs_device_fetch(device, d_text, static_cast<uint8_t *>(buf[set].p), n_bytes) != GS_OK) return hfail(GS_E_HIP, gs_inflate_last_error());
+        }
+        bytes_text += n_bytes;
+        bytes_file += n_out;
+        auto pr = std::make_shared<std::promise<void>>();
+        written[set] = pr->get_future();
+        out->write_ref(static_cast<const uint8_t *>(buf[set].p), (size_t)n_out, [pr] { pr->set_value(); });
+        return GS_OK;
+    }
+    // every buffer handed to the writer thread has been written; the deflater goes back to its pool
+    void finish() {
+        for (auto &w : written)
+            if (w.valid()) w.get();
+        if (defl) deflater_pool().put(device, defl);
+        defl = nullptr;
+    }
+    ~DeviceWriter() { finish(); }
+};
+
 // compressed bytes of a stream's first batch when writers wait for its text (GS_HOST_GUNZIP_FIRST; 0: a full batch)
 inline int64_t gunzip_first_span() {
     if (const char *e = getenv("GS_HOST_GUNZIP_FIRST")) return std::max<int64_t>(0, atoll(e));
@@ -1742,6 +1823,7 @@ struct FilterCtx {
     int64_t accepted = 0, reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
     FormatPool pool{format_threads()};
+    DeviceWriter acc_dev, rest_dev;  // (declared behind the files: they wait for their writes before the files close)
 };
 
 struct FilterPart {
@@ -1887,6 +1969,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     PooledBuf text_sets[2], nl_sets[2];
     PinnedVec<uint8_t> acc_sets[2];
     std::future<void> formatting;
+    std::future<int> dev_job;  // device output: gather -> (deflate) -> fetch -> writer of the chunk before
+    const bool dev_out = device_output();
+    c.acc_dev.begin(&c.acc_out, device);
+    c.rest_dev.begin(&c.rest_out, device);
     int64_t n_formatted = 0, text_off = 0, fallback_off = -1;
     int64_t tot[3] = {0, 0, 0}, failed = -1, bad = -1;
     std::vector<uint8_t> carry;
@@ -1951,7 +2037,55 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
             }
             a = b;
         }
-        if (n_lines > 0) {
+        if (n_lines > 0 && dev_out) {
+            // The writers' side stays on the device: the records each file wants are gathered there (gs_filter_compact_text), a .gz
+            // file's are compressed there (DeviceWriter::emit -> gs_deflater_pack), and only what the files will hold crosses PCIe --
+            // on a thread of its own, while the next feed is inflated and filtered.
+            const int64_t n_reads = n_lines >> 2;
+            const int set = (int)(n_formatted & 1);
+            if ((err = acc_sets[set].resize((size_t)n_reads))) break;
+            uint8_t *h_acc = acc_sets[set].data();
+            int64_t ticket = -1;
+            static const bool trace = getenv("GS_HOST_TRACE") != nullptr;
+            const double t1 = now_s();
+            err = gs_filter_submit_text(c.bloom, c.k, c.min_pos_count, c.positive_ratio, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, h_acc, nullptr, 0, &ticket);
+            if (!err) err = gs_filter_text_status(c.bloom, &failed, &bad, tot);  // synchronises: results are needed now
+            const double t2 = now_s();
+            c.t_gpu += t2 - tg;
+            if (err) break;
+            if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
+                fallback_off = text_off;
+                break;
+            }
+            const uint8_t *d_a = nullptr, *d_r = nullptr;
+            int64_t nb_a = 0, nr_a = 0, nb_r = 0, nr_r = 0;
+            if (c.acc_out.active()) err = gs_filter_compact_text(c.bloom, 1, c.with_probs ? 1 : 0, set, &d_a, &nb_a, &nr_a);
+            if (!err && c.rest_out.active()) err = gs_filter_compact_text(c.bloom, 0, c.with_probs ? 1 : 0, set, &d_r, &nb_r, &nr_r);
+            if (err) break;
+            if (c.acc_out.active())
+                c.accepted += nr_a;
+            else if (c.rest_out.active())
+                c.accepted += n_reads - nr_r;
+            else
+                for (int64_t r = 0; r < n_reads; r++) c.accepted += h_acc[r] != 0;
+            const double t3 = now_s();
+            if (dev_job.valid() && (err = dev_job.get())) break;  // one chunk at a time: output order
+            if (trace)
+                fprintf(stderr, "filter feed (device output): %lld bytes, inflate %.2f ms, filter %.2f, gather %.2f (%lld + %lld bytes), writers of the chunk before %.2f\n",
+                        (long long)n_bytes, (t1 - tg) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (long long)nb_a, (long long)nb_r, (now_s() - t3) * 1e3);
+            n_formatted++;
+            auto job = [&c, set, d_a, nb_a, d_r, nb_r]() -> int {
+                const int e1 = c.acc_dev.emit(set, d_a, nb_a);
+                const int e2 = c.rest_dev.emit(set, d_r, nb_r);
+                return e1 ? e1 : e2;
+            };
+            try {
+                dev_job = std::async(std::launch::async, job);
+            } catch (const std::system_error &) {  // no thread to be had: on this one
+                if ((err = job())) break;
+            }
+            text_off += n_bytes;
+        } else if (n_lines > 0) {
             const int64_t n_reads = n_lines >> 2;
             const int set = (int)(n_formatted & 1);  // (the set of the chunk before last: its writers are through)
             if ((err = acc_sets[set].resize((size_t)n_reads)) || (err = nl_sets[set].need(sizeof(uint32_t) * (size_t)n_lines)) || (err = text_sets[set].need((size_t)n_bytes)))
@@ -2000,6 +2134,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     }
     const double te0 = now_s();
     if (formatting.valid()) formatting.get();
+    if (dev_job.valid()) {
+        const int e2 = dev_job.get();
+        if (!err) err = e2;
+    }
     const double te1 = now_s();
     if (inf) inflater_pool().put(device, inf);
     if (gzr) gunzipper_pool().put(device, gzr);  // (every slice's filter run has been waited for: gs_filter_text_status)
@@ -2041,6 +2179,13 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
     PinnedVec<uint8_t> acc_sets[2];
     PinnedVec<uint32_t> nl_sets[2];
     std::future<void> formatting;
+    std::future<int> dev_job;
+    // (plain outputs from a plain file are formatted from the reader's page-locked block, which is on the host anyway)
+    int device = 0;
+    const bool dev_out = device_output() && ((c.acc_out.active() && c.acc_out.gzip()) || (c.rest_out.active() && c.rest_out.gzip())) &&
+                         gs_filter_get_device(c.bloom, &device) == GS_OK;
+    c.acc_dev.begin(&c.acc_out, device);
+    c.rest_dev.begin(&c.rest_out, device);
     int64_t n_formatted = 0;
     std::vector<uint8_t> carry;
     int64_t carry_lines = 0, carry_file_off = 0, fallback_off = -1;
@@ -2082,6 +2227,31 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
             if (err) break;
             if (failed >= 0) {  // not four-line FASTQ from here on: the general parser continues at this chunk
                 fallback_off = carry_file_off;
+            } else if (dev_out) {
+                // a .gz output: the records are gathered and compressed on the device (the chunk's text is there already), the block
+                // goes straight back to its reader
+                const int set = (int)(n_formatted & 1);
+                const uint8_t *d_a = nullptr, *d_r = nullptr;
+                int64_t nb_a = 0, nr_a = 0, nb_r = 0, nr_r = 0;
+                if (c.acc_out.active()) err = gs_filter_compact_text(c.bloom, 1, c.with_probs ? 1 : 0, set, &d_a, &nb_a, &nr_a);
+                if (!err && c.rest_out.active()) err = gs_filter_compact_text(c.bloom, 0, c.with_probs ? 1 : 0, set, &d_r, &nb_r, &nr_r);
+                if (err) break;
+                c.accepted += c.acc_out.active() ? nr_a : n_reads - nr_r;
+                carry_file_off = i * (int64_t)tr.block + cut + 1;
+                carry.assign(blk + cut + 1, blk + sl.n);
+                carry_lines = rem;
+                if (dev_job.valid() && (err = dev_job.get())) break;  // one chunk at a time: output order
+                n_formatted++;
+                auto job = [&c, set, d_a, nb_a, d_r, nb_r]() -> int {
+                    const int e1 = c.acc_dev.emit(set, d_a, nb_a);
+                    const int e2 = c.rest_dev.emit(set, d_r, nb_r);
+                    return e1 ? e1 : e2;
+                };
+                try {
+                    dev_job = std::async(std::launch::async, job);
+                } catch (const std::system_error &) {  // no thread to be had: on this one
+                    if ((err = job())) break;
+                }
             } else {
                 // (the carry is taken out first: the block returns to its reader when the writers are through with it)
                 carry_file_off = i * (int64_t)tr.block + cut + 1;
@@ -2105,6 +2275,10 @@ int filter_text_file(FilterCtx &c, const std::string &path, bool gzip) {
         if (eof || fallback_off >= 0) break;
     }
     if (formatting.valid()) formatting.get();
+    if (dev_job.valid()) {
+        const int e2 = dev_job.get();
+        if (!err) err = e2;
+    }
     tr.close();
     c.t_parse += now_s() - t0;
     if (err) return err;
@@ -2374,6 +2548,12 @@ void release_pools_impl() {
         std::lock_guard<std::mutex> l(gp.m);
         for (auto &x : gp.idle) gs_gunzipper_close(x.second);
         gp.idle.clear();
+    }
+    {
+        DeflaterPool &dp = deflater_pool();
+        std::lock_guard<std::mutex> l(dp.m);
+        for (auto &x : dp.idle) gs_deflater_destroy(x.second);
+        dp.idle.clear();
     }
 }
 }  // namespace

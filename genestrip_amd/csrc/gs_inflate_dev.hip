@@ -1972,6 +1972,24 @@ struct GiDevBufs {  // freed on every way out
     }
 };
 
+// the CRC kernel for other translation units (gs_deflate_dev.hip: the members it writes): raw registers (no pre / post inversion)
+// of the tiles of `tile` bytes of d_text[0, n) into d_crc, on `stream`; a tile that is a multiple of 1024 bytes takes the fast join
+extern "C" int gs_crc_tiles_device(const uint8_t *d_text, int64_t n, uint32_t tile, uint32_t *d_crc, hipStream_t stream) {
+    if (n <= 0) return GS_OK;
+    if (tile < 64 || (tile & 63u)) return gi_fail(GS_E_INVALID, "gs_crc_tiles_device: the tile must be a multiple of 64 bytes");
+    int rc = gi_upload_crc_table();
+    if (rc) return rc;
+    GiCrcPow pw;
+    for (int sidx = 0; sidx < 6; sidx++) pw.p[sidx] = gi_h_x_pow_8n((uint64_t)(tile / 64u) << sidx);
+    const int64_t n_tiles = (n + tile - 1) / tile;
+    hipLaunchKernelGGL(gi_crc_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, d_text, n, tile, d_crc, pw);
+    GI_TRY(hipGetLastError());
+    return GS_OK;
+}
+// CRC-32 of n bytes from their raw register: ~(raw ^ 0xffffffff x^(8 n))
+extern "C" uint32_t gs_crc_finish_raw(uint32_t raw, uint64_t n) { return ~(raw ^ gi_h_gf_mul(0xffffffffu, gi_h_x_pow_8n(n))); }
+extern "C" uint32_t gs_crc_init_term(uint64_t n) { return gi_h_gf_mul(0xffffffffu, gi_h_x_pow_8n(n)); }
+
 // ---- the streaming form: the stream is taken in BATCHES of about one segment per wave slot of the device (its compressed bytes, the
 // finder, the segments, the window pass chained to the window the batch before left, the text, the CRC-32 folded into a running
 // register), so that a file of any size goes through buffers of a few gigabytes.

@@ -756,12 +756,33 @@ public:
         std::unique_lock<std::mutex> l(m_);
         if (!th_.joinable()) th_ = std::thread([this] { drain(); });
         cv_.wait(l, [&] { return q_.size() < 64; });
-        q_.push(Item{std::move(buf), packed});
+        Item it;
+        it.buf = std::move(buf);
+        it.packed = packed;
+        q_.push(std::move(it));
         cv_.notify_all();
     }
     void write(const void *p, size_t n) {
         const uint8_t *b = static_cast<const uint8_t *>(p);
         write(std::vector<uint8_t>(b, b + n));
+    }
+    // The same without taking the bytes over: [p, p + n) -- text for a plain file, finished gzip members for a gzip file (what the
+    // device writer delivers: gs_deflater_pack) -- stays the caller's until `done` has been called from the writer thread.
+    void write_ref(const uint8_t *p, size_t n, std::function<void()> done) {
+        if (!active() || n == 0) {
+            if (done) done();
+            return;
+        }
+        std::unique_lock<std::mutex> l(m_);
+        if (!th_.joinable()) th_ = std::thread([this] { drain(); });
+        cv_.wait(l, [&] { return q_.size() < 64; });
+        Item it;
+        it.packed = true;
+        it.ref = p;
+        it.ref_n = n;
+        it.done = std::move(done);
+        q_.push(std::move(it));
+        cv_.notify_all();
     }
     // an empty buffer that keeps the capacity of one written earlier (fresh memory costs page faults)
     std::vector<uint8_t> take() {
@@ -797,7 +818,10 @@ public:
 private:
     struct Item {
         std::vector<uint8_t> buf;
-        bool packed;
+        bool packed = false;
+        const uint8_t *ref = nullptr;  // write_ref: the bytes lie here (buf is empty)
+        size_t ref_n = 0;
+        std::function<void()> done;
     };
     void give_back(std::vector<uint8_t> &&b) {
         b.clear();
@@ -825,6 +849,12 @@ private:
             }
             cv_.notify_all();
             // (a dead file keeps taking buffers so that the producer never blocks on it)
+            if (it.ref) {
+                if (gzip_) flush_pending();  // order
+                if (!failed_ && fwrite(it.ref, 1, it.ref_n, f_) != it.ref_n) failed_ = true;
+                if (it.done) it.done();
+                continue;
+            }
             if (!gzip_ || it.packed) {
                 if (gzip_) flush_pending();  // order
                 put(it.buf);

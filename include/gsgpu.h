@@ -539,6 +539,44 @@ int gs_inflater_destroy(gs_inflater *inf);
 const char *gs_inflate_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The output side on the device (genestrip_amd/csrc/gs_deflate_dev.hip)
+ *
+ * Replaces, for the records of a four-line text chunk, the per-read writers of the reference: ReadEntry.write
+ * (C/fastq/AbstractFastqReader.java:570-584) as called by FastqBloomFilter.nextEntry -> rewriteInput (C/bloom/FastqBloomFilter.java:92-105,
+ * AbstractFastqReader.java:465-470) and by FastqKMerMatcher.afterMatch (C/match/FastqKMerMatcher.java:304-307), and the
+ * java.util.zip.GZIPOutputStream behind them (B/io/StreamProvider.java getOutputStreamForFile; gzipFastqOutput is the reference's
+ * default, C/GSConfigKey.java:155).
+ *
+ * gs_filter_compact_text / gs_match_compact_text: the records of the handle's most recent four-line chunk (gs_filter_submit_text /
+ * gs_match_submit_text with per-read flags; it must not have been refused) that the writer wants -- filter: accept flag set
+ * (which != 0) or clear (which == 0: the reference's dump file); match: GS_F_RETURNED set -- rewritten exactly as ReadEntry.write
+ * does (descriptor, '\n', read, "\n+\n", the record's quality line if with_probs else '~' x length, '\n'), back to back in a
+ * device buffer of the handle's: *d_out (valid until the next compact call with the same `which` and `slot`; slot 0 / 1: two
+ * buffers, so that chunk i can be on its way out while chunk i + 1 is gathered), *n_bytes, *n_records.  To be called before the
+ * next chunk is submitted on the handle.  Synchronises the handle's stream.
+ *
+ * gs_deflater_*: n bytes of device text -> block-gzip (BGZF) members in host memory: gzip members (RFC 1952) of at most 63 KiB of
+ * text, each with its size in a 'BC' extra subfield (what bgzip writes; GZIPInputStream / zcat read the file as one stream, this
+ * library's device inflater takes the members side by side).  One wave per member: run / hash matches chosen per lane, greedy
+ * parse, Huffman code from a counting pass over a sample of the call's text, built on the host, shared by the call's members;
+ * CRC-32 and ISIZE as GZIPOutputStream writes them.  out_cap >= gs_deflate_bound(n).  No end-of-file block (28 bytes, the
+ * caller's: an empty member).  Synchronous.  gs_deflate_host: host text through the same path (tests, tools);
+ * gs_deflate_host_reference: the same format from a plain CPU loop over the same tables (a test of the table builder that runs
+ * without a device).  gs_deflater_info: [0] members, [1] text bytes, [2] compressed bytes so far.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gs_deflater gs_deflater;
+int gs_filter_compact_text(gs_bloom *bloom, int which, int with_probs, int slot, const uint8_t **d_out, int64_t *n_bytes, int64_t *n_records);
+int gs_match_compact_text(gs_run *run, int with_probs, int slot, const uint8_t **d_out, int64_t *n_bytes, int64_t *n_records);
+int gs_deflater_create(gs_deflater **out, int device);
+int gs_deflater_pack(gs_deflater *d, const uint8_t *d_text, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_out);
+int gs_deflater_info(const gs_deflater *d, int64_t info[3]);
+int gs_deflater_destroy(gs_deflater *d);
+int64_t gs_deflate_bound(int64_t n);
+int gs_deflate_host(int device, const uint8_t *text, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_out);
+int gs_deflate_host_reference(const uint8_t *text, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_out);
+const char *gs_deflate_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement support (no reference counterpart; not on the data path): the ceilings of the device the kernels run on,
  * measured with small calibration kernels at the match kernel's occupancy (8 waves per SIMD), so that a benchmark prices
  * its kernels against numbers taken in the same process on the same chip (bench.py `roofline`).

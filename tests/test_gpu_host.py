@@ -517,3 +517,99 @@ def test_match_files_few_blocks_many_readers(sdb, tmp_path, monkeypatch, readers
             assert (tot.reads, tot.kmers, tot.bps) == want_tot
             assert np.array_equal(t, want_t)
     store.close()
+
+
+def test_refused_first_chunk_of_a_multi_batch_gz_while_its_upload_runs(sdb, tmp_path, monkeypatch):
+    """a single-member .gz larger than its first batch is uploaded whole by a thread of the device decoder while the
+    batches are decoded.  When the first chunk is refused (here: a record whose sequence runs over two lines) the job falls back and
+    unmaps the file -- the decoder must have been parked BEFORE that, or the thread copies out of a mapping that is gone.  Result =
+    the run through the host decoders."""
+    import zlib
+    n = 400_000
+    seq, off = synth.reads_host(sdb.genomes, n, read_len=150, seed=41)
+    a = np.empty((n, 2 + 8 + 1 + 150 + 3 + 150 + 1), dtype=np.uint8)
+    a[:, 0], a[:, 1] = ord("@"), ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(8):
+        a[:, 9 - d] = (idx % 10 + 48).astype(np.uint8)
+        idx //= 10
+    a[:, 10] = 10
+    a[:, 11:161] = seq.reshape(n, 150)
+    a[:, 161:164] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    a[:, 164:314] = ord("I")
+    a[:, 314] = 10
+    first = b"@first\n" + seq[:75].tobytes() + b"\n" + seq[75:150].tobytes() + b"\n+\n" + b"I" * 150 + b"\n"  # sequence over two lines
+    text = first + a.reshape(-1).tobytes()
+    z = zlib.compressobj(1, zlib.DEFLATED, 31)
+    path = str(tmp_path / "big.fastq.gz")
+    with open(path, "wb") as f:
+        f.write(z.compress(text) + z.flush())
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    monkeypatch.setenv("GS_GUNZIP_SLOTS", "16")        # 1 MiB of compressed data per batch: the upload outlives the first one
+    monkeypatch.setenv("GS_HOST_GUNZIP_FIRST", "0")
+    table, _, tot = host.match_files(store, [path])
+    monkeypatch.setenv("GS_DEVICE_INFLATE", "0")
+    want, _, tot2 = host.match_files(store, [path])
+    assert tot.reads == n + 1 == tot2.reads and np.array_equal(table, want)
+    # and the same file without the odd first record goes through the device decoder batch by batch
+    monkeypatch.delenv("GS_DEVICE_INFLATE")
+    z = zlib.compressobj(1, zlib.DEFLATED, 31)
+    with open(path, "wb") as f:
+        f.write(z.compress(text[len(first):]) + z.flush())
+    table2, _, tot3 = host.match_files(store, [path])
+    orun = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    orun.submit(seq, off, threads=8, per_read=False)
+    otable, _ = orun.finish()
+    assert tot3.reads == n and np.array_equal(table2, otable)
+    store.close()
+
+
+@pytest.mark.parametrize("with_probs", [False, True])
+@pytest.mark.parametrize("container", ["bgzf", "gzip", "plain"])
+def test_filter_outputs_written_from_the_device(sdb, tmp_path, monkeypatch, container, with_probs):
+    """The reference's default shape of the filter goal -- gzip in, gzip out (gzipFastqOutput, C/GSConfigKey.java:155;
+    C/goals/FilterGoal.java:76) -- with the output side on the device: accepted and dumped records gathered there
+    (gs_filter_compact_text), compressed there (gs_deflater_pack), only the files' bytes cross PCIe.  The .gz files must hold exactly
+    what the plain files of the host formatter hold (GS_DEVICE_OUTPUT=0), and must be BGZF that the device inflater takes back."""
+    from conftest import bgzf
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    recs = _fastq_bytes(sdb, 6000, seed=77)
+    if with_probs:  # quality lines that differ from record to record
+        rng = np.random.default_rng(4)
+        for i, r in enumerate(recs):
+            parts = r.split(b"\n")
+            parts[3] = bytes(rng.integers(35, 74, len(parts[3]), dtype=np.uint8))
+            recs[i] = b"\n".join(parts)
+    data = b"".join(recs) + b"@last\nACGT\n+\nIII"  # (an unterminated tail: goes through the reference-exact parser, behind the device's chunks)
+    path = str(tmp_path / ("in.fastq" if container == "plain" else "in.fastq.gz"))
+    if container == "bgzf":
+        open(path, "wb").write(bgzf(data, block=30000, level=1))
+    elif container == "gzip":
+        open(path, "wb").write(gzip.compress(data, compresslevel=1, mtime=0))
+    else:
+        open(path, "wb").write(data)
+    monkeypatch.setenv("GS_HOST_BGZF_TEXT", "400000")  # several feeds
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", "300000")
+    monkeypatch.setenv("GS_DEVICE_OUTPUT", "0")
+    a0, r0 = str(tmp_path / "acc0.fastq"), str(tmp_path / "rest0.fastq")
+    tot0 = host.filter_files(gb, 31, [path], filtered_path=a0, rest_path=r0, with_probs=with_probs)
+    monkeypatch.setenv("GS_DEVICE_OUTPUT", "1")
+    a1, r1 = str(tmp_path / "acc1.fastq.gz"), str(tmp_path / "rest1.fastq.gz")
+    tot1 = host.filter_files(gb, 31, [path], filtered_path=a1, rest_path=r1, with_probs=with_probs)
+    assert (tot1.reads, tot1.filtered_reads) == (tot0.reads, tot0.filtered_reads) and tot0.reads >= 6000 and 0 < tot0.filtered_reads < 6000
+    for gz_p, plain_p in ((a1, a0), (r1, r0)):
+        comp, want = open(gz_p, "rb").read(), open(plain_p, "rb").read()
+        assert gzip.decompress(comp) == want
+        members, reached = ga.bgzf_members(comp)
+        assert reached == len(comp) and members[-1][2] == 0  # BGZF to the end, closed by the empty member
+        text, status = ga.inflate_members(comp, [m for m in members if m[2]])
+        assert not status.any() and text.tobytes() == want
+    # ... and plain outputs through the device path (BGZF / gzip input: the text never comes to the host)
+    if container != "plain":
+        a2, r2 = str(tmp_path / "acc2.fastq"), str(tmp_path / "rest2.fastq")
+        host.filter_files(gb, 31, [path], filtered_path=a2, rest_path=r2, with_probs=with_probs)
+        assert open(a2, "rb").read() == open(a0, "rb").read() and open(r2, "rb").read() == open(r0, "rb").read()
+    gb.close()
