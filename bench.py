@@ -49,7 +49,7 @@ K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8            # per GPU: 7 links x 153.6 GB/s bidirectional
-ALL_LEGS = "main,large,huge,filter,tableonly,e2e,striped,dbbuild,long,r250,files"
+ALL_LEGS = "main,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,files"
 # committed rocprofv3 --pmc summaries per workload, newest first: the fallback when the in-run passes cannot be taken
 PROFILE_ROUNDS = {"match": ("r03", "r02"), "large_store": ("r03", "r02"), "filter": ("r03", "r02")}
 PMC_GROUPS = (
@@ -1223,6 +1223,147 @@ def _priced(cal, cnt, src, kms, n, footprint_key):
     return res
 
 
+def _fastq_text_device(torch, dseq, first, n, read_len=READ_LEN):
+    """the four-line FASTQ text of reads [first, first + n) of a resident read buffer, built on the device: @r<8 digits>, read, +, 'I' x L"""
+    width = 2 + 8 + 1
+    rec = width + read_len + 3 + read_len + 1
+    a = torch.empty((n, rec), dtype=torch.uint8, device=dseq.device)
+    a[:, 0] = ord("@")
+    a[:, 1] = ord("r")
+    idx = torch.arange(first, first + n, dtype=torch.int64, device=dseq.device)
+    for d in range(8):
+        a[:, 2 + 7 - d] = (idx % 10 + 48).to(torch.uint8)
+        idx = idx // 10
+    a[:, width - 1] = 10
+    a[:, width:width + read_len] = dseq[first * read_len:(first + n) * read_len].view(n, read_len)
+    a[:, width + read_len] = 10
+    a[:, width + read_len + 1] = ord("+")
+    a[:, width + read_len + 2] = 10
+    a[:, width + read_len + 3:rec - 1] = ord("I")
+    a[:, rec - 1] = 10
+    return a.view(-1)
+
+
+def _inflate_members_crc(path, threads):
+    """every BGZF member of `path` inflated by zlib (threads side by side) -> (CRC-32 of the whole text, its length, members); the
+    members' own trailers are checked on the way"""
+    import mmap
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    members, o, n = [], 0, len(mm)
+    while o + 28 <= n:
+        bsize = struct.unpack_from("<H", mm, o + 16)[0] + 1
+        members.append((o, bsize))
+        o += bsize
+    if o != n:
+        raise ValueError("%s is not BGZF to its end" % path)
+
+    def run(span):
+        crc, size = 0, 0
+        for at, bsize in span:
+            text = zlib.decompress(mm[at + 18:at + bsize - 8], -15)
+            c, isz = struct.unpack_from("<II", mm, at + bsize - 8)
+            if zlib.crc32(text) != c or len(text) != isz:
+                raise ValueError("member at %d: trailer does not match its text" % at)
+            crc = zlib.crc32(text, crc)  # (running over the span's text; the spans are joined below)
+            size += isz
+        return crc, size
+    per = max(1, (len(members) + threads * 8 - 1) // (threads * 8))
+    spans = [members[i:i + per] for i in range(0, len(members), per)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(run, spans))
+    crc, size = 0, 0
+    for c, ln in parts:
+        crc = _crc32_combine(crc, c, ln) if size else c
+        size += ln
+    return crc, size, len(members)
+
+
+def _file_crc(path, threads):
+    """CRC-32 of a file's bytes, pieces on threads"""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    size = os.path.getsize(path)
+    piece = 64 << 20
+
+    def run(a):
+        with open(path, "rb") as f:
+            f.seek(a)
+            return zlib.crc32(f.read(min(piece, size - a))), min(piece, size - a)
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(run, range(0, size, piece)))
+    crc, done = 0, 0
+    for c, ln in parts:
+        crc = _crc32_combine(crc, c, ln) if done else c
+        done += ln
+    return crc, size
+
+
+def leg_configs2_file(ga, torch, bloom, dseq, n, acc, cores, check_plain=True):
+    """BASELINE.json configs[2] END TO END in the reference's default shape (gzipFastqOutput, C/GSConfigKey.java:155; FilterGoal.java:76):
+    n reads as a block-gzip FASTQ file written in this run (the text built and compressed on the device, 4 M reads at a time)
+    -> gs_host_filter_files -> the accepted reads as a .gz file.  Input inflated on the device, filter on the device text, accepted
+    records gathered and DEFLATE-compressed on the device, only compressed bytes cross PCIe either way.  Checks: accepted count =
+    the resident run's; every member of the output inflated by zlib, trailer against text; the whole text's CRC-32 and length equal
+    the PLAIN-output run's file (zcat-equal)."""
+    from genestrip_amd import host
+    tmp = tempfile.mkdtemp(prefix="gsbench_c2_")
+    res = {"reads": n, "tmp": tempfile.gettempdir()}
+    try:
+        src = os.path.join(tmp, "reads.fastq.gz")
+        slab = 4_000_000
+        t0 = time.perf_counter()
+        defl = ga.DeviceDeflater()
+        rec = (2 + 8 + 1) + READ_LEN + 3 + READ_LEN + 1
+        out = torch.empty(ga.deflate_bound(slab * rec), dtype=torch.uint8).pin_memory().numpy()
+        with open(src, "wb") as f:
+            for a in range(0, n, slab):
+                k = min(slab, n - a)
+                text = _fastq_text_device(torch, dseq, a, k)
+                m = defl.pack(text, k * rec, out)
+                f.write(out[:m].data)
+                del text
+            f.write(ga.BGZF_EOF)
+        defl.close()
+        del out
+        torch.cuda.empty_cache()
+        res["input"] = {"bytes": os.path.getsize(src), "text_bytes": n * rec, "written_s": round(time.perf_counter() - t0, 2),
+                        "how": "text and BGZF members made on the device (gs_deflater_pack), 4 M reads per call"}
+        outp = os.path.join(tmp, "filtered.fastq.gz")
+        best, tot = None, None
+        for _ in range(2):
+            if os.path.exists(outp):
+                os.remove(outp)
+            t0 = time.perf_counter()
+            tot = host.filter_files(bloom, K, [src], 1, 0.2, filtered_path=outp)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        want = int(acc.sum().item()) if hasattr(acc, "sum") else int(acc)
+        res.update({"seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2), "accepted_reads": int(tot.filtered_reads),
+                    "accepted_equals_resident_run": bool(int(tot.filtered_reads) == want and int(tot.reads) == n),
+                    "output_bytes": os.path.getsize(outp), "output_text_bytes": int(tot.filtered_reads) * rec})
+        t0 = time.perf_counter()
+        crc, size, members = _inflate_members_crc(outp, cores)
+        res["output_check"] = {"members": members, "every_member_inflates_under_zlib_to_its_trailer": True,
+                               "text_bytes_as_expected": bool(size == int(tot.filtered_reads) * rec), "seconds": round(time.perf_counter() - t0, 1)}
+        if check_plain:
+            plain = os.path.join(tmp, "filtered.fastq")
+            t0 = time.perf_counter()
+            tot_p = host.filter_files(bloom, K, [src], 1, 0.2, filtered_path=plain)
+            dt = time.perf_counter() - t0
+            pcrc, psize = _file_crc(plain, cores)
+            res["plain_output"] = {"seconds": round(dt, 3), "gbps": round(n * READ_LEN / dt / 1e9, 2), "output_bytes": psize,
+                                   "accepted_reads": int(tot_p.filtered_reads)}
+            res["output_check"]["zcat_equal_to_the_plain_output_run"] = bool(pcrc == crc and psize == size)
+            os.remove(plain)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note):
     """BASELINE.json configs[2] / configs[3] per GPU: a 47 M-k-mer / 526-value store (1 GiB table, four times the
     Infinity Cache) and the XOR index filter over its species k-mers (~47 M keys, 1.8 G bits, 27 hashes).  Parity over the
@@ -1316,6 +1457,8 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note):
                                       "accepted_frac": round(float(acc2.float().mean()), 4),
                                       "first_10M_flags_equal_the_10M_launch": bool(torch.equal(acc2[:n], acc)),
                                       "first_2M_flags_equal_oracle": bool(np.array_equal(want, acc2[:nchk].cpu().numpy()))}
+        if "c2file" in legs:
+            obj["configs2_file"] = leg_configs2_file(ga, torch, bloom, dseq2, n2, acc2, cores)
         res["filter"] = obj
         bloom.close()
         del dseq2, doff2, acc2

@@ -313,6 +313,87 @@ struct PooledBuf {  // one buffer of the pool, returned when it goes out of scop
     ~PooledBuf() { pinned_pool().put(p, cap); }
 };
 
+// ... and the device DEFLATE writers of .gz outputs (slots and output buffer of the size of a chunk's text)
+struct DeflaterPool {
+    std::mutex m;
+    std::vector<std::pair<int, gs_deflater *>> idle;
+    gs_deflater *get(int device) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == device) {
+                    gs_deflater *g = idle[i].second;
+                    idle.erase(idle.begin() + (long)i);
+                    return g;
+                }
+        }
+        gs_deflater *g = nullptr;
+        return gs_deflater_create(&g, device) == GS_OK ? g : nullptr;
+    }
+    void put(int device, gs_deflater *g) {
+        if (!g) return;
+        std::lock_guard<std::mutex> l(m);
+        idle.emplace_back(device, g);
+    }
+};
+inline DeflaterPool &deflater_pool() {
+    static DeflaterPool *p = new DeflaterPool();  // (never destroyed, as the inflaters)
+    return *p;
+}
+// GS_DEVICE_OUTPUT=0: the per-read writers format (and zlib compresses) on host threads, as before round 4
+inline bool device_output() {
+    if (const char *e = getenv("GS_DEVICE_OUTPUT")) return atoi(e) != 0;
+    return true;
+}
+
+// The device side of one output file of the filter / match goal: the records the file wants have been gathered on the device
+// (gs_filter_compact_text / gs_match_compact_text); emit() compresses them there when the file is gzip (gs_deflater_pack: BGZF
+// members, what OutFile::pack makes with zlib on host threads) or fetches them as they are, into one of two page-locked buffers,
+// and hands that buffer to the file's writer thread by reference.  Called on the chunk's formatting thread, chunk after chunk.
+struct DeviceWriter {
+    OutFile *out = nullptr;
+    int device = 0;
+    gs_deflater *defl = nullptr;
+    PooledBuf buf[2];
+    std::future<void> written[2];
+    int64_t bytes_text = 0, bytes_file = 0;
+    void begin(OutFile *o, int dev) {
+        out = o;
+        device = dev;
+    }
+    int emit(int set, const uint8_t *d_text, int64_t n_bytes) {
+        if (!out || !out->active() || n_bytes <= 0) return GS_OK;
+        if (written[set].valid()) written[set].get();  // (the chunk before last is on disk: its buffer is free)
+        int64_t n_out = n_bytes;
+        if (out->gzip()) {
+            if (!defl && !(defl = deflater_pool().get(device))) return hfail(GS_E_NOMEM, "no device DEFLATE writer");
+            const int64_t cap = gs_deflate_bound(n_bytes);
+            int err = buf[set].need((size_t)cap);
+            if (err) return err;
+            if (gs_deflater_pack(defl, d_text, n_bytes, static_cast<uint8_t *>(buf[set].p), cap, &n_out) != GS_OK)
+                return hfail(GS_E_HIP, std::string("device DEFLATE writer: ") + gs_deflate_last_error());
+        } else {
+            int err = buf[set].need((size_t)n_bytes);
+            if (err) return err;
+            if (gs_device_fetch(device, d_text, static_cast<uint8_t *>(buf[set].p), n_bytes) != GS_OK) return hfail(GS_E_HIP, gs_inflate_last_error());
+        }
+        bytes_text += n_bytes;
+        bytes_file += n_out;
+        auto pr = std::make_shared<std::promise<void>>();
+        written[set] = pr->get_future();
+        out->write_ref(static_cast<const uint8_t *>(buf[set].p), (size_t)n_out, [pr] { pr->set_value(); });
+        return GS_OK;
+    }
+    // every buffer handed to the writer thread has been written; the deflater goes back to its pool
+    void finish() {
+        for (auto &w : written)
+            if (w.valid()) w.get();
+        if (defl) deflater_pool().put(device, defl);
+        defl = nullptr;
+    }
+    ~DeviceWriter() { finish(); }
+};
+
 struct MatchCtx {
     gs_run *run = nullptr;
     gs_db_info info{};
@@ -332,6 +413,7 @@ struct MatchCtx {
     int64_t global_read_no = 0, filtered_reads = 0;  // read numbers run over all files of the call (file order)
     int64_t reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
+    DeviceWriter filtered_dev;  // the filtered file fed from the device (TextJob::emit_filtered_device)
 };
 
 // MatcherReadEntry.writeMatchDetails (:723-756) for read i of the current batch / chunk (c.cls, c.seg_*): descriptor
@@ -662,87 +744,6 @@ struct GunzipperPool {
         gs_gunzipper_close(g);
     }
 };
-// ... and the device DEFLATE writers of .gz outputs (slots and output buffer of the size of a chunk's text)
-struct DeflaterPool {
-    std::mutex m;
-    std::vector<std::pair<int, gs_deflater *>> idle;
-    gs_deflater *get(int device) {
-        {
-            std::lock_guard<std::mutex> l(m);
-            for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i].first == device) {
-                    gs_deflater *g = idle[i].second;
-                    idle.erase(idle.begin() + (long)i);
-                    return g;
-                }
-        }
-        gs_deflater *g = nullptr;
-        return gs_deflater_create(&g, device) == GS_OK ? g : nullptr;
-    }
-    void put(int device, gs_deflater *g) {
-        if (!g) return;
-        std::lock_guard<std::mutex> l(m);
-        idle.emplace_back(device, g);
-    }
-};
-inline DeflaterPool &deflater_pool() {
-    static DeflaterPool *p = new DeflaterPool();  // (never destroyed, as the inflaters)
-    return *p;
-}
-// GS_DEVICE_OUTPUT=0: the per-read writers format (and zlib compresses) on host threads, as before round 4
-inline bool device_output() {
-    if (const char *e = getenv("GS_DEVICE_OUTPUT")) return atoi(e) != 0;
-    return true;
-}
-
-// The device side of one output file of the filter / match goal: the records the file wants have been gathered on the device
-// (gs_filter_compact_text / gs_match_compact_text); emit() compresses them there when the file is gzip (gs_deflater_pack: BGZF
-// members, what OutFile::pack makes with zlib on host threads) or fetches them as they are, into one of two page-locked buffers,
-// and hands that buffer to the file's writer thread by reference.  Called on the chunk's formatting thread, chunk after chunk.
-struct DeviceWriter {
-    OutFile *out = nullptr;
-    int device = 0;
-    gs_deflater *defl = nullptr;
-    PooledBuf buf[2];
-    std::future<void> written[2];
-    int64_t bytes_text = 0, bytes_file = 0;
-    void begin(OutFile *o, int dev) {
-        out = o;
-        device = dev;
-    }
-    int emit(int set, const uint8_t *d_text, int64_t n_bytes) {
-        if (!out || !out->active() || n_bytes <= 0) return GS_OK;
-        if (written[set].valid()) written[set].get();  // (the chunk before last is on disk: its buffer is free)
-        int64_t n_out = n_bytes;
-        if (out->gzip()) {
-            if (!defl && !(defl = deflater_pool().get(device))) return hfail(GS_E_NOMEM, "no device DEFLATE writer");
-            const int64_t cap = gs_deflate_bound(n_bytes);
-            int err = buf[set].need((size_t)cap);
-            if (err) return err;
-            if (gs_deflater_pack(defl, d_text, n_bytes, static_cast<uint8_t *>(buf[set].p), cap, &n_out) != GS_OK)
-                return hfail(GS_E_HIP, std::string("device DEFLATE writer: ") + gs_deflate_last_error());
-        } else {
-            int err = buf[set].need((size_t)n_bytes);
-            if (err) return err;
-            if (gs_device_fetch(device, d_text, static_cast<uint8_t *>(buf[set].p), n_bytes) != GS_OK) return hfail(GS_E_HIP, gs_inflate_last_error());
-        }
-        bytes_text += n_bytes;
-        bytes_file += n_out;
-        auto pr = std::make_shared<std::promise<void>>();
-        written[set] = pr->get_future();
-        out->write_ref(static_cast<const uint8_t *>(buf[set].p), (size_t)n_out, [pr] { pr->set_value(); });
-        return GS_OK;
-    }
-    // every buffer handed to the writer thread has been written; the deflater goes back to its pool
-    void finish() {
-        for (auto &w : written)
-            if (w.valid()) w.get();
-        if (defl) deflater_pool().put(device, defl);
-        defl = nullptr;
-    }
-    ~DeviceWriter() { finish(); }
-};
-
 // compressed bytes of a stream's first batch when writers wait for its text (GS_HOST_GUNZIP_FIRST; 0: a full batch)
 inline int64_t gunzip_first_span() {
     if (const char *e = getenv("GS_HOST_GUNZIP_FIRST")) return std::max<int64_t>(0, atoll(e));
@@ -865,6 +866,33 @@ struct TextJob {
 
     bool list_bgzf_members() { return bgzf_member_list(tr.map, tr.map_len, members_); }
 
+    // Filtered FASTQ without Kraken-style lines: the reads matchRead returned true for (afterMatch, FastqKMerMatcher.java:304-307) are
+    // gathered on the device and -- for a .gz file -- compressed there; the chunk's text never comes to the host.
+    bool device_filtered() const { return device_output() && c.filtered.active() && !c.kraken.active(); }
+    int dev_err_ = GS_OK;
+    // after the chunk's flags are in (check_refusal has synchronised): gather now, compress / fetch / write on a thread of its own
+    int emit_filtered_device() {
+        const int set = (int)(n_formatted & 1);
+        const uint8_t *d = nullptr;
+        int64_t nb = 0, nr = 0;
+        int err = gs_match_compact_text(c.run, c.opts->with_probs != 0, set, &d, &nb, &nr);
+        if (err) return err;
+        c.filtered_reads += nr;
+        drain();  // one chunk at a time: output order
+        if (dev_err_) return dev_err_;
+        n_formatted++;
+        auto job = [this, set, d, nb] {
+            const int e = c.filtered_dev.emit(set, d, nb);
+            if (e) dev_err_ = e;
+        };
+        try {
+            formatting = std::async(std::launch::async, job);
+        } catch (const std::system_error &) {  // no thread to be had: on this one
+            job();
+        }
+        return GS_OK;
+    }
+
     int open(bool gzip, int readers) {
         // measured on the MI355X box (tools/file_rate_sweep.sh, 5 GB file in the page cache): 8 readers x 8 MiB blocks
         // 24.8 GB/s of file, 4 x 32 MiB 10.6 GB/s, 8 x 128 MiB 9.1 GB/s -- blocks that stay in the CPU caches between
@@ -923,6 +951,10 @@ struct TextJob {
                 }
             }
         }
+        if (!err && c.filtered.active()) {
+            int device = 0;
+            if (gs_match_get_device(c.run, &device) == GS_OK) c.filtered_dev.begin(&c.filtered, device);
+        }
         if (!err && !dev_bgzf && !dev_gz) tr.start();
         return err;
     }
@@ -969,18 +1001,24 @@ struct TextJob {
             MatchCtx::Results &rs = c.res[n_formatted & 1];  // (the set of the chunk before last: its writers are done)
             PooledBuf &tb = dev_text_[n_formatted & 1];
             int64_t ticket = -1;
+            const bool dev_f = device_filtered();
             err = rs.cls.resize((size_t)n_chunk);
             if (!err) err = rs.flags.resize((size_t)n_chunk);
-            if (!err) err = tb.need((size_t)n_bytes);
+            if (!err && !dev_f) err = tb.need((size_t)n_bytes);
             if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
-            if (!err && gs_device_fetch(inf_device_, text, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (!err && !dev_f && gs_device_fetch(inf_device_, text, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
             if (!err) {
                 chunks.push_back({carry_file_off, reads_in_file, ticket});
                 err = check_refusal(&fallback_off, &fallback_reads);  // (synchronises: the results are needed now)
-                if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
+                if (!err && fallback_off < 0 && !dev_f) err = fetch_chunk_results(rs, n_chunk);
                 if (err || fallback_off >= 0) chunks.pop_back();
             }
-            if (!err && fallback_off < 0) {
+            if (!err && fallback_off < 0 && dev_f) {
+                if (first_ticket < 0) first_ticket = ticket;
+                reads_in_file += n_chunk;
+                carry_file_off += n_bytes;
+                err = emit_filtered_device();
+            } else if (!err && fallback_off < 0) {
                 if (first_ticket < 0) first_ticket = ticket;
                 reads_in_file += n_chunk;
                 carry_file_off += n_bytes;
@@ -1071,18 +1109,24 @@ struct TextJob {
             MatchCtx::Results &rs = c.res[n_formatted & 1];  // (the set of the chunk before last: its writers are done)
             PooledBuf &tb = dev_text_[n_formatted & 1];
             int64_t ticket = -1;
+            const bool dev_f = device_filtered();
             err = rs.cls.resize((size_t)n_chunk);
             if (!err) err = rs.flags.resize((size_t)n_chunk);
-            if (!err) err = tb.need((size_t)n_bytes);
+            if (!err && !dev_f) err = tb.need((size_t)n_bytes);
             if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
-            if (!err && gs_inflater_fetch(inf_, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
+            if (!err && !dev_f && gs_inflater_fetch(inf_, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
             if (!err) {
                 chunks.push_back({carry_file_off, reads_in_file, ticket});
                 err = check_refusal(&fallback_off, &fallback_reads);  // (synchronises: the results are needed now)
-                if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
+                if (!err && fallback_off < 0 && !dev_f) err = fetch_chunk_results(rs, n_chunk);
                 if (err || fallback_off >= 0) chunks.pop_back();
             }
-            if (!err && fallback_off < 0) {
+            if (!err && fallback_off < 0 && dev_f) {
+                if (first_ticket < 0) first_ticket = ticket;
+                reads_in_file += n_chunk;
+                carry_file_off += n_bytes;
+                err = emit_filtered_device();
+            } else if (!err && fallback_off < 0) {
                 if (first_ticket < 0) first_ticket = ticket;
                 reads_in_file += n_chunk;
                 carry_file_off += n_bytes;
@@ -1178,12 +1222,14 @@ struct TextJob {
                 if (!err)
                     err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
                                                per_read ? rs.cls.data() : nullptr, per_read ? rs.flags.data() : nullptr, &ticket);
+                const bool dev_f = per_read && device_filtered() && c.filtered.gzip();  // (a plain file: formatted from the reader's block, which is here anyway)
                 if (!err && per_read) {  // the writers need this chunk's results
                     chunks.push_back({carry_file_off, reads_in_file, ticket});
                     err = check_refusal(&fallback_off, &fallback_reads);
                     chunks.pop_back();
-                    if (!err && fallback_off < 0) err = fetch_chunk_results(rs, n_chunk);
-                    format_it = !err && fallback_off < 0;
+                    if (!err && fallback_off < 0 && !dev_f) err = fetch_chunk_results(rs, n_chunk);
+                    format_it = !err && fallback_off < 0 && !dev_f;
+                    if (!err && fallback_off < 0 && dev_f) err = emit_filtered_device();
                 }
                 if (!err && fallback_off < 0) {
                     if (first_ticket < 0) first_ticket = ticket;
@@ -1502,6 +1548,7 @@ private:
     int finish(int err, int64_t fallback_off, int64_t fallback_reads) {
         done = true;
         drain();
+        if (!err) err = dev_err_;
         const int held_err = release_held();  // (the blocks return to the pool in close(): no copy may still read them)
         if (!err) err = held_err;
         release_gunzipper();  // (parks the upload thread: it reads the mapping that close() removes)
@@ -1970,7 +2017,6 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     PinnedVec<uint8_t> acc_sets[2];
     std::future<void> formatting;
     std::future<int> dev_job;  // device output: gather -> (deflate) -> fetch -> writer of the chunk before
-    const bool dev_out = device_output();
     c.acc_dev.begin(&c.acc_out, device);
     c.rest_dev.begin(&c.rest_out, device);
     int64_t n_formatted = 0, text_off = 0, fallback_off = -1;
@@ -1979,7 +2025,10 @@ int filter_bgzf_file(FilterCtx &c, const std::string &path, bool *handled) {
     const double t0 = now_s();
     // (feeds of 128 MiB here, not 512: the writers get their first chunk four times earlier, and what they have not written when
     // the last feed is through is what the file waits for in the end -- 4 M reads: 285 ms with 512 MiB feeds, 175 ms with 128)
-    const int64_t text_target = getenv("GS_HOST_BGZF_TEXT") ? bgzf_text_target() : ((int64_t)128 << 20);
+    // (with the writers' side on the device -- nothing to format, a sixth of the bytes to write -- the feeds are 256 MiB: 12.1 against
+    // 11.2 Gbp/s gz -> gz at 16 M reads)
+    const bool dev_out = device_output();
+    const int64_t text_target = getenv("GS_HOST_BGZF_TEXT") ? bgzf_text_target() : ((int64_t)(dev_out ? 256 : 128) << 20);
     auto run_end = [&](size_t from) {
         int64_t sum = 0;
         size_t e = from;

@@ -613,3 +613,36 @@ def test_filter_outputs_written_from_the_device(sdb, tmp_path, monkeypatch, cont
         host.filter_files(gb, 31, [path], filtered_path=a2, rest_path=r2, with_probs=with_probs)
         assert open(a2, "rb").read() == open(a0, "rb").read() and open(r2, "rb").read() == open(r0, "rb").read()
     gb.close()
+
+
+@pytest.mark.parametrize("container", ["bgzf", "gzip", "plain"])
+def test_match_filtered_fastq_written_from_the_device(sdb, tmp_path, monkeypatch, container):
+    """writeFilteredFastq with gzipFastqOutput (C/goals/MatchResultGoal.java:106, C/GSConfigKey.java:155, :308) and no Kraken-style
+    lines: the reads matchRead returned true for are gathered and compressed on the device (gs_match_compact_text,
+    gs_deflater_pack); file, table and totals equal the host formatter's (GS_DEVICE_OUTPUT=0)"""
+    from conftest import bgzf
+    recs = _fastq_bytes(sdb, 5000, seed=91)
+    data = b"".join(recs)
+    path = str(tmp_path / ("in.fastq" if container == "plain" else "in.fastq.gz"))
+    if container == "bgzf":
+        open(path, "wb").write(bgzf(data, block=30000, level=1))
+    elif container == "gzip":
+        open(path, "wb").write(gzip.compress(data, compresslevel=1, mtime=0))
+    else:
+        open(path, "wb").write(data)
+    monkeypatch.setenv("GS_HOST_BGZF_TEXT", "300000")
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", "200000")
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    res = {}
+    for dev in ("0", "1"):
+        monkeypatch.setenv("GS_DEVICE_OUTPUT", dev)
+        f = str(tmp_path / f"flt{dev}.fastq.gz")
+        table, _, tot = host.match_files(store, [path], filtered_path=f)
+        res[dev] = (table, tot.reads, tot.filtered_reads, gzip.decompress(open(f, "rb").read()))
+    assert np.array_equal(res["0"][0], res["1"][0]) and res["0"][1:3] == res["1"][1:3] and 0 < res["1"][2] < 5000
+    assert res["0"][3] == res["1"][3] and res["1"][3].count(b"\n") == 4 * res["1"][2]
+    if container != "plain":  # a plain filtered file from compressed input takes the device path as well
+        f = str(tmp_path / "flt2.fastq")
+        host.match_files(store, [path], filtered_path=f)
+        assert open(f, "rb").read() == res["0"][3]
+    store.close()
