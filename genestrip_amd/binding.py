@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "gs_calibrate",
     "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_first_span", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
     "gs_filter_compact_text", "gs_match_compact_text", "gs_deflater_create", "gs_deflater_pack", "gs_deflater_info", "gs_deflater_destroy",
-    "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error",
+    "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error", "gs_match_text_descriptors",
 )
 
 
@@ -191,6 +191,7 @@ def lib():
         "gs_deflate_host": (ci, [ci, vp, i64, vp, i64, vp]),
         "gs_deflate_host_reference": (ci, [vp, i64, vp, i64, vp]),
         "gs_deflate_last_error": (C.c_char_p, []),
+        "gs_match_text_descriptors": (ci, [vp, vp, i32, vp, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -2686,6 +2686,32 @@ extern "C" int gs_match_compact_text(gs_run *run, int with_probs, int slot, cons
     return text_compact(run->text, run->stream, GS_F_RETURNED, 1, 1, slot, with_probs, d_out, n_bytes, n_records);
 }
 
+extern "C" int gs_gather_descriptors_device(hipStream_t stream, const uint8_t *d_text, const uint32_t *d_nl, const int64_t *d_records, int n, uint8_t *d_out, int stride);
+
+// the descriptor lines (whole first lines, '@' included) of a few records of the last four-line chunk: out[i * stride ..], NUL-terminated
+extern "C" int gs_match_text_descriptors(gs_run *run, const int64_t *records, int32_t n, uint8_t *out, int32_t stride) {
+    if (!run || n < 0 || (n > 0 && (!records || !out)) || stride < 2) return fail(GS_E_INVALID, "bad argument");
+    if (n == 0) return GS_OK;
+    TextScan &t = run->text;
+    if (t.tickets == 0 || !t.last_four_line) return fail(GS_E_STATE, "the last chunk was not four-line FASTQ");
+    for (int32_t i = 0; i < n; i++)
+        if (records[i] < 0 || records[i] >= t.last_reads) return fail(GS_E_INVALID, "record outside the last chunk");
+    HIP_TRY(hipSetDevice(run->db->device));
+    int64_t *d_rec = nullptr;
+    uint8_t *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rec, sizeof(int64_t) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n * (size_t)stride);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rec, records, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, run->stream);
+    int rc = GS_OK;
+    if (e == hipSuccess && gs_gather_descriptors_device(run->stream, t.d_text, t.d_nl, d_rec, n, d_out, stride) != GS_OK) rc = fail(GS_E_HIP, gs_deflate_last_error());
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(out, d_out, (size_t)n * (size_t)stride, hipMemcpyDeviceToHost, run->stream);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(run->stream);
+    hipFree(d_rec);
+    hipFree(d_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gs_match_text_descriptors: ") + hipGetErrorString(e));
+    return rc;
+}
+
 extern "C" int gs_match_text_wait_copy(gs_run *run, int64_t ticket) {
     if (!run) return fail(GS_E_INVALID, "run is NULL");
     HIP_TRY(hipSetDevice(run->db->device));

@@ -530,6 +530,19 @@ __global__ __launch_bounds__(GC_BLOCK) void gc_copy_kernel(const uint8_t *text, 
     }
 }
 
+// the descriptor lines of a few records of a four-line chunk, each into `stride` bytes (NUL-terminated, cut to fit): for a host
+// that wants the name of a read it has never seen (CountsPerTaxid.maxContigDescriptor, FastqKMerMatcher.java:401-407)
+__global__ __launch_bounds__(64) void gc_desc_kernel(const uint8_t *text, const uint32_t *nl, const int64_t *records, int n, uint8_t *out, int stride) {
+    const int i = (int)blockIdx.x;
+    if (i >= n) return;
+    const int64_t r = records[i];
+    const uint32_t d0 = r ? nl[4 * r - 1] + 1u : 0u, len = nl[4 * r] - d0;
+    const uint32_t m = len < (uint32_t)(stride - 1) ? len : (uint32_t)(stride - 1);
+    uint8_t *o = out + (size_t)i * (size_t)stride;
+    for (uint32_t j = threadIdx.x; j < m; j += 64u) o[j] = text[d0 + j];
+    if (threadIdx.x == 0) o[m] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -1062,5 +1075,14 @@ extern "C" int gs_compact_records_device(hipStream_t stream, const uint8_t *d_te
     hipLaunchKernelGGL(gc_copy_kernel, dim3((unsigned)n_blocks), dim3(GC_BLOCK), 0, stream, d_text, d_nl, n_records, d_len, sum, with_probs, d_out);
     GD_TRY(hipGetLastError());
     GD_TRY(hipMemcpyAsync(h_totals, tot, 2 * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    return GS_OK;
+}
+
+// descriptor lines of records[0 .. n) of a four-line chunk (device arrays) into d_out (n x stride bytes); asynchronous on `stream`
+extern "C" int gs_gather_descriptors_device(hipStream_t stream, const uint8_t *d_text, const uint32_t *d_nl, const int64_t *d_records, int n, uint8_t *d_out, int stride) {
+    if (n <= 0) return GS_OK;
+    if (stride < 2) return gd_fail(GS_E_INVALID, "stride < 2");
+    hipLaunchKernelGGL(gc_desc_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_text, d_nl, d_records, n, d_out, stride);
+    GD_TRY(hipGetLastError());
     return GS_OK;
 }

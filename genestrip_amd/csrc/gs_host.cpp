@@ -414,6 +414,43 @@ struct MatchCtx {
     int64_t reads = 0, kmers = 0, bps = 0;
     double t_gpu = 0, t_parse = 0;
     DeviceWriter filtered_dev;  // the filtered file fed from the device (TextJob::emit_filtered_device)
+    // CountsPerTaxid.maxContigDescriptor for a host that never sees the reads (opts->max_contig_desc): after every chunk the device
+    // names the read that holds each tax id's longest contig (gs_match_max_contig_reads); a holder that lies in the chunk just
+    // submitted gets its name fetched while the chunk's text is at hand.  A maximum only moves to a later read by beating it, so
+    // the name kept at the end is the one gs_match_finish's read number stands for.
+    std::vector<int64_t> max_holder, max_now;
+    bool track_desc() const { return opts && opts->max_contig_desc != nullptr && opts->max_contig_desc_stride >= 2; }
+    // fetch(records in the chunk, n, out, stride) -> the records' descriptor lines, NUL-terminated; null: the text is not at hand
+    int update_max_contig(int64_t first_no, int64_t n_reads, const std::function<int(const int64_t *, int32_t, uint8_t *, int32_t)> &fetch) {
+        if (!track_desc() || n_reads <= 0) return GS_OK;
+        const size_t nv = (size_t)info.n_values;
+        if (max_holder.size() != nv) max_holder.assign(nv, -1);
+        max_now.resize(nv);
+        int err = gs_match_max_contig_reads(run, max_now.data());
+        if (err) return err;
+        std::vector<int64_t> recs;
+        std::vector<size_t> vis;
+        for (size_t v = 0; v < nv; v++) {
+            const int64_t r = max_now[v];
+            if (r != max_holder[v] && r >= first_no && r < first_no + n_reads) {
+                recs.push_back(r - first_no);
+                vis.push_back(v);
+            }
+            max_holder[v] = r;
+        }
+        if (recs.empty()) return GS_OK;
+        const int32_t stride = opts->max_contig_desc_stride;
+        std::vector<uint8_t> lines(recs.size() * (size_t)stride + 1, 0);
+        if (fetch && (err = fetch(recs.data(), (int32_t)recs.size(), lines.data(), stride))) return err;
+        for (size_t i = 0; i < recs.size(); i++) {
+            const uint8_t *l = lines.data() + i * (size_t)stride;
+            uint8_t *o = opts->max_contig_desc + vis[i] * (size_t)stride;
+            int32_t j = 1;  // (behind the line's first character, up to the first blank: FastqKMerMatcher.java:404-407)
+            for (; l[0] && j < stride && l[j] && l[j] != ' '; j++) o[j - 1] = l[j];
+            o[j - 1] = 0;
+        }
+        return GS_OK;
+    }
 };
 
 // MatcherReadEntry.writeMatchDetails (:723-756) for read i of the current batch / chunk (c.cls, c.seg_*): descriptor
@@ -519,6 +556,16 @@ int consume_batch(MatchCtx &c, Batch &b, int64_t &read_no) {
         if (!err) err = gs_match_segments_fetch(c.run, rs.seg_code.data(), rs.seg_start.data());
     }
     c.t_gpu += now_s() - t0;
+    if (err) return err;
+    err = c.update_max_contig(read_no, n, [&b](const int64_t *recs, int32_t m, uint8_t *out, int32_t stride) {
+        for (int32_t i = 0; i < m; i++) {
+            const size_t d0 = b.desc_off[(size_t)recs[i]], d1 = b.desc_off[(size_t)recs[i] + 1];
+            const size_t len = std::min<size_t>(d1 - d0, (size_t)stride - 1);
+            memcpy(out + (size_t)i * (size_t)stride, b.desc.data() + d0, len);
+            out[(size_t)i * (size_t)stride + len] = 0;
+        }
+        return (int)GS_OK;
+    });
     if (err) return err;
     read_no += n;
     if (!c.filtered.active() && !c.kraken.active()) return GS_OK;
@@ -866,6 +913,16 @@ struct TextJob {
 
     bool list_bgzf_members() { return bgzf_member_list(tr.map, tr.map_len, members_); }
 
+    // the chunk that was just submitted: first read number, reads; four_line: its descriptor lines can be fetched from the device
+    int chunk_submitted(int64_t first_no, int64_t n_reads, bool four_line) {
+        if (!c.track_desc()) return GS_OK;
+        gs_run *run = c.run;
+        if (!four_line) return c.update_max_contig(first_no, n_reads, nullptr);
+        return c.update_max_contig(first_no, n_reads, [run](const int64_t *recs, int32_t m, uint8_t *out, int32_t stride) {
+            return gs_match_text_descriptors(run, recs, m, out, stride);
+        });
+    }
+
     // Filtered FASTQ without Kraken-style lines: the reads matchRead returned true for (afterMatch, FastqKMerMatcher.java:304-307) are
     // gathered on the device and -- for a .gz file -- compressed there; the chunk's text never comes to the host.
     bool device_filtered() const { return device_output() && c.filtered.active() && !c.kraken.active(); }
@@ -1006,6 +1063,7 @@ struct TextJob {
             if (!err) err = rs.flags.resize((size_t)n_chunk);
             if (!err && !dev_f) err = tb.need((size_t)n_bytes);
             if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
+            if (!err) err = chunk_submitted(read_no + reads_in_file, n_chunk, true);
             if (!err && !dev_f && gs_device_fetch(inf_device_, text, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
             if (!err) {
                 chunks.push_back({carry_file_off, reads_in_file, ticket});
@@ -1034,6 +1092,7 @@ struct TextJob {
         } else if (!err && n_lines > 0) {
             int64_t ticket = -1;
             err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
+            if (!err) err = chunk_submitted(read_no + reads_in_file, n_lines >> 2, true);
             if (!err) {
                 gz_ticket_ = ticket;
                 if (first_ticket < 0) first_ticket = ticket;
@@ -1114,6 +1173,7 @@ struct TextJob {
             if (!err) err = rs.flags.resize((size_t)n_chunk);
             if (!err && !dev_f) err = tb.need((size_t)n_bytes);
             if (!err) err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE_TEXT, read_no + reads_in_file, rs.cls.data(), rs.flags.data(), &ticket);
+            if (!err) err = chunk_submitted(read_no + reads_in_file, n_chunk, true);
             if (!err && !dev_f && gs_inflater_fetch(inf_, static_cast<uint8_t *>(tb.p), n_bytes) != GS_OK) err = hfail(GS_E_HIP, gs_inflate_last_error());
             if (!err) {
                 chunks.push_back({carry_file_off, reads_in_file, ticket});
@@ -1142,6 +1202,7 @@ struct TextJob {
         } else if (!err && n_lines > 0) {
             int64_t ticket = -1;
             err = gs_match_submit_text(c.run, text, n_bytes, n_lines, GS_MEM_DEVICE, read_no + reads_in_file, nullptr, nullptr, &ticket);
+            if (!err) err = chunk_submitted(read_no + reads_in_file, n_lines >> 2, true);
             if (!err) {
                 dev_tickets_[slot] = ticket;
                 if (first_ticket < 0) first_ticket = ticket;
@@ -1222,6 +1283,7 @@ struct TextJob {
                 if (!err)
                     err = gs_match_submit_text(c.run, start, (int64_t)carry.size() + cut + 1, usable, GS_MEM_HOST, read_no + reads_in_file,
                                                per_read ? rs.cls.data() : nullptr, per_read ? rs.flags.data() : nullptr, &ticket);
+                if (!err) err = chunk_submitted(read_no + reads_in_file, usable >> 2, true);
                 const bool dev_f = per_read && device_filtered() && c.filtered.gzip();  // (a plain file: formatted from the reader's block, which is here anyway)
                 if (!err && per_read) {  // the writers need this chunk's results
                     chunks.push_back({carry_file_off, reads_in_file, ticket});
@@ -1324,6 +1386,7 @@ struct TextJob {
                     if (!err)
                         err = gs_match_submit_fasta(c.run, start, (int64_t)carry.size() + cut, lines, records, GS_MEM_HOST,
                                                     read_no + reads_in_file, kr ? rs.cls.data() : nullptr, kr ? rs.flags.data() : nullptr, &ticket);
+                    if (!err) err = chunk_submitted(read_no + reads_in_file, records, false);
                     if (!err && kr && records > 0) {  // the per-read outputs of this chunk's records, before the block goes back
                         chunks.push_back({carry_file_off, reads_in_file, ticket});
                         err = check_refusal(&fallback_off, &fallback_reads);
@@ -1401,6 +1464,7 @@ struct TextJob {
                 if (!err)
                     err = gs_match_submit_fastq_ml(c.run, start, bytes, lines, GS_MEM_HOST, read_no + reads_in_file, kr ? rs.cls.data() : nullptr,
                                                    kr ? rs.flags.data() : nullptr, &n_rec, &used, &used_lines, &ticket);
+                if (!err && n_rec > 0) err = chunk_submitted(read_no + reads_in_file, n_rec, false);
                 if (!err && kr && n_rec > 0) err = outputs_general(rs, start, used_lines, n_rec, false);
                 if (!err && n_rec < 0) {  // refused (NUL byte, a record of thousands of lines): the general parser from here
                     err = gs_match_text_clear_error(c.run);
@@ -1599,7 +1663,7 @@ namespace {
 // (file_index << 32 | read in file).  reads_of_file[n_paths] receives the read counts, *composite says whether the
 // max-contig read numbers of the run are in that (file, read) form.
 int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t *file_index, std::vector<int64_t> &reads_of_file_out,
-              bool *composite) {
+              bool *composite, bool allow_side_by_side = true) {
     bool fast = true;
     if (const char *e = getenv("GS_HOST_FAST")) fast = atoi(e) != 0;
     int err = GS_OK;
@@ -1619,6 +1683,7 @@ int run_files(MatchCtx &c, const char *const *paths, int n_paths, const int32_t 
     // (per-read outputs follow the read order: one file after the other)
     bool side_by_side = n_gzip >= 2 && n_paths <= 256 && !c.filtered.active() && !c.kraken.active();
     if (const char *e = getenv("GS_HOST_PARALLEL_FILES")) side_by_side = side_by_side && atoi(e) != 0;
+    side_by_side = side_by_side && allow_side_by_side;
     if (file_index) side_by_side = true;  // read numbers are (file << 32 | read): the files are independent anyway
     std::vector<int64_t> reads_of_file((size_t)n_paths, 0);
     if (!side_by_side) {
@@ -1706,6 +1771,7 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
             c.taxid_max = std::max(c.taxid_max, (size_t)c.taxid_len[(size_t)v]);
         }
     }
+    if (c.track_desc()) memset(opts->max_contig_desc, 0, (size_t)c.info.n_values * (size_t)opts->max_contig_desc_stride);
     if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
     const double t_begin = now_s();
     rc = gs_match_begin(&c.run, db, cfg);
@@ -1747,6 +1813,51 @@ extern "C" int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const cha
     return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
 }
 
+
+// runMatcher's body for a host that keeps its own run (begin / reset ... finish): the files into `run`, per-read outputs included
+extern "C" int gs_host_match_run(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const gs_host_match_opts *opts,
+                                 gs_host_totals *totals) try {
+    if (!run || !db || !paths || n_paths < 0) return hfail(GS_E_INVALID, "NULL argument");
+    MatchCtx c;
+    int rc = gs_db_get_info(db, &c.info);
+    if (rc) return rc;
+    const gs_host_match_opts none{};
+    if (!opts) opts = &none;
+    c.opts = opts;
+    if (opts->kraken_out_path && !opts->taxids) return hfail(GS_E_INVALID, "Kraken-style output needs the taxid strings");
+    if (opts->kraken_out_path) {
+        c.taxid_len.resize((size_t)c.info.n_values);
+        for (int32_t v = 0; v < c.info.n_values; v++) {
+            if (!opts->taxids[v]) return hfail(GS_E_INVALID, "Kraken-style output: a taxid string is NULL");
+            c.taxid_len[(size_t)v] = (uint32_t)strlen(opts->taxids[v]);
+            c.taxid_max = std::max(c.taxid_max, (size_t)c.taxid_len[(size_t)v]);
+        }
+    }
+    if (c.track_desc()) memset(opts->max_contig_desc, 0, (size_t)c.info.n_values * (size_t)opts->max_contig_desc_stride);
+    if (!c.filtered.open(opts->filtered_path) || !c.kraken.open(opts->kraken_out_path)) return hfail(GS_E_INVALID, "cannot open output file");
+    c.run = run;
+    const double t_start = now_s();
+    std::vector<int64_t> reads_of_file;
+    bool composite = false;
+    int err = run_files(c, paths, n_paths, nullptr, reads_of_file, &composite, false);  // (one file after the other: running read numbers)
+    if (!err) err = gs_match_sync(run);
+    const bool wrote = c.filtered.close() & c.kraken.close();
+    if (!err && !wrote) err = hfail(GS_E_IO, "write to an output file failed");
+    if (totals) {
+        totals->reads = c.reads;
+        totals->kmers = c.kmers;
+        totals->bps = c.bps;
+        totals->filtered_reads = c.filtered_reads;
+        totals->seconds_total = now_s() - t_start;
+        totals->seconds_parse = c.t_parse;
+        totals->seconds_gpu = c.t_gpu;
+    }
+    return err;
+} catch (const std::bad_alloc &) {
+    return hfail(GS_E_NOMEM, "out of host memory");
+} catch (const std::exception &e) {  // (nothing may leave through the C ABI)
+    return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());
+}
 
 // runMatcher over the files of a sample on SEVERAL devices of this process: dbs[d] = a replica of the store on device d
 // (the same arrays through gs_db_create, or the same store file).  File i goes to replica i % n_dbs; every replica has its

@@ -18,7 +18,8 @@ class _ReadBatch(C.Structure):
 
 class _MatchOpts(C.Structure):
     _fields_ = [("filtered_path", C.c_char_p), ("kraken_out_path", C.c_char_p), ("write_all", C.c_int32),
-                ("taxids", C.POINTER(C.c_char_p)), ("batch_reads", C.c_int64), ("with_probs", C.c_int32)]
+                ("taxids", C.POINTER(C.c_char_p)), ("batch_reads", C.c_int64), ("with_probs", C.c_int32),
+                ("max_contig_desc", C.c_void_p), ("max_contig_desc_stride", C.c_int32)]
 
 
 class Totals(C.Structure):
@@ -48,6 +49,7 @@ def lib():
         "gs_fastq_totals": (ci, [vp, vp, vp, vp]), "gs_fastq_close": (ci, [vp]),
         "gs_host_match_files": (ci, [vp, vp, vp, ci, vp, vp, vp, vp]),
         "gs_host_match_into": (ci, [vp, vp, vp, ci, vp, vp, vp]),
+        "gs_host_match_run": (ci, [vp, vp, vp, ci, vp, vp]),
         "gs_host_match_files_multi": (ci, [vp, ci, vp, vp, ci, vp, vp, vp]),
         "gs_host_stat": (C.c_int64, [ci]),
         "gs_host_release_pools": (ci, []),
@@ -127,21 +129,26 @@ def release_pools():
 
 
 def match_files(store, paths, config=None, filtered_path=None, kraken_out_path=None, write_all=True, taxids=None,
-                batch_reads=0, with_probs=False):
+                batch_reads=0, with_probs=False, max_contig_desc=False):
     """FastqKMerMatcher.runMatcher over files: returns (table, dtable, Totals); with_probs = the reference's withProbs
-    (written reads keep their quality lines)"""
+    (written reads keep their quality lines); max_contig_desc=True: a fourth result, the names of the reads that hold the longest
+    contigs (list of bytes per value index)"""
     cfg = (config or _b.MatchConfig())._c()
     parr = _cstr_array(list(paths))
     tarr = _cstr_array(taxids)
+    nv = store.n_values
+    stride = 128
+    descs = np.zeros((nv, stride), dtype=np.uint8) if max_contig_desc else None
     opts = _MatchOpts(None if filtered_path is None else str(filtered_path).encode(),
                       None if kraken_out_path is None else str(kraken_out_path).encode(), int(write_all),
-                      tarr, batch_reads, int(with_probs))
-    nv = store.n_values
+                      tarr, batch_reads, int(with_probs), None if descs is None else descs.ctypes.data_as(C.c_void_p), stride)
     table = np.zeros((nv, _b.N_COLS), dtype=np.int64)
     dtable = np.zeros((nv, _b.N_DCOLS), dtype=np.float64)
     tot = Totals()
     _check(lib().gs_host_match_files(store.h, C.byref(cfg), parr, len(paths), C.byref(opts),
                                      table.ctypes.data_as(C.c_void_p), dtable.ctypes.data_as(C.c_void_p), C.byref(tot)))
+    if descs is not None:
+        return table, dtable, tot, [bytes(row).split(b"\0", 1)[0] for row in descs]
     return table, dtable, tot
 
 

@@ -396,6 +396,10 @@ int gs_match_segments_fetch(gs_run *run, int32_t *codes, int32_t *starts);
  * the filtered FASTQ and the Kraken-style lines from its copy of the raw text.  Both synchronise. */
 int gs_match_segments_text(gs_run *run, uint64_t *seg_off);
 int gs_match_text_newlines(gs_run *run, uint32_t *newlines);
+/* ... and the descriptor LINES (the '@' included) of n of that chunk's records (0-based in the chunk), each into `stride` bytes of
+ * host memory, NUL-terminated, cut to fit: what a host that never sees the reads needs for CountsPerTaxid.maxContigDescriptor
+ * (C/match/FastqKMerMatcher.java:401-407) once gs_match_max_contig_reads has named the reads.  Synchronises. */
+int gs_match_text_descriptors(gs_run *run, const int64_t *records, int32_t n, uint8_t *out, int32_t stride);
 /* After a FASTA or general-FASTQ chunk: bounds[0 .. n_records] of its reads in the gathered sequence buffer, i.e. the read
  * lengths (bounds[r + 1] - bounds[r]); waits for the chunk. */
 int gs_match_text_read_bounds(gs_run *run, uint64_t *bounds);

@@ -57,6 +57,12 @@ typedef struct {
     int64_t batch_reads;           /* 0 = default (1 Mi reads)                                                 */
     int32_t with_probs;            /* withProbs (C/GSConfigKey.java:364): written reads keep their quality line(s)
                                       (ReadEntry.write, AbstractFastqReader.java:570-584) instead of '~' x length */
+    uint8_t *max_contig_desc;      /* NULL, or n_values x max_contig_desc_stride bytes: per value index the name of the read
+                                      that holds the longest contig (CountsPerTaxid.maxContigDescriptor, FastqKMerMatcher.java
+                                      :401-407: the descriptor behind its first character up to the first blank), NUL-terminated,
+                                      cut to fit; empty when there is none.  Costs one synchronisation per chunk.  Reads of FASTA /
+                                      multi-line FASTQ chunks that the device parsed leave the name empty.              */
+    int32_t max_contig_desc_stride;
 } gs_host_match_opts;
 
 typedef struct {
@@ -68,6 +74,12 @@ typedef struct {
 /* processes the files in order with ONE gs_run (begin..finish); table/dtable as gs_match_finish */
 int gs_host_match_files(gs_db *db, const gs_match_cfg *cfg, const char *const *paths, int n_paths,
                         const gs_host_match_opts *opts, int64_t *table, double *dtable, gs_host_totals *totals);
+
+/* The same into a run the caller began and will finish (gs_match_begin ... gs_match_finish), per-read outputs included: what a
+ * host that keeps ONE run per matcher calls once per runMatcher -- java/src/.../match/GpuFastqKMerMatcher.java: a store allows one
+ * unique-counting run at a time, and the matcher's own run is it.  Read numbers run over the files in order, from 0. */
+int gs_host_match_run(gs_run *run, gs_db *db, const char *const *paths, int n_paths, const gs_host_match_opts *opts,
+                      gs_host_totals *totals);
 
 /* The files of a run into a gs_run that the caller began and will finish -- for one-process-per-GPU runs that share
  * the files of a sample (genestrip_amd/distributed.py: match_files_sharded): every process takes some of the files,

@@ -8,9 +8,15 @@
  * The device copy replicates the bit array and the hash factors exactly, so false positives are identical.
  *
  * Hook: GpuFilterGoal.makeFile constructs this class where FilterGoal.makeFile (goals/FilterGoal.java:80-108) constructs
- * the FastqBloomFilter.  Reads are batched in nextEntry(); the accept flags come back per batch and the reads are
- * rewritten in input order exactly like the reference's nextEntry (FastqBloomFilter.java:92-105).  The two output
- * streams of the reference are private, so runFilter is overridden with streams of its own.
+ * the FastqBloomFilter.  Two flows, chosen per runFilter call:
+ *   FILES -- every resource is a local file (StreamingFileResource): runFilter hands the paths to gs_host_filter_files
+ *     (GsGpuNative.hostFilterFiles) and the whole goal runs below the JVM: gzip input inflated on the device, the filter on the
+ *     device text, accepted / dumped records gathered AND gzip-compressed on the device (gzipFastqOutput is the default,
+ *     GSConfigKey.java:155), only compressed bytes cross PCIe: 11 Gbp/s gz -> gz at 100 M reads.
+ *   STREAMS -- anything else: reads are batched in nextEntry(); the accept flags come back per batch and the reads are rewritten
+ *     in input order exactly like the reference's nextEntry (FastqBloomFilter.java:92-105) -- at the speed of the reference's
+ *     parser thread (0.2-0.7 Gbp/s).  The two output streams of the reference are private, so runFilter is overridden with streams
+ *     of its own.
  */
 package org.metagene.genestrip.bloom;
 
@@ -27,6 +33,8 @@ import org.metagene.genestrip.DefaultExecutionContext;
 import org.metagene.genestrip.ExecutionContext;
 import org.metagene.genestrip.gpu.GsGpuNative;
 import org.metagene.genestrip.io.StreamProvider;
+import org.metagene.genestrip.io.StreamingFileResource;
+import org.metagene.genestrip.io.StreamingResource;
 import org.metagene.genestrip.io.StreamingResourceStream;
 
 public class GpuFastqBloomFilter extends FastqBloomFilter {
@@ -37,6 +45,7 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 	private final int kk;
 	private final int minPos;
 	private final double ratio;
+	private final boolean keepQualities;
 	private final ByteBuffer seq = ByteBuffer.allocateDirect(BATCH_BYTES).order(ByteOrder.nativeOrder());
 	private final ByteBuffer offsets = ByteBuffer.allocateDirect(8 * (BATCH_READS + 1)).order(ByteOrder.nativeOrder());
 	private final ByteBuffer accept = ByteBuffer.allocateDirect(BATCH_READS);
@@ -51,6 +60,7 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 		this.kk = k;
 		this.minPos = minPosCount;
 		this.ratio = positiveRatio;
+		this.keepQualities = withProbs;
 		if (filter.bitVector.isLarge()) {
 			throw new UnsupportedOperationException("index filters beyond 2^31 words: hand largeBits over segment by segment");
 		}
@@ -61,8 +71,30 @@ public class GpuFastqBloomFilter extends FastqBloomFilter {
 		bloom = GsGpuNative.bloomCreate(device, kind, filter.bits, filter.hashes, filter.hashFactors, w, words.length);
 	}
 
+	/** the paths of the resources if every one of them is a local FASTQ file, else null (FASTA resources take the STREAMS flow too) */
+	private String[] localFiles(StreamingResourceStream fastqs) {
+		List<String> paths = new ArrayList<>();
+		for (StreamingResource r : fastqs) {
+			if (!(r instanceof StreamingFileResource) || isFastaStream(r)) {
+				return null;
+			}
+			paths.add(((StreamingFileResource) r).getFile().getPath());
+		}
+		return paths.toArray(new String[0]);
+	}
+
 	@Override
 	public void runFilter(StreamingResourceStream fastqs, File filteredFile, File restFile) throws IOException {
+		String[] files = localFiles(fastqs);
+		if (files != null) { // FILES flow: FastqBloomFilter.runFilter (:80-89) in one native call
+			long[] totals = new long[4];
+			GsGpuNative.hostFilterFiles(bloom, kk, minPos, ratio, files, filteredFile == null ? null : filteredFile.getPath(),
+					restFile == null ? null : restFile.getPath(), keepQualities, totals);
+			totalReads = totals[0];
+			totalKMers = totals[1];
+			totalBPs = totals[2];
+			return;
+		}
 		try (OutputStream a = filteredFile != null ? StreamProvider.getOutputStreamForFile(filteredFile) : null;
 				OutputStream r = restFile != null ? StreamProvider.getOutputStreamForFile(restFile) : null) {
 			accepted = a;

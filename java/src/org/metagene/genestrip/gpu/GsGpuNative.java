@@ -132,6 +132,38 @@ public final class GsGpuNative {
 	public static native void filterSubmit(long bloom, int k, int minPosCount, double positiveRatio, ByteBuffer seq,
 			ByteBuffer offsets, long nReads, ByteBuffer accept);
 
+	/**
+	 * gs_host_match_files (include/gshost.h): one runMatcher over LOCAL FILES below the JVM -- file, gunzip (on the device), record
+	 * scan, kernels, per-read outputs (gathered and gzip-compressed on the device) -- with a run of its own.  paths: the FASTQ /
+	 * FASTA files in order; filteredPath / krakenOutPath: null = off, a name ending in .gz / .gzip is written gzip (BGZF members);
+	 * taxids: tax id per value index (needed for Kraken-style lines, else null); table / dtable as matchFinish; maxContigDesc: null,
+	 * or nValues x descStride bytes that receive CountsPerTaxid.maxContigDescriptor per value index (NUL-terminated);
+	 * totals[4] = totalReads, totalKMers, totalBPs, reads written to filteredPath.
+	 */
+	public static native void hostMatchFiles(long db, boolean classify, boolean countUnique, int maxPaths, int threshold,
+			double maxReadTaxErr, double maxReadClassErr, int maxKmerResCounts, String[] paths, String filteredPath,
+			String krakenOutPath, boolean writeAll, String[] taxids, boolean withProbs, ByteBuffer table, ByteBuffer dtable,
+			ByteBuffer maxContigDesc, int descStride, long[] totals);
+
+	/** gs_host_match_run: the same into the matcher's own run -- matchReset before, matchFinish (and matchMaxCounts) after */
+	public static native void hostMatchRun(long run, long db, String[] paths, String filteredPath, String krakenOutPath,
+			boolean writeAll, String[] taxids, boolean withProbs, ByteBuffer maxContigDesc, int descStride, long[] totals);
+
+	/** gs_host_match_into: some of a sample's files into a run that is merged with the runs of other GPUs (matchMerge) before
+	 *  matchFinish; fileIndex[i] = position of paths[i] in the sample's file order, readsOfFile[i] receives its read count */
+	public static native void hostMatchInto(long run, long db, String[] paths, int[] fileIndex, long[] readsOfFile, long[] totals);
+
+	/** gs_host_filter_files: one runFilter over local files; filteredPath / restPath: null = off, .gz = gzip; totals as above
+	 *  (totals[3] = accepted reads) */
+	public static native void hostFilterFiles(long bloom, int k, int minPosCount, double positiveRatio, String[] paths,
+			String filteredPath, String restPath, boolean withProbs, long[] totals);
+
+	/** gs_host_last_error: the message of the last failure inside the host layer on this thread */
+	public static native String hostLastError();
+
+	/** gs_host_release_pools: page-locked blocks and device decoders the host layer keeps from call to call go back to the system */
+	public static native void hostReleasePools();
+
 	// column indices of the integer table (include/gsgpu.h, GS_C_*)
 	public static final int C_READS = 0, C_READS_KMERS = 1, C_KMERS = 2, C_UNIQUE_KMERS = 3, C_CONTIGS = 4,
 			C_CONTIG_LEN_SQ_SUM = 5, C_MAX_CONTIG_LEN = 6, C_READS_1KMER = 7, C_READS_BPS = 8,

@@ -6,12 +6,17 @@
  * It lives in the reference's own package because it fills the protected CountsPerTaxid fields
  * (CountsPerTaxid.java:127-159) and the protected statsIndex array (FastqKMerMatcher.java:76).
  *
- * How it hooks in (all seams are the reference's own virtual methods):
- *   - the parser stays the reference's (AbstractFastqReader.doReadFastq); with a zero-consumer execution context it
- *     calls nextEntry -> matchRead(entry, 0) on the producer thread (AbstractFastqReader.java:350-352);
- *   - matchRead() only appends the read to a direct-buffer batch; a full batch goes to gs_match_submit, and the
- *     per-read outcome (class, flags, Kraken-style runs) drives the same writeback afterMatch does
- *     (FastqKMerMatcher.java:304-315), in input order;
+ * How it hooks in (all seams are the reference's own virtual methods).  Two flows, chosen per runMatcher call:
+ *   FILES -- every resource of the StreamingResourceStream is a local file (StreamingFileResource: the normal case, `-f reads.fastq.gz`):
+ *     processFastqStreams() hands the paths to gs_host_match_run (GsGpuNative.hostMatchRun) and the whole pipeline runs below the JVM:
+ *     file -> gunzip on the device -> record scan -> match kernel -> filtered FASTQ gathered and gzip-compressed on the device,
+ *     Kraken-style lines formatted by the host layer's threads; 11-19 Gbp/s.  The reference's parser never runs.
+ *   STREAMS -- anything else (URL resources): the parser stays the reference's (AbstractFastqReader.doReadFastq, one thread behind
+ *     GZIPInputStream: 0.2-0.7 Gbp/s, which is what this flow delivers whatever the GPU does); with a zero-consumer execution
+ *     context it calls nextEntry -> matchRead(entry, 0) on the producer thread (AbstractFastqReader.java:350-352);
+ *   - matchRead() only appends the read to one of TWO page-locked batches; a full batch goes to gs_match_submit_async, the parser
+ *     fills the other one meanwhile, and the per-read outcome (class, flags, Kraken-style runs) of the batch before drives the
+ *     same writeback afterMatch does (FastqKMerMatcher.java:304-315), in input order;
  *   - processFastqStreams() flushes the last batch and turns the device table into CountsPerTaxid objects before
  *     runMatcher() collects them (FastqKMerMatcher.java:199-204);
  *   - unique k-mer counts come from the device, so runMatcher() is called without a KMerUniqueCounterBits and the
@@ -31,6 +36,8 @@ import java.util.Arrays;
 import org.metagene.genestrip.DefaultExecutionContext;
 import org.metagene.genestrip.ExecutionContext;
 import org.metagene.genestrip.gpu.GsGpuNative;
+import org.metagene.genestrip.io.StreamingFileResource;
+import org.metagene.genestrip.io.StreamingResource;
 import org.metagene.genestrip.io.StreamingResourceStream;
 import org.metagene.genestrip.store.KMerStore;
 import org.metagene.genestrip.store.KMerUniqueCounterBits;
@@ -41,6 +48,31 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	private static final int BATCH_READS = 1 << 20;
 	private static final int BATCH_BYTES = 256 << 20;
 	private static final long UPLOAD_SLICE = 1L << 26; // entries per direct-buffer slice of the store hand-over
+	private static final int DESC_STRIDE = 256;        // bytes per value index for the names of the max-contig reads (FILES flow)
+	private static final String[] FASTA_SUFFIXES = { "fasta", "fa", "fna", "fas" }; // (+ .gz / .gzip: FastqMapGoal.java:64)
+
+	/** everything one batch of the STREAMS flow carries: page-locked device-facing buffers + the host-side copies for the writeback */
+	private static final class Batch {
+		final ByteBuffer seq = GsGpuNative.pinnedAlloc(BATCH_BYTES).order(ByteOrder.nativeOrder());
+		final ByteBuffer offsets = GsGpuNative.pinnedAlloc(8L * (BATCH_READS + 1)).order(ByteOrder.nativeOrder());
+		final ByteBuffer classVi = GsGpuNative.pinnedAlloc(4L * BATCH_READS).order(ByteOrder.nativeOrder());
+		final ByteBuffer flags = GsGpuNative.pinnedAlloc(BATCH_READS);
+		// descriptors (and qualities, if they are written) of the batch, for the writeback after the submit
+		byte[] descs = new byte[64 * 1024 * 1024];
+		byte[] quals = new byte[0];
+		final int[] descOff = new int[BATCH_READS + 1];
+		final int[] qualOff = new int[BATCH_READS + 1];
+		int reads;
+		long firstReadNo;
+		long ticket = -1; // of the submit that is under way (-1: none)
+
+		void free() {
+			GsGpuNative.pinnedFree(seq);
+			GsGpuNative.pinnedFree(offsets);
+			GsGpuNative.pinnedFree(classVi);
+			GsGpuNative.pinnedFree(flags);
+		}
+	}
 
 	private final long db;
 	private final long run;
@@ -48,23 +80,19 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	private final boolean keepQualities;
 	private final SmallTaxIdNode[] nodeOfValue; // value index -> tree node (null: value without node)
 	private final byte[][] taxidBytes;          // value index -> tax id as bytes (Kraken-style lines)
+	private final String[] taxidStrings;        // the same as strings (gs_host_match_opts.taxids)
 
-	private final ByteBuffer seq = direct(BATCH_BYTES);
-	private final ByteBuffer offsets = direct(8L * (BATCH_READS + 1));
-	private final ByteBuffer classVi = direct(4L * BATCH_READS);
-	private final ByteBuffer flags = direct(BATCH_READS);
+	private Batch[] batches;  // STREAMS flow only (allocated on first use)
+	private int filling;      // the batch matchRead appends to
 	private final ByteBuffer segOff = direct(8L * (BATCH_READS + 1));
 	private final ByteBuffer maxReadNo;
 	private ByteBuffer segCodes = direct(4L << 20), segStarts = direct(4L << 20);
-	// descriptors (and qualities, if they are written) of the batch, for the writeback after the submit
-	private byte[] descs = new byte[64 << 20], quals = new byte[0];
-	private final int[] descOff = new int[BATCH_READS + 1], qualOff = new int[BATCH_READS + 1];
-	private int batchReads;
-	private long batchFirstReadNo;
 	private long globalReadNo; // file-order read number over all files of this runMatcher call
 	private long[] uniqueCounts;
 	private short[][] maxCounts;
 	private final byte[][] maxContigDescriptor; // per value index: descriptor of the read that holds the longest contig
+	// FILES flow: the output files of the current runMatcher call (written below the JVM)
+	private File nativeFiltered, nativeKraken;
 
 	public GpuFastqKMerMatcher(KMerStore<SmallTaxIdNode> kmerStore, int initialReadSize, int maxQueueSize,
 			ExecutionContext bundle, boolean withProbs, int maxKmerResCounts, SmallTaxTree taxTree, int maxPaths,
@@ -79,6 +107,7 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		keepQualities = withProbs;
 		nodeOfValue = new SmallTaxIdNode[nValues];
 		taxidBytes = new byte[nValues][];
+		taxidStrings = new String[nValues];
 		maxContigDescriptor = new byte[nValues][];
 		maxReadNo = direct(8L * nValues);
 		db = upload(kmerStore, taxTree, device);
@@ -112,7 +141,8 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		});
 		for (int v = 0; v < nValues; v++) {
 			nodeOfValue[v] = store.getValueForIndex(v);
-			taxidBytes[v] = nodeOfValue[v] == null ? null : nodeOfValue[v].getTaxId().getBytes(StandardCharsets.UTF_8);
+			taxidStrings[v] = nodeOfValue[v] == null ? "" : nodeOfValue[v].getTaxId();
+			taxidBytes[v] = nodeOfValue[v] == null ? null : taxidStrings[v].getBytes(StandardCharsets.UTF_8);
 		}
 		ByteBuffer parent = null;
 		if (tree != null) {
@@ -126,6 +156,41 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		return GsGpuNative.dbCreate(device, store.getK(), n, kmers, vidx, nValues, parent);
 	}
 
+	/**
+	 * The paths of the resources if EVERY one of them is a local file whose type the host layer decides as the reference does
+	 * (FASTA by suffix: FastqMapGoal.java:64, 188-201; gzip by content), else null: the STREAMS flow.
+	 */
+	private String[] localFiles(StreamingResourceStream fastqs) {
+		java.util.List<String> paths = new java.util.ArrayList<>();
+		for (StreamingResource r : fastqs) {
+			if (!(r instanceof StreamingFileResource)) {
+				return null;
+			}
+			File f = ((StreamingFileResource) r).getFile();
+			if (isFastaStream(r) != hasFastaName(f.getName())) {
+				return null;
+			}
+			paths.add(f.getPath());
+		}
+		return paths.toArray(new String[0]);
+	}
+
+	private static boolean hasFastaName(String name) {
+		String n = name.toLowerCase();
+		for (String gz : new String[] { ".gzip", ".gz" }) {
+			if (n.endsWith(gz)) {
+				n = n.substring(0, n.length() - gz.length());
+				break;
+			}
+		}
+		for (String suffix : FASTA_SUFFIXES) {
+			if (n.endsWith("." + suffix)) {
+				return true;
+			}
+		}
+		return false;
+	}
+
 	@Override
 	public MatchingResult runMatcher(StreamingResourceStream fastqs, File filteredFile, File krakenOutStyleFile,
 			KMerUniqueCounterBits uniqueCounter) throws IOException {
@@ -134,8 +199,14 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		uniqueCounts = null;
 		maxCounts = null;
 		Arrays.fill(maxContigDescriptor, null);
-		// the base class opens `indexed` / `out`, runs processFastqStreams (overridden below) and collects statsIndex
-		MatchingResult res = super.runMatcher(fastqs, filteredFile, krakenOutStyleFile, null);
+		final boolean files = localFiles(fastqs) != null;
+		// FILES: the output files are written below the JVM, so the base class must not open them; STREAMS: the base class opens
+		// `indexed` / `out`.  Either way it runs processFastqStreams (overridden below) and collects statsIndex.
+		nativeFiltered = files ? filteredFile : null;
+		nativeKraken = files ? krakenOutStyleFile : null;
+		MatchingResult res = super.runMatcher(fastqs, files ? null : filteredFile, files ? null : krakenOutStyleFile, null);
+		nativeFiltered = null;
+		nativeKraken = null;
 		for (int vi = 0; vi < nValues; vi++) {
 			CountsPerTaxid stats = statsIndex[vi];
 			if (stats != null) {
@@ -150,68 +221,127 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 
 	@Override
 	public void processFastqStreams(StreamingResourceStream fastqs) throws IOException {
-		super.processFastqStreams(fastqs);
-		flush();
+		String[] files = localFiles(fastqs);
+		if (files != null) {
+			// FILES flow: one native call does what the loop of AbstractLoggingFastqStreamer.processFastqStreams (:95-131) does
+			ByteBuffer descs = direct((long) nValues * DESC_STRIDE);
+			long[] totals = new long[4];
+			GsGpuNative.hostMatchRun(run, db, files, nativeFiltered == null ? null : nativeFiltered.getPath(),
+					nativeKraken == null ? null : nativeKraken.getPath(), writeAll, taxidStrings, keepQualities, descs,
+					DESC_STRIDE, totals);
+			totalReads = totals[0];
+			totalKMers = totals[1];
+			totalBPs = totals[2];
+			byte[] row = new byte[DESC_STRIDE];
+			for (int vi = 0; vi < nValues; vi++) {
+				descs.position(vi * DESC_STRIDE);
+				descs.get(row);
+				int n = 0;
+				while (n < DESC_STRIDE && row[n] != 0) {
+					n++;
+				}
+				maxContigDescriptor[vi] = n == 0 ? null : Arrays.copyOf(row, n);
+			}
+		} else {
+			super.processFastqStreams(fastqs);
+			drain();
+		}
 		fillStatsFromDevice();
 	}
 
 	@Override
 	protected void readFastq(InputStream inputStream, boolean fasta) throws IOException {
 		super.readFastq(inputStream, fasta);
-		flush(); // the writeback of a file's last reads belongs before the next file starts
+		drain(); // the writeback of a file's last reads belongs before the next file starts
+	}
+
+	private Batch batch() {
+		if (batches == null) {
+			batches = new Batch[] { new Batch(), new Batch() };
+		}
+		return batches[filling];
 	}
 
 	/** Called by the (final) nextEntry for every parsed read; only batches the read. */
 	@Override
 	protected boolean matchRead(final MatcherReadEntry entry, final int index) {
 		final boolean outputs = indexed != null || out != null;
-		if (batchReads == BATCH_READS || seq.remaining() < entry.readSize
-				|| descOff[batchReads] + entry.readDescriptorSize > descs.length) {
+		Batch b = batch();
+		if (b.reads == BATCH_READS || b.seq.remaining() < entry.readSize
+				|| b.descOff[b.reads] + entry.readDescriptorSize > b.descs.length) {
 			try {
-				flush();
+				submit();
 			} catch (IOException e) {
 				throw new RuntimeException(e);
 			}
+			b = batch();
 		}
-		if (batchReads == 0) {
-			batchFirstReadNo = globalReadNo;
-			offsets.clear();
-			offsets.putLong(0);
-			descOff[0] = 0;
-			qualOff[0] = 0;
+		if (b.reads == 0) {
+			b.firstReadNo = globalReadNo;
+			b.seq.clear();
+			b.offsets.clear();
+			b.offsets.putLong(0);
+			b.descOff[0] = 0;
+			b.qualOff[0] = 0;
 		}
-		seq.put(entry.read, 0, entry.readSize);
-		offsets.putLong(seq.position());
+		b.seq.put(entry.read, 0, entry.readSize);
+		b.offsets.putLong(b.seq.position());
 		// descriptors are kept for every batch: the longest contig of a tax id may turn up in any read
-		System.arraycopy(entry.readDescriptor, 0, descs, descOff[batchReads], entry.readDescriptorSize);
-		descOff[batchReads + 1] = descOff[batchReads] + entry.readDescriptorSize;
-		int q = qualOff[batchReads];
+		System.arraycopy(entry.readDescriptor, 0, b.descs, b.descOff[b.reads], entry.readDescriptorSize);
+		b.descOff[b.reads + 1] = b.descOff[b.reads] + entry.readDescriptorSize;
+		int q = b.qualOff[b.reads];
 		if (outputs && keepQualities && entry.readProbs != null && entry.readProbsSize >= 0) {
-			if (q + entry.readProbsSize > quals.length) {
-				quals = Arrays.copyOf(quals, Math.max(2 * quals.length, q + entry.readProbsSize + (1 << 20)));
+			if (q + entry.readProbsSize > b.quals.length) {
+				b.quals = Arrays.copyOf(b.quals, Math.max(2 * b.quals.length, q + entry.readProbsSize + (1 << 20)));
 			}
-			System.arraycopy(entry.readProbs, 0, quals, q, entry.readProbsSize);
+			System.arraycopy(entry.readProbs, 0, b.quals, q, entry.readProbsSize);
 			q += entry.readProbsSize;
 		}
-		qualOff[batchReads + 1] = q;
-		batchReads++;
+		b.qualOff[b.reads + 1] = q;
+		b.reads++;
 		globalReadNo++;
 		return false; // the per-read outcome arrives with the batch: afterMatch below has nothing to do per read
 	}
 
 	@Override
 	protected void afterMatch(MatcherReadEntry myEntry, boolean found) throws IOException {
-		// the writeback happens per batch in flush(): it needs the outcome of the device
+		// the writeback happens per batch in complete(): it needs the outcome of the device
 	}
 
-	private void flush() throws IOException {
-		if (batchReads == 0) {
+	/**
+	 * The batch that was being filled goes to the device (gs_match_submit_async: returns at once, its copy runs under the kernel
+	 * of the batch before); the OTHER batch -- submitted one call earlier -- is waited for and written back; the parser then
+	 * refills it while this one is on the device.
+	 */
+	private void submit() throws IOException {
+		Batch b = batch();
+		if (b.reads == 0) {
 			return;
 		}
-		GsGpuNative.matchSubmit(run, seq, offsets, batchReads, batchFirstReadNo, classVi, flags);
+		b.ticket = GsGpuNative.matchSubmitAsync(run, b.seq, b.offsets, b.reads, b.firstReadNo, b.classVi, b.flags);
+		filling ^= 1;
+		complete(batches[filling]);
+	}
+
+	/** both batches through: at the end of a file and of the run */
+	private void drain() throws IOException {
+		if (batches == null) {
+			return;
+		}
+		submit();                     // what is being filled (its predecessor is completed inside)
+		complete(batches[filling ^ 1]); // ... and the one that was just submitted
+	}
+
+	/** waits for the batch's outcome, then does for its reads what afterMatch does per read */
+	private void complete(Batch b) throws IOException {
+		if (b.ticket < 0) {
+			return;
+		}
+		GsGpuNative.matchWait(run, b.ticket);
+		b.ticket = -1;
 		if (out != null) {
-			GsGpuNative.matchSegments(run, seq, offsets, batchReads, segOff);
-			long nSeg = segOff.getLong(8 * batchReads);
+			GsGpuNative.matchSegments(run, b.seq, b.offsets, b.reads, segOff);
+			long nSeg = segOff.getLong(8 * b.reads);
 			if (4 * nSeg > segCodes.capacity()) {
 				segCodes = direct(8 * nSeg);
 				segStarts = direct(8 * nSeg);
@@ -221,26 +351,25 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 		// maxContigDescriptor (FastqKMerMatcher.java:401-407): the read that holds a tax id's longest contig right now
 		GsGpuNative.matchMaxContigReads(run, maxReadNo);
 		for (int vi = 0; vi < nValues; vi++) {
-			long r = maxReadNo.getLong(8 * vi) - batchFirstReadNo;
-			if (r >= 0 && r < batchReads) {
+			long r = maxReadNo.getLong(8 * vi) - b.firstReadNo;
+			if (r >= 0 && r < b.reads) {
 				int i = (int) r;
-				int end = indexOfBlank(descs, descOff[i] + 1, descOff[i + 1]);
-				maxContigDescriptor[vi] = Arrays.copyOfRange(descs, descOff[i] + 1, end); // chars after '@' up to the first blank
+				int end = indexOfBlank(b.descs, b.descOff[i] + 1, b.descOff[i + 1]);
+				maxContigDescriptor[vi] = Arrays.copyOfRange(b.descs, b.descOff[i] + 1, end); // chars after '@' up to the first blank
 			}
 		}
-		for (int i = 0; i < batchReads; i++) {
-			int f = flags.get(i);
-			int cls = classVi.getInt(4 * i);
+		for (int i = 0; i < b.reads; i++) {
+			int f = b.flags.get(i);
+			int cls = b.classVi.getInt(4 * i);
 			if ((f & GsGpuNative.F_RETURNED) != 0 && indexed != null) {
-				writeRead(indexed, i); // rewriteInput(myEntry, indexed) of afterMatch
+				writeRead(indexed, b, i); // rewriteInput(myEntry, indexed) of afterMatch
 				updateWriteStats();
 			}
 			if (out != null && (writeAll || cls >= 0)) {
-				writeKrakenLine(out, i, cls);
+				writeKrakenLine(out, b, i, cls);
 			}
 		}
-		seq.clear();
-		batchReads = 0;
+		b.reads = 0;
 	}
 
 	private static int indexOfBlank(byte[] a, int from, int to) {
@@ -253,20 +382,20 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	}
 
 	/** ReadEntry.write (AbstractFastqReader.java:570-584) for read i of the batch */
-	private void writeRead(OutputStream o, int i) throws IOException {
-		int s0 = (int) offsets.getLong(8 * i), s1 = (int) offsets.getLong(8 * (i + 1));
+	private void writeRead(OutputStream o, Batch b, int i) throws IOException {
+		int s0 = (int) b.offsets.getLong(8 * i), s1 = (int) b.offsets.getLong(8 * (i + 1));
 		byte[] line = new byte[s1 - s0];
-		o.write(descs, descOff[i], descOff[i + 1] - descOff[i]);
+		o.write(b.descs, b.descOff[i], b.descOff[i + 1] - b.descOff[i]);
 		o.write('\n');
 		for (int j = 0; j < line.length; j++) {
-			line[j] = seq.get(s0 + j);
+			line[j] = b.seq.get(s0 + j);
 		}
 		o.write(line);
 		o.write('\n');
 		o.write('+');
 		o.write('\n');
-		if (qualOff[i + 1] > qualOff[i]) {
-			o.write(quals, qualOff[i], qualOff[i + 1] - qualOff[i]);
+		if (b.qualOff[i + 1] > b.qualOff[i]) {
+			o.write(b.quals, b.qualOff[i], b.qualOff[i + 1] - b.qualOff[i]);
 		} else {
 			Arrays.fill(line, (byte) '~');
 			o.write(line);
@@ -275,17 +404,17 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	}
 
 	/** MatcherReadEntry.writeMatchDetails (FastqKMerMatcher.java:723-756) from the device's runs of read i */
-	private void writeKrakenLine(OutputStream o, int i, int cls) throws IOException {
+	private void writeKrakenLine(OutputStream o, Batch b, int i, int cls) throws IOException {
 		long s0 = segOff.getLong(8 * i), s1 = segOff.getLong(8 * (i + 1));
 		if (s1 == s0) {
 			return; // no k-mer position: the reference has no buffer for this read
 		}
-		int len = (int) (offsets.getLong(8 * (i + 1)) - offsets.getLong(8 * i));
+		int len = (int) (b.offsets.getLong(8 * (i + 1)) - b.offsets.getLong(8 * i));
 		int max = len - k + 1;
 		StringBuilder sb = new StringBuilder();
 		sb.append(cls >= 0 ? 'C' : 'U').append('\t');
-		int end = indexOfBlank(descs, descOff[i] + 1, descOff[i + 1]);
-		sb.append(new String(descs, descOff[i] + 1, end - descOff[i] - 1, StandardCharsets.ISO_8859_1)).append('\t');
+		int end = indexOfBlank(b.descs, b.descOff[i] + 1, b.descOff[i + 1]);
+		sb.append(new String(b.descs, b.descOff[i] + 1, end - b.descOff[i] - 1, StandardCharsets.ISO_8859_1)).append('\t');
 		sb.append(cls >= 0 ? new String(taxidBytes[cls], StandardCharsets.UTF_8) : "0").append('\t').append(len).append('\t');
 		for (long s = s0; s < s1; s++) {
 			int code = segCodes.getInt((int) (4 * s));
@@ -349,6 +478,12 @@ public class GpuFastqKMerMatcher extends FastqKMerMatcher {
 	}
 
 	public void close() {
+		if (batches != null) {
+			for (Batch b : batches) {
+				b.free();
+			}
+			batches = null;
+		}
 		GsGpuNative.matchDestroy(run);
 		GsGpuNative.dbDestroy(db);
 	}

@@ -14,6 +14,8 @@ typedef jobject jclass;
 typedef jobject jstring;
 typedef jobject jarray;
 typedef jarray jlongArray;
+typedef jarray jintArray;
+typedef jarray jobjectArray;
 typedef jobject jthrowable;
 #define JNIEXPORT
 #define JNICALL
@@ -31,5 +33,10 @@ struct JNINativeInterface_ {
     void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);
     const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
     void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
+    jobject (*GetObjectArrayElement)(JNIEnv *, jobjectArray, jsize);
+    void (*DeleteLocalRef)(JNIEnv *, jobject);
+    jint *(*GetIntArrayElements)(JNIEnv *, jintArray, jboolean *);
+    void (*ReleaseIntArrayElements)(JNIEnv *, jintArray, jint *, jint);
+    jstring (*NewStringUTF)(JNIEnv *, const char *);
 };
 #endif

@@ -94,7 +94,14 @@ def test_jni_shim_syntax_and_coverage():
             for m in re.finditer(r"JNAME\((\w+)\)\s*\(([^)]*)\)", c, re.S)}
     assert natives == impl, (set(natives) ^ set(impl), {k: (natives[k], impl[k]) for k in natives if k in impl and natives[k] != impl[k]})
     assert len(natives) >= 26
-    header = open(os.path.join(ROOT, "include", "gsgpu.h")).read()
+    header = open(os.path.join(ROOT, "include", "gsgpu.h")).read() + open(os.path.join(ROOT, "include", "gshost.h")).read()
     declared = set(re.findall(r"\b(gs_[a-z_0-9]+)\s*\(", header))
     called = set(re.findall(r"\b(gs_[a-z_0-9]+)\s*\(", c))
     assert called <= declared, called - declared
+    # the file-level flows of the reference's seam (runMatcher / runFilter over local files) are bound (missing 2)
+    for name in ("hostMatchFiles", "hostMatchRun", "hostMatchInto", "hostFilterFiles", "hostLastError"):
+        assert name in natives, name
+    glue = open(os.path.join(ROOT, "java", "src", "org", "metagene", "genestrip", "match", "GpuFastqKMerMatcher.java")).read()
+    assert "GsGpuNative.hostMatchRun(" in glue and "GsGpuNative.matchSubmitAsync(" in glue and "GsGpuNative.matchSubmit(" not in glue
+    glue = open(os.path.join(ROOT, "java", "src", "org", "metagene", "genestrip", "bloom", "GpuFastqBloomFilter.java")).read()
+    assert "GsGpuNative.hostFilterFiles(" in glue

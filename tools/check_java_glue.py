@@ -213,8 +213,10 @@ def parse_source(src, path, keep_bodies=False):
                 decl = re.sub(r"@\w+(\s*\([^()]*\))?", " ", src[start:i]).strip()
                 cls = top[1]
                 if decl and not decl.startswith(("import", "package")):
-                    head = decl.split("=")[0] if not re.search(r"\)\s*(throws[\w.,\s]+)?$", decl) else decl
-                    if "(" in head and re.search(r"\)\s*(throws[\w.,\s]+)?$", decl):   # abstract / interface method
+                    # (a field whose initialiser ends in a call -- `final ByteBuffer b = alloc(n).order(x);` -- is not a method declaration)
+                    ends_in_paren = bool(re.search(r"\)\s*(throws[\w.,\s]+)?$", decl)) and "=" not in strip_generics(decl.split("(")[0])
+                    head = decl.split("=")[0] if not ends_in_paren else decl
+                    if "(" in head and ends_in_paren:   # abstract / interface method
                         hm = re.search(r"((?:[\w@.<>\[\],?\s]|\([^)]*\))*?)\b(\w+)\s*\((.*)\)\s*(?:throws\s+[\w.,\s]+)?$", decl, re.S)
                         if hm:
                             toks = strip_generics(re.sub(r"@\w+(\([^)]*\))?", " ", hm.group(1))).split()
