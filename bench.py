@@ -49,7 +49,7 @@ K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8            # per GPU: 7 links x 153.6 GB/s bidirectional
-ALL_LEGS = "main,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,files"
+ALL_LEGS = "main,occ,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,files"
 # committed rocprofv3 --pmc summaries per workload, newest first: the fallback when the in-run passes cannot be taken
 PROFILE_ROUNDS = {"match": ("r03", "r02"), "large_store": ("r03", "r02"), "filter": ("r03", "r02")}
 PMC_GROUPS = (
@@ -59,7 +59,8 @@ PMC_GROUPS = (
     "WRITE_SIZE",
     "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE",
 )
-PMC_KERNELS = {"match": r"gs_match_kernel<true", "large_store": r"gs_match_kernel<false", "filter": r"gs_filter_kernel",
+PMC_KERNELS = {"match": r"gs_match_kernel<true", "large_store": r"gs_match_kernel<false, false, 31, false, false, 0>",
+               "huge_store": r"gs_match_kernel<false, false, 31, false, false, 1>", "filter": r"gs_filter_kernel",
                "cal_lines": r"cal_random_lines"}
 CAL_LINES_BYTES = 1 << 30
 
@@ -74,6 +75,15 @@ def _usable_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, int(os.environ.get("GS_CPU_THREADS", n))))
+
+
+def _submit_reads(m, dseq, doff, first, n, read_len=None):
+    """one resident batch to the matcher: the reads are all of one length and lie back to back, so no offsets array is handed over
+    (gs_match_submit_fixed) unless GS_BENCH_OFFSETS=array asks for the general call"""
+    if os.environ.get("GS_BENCH_OFFSETS", "fixed") == "array":
+        m.submit(dseq, doff, first, n_reads=n)
+    else:
+        m.submit_fixed(dseq, READ_LEN if read_len is None else read_len, n, first)
 
 
 class _DevArray:
@@ -107,7 +117,7 @@ def _pmc_child():
         m = ga.FastqKMerMatcher(store)
         for _ in range(2):
             m.reset()
-            m.submit(dseq, doff, 0, n_reads=n)
+            _submit_reads(m, dseq, doff, 0, n)
         m.sync()
         m.close()
         store.close()
@@ -121,8 +131,47 @@ def _pmc_child():
             bloom.close()
         del gen, dseq, doff
         torch.cuda.empty_cache()
+    if os.environ.get("GS_BENCH_PMC_HUGE", "1") != "0":
+        # the 473 M-k-mer store of configs[4] (context-keyed gate: its own instantiation of the kernel), built on the device as leg_huge does
+        store, gen, g = _huge_store(ga, synth, torch, dev)[:3]
+        dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+        doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        synth.reads_device(gen, g.shape[0], g.shape[1], n, dseq, doff, read_len=READ_LEN)
+        torch.cuda.synchronize()
+        m = ga.FastqKMerMatcher(store)
+        for _ in range(2):
+            m.reset()
+            _submit_reads(m, dseq, doff, 0, n)
+        m.sync()
+        m.close()
+        store.close()
+        del gen, dseq, doff
+        torch.cuda.empty_cache()
     r = ga.calibrate(ga.CAL_RANDOM_LINES, CAL_LINES_BYTES)
     print("pmc-child done; cal lines per timed launch %d" % int(r["count"]), flush=True)
+
+
+def _huge_store(ga, synth, torch, dev, genera=250):
+    """~473 M k-mers / 5 251 values built ON THE DEVICE from 5 000 synthetic genomes (gs_dbbuild + the device layout builder)
+    -> (store, genomes on the device, genomes, db, kmers, values, seconds)"""
+    t0 = time.perf_counter()
+    db = synth.SynthDB(k=K, genera=genera, species_per_genus=20, build=False)
+    t_gen = time.perf_counter() - t0
+    g = db.genomes
+    gen = torch.from_numpy(g).to(dev)
+    goff = torch.arange(g.shape[0] + 1, dtype=torch.int64, device=dev) * g.shape[1]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = ga.DeviceDbBuilder(K, db.n_values, db.parent_vi)
+    b.add(gen.reshape(-1), goff, db.species_vi, update=False)
+    b.add(gen.reshape(-1), goff, db.species_vi, update=True)
+    kmers, vals = b.finish()
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    store = b.to_store()
+    t_layout = time.perf_counter() - t0
+    b.close()
+    return store, gen, g, db, kmers, vals, (t_gen, t_build, t_layout)
 
 
 def _sync_filter(ga, bloom):
@@ -242,10 +291,19 @@ def _resources(cnt, kern_ms, n_reads, ceil, footprint_key, src):
         fr["line_requests"] = out["line_requests"]["frac"]
     if "SQ_INSTS_VALU" in cnt:
         v = cnt["SQ_INSTS_VALU"]
+        # the hardware-rate view: against the rate of full-rate 32-bit VALU ops measured in this run (and the guide's 2 cycles per
+        # wave64 op and SIMD at 2.4 GHz); the fraction against the kernel's OWN mix (quarter-rate multiplies, 64-bit shifts) reads
+        # high for any kernel with such ops and is kept as information only (not a demonstrated saturation)
+        guide = ceil["n_cu"] * 4 * 2.4e9 / 2.0 if ceil.get("n_cu") else None
         out["valu_issue"] = {"per_read": round(v / n_reads, 1), "G_winst_per_s": round(v / sec / 1e9, 1),
-                             "ceiling_G_winst_per_s": round(ceil["valu_mix"] / 1e9, 1), "frac": round(v / sec / ceil["valu_mix"], 4),
-                             "note": "wave64 VALU instructions over the rate the calibration kernel with the match kernel's instruction mix "
-                                     "sustains at 8 waves per SIMD (measured in this run)"}
+                             "ceiling_G_winst_per_s": round(ceil.get("valu_pure", ceil["valu_mix"]) / 1e9, 1),
+                             "frac": round(v / sec / ceil.get("valu_pure", ceil["valu_mix"]), 4),
+                             "frac_vs_guide_2_cycles_per_op": round(v / sec / guide, 4) if guide else None,
+                             "frac_vs_own_instruction_mix": round(v / sec / ceil["valu_mix"], 4),
+                             "own_mix_ceiling_G_winst_per_s": round(ceil["valu_mix"] / 1e9, 1),
+                             "note": "wave64 VALU instructions over the measured rate of full-rate 32-bit VALU ops at 8 waves per SIMD (gs_calibrate, "
+                                     "this run); frac_vs_own_instruction_mix prices the same count against a calibration kernel with the match kernel's "
+                                     "mix -- a ceiling defined by the kernel itself, not a hardware rate"}
         fr["valu_issue"] = out["valu_issue"]["frac"]
     if "SQ_INSTS_SALU" in cnt:
         s = cnt["SQ_INSTS_SALU"] + cnt.get("SQ_INSTS_SMEM", 0.0)
@@ -277,7 +335,7 @@ def _name_bound(fr):
     top = max(fr, key=fr.get)
     if fr[top] >= 0.6:
         return top, fr[top], top
-    return top, fr[top], "latency (no resource reaches 0.6 of its measured ceiling; largest: %s)" % top
+    return top, fr[top], "latency / mixed (no resource reaches 0.6 of a hardware-rate ceiling; largest: %s)" % top
 
 
 def _calibrate(ga, footprints):
@@ -507,7 +565,7 @@ def main():
         if partitioned:
             partitioned_match_batch(m, K, dseq, doff, n_reads, first)
             return partitioned_finish(m, t_sums, t_max, t_dsum)
-        m.submit(dseq, doff, first, n_reads=n_reads)
+        _submit_reads(m, dseq, doff, first, n_reads)
         if use_dist:
             m.device_state()  # syncs the library's stream and refreshes the compact unique bitmap (same pointers)
             if rehearsal:  # gloo: merge host copies, write them back, mark the bitmap as merged
@@ -608,6 +666,8 @@ def main():
             roof.update({"achieved": res["line_requests"]["G_per_s"], "peak": res["line_requests"]["ceiling_G_per_s"], "unit": "G lines/s"})
         elif top == "valu_issue":
             roof.update({"achieved": res["valu_issue"]["G_winst_per_s"], "peak": res["valu_issue"]["ceiling_G_winst_per_s"], "unit": "G wave-instructions/s"})
+        elif top == "vmem_address":
+            roof.update({"achieved": res["vmem_address"]["frac"], "peak": 1.0, "unit": "busy fraction of the CUs' vector-memory address units"})
         else:
             roof.update({"achieved": res["salu_issue"]["G_inst_per_s"], "peak": res["salu_issue"]["ceiling_G_inst_per_s"], "unit": "G instructions/s"})
         roof.setdefault("traffic", None)
@@ -694,6 +754,10 @@ def main():
         if world == 1 and default_workload:
             extra = {}
             lps = roof.get("line_requests", {}).get("per_read")
+            if "occ" in legs:  # (one unique-counting run per store: the headline matcher makes room and comes back)
+                m.close()
+                out["roofline"]["occupancy"] = leg_occupancy(ga, store, dseq, doff, n)
+                m = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
             if "striped" in legs:
                 extra["striped_store"] = leg_striped(ga, db, local_rank, dseq, doff, n, otable, kern_ms, lps)
             if "e2e" in legs:
@@ -715,12 +779,34 @@ def main():
             if legs & {"large", "filter", "dbbuild"}:
                 extra.update(legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note))
             if "huge" in legs:
-                extra["huge_store"] = leg_huge(ga, synth, orc, torch, dev, cores)
+                extra["huge_store"] = leg_huge(ga, synth, orc, torch, dev, cores, cal, pmc, pmc_note)
             out.update(extra)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def leg_occupancy(ga, store, dseq, doff, n):
+    """kernel time of the headline launch at 8 and at 7 resident workgroups per CU (= waves per SIMD; 8 is the hardware's limit at 64
+    VGPRs): how much the last wave is still worth says how far the kernel is from being bound by anything but latency"""
+    res = {}
+    for b in (8, 7):
+        os.environ["GS_MATCH_BLOCKS_PER_CU"] = str(b)
+        try:
+            mo = ga.FastqKMerMatcher(store, ga.MatchConfig(profile=True))
+        finally:
+            del os.environ["GS_MATCH_BLOCKS_PER_CU"]
+
+        def launch():
+            mo.reset()
+            _submit_reads(mo, dseq, doff, 0, n)
+
+        kms, _ = _kernel_ms(mo, launch, 5)
+        mo.close()
+        res["kernel_ms_at_%d_blocks_per_cu" % b] = round(kms, 4)
+    res["gain_from_the_8th_wave_per_simd"] = round(res["kernel_ms_at_7_blocks_per_cu"] / res["kernel_ms_at_8_blocks_per_cu"] - 1.0, 4)
+    return res
 
 
 def leg_striped(ga, db, device, dseq, doff, n, otable, plain_ms, lines_per_read, stripes=8):
@@ -734,11 +820,11 @@ def leg_striped(ga, db, device, dseq, doff, n, otable, plain_ms, lines_per_read,
 
     def launch():
         ms.reset()
-        ms.submit(dseq, doff, 0, n_reads=n)
+        _submit_reads(ms, dseq, doff, 0, n)
 
     kms, _ = _kernel_ms(ms, launch, 5)
     ms.reset()
-    ms.submit(dseq, doff, 0, n_reads=n)
+    _submit_reads(ms, dseq, doff, 0, n)
     table, _ = ms.finish()
     ms.close()
     for s in stores:
@@ -780,12 +866,12 @@ def leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, read_len, n, nch
         m.reset()
         m.sync()
         t0 = time.perf_counter()
-        m.submit(dseq, doff, 0, n_reads=n)
+        _submit_reads(m, dseq, doff, 0, n, read_len)
         m.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     m.reset()
-    m.submit(dseq, doff, 0, n_reads=nchk)
+    _submit_reads(m, dseq, doff, 0, nchk, read_len)
     table, _ = m.finish()
     seq, off = synth.reads_host(db.genomes, nchk, read_len=read_len)
     odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
@@ -832,7 +918,7 @@ def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):
     run(1)
     host_table, _ = m.finish()
     m.reset()
-    m.submit(dseq, doff, 0, n_reads=n)
+    _submit_reads(m, dseq, doff, 0, n)
     dev_table, _ = m.finish()
     return {"pinned_host_gbps": round(n * READ_LEN / dt / 1e9, 2), "reads": n, "batches_in_flight": 2,
             "ms_per_batch_pair": round(dt * 1e3, 3), "h2d_gbs_of_sequence": round(n * READ_LEN / dt / 1e9, 2),
@@ -1078,12 +1164,12 @@ def leg_table_only(ga, synth, orc, torch, dev, cores, k=16, n=10_000_000, nchk=1
         m.reset()
         m.sync()
         t0 = time.perf_counter()
-        m.submit(dseq, doff, 0, n_reads=n)
+        _submit_reads(m, dseq, doff, 0, n)
         m.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     m.reset()
-    m.submit(dseq, doff, 0, n_reads=nchk)
+    _submit_reads(m, dseq, doff, 0, nchk)
     gt, _ = m.finish()
     seq, off = synth.reads_host(db.genomes, nchk, read_len=READ_LEN)
     odb = orc.DB(k, db.kmers, db.value_idx, db.n_values, db.parent_vi)
@@ -1098,27 +1184,11 @@ def leg_table_only(ga, synth, orc, torch, dev, cores, k=16, n=10_000_000, nchk=1
             "gbps": round(n * READ_LEN / best / 1e9, 2), "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))}}
 
 
-def leg_huge(ga, synth, orc, torch, dev, cores, genera=250, n=10_000_000, nchk=200_000):
+def leg_huge(ga, synth, orc, torch, dev, cores, cal=None, pmc=None, pmc_note=None, genera=250, n=10_000_000, nchk=1_000_000):
     """BASELINE.json configs[4]'s store size on ONE GPU: ~473 M k-mers / 5 251 values built ON THE DEVICE from 5 000 synthetic
     genomes (gs_dbbuild: FillDBGoal + DBGoal, then the device layout builder), 10 M reads through the fused kernel -- plain and as
     8 stripes in this GPU's HBM --, oracle spot check over the first nchk reads against the arrays the builder returned."""
-    t0 = time.perf_counter()
-    db = synth.SynthDB(k=K, genera=genera, species_per_genus=20, build=False)
-    t_gen = time.perf_counter() - t0
-    g = db.genomes
-    gen = torch.from_numpy(g).to(dev)
-    goff = torch.arange(g.shape[0] + 1, dtype=torch.int64, device=dev) * g.shape[1]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    b = ga.DeviceDbBuilder(K, db.n_values, db.parent_vi)
-    b.add(gen.reshape(-1), goff, db.species_vi, update=False)
-    b.add(gen.reshape(-1), goff, db.species_vi, update=True)
-    kmers, vals = b.finish()
-    t_build = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    store = b.to_store()
-    t_layout = time.perf_counter() - t0
-    b.close()
+    store, gen, g, db, kmers, vals, (t_gen, t_build, t_layout) = _huge_store(ga, synth, torch, dev, genera)
     info = store.info
     dseq = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
     doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
@@ -1128,11 +1198,11 @@ def leg_huge(ga, synth, orc, torch, dev, cores, genera=250, n=10_000_000, nchk=2
 
     def launch():
         m.reset()
-        m.submit(dseq, doff, 0, n_reads=n)
+        _submit_reads(m, dseq, doff, 0, n)
 
     kms, wall = _kernel_ms(m, launch, 4)
     m.reset()
-    m.submit(dseq, doff, 0, n_reads=nchk)
+    _submit_reads(m, dseq, doff, 0, nchk)
     gt, _ = m.finish()
     m.close()
     seq, off = synth.reads_host(g, nchk, read_len=READ_LEN)
@@ -1147,6 +1217,13 @@ def leg_huge(ga, synth, orc, torch, dev, cores, genera=250, n=10_000_000, nchk=2
            "kernel_ms": round(kms, 3), "ms_per_step": round(wall, 3), "gbps": round(n * READ_LEN / (kms * 1e-3) / 1e9, 2),
            "build_s": {"genomes_host": round(t_gen, 1), "gs_dbbuild_incl_fetch": round(t_build, 2), "layout_on_device": round(t_layout, 2)},
            "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(ot, gt))}}
+    if cal is not None:  # the same pricing as the headline: counters of the in-run PMC passes, ceilings of this run
+        foot = int(info.rec_bytes + info.table_bytes + info.mgate_bytes)
+        if "lines_huge" not in cal:
+            cal["lines_huge"] = ga.calibrate(ga.CAL_RANDOM_LINES, foot)["rate"]
+        cnt = (pmc or {}).get("huge_store") or None
+        res.update(_priced(cal, cnt, pmc_note if cnt else None, kms, n, "lines_huge"))
+        res["random_line_ceiling_G_per_s"] = round(cal["lines_huge"] / 1e9, 2)
     store.close()
     torch.cuda.empty_cache()
     # the same store as 8 stripes in this GPU's HBM (what every GPU of configs[4] would run, minus the xGMI hop)
@@ -1155,11 +1232,11 @@ def leg_huge(ga, synth, orc, torch, dev, cores, genera=250, n=10_000_000, nchk=2
 
     def launch_s():
         ms.reset()
-        ms.submit(dseq, doff, 0, n_reads=n)
+        _submit_reads(ms, dseq, doff, 0, n)
 
     kms_s, _ = _kernel_ms(ms, launch_s, 4)
     ms.reset()
-    ms.submit(dseq, doff, 0, n_reads=nchk)
+    _submit_reads(ms, dseq, doff, 0, nchk)
     gts, _ = ms.finish()
     ms.close()
     for s in stores:
@@ -1397,7 +1474,7 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note):
 
         def launch():
             m.reset()
-            m.submit(dseq, doff, 0, n_reads=n)
+            _submit_reads(m, dseq, doff, 0, n)
 
         kms, wall = _kernel_ms(m, launch, 5)
         odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi, bloom_gate=True)
@@ -1406,7 +1483,7 @@ def legs_large(ga, synth, orc, torch, dev, legs, cores, cal, pmc, pmc_note):
         ot, _ = orun.finish()
         odb.close()
         m.reset()
-        m.submit(dseq, doff, 0, n_reads=nchk)
+        _submit_reads(m, dseq, doff, 0, nchk)
         gt, _ = m.finish()
         cnt, src = counters("large_store")
         ach = n * BYTES_PER_READ / (kms * 1e-3) / 1e9

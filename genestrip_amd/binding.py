@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "gs_calibrate",
     "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_first_span", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
     "gs_filter_compact_text", "gs_match_compact_text", "gs_deflater_create", "gs_deflater_pack", "gs_deflater_info", "gs_deflater_destroy",
-    "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error", "gs_match_text_descriptors",
+    "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error", "gs_match_text_descriptors", "gs_match_submit_fixed",
 )
 
 
@@ -192,6 +192,7 @@ def lib():
         "gs_deflate_host_reference": (ci, [vp, i64, vp, i64, vp]),
         "gs_deflate_last_error": (C.c_char_p, []),
         "gs_match_text_descriptors": (ci, [vp, vp, i32, vp, i32]),
+        "gs_match_submit_fixed": (ci, [vp, vp, i32, i64, i64, ci, vp, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -628,6 +629,14 @@ class FastqKMerMatcher:
         pf, _ = _ptr(flags)
         _ready(seq, offsets, class_vi, flags)
         _check(lib().gs_match_submit(self.h, ps, po, n_reads, first_read_no, mem, pc, pf))
+
+    def submit_fixed(self, seq, read_len, n_reads, first_read_no=0, class_vi=None, flags=None):
+        """gs_match_submit_fixed: n_reads reads of read_len bytes each, back to back in `seq` (numpy = host, tensor = device)"""
+        ps, mem = _ptr(seq)
+        pc, _ = _ptr(class_vi)
+        pf, _ = _ptr(flags)
+        _ready(seq, class_vi, flags)
+        _check(lib().gs_match_submit_fixed(self.h, ps, int(read_len), int(n_reads), int(first_read_no), mem, pc, pf))
 
     def submit_async(self, seq, offsets, first_read_no=0, class_vi=None, flags=None, n_reads=None):
         """host batch (numpy arrays, best page-locked), queued: returns a ticket for wait(); the arrays must stay as they

@@ -577,7 +577,7 @@ extern "C" hipError_t gs_lb_table(const u64 *t_key, const int32_t *t_val, int64_
                                   uint32_t *fill_b, u64 *table, int64_t *overflow, int *max_disp, hipStream_t stream);
 extern "C" hipError_t gs_lb_distinct(uint32_t *h_gh, uint32_t *h_alt, int64_t n_h, u64 *d_scratch, int64_t *distinct, uint32_t **sorted,
                                      hipStream_t stream);
-extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream);
+extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, int ctx, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream);
 extern "C" hipError_t gs_lb_hint_collect(const uint32_t *w_valid, const uint32_t *w_gh, const u64 *w_hi, const u64 *w_lo, const uint32_t *win_bucket,
                                          int64_t n_w, uint32_t rec_bits, int k, uint32_t *hint_gh, uint32_t *hint_cx, u64 *cnt, hipStream_t stream);
 extern "C" hipError_t gs_lb_hint(const uint32_t *hint_gh, const uint32_t *hint_cx, int64_t n, int ctx, uint32_t mgate_bits, uint32_t *mgate,
@@ -792,7 +792,7 @@ static int db_create_on_device(gs_db **out, int device, int k, int64_t n, const 
     while (mgate_bits < 30 && (double)((size_t)32 << mgate_bits) < (double)distinct * bits_per_min) mgate_bits++;
     uint32_t *d_mgate = pool.get<uint32_t>((size_t)1 << mgate_bits);
     LB_TRY(pool.err, "gate");
-    LB_TRY(gs_lb_gate(h_sorted, n_gate, (uint32_t)mgate_bits, d_mgate, stream), "gate");
+    LB_TRY(gs_lb_gate(h_sorted, n_gate, (int)mgate_ctx, (uint32_t)mgate_bits, d_mgate, stream), "gate");
     LB_TRY(gs_lb_hint(hint_gh, hint_cx, n_hint, (int)mgate_ctx, (uint32_t)mgate_bits, d_mgate, stream), "gate hints");
     int32_t *d_tree = pool.get<int32_t>(4 * (size_t)n_values);
     LB_TRY(pool.err, "tree");
@@ -1455,7 +1455,7 @@ extern "C" int gs_db_get_info(const gs_db *db, gs_db_info *info) {
 // ---- native store file: the built device image (table, gate, tree) so that a later process skips the rebuild.
 // Layout: GsStoreFileHeader | table (n_buckets*8 u64) | gate (gate_bytes) | tree (4*n_values int32)
 struct GsStoreFileHeader {
-    char magic[8];  // "GSSTORE8"
+    char magic[8];  // "GSSTORE9"
     gs_db_info info;
     uint32_t bucket_bits, vbits;  // (bit 31 of vbits: the minimizer gate is keyed by gs_gate_ctx_key, GsDbDev::mgate_ctx)
     uint64_t gate_words;
@@ -1611,7 +1611,7 @@ extern "C" int gs_db_save(gs_db *db, const char *path) try {
     if (db->unique_owner) return fail(GS_E_STATE, "a unique-counting run is active on this store (seen bits are set)");
     if (db->striped()) return fail(GS_E_UNSUPPORTED, "a striped store is not saved as such: save the store built by gs_db_create");
     GsStoreFileHeader h{};
-    memcpy(h.magic, "GSSTORE8", 8);
+    memcpy(h.magic, "GSSTORE9", 8);
     h.info = db->info;
     h.bucket_bits = db->dev.bucket_bits;
     h.vbits = db->dev.vbits;
@@ -1697,7 +1697,7 @@ static int db_load_impl(gs_db **out, int device, const char *path, int stripes, 
         file_mgate_ctx = h.vbits >> 31;
         h.vbits &= 0x7fffffffu;
     }
-    if (!got_header || memcmp(h.magic, "GSSTORE8", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
+    if (!got_header || memcmp(h.magic, "GSSTORE9", 8) != 0 || h.info.n_values < 1 || h.info.n_values > (1 << 24) ||
         h.bucket_bits > 29 || h.info.n_buckets != ((int64_t)1 << h.bucket_bits) || h.vbits > 25 ||
         h.gate_words > ((uint64_t)1 << 28) || h.mgate_words > ((uint64_t)1 << 30) || h.rec_buckets > ((uint64_t)1 << 29)) {
         fclose(f);
@@ -2398,7 +2398,7 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
 
 static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int64_t first_read_no,
                         int32_t *d_class, uint8_t *d_flags, const int32_t *d_nodes = nullptr,
-                        const uint64_t *d_pos_off = nullptr, int off_stride = 1, const uint32_t *d_skip = nullptr) {
+                        const uint64_t *d_pos_off = nullptr, int off_stride = 1, const uint32_t *d_skip = nullptr, int fixed_len = 0) {
     if (n_reads > (int64_t)0xffffffffLL) return fail(GS_E_INVALID, "more than 2^32-1 reads in one batch");
     int rc = ensure_long(run, n_reads);
     if (rc) return rc;
@@ -2428,6 +2428,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.nodes = d_nodes;
     P.pos_off = (const unsigned long long *)d_pos_off;
     P.off_stride = off_stride;
+    P.fixed_len = fixed_len;
     P.skip = d_skip;
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + (GS_BLOCK / 64) - 1) / (GS_BLOCK / 64));
     if (grid < 1) grid = 1;
@@ -2512,6 +2513,49 @@ extern "C" int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *
     if (rc) return rc;
     if (class_vi)
         HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
+    HIP_TRY(hipStreamSynchronize(run->stream));
+    return collect_events(run);
+}
+
+// reads of ONE length, back to back, without an offsets array (what a sequencer's FASTQ gives once parsed: `read_len` bases each)
+extern "C" int gs_match_submit_fixed(gs_run *run, const uint8_t *seq, int32_t read_len, int64_t n_reads, int64_t first_read_no, int mem,
+                                     int32_t *class_vi, uint8_t *flags) {
+    if (!run) return fail(GS_E_INVALID, "run is NULL");
+    if (n_reads < 0 || read_len < 0 || (n_reads > 0 && !seq)) return fail(GS_E_INVALID, "bad batch arrays");
+    if (n_reads == 0) return GS_OK;
+    HIP_TRY(hipSetDevice(run->db->device));
+    if (mem == GS_MEM_DEVICE)
+        return launch_batch(run, seq, nullptr, n_reads, first_read_no, class_vi, flags, nullptr, nullptr, 0, nullptr, read_len);
+    if (mem != GS_MEM_HOST) return fail(GS_E_INVALID, "mem must be GS_MEM_HOST or GS_MEM_DEVICE");
+    const size_t nbytes = (size_t)n_reads * (size_t)read_len;
+    if (run->seq_cap < nbytes + 1) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_seq);
+        run->d_seq = nullptr;
+        run->seq_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_seq, nbytes + 1));
+        run->seq_cap = nbytes + 1;
+    }
+    if (run->reads_cap < (size_t)n_reads) {
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        hipFree(run->d_off);
+        hipFree(run->d_class);
+        hipFree(run->d_flags);
+        run->d_off = nullptr;
+        run->d_class = nullptr;
+        run->d_flags = nullptr;
+        run->reads_cap = 0;
+        HIP_TRY(hipMalloc((void **)&run->d_off, sizeof(uint64_t) * ((size_t)n_reads + 1)));
+        HIP_TRY(hipMalloc((void **)&run->d_class, sizeof(int32_t) * (size_t)n_reads));
+        HIP_TRY(hipMalloc((void **)&run->d_flags, (size_t)n_reads));
+        run->reads_cap = (size_t)n_reads;
+    }
+    HIP_TRY(hipMemcpyAsync(run->d_seq, seq, nbytes, hipMemcpyHostToDevice, run->stream));
+    int rc = launch_batch(run, run->d_seq, nullptr, n_reads, first_read_no, class_vi ? run->d_class : nullptr, flags ? run->d_flags : nullptr, nullptr, nullptr,
+                          0, nullptr, read_len);
+    if (rc) return rc;
+    if (class_vi) HIP_TRY(hipMemcpyAsync(class_vi, run->d_class, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
     if (flags) HIP_TRY(hipMemcpyAsync(flags, run->d_flags, (size_t)n_reads, hipMemcpyDeviceToHost, run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
     return collect_events(run);

@@ -392,7 +392,13 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
 
 #define GS_ACT(m) __builtin_amdgcn_inverse_ballot_w64(m)  // a wave-level mask as a per-lane condition
 // CTX: is the gate keyed by gs_gate_ctx_key?  0 never (the launcher has looked), 1 always, 2 ask the store (GsDbDev::mgate_ctx)
-template <int KC, bool STRIPED, int CTX = 2>
+// AGG: the unique-k-mer marks of the k-mers that share a record line leave as ONE atomic per line.  A device-scope atomic is
+// executed on the memory side of the L2s (eight XCDs, eight L2s): every one is a request to the fabric, and on a store that does not
+// fit the caches they were HALF of the kernel's fabric requests (473 M k-mers: 30 read + 36 write requests per read, 61 writes per
+// read from the store -- one per first-seen k-mer; tools/huge_lines.py), with the fabric's line rate the bound (0.89).  The lanes of
+// a minimizer run OR their offset bits into a word of the wave's LDS rows (free again after the minimizer scan), the lane that owns
+// the lowest bit sends the word: ~13 atomics per read from the store instead of ~60.
+template <int KC, bool STRIPED, int CTX = 2, bool AGG = false>
 __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
                                                 const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
                                                 uint32_t *wave_g, const GsMark &mk) {
@@ -453,7 +459,8 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
 #pragma unroll
             for (int s = 0; s < 2; s++) gk[s] = (CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_gate_ctx_key(gh[s], ohi[s], olo[s], j[s], k) : gh[s];
 #pragma unroll
-            for (int s = 0; s < 2; s++) gw[s] = db.mgate[GS_ACT(act[s]) ? gs_mgate_word(gk[s], db.mgate_bits) : 0u];
+            for (int s = 0; s < 2; s++)
+                gw[s] = db.mgate[GS_ACT(act[s]) ? ((CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_mgate_word_ctx(gk[s], db.mgate_bits) : gs_mgate_word(gk[s], db.mgate_bits)) : 0u];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 const uint32_t bits = gs_mgate_bits(gk[s]);
@@ -476,6 +483,12 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // compares are straight-line code (bitwise, no short-circuit branches: every branch is an exec-mask save /
             // restore on the scalar unit, which this kernel keeps as busy as the vector unit)
             if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
+            if (AGG && mk.count_unique) {  // accumulators of the seen bits: 80 minimizer positions x 2 buckets per sub-round
+#pragma unroll
+                for (int q = 0; q < 5; q++) wave_g[64 * q + lane] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             // (Tried in round 3 and dropped, twice: touching sub-round 1's lines -- one dword each -- before sub-round 0's loads go
             // out, so that the second record round trip (3 400 + 3 200 of 24 900 wave cycles per read on the 473 M-k-mer store,
             // tools/phase_times.sh huge) is an L2 hit.  With plain loads, which the compiler is free to sink: configs[1] 6.80 ->
@@ -516,8 +529,26 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
                     const int val = (int)((V >> (GS_REC_VAL_BITS * ((int)jj - 3 * jw))) & (GS_REC_MAX_VALUES - 1));
                     node[s] = hit ? val : node[s];
                     if (hit) {
-                        if (STRIPED) {
+                        if (STRIPED && AGG) {
+                            if (mk.count_unique && ((mk.rec_seen[rb] >> jj) & 1u) == 0) {
+                                uint32_t *acc = wave_g + GS_ROW * s + 2 * (mp[s] + lane) + (ok0 ? 0 : 1);
+                                atomicOr(acc, 1u << jj);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                const uint32_t w = *(volatile uint32_t *)acc;
+                                if ((w & (0u - w)) == (1u << jj)) atomicOr(mk.rec_seen + rb, w);
+                            }
+                        } else if (STRIPED) {
                             if (mk.count_unique && ((mk.rec_seen[rb] >> jj) & 1u) == 0) atomicOr(mk.rec_seen + rb, 1u << jj);
+                        } else if (AGG) {
+                            if (mk.count_unique && (seen_hi & fbit) == 0) {
+                                // (the lanes of a minimizer occurrence share both buckets; occurrence = mp + lane inside the sub-round, < 80)
+                                uint32_t *acc = wave_g + GS_ROW * s + 2 * (mp[s] + lane) + (ok0 ? 0 : 1);
+                                atomicOr(acc, 1u << jj);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                const uint32_t w = *(volatile uint32_t *)acc;
+                                if ((w & (0u - w)) == (1u << jj))  // the owner of the lowest bit sends the run's bits
+                                    atomicOr(const_cast<u64 *>(db.rec) + (u64)rb * GS_REC_WORDS, (u64)w << GS_REC_WIN_BITS);
+                            }
                         } else if (mk.count_unique && (seen_hi & fbit) == 0)
                             atomicOr(const_cast<u64 *>(db.rec) + (u64)rb * GS_REC_WORDS, 1ULL << (GS_REC_WIN_BITS + jj));
                         if (mk.hit_counts != nullptr)
@@ -653,7 +684,10 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
                 // (4a. unique k-mers and per-k-mer hit counters are marked by the probe itself)
                 const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap : nullptr,
                                    STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
-                gs_probe_planes<KC, STRIPED, CTX>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
+#ifndef GS_AGG_ALL
+#define GS_AGG_ALL 0
+#endif
+                gs_probe_planes<KC, STRIPED, CTX, (REC || GS_AGG_ALL) && !LONG>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             }
 
             if (!LONG) GS_STAMP(5, node[0] ^ node[1])
@@ -1143,8 +1177,15 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
         GsKernargPtr kp = kp0;
         asm volatile("" : "+s"(kp));
         const GsMatchParams &Q = *(const GsMatchParams *)kp;
-        const u64 off = po[0];
-        const int L = (int)(po[1] - off);
+        u64 off;
+        int L;
+        if (Q.off_stride == 0) {  // reads of one length, back to back: nothing to load
+            L = Q.fixed_len;
+            off = (u64)r * (u64)(uint32_t)L;
+        } else {
+            off = po[0];
+            L = (int)(po[1] - off);
+        }
         GS_STAMP(0, L)
         if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
             if (lq_used == GS_LONG_CHUNK) {  // a fresh chunk of the queue for this wave
@@ -1231,10 +1272,18 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
                 serial = 1;
             }
             const int64_t r = (int64_t)(uint32_t)gs_readlane((int)mine, __builtin_ctzll(todo));
-            const uint64_t *po = P.off + r * P.off_stride;
-            const u64 off = po[0];
+            u64 off;
+            int L;
+            if (P.off_stride == 0) {
+                L = P.fixed_len;
+                off = (u64)r * (u64)(uint32_t)L;
+            } else {
+                const uint64_t *po = P.off + r * P.off_stride;
+                off = po[0];
+                L = (int)(po[1] - off);
+            }
             const uint32_t none[3] = {0, 0, 0};
-            gs_process_read<true, FROM_NODES, KC, WIDE, false, STRIPED>(P, st, r, off, (int)(po[1] - off), lane, nullptr, nullptr, wave_in_block, tag,
+            gs_process_read<true, FROM_NODES, KC, WIDE, false, STRIPED>(P, st, r, off, L, lane, nullptr, nullptr, wave_in_block, tag,
                                                        cnt, (int)serial, none, s_g[wave_in_block], nullptr);
         }
     }

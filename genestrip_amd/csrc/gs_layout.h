@@ -181,7 +181,18 @@ GS_HD uint32_t gs_mgate_bits(uint32_t m) {
 // `more` bit of EITHER bucket line announces.)
 GS_HD uint32_t gs_mgate_hint(uint32_t m) { return 1u << (((m * 0xC2B2AE3Du) >> 17) & 31); }
 // the two context keys of a window (gs_gate_ctx_key of its k-mers with j >= 4 / j <= 3) from the window planes; c = k - 15
-GS_HD uint32_t gs_gate_ctx_key_raw(uint32_t gh, uint32_t ctx) { return gh ^ ((ctx + 1u) * 0x9E3779B1u); }
+// The context key keeps its top 24 bits from the MINIMIZER alone and takes the low 8 from minimizer and context together: the gate
+// word of a context key (gs_mgate_word_ctx) then lies in a 64-byte line chosen by the minimizer, so that the two keys a run of
+// k-mers around one minimizer asks for (front / behind) -- and the keys of all windows of that minimizer -- cost ONE line request
+// where they cost two (round 4: the 473 M-k-mer store sits at 0.89 of the fabric's random-line rate, a third of its 65 requests
+// per read are gate words).  Which word of the line and which bits of the word still depend on the whole key.
+GS_HD uint32_t gs_gate_ctx_key_raw(uint32_t gh, uint32_t ctx) {
+    return ((gh * 0x85EBCA77u) & 0xffffff00u) | (((gh ^ ((ctx + 1u) * 0x9E3779B1u)) * 0xC2B2AE3Du) >> 24);
+}
+// word of a context-keyed gate: line = top bits of the key (minimizer only, up to 2^24 lines = 1 GiB of gate), word of the line = a hash of the key
+GS_HD uint32_t gs_mgate_word_ctx(uint32_t ck, uint32_t word_bits) {
+    return word_bits > 4u ? ((ck >> (36u - word_bits)) << 4) | ((ck * 0x9E3779B1u) >> 28) : (ck * 0x85EBCA77u) >> (32u - word_bits);
+}
 GS_HD uint32_t gs_window_ctx(uint64_t w_hi, uint64_t w_lo, int k, bool behind) {
     const int pos = behind ? (k - GS_MIN_L) + GS_MIN_L : (k - GS_MIN_L) - 4;
     return ((uint32_t)(w_hi >> pos) & 15u) | (((uint32_t)(w_lo >> pos) & 15u) << 4) | (behind ? 256u : 0u);

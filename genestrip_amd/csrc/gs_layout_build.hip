@@ -408,9 +408,9 @@ __global__ __launch_bounds__(256) void gs_lb_tcompact_kernel(const u64 *rot, con
         }
 }
 
-__global__ __launch_bounds__(256) void gs_lb_gate_kernel(const uint32_t *h_gh, int64_t n, uint32_t mgate_bits, uint32_t *mgate) {
+__global__ __launch_bounds__(256) void gs_lb_gate_kernel(const uint32_t *h_gh, int64_t n, int ctx, uint32_t mgate_bits, uint32_t *mgate) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t *w = mgate + gs_mgate_word(h_gh[i], mgate_bits);
+        uint32_t *w = mgate + (ctx ? gs_mgate_word_ctx(h_gh[i], mgate_bits) : gs_mgate_word(h_gh[i], mgate_bits));
         const uint32_t bits = gs_mgate_bits(h_gh[i]);
         if ((*w & bits) != bits) atomicOr(w, bits);
     }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void gs_lb_hint_kernel(const uint32_t *hint_gh
         const uint32_t gh = hint_gh[i];
         for (int side = 0; side < (ctx ? 2 : 1); side++) {
             const uint32_t key = ctx ? gs_gate_ctx_key_raw(gh, (hint_cx[i] >> (16 * side)) & 0xffffu) : gh;
-            uint32_t *w = mgate + gs_mgate_word(key, mgate_bits);
+            uint32_t *w = mgate + (ctx ? gs_mgate_word_ctx(key, mgate_bits) : gs_mgate_word(key, mgate_bits));
             const uint32_t bit = gs_mgate_hint(key);
             if ((*w & bit) == 0) atomicOr(w, bit);
         }
@@ -734,9 +734,9 @@ extern "C" hipError_t gs_lb_hint(const uint32_t *hint_gh, const uint32_t *hint_c
     return hipGetLastError();
 }
 
-extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream) {
+extern "C" hipError_t gs_lb_gate(const uint32_t *h_gh, int64_t n_h, int ctx, uint32_t mgate_bits, uint32_t *mgate, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(mgate, 0, ((size_t)1 << mgate_bits) * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    LB_LAUNCH(gs_lb_gate_kernel, n_h, h_gh, n_h, mgate_bits, mgate);
+    LB_LAUNCH(gs_lb_gate_kernel, n_h, h_gh, n_h, ctx, mgate_bits, mgate);
     return hipGetLastError();
 }

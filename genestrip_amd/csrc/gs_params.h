@@ -51,7 +51,11 @@ struct GsMatchParams {
     // text mode (gs_match_submit_text): `off` holds (start, end) PAIRS of the in-place sequence lines (off_stride 2,
     // else 1: n_reads + 1 running offsets), and the whole launch is skipped when *skip != 0 (chunk refused by the
     // device-side record scan, gs_text.hip)
+    // off_stride 0: NO offsets at all -- every read is fixed_len bytes, read r at r * fixed_len (gs_match_submit_fixed): the offsets'
+    // round trip in front of the bases' (14 % of a wave's cycles on a store that does not fit the caches) is gone
     int32_t off_stride;
+    int32_t fixed_len;
+    int32_t pad0;
     // direct global-atomic counters (n_values > GS_NV_LDS) exist in `stat_copies` copies, one per group of workgroups
     // (blockIdx % stat_copies): the atomics of one tax id are spread over that many cache lines; the copies are
     // folded into copy 0 before anything reads the accumulators

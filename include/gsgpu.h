@@ -155,6 +155,11 @@ int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg);
  * gs_match_sync / gs_match_finish before reading outputs); synchronous for GS_MEM_HOST. */
 int gs_match_submit(gs_run *run, const uint8_t *seq, const uint64_t *offsets, int64_t n_reads,
                     int64_t first_read_no, int mem, int32_t *class_vi, uint8_t *flags);
+/* The same for reads of ONE length lying back to back (read i = seq[i * read_len .. (i + 1) * read_len)): no offsets array to
+ * build, stage or read -- on the device the offsets' round trip in front of every read's bases is gone.  What a host holds after
+ * parsing a sequencer's FASTQ (fixed cycles) and what bench.py's resident reads are. */
+int gs_match_submit_fixed(gs_run *run, const uint8_t *seq, int32_t read_len, int64_t n_reads, int64_t first_read_no, int mem,
+                          int32_t *class_vi, uint8_t *flags);
 int gs_match_sync(gs_run *run);
 /* The asynchronous form for HOST batches (the producer thread of AbstractFastqReader fills batch i+1 while batch i is
  * on the device): returns as soon as the work is queued -- for page-locked arrays (gs_pinned_alloc) that is at once,

@@ -9,7 +9,7 @@ import bench  # noqa: E402
 
 
 def _ceil():
-    return {"valu_mix": 690e9, "salu": 585e9, "lines_main": 59.5e9, "n_cu": 256, "fetch_correction": 1.0}
+    return {"valu_mix": 690e9, "valu_pure": 988e9, "salu": 585e9, "lines_main": 59.5e9, "n_cu": 256, "fetch_correction": 1.0}
 
 
 def test_resource_fractions_from_counters():
@@ -19,14 +19,16 @@ def test_resource_fractions_from_counters():
            "GRBM_GUI_ACTIVE": 8 * 1.62e7, "TA_TA_BUSY_sum": 0.54 * 256 * 1.62e7, "TCP_TOTAL_CACHE_ACCESSES_sum": 159.0 * n}
     out, fr = bench._resources(cnt, 6.8, n, _ceil(), "lines_main", "test")
     sec = 6.8e-3
-    assert abs(fr["valu_issue"] - 299.0 * n / sec / 690e9) < 1e-3
+    assert abs(fr["valu_issue"] - 299.0 * n / sec / 988e9) < 1e-3  # against the hardware rate, not the kernel's own mix
+    assert abs(out["valu_issue"]["frac_vs_own_instruction_mix"] - 299.0 * n / sec / 690e9) < 1e-3
+    assert abs(out["valu_issue"]["frac_vs_guide_2_cycles_per_op"] - 299.0 * n / sec / (256 * 4 * 1.2e9)) < 1e-3
     assert abs(fr["salu_issue"] - 226.0 * n / sec / 585e9) < 1e-3
     assert abs(fr["line_requests"] - 14.0 * n / sec / 59.5e9) < 1e-3
     assert abs(fr["hbm"] - (8.7e6 + 6.9e4) * 1024 / sec / 8e12) < 1e-3
     assert abs(fr["vmem_address"] - 0.54) < 1e-3 and out["vmem_address"]["l1_line_accesses_per_read"] == 159.0
     assert out["wait_frac"] == 0.46 and out["vmem_loads_per_read"] == 10.5
     top, frac, name = bench._name_bound(fr)
-    assert top == "valu_issue" and name == "valu_issue" and 0.6 < frac < 1.0
+    assert top == "salu_issue" and name.startswith("latency / mixed") and 0.5 < frac < 0.6
 
 
 def test_no_counters_and_latency_bound():

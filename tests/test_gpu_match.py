@@ -393,3 +393,29 @@ def test_many_long_reads_between_short_ones(sdb, monkeypatch, blocks_per_cu):
     assert np.array_equal(ot, gt)
     m.close()
     store.close()
+
+
+def test_fixed_length_batches_without_offsets(sdb):
+    """gs_match_submit_fixed: reads of one length back to back, no offsets array -- table, classes and flags as with offsets, for
+    short reads (one iteration), reads of 129..256 positions and long ones, from device and from host memory"""
+    import torch
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    for L, n in ((150, 20000), (31, 500), (30, 300), (200, 6000), (1000, 1500)):
+        seq, off = synth.reads_host(sdb.genomes, n, read_len=L, seed=L)
+        seq = seq.copy()
+        seq[::977] = ord("N")
+        m.reset()
+        cv, fl = m.match_reads(seq, off)
+        want, _ = m.finish()
+        for dev in (False, True):
+            m.reset()
+            s = torch.from_numpy(seq).cuda() if dev else seq
+            c2 = torch.empty(n, dtype=torch.int32, device="cuda") if dev else np.zeros(n, dtype=np.int32)
+            f2 = torch.empty(n, dtype=torch.uint8, device="cuda") if dev else np.zeros(n, dtype=np.uint8)
+            m.submit_fixed(s, L, n, class_vi=c2, flags=f2)
+            got, _ = m.finish()
+            assert np.array_equal(got, want), (L, dev)
+            assert np.array_equal(c2.cpu().numpy() if dev else c2, cv) and np.array_equal(f2.cpu().numpy() if dev else f2, fl), (L, dev)
+    m.close()
+    store.close()
