@@ -1140,6 +1140,22 @@ def leg_files(ga, synth, orc, torch, dev, db, store, m, cores, n=4_000_000):
             best = dt if best is None else min(best, dt)
         res["filter_writeback_gz"] = {"seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2), "accepted_reads": int(tot.filtered_reads),
                                       "output_equals_plain_input_run": bool(plain_out is not None and open(outp, "rb").read() == plain_out)}
+        # ... and in the reference's default shape, gzipFastqOutput (C/GSConfigKey.java:155): the accepted reads as a .gz file -- gathered
+        # and DEFLATE-compressed on the device (gs_deflate_dev.hip), a sixth of the bytes to fetch and to write
+        import gzip as _gzip
+        outz = outp + ".gz"
+        for label, src in (("plain", plain), ("bgzf", bz), ("gz", gz)):
+            best = None
+            for _ in range(2):
+                if os.path.exists(outz):
+                    os.remove(outz)
+                t0 = time.perf_counter()
+                tot = host.filter_files(bloom, K, [src], 1, 0.2, filtered_path=outz)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            res["filter_%s_to_gz" % label] = {"seconds": round(best, 3), "gbps": round(n * READ_LEN / best / 1e9, 2), "accepted_reads": int(tot.filtered_reads),
+                                              "output_bytes": os.path.getsize(outz),
+                                              "zcat_equals_plain_output_run": bool(plain_out is not None and _gzip.decompress(open(outz, "rb").read()) == plain_out)}
         bloom.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

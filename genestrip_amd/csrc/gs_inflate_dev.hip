@@ -46,6 +46,7 @@
 #include <vector>
 
 #include "../../include/gsgpu.h"
+#include "gs_upload.h"
 
 typedef unsigned long long u64;
 struct __attribute__((aligned(16))) gs_u16x8 {
@@ -1879,81 +1880,84 @@ static bool gi_trace() {  // GS_HOST_TRACE: the host layer's timeline on stderr;
     return on;
 }
 
-// `after_piece(bytes uploaded so far, the event behind that piece's copy)`: work on other streams that waits for the piece
-static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, const std::function<int(size_t, hipEvent_t)> &after_piece) {
-    // Two page-locked pieces + their events, taken from a per-device free list for the length of ONE call: a second decoder on the
-    // same device (a filter and a match job, two threads of a JVM) gets a set of its own instead of waiting for a whole stream.
+// The device as the upload threads of gs_upload.h see it: a stream, events, and two page-locked pieces of 32 MiB taken from a per-device
+// free list for the length of ONE copy -- a second decoder on the same device (a filter and a match job, two threads of a JVM) gets a
+// set of its own instead of waiting for a whole stream.
+struct GiHipDev {
+    typedef hipEvent_t Event;
+    int device = 0;
+    hipStream_t stream = nullptr;
     struct Staging {
         uint8_t *h[2] = {nullptr, nullptr};
         hipEvent_t done[2] = {nullptr, nullptr};
+        size_t piece = 0;
     };
     struct StagingList {
         std::mutex m;
-        std::vector<Staging *> idle;
+        std::vector<Staging> idle;
     };
-    static StagingList per_device[64];
-    int dev = 0;
-    GI_TRY(hipGetDevice(&dev));
-    StagingList &sl = per_device[(dev >= 0 && dev < 64) ? dev : 0];
-    Staging *stp = nullptr;
-    {
-        std::lock_guard<std::mutex> l(sl.m);
-        if (!sl.idle.empty()) {
-            stp = sl.idle.back();
-            sl.idle.pop_back();
-        }
+    static StagingList &list(int dev) {
+        static StagingList per_device[64];
+        return per_device[(dev >= 0 && dev < 64) ? dev : 0];
     }
-    if (!stp) stp = new Staging();
-    struct Return {  // (back to the list on every way out; every way out has synchronised the stream first)
-        StagingList &sl;
-        Staging *st;
-        ~Return() {
+    int bind() { return hipSetDevice(device) == hipSuccess ? GS_OK : GS_E_HIP; }
+    int take_staging(uint8_t *h[2], Event ev[2], size_t piece) {
+        Staging st;
+        {
+            StagingList &sl = list(device);
             std::lock_guard<std::mutex> l(sl.m);
-            sl.idle.push_back(st);
+            for (size_t i = 0; i < sl.idle.size(); i++)
+                if (sl.idle[i].piece == piece) {
+                    st = sl.idle[i];
+                    sl.idle.erase(sl.idle.begin() + (long)i);
+                    break;
+                }
         }
-    } give_back{sl, stp};
-    uint8_t **h = stp->h;
-    hipEvent_t *done = stp->done;
-    const size_t piece = (size_t)32 << 20;
-    for (int i = 0; i < 2; i++) {
-        if (!h[i]) GI_TRY(hipHostMalloc((void **)&h[i], piece));
-        if (!done[i]) GI_TRY(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        st.piece = piece;
+        for (int i = 0; i < 2; i++) {
+            if (!st.h[i] && hipHostMalloc((void **)&st.h[i], piece) != hipSuccess) st.h[i] = nullptr;
+            if (!st.done[i] && hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming) != hipSuccess) st.done[i] = nullptr;
+            h[i] = st.h[i];
+            ev[i] = st.done[i];
+        }
+        if (!h[0] || !h[1] || !ev[0] || !ev[1]) {
+            give_staging(h, ev);
+            return GS_E_NOMEM;
+        }
+        piece_ = piece;
+        return GS_OK;
     }
-    int which = 0;
-    bool used[2] = {false, false};
-    for (size_t at = 0; at < n; at += piece, which ^= 1) {
-        const size_t len = std::min(piece, n - at);
-        if (used[which] && hipEventSynchronize(done[which]) != hipSuccess) {
-            hipStreamSynchronize(stream);
-            return gi_fail(GS_E_HIP, "gi_h2d_staged: waiting for a staging buffer failed");
+    void give_staging(uint8_t *h[2], Event ev[2]) {
+        Staging st;
+        for (int i = 0; i < 2; i++) {
+            st.h[i] = h[i];
+            st.done[i] = ev[i];
         }
-        int n_thr = (int)std::min<size_t>(8, std::max<size_t>(1, len >> 22));
-        if (const char *e = getenv("GS_INFLATE_COPY_THREADS")) n_thr = std::max(1, std::min(32, atoi(e)));
-        std::vector<std::thread> th;
-        for (int t = 1; t < n_thr; t++) {
-            const size_t a = len * (size_t)t / (size_t)n_thr, b = len * ((size_t)t + 1) / (size_t)n_thr;
-            uint8_t *dst = h[which];
-            th.emplace_back([=] { memcpy(dst + a, src + at + a, b - a); });
-        }
-        memcpy(h[which], src + at, len / (size_t)n_thr);
-        for (auto &x : th) x.join();
-        hipError_t ce = hipMemcpyAsync(d_dst + at, h[which], len, hipMemcpyHostToDevice, stream);
-        if (ce == hipSuccess) ce = hipEventRecord(done[which], stream);
-        if (ce != hipSuccess) {
-            hipStreamSynchronize(stream);
-            return gi_fail(ce == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string("gi_h2d_staged: ") + hipGetErrorString(ce));
-        }
-        used[which] = true;
-        if (after_piece) {
-            const int rc = after_piece(at + len, done[which]);
-            if (rc) {  // (cancelled or failed: the copies under way still read h[], which the next caller fills)
-                hipStreamSynchronize(stream);
-                return rc;
-            }
-        }
+        st.piece = piece_;
+        StagingList &sl = list(device);
+        std::lock_guard<std::mutex> l(sl.m);
+        sl.idle.push_back(st);
     }
-    GI_TRY(hipStreamSynchronize(stream));
-    return GS_OK;
+    int copy_async(uint8_t *d_dst, const uint8_t *h_src, size_t n) { return hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, stream) == hipSuccess ? GS_OK : GS_E_HIP; }
+    int record(Event ev) { return hipEventRecord(ev, stream) == hipSuccess ? GS_OK : GS_E_HIP; }
+    int wait_event(Event ev) { return hipEventSynchronize(ev) == hipSuccess ? GS_OK : GS_E_HIP; }
+    int drain() { return hipStreamSynchronize(stream) == hipSuccess ? GS_OK : GS_E_HIP; }
+    size_t piece_ = 0;
+};
+static const size_t GI_UPLOAD_PIECE = (size_t)32 << 20;
+static int gi_copy_threads() {
+    if (const char *e = getenv("GS_INFLATE_COPY_THREADS")) return std::max(1, std::min(32, atoi(e)));
+    return 0;  // (by the size of the piece: gs_staged_copy)
+}
+
+// `after_piece(bytes uploaded so far, the event behind that piece's copy)`: work on other streams that waits for the piece
+static int gi_h2d_staged(uint8_t *d_dst, const uint8_t *src, size_t n, hipStream_t stream, const std::function<int(size_t, hipEvent_t)> &after_piece) {
+    GiHipDev dev;
+    GI_TRY(hipGetDevice(&dev.device));
+    dev.stream = stream;
+    const int rc = gs_staged_copy<GiHipDev>(dev, d_dst, src, n, GI_UPLOAD_PIECE, gi_copy_threads(), after_piece);
+    if (rc && rc != GS_E_STATE) return gi_fail(rc, "the copy of the compressed bytes to the device failed");
+    return rc;
 }
 
 struct GiDevBufs {  // freed on every way out
@@ -2011,12 +2015,8 @@ struct gs_gunzipper {
     bool whole = false;
     uint8_t *d_all = nullptr;
     size_t all_cap = 0;
-    std::thread up_thr;
-    std::mutex up_m;
-    std::condition_variable up_cv;
-    int64_t up_done = 0;  // bytes of the deflate stream that have arrived (under up_m)
-    int up_rc = GS_OK;
-    bool up_cancel = false, up_finished = false;
+    GiHipDev up_dev;            // the upload's view of the device (stream s_up)
+    GsUploader<GiHipDev> up;    // the thread itself, the bytes that have arrived, cancel / park: gs_upload.h (sanitizer harness: tests/native/uploader_sanitize.cpp)
     int text_only = 1;
     hipStream_t s_up = nullptr, s_find[2] = {nullptr, nullptr};  // the upload, and the finder launches behind its pieces
     unsigned long long *d_fq = nullptr;                        // one work counter per finder launch
@@ -2063,59 +2063,20 @@ extern "C" int gs_gunzipper_first_span(gs_gunzipper *g, int64_t bytes) {
 // the caller is through with the file (or gives up on it): the upload thread is stopped -- `gz` may go away; the buffers stay
 extern "C" int gs_gunzipper_park(gs_gunzipper *g) {
     if (!g) return GS_OK;
-    if (g->up_thr.joinable()) {
-        {
-            std::lock_guard<std::mutex> l(g->up_m);
-            g->up_cancel = true;
-        }
-        g->up_thr.join();
-    }
-    g->up_cancel = false;
+    g->up.park();
     return GS_OK;
 }
 
-static void gu_start_upload(gs_gunzipper *g) {
-    g->up_done = 0;
-    g->up_rc = GS_OK;
-    g->up_cancel = g->up_finished = false;
-    g->up_thr = std::thread([g] {
-        int rc = hipSetDevice(g->device) == hipSuccess ? GS_OK : GS_E_HIP;
-        hipEvent_t prev = nullptr;
-        size_t prev_end = 0;
-        auto publish = [g](int64_t done, int rc_now, bool fin) {
-            {
-                std::lock_guard<std::mutex> l(g->up_m);
-                g->up_done = std::max(g->up_done, done);
-                if (rc_now) g->up_rc = rc_now;
-                g->up_finished = g->up_finished || fin;
-            }
-            g->up_cv.notify_all();
-        };
-        try {
-        if (!rc)
-            rc = gi_h2d_staged(g->d_all, g->gz + g->hdr, (size_t)g->in_len, g->s_up, [&](size_t up, hipEvent_t ev) -> int {
-                if (prev) {  // the piece before this one has arrived when its event has (this one is on its way)
-                    if (hipEventSynchronize(prev) != hipSuccess) return GS_E_HIP;
-                    publish((int64_t)prev_end, GS_OK, false);
-                }
-                prev = ev;
-                prev_end = up;
-                std::lock_guard<std::mutex> l(g->up_m);
-                return g->up_cancel ? GS_E_STATE : GS_OK;
-            });
-        } catch (...) {  // (the copy helpers' threads, memory: the batches then fail with this code)
-            rc = GS_E_NOMEM;
-        }
-        publish(rc ? 0 : g->in_len, rc, true);
-    });
+static void gu_start_upload(gs_gunzipper *g) {  // (throws std::system_error when no thread can be had)
+    g->up_dev.device = g->device;
+    g->up_dev.stream = g->s_up;
+    g->up.start(&g->up_dev, g->d_all, g->gz + g->hdr, g->in_len, GI_UPLOAD_PIECE, gi_copy_threads());
 }
 
 // until `need` bytes of the stream have arrived; *have: how many have
 static int gu_wait_uploaded(gs_gunzipper *g, int64_t need, int64_t *have) {
-    std::unique_lock<std::mutex> l(g->up_m);
-    g->up_cv.wait(l, [&] { return g->up_done >= need || g->up_finished; });
-    *have = g->up_done;
-    if (g->up_done < need) return gi_fail(g->up_rc ? g->up_rc : GS_E_HIP, "gs_gunzipper: the upload of the stream failed");
+    const int rc = g->up.wait(need, have);
+    if (rc) return gi_fail(rc, "gs_gunzipper: the upload of the stream failed");
     return GS_OK;
 }
 

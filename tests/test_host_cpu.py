@@ -336,6 +336,28 @@ def test_writers_under_sanitizers(tmp_path, sanitizer):
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_gunzipper_upload_threads_under_sanitizers(tmp_path, sanitizer):
+    """the host threads of the DEVICE gunzip (gs_gunzipper_*: the staged copy and the upload thread, genestrip_amd/csrc/gs_upload.h)
+    against a mock device under ThreadSanitizer / AddressSanitizer: batches following the upload, park() with the source freed,
+    reopen, a failing copy helper, an uploader destroyed while it runs (ADVICE r03 high was a use-after-unmap
+    of exactly this thread)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(__file__), "native", "uploader_sanitize.cpp")
+    exe = str(tmp_path / "uploader_sanitize")
+    flags = ["-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize=alignment", "-std=c++17", "-pthread"]
+    b = subprocess.run(["g++", *flags, "-o", exe, src, "-lz"], capture_output=True, text=True)
+    if b.returncode != 0 and "sanitize" in b.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fails 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
 # ------------------------------------------------------------------ f4: the report writer against rows the reference prints
 def test_csv_writer_reproduces_the_readme_rows(tmp_path):
     """README.md:168-181 prints the header and 13 rows of `human_virus_match_sample.csv` (fixture
