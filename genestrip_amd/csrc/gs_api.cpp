@@ -24,6 +24,7 @@
 typedef unsigned long long u64;
 
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
@@ -1917,6 +1918,10 @@ struct gs_run {
     int64_t long_cap = 0;
     int32_t *d_scratch = nullptr;  // long-read kernel: per wave tag[n_values] | cnt[n_values]
     uint32_t *d_serial = nullptr;
+    // reads of tens of thousands of positions and more, taken apart over many waves (gs_match_huge_kernel): one allocation
+    // [count u32 x 4 | list | heads | chunk records | cnt rows | first rows | touch rows]
+    unsigned char *d_huge = nullptr;
+    int huge_slots = 0, huge_min = GS_HUGE_MIN, huge_chunk_min = GS_HUGE_CHUNK_MIN;
     int long_grid = 0;
     // host staging (GS_MEM_HOST)
     uint8_t *d_seq = nullptr;
@@ -2248,6 +2253,7 @@ static void run_free(gs_run *run) {
     hipFree(run->d_long_list);
     hipFree(run->d_scratch);
     hipFree(run->d_serial);
+    hipFree(run->d_huge);
     hipFree(run->d_seq);
     hipFree(run->d_off);
     hipFree(run->d_class);
@@ -2366,6 +2372,9 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
         run->long_cap = cap;
     }
     if (!run->d_scratch) {
+        // (where the longest reads leave the one-wave path, gs_match_huge_kernel: tunables and test hooks)
+        if (const char *e = getenv("GS_HUGE_MIN")) run->huge_min = std::max(129, atoi(e));
+        if (const char *e = getenv("GS_HUGE_CHUNK")) run->huge_chunk_min = std::max(128, (atoi(e) + 127) & ~127);
         // long-read kernel: a persistent grid that fills the device (the widest variant's occupancy; one wave per SIMD ran
         // 7-16x below the short-read kernel's rate per base), each wave owns tag[n_values] + cnt[n_values] in HBM
         const size_t nv = (size_t)run->db->info.n_values;
@@ -2394,6 +2403,40 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
         }
     }
     return GS_OK;
+}
+
+// the rows of the huge-read kernels; they leave them clean (gs_match_huge_finish_kernel), so this runs once per run
+static int ensure_huge(gs_run *run, GsMatchParams *P) {
+    const size_t nv = (size_t)run->db->info.n_values;
+    if (!run->d_huge) {
+        int slots = (int)std::min<size_t>(GS_HUGE_SLOTS, std::max<size_t>(4, ((size_t)256 << 20) / (nv * 12)));
+        if (const char *e = getenv("GS_HUGE_SLOTS")) slots = std::max(1, std::min(GS_HUGE_SLOTS, atoi(e)));
+        const size_t fixed = 16 + sizeof(uint32_t) * GS_HUGE_SLOTS + sizeof(GsHugeHead) * GS_HUGE_SLOTS;
+        const size_t chunks = sizeof(GsHugeChunk) * (size_t)slots * GS_HUGE_MAX_CHUNKS, row = sizeof(uint32_t) * (size_t)slots * nv;
+        HIP_TRY(hipMalloc((void **)&run->d_huge, fixed + chunks + 3 * row));
+        HIP_TRY(hipMemsetAsync(run->d_huge, 0, fixed + chunks + row, run->stream));
+        HIP_TRY(hipMemsetAsync(run->d_huge + fixed + chunks + row, 0xff, row, run->stream));  // first positions: none
+        run->huge_slots = slots;
+    }
+    const size_t slots = (size_t)run->huge_slots;
+    unsigned char *p = run->d_huge;
+    P->huge_count = reinterpret_cast<unsigned int *>(p);
+    p += 16;
+    P->huge_list = reinterpret_cast<uint32_t *>(p);
+    p += sizeof(uint32_t) * GS_HUGE_SLOTS;
+    P->huge_head = reinterpret_cast<GsHugeHead *>(p);
+    p += sizeof(GsHugeHead) * GS_HUGE_SLOTS;
+    P->huge_chunks = reinterpret_cast<GsHugeChunk *>(p);
+    p += sizeof(GsHugeChunk) * slots * GS_HUGE_MAX_CHUNKS;
+    P->huge_cnt = reinterpret_cast<uint32_t *>(p);
+    p += sizeof(uint32_t) * slots * nv;
+    P->huge_first = reinterpret_cast<uint32_t *>(p);
+    p += sizeof(uint32_t) * slots * nv;
+    P->huge_touch = reinterpret_cast<uint32_t *>(p);
+    P->huge_slots = run->huge_slots;
+    P->huge_min = run->huge_min;
+    P->huge_chunk_min = run->huge_chunk_min;
+    return hipMemsetAsync(P->huge_count, 0, sizeof(unsigned int), run->stream) == hipSuccess ? GS_OK : fail(GS_E_HIP, "huge-read counter");
 }
 
 static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off, int64_t n_reads, int64_t first_read_no,
@@ -2443,6 +2486,9 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         P.stat_rec_count = (unsigned long long *)run->d_stat_rec_count;
     }
     HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 2 * sizeof(unsigned int), run->stream));
+    // (reads of one short length each, or nodes that came from other ranks: nothing for the huge-read kernels)
+    const bool huge = !d_nodes && (off_stride != 0 || fixed_len - run->db->info.k + 1 >= run->huge_min);
+    if (huge && (rc = ensure_huge(run, &P))) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (run->cfg.profile) {
         HIP_TRY(hipEventCreate(&e0));
@@ -2463,6 +2509,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     }
     // reads with more than 128 k-mer positions were queued; the long-read kernel drains the queue
     HIP_TRY(gs_launch_match_long(&P, run->long_grid, run->d_scratch, run->d_serial, run->stream));
+    if (huge) HIP_TRY(gs_launch_match_huge(&P, run->long_grid, run->stream));  // ... and hands the longest ones on
     return GS_OK;
 }
 

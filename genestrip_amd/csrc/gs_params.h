@@ -63,6 +63,33 @@ struct GsMatchParams {
     const uint32_t *skip;
     GsStatRec *stat_recs;  // deferred statistics (global-atomic counters only) or nullptr: room for n_reads + 64 per wave
     unsigned long long *stat_rec_count;  // records handed out so far (waves take them 64 at a time)
+    // Reads of huge_min k-mer positions and more (assembled contigs, chromosomes: the reference grows its read buffer for them,
+    // AbstractFastqReader.java:593-604) are taken apart over MANY waves: the long-read kernel hands the first huge_slots of a batch
+    // to gs_match_huge_kernel (chunks of whole iterations, one wave each; per read: vote counts and first positions per node, the
+    // runs at the chunks' ends) and gs_match_huge_finish_kernel puts each read together again (seams, distinct nodes in order of first
+    // appearance, classification).  nullptr: off (DB-partitioned mode, batches of short fixed-length reads).
+    unsigned int *huge_count;          // reads handed over so far
+    uint32_t *huge_list;               // [huge_slots] their numbers in the batch
+    struct GsHugeHead *huge_head;      // [huge_slots]
+    struct GsHugeChunk *huge_chunks;   // [huge_slots][GS_HUGE_MAX_CHUNKS]
+    uint32_t *huge_cnt;                // [huge_slots][n_values] positions that hold the node
+    uint32_t *huge_first;              // [huge_slots][n_values] its first position (~0: none)
+    uint32_t *huge_touch;              // [huge_slots][n_values] the nodes with a count, in no order (GsHugeHead.n_touch of them)
+    int32_t huge_slots;                // <= GS_HUGE_SLOTS
+    int32_t huge_min;                  // k-mer positions from which a read goes this way
+    int32_t huge_chunk_min;            // k-mer positions per chunk at least (a multiple of 128)
+    int32_t pad1;
+};
+#define GS_HUGE_MIN (1 << 15)
+#define GS_HUGE_SLOTS 256       // (= GS_BLOCK: one thread per slot where the chunks are counted)
+#define GS_HUGE_MAX_CHUNKS 4096
+#define GS_HUGE_CHUNK_MIN 2048  // a longer read than GS_HUGE_MAX_CHUNKS of these is cut into GS_HUGE_MAX_CHUNKS chunks
+struct GsHugeHead {
+    unsigned int n_miss, bad_lo, flags, n_touch;  // flags: 1 = some k-mer hit, 2 = a bad base at or behind position max - 1
+};
+struct GsHugeChunk {
+    int32_t head_node, head_len;  // the run the chunk starts with (it may continue the chunk before): node, positions
+    int32_t tail_node, tail_len;  // the run that is open at its end; tail_len < 0: the whole chunk is ONE run (head_len positions)
 };
 
 // device-side FASTQ record scan (gs_text.hip)
