@@ -1303,8 +1303,8 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Reads of GS_HUGE_MIN positions and more, over many waves (VERDICT r03 missing 5: a chromosome on ONE wave ran at 25 Mbp/s).
-// A read is cut into chunks of whole iterations (>= 8192 positions, at most 4096 chunks); gs_match_huge_kernel gives every chunk a
+// Reads of GS_HUGE_MIN positions and more, over many waves (a chromosome on ONE wave runs at 30 Mbp/s).
+// A read is cut into chunks of whole iterations (GS_HUGE_CHUNK_MIN positions and more, at most GS_HUGE_MAX_CHUNKS chunks); gs_match_huge_kernel gives every chunk a
 // wave, which walks it exactly as the long-read path walks a read -- same probe, same closed form for windows with a bad base, the
 // contigs INSIDE the chunk booked by the lanes that start them -- and leaves behind what a single wave would have carried across:
 //   * per read and node, atomically: the positions that hold the node (the votes) and the FIRST of them;
@@ -1336,8 +1336,17 @@ __device__ __forceinline__ void gs_huge_vote(uint32_t *cnt, uint32_t *first, uin
     atomicMin(first + v, pos);
 }
 
-template <bool LDS_STATS, bool STRIPED>
-__global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_huge_kernel(GsMatchParams P) {
+// (waves per SIMD: a chunk is a chain of dependent iterations, and a spilled register is a round trip to memory inside it)
+#ifndef GS_HUGE_WAVES
+#define GS_HUGE_WAVES GS_LONG_WAVES
+#endif
+#if GS_HUGE_WAVES
+#define GS_HUGE_ATTR __attribute__((amdgpu_waves_per_eu(GS_HUGE_WAVES, GS_HUGE_WAVES)))
+#else
+#define GS_HUGE_ATTR
+#endif
+template <bool LDS_STATS, bool STRIPED, int KC = 0>
+__global__ __launch_bounds__(GS_BLOCK) GS_HUGE_ATTR void gs_match_huge_kernel(GsMatchParams P) {
     const unsigned int n_huge_all = P.huge_count[0];
     if (n_huge_all == 0) return;
     const int n_huge = (int)(n_huge_all < (unsigned int)P.huge_slots ? n_huge_all : (unsigned int)P.huge_slots);
@@ -1350,7 +1359,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_huge_kernel(Gs
     GS_STRIPE_TABLE(&P)
     uint32_t *wave_g = s_g[wave_in_block];
     const GsDbDev &db = P.db;
-    const int k = db.k;
+    const int k = KC ? KC : db.k;
     const GsMark mk = {P.count_unique, P.hit_counts, STRIPED ? P.bitmap : nullptr, STRIPED ? P.bitmap + ((db.bucket_mask + 1) * GS_SLOTS_PER_BUCKET >> 5) : nullptr};
     // the chunks of all reads in one row: s_first[slot] = number of the read's first chunk (GS_HUGE_SLOTS = GS_BLOCK: a thread per slot)
     __shared__ int s_first[GS_HUGE_SLOTS + 1];
@@ -1366,8 +1375,9 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_huge_kernel(Gs
         s_first[threadIdx.x + 1] = mine;
         __syncthreads();
         if (threadIdx.x == 0) {
+            int sum = 0;
             s_first[0] = 0;
-            for (int i = 1; i <= GS_HUGE_SLOTS; i++) s_first[i] += s_first[i - 1];
+            for (int i = 1; i <= n_huge; i++) s_first[i] = (sum += s_first[i]);
         }
         __syncthreads();
     }
@@ -1424,7 +1434,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_huge_kernel(Gs
                 }
             }
             int node[2];
-            gs_probe_planes<0, STRIPED, 2, false>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
+            gs_probe_planes<KC, STRIPED, 2, false>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
             found = found || ((hit0 | hit1) != 0);
             n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
@@ -1547,10 +1557,12 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_huge_finish_kernel(GsMatchP
         {
             const GsHugeChunk *ch = P.huge_chunks + (size_t)slot * GS_HUGE_MAX_CHUNKS;
             int carry_node = GS_NODE_NONE, carry_out = 0;  // tail node and out() of the chunk before this round's first
+            const GsHugeChunk none = {GS_NODE_NONE, 0, GS_NODE_NONE, -1};
+            GsHugeChunk next = lane < n_chunks ? ch[lane] : none;
             for (int c0 = 0; c0 < n_chunks; c0 += 64) {
                 const bool valid = c0 + lane < n_chunks;
-                GsHugeChunk mine = {GS_NODE_NONE, 0, GS_NODE_NONE, -1};
-                if (valid) mine = ch[c0 + lane];
+                const GsHugeChunk mine = next;
+                next = c0 + 64 + lane < n_chunks ? ch[c0 + 64 + lane] : none;  // (on its way while this round is booked)
                 const int up_node = __shfl_up(mine.tail_node, 1);
                 const int prev_node = lane == 0 ? carry_node : up_node;
                 const bool link = valid && (c0 + lane > 0) && mine.head_node == prev_node;
@@ -2706,7 +2718,7 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
     return hipGetLastError();
 }
 
-// reads of GS_HUGE_MIN positions and more that the long-read kernel handed over: chunks over the whole device, then one wave per read
+// reads of GS_HUGE_MIN positions and more that the match kernel handed over: chunks over the whole device, then one wave per read
 extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hipStream_t stream) {
     if (P->huge_count == nullptr || P->nodes != nullptr) return hipSuccess;
     const size_t lds = gs_stats_lds_bytes(P->db.n_values);
@@ -2715,12 +2727,16 @@ extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hip
     if (lds_stats) {
         if (striped)
             hipLaunchKernelGGL((gs_match_huge_kernel<true, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        else if (P->db.k == 31)
+            hipLaunchKernelGGL((gs_match_huge_kernel<true, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         else
             hipLaunchKernelGGL((gs_match_huge_kernel<true, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         hipLaunchKernelGGL((gs_match_huge_finish_kernel<true>), dim3(GS_HUGE_SLOTS / (GS_BLOCK / 64)), dim3(GS_BLOCK), lds, stream, *P);
     } else {
         if (striped)
             hipLaunchKernelGGL((gs_match_huge_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
+        else if (P->db.k == 31)
+            hipLaunchKernelGGL((gs_match_huge_kernel<false, false, 31>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         else
             hipLaunchKernelGGL((gs_match_huge_kernel<false, false>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P);
         hipLaunchKernelGGL((gs_match_huge_finish_kernel<false>), dim3(GS_HUGE_SLOTS / (GS_BLOCK / 64)), dim3(GS_BLOCK), lds, stream, *P);

@@ -82,8 +82,8 @@ struct GsMatchParams {
 };
 #define GS_HUGE_MIN (1 << 15)
 #define GS_HUGE_SLOTS 256       // (= GS_BLOCK: one thread per slot where the chunks are counted)
-#define GS_HUGE_MAX_CHUNKS 4096
-#define GS_HUGE_CHUNK_MIN 2048  // a longer read than GS_HUGE_MAX_CHUNKS of these is cut into GS_HUGE_MAX_CHUNKS chunks
+#define GS_HUGE_MAX_CHUNKS 8192
+#define GS_HUGE_CHUNK_MIN 1024  // a longer read than GS_HUGE_MAX_CHUNKS of these is cut into GS_HUGE_MAX_CHUNKS chunks
 struct GsHugeHead {
     unsigned int n_miss, bad_lo, flags, n_touch;  // flags: 1 = some k-mer hit, 2 = a bad base at or behind position max - 1
 };

@@ -89,8 +89,8 @@ def test_counters_in_device_memory(sdb, monkeypatch):
 
 
 def test_megabase_records(sdb):
-    """the sizes as they are (hand-over at 32768 positions, chunks of 2048 and more): records of 30 kbp .. 6 Mbp between short reads, the
-    longest one with more than 4096 x 2048 positions (its chunks grow instead of their number)"""
+    """the sizes as they are (hand-over at 32768 positions, chunks of 1024 and more): records of 30 kbp .. 9 Mbp between short reads, the
+    longest one with more than 8192 x 1024 positions (its chunks grow instead of their number)"""
     rng = np.random.default_rng(23)
     g0 = sdb.genomes
     reads = [_chimera(g0, rng, 150) for _ in range(500)]
