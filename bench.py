@@ -49,7 +49,7 @@ K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8            # per GPU: 7 links x 153.6 GB/s bidirectional
-ALL_LEGS = "main,occ,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,files"
+ALL_LEGS = "main,occ,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,fasta,files"
 # committed rocprofv3 --pmc summaries per workload, newest first: the fallback when the in-run passes cannot be taken
 PROFILE_ROUNDS = {"match": ("r03", "r02"), "large_store": ("r03", "r02"), "filter": ("r03", "r02")}
 PMC_GROUPS = (
@@ -768,6 +768,8 @@ def main():
             if "r250" in legs:
                 extra["reads_250bp"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 250, 6_000_000, 1_000_000,
                                                     "gs_match_kernel (220 k-mer positions per read)")
+            if "fasta" in legs:
+                extra["fasta_records"] = leg_fasta_records(ga, orc, torch, db, m, dev, cores)
             if "files" in legs:  # (last: it closes the matcher)
                 extra["file_pipeline"] = leg_files(ga, synth, orc, torch, dev, db, store, m, cores)
             m.close()
@@ -883,6 +885,62 @@ def leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, read_len, n, nch
     return {"workload": "match: %d reads x %d bp, k=%d, the configs[1] store" % (n, read_len, K), "kernel": kernel,
             "ms_per_step": round(best * 1e3, 3), "gbps": round(n * read_len / best / 1e9, 2),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
+
+
+def leg_fasta_records(ga, orc, torch, db, m, dev, cores):
+    """Records of an assembly or a chromosome FASTA against the configs[1] store: one record of 5 Mbp, and 64 of 1 Mbp.  A record of
+    32 768 k-mer positions and more is cut into chunks over many waves (gs_match_huge_kernel + gs_match_huge_finish_kernel); on one
+    wave (the long-read path) the 5 Mbp record takes 150 ms.  Whole step (reset, submit, sync) by the host clock, best of 5.  Parity:
+    table, class and flags of every record against the oracle."""
+    rng = np.random.default_rng(5)
+    g0 = db.genomes
+    out = {"kernel": "gs_match_kernel (hands over) + gs_match_huge_kernel + gs_match_huge_finish_kernel"}
+    for name, n, L in (("one_5mbp_record", 1, 5_000_000), ("records_64x1mbp", 64, 1_000_000)):
+        recs = []
+        for _ in range(n):  # pieces of 1 .. 60 kbp of the genomes, now and then an N
+            parts, left = [], L
+            while left > 0:
+                sp = int(rng.integers(0, g0.shape[0]))
+                c = min(left, int(rng.integers(1000, 60000)))
+                p0 = int(rng.integers(0, g0.shape[1] - c))
+                parts.append(g0[sp][p0:p0 + c])
+                left -= c
+            r = np.concatenate(parts)
+            r[rng.integers(0, L, L // 50000)] = ord("N")
+            recs.append(r)
+        seq = np.concatenate(recs)
+        off = np.arange(n + 1, dtype=np.int64) * L
+        dseq, doff = torch.from_numpy(seq).to(dev), torch.from_numpy(off).to(dev)
+        best = None
+        for _ in range(5):
+            m.reset()
+            m.sync()
+            t0 = time.perf_counter()
+            m.submit(dseq, doff, 0, n_reads=n)
+            m.sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        m.reset()
+        cv, fl = m.match_reads(seq, off, 0)
+        table, _ = m.finish()
+        odb = orc.DB(K, db.kmers, db.value_idx, db.n_values, db.parent_vi)
+        orun = orc.MatchRun(odb)
+        ocv, ofl = orun.submit(seq, off, threads=cores)
+        otable, _ = orun.finish()
+        # Kraken-style segments of the first record (two passes over its pieces of 32 iterations)
+        t0 = time.perf_counter()
+        seg_off, codes, _, lens = m.segments(seq[:L], off[:2])
+        seg_ms = (time.perf_counter() - t0) * 1e3
+        want = odb.segments(seq[:L], cap=1 << 22)
+        seg_ok = list(zip(codes.tolist(), lens.tolist())) == want
+        odb.close()
+        out[name] = {"workload": "match: %d record(s) x %d bp, k=%d, the configs[1] store" % (n, L, K), "ms_per_step": round(best * 1e3, 3),
+                     "gbps": round(n * L / best / 1e9, 2), "segments_of_one_record_ms_from_host_memory": round(seg_ms, 3),
+                     "parity": {"records_checked": n, "bit_exact": bool(np.array_equal(table, otable) and np.array_equal(cv, ocv) and np.array_equal(fl, ofl)),
+                                "segments_checked": len(want), "segments_equal": bool(seg_ok)}}
+        del dseq, doff
+    m.reset()
+    return out
 
 
 def leg_end_to_end(ga, synth, torch, db, m, n, dseq, doff):

@@ -3650,6 +3650,8 @@ static int segments_core(gs_run *run, const uint8_t *d_seq, const uint64_t *d_of
     P.off_stride = off_stride;
     P.n_reads = n_reads;
     P.seg_count = run->d_seg_count;
+    P.huge_min = GS_HUGE_MIN;
+    if (const char *e = getenv("GS_HUGE_MIN")) P.huge_min = std::max(129, atoi(e));
     int grid = (int)std::min<int64_t>(run->grid, (n_reads + 3) / 4);
     if (grid < 1) grid = 1;
     HIP_TRY(gs_launch_segments(&P, 0, grid, run->stream));
@@ -3657,6 +3659,66 @@ static int segments_core(gs_run *run, const uint8_t *d_seq, const uint64_t *d_of
     HIP_TRY(hipMemcpyAsync(counts.data(), run->d_seg_count, sizeof(uint32_t) * (size_t)n_reads, hipMemcpyDeviceToHost,
                            run->stream));
     HIP_TRY(hipStreamSynchronize(run->stream));
+    // Reads of tens of thousands of positions and more were left out (one wave would walk a chromosome for 150 ms per pass): they come
+    // back in pieces of GS_SEG_PIECE_ITERS iterations, one wave each.  A piece counts its first position as the start of a run; the
+    // seams where the node goes on are taken off here, and the write pass gets the node in front of every piece.
+    std::vector<GsSegPiece> pieces;
+    std::vector<size_t> first_piece;  // per left-out read, + end
+    std::vector<int64_t> huge_reads;
+    struct Dev {  // (freed on every way out)
+        GsSegPiece *pieces = nullptr;
+        GsSegPieceOut *out = nullptr;
+        ~Dev() {
+            hipFree(pieces);
+            hipFree(out);
+        }
+    } dv;
+    for (int64_t r = 0; r < n_reads; r++)
+        if (counts[(size_t)r] == GS_SEG_HUGE) huge_reads.push_back(r);
+    if (!huge_reads.empty()) {
+        const int k = run->db->info.k;
+        for (int64_t r : huge_reads) {
+            uint64_t se[2];
+            HIP_TRY(hipMemcpy(se, d_off + r * off_stride, sizeof(se), hipMemcpyDeviceToHost));
+            const int64_t max = (int64_t)(se[1] - se[0]) - k + 1, n_iter = (max + 127) >> 7;
+            first_piece.push_back(pieces.size());
+            for (int64_t it = 0; it < n_iter; it += GS_SEG_PIECE_ITERS) {
+                GsSegPiece pc{};
+                pc.read = (uint32_t)r;
+                pc.it0 = (int32_t)it;
+                pc.n_iter = (int32_t)std::min<int64_t>(GS_SEG_PIECE_ITERS, n_iter - it);
+                pc.carry = -3;  // GS_NODE_NONE
+                pieces.push_back(pc);
+            }
+        }
+        first_piece.push_back(pieces.size());
+        HIP_TRY(hipMalloc((void **)&dv.pieces, sizeof(GsSegPiece) * pieces.size()));
+        HIP_TRY(hipMalloc((void **)&dv.out, sizeof(GsSegPieceOut) * pieces.size()));
+        HIP_TRY(hipMemcpyAsync(dv.pieces, pieces.data(), sizeof(GsSegPiece) * pieces.size(), hipMemcpyHostToDevice, run->stream));
+        GsSegParams Q = P;
+        Q.pieces = dv.pieces;
+        Q.piece_out = dv.out;
+        Q.n_pieces = (int64_t)pieces.size();
+        const int pgrid = (int)std::max<int64_t>(1, std::min<int64_t>(run->grid, ((int64_t)pieces.size() + 3) / 4));
+        HIP_TRY(gs_launch_segments(&Q, 0, pgrid, run->stream));
+        std::vector<GsSegPieceOut> outs(pieces.size());
+        HIP_TRY(hipMemcpyAsync(outs.data(), dv.out, sizeof(GsSegPieceOut) * pieces.size(), hipMemcpyDeviceToHost, run->stream));
+        HIP_TRY(hipStreamSynchronize(run->stream));
+        for (size_t h = 0; h < huge_reads.size(); h++) {
+            uint64_t total = 0;
+            for (size_t i = first_piece[h]; i < first_piece[h + 1]; i++) {
+                uint32_t c = outs[i].count;
+                if (i > first_piece[h]) {
+                    pieces[i].carry = outs[i - 1].last_node;
+                    if (outs[i].first_node == outs[i - 1].last_node) c--;  // the run goes on across the seam
+                }
+                pieces[i].out_off = total;
+                total += c;
+            }
+            if (total >= GS_SEG_HUGE) return fail(GS_E_INVALID, "more than 2^32 - 2 segments in one read");
+            counts[(size_t)huge_reads[h]] = (uint32_t)total;
+        }
+    }
     for (int64_t i = 0; i < n_reads; i++) seg_off[i + 1] = seg_off[i] + counts[(size_t)i];
     run->seg_total = (int64_t)seg_off[n_reads];
     if (run->seg_total > 0) {
@@ -3667,6 +3729,14 @@ static int segments_core(gs_run *run, const uint8_t *d_seq, const uint64_t *d_of
         P.seg_code = run->d_seg_code;
         P.seg_start = run->d_seg_start;
         HIP_TRY(gs_launch_segments(&P, 1, grid, run->stream));
+        if (!pieces.empty()) {
+            HIP_TRY(hipMemcpyAsync(dv.pieces, pieces.data(), sizeof(GsSegPiece) * pieces.size(), hipMemcpyHostToDevice, run->stream));
+            GsSegParams Q = P;
+            Q.pieces = dv.pieces;
+            Q.n_pieces = (int64_t)pieces.size();
+            const int pgrid = (int)std::max<int64_t>(1, std::min<int64_t>(run->grid, ((int64_t)pieces.size() + 3) / 4));
+            HIP_TRY(gs_launch_segments(&Q, 1, pgrid, run->stream));
+        }
         HIP_TRY(hipStreamSynchronize(run->stream));
     }
     return GS_OK;

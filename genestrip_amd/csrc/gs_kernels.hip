@@ -2202,6 +2202,40 @@ __global__ __launch_bounds__(256) void gs_probe_keys_kernel(GsDbDev db, const u6
 // of equal node over the k-mer positions of a read.  WRITE = false counts them per read; WRITE = true stores
 // (code, start) of every run at seg_off[r] + i (code = value index, -1 miss "0", -2 INVALID "A").
 // ---------------------------------------------------------------------------------------------------
+// iterations [it0, it1) of one read: runs that start there, written behind out_base when WRITE; carry_last: node in front of it0
+template <bool WRITE, bool STRIPED>
+__device__ __forceinline__ uint32_t gs_segments_span(const GsSegParams &P, const uint8_t *rd, int L, int max, int it0, int it1, int &carry_last, u64 out_base,
+                                                     int lane, uint32_t *wave_g, int &first_node) {
+    const GsMark nomark = {0, nullptr, nullptr, nullptr};
+    uint32_t nseg = 0;
+    for (int it = it0; it < it1; it++) {
+        const int base = it << 7;
+        u64 Bhi[3], Blo[3], Bbad[3];
+#pragma unroll
+        for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
+        int node[2];
+        gs_probe_planes<0, STRIPED>(P.db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, nomark);
+        if (it == it0) first_node = gs_readlane(node[0], 0);
+        const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
+        const int last0 = gs_readlane(node[0], 63);
+        const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const bool head = node[s] != GS_NODE_NONE && node[s] != prev[s];
+            const u64 H = __ballot(head);
+            if (WRITE && head) {
+                const u64 idx = out_base + nseg + (u64)__popcll(H & ((1ULL << lane) - 1));
+                P.seg_code[idx] = node[s];
+                P.seg_start[idx] = base + 64 * s + lane;
+            }
+            nseg += (uint32_t)__popcll(H);
+        }
+        const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
+        carry_last = gs_readlane(((last_p - base) >> 6) ? node[1] : node[0], (last_p - base) & 63);
+    }
+    return nseg;
+}
+
 template <bool WRITE, bool STRIPED>
 __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
     __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
@@ -2212,41 +2246,34 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_segments_kernel(GsSegParams P) {
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (GS_BLOCK / 64);
     const int k = db.k;
-    const GsMark nomark = {0, nullptr, nullptr, nullptr};
+    if (P.pieces != nullptr) {  // the pieces of the reads that were left out
+        for (int64_t i = wave_id; i < P.n_pieces; i += n_waves) {
+            const GsSegPiece pc = P.pieces[i];
+            const uint64_t *po = P.off + (int64_t)pc.read * P.off_stride;
+            const u64 off = po[0];
+            const int L = (int)(po[1] - off);
+            int carry_last = WRITE ? pc.carry : GS_NODE_NONE, first_node = GS_NODE_NONE;
+            const uint32_t nseg = gs_segments_span<WRITE, STRIPED>(P, P.seq + off, L, L - k + 1, pc.it0, pc.it0 + pc.n_iter, carry_last,
+                                                                   WRITE ? P.seg_off[pc.read] + pc.out_off : 0, lane, s_g[wave_in_block], first_node);
+            if (!WRITE && lane == 0) {
+                GsSegPieceOut o = {first_node, carry_last, nseg, 0};
+                P.piece_out[i] = o;
+            }
+        }
+        return;
+    }
     for (int64_t r = wave_id; r < P.n_reads; r += n_waves) {
         const uint64_t *po = P.off + r * P.off_stride;
         const u64 off = po[0];
         const int L = (int)(po[1] - off);
         const int max = L - k + 1;
-        const uint8_t *rd = P.seq + off;
-        const int n_iter = max > 0 ? (max + 127) >> 7 : 0;
-        int carry_last = GS_NODE_NONE;
-        uint32_t nseg = 0;
-        const u64 out_base = WRITE ? P.seg_off[r] : 0;
-        for (int it = 0; it < n_iter; it++) {
-            const int base = it << 7;
-            u64 Bhi[3], Blo[3], Bbad[3];
-#pragma unroll
-            for (int w = 0; w < 3; w++) gs_load_word(rd, L, 2 * it + w, lane, Bhi[w], Blo[w], Bbad[w]);
-            int node[2];
-            gs_probe_planes<0, STRIPED>(db, Bhi, Blo, Bbad, base, max, lane, node, s_g[wave_in_block], nomark);
-            const int up0 = __shfl_up(node[0], 1), up1 = __shfl_up(node[1], 1);
-            const int last0 = gs_readlane(node[0], 63);
-            const int prev[2] = {lane == 0 ? carry_last : up0, lane == 0 ? last0 : up1};
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const bool head = node[s] != GS_NODE_NONE && node[s] != prev[s];
-                const u64 H = __ballot(head);
-                if (WRITE && head) {
-                    const u64 idx = out_base + nseg + (u64)__popcll(H & ((1ULL << lane) - 1));
-                    P.seg_code[idx] = node[s];
-                    P.seg_start[idx] = base + 64 * s + lane;
-                }
-                nseg += (uint32_t)__popcll(H);
-            }
-            const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
-            carry_last = gs_readlane(((last_p - base) >> 6) ? node[1] : node[0], (last_p - base) & 63);
+        if (max >= P.huge_min) {
+            if (!WRITE && lane == 0) P.seg_count[r] = GS_SEG_HUGE;
+            continue;
         }
+        int carry_last = GS_NODE_NONE, first_node;
+        const uint32_t nseg = gs_segments_span<WRITE, STRIPED>(P, P.seq + off, L, max, 0, max > 0 ? (max + 127) >> 7 : 0, carry_last, WRITE ? P.seg_off[r] : 0, lane,
+                                                               s_g[wave_in_block], first_node);
         if (!WRITE && lane == 0) P.seg_count[r] = nseg;
     }
 }

@@ -158,7 +158,23 @@ struct GsSegParams {
     int32_t *seg_code;
     int32_t *seg_start;
     int32_t off_stride;  // 1: running offsets; 2: (start, end) pairs (text mode)
-    int32_t pad3;
+    int32_t huge_min;    // reads of this many k-mer positions and more are left out (count pass: seg_count = GS_SEG_HUGE) ...
+    // ... and come back cut into pieces of whole iterations, one wave each (a chromosome on one wave: 150 ms per 5 Mbp and pass)
+    const struct GsSegPiece *pieces;
+    struct GsSegPieceOut *piece_out;  // count pass
+    int64_t n_pieces;
+};
+#define GS_SEG_HUGE 0xffffffffu
+#define GS_SEG_PIECE_ITERS 32  // iterations (of 128 positions) per piece
+struct GsSegPiece {
+    uint32_t read;
+    int32_t it0, n_iter;  // its iterations
+    int32_t carry;        // write pass: the node of the position in front of it (GS_NODE_NONE: the read starts here)
+    unsigned long long out_off;  // write pass: where its first run goes, relative to the read's first
+};
+struct GsSegPieceOut {
+    int32_t first_node, last_node;  // of its first and its last position
+    uint32_t count, pad;            // runs that start in it, its first position taken as a start
 };
 
 struct GsEncodeParams {

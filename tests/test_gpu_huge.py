@@ -101,3 +101,34 @@ def test_megabase_records(sdb):
         o, g = _both(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi, reads, **cfg)
         _assert_same(o, g)
     assert (o[2] & ga.F_FOUND).sum() > 400
+
+
+def _gpu_segments(m, reads):
+    seq, off = orc.pack_reads(reads)
+    seg_off, codes, starts, lens = m.segments(seq, off)
+    return [list(zip(codes[int(a):int(b)].tolist(), lens[int(a):int(b)].tolist())) for a, b in zip(seg_off[:-1], seg_off[1:])]
+
+
+@pytest.mark.parametrize("huge_min", ["300", None])
+def test_kraken_style_segments_of_long_records(sdb, monkeypatch, huge_min):
+    """printKrakenStyleOut (C/match/FastqKMerMatcher.java:597-611) for records that are cut into pieces of 32 iterations: the runs are
+    those of one pass over the record -- a run that crosses a seam is one run, one that ends at a seam is two"""
+    if huge_min:
+        monkeypatch.setenv("GS_HUGE_MIN", huge_min)
+    rng = np.random.default_rng(31)
+    g0 = sdb.genomes
+    reads = [_chimera(g0, rng, int(rng.integers(20, 20000)), n_frac=0.0005) for _ in range(300)]
+    reads.append(bytes(np.tile(g0[5], 3)))                                 # runs across many seams
+    reads.append(bytes(g0[2][:4096 + 30]) + bytes(g0[7][:4096]))            # a change exactly at a seam
+    reads.append(_chimera(g0, rng, 3_000_000, lo=40, hi=9000, n_frac=2e-5))
+    reads.append(b"ACGT" * 20000)
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    m = ga.FastqKMerMatcher(store)
+    got = _gpu_segments(m, reads)
+    for i, r in enumerate(reads):
+        want = odb.segments(r, cap=1 << 20)
+        assert got[i] == want, (i, len(r), got[i][:6], want[:6])
+        assert sum(n for _, n in got[i]) == len(r) - 30
+    m.close()
+    store.close()

@@ -47,4 +47,8 @@ for n, L in cases:
     table, _ = m.finish()
     print(f"{n:4d} records of {L:8d} bp: {best * 1e3:9.3f} ms -> {n * L / best / 1e9:8.2f} Gbp/s   (k-mers found: {int(table[:, 2].sum())})", flush=True)
     m.reset()
+    t0 = time.perf_counter()
+    seg_off = m.segments(seq, off)[0]  # (stages the batch: the copy is part of the time)
+    dt = time.perf_counter() - t0
+    print(f"     Kraken-style segments (from host memory, two passes, fetched): {int(seg_off[-1])} runs, {dt * 1e3:9.3f} ms", flush=True)
     del dseq, doff
