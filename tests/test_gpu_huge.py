@@ -132,3 +132,37 @@ def test_kraken_style_segments_of_long_records(sdb, monkeypatch, huge_min):
         assert sum(n for _, n in got[i]) == len(r) - 30
     m.close()
     store.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_chromosome_sized_record_in_a_fasta_file(sdb, tmp_path, gz):
+    """gs_host_match_files on a FASTA with a 3 Mbp record between contigs (60 bases per line; the record is longer than the pipeline's
+    blocks): table, totals and the Kraken-style lines are the oracle's"""
+    import gzip
+    from genestrip_amd import host
+    rng = np.random.default_rng(41)
+    g0 = sdb.genomes
+    recs = [_chimera(g0, rng, int(rng.integers(100, 3000))) for _ in range(40)]
+    recs.insert(17, _chimera(g0, rng, 3_000_000, lo=40, hi=9000, n_frac=2e-5))
+    recs.append(_chimera(g0, rng, 200_000, lo=40, hi=9000))
+    text = b"".join(b">rec%d len=%d\n" % (i, len(r)) + b"\n".join(r[j:j + 60] for j in range(0, len(r), 60)) + b"\n" for i, r in enumerate(recs))
+    p = str(tmp_path / ("asm.fa.gz" if gz else "asm.fasta"))
+    with (gzip.open(p, "wb", compresslevel=1) if gz else open(p, "wb")) as f:
+        f.write(text)
+    odb = orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    orun = orc.MatchRun(odb)
+    seq, off = orc.pack_reads(recs)
+    ocv, _ = orun.submit(seq, off)
+    want, _ = orun.finish()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    kr = str(tmp_path / "kraken.out")
+    table, _, tot = host.match_files(store, [p], kraken_out_path=kr, taxids=sdb.taxids)
+    assert np.array_equal(table, want) and tot.reads == len(recs) and tot.bps == sum(map(len, recs))
+    names = {-1: "0", -2: "A"}
+    lines = []
+    for i, r in enumerate(recs):
+        segs = odb.segments(r, cap=1 << 20)
+        segtxt = " ".join(f"{sdb.taxids[c] if c >= 0 else names[c]}:{n}" for c, n in segs)
+        lines.append(f"{'C' if ocv[i] >= 0 else 'U'}\trec{i}\t{sdb.taxids[ocv[i]] if ocv[i] >= 0 else '0'}\t{len(r)}\t{segtxt}")
+    assert open(kr).read().rstrip("\n").split("\n") == lines
+    store.close()
