@@ -1241,7 +1241,10 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
 #endif
 template <bool LDS_STATS, bool FROM_NODES, bool WIDE = false, bool STRIPED = false, int KC = 0>
 __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(GsMatchParams P, int32_t *scratch, uint32_t *serials) {
-    if (P.long_count[0] == 0) return;  // (a batch of short reads: nothing queued, no counters to set up and flush)
+    // long_list == nullptr: EVERY read of the batch is a long one (reads of one length, gs_match_submit_fixed: the launcher has looked) --
+    // no queue was written, chunk c holds the reads 64 c .. 64 c + 63
+    const bool all_long = P.long_list == nullptr;
+    if (!all_long && P.long_count[0] == 0) return;  // (a batch of short reads: nothing queued, no counters to set up and flush)
     GS_STATS_PROLOGUE()
     const int lane = gs_lane();
     const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));  // wave-uniform: per-read bookkeeping runs on the scalar unit
@@ -1252,7 +1255,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
     // one wave of that kernel and padded with GS_LONG_NONE.  The waves of this kernel draw chunks from a shared cursor
     // (long_count[1]) until the queue is empty: reads of very different lengths spread over the waves by themselves, and
     // every wave leaves the loop with the first chunk index beyond the end.
-    const unsigned int n_long = P.long_count[0];
+    const u64 n_long = all_long ? (u64)P.n_reads : (u64)P.long_count[0];
     // per-wave vote rows (tag = serial of the read that last touched a node, cnt = its votes in that read): in LDS for the
     // taxonomies whose counters are in LDS as well (every distinct node of every iteration reads and writes them: two
     // dependent round trips to HBM otherwise), else this wave's rows of `scratch`, which persist from launch to launch
@@ -1273,8 +1276,9 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(P.long_count + 1, 1u);
         c = (uint32_t)gs_rfl((int)c);
-        if ((u64)c * GS_LONG_CHUNK >= (u64)n_long) break;
-        const uint32_t mine = P.long_list[(size_t)c * GS_LONG_CHUNK + (size_t)lane];
+        if ((u64)c * GS_LONG_CHUNK >= n_long) break;
+        const u64 at = (u64)c * GS_LONG_CHUNK + (u64)lane;
+        const uint32_t mine = all_long ? (at < n_long ? (uint32_t)at : GS_LONG_NONE) : P.long_list[at];
         for (u64 todo = __ballot(mine != GS_LONG_NONE); todo; todo &= todo - 1) {
             serial++;
             if (serial == 0) {  // wrap after 2^32 - 1 long reads on this wave: old tags could alias, so the wave's tag row starts over
