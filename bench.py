@@ -49,7 +49,7 @@ K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 64   # sequence bytes once + one 64 B line per k-mer
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 XGMI_LINKS, XGMI_GBS_PER_LINK_DIR = 7, 76.8            # per GPU: 7 links x 153.6 GB/s bidirectional
-ALL_LEGS = "main,occ,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,fasta,files"
+ALL_LEGS = "main,occ,large,huge,filter,c2file,tableonly,e2e,striped,dbbuild,long,r250,fasta,sweep,files"
 # committed rocprofv3 --pmc summaries per workload, newest first: the fallback when the in-run passes cannot be taken
 PROFILE_ROUNDS = {"match": ("r03", "r02"), "large_store": ("r03", "r02"), "filter": ("r03", "r02")}
 PMC_GROUPS = (
@@ -768,6 +768,8 @@ def main():
             if "r250" in legs:
                 extra["reads_250bp"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 250, 6_000_000, 1_000_000,
                                                     "gs_match_kernel (220 k-mer positions per read)")
+            if "sweep" in legs:
+                extra["read_len_sweep"] = leg_read_len_sweep(synth, torch, db, gen, m, dev)
             if "fasta" in legs:
                 extra["fasta_records"] = leg_fasta_records(ga, orc, torch, db, m, dev, cores)
             if "files" in legs:  # (last: it closes the matcher)
@@ -885,6 +887,42 @@ def leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, read_len, n, nch
     return {"workload": "match: %d reads x %d bp, k=%d, the configs[1] store" % (n, read_len, K), "kernel": kernel,
             "ms_per_step": round(best * 1e3, 3), "gbps": round(n * read_len / best / 1e9, 2),
             "parity": {"reads_checked": nchk, "bit_exact": bool(np.array_equal(table, otable))}}
+
+
+def leg_read_len_sweep(synth, torch, db, gen, m, dev, lengths=(100, 125, 150, 158, 159, 190, 222, 250, 286, 287, 300), bases=1_200_000_000):
+    """Gbp/s by read length on the configs[1] store at a constant number of bases: up to 128 k-mer positions (158 bp) a read is one
+    iteration of gs_match_kernel, above that one iteration of gs_match_long_kernel per 128 positions -- an iteration costs what a whole
+    short read does however few of its positions are live, which is the step at 159 bp.  Whole step by the host clock, best of 3,
+    batches of one length without an offsets array (gs_match_submit_fixed) and, for the lengths around the step, with one."""
+    rows = {}
+    for L in lengths:
+        n = bases // L
+        dseq = torch.empty(n * L, dtype=torch.uint8, device=dev)
+        doff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        synth.reads_device(gen, db.genomes.shape[0], db.genomes.shape[1], n, dseq, doff, read_len=L)
+        torch.cuda.synchronize()
+        row = {}
+        for how in ("fixed", "offsets") if L in (150, 159, 250) else ("fixed",):
+            best = None
+            for _ in range(3):
+                m.reset()
+                m.sync()
+                t0 = time.perf_counter()
+                if how == "fixed":
+                    m.submit_fixed(dseq, L, n, 0)
+                else:
+                    m.submit(dseq, doff, 0, n_reads=n)
+                m.sync()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            row[how] = round(n * L / best / 1e9, 1)
+        rows[str(L)] = row["fixed"] if len(row) == 1 else row
+        del dseq, doff
+    m.reset()
+    fixed = [v if not isinstance(v, dict) else v["fixed"] for v in rows.values()]
+    steps = [abs(a - b) / max(a, b) for a, b in zip(fixed[:-1], fixed[1:])]
+    return {"workload": "match: %.1f Gbases per length, k=%d, the configs[1] store" % (bases / 1e9, K), "gbps_by_read_length": rows,
+            "min_gbps": min(fixed), "max_gbps": max(fixed), "largest_step_between_adjacent_lengths": round(max(steps), 3)}
 
 
 def leg_fasta_records(ga, orc, torch, db, m, dev, cores):

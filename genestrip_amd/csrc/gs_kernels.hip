@@ -1175,7 +1175,9 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     const uint64_t *po = P.off + wave_id * P.off_stride;   // offsets of the current read
     for (int64_t r = wave_id; r < n_reads; r += n_waves, po += po_step) {
         GsKernargPtr kp = kp0;
+#ifndef GS_KERNARG_HOISTED  // (experiment, DESIGN 8.1 "kernarg re-reads": let the compiler keep the parameters live across the loop)
         asm volatile("" : "+s"(kp));
+#endif
         const GsMatchParams &Q = *(const GsMatchParams *)kp;
         u64 off;
         int L;

@@ -164,22 +164,50 @@ GS_HD uint64_t gs_tab_stripe_first(uint32_t bucket_bits, uint32_t n_parts, uint3
     return 4 * gs_stripe_first(bucket_bits - 2, n_parts, p);
 }
 
+#ifndef GS_ONE_PRODUCT
+#define GS_ONE_PRODUCT 0  // experiment ("quarter-rate multiplies"): gate bits / second bucket from the bits of ONE product
+#endif
+GS_HD uint32_t gs_bitrev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
 GS_HD uint32_t gs_rec_bucket(uint32_t gh, uint32_t rec_bits, int choice) {
+#if GS_ONE_PRODUCT
+    const uint32_t p = gh * 0x27D4EB2Fu;
+    return (choice ? gs_bitrev32(p) : p) >> (32 - rec_bits);
+#else
     return (gh * (choice ? 0x165667B1u : 0x27D4EB2Fu)) >> (32 - rec_bits);
+#endif
 }
 
 // minimizer gate word (32 bits) and the two bits an entry sets in it
 GS_HD uint32_t gs_mgate_word(uint32_t m, uint32_t word_bits) { return (m * 0x85EBCA77u) >> (32 - word_bits); }
 GS_HD uint32_t gs_mgate_bits(uint32_t m) {
+#if GS_ONE_PRODUCT
+    const uint32_t y = m * 0x85EBCA77u;  // (the word's product: its low bits)
+    return (1u << (y & 31)) | (1u << ((y >> 5) & 31));
+#else
     const uint32_t y = m * 0xC2B2AE3Du;  // a second product: independent of the word index at any gate size
     return (1u << (y >> 27)) | (1u << ((y >> 22) & 31));
+#endif
 }
 // A third bit of the same word, the "second bucket" hint: set for a gate key iff a window of its minimizer was placed in the
 // minimizer's SECOND candidate bucket (gs_rec_bucket(gh, 1)).  A probe whose hint is clear loads the first bucket's line only --
 // cuckoo placement tries the first choice first, so about two windows in three sit there --; a hint set by a neighbour of the
 // word costs the second line, nothing else.  (Windows without a bucket need no hint: their k-mers are in the table, which the
 // `more` bit of EITHER bucket line announces.)
+#if GS_ONE_PRODUCT
+GS_HD uint32_t gs_mgate_hint(uint32_t m) { return 1u << (((m * 0x85EBCA77u) >> 10) & 31); }
+#else
 GS_HD uint32_t gs_mgate_hint(uint32_t m) { return 1u << (((m * 0xC2B2AE3Du) >> 17) & 31); }
+#endif
 // the two context keys of a window (gs_gate_ctx_key of its k-mers with j >= 4 / j <= 3) from the window planes; c = k - 15
 // The context key keeps its top 24 bits from the MINIMIZER alone and takes the low 8 from minimizer and context together: the gate
 // word of a context key (gs_mgate_word_ctx) then lies in a 64-byte line chosen by the minimizer, so that the two keys a run of
