@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "gs_bloom_create", "gs_bloom_build", "gs_bloom_get", "gs_bloom_destroy", "gs_filter_submit", "gs_filter_sync", "gs_filter_kernel_time",
     "gs_calibrate",
     "gs_match_get_device", "gs_inflate_members", "gs_inflater_create", "gs_inflater_feed", "gs_inflater_tail", "gs_gunzipper_open", "gs_gunzipper_reopen", "gs_gunzipper_next", "gs_gunzipper_info", "gs_gunzipper_first_span", "gs_gunzipper_park", "gs_gunzipper_close", "gs_gunzip_plan_device", "gs_gunzip_free", "gs_gunzip_device", "gs_text_cut_device", "gs_device_fetch", "gs_inflater_fetch", "gs_filter_get_device", "gs_inflater_reset", "gs_inflater_destroy", "gs_inflate_last_error",
-    "gs_filter_compact_text", "gs_match_compact_text", "gs_deflater_create", "gs_deflater_pack", "gs_deflater_info", "gs_deflater_destroy",
+    "gs_filter_compact_text", "gs_match_compact_text", "gs_deflater_create", "gs_deflater_pack", "gs_deflater_info", "gs_deflater_destroy", "gs_deflater_append", "gs_deflater_pending", "gs_deflater_flush",
     "gs_deflate_bound", "gs_deflate_host", "gs_deflate_host_reference", "gs_deflate_last_error", "gs_match_text_descriptors", "gs_match_submit_fixed",
 )
 
@@ -186,6 +186,9 @@ def lib():
         "gs_deflater_create": (ci, [vp, ci]),
         "gs_deflater_pack": (ci, [vp, vp, i64, vp, i64, vp]),
         "gs_deflater_info": (ci, [vp, vp]),
+        "gs_deflater_append": (ci, [vp, vp, i64]),
+        "gs_deflater_pending": (i64, [vp]),
+        "gs_deflater_flush": (ci, [vp, vp, i64, vp]),
         "gs_deflater_destroy": (ci, [vp]),
         "gs_deflate_bound": (i64, [i64]),
         "gs_deflate_host": (ci, [ci, vp, i64, vp, i64, vp]),
@@ -329,6 +332,26 @@ class DeviceDeflater:
         if rc != 0:
             raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
         return n_out.value
+
+    def append(self, d_text, n):
+        """gs_deflater_append: the text waits on the device for flush()"""
+        p = C.c_void_p(d_text.data_ptr() if hasattr(d_text, "data_ptr") else int(d_text))
+        _ready(d_text)
+        rc = lib().gs_deflater_append(self.h, p, int(n))
+        if rc != 0:
+            raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
+
+    def pending(self):
+        return int(lib().gs_deflater_pending(self.h))
+
+    def flush(self):
+        """the waiting text as BGZF members (numpy uint8)"""
+        out = np.empty(deflate_bound(self.pending()), dtype=np.uint8)
+        n_out = C.c_int64(0)
+        rc = lib().gs_deflater_flush(self.h, out.ctypes.data_as(C.c_void_p), int(out.shape[0]), C.byref(n_out))
+        if rc != 0:
+            raise GsError(rc, (lib().gs_deflate_last_error() or b"").decode(errors="replace"))
+        return out[:n_out.value]
 
     def close(self):
         if getattr(self, "h", None):

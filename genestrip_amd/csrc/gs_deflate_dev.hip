@@ -901,6 +901,11 @@ struct gs_deflater {
     uint32_t *h_hist = nullptr;    // page-locked, 320 words
     u64 *h_total = nullptr;        // page-locked
     int64_t stored_members = 0, members = 0, bytes_in = 0, bytes_out = 0;
+    // text waiting for gs_deflater_flush (gs_deflater_append): chunks of a few MiB are compressed together -- a call costs ~0.6 ms of
+    // launches, the code's construction on the host and two waits whatever its size
+    uint8_t *d_acc = nullptr;
+    size_t acc_cap = 0;
+    int64_t acc_n = 0;
 };
 
 extern "C" int gs_deflater_create(gs_deflater **out, int device) {
@@ -938,7 +943,7 @@ extern "C" int gs_deflater_destroy(gs_deflater *d) {
     if (!d) return GS_OK;
     hipSetDevice(d->device);
     if (d->stream) hipStreamSynchronize(d->stream);
-    for (void *p : {(void *)d->d_slots, (void *)d->d_out, (void *)d->d_sizes, (void *)d->d_crc, (void *)d->d_hist, (void *)d->d_off, (void *)d->d_tables}) hipFree(p);
+    for (void *p : {(void *)d->d_slots, (void *)d->d_out, (void *)d->d_sizes, (void *)d->d_crc, (void *)d->d_hist, (void *)d->d_off, (void *)d->d_tables, (void *)d->d_acc}) hipFree(p);
     hipHostFree(d->h_tables);
     hipHostFree(d->h_hist);
     hipHostFree(d->h_total);
@@ -1028,6 +1033,42 @@ extern "C" int gs_deflater_pack(gs_deflater *d, const uint8_t *d_text, int64_t n
     return GS_OK;
 } catch (const std::bad_alloc &) {
     return gd_fail(GS_E_NOMEM, "out of host memory");
+}
+
+// d_text[0, n) (device memory, complete) behind the text that is waiting; the source is free again when the call returns
+extern "C" int gs_deflater_append(gs_deflater *d, const uint8_t *d_text, int64_t n) {
+    if (!d || n < 0 || (n > 0 && !d_text)) return gd_fail(GS_E_INVALID, "bad argument");
+    if (n == 0) return GS_OK;
+    GD_TRY(hipSetDevice(d->device));
+    const size_t need = (size_t)(d->acc_n + n) + 64;
+    if (d->acc_cap < need) {
+        uint8_t *p = nullptr;
+        const size_t cap = std::max(need + need / 2, (size_t)48 << 20);
+        GD_TRY(hipStreamSynchronize(d->stream));
+        if (hipMalloc((void **)&p, cap) != hipSuccess) return gd_fail(GS_E_NOMEM, "gs_deflater_append: no device memory");
+        if (d->acc_n > 0 && hipMemcpy(p, d->d_acc, (size_t)d->acc_n, hipMemcpyDeviceToDevice) != hipSuccess) {
+            hipFree(p);
+            return gd_fail(GS_E_HIP, "gs_deflater_append: copy");
+        }
+        hipFree(d->d_acc);
+        d->d_acc = p;
+        d->acc_cap = cap;
+    }
+    GD_TRY(hipMemcpyAsync(d->d_acc + d->acc_n, d_text, (size_t)n, hipMemcpyDeviceToDevice, d->stream));
+    GD_TRY(hipMemsetAsync(d->d_acc + d->acc_n + n, 0, 64, d->stream));  // (the kernels read a little past the end)
+    GD_TRY(hipStreamSynchronize(d->stream));
+    d->acc_n += n;
+    return GS_OK;
+}
+extern "C" int64_t gs_deflater_pending(const gs_deflater *d) { return d ? d->acc_n : 0; }
+// the waiting text as BGZF members into out (room for gs_deflate_bound(gs_deflater_pending)); nothing waits afterwards
+extern "C" int gs_deflater_flush(gs_deflater *d, uint8_t *out, int64_t out_cap, int64_t *n_out) {
+    if (!d || !n_out) return gd_fail(GS_E_INVALID, "bad argument");
+    *n_out = 0;
+    if (d->acc_n == 0) return GS_OK;
+    const int rc = gs_deflater_pack(d, d->d_acc, d->acc_n, out, out_cap, n_out);
+    if (rc == GS_OK) d->acc_n = 0;
+    return rc;
 }
 
 // [0] members written, [1] text bytes, [2] compressed bytes so far

@@ -751,8 +751,12 @@ public:
         give_back(std::move(out));
         return true;
     }
+    // text of this file that waits somewhere else (DeviceWriter: chunks gathered on the device are compressed together) has to be
+    // in the queue before bytes from the host are: called in front of every host-side write and of close()
+    std::function<void()> before_host_write;
     void write(std::vector<uint8_t> &&buf, bool packed = false) {
         if (!active() || buf.empty()) return;
+        if (before_host_write) before_host_write();
         std::unique_lock<std::mutex> l(m_);
         if (!th_.joinable()) th_ = std::thread([this] { drain(); });
         cv_.wait(l, [&] { return q_.size() < 64; });
@@ -794,6 +798,7 @@ public:
     }
     // flushes and closes; false if any write failed
     bool close() {
+        if (active() && before_host_write) before_host_write();
         if (th_.joinable()) {
             {
                 std::lock_guard<std::mutex> l(m_);

@@ -572,6 +572,9 @@ const char *gs_inflate_last_error(void);
  * caller's: an empty member).  Synchronous.  gs_deflate_host: host text through the same path (tests, tools);
  * gs_deflate_host_reference: the same format from a plain CPU loop over the same tables (a test of the table builder that runs
  * without a device).  gs_deflater_info: [0] members, [1] text bytes, [2] compressed bytes so far.
+ * gs_deflater_append / _pending / _flush: chunks of a few MiB are better compressed together (a call costs ~0.6 ms whatever its
+ * size): append copies d_text[0, n) behind the text that is waiting on the device (the source is free when it returns), flush
+ * compresses what waits (out_cap >= gs_deflate_bound(gs_deflater_pending(d))).
  * ------------------------------------------------------------------------------------------------- */
 typedef struct gs_deflater gs_deflater;
 int gs_filter_compact_text(gs_bloom *bloom, int which, int with_probs, int slot, const uint8_t **d_out, int64_t *n_bytes, int64_t *n_records);
@@ -579,6 +582,9 @@ int gs_match_compact_text(gs_run *run, int with_probs, int slot, const uint8_t *
 int gs_deflater_create(gs_deflater **out, int device);
 int gs_deflater_pack(gs_deflater *d, const uint8_t *d_text, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_out);
 int gs_deflater_info(const gs_deflater *d, int64_t info[3]);
+int gs_deflater_append(gs_deflater *d, const uint8_t *d_text, int64_t n);
+int64_t gs_deflater_pending(const gs_deflater *d);
+int gs_deflater_flush(gs_deflater *d, uint8_t *out, int64_t out_cap, int64_t *n_out);
 int gs_deflater_destroy(gs_deflater *d);
 int64_t gs_deflate_bound(int64_t n);
 int gs_deflate_host(int device, const uint8_t *text, int64_t n, uint8_t *out, int64_t out_cap, int64_t *n_out);

@@ -168,3 +168,20 @@ def test_gather_needs_a_four_line_chunk_with_flags(sdb):
         m.compact_text()
     m.close()
     store.close()
+
+
+def test_chunks_compressed_together():
+    """gs_deflater_append / _flush: chunks wait on the device and leave as the members of ONE call; the members inflate to the chunks
+    in order, and nothing waits afterwards"""
+    import torch
+    d = ga.DeviceDeflater()
+    parts = [_fastq(700, seed=s) for s in (1, 2, 3)] + [b"@x\nACGT\n+\n~~~~\n"]
+    for p in parts:
+        t = torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda()
+        d.append(t, len(p))
+        del t  # (the source is free as soon as append returns)
+    assert d.pending() == sum(map(len, parts))
+    comp = d.flush().tobytes()
+    assert d.pending() == 0 and len(d.flush()) == 0
+    assert gzip.decompress(comp + ga.BGZF_EOF) == b"".join(parts)
+    d.close()
