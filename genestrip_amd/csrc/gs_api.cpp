@@ -25,6 +25,8 @@ typedef unsigned long long u64;
 
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hipStream_t stream);
+extern "C" hipError_t gs_launch_match_wide(const GsMatchParams *P, int ns, int n_cu, hipStream_t stream);
+extern "C" int gs_match_wide_mask(const GsMatchParams *P);
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
@@ -2313,7 +2315,7 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
     }
     const size_t cp = (size_t)run->stat_copies;
     // sums | max keys | double sums | long-read queue counters in ONE allocation: one memset clears them (gs_match_reset)
-    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * (GS_N_SUMS + 1 + GS_N_DCOLS) * cp + 2 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * (GS_N_SUMS + 1 + GS_N_DCOLS) * cp + 8 * sizeof(unsigned int));
     if (e == hipSuccess) {
         run->d_max = run->d_sums + nv * GS_N_SUMS * cp;
         run->d_dsums = reinterpret_cast<double *>(run->d_max + nv * cp);
@@ -2363,12 +2365,13 @@ static int collect_events(gs_run *run) {
 static int ensure_long(gs_run *run, int64_t n_reads) {
     // (the queue is filled in chunks of 64 entries per wave of the match kernel: every wave may leave one partly used)
     const int64_t room = n_reads + (int64_t)run->grid * (GS_BLOCK / 64) * 64;
-    if (run->long_cap < room) {
+    if (run->long_cap < room) {  // (three queues: long reads, reads for the three- and the four-sub-round kernel)
         HIP_TRY(hipStreamSynchronize(run->stream));
         hipFree(run->d_long_list);
         run->d_long_list = nullptr;
+        run->long_cap = 0;
         int64_t cap = std::max<int64_t>(room, 1024);
-        HIP_TRY(hipMalloc((void **)&run->d_long_list, sizeof(uint32_t) * (size_t)cap));
+        HIP_TRY(hipMalloc((void **)&run->d_long_list, sizeof(uint32_t) * (size_t)cap * 3));
         run->long_cap = cap;
     }
     if (!run->d_scratch) {
@@ -2468,6 +2471,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.flags = d_flags;
     P.long_count = run->d_long_count;
     P.long_list = run->d_long_list;
+    P.long_cap = run->long_cap;
     P.nodes = d_nodes;
     P.pos_off = (const unsigned long long *)d_pos_off;
     P.off_stride = off_stride;
@@ -2485,7 +2489,7 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
         P.stat_recs = run->d_stat_recs;
         P.stat_rec_count = (unsigned long long *)run->d_stat_rec_count;
     }
-    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 2 * sizeof(unsigned int), run->stream));
+    HIP_TRY(hipMemsetAsync(run->d_long_count, 0, 6 * sizeof(unsigned int), run->stream));
     // (reads of one short length each, or nodes that came from other ranks: nothing for the huge-read kernels)
     const bool huge = !d_nodes && (off_stride != 0 || fixed_len - run->db->info.k + 1 >= run->huge_min);
     if (huge && (rc = ensure_huge(run, &P))) return rc;
@@ -2502,6 +2506,8 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     // reads of one length with more than 128 k-mer positions (250-bp pairs, 150 bp at k < 23): every one of them would be queued for the
     // long-read kernel -- the pass that queues them is skipped (2.0 of 16.2 ms for 10 M reads of 150 bp at k = 16), the queue is the batch
     const bool all_long = off_stride == 0 && !d_nodes && !d_skip && fixed_len - run->db->info.k + 1 > 128 && !huge;
+    static const bool wide_on = !getenv("GS_WIDE") || atoi(getenv("GS_WIDE")) != 0;  // (GS_WIDE=0: every read above 128 positions on the long-read path)
+    P.wide_mask = wide_on ? gs_match_wide_mask(&P) : 0;
     if (all_long)
         P.long_list = nullptr;
     else
@@ -2512,6 +2518,15 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     if (run->cfg.profile) {
         HIP_TRY(hipEventRecord(e1, run->stream));
         run->pending.push_back({e0, e1});
+    }
+    const int pos_fixed = fixed_len - run->db->info.k + 1;
+    if (all_long && pos_fixed <= 256 && ((P.wide_mask >> (pos_fixed <= 192 ? 0 : 1)) & 1)) {  // the whole batch in trips of three / four sub-rounds
+        HIP_TRY(gs_launch_match_wide(&P, pos_fixed <= 192 ? 3 : 4, run->db->n_cu, run->stream));
+        return GS_OK;
+    }
+    if (!all_long && P.wide_mask) {  // what gs_match_kernel put into queues 1 and 2 (the kernels return at once when their queue is empty)
+        if (P.wide_mask & 1) HIP_TRY(gs_launch_match_wide(&P, 3, run->db->n_cu, run->stream));
+        if (P.wide_mask & 2) HIP_TRY(gs_launch_match_wide(&P, 4, run->db->n_cu, run->stream));
     }
     // reads with more than 128 k-mer positions were queued; the long-read kernel drains the queue
     HIP_TRY(gs_launch_match_long(&P, run->long_grid, run->d_scratch, run->d_serial, run->stream));

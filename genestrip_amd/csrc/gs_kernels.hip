@@ -346,24 +346,40 @@ __device__ __forceinline__ void gs_lookup_rest(const GsDbDev &db, uint32_t bkt, 
 // row index, so the minimum is the position as well).  Returns the offset of the chosen 15-mer inside the lane's k-mer.
 // wave_g: two rows of GS_ROW words per wave -- the ranks, and behind them (canonical 15-mer << 1 | strand) of every position,
 // which the lane that picks a position reads back instead of recomputing it.  cf[s] = that word for the lane's minimizer.
-template <int KC>
-__device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u64 (&Blo)[3], const uint32_t (&fhi)[2],
-                                                   const uint32_t (&flo)[2], const uint32_t (&rhi)[2], const uint32_t (&rlo)[2], int k,
-                                                   int lane, uint32_t *wave_g, int (&p)[2], uint32_t (&cf)[2]) {
+// NS: sub-rounds of 64 positions per trip (2: the kernels' iteration of 128 positions; 3, 4: gs_match_wide_kernel, reads of up to
+// 192 / 256 positions in ONE trip).  The rank carries its row index in eight bits, so beyond two sub-rounds there are TWO rank rows:
+// A for positions 0 .. 143 (read by sub-rounds 0 and 1), B for positions 128 .. 64 NS + 15 with the index counted from 128 (read by
+// sub-rounds 2 and 3); the 16 positions both need are written twice.  Layout of the wave's words: [A: GS_ROW][B: GS_ROW, NS > 2 only]
+// [canonical 15-mers of all positions: 64 NS + 16].
+#define GS_WIDE_WORDS(NS) (2 * GS_ROW + 64 * (NS) + 32)
+template <int KC, int NS = 2>
+__device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[NS + 1], const u64 (&Blo)[NS + 1], const uint32_t (&fhi)[NS],
+                                                   const uint32_t (&flo)[NS], const uint32_t (&rhi)[NS], const uint32_t (&rlo)[NS], int k,
+                                                   int lane, uint32_t *wave_g, int (&p)[NS], uint32_t (&cf)[NS]) {
+    static_assert(NS >= 2 && NS <= 4, "two rank rows of 144 positions");
+    constexpr bool TWO = NS > 2;
+    constexpr int ROWB = GS_ROW, CAN = TWO ? 2 * GS_ROW : GS_ROW;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
         // gs_lmer_canon of the k-mer's first 15-mer; its reverse complement is the top 15 bases of the k-mer's (rhi, rlo: the
         // orientation step needs them anyway), and "the smaller of f and r, low bit = f was it" is min(2f + 1, 2r)
         const uint32_t f = ((fhi[s] & 0x7fffu) << GS_MIN_L) | (flo[s] & 0x7fffu);
         const uint32_t rr = ((rhi[s] >> (k - GS_MIN_L)) << GS_MIN_L) | (rlo[s] >> (k - GS_MIN_L));
         const uint32_t c = min((f << 1) | 1u, rr << 1);
-        wave_g[64 * s + lane] = gs_lmer_rank(gs_canon_hash(c >> 1), (uint32_t)(64 * s + lane));
-        wave_g[GS_ROW + 64 * s + lane] = c;
+        const uint32_t h = gs_canon_hash(c >> 1);
+        if (!TWO || s < 2) wave_g[64 * s + lane] = gs_lmer_rank(h, (uint32_t)(64 * s + lane));
+        if (TWO && s >= 2) wave_g[ROWB + 64 * (s - 2) + lane] = gs_lmer_rank(h, (uint32_t)(64 * (s - 2) + lane));
+        if (TWO && s == 2 && lane < 16) wave_g[128 + lane] = gs_lmer_rank(h, (uint32_t)(128 + lane));
+        wave_g[CAN + 64 * s + lane] = c;
     }
     if (lane < 16) {
-        const uint32_t c = gs_lmer_canon((uint32_t)(Bhi[2] >> lane) & 0x7fffu, (uint32_t)(Blo[2] >> lane) & 0x7fffu);
-        wave_g[128 + lane] = gs_lmer_rank(gs_canon_hash(c >> 1), (uint32_t)(128 + lane));
-        wave_g[GS_ROW + 128 + lane] = c;
+        const uint32_t c = gs_lmer_canon((uint32_t)(Bhi[NS] >> lane) & 0x7fffu, (uint32_t)(Blo[NS] >> lane) & 0x7fffu);
+        const uint32_t h = gs_canon_hash(c >> 1);
+        if (!TWO)
+            wave_g[64 * NS + lane] = gs_lmer_rank(h, (uint32_t)(64 * NS + lane));
+        else
+            wave_g[ROWB + 64 * (NS - 2) + lane] = gs_lmer_rank(h, (uint32_t)(64 * (NS - 2) + lane));
+        wave_g[CAN + 64 * NS + lane] = c;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -374,17 +390,18 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
     // folded with min3.
     constexpr int ND = KC ? KC - GS_MIN_L + 1 : 32 - GS_MIN_L;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
+        const uint32_t *row = (TWO && s >= 2) ? wave_g + ROWB + 64 * (s - 2) + lane : wave_g + 64 * s + lane;
         uint32_t g[ND];
 #pragma unroll
-        for (int d = 0; d < ND; d++) g[d] = (KC || d < w) ? wave_g[64 * s + lane + d] : 0xffffffffu;
+        for (int d = 0; d < ND; d++) g[d] = (KC || d < w) ? row[d] : 0xffffffffu;
         __builtin_amdgcn_sched_group_barrier(0x100, (ND + 1) / 2, 0);  // the DS reads first ...
         uint32_t mn = g[0];
 #pragma unroll
         for (int d = 1; d < ND; d++) mn = g[d] < mn ? g[d] : mn;
         __builtin_amdgcn_sched_group_barrier(0x002, ND, 0);            // ... then the min chain
-        const int idx = (int)(mn & 0xffu);
-        cf[s] = wave_g[GS_ROW + idx];
+        const int idx = (int)(mn & 0xffu) + ((TWO && s >= 2) ? 128 : 0);
+        cf[s] = wave_g[CAN + idx];
         p[s] = idx - (64 * s + lane);
     }
     __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next iteration / read
@@ -398,24 +415,27 @@ __device__ __forceinline__ void gs_wave_minimizers(const u64 (&Bhi)[3], const u6
 // read from the store -- one per first-seen k-mer; tools/huge_lines.py), with the fabric's line rate the bound (0.89).  The lanes of
 // a minimizer run OR their offset bits into a word of the wave's LDS rows (free again after the minimizer scan), the lane that owns
 // the lowest bit sends the word: ~13 atomics per read from the store instead of ~60.
-template <int KC, bool STRIPED, int CTX = 2, bool AGG = false>
-__device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[3], const u64 (&Blo)[3],
-                                                const u64 (&Bbad)[3], int base, int max, int lane, int (&node)[2],
+template <int KC, bool STRIPED, int CTX = 2, bool AGG = false, int NS = 2>
+__device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&Bhi)[NS + 1], const u64 (&Blo)[NS + 1],
+                                                const u64 (&Bbad)[NS + 1], int base, int max, int lane, int (&node)[NS],
                                                 uint32_t *wave_g, const GsMark &mk) {
+    static_assert(NS == 2 || !AGG, "the seen-bit accumulators are laid out for two sub-rounds");
     const int k = KC ? KC : db.k;  // KC = compile-time k of the specialised kernels (0: any k)
     const uint32_t kmask = (1u << k) - 1u;
     const uint32_t vmask2 = 2u * ((1u << db.vbits) - 1u);
     const int shift_rem = (int)db.vbits + 3;
     const uint32_t bmask = (uint32_t)db.bucket_mask;  // n_buckets <= 2^29
-    const bool any_bad = (Bbad[0] | Bbad[1] | Bbad[2]) != 0;
-    uint32_t fhi[2], flo[2];
+    bool any_bad = false;
+#pragma unroll
+    for (int w = 0; w <= NS; w++) any_bad = any_bad || Bbad[w] != 0;
+    uint32_t fhi[NS], flo[NS];
     // Which lanes hold a live k-mer is kept as a wave-level MASK (a scalar register pair), not as a per-lane flag: "position < max"
     // is a mask the scalar unit builds from the read length, every later condition is one vector compare whose result is a
     // mask already, and a mask conditions a lane directly (inverse ballot) -- no flag is materialised in a vector register and
     // compared again.
-    u64 act[2];
+    u64 act[NS];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
         const int nv = max - base - 64 * s;  // valid positions of this sub-round
         const u64 vm = nv >= 64 ? ~0ULL : (nv <= 0 ? 0ULL : ((1ULL << nv) - 1ULL));
         fhi[s] = (uint32_t)gs_funnel(Bhi[s], Bhi[s + 1], lane) & kmask;
@@ -430,39 +450,41 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
     }
     if (db.mgate != nullptr) {
         // minimizer gate: lanes that share a minimizer read the same gate word -> one request
-        int mp[2];
-        uint32_t cf[2];
+        int mp[NS];
+        uint32_t cf[NS];
         GS_STAMP(2, fhi[1] ^ flo[1])
-        uint32_t rhi[2], rlo[2];  // reverse complement of the k-mer
+        uint32_t rhi[NS], rlo[NS];  // reverse complement of the k-mer
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < NS; s++) {
             rhi[s] = __brev(fhi[s]) >> (32 - k);
             rlo[s] = (__brev(flo[s]) >> (32 - k)) ^ kmask;
         }
-        gs_wave_minimizers<KC>(Bhi, Blo, fhi, flo, rhi, rlo, k, lane, wave_g, mp, cf);
+        gs_wave_minimizers<KC, NS>(Bhi, Blo, fhi, flo, rhi, rlo, k, lane, wave_g, mp, cf);
         GS_STAMP(3, cf[0] ^ cf[1])
-        uint32_t gh[2], ohi[2], olo[2];
-        int j[2];
+        uint32_t gh[NS], ohi[NS], olo[NS];
+        int j[NS];
 #pragma unroll
-        for (int s = 0; s < 2; s++) gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi[s], rlo[s], k, mp[s], gh[s], ohi[s], olo[s], j[s]);
+        for (int s = 0; s < NS; s++) gs_min_oriented_cf(cf[s], fhi[s], flo[s], rhi[s], rlo[s], k, mp[s], gh[s], ohi[s], olo[s], j[s]);
         // Lanes that look into their minimizer's second bucket as well.  Every store carries the hint bits (gs_mgate_hint); they
         // are USED where a record line is dear -- a context-keyed store (hundreds of millions of k-mers, lines from HBM) and a
         // striped one (lines over xGMI) --: on a store whose records sit in the caches the second line costs less than the
         // test (measured on configs[1]: 6.74 ms without, 6.94 ms with it; 47 M store 8.66 / 8.68; 473 M store 15.39 / 15.03).
         const bool use_hint = STRIPED || CTX == 1 || (CTX == 2 && db.mgate_ctx);
-        u64 two[2] = {~0ULL, ~0ULL};
+        u64 two[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) two[s] = ~0ULL;
         if ((GS_ABLATE & 4) == 0) {
             // the gate words of both sub-rounds are requested together (lanes without a live k-mer read word 0): one round
             // trip, no exec-mask regions
-            uint32_t gw[2];
-            uint32_t gk[2];  // what the gate is keyed by: the minimizer, or (big stores) the minimizer + four bases next to it
+            uint32_t gw[NS];
+            uint32_t gk[NS];  // what the gate is keyed by: the minimizer, or (big stores) the minimizer + four bases next to it
 #pragma unroll
-            for (int s = 0; s < 2; s++) gk[s] = (CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_gate_ctx_key(gh[s], ohi[s], olo[s], j[s], k) : gh[s];
+            for (int s = 0; s < NS; s++) gk[s] = (CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_gate_ctx_key(gh[s], ohi[s], olo[s], j[s], k) : gh[s];
 #pragma unroll
-            for (int s = 0; s < 2; s++)
+            for (int s = 0; s < NS; s++)
                 gw[s] = db.mgate[GS_ACT(act[s]) ? ((CTX == 1 || (CTX == 2 && db.mgate_ctx)) ? gs_mgate_word_ctx(gk[s], db.mgate_bits) : gs_mgate_word(gk[s], db.mgate_bits)) : 0u];
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
+            for (int s = 0; s < NS; s++) {
                 const uint32_t bits = gs_mgate_bits(gk[s]);
                 act[s] &= __ballot((gw[s] & bits) == bits);  // no false negatives
                 if (use_hint) two[s] = __ballot((gw[s] & gs_mgate_hint(gk[s])) != 0u);  // a window of this key may sit in the second bucket
@@ -471,7 +493,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         }
         if (GS_ABLATE & 6) {  // keep the values alive, look nothing up
 #pragma unroll
-            for (int s = 0; s < 2; s++)
+            for (int s = 0; s < NS; s++)
                 if (GS_ACT(act[s]) && (gh[s] ^ ohi[s] ^ olo[s] ^ (uint32_t)j[s]) == 0x12345u) node[s] = 0;
             return;
         }
@@ -482,7 +504,10 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // is what bounds a store that does not fit the caches).  Both loads of a sub-round are in flight together and the
             // compares are straight-line code (bitwise, no short-circuit branches: every branch is an exec-mask save /
             // restore on the scalar unit, which this kernel keeps as busy as the vector unit)
-            if ((act[0] | act[1]) == 0) return;  // nothing passed the gate: a read that is not from the store
+            u64 any_act = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) any_act |= act[s];
+            if (any_act == 0) return;  // nothing passed the gate: a read that is not from the store
             if (AGG && mk.count_unique) {  // accumulators of the seen bits: 80 minimizer positions x 2 buckets per sub-round
 #pragma unroll
                 for (int q = 0; q < 5; q++) wave_g[64 * q + lane] = 0u;
@@ -496,7 +521,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
             // first for certain; big stores only): 473 M store 15.0 -> 15.2 ms, striped 7.24 -> 7.40.  The round trip that was
             // taken out does not come off the kernel's time.)
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
+            for (int s = 0; s < NS; s++) {
                 bool pending = false;
                 if (GS_ACT(act[s])) {
                     const uint32_t jj = (uint32_t)j[s];
@@ -568,11 +593,11 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         }
     }
     // ---- the ordinary table: one 64-byte bucket line per k-mer (stores without records: k < 19, partitions, > 2^21 values)
-    uint32_t bkt[2];
-    u64 want[2];
-    GsHalf bk[2];
+    uint32_t bkt[NS];
+    u64 want[NS];
+    GsHalf bk[NS];
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
         const u64 h = gs_kmer_hash(fhi[s], flo[s], k, kmask);
         bkt[s] = (uint32_t)h & bmask;
         want[s] = (h >> db.bucket_bits) << shift_rem;
@@ -587,7 +612,7 @@ __device__ __forceinline__ void gs_probe_planes(const GsDbDev &db, const u64 (&B
         if (GS_ACT(act[s])) gs_load_half(db.table, bkt[s], 0, bk[s]);  // both sub-rounds' loads in flight together
     }
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NS; s++) {
         bool pending = false;
         if (GS_ACT(act[s])) {
             int vs = -1, sl = 0;
@@ -1165,6 +1190,8 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     gs_stamp(-1);
 #endif
     uint32_t lq_base = 0, lq_used = GS_LONG_CHUNK;  // this wave's chunk of the long-read queue
+    __shared__ uint32_t s_wq[GS_BLOCK / 64][2][2];  // ... and of the two queues of the wide kernels: base, entries used
+    if (lane < 4) s_wq[wave_in_block][lane >> 1][lane & 1] = (lane & 1) ? GS_LONG_CHUNK : 0u;
     // (Software pipelines over the wave's reads were measured again in round 3, after the LDS and gate round trips had been batched:
     // (1) the bases of the next read into a second LDS buffer by LDS-DMA and the offsets two reads ahead, requested at the top of
     // the iteration: 7.59 -> 7.77 ms on configs[1] -- requests OLDER than the gate loads are waited for with them (in-order
@@ -1201,6 +1228,26 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
                     continue;
                 }
             }
+            {   // 129 .. 256 positions: to the kernel that takes such a read in ONE trip of three / four sub-rounds, where there is one
+                const int pos = L - k + 1;
+                const int wq = (pos <= 192 && (Q.wide_mask & 1)) ? 1 : ((pos <= 256 && (Q.wide_mask & 2)) ? 2 : 0);
+                if (wq) {  // (this wave's chunk of that queue: base and entries used, in LDS -- a cold path)
+                    uint32_t *ws = s_wq[wave_in_block][wq - 1];
+                    uint32_t wb = (uint32_t)gs_rfl((int)ws[0]), wu = (uint32_t)gs_rfl((int)ws[1]);
+                    if (wu == GS_LONG_CHUNK) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(Q.long_count + 2 * wq, (unsigned int)GS_LONG_CHUNK);
+                        wb = (uint32_t)gs_rfl((int)b);
+                        wu = 0;
+                    }
+                    if (lane == 0) {
+                        Q.long_list[(size_t)wq * (size_t)Q.long_cap + wb + wu] = (uint32_t)r;
+                        ws[0] = wb;
+                        ws[1] = wu + 1;
+                    }
+                    continue;
+                }
+            }
             if (lq_used == GS_LONG_CHUNK) {  // a fresh chunk of the queue for this wave
                 uint32_t b = 0;
                 if (lane == 0) b = atomicAdd(Q.long_count, (unsigned int)GS_LONG_CHUNK);
@@ -1223,10 +1270,307 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     if (lane < 15) atomicAdd(&gs_phase_acc[lane], gs_phase_row()[lane]);
 #endif
     if (lq_used < GS_LONG_CHUNK && (uint32_t)lane >= lq_used) P.long_list[lq_base + (uint32_t)lane] = GS_LONG_NONE;  // (rest of the last chunk)
+    if (P.wide_mask) {
+#pragma unroll
+        for (int wq = 1; wq <= 2; wq++) {
+            const uint32_t wb = s_wq[wave_in_block][wq - 1][0], wu = s_wq[wave_in_block][wq - 1][1];
+            if (wu < GS_LONG_CHUNK && (uint32_t)lane >= wu) P.long_list[(size_t)wq * (size_t)P.long_cap + wb + (uint32_t)lane] = GS_LONG_NONE;
+        }
+    }
     if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const u64 base = s_cur[wave_in_block][0], used = s_cur[wave_in_block][1];
         if (used < 64 && (u64)lane >= used) P.stat_recs[base + (u64)lane].vi = -1;
+    }
+    GS_STATS_EPILOGUE()
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Reads of 129 .. 64 NS k-mer positions in ONE trip (NS = 3: up to 192 positions, 159 .. 222 bp at k = 31, 150 bp at k < 23).  The
+// long-read path takes such a read in two iterations of 128 positions, each a chain of dependent round trips (bases, gate word,
+// record lines) that costs what a whole short read does however few of its positions are live: 158 bp 233 Gbp/s, 159 bp 129.  Here
+// the NS sub-rounds of the read go through the probe together -- their gate words and record lines are in flight side by side --
+// and the read is reduced like a short read (one pass, distinct tax ids in registers); the price is registers (planes, k-mers and
+// nodes of NS sub-rounds), i.e. fewer waves per SIMD.  Same results as gs_process_read by construction: the same probe, the same
+// closed forms, and every rule of matchRead (C/match/FastqKMerMatcher.java:330-531) restated for NS words of positions.
+// ---------------------------------------------------------------------------------------------------
+template <int NS, int KC, int CTX>
+__device__ __forceinline__ void gs_process_read_wide(const GsMatchParams &P, const GsStats &st, int64_t r, u64 off, int L, int lane, uint32_t *wave_g) {
+    // (the list of distinct tax ids goes through the wave's rows when the threshold rule needs it in memory: the probe is through with them)
+    int *s_dvi = reinterpret_cast<int *>(wave_g), *s_dcnt = reinterpret_cast<int *>(wave_g) + 64 * NS;
+    static_assert(GS_WIDE_WORDS(NS) >= 2 * 64 * NS, "room for the list");
+    const GsDbDev &db = P.db;
+    const int k = KC ? KC : db.k;
+    const int max = L - k + 1;
+    const uint8_t *rd = P.seq + off;
+    int out_class = -1, out_flags = 0;
+    if (max > 0) {
+        const u64 key_lo = ((1ULL << 40) - 1) - ((u64)(P.first_read_no + r) & ((1ULL << 40) - 1));
+        u64 Bhi[NS + 1], Blo[NS + 1], Bbad[NS + 1];
+#pragma unroll
+        for (int w = 0; w <= NS; w++) gs_load_word(rd, L, w, lane, Bhi[w], Blo[w], Bbad[w]);
+        int bad_lo = 0;
+        bool bad_hi = false;
+        {   // bad-base census for the closed form of the INVALID steps (as gs_process_read; every word belongs to this one trip)
+            const int q = max - 1;
+#pragma unroll
+            for (int w = 0; w <= NS; w++) {
+                const int lo_bits = q - 64 * w;
+                const u64 m_lo = lo_bits >= 64 ? ~0ULL : (lo_bits <= 0 ? 0ULL : ((1ULL << lo_bits) - 1));
+                bad_lo += __popcll(Bbad[w] & m_lo);
+                bad_hi = bad_hi || ((Bbad[w] & ~m_lo) != 0);
+            }
+        }
+        int node[NS];
+        const GsMark mk = {P.count_unique, P.hit_counts, nullptr, nullptr};
+        gs_probe_planes<KC, false, CTX, false, NS>(db, Bhi, Blo, Bbad, 0, max, lane, node, wave_g, mk);
+        u64 hit[NS], any_hit = 0;
+        int n_miss = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            hit[s] = __ballot(node[s] >= 0);
+            any_hit |= hit[s];
+            n_miss += __popcll(__ballot(node[s] == GS_NODE_MISS));
+        }
+        if (any_hit != 0) {
+            out_flags = GS_F_FOUND | GS_F_RETURNED;
+            // ---- contigs (:390-413, :455-473): a lane that starts a run of a hit node books it; the run ends at the next change of
+            // node, in its own word or a later one, or with the read
+            u64 chg[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const int up = __shfl_up(node[s], 1);
+                int before = GS_NODE_NONE;  // (in front of position 0: nothing -- the first position starts a run)
+                if (s > 0) before = gs_readlane(node[s - 1], 63);
+                const int prev = lane == 0 ? before : up;
+                const int nvs = max - 64 * s;
+                const u64 vm = nvs >= 64 ? ~0ULL : (nvs <= 0 ? 0ULL : ((1ULL << nvs) - 1ULL));
+                chg[s] = __ballot(node[s] != prev) & vm;
+            }
+            int later = max;  // first change in the words behind the current one (or the read's end)
+#pragma unroll
+            for (int s = NS - 1; s >= 0; s--) {
+                const u64 above = (chg[s] >> 1) >> lane;
+                const int end = above ? 64 * s + lane + 1 + __builtin_ctzll(above) : later;
+                if (GS_ACT(hit[s] & chg[s])) st.contig(node[s], end - (64 * s + lane), key_lo);
+                if (chg[s]) later = 64 * s + __builtin_ctzll(chg[s]);
+            }
+            // ---- the distinct hit nodes in order of first appearance: reads1KMer (:434-439), mergeReadTaxidPath (:568-586); entry i
+            // of the list (node, votes) lives in lane i & 63 of register set i >> 6
+            int dvi[NS], dcnt[NS], nd = 0;
+            int path = -1, ptin = 0, ptout = 0, used = 0;
+#pragma unroll
+            for (int h = 0; h < NS; h++) {
+                dvi[h] = -1;
+                dcnt[h] = 0;
+            }
+            u64 m[NS];
+#pragma unroll
+            for (int s = 0; s < NS; s++) m[s] = hit[s];
+            for (;;) {
+                int j = -1;
+#pragma unroll
+                for (int s = NS - 1; s >= 0; s--)
+                    if (m[s]) j = 64 * s + __builtin_ctzll(m[s]);
+                if (j < 0) break;
+                int nvj = 0;
+#pragma unroll
+                for (int s = 0; s < NS; s++)
+                    if ((j >> 6) == s) nvj = gs_readlane(node[s], j & 63);
+                int c = 0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const u64 e = __ballot(node[s] == nvj);
+                    c += __popcll(e);
+                    m[s] &= ~e;
+                }
+#pragma unroll
+                for (int h = 0; h < NS; h++)
+                    if ((nd >> 6) == h && lane == (nd & 63)) {
+                        dvi[h] = nvj;
+                        dcnt[h] = c;
+                    }
+                nd++;
+                if (lane == 0) st.add(nvj, GS_S_READS_1KMER, 1);
+                if (P.classify) {
+                    const int ntin = st.tin[nvj], ntout = st.tout[nvj];
+                    const bool mine = lane < used;
+                    const bool a = mine && gs_anc_or_self(ptin, ptout, ntin);  // path anc-or-self of node
+                    const bool b = mine && gs_anc_or_self(ntin, ntout, ptin);  // node anc-or-self of path
+                    const u64 rel = __ballot(a || b);
+                    if (rel) {
+                        if (lane == __builtin_ctzll(rel) && a) {
+                            path = nvj;
+                            ptin = ntin;
+                            ptout = ntout;
+                        }
+                    } else if (used < P.max_paths) {
+                        if (lane == used) {
+                            path = nvj;
+                            ptin = ntin;
+                            ptout = ntout;
+                        }
+                        used++;
+                    }
+                }
+            }
+            // ---- classification (:474-531)
+            if (P.classify) {
+                const int tax_err = n_miss + bad_lo + (bad_hi ? 1 : 0);
+                const double mt = P.max_read_tax_err;
+                const bool disabled = mt >= 0 && ((mt >= 1 && (double)tax_err > mt) || ((double)tax_err > mt * (double)max));
+                if (!disabled) {
+                    int cn = -1, first_node = -1, best = 0;
+                    // sumCounts per candidate path (SmallTaxTree.java:184-193): lanes = paths
+                    int sum = 0;
+                    for (int dd = 0; dd < nd; dd++) {
+                        int v = 0, c = 0;
+#pragma unroll
+                        for (int h = 0; h < NS; h++)
+                            if ((dd >> 6) == h) {
+                                v = gs_readlane(dvi[h], dd & 63);
+                                c = gs_readlane(dcnt[h], dd & 63);
+                            }
+                        if (lane < used && gs_anc_or_self(st.tin[v], st.tout[v], ptin)) sum += c;
+                    }
+                    u64 tie_mask = 0;  // max + ties exactly as the in-place scan (:476-487); tie order = path order
+                    for (int i = 0; i < used; i++) {
+                        const int si = gs_readlane(sum, i);
+                        if (si > best) {
+                            best = si;
+                            tie_mask = 0;
+                        }
+                        if (si >= best) tie_mask |= 1ULL << i;
+                    }
+                    int cand = path;
+                    if (P.threshold > 1) {  // lowestNodeWhereSumAboveThreshold per tied path (SmallTaxTree.java:208-221)
+#pragma unroll
+                        for (int h = 0; h < NS; h++) {
+                            s_dvi[64 * h + lane] = dvi[h];
+                            s_dcnt[64 * h + lane] = dcnt[h];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        int mapped = -1;
+                        if ((tie_mask >> lane) & 1ULL) {
+                            int acc = 0;
+                            for (int x = path; x >= 0 && mapped < 0; x = st.parent[x])
+                                for (int dd = 0; dd < nd; dd++)
+                                    if (s_dvi[dd] == x) {
+                                        acc += s_dcnt[dd];
+                                        if (acc >= P.threshold) mapped = x;
+                                    }
+                        }
+                        cand = mapped;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    {
+                        bool first = true;
+                        for (u64 tm = tie_mask; tm; tm &= tm - 1) {
+                            const int x = gs_readlane(cand, __builtin_ctzll(tm));
+                            if (first) {
+                                cn = x;
+                                first_node = x;
+                                first = false;
+                            } else
+                                cn = gs_lca(st, cn, x);
+                        }
+                    }
+                    out_class = cn;
+                    if (cn < 0) {
+                        out_flags &= ~GS_F_RETURNED;  // "return false" (:497-500)
+                    } else {
+                        int read_kmers = best;
+                        if (P.threshold > 1) {  // sumCounts(readTaxIdNode[0]) after the promotion (:506-507)
+                            read_kmers = 0;
+                            const int ft = st.tin[first_node];
+                            for (int dd = 0; dd < nd; dd++) {
+                                int v = 0, c = 0;
+#pragma unroll
+                                for (int h = 0; h < NS; h++)
+                                    if ((dd >> 6) == h) {
+                                        v = gs_readlane(dvi[h], dd & 63);
+                                        c = gs_readlane(dcnt[h], dd & 63);
+                                    }
+                                if (gs_anc_or_self(st.tin[v], st.tout[v], ft)) read_kmers += c;
+                            }
+                        }
+                        const int class_err = max - read_kmers;
+                        const double mc = P.max_read_class_err;
+                        if (mc < 0 || (mc >= 1 && (double)class_err <= mc) || ((double)class_err <= mc * (double)max)) {
+                            out_flags |= GS_F_COUNTED;
+                            if (lane == 0) {
+                                const double err = (double)tax_err / (double)max;
+                                const double cerr = (double)class_err / (double)max;
+                                st.add(cn, GS_S_READS, 1);
+                                st.add(cn, GS_S_READS_KMERS, (u64)read_kmers);
+                                st.add(cn, GS_S_READS_BPS, (u64)L);
+                                st.dadd(cn, GS_D_ERR_SUM, err);
+                                st.dadd(cn, GS_D_ERR_SQ_SUM, err * err);
+                                st.dadd(cn, GS_D_CLASS_ERR_SUM, cerr);
+                                st.dadd(cn, GS_D_CLASS_ERR_SQ_SUM, cerr * cerr);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (P.class_vi) P.class_vi[r] = out_class;
+        if (P.flags) P.flags[r] = (uint8_t)out_flags;
+    }
+}
+
+// waves per SIMD, three sub-rounds: 8 (64 VGPRs, a few spilled) beats 7 / 6 (80 VGPRs, none spilled) / 5 / 4 on reads of 159, 190
+// and 222 bp -- 168 / 168 / 161 / 149 / 105 Gbp/s at 159 bp; four sub-rounds: 6 beats 8 / 7 / 5 -- 196 / 169 / 189 / 179 Gbp/s at
+// 250 bp (the long-read path: 180)
+#ifndef GS_WIDE_WAVES
+#define GS_WIDE_WAVES 8
+#endif
+#ifndef GS_WIDE4_WAVES
+#define GS_WIDE4_WAVES 6
+#endif
+#ifndef GS_WIDE_ANYK_WAVES  // (k as a run-time value; a store without records keeps half a bucket line per sub-round in registers: k = 16 table-only 112.6 Gbp/s at 7, 91.8 at 8, 112.0 at 6; a k = 25 record store: 7 = 8 > 6)
+#define GS_WIDE_ANYK_WAVES 7
+#endif
+#define GS_WIDE_WAVES_OF(NS, KC) ((NS) == 4 ? GS_WIDE4_WAVES : ((KC) ? GS_WIDE_WAVES : GS_WIDE_ANYK_WAVES))
+// The reads of queue NS - 2 (filled by gs_match_kernel: 129 .. 192 positions in queue 1, 193 .. 256 in queue 2, GsMatchParams::
+// wide_mask), or -- long_list == nullptr: reads of one length, gs_match_submit_fixed, the launcher has looked -- every read of the batch.
+template <bool LDS_STATS, int NS, int KC>
+__global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WIDE_WAVES_OF(NS, KC), GS_WIDE_WAVES_OF(NS, KC)))) void gs_match_wide_kernel(GsMatchParams P) {
+    const bool all = P.long_list == nullptr;
+    unsigned int *qc = P.long_count + 2 * (NS - 2);  // [0] entries (whole chunks of GS_LONG_CHUNK), [1] the cursor the waves draw chunks from
+    if (!all && qc[0] == 0) return;
+    GS_STATS_PROLOGUE()
+    __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][GS_WIDE_WORDS(NS)];
+    const int lane = gs_lane();
+    const int wave_in_block = gs_rfl((int)(threadIdx.x >> 6));
+    const u64 n_q = all ? (u64)P.n_reads : (u64)qc[0];
+    const uint32_t *list = all ? nullptr : P.long_list + (size_t)(NS - 2) * (size_t)P.long_cap;
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();  // (as gs_match_long_kernel: no lane-0 test threaded through the back edge)
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(qc + 1, 1u);
+        c = (uint32_t)gs_rfl((int)c);
+        if ((u64)c * GS_LONG_CHUNK >= n_q) break;
+        const u64 at = (u64)c * GS_LONG_CHUNK + (u64)lane;
+        const uint32_t mine = all ? (at < n_q ? (uint32_t)at : GS_LONG_NONE) : list[at];
+        for (u64 todo = __ballot(mine != GS_LONG_NONE); todo; todo &= todo - 1) {
+            const int64_t r = (int64_t)(uint32_t)gs_readlane((int)mine, __builtin_ctzll(todo));
+            u64 off;
+            int L;
+            if (P.off_stride == 0) {
+                L = P.fixed_len;
+                off = (u64)r * (u64)(uint32_t)L;
+            } else {
+                const uint64_t *po = P.off + r * P.off_stride;
+                off = po[0];
+                L = (int)(po[1] - off);
+            }
+            gs_process_read_wide<NS, KC, 2>(P, st, r, off, L, lane, s_g[wave_in_block]);
+        }
     }
     GS_STATS_EPILOGUE()
 }
@@ -2748,6 +3092,38 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
         else
             hipLaunchKernelGGL((gs_match_long_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
     }
+    return hipGetLastError();
+}
+
+// which of the wide kernels (bit 0: three sub-rounds, reads of 129 .. 192 positions; bit 1: four, 193 .. 256) serve this store and run
+extern "C" int gs_match_wide_mask(const GsMatchParams *P) {
+    if (P->nodes != nullptr || P->db.n_parts > 1 || P->max_paths > 64) return 0;
+    return 3;
+}
+// ns = 3 / 4: the reads of that queue -- or all reads of the batch when P->long_list is null -- each in one trip; grid: the device's CUs
+extern "C" hipError_t gs_launch_match_wide(const GsMatchParams *P, int ns, int n_cu, hipStream_t stream) {
+    if ((ns != 3 && ns != 4) || ((gs_match_wide_mask(P) >> (ns - 3)) & 1) == 0) return hipErrorNotSupported;
+    const size_t lds = gs_stats_lds_bytes(P->db.n_values);
+    const bool lds_stats = P->db.n_values <= GS_NV_LDS && !gs_force_global_stats();
+    const int v = (lds_stats ? 4 : 0) | (ns == 4 ? 2 : 0) | (P->db.k == 31 ? 1 : 0);
+    void (*kern)(GsMatchParams) = nullptr;
+    switch (v) {
+        case 0: kern = gs_match_wide_kernel<false, 3, 0>; break;
+        case 1: kern = gs_match_wide_kernel<false, 3, 31>; break;
+        case 2: kern = gs_match_wide_kernel<false, 4, 0>; break;
+        case 3: kern = gs_match_wide_kernel<false, 4, 31>; break;
+        case 4: kern = gs_match_wide_kernel<true, 3, 0>; break;
+        case 5: kern = gs_match_wide_kernel<true, 3, 31>; break;
+        case 6: kern = gs_match_wide_kernel<true, 4, 0>; break;
+        default: kern = gs_match_wide_kernel<true, 4, 31>; break;
+    }
+    static int occ_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // resident workgroups per CU (dynamic LDS aside: small against the static part)
+    int occ = occ_of[v];
+    if (occ == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, GS_BLOCK, lds) != hipSuccess || occ < 1) occ = 1;
+        occ_of[v] = occ;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_cu * occ), dim3(GS_BLOCK), lds, stream, *P);
     return hipGetLastError();
 }
 

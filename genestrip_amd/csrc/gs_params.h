@@ -75,6 +75,11 @@ struct GsMatchParams {
     uint32_t *huge_cnt;                // [huge_slots][n_values] positions that hold the node
     uint32_t *huge_first;              // [huge_slots][n_values] its first position (~0: none)
     uint32_t *huge_touch;              // [huge_slots][n_values] the nodes with a count, in no order (GsHugeHead.n_touch of them)
+    // long_count: three queues x (entries, cursor) -- queue 0 the long-read kernel's, queues 1 / 2 those of gs_match_wide_kernel<3 / 4>
+    // (reads of 129 .. 192 / 193 .. 256 positions, where wide_mask says that kernel serves this run); long_list: queue q at q * long_cap
+    int64_t long_cap;
+    int32_t wide_mask;
+    int32_t pad2;
     int32_t huge_slots;                // <= GS_HUGE_SLOTS
     int32_t huge_min;                  // k-mer positions from which a read goes this way
     int32_t huge_chunk_min;            // k-mer positions per chunk at least (a multiple of 128)

@@ -1,5 +1,6 @@
 """Gbp/s of the match path by read length on the configs[1] store (developer tool): where the short-read kernel (<= 128 k-mer positions)
-hands over to the long-read kernel.    python tools/read_len_sweep.py [len ...]"""
+hands over to the long-read kernel (and, for batches of one length with 129 .. 192 positions, to the three-sub-round kernel).
+    [GS_SWEEP_OFFSETS=1] python tools/read_len_sweep.py [len ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +24,10 @@ for L in lens:
         m.reset()
         m.sync()
         t0 = time.perf_counter()
-        m.submit(dseq, doff, 0, n_reads=n)
+        if os.environ.get("GS_SWEEP_OFFSETS"):
+            m.submit(dseq, doff, 0, n_reads=n)  # the general call: an offsets array
+        else:
+            m.submit_fixed(dseq, L, n, 0)       # reads of one length, back to back
         m.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
