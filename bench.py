@@ -764,10 +764,10 @@ def main():
                 extra["end_to_end"] = leg_end_to_end(ga, synth, torch, db, m, min(n, 4_000_000), dseq, doff)
             if "long" in legs:
                 extra["long_reads"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 1000, 1_500_000, 200_000,
-                                                   "gs_match_kernel (queues) + gs_match_long_kernel")
+                                                   "gs_match_long_kernel (the batch is its queue: reads of one length)")
             if "r250" in legs:
                 extra["reads_250bp"] = leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, 250, 6_000_000, 1_000_000,
-                                                    "gs_match_kernel (220 k-mer positions per read)")
+                                                    "gs_match_wide_kernel<4> (220 k-mer positions per read, one trip of four sub-rounds)")
             if "sweep" in legs:
                 extra["read_len_sweep"] = leg_read_len_sweep(synth, torch, db, gen, m, dev)
             if "fasta" in legs:
@@ -891,9 +891,11 @@ def leg_reads_of(ga, synth, orc, torch, db, gen, m, dev, cores, read_len, n, nch
 
 def leg_read_len_sweep(synth, torch, db, gen, m, dev, lengths=(100, 125, 150, 158, 159, 190, 222, 250, 286, 287, 300), bases=1_200_000_000):
     """Gbp/s by read length on the configs[1] store at a constant number of bases: up to 128 k-mer positions (158 bp) a read is one
-    iteration of gs_match_kernel, above that one iteration of gs_match_long_kernel per 128 positions -- an iteration costs what a whole
-    short read does however few of its positions are live, which is the step at 159 bp.  Whole step by the host clock, best of 3,
-    batches of one length without an offsets array (gs_match_submit_fixed) and, for the lengths around the step, with one."""
+    trip of gs_match_kernel (two sub-rounds of 64 positions), up to 192 / 256 positions (222 / 286 bp) one trip of
+    gs_match_wide_kernel (three / four sub-rounds), above that one iteration of gs_match_long_kernel per 128 positions -- a trip costs
+    about the same however few positions of its last sub-round are live, hence the steps at 159, 223 and 287 bp.  Whole step by the host
+    clock, best of 3, batches of one length without an offsets array (gs_match_submit_fixed) and, for three lengths, with one (the
+    queueing pass of gs_match_kernel in front of the other kernels)."""
     rows = {}
     for L in lengths:
         n = bases // L

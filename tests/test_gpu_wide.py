@@ -111,3 +111,25 @@ def test_other_k(k):
         n = 2500
         seq = np.frombuffer(b"".join(_chimera(db.genomes, rng, L, lo=k, hi=int(rng.choice([60, 300])), n_frac=0.002) for _ in range(n)), dtype=np.uint8)
         _fixed((k, db.kmers, db.value_idx, db.n_values, db.parent_vi), seq, L, n)
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_paired_end_lengths_from_a_fastq_file(sdb, tmp_path, gz):
+    """2 x 250-like reads (trimmed: 120 .. 251 bases) in a FASTQ file through gs_host_match_files: the device's record scan hands
+    (start, end) pairs to the match kernel, which spreads the reads over its queues; table and totals are the oracle's"""
+    import gzip
+    from genestrip_amd import host
+    rng = np.random.default_rng(8)
+    reads = [_chimera(sdb.genomes, rng, int(rng.integers(120, 252)), lo=60, hi=400, n_frac=0.001) for _ in range(20000)]
+    text = b"".join(b"@m%d/1\n%s\n+\n%s\n" % (i, r, b"F" * len(r)) for i, r in enumerate(reads))
+    p = str(tmp_path / ("r.fastq.gz" if gz else "r.fastq"))
+    with (gzip.open(p, "wb", compresslevel=1) if gz else open(p, "wb")) as f:
+        f.write(text)
+    seq, off = orc.pack_reads(reads)
+    orun = orc.MatchRun(orc.DB(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi))
+    orun.submit(seq, off, threads=4, per_read=False)
+    want, _ = orun.finish()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    table, _, tot = host.match_files(store, [p])
+    assert np.array_equal(table, want) and tot.reads == len(reads) and tot.bps == sum(map(len, reads))
+    store.close()
