@@ -27,6 +27,7 @@ extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStrea
 extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_wide(const GsMatchParams *P, int ns, int n_cu, hipStream_t stream);
 extern "C" int gs_match_wide_mask(const GsMatchParams *P);
+extern "C" hipError_t gs_launch_classify(const GsMatchParams *P, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
@@ -2510,8 +2511,11 @@ static int launch_batch(gs_run *run, const uint8_t *d_seq, const uint64_t *d_off
     P.wide_mask = wide_on ? gs_match_wide_mask(&P) : 0;
     if (all_long)
         P.long_list = nullptr;
-    else
+    else {
+        // reads of more than 128 positions into the queues of the kernels that take them (reads of one short length: there are none)
+        if (off_stride != 0 || fixed_len - run->db->info.k + 1 > 128) HIP_TRY(gs_launch_classify(&P, run->stream));
         HIP_TRY(gs_launch_match(&P, grid, run->stream));
+    }
     if (P.stat_recs && !all_long)  // (into copy 0 of the counters; part of the timed region)
         HIP_TRY(gs_launch_stat_reduce(P.stat_recs, run->d_stat_rec_count, rec_room, run->db->info.n_values, run->d_sums, run->d_max,
                                       run->d_dsums, run->d_stat_vi, run->stream));

@@ -1157,6 +1157,80 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
         __builtin_amdgcn_wave_barrier();                                                                                 \
     }
 
+// ---------------------------------------------------------------------------------------------------
+// Which kernel takes which read of a batch with an offsets array: up to 128 k-mer positions gs_match_kernel (which skips the others);
+// 129 .. 192 / 193 .. 256 positions gs_match_wide_kernel<3 / 4> where wide_mask says it serves this run (queues 1 / 2); more
+// gs_match_long_kernel (queue 0); huge_min positions and more the kernels that cut a read into chunks over many waves (the first
+// huge_slots of a batch).  A queue is a dense list of read numbers.  One thread per read and round, GS_CLS_READS reads per workgroup:
+// first the workgroup counts its reads per class (in LDS), ONE atomic per class reserves their places, then every read is written to
+// its place.  (Queued by gs_match_kernel itself -- one atomic per 64 reads and wave, all on one address -- 9.4 M reads of 159 bp cost
+// 1.9 ms: atomics on one address execute one after the other, about 11 ns each.)
+// ---------------------------------------------------------------------------------------------------
+#define GS_CLS_THREADS 1024
+#define GS_CLS_ROUNDS 8
+#define GS_CLS_READS (GS_CLS_THREADS * GS_CLS_ROUNDS)
+__global__ __launch_bounds__(GS_CLS_THREADS) void gs_classify_kernel(GsMatchParams P, int from_nodes) {
+    __shared__ unsigned int s_n[4], s_base[4];
+    if (P.skip != nullptr && *P.skip != 0) return;
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = gs_lane();
+    const int k = P.db.k;
+    const int64_t b0 = (int64_t)blockIdx.x * GS_CLS_READS;
+    unsigned int place[GS_CLS_ROUNDS];  // class << 30 | place among the workgroup's reads of that class
+#pragma unroll
+    for (int j = 0; j < GS_CLS_ROUNDS; j++) {
+        const int64_t r = b0 + (int64_t)j * GS_CLS_THREADS + threadIdx.x;
+        int cls = 0;  // 0: gs_match_kernel; 1 / 2: wide queues; 3: long-read queue (queue 0); huge reads take a slot or class 3
+        if (r < P.n_reads) {
+            int L;
+            if (P.off_stride == 0)
+                L = P.fixed_len;
+            else {
+                const uint64_t *po = P.off + r * P.off_stride;
+                L = (int)(po[1] - po[0]);
+            }
+            const int pos = L - k + 1;
+            if (pos > 128) {
+                cls = (pos <= 192 && (P.wide_mask & 1)) ? 1 : ((pos <= 256 && (P.wide_mask & 2)) ? 2 : 3);
+                if (!from_nodes && P.huge_count != nullptr && pos >= P.huge_min) {
+                    const unsigned int slot = atomicAdd(P.huge_count, 1u);  // (rare: contigs, chromosomes)
+                    if (slot < (unsigned int)P.huge_slots) {
+                        P.huge_list[slot] = (uint32_t)r;
+                        cls = 0;
+                    } else
+                        cls = 3;
+                }
+            }
+        }
+        unsigned int pl = 0;
+#pragma unroll
+        for (int c = 1; c <= 3; c++) {
+            const u64 m = __ballot(cls == c);
+            if (m != 0) {  // (wave-uniform)
+                unsigned int wb = 0;
+                if (lane == 0) wb = atomicAdd(&s_n[c], (unsigned int)__popcll(m));
+                wb = (unsigned int)gs_rfl((int)wb);
+                if (cls == c) pl = ((unsigned int)c << 30) | (wb + (unsigned int)__popcll(m & ((1ULL << lane) - 1ULL)));
+            }
+        }
+        place[j] = pl;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= 3 && s_n[threadIdx.x] != 0) s_base[threadIdx.x] = atomicAdd(P.long_count + 2 * (threadIdx.x % 3), s_n[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GS_CLS_ROUNDS; j++) {
+        const unsigned int c = place[j] >> 30;
+        if (c != 0) P.long_list[(size_t)(c % 3) * (size_t)P.long_cap + s_base[c] + (place[j] & 0x3fffffffu)] = (uint32_t)(b0 + (int64_t)j * GS_CLS_THREADS + threadIdx.x);
+    }
+}
+extern "C" hipError_t gs_launch_classify(const GsMatchParams *P, hipStream_t stream) {
+    if (P->n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gs_classify_kernel, dim3((unsigned)((P->n_reads + GS_CLS_READS - 1) / GS_CLS_READS)), dim3(GS_CLS_THREADS), 0, stream, *P, P->nodes != nullptr ? 1 : 0);
+    return hipGetLastError();
+}
+
 template <bool LDS_STATS, bool FROM_NODES, int KC, bool WIDE = false, bool STRIPED = false, int CTX = 0>
 __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAVES, GS_WAVES))) void gs_match_kernel(GsMatchParams P) {
     GS_STATS_PROLOGUE()
@@ -1189,9 +1263,6 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     __builtin_amdgcn_wave_barrier();
     gs_stamp(-1);
 #endif
-    uint32_t lq_base = 0, lq_used = GS_LONG_CHUNK;  // this wave's chunk of the long-read queue
-    __shared__ uint32_t s_wq[GS_BLOCK / 64][2][2];  // ... and of the two queues of the wide kernels: base, entries used
-    if (lane < 4) s_wq[wave_in_block][lane >> 1][lane & 1] = (lane & 1) ? GS_LONG_CHUNK : 0u;
     // (Software pipelines over the wave's reads were measured again in round 3, after the LDS and gate round trips had been batched:
     // (1) the bases of the next read into a second LDS buffer by LDS-DMA and the offsets two reads ahead, requested at the top of
     // the iteration: 7.59 -> 7.77 ms on configs[1] -- requests OLDER than the gate loads are waited for with them (in-order
@@ -1216,48 +1287,7 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
             L = (int)(po[1] - off);
         }
         GS_STAMP(0, L)
-        if (L - k + 1 > 128) {  // long read: queue it for gs_match_long_kernel
-            if (!FROM_NODES && Q.huge_count != nullptr && L - k + 1 >= Q.huge_min) {
-                // tens of thousands of positions and more: to the kernels that take a read apart over many waves (the first huge_slots
-                // of a batch; the others go the way of the long reads)
-                unsigned int slot = 0;
-                if (lane == 0) slot = atomicAdd(Q.huge_count, 1u);
-                slot = (unsigned int)gs_rfl((int)slot);
-                if (slot < (unsigned int)Q.huge_slots) {
-                    if (lane == 0) Q.huge_list[slot] = (uint32_t)r;
-                    continue;
-                }
-            }
-            {   // 129 .. 256 positions: to the kernel that takes such a read in ONE trip of three / four sub-rounds, where there is one
-                const int pos = L - k + 1;
-                const int wq = (pos <= 192 && (Q.wide_mask & 1)) ? 1 : ((pos <= 256 && (Q.wide_mask & 2)) ? 2 : 0);
-                if (wq) {  // (this wave's chunk of that queue: base and entries used, in LDS -- a cold path)
-                    uint32_t *ws = s_wq[wave_in_block][wq - 1];
-                    uint32_t wb = (uint32_t)gs_rfl((int)ws[0]), wu = (uint32_t)gs_rfl((int)ws[1]);
-                    if (wu == GS_LONG_CHUNK) {
-                        uint32_t b = 0;
-                        if (lane == 0) b = atomicAdd(Q.long_count + 2 * wq, (unsigned int)GS_LONG_CHUNK);
-                        wb = (uint32_t)gs_rfl((int)b);
-                        wu = 0;
-                    }
-                    if (lane == 0) {
-                        Q.long_list[(size_t)wq * (size_t)Q.long_cap + wb + wu] = (uint32_t)r;
-                        ws[0] = wb;
-                        ws[1] = wu + 1;
-                    }
-                    continue;
-                }
-            }
-            if (lq_used == GS_LONG_CHUNK) {  // a fresh chunk of the queue for this wave
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(Q.long_count, (unsigned int)GS_LONG_CHUNK);
-                lq_base = (uint32_t)gs_rfl((int)b);
-                lq_used = 0;
-            }
-            if (lane == 0) Q.long_list[lq_base + lq_used] = (uint32_t)r;
-            lq_used++;
-            continue;
-        }
+        if (L - k + 1 > 128) continue;  // another kernel's: gs_classify_kernel has put it into that kernel's queue
         uint32_t pre[3];
         const uint8_t *rd = Q.seq + off;
 #pragma unroll
@@ -1269,14 +1299,6 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WAV
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < 15) atomicAdd(&gs_phase_acc[lane], gs_phase_row()[lane]);
 #endif
-    if (lq_used < GS_LONG_CHUNK && (uint32_t)lane >= lq_used) P.long_list[lq_base + (uint32_t)lane] = GS_LONG_NONE;  // (rest of the last chunk)
-    if (P.wide_mask) {
-#pragma unroll
-        for (int wq = 1; wq <= 2; wq++) {
-            const uint32_t wb = s_wq[wave_in_block][wq - 1][0], wu = s_wq[wave_in_block][wq - 1][1];
-            if (wu < GS_LONG_CHUNK && (uint32_t)lane >= wu) P.long_list[(size_t)wq * (size_t)P.long_cap + wb + (uint32_t)lane] = GS_LONG_NONE;
-        }
-    }
     if (!LDS_STATS && P.stat_recs != nullptr) {  // the rest of the wave's last chunk
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const u64 base = s_cur[wave_in_block][0], used = s_cur[wave_in_block][1];
@@ -1541,7 +1563,7 @@ __device__ __forceinline__ void gs_process_read_wide(const GsMatchParams &P, con
 template <bool LDS_STATS, int NS, int KC>
 __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WIDE_WAVES_OF(NS, KC), GS_WIDE_WAVES_OF(NS, KC)))) void gs_match_wide_kernel(GsMatchParams P) {
     const bool all = P.long_list == nullptr;
-    unsigned int *qc = P.long_count + 2 * (NS - 2);  // [0] entries (whole chunks of GS_LONG_CHUNK), [1] the cursor the waves draw chunks from
+    unsigned int *qc = P.long_count + 2 * (NS - 2);  // [0] entries, [1] the cursor the waves draw chunks of GS_LONG_CHUNK entries from
     if (!all && qc[0] == 0) return;
     GS_STATS_PROLOGUE()
     __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][GS_WIDE_WORDS(NS)];
@@ -1556,18 +1578,26 @@ __global__ __launch_bounds__(GS_BLOCK) __attribute__((amdgpu_waves_per_eu(GS_WID
         c = (uint32_t)gs_rfl((int)c);
         if ((u64)c * GS_LONG_CHUNK >= n_q) break;
         const u64 at = (u64)c * GS_LONG_CHUNK + (u64)lane;
-        const uint32_t mine = all ? (at < n_q ? (uint32_t)at : GS_LONG_NONE) : list[at];
+        const uint32_t mine = at < n_q ? (all ? (uint32_t)at : list[at]) : GS_LONG_NONE;
+        // the offsets of the chunk's reads with one gather (every lane its own read's), not one dependent load per read
+        u64 my_off = 0;
+        int my_len = 0;
+        if (P.off_stride != 0 && mine != GS_LONG_NONE) {
+            const uint64_t *po = P.off + (int64_t)mine * P.off_stride;
+            my_off = po[0];
+            my_len = (int)(po[1] - my_off);
+        }
         for (u64 todo = __ballot(mine != GS_LONG_NONE); todo; todo &= todo - 1) {
-            const int64_t r = (int64_t)(uint32_t)gs_readlane((int)mine, __builtin_ctzll(todo));
+            const int i = __builtin_ctzll(todo);
+            const int64_t r = (int64_t)(uint32_t)gs_readlane((int)mine, i);
             u64 off;
             int L;
             if (P.off_stride == 0) {
                 L = P.fixed_len;
                 off = (u64)r * (u64)(uint32_t)L;
             } else {
-                const uint64_t *po = P.off + r * P.off_stride;
-                off = po[0];
-                L = (int)(po[1] - off);
+                off = ((u64)(uint32_t)gs_readlane((int)(my_off >> 32), i) << 32) | (u64)(uint32_t)gs_readlane((int)(uint32_t)my_off, i);
+                L = gs_readlane(my_len, i);
             }
             gs_process_read_wide<NS, KC, 2>(P, st, r, off, L, lane, s_g[wave_in_block]);
         }
@@ -1597,8 +1627,8 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
     const int64_t wave_id = (int64_t)blockIdx.x * (GS_BLOCK / 64) + wave_in_block;
     __shared__ __attribute__((aligned(8))) uint32_t s_g[GS_BLOCK / 64][2 * GS_ROW + (STRIPED ? GS_STRIPE_WORDS : 0)];
     GS_STRIPE_TABLE(&P)
-    // The queue (written by the preceding kernel on the same stream) comes in chunks of GS_LONG_CHUNK entries, each filled by
-    // one wave of that kernel and padded with GS_LONG_NONE.  The waves of this kernel draw chunks from a shared cursor
+    // The queue (written by gs_classify_kernel on the same stream) is a dense list; the waves of this kernel draw chunks of
+    // GS_LONG_CHUNK entries from a shared cursor
     // (long_count[1]) until the queue is empty: reads of very different lengths spread over the waves by themselves, and
     // every wave leaves the loop with the first chunk index beyond the end.
     const u64 n_long = all_long ? (u64)P.n_reads : (u64)P.long_count[0];
@@ -1624,7 +1654,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_LONG_ATTR void gs_match_long_kernel(Gs
         c = (uint32_t)gs_rfl((int)c);
         if ((u64)c * GS_LONG_CHUNK >= n_long) break;
         const u64 at = (u64)c * GS_LONG_CHUNK + (u64)lane;
-        const uint32_t mine = all_long ? (at < n_long ? (uint32_t)at : GS_LONG_NONE) : P.long_list[at];
+        const uint32_t mine = at < n_long ? (all_long ? (uint32_t)at : P.long_list[at]) : GS_LONG_NONE;  // (the queue is a dense list)
         for (u64 todo = __ballot(mine != GS_LONG_NONE); todo; todo &= todo - 1) {
             serial++;
             if (serial == 0) {  // wrap after 2^32 - 1 long reads on this wave: old tags could alias, so the wave's tag row starts over
