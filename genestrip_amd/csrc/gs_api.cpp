@@ -28,6 +28,7 @@ extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hip
 extern "C" hipError_t gs_launch_match_wide(const GsMatchParams *P, int ns, int n_cu, hipStream_t stream);
 extern "C" int gs_match_wide_mask(const GsMatchParams *P);
 extern "C" hipError_t gs_launch_classify(const GsMatchParams *P, hipStream_t stream);
+extern "C" hipError_t gs_launch_fold_stats(long long *sums, unsigned long long *maxk, double *dsums, long long nv, int copies, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int32_t *scratch, uint32_t *serial,
                                            hipStream_t stream);
 extern "C" hipError_t gs_launch_unique_count(const u64 *table, const uint32_t *bitmap, int64_t n_slots, uint32_t vbits,
@@ -2314,6 +2315,12 @@ extern "C" int gs_match_begin(gs_run **out, gs_db *db, const gs_match_cfg *cfg) 
         run->use_stat_recs = nv <= GS_STAT_REC_MAX_VALUES;
         if (const char *ev = getenv("GS_STAT_RECS")) run->use_stat_recs = run->use_stat_recs && atoi(ev) != 0;
     }
+    else {
+        // counters in LDS: every workgroup adds its table to the device's when it ends -- 2 048 workgroups x the same few cache lines,
+        // and atomics on one line execute one after the other (~11 ns each: a tail of 0.1-0.2 ms behind the kernel).  16 copies here too.
+        run->stat_copies = 16;
+        if (const char *ev = getenv("GS_STAT_COPIES")) run->stat_copies = std::max(1, std::min(64, atoi(ev)));
+    }
     const size_t cp = (size_t)run->stat_copies;
     // sums | max keys | double sums | long-read queue counters in ONE allocation: one memset clears them (gs_match_reset)
     if (e == hipSuccess) e = hipMalloc((void **)&run->d_sums, sizeof(int64_t) * nv * (GS_N_SUMS + 1 + GS_N_DCOLS) * cp + 8 * sizeof(unsigned int));
@@ -2412,14 +2419,17 @@ static int ensure_long(gs_run *run, int64_t n_reads) {
 // the rows of the huge-read kernels; they leave them clean (gs_match_huge_finish_kernel), so this runs once per run
 static int ensure_huge(gs_run *run, GsMatchParams *P) {
     const size_t nv = (size_t)run->db->info.n_values;
+    const size_t per_slot_words = (3 * (size_t)GS_HUGE_COPIES + 2) * nv;  // votes, first positions, touch list per copy + the folded pair
     if (!run->d_huge) {
-        int slots = (int)std::min<size_t>(GS_HUGE_SLOTS, std::max<size_t>(4, ((size_t)256 << 20) / (nv * 12)));
+        int slots = (int)std::min<size_t>(GS_HUGE_SLOTS, std::max<size_t>(4, ((size_t)256 << 20) / (per_slot_words * 4)));
         if (const char *e = getenv("GS_HUGE_SLOTS")) slots = std::max(1, std::min(GS_HUGE_SLOTS, atoi(e)));
-        const size_t fixed = 16 + sizeof(uint32_t) * GS_HUGE_SLOTS + sizeof(GsHugeHead) * GS_HUGE_SLOTS;
-        const size_t chunks = sizeof(GsHugeChunk) * (size_t)slots * GS_HUGE_MAX_CHUNKS, row = sizeof(uint32_t) * (size_t)slots * nv;
-        HIP_TRY(hipMalloc((void **)&run->d_huge, fixed + chunks + 3 * row));
+        const size_t fixed = 16 + sizeof(uint32_t) * GS_HUGE_SLOTS + sizeof(GsHugeHead) * GS_HUGE_SLOTS * GS_HUGE_COPIES;
+        const size_t chunks = sizeof(GsHugeChunk) * (size_t)slots * GS_HUGE_MAX_CHUNKS, row = sizeof(uint32_t) * (size_t)slots * GS_HUGE_COPIES * nv;
+        const size_t fold = sizeof(uint32_t) * (size_t)slots * 2 * nv;
+        HIP_TRY(hipMalloc((void **)&run->d_huge, fixed + chunks + 3 * row + fold));
         HIP_TRY(hipMemsetAsync(run->d_huge, 0, fixed + chunks + row, run->stream));
         HIP_TRY(hipMemsetAsync(run->d_huge + fixed + chunks + row, 0xff, row, run->stream));  // first positions: none
+        HIP_TRY(hipMemsetAsync(run->d_huge + fixed + chunks + 3 * row, 0, fold, run->stream));
         run->huge_slots = slots;
     }
     const size_t slots = (size_t)run->huge_slots;
@@ -2429,14 +2439,16 @@ static int ensure_huge(gs_run *run, GsMatchParams *P) {
     P->huge_list = reinterpret_cast<uint32_t *>(p);
     p += sizeof(uint32_t) * GS_HUGE_SLOTS;
     P->huge_head = reinterpret_cast<GsHugeHead *>(p);
-    p += sizeof(GsHugeHead) * GS_HUGE_SLOTS;
+    p += sizeof(GsHugeHead) * GS_HUGE_SLOTS * GS_HUGE_COPIES;
     P->huge_chunks = reinterpret_cast<GsHugeChunk *>(p);
     p += sizeof(GsHugeChunk) * slots * GS_HUGE_MAX_CHUNKS;
     P->huge_cnt = reinterpret_cast<uint32_t *>(p);
-    p += sizeof(uint32_t) * slots * nv;
+    p += sizeof(uint32_t) * slots * GS_HUGE_COPIES * nv;
     P->huge_first = reinterpret_cast<uint32_t *>(p);
-    p += sizeof(uint32_t) * slots * nv;
+    p += sizeof(uint32_t) * slots * GS_HUGE_COPIES * nv;
     P->huge_touch = reinterpret_cast<uint32_t *>(p);
+    p += sizeof(uint32_t) * slots * GS_HUGE_COPIES * nv;
+    P->huge_fold = reinterpret_cast<uint32_t *>(p);
     P->huge_slots = run->huge_slots;
     P->huge_min = run->huge_min;
     P->huge_chunk_min = run->huge_chunk_min;
@@ -2892,16 +2904,7 @@ static int run_unique_counts(gs_run *run) {
 // the copies of the global-atomic counters into copy 0 (the others start from zero again)
 static int fold_stats(gs_run *run) {
     if (!run->stats_spread) return GS_OK;
-    const size_t nv = (size_t)run->db->info.n_values;
-    for (int c = 1; c < run->stat_copies; c++) {
-        HIP_TRY(gs_launch_merge_i64(run->d_sums, run->d_sums + (size_t)c * nv * GS_N_SUMS, (int64_t)(nv * GS_N_SUMS), 0, run->stream));
-        HIP_TRY(gs_launch_merge_i64(run->d_max, run->d_max + (size_t)c * nv, (int64_t)nv, 1, run->stream));
-        HIP_TRY(gs_launch_merge_f64(run->d_dsums, run->d_dsums + (size_t)c * nv * GS_N_DCOLS, (int64_t)(nv * GS_N_DCOLS), run->stream));
-    }
-    const size_t rest = (size_t)run->stat_copies - 1;
-    HIP_TRY(hipMemsetAsync(run->d_sums + nv * GS_N_SUMS, 0, sizeof(int64_t) * nv * GS_N_SUMS * rest, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_max + nv, 0, sizeof(int64_t) * nv * rest, run->stream));
-    HIP_TRY(hipMemsetAsync(run->d_dsums + nv * GS_N_DCOLS, 0, sizeof(double) * nv * GS_N_DCOLS * rest, run->stream));
+    HIP_TRY(gs_launch_fold_stats((long long *)run->d_sums, (unsigned long long *)run->d_max, run->d_dsums, (long long)run->db->info.n_values, run->stat_copies, run->stream));
     run->stats_spread = false;
     return GS_OK;
 }

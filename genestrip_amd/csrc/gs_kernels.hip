@@ -1138,12 +1138,13 @@ __device__ __forceinline__ void gs_process_read(const GsMatchParams &P, const Gs
 #define GS_STATS_EPILOGUE()                                                                           \
     if (LDS_STATS) {                                                                                  \
         __syncthreads();                                                                              \
+        const size_t ecopy = P.stat_copies > 1 ? (size_t)(blockIdx.x % (unsigned)P.stat_copies) : 0;  \
         for (int i = threadIdx.x; i < nv * GS_N_SUMS; i += blockDim.x)                                \
-            if (s_sums[i]) atomicAdd((u64 *)P.sums + i, s_sums[i]);                                   \
+            if (s_sums[i]) atomicAdd((u64 *)P.sums + ecopy * (size_t)nv * GS_N_SUMS + i, s_sums[i]);  \
         for (int i = threadIdx.x; i < nv; i += blockDim.x)                                            \
-            if (s_max[i]) atomicMax((u64 *)P.max_keys + i, s_max[i]);                                 \
+            if (s_max[i]) atomicMax((u64 *)P.max_keys + ecopy * (size_t)nv + i, s_max[i]);            \
         for (int i = threadIdx.x; i < nv * GS_N_DCOLS; i += blockDim.x)                               \
-            if (s_d[i] != 0.0) atomicAdd(P.dsums + i, s_d[i]);                                        \
+            if (s_d[i] != 0.0) atomicAdd(P.dsums + ecopy * (size_t)nv * GS_N_DCOLS + i, s_d[i]);      \
     }
 
 // STRIPED: the record table is split over several devices (GsDbDev::rec_biased); every wave keeps the stripe pointers in
@@ -1711,8 +1712,8 @@ __device__ __forceinline__ void gs_huge_read(const GsMatchParams &P, int64_t r, 
 }
 
 // votes of one node from one chunk into the read's rows; the wave that brings the first ones puts the node on the read's list
-__device__ __forceinline__ void gs_huge_vote(uint32_t *cnt, uint32_t *first, uint32_t *touch, GsHugeHead *h, int v, uint32_t c, uint32_t pos) {
-    if (atomicAdd(cnt + v, c) == 0) touch[atomicAdd(&h->n_touch, 1u)] = (uint32_t)v;
+__device__ __forceinline__ void gs_huge_vote(uint32_t *cnt, uint32_t *first, uint32_t *touch, GsHugeHead *h0, int v, uint32_t c, uint32_t pos) {
+    if (atomicAdd(cnt + v, c) == 0) touch[atomicAdd(&h0->n_touch, 1u)] = (uint32_t)v;  // (once per copy: the list may hold a node several times)
     atomicMin(first + v, pos);
 }
 
@@ -1785,9 +1786,14 @@ __global__ __launch_bounds__(GS_BLOCK) GS_HUGE_ATTR void gs_match_huge_kernel(Gs
         const int C = gs_huge_chunk_positions(max, P.huge_chunk_min);
         const int n_iter_all = (max + 127) >> 7;
         const u64 key_lo = ((1ULL << 40) - 1) - ((u64)(P.first_read_no + r) & ((1ULL << 40) - 1));
-        uint32_t *cnt = P.huge_cnt + (size_t)slot * (size_t)nv, *first = P.huge_first + (size_t)slot * (size_t)nv;
-        uint32_t *touch = P.huge_touch + (size_t)slot * (size_t)nv;
-        GsHugeHead *h = P.huge_head + slot;
+        // (GS_HUGE_COPIES copies of the read's rows and counters, chunk c on copy c mod GS_HUGE_COPIES: the chunks of a chromosome vote
+        // for the same handful of tax ids, and atomics on ONE address execute one after the other -- 4 883 chunks x 2 atomics per tax id
+        // were most of the kernel's 0.17 ms; the finish kernel folds the copies)
+        const size_t copy = (size_t)(c & (GS_HUGE_COPIES - 1)), row = ((size_t)slot * GS_HUGE_COPIES + copy) * (size_t)nv;
+        uint32_t *cnt = P.huge_cnt + row, *first = P.huge_first + row;
+        uint32_t *touch = P.huge_touch + (size_t)slot * GS_HUGE_COPIES * (size_t)nv;
+        GsHugeHead *h = P.huge_head + (size_t)slot * GS_HUGE_COPIES + copy;
+        GsHugeHead *h0 = P.huge_head + (size_t)slot * GS_HUGE_COPIES;  // (the touch list's length lives in copy 0)
         const int p0 = c * C, p1 = p0 + C < max ? p0 + C : max;
         int carry_last = GS_NODE_NONE, cur_start = p0, head_node = GS_NODE_NONE, head_len = 0;
         bool head_open = true, found = false, bad_hi = false;
@@ -1814,7 +1820,9 @@ __global__ __launch_bounds__(GS_BLOCK) GS_HUGE_ATTR void gs_match_huge_kernel(Gs
                 }
             }
             int node[2];
-            gs_probe_planes<KC, STRIPED, 2, false>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
+            // (the marks of first-seen k-mers as ONE atomic per record line: a chromosome of the store's own species is nothing but
+            // first-seen k-mers -- 5 M device-scope atomics, each a request to the fabric, were 0.09 of the chunk kernel's 0.13 ms)
+            gs_probe_planes<KC, STRIPED, 2, true>(db, Bhi, Blo, Bbad, base, max, lane, node, wave_g, mk);
             const u64 hit0 = __ballot(node[0] >= 0), hit1 = __ballot(node[1] >= 0);
             found = found || ((hit0 | hit1) != 0);
             n_miss += __popcll(__ballot(node[0] == GS_NODE_MISS)) + __popcll(__ballot(node[1] == GS_NODE_MISS));
@@ -1877,7 +1885,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_HUGE_ATTR void gs_match_huge_kernel(Gs
                     }
                     n_cached++;
                 } else if (lane == 0)
-                    gs_huge_vote(cnt, first, touch, h, nvj, votes, (uint32_t)(base + j));
+                    gs_huge_vote(cnt, first, touch, h0, nvj, votes, (uint32_t)(base + j));
             }
             {
                 const int last_p = (max - 1 < base + 127) ? max - 1 : base + 127;
@@ -1885,7 +1893,7 @@ __global__ __launch_bounds__(GS_BLOCK) GS_HUGE_ATTR void gs_match_huge_kernel(Gs
                 carry_last = gs_readlane(ls ? node[1] : node[0], ll);
             }
         }
-        if (c_node >= 0) gs_huge_vote(cnt, first, touch, h, c_node, c_cnt, c_first);
+        if (c_node >= 0) gs_huge_vote(cnt, first, touch, h0, c_node, c_cnt, c_first);
         if (lane == 0) {
             GsHugeChunk rec;
             rec.head_node = head_node;
@@ -1921,13 +1929,39 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_huge_finish_kernel(GsMatchP
         const int C = gs_huge_chunk_positions(max, P.huge_chunk_min);
         const int n_chunks = (max + C - 1) / C;
         const u64 key_lo = ((1ULL << 40) - 1) - ((u64)(P.first_read_no + r) & ((1ULL << 40) - 1));
-        uint32_t *cnt = P.huge_cnt + (size_t)slot * (size_t)nv, *first = P.huge_first + (size_t)slot * (size_t)nv;
-        uint32_t *touch = P.huge_touch + (size_t)slot * (size_t)nv;
-        GsHugeHead *hd = P.huge_head + slot;
-        const unsigned int hflags = hd->flags;
+        uint32_t *cnt_c = P.huge_cnt + (size_t)slot * GS_HUGE_COPIES * (size_t)nv, *first_c = P.huge_first + (size_t)slot * GS_HUGE_COPIES * (size_t)nv;
+        uint32_t *touch = P.huge_touch + (size_t)slot * GS_HUGE_COPIES * (size_t)nv;
+        uint32_t *cnt = P.huge_fold + (size_t)slot * 2 * (size_t)nv, *first = cnt + nv;  // the copies folded: votes and first position per node
+        GsHugeHead *hd = P.huge_head + (size_t)slot * GS_HUGE_COPIES;
+        unsigned int hflags = 0, h_miss = 0, h_bad = 0;
+        if (lane < GS_HUGE_COPIES) {
+            hflags = hd[lane].flags;
+            h_miss = hd[lane].n_miss;
+            h_bad = hd[lane].bad_lo;
+        }
+#pragma unroll
+        for (int o = GS_HUGE_COPIES / 2; o >= 1; o >>= 1) {
+            hflags |= (unsigned int)__shfl_xor((int)hflags, o);
+            h_miss += (unsigned int)__shfl_xor((int)h_miss, o);
+            h_bad += (unsigned int)__shfl_xor((int)h_bad, o);
+        }
+        hflags = (unsigned int)gs_rfl((int)hflags);
         const bool found = (hflags & 1u) != 0;
-        const int tax_err = (int)hd->n_miss + (int)hd->bad_lo + ((hflags & 2u) ? 1 : 0);
-        const int n_touch = (int)hd->n_touch;
+        const int tax_err = gs_rfl((int)h_miss) + gs_rfl((int)h_bad) + ((hflags & 2u) ? 1 : 0);
+        const int n_touch = (int)hd[0].n_touch;
+        for (int i = lane; i < n_touch; i += 64) {  // (a node that is on the list twice is folded twice, to the same values)
+            const int v = (int)touch[i];
+            uint32_t total = 0, fmin = 0xffffffffu;
+            for (int cp = 0; cp < GS_HUGE_COPIES; cp++) {
+                total += cnt_c[(size_t)cp * nv + v];
+                const uint32_t f = first_c[(size_t)cp * nv + v];
+                fmin = f < fmin ? f : fmin;
+            }
+            cnt[v] = total;
+            first[v] = fmin;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         int out_class = -1, out_flags = 0;
         // ---- the runs across the seams, 64 chunks at a time, one per lane.  With link(c) = "chunk c starts with the node chunk c - 1
         // ends with" and whole(c) = "no change inside c", the length of the run that is open at the end of chunk c is
@@ -1979,7 +2013,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_huge_finish_kernel(GsMatchP
             int path[2] = {-1, -1}, ptin[2] = {0, 0}, ptout[2] = {0, 0}, used = 0;
             uint32_t last_pos = 0;
             for (int step = 0; step < n_touch; step++) {
-                // the node with the smallest first position beyond the last one taken (one node per position: no ties)
+                // the node with the smallest first position beyond the last one taken (one node per position: a tie is the same node twice)
                 uint32_t best = 0xffffffffu;
                 int best_v = -1;
                 for (int i = lane; i < n_touch; i += 64) {
@@ -2133,9 +2167,12 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_huge_finish_kernel(GsMatchP
         for (int i = lane; i < n_touch; i += 64) {
             const int v = (int)touch[i];
             cnt[v] = 0;
-            first[v] = 0xffffffffu;
+            for (int cp = 0; cp < GS_HUGE_COPIES; cp++) {
+                cnt_c[(size_t)cp * nv + v] = 0;
+                first_c[(size_t)cp * nv + v] = 0xffffffffu;
+            }
         }
-        if (lane == 0) hd->n_miss = hd->bad_lo = hd->flags = hd->n_touch = 0;
+        if (lane < GS_HUGE_COPIES) hd[lane].n_miss = hd[lane].bad_lo = hd[lane].flags = hd[lane].n_touch = 0;
     }
     GS_STATS_EPILOGUE()
 }
@@ -3122,6 +3159,43 @@ extern "C" hipError_t gs_launch_match_long(const GsMatchParams *P, int grid, int
         else
             hipLaunchKernelGGL((gs_match_long_kernel<false, true>), dim3(grid), dim3(GS_BLOCK), lds, stream, *P, scratch, serial);
     }
+    return hipGetLastError();
+}
+
+// the copies 1 .. copies - 1 of the run's counters into copy 0 (sums and double sums added, max keys by maximum), the copies zeroed:
+// one launch (one per copy and array -- 45 for 16 copies -- cost 0.2 ms per job)
+__global__ __launch_bounds__(256) void gs_fold_stats_kernel(long long *sums, unsigned long long *maxk, double *dsums, long long nv, int copies) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n_s = nv * GS_N_SUMS, n_d = nv * GS_N_DCOLS;
+    if (i < n_s) {
+        long long a = sums[i];
+        for (int c = 1; c < copies; c++) {
+            a += sums[(long long)c * n_s + i];
+            sums[(long long)c * n_s + i] = 0;
+        }
+        sums[i] = a;
+    }
+    if (i < nv) {
+        unsigned long long m = maxk[i];
+        for (int c = 1; c < copies; c++) {
+            const unsigned long long x = maxk[(long long)c * nv + i];
+            m = x > m ? x : m;
+            maxk[(long long)c * nv + i] = 0;
+        }
+        maxk[i] = m;
+    }
+    if (i < n_d) {
+        double a = dsums[i];
+        for (int c = 1; c < copies; c++) {
+            a += dsums[(long long)c * n_d + i];
+            dsums[(long long)c * n_d + i] = 0.0;
+        }
+        dsums[i] = a;
+    }
+}
+extern "C" hipError_t gs_launch_fold_stats(long long *sums, unsigned long long *maxk, double *dsums, long long nv, int copies, hipStream_t stream) {
+    const long long n = nv * (GS_N_SUMS > GS_N_DCOLS ? GS_N_SUMS : GS_N_DCOLS);
+    hipLaunchKernelGGL(gs_fold_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sums, maxk, dsums, nv, copies);
     return hipGetLastError();
 }
 

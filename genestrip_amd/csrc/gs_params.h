@@ -70,11 +70,12 @@ struct GsMatchParams {
     // appearance, classification).  nullptr: off (DB-partitioned mode, batches of short fixed-length reads).
     unsigned int *huge_count;          // reads handed over so far
     uint32_t *huge_list;               // [huge_slots] their numbers in the batch
-    struct GsHugeHead *huge_head;      // [huge_slots]
+    struct GsHugeHead *huge_head;      // [huge_slots][GS_HUGE_COPIES]
     struct GsHugeChunk *huge_chunks;   // [huge_slots][GS_HUGE_MAX_CHUNKS]
-    uint32_t *huge_cnt;                // [huge_slots][n_values] positions that hold the node
-    uint32_t *huge_first;              // [huge_slots][n_values] its first position (~0: none)
-    uint32_t *huge_touch;              // [huge_slots][n_values] the nodes with a count, in no order (GsHugeHead.n_touch of them)
+    uint32_t *huge_cnt;                // [huge_slots][GS_HUGE_COPIES][n_values] positions that hold the node (chunk c votes on copy c mod GS_HUGE_COPIES)
+    uint32_t *huge_first;              // [huge_slots][GS_HUGE_COPIES][n_values] its first position (~0: none)
+    uint32_t *huge_touch;              // [huge_slots][GS_HUGE_COPIES * n_values] the nodes with a count, in no order, once per copy (GsHugeHead.n_touch of them)
+    uint32_t *huge_fold;               // [huge_slots][2][n_values] the copies folded by the finish kernel: votes, first position
     // long_count: three queues x (entries, cursor) -- queue 0 the long-read kernel's, queues 1 / 2 those of gs_match_wide_kernel<3 / 4>
     // (reads of 129 .. 192 / 193 .. 256 positions, where wide_mask says that kernel serves this run); long_list: queue q at q * long_cap
     int64_t long_cap;
@@ -88,6 +89,7 @@ struct GsMatchParams {
 #define GS_HUGE_MIN (1 << 15)
 #define GS_HUGE_SLOTS 256       // (= GS_BLOCK: one thread per slot where the chunks are counted)
 #define GS_HUGE_MAX_CHUNKS 8192
+#define GS_HUGE_COPIES 16      // of a read's vote rows and counters (a power of two, at most 64)
 #define GS_HUGE_CHUNK_MIN 1024  // a longer read than GS_HUGE_MAX_CHUNKS of these is cut into GS_HUGE_MAX_CHUNKS chunks
 struct GsHugeHead {
     unsigned int n_miss, bad_lo, flags, n_touch;  // flags: 1 = some k-mer hit, 2 = a bad base at or behind position max - 1
