@@ -333,6 +333,7 @@ def partitioned_finish(matcher, sums, max_keys, dsums, group=None):
     """merge the per-read statistics (all-reduce) and add up the disjoint per-partition unique counts.
     Returns the global (table, dtable) as numpy arrays, identical on every rank."""
     import numpy as np
+    matcher.device_state()  # (the kernels spread their counters over several copies: folded into the arrays below, the stream synchronised)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(max_keys, op=dist.ReduceOp.MAX, group=group)
     dist.all_reduce(dsums, op=dist.ReduceOp.SUM, group=group)
