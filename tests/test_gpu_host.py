@@ -646,3 +646,40 @@ def test_match_filtered_fastq_written_from_the_device(sdb, tmp_path, monkeypatch
         host.match_files(store, [path], filtered_path=f)
         assert open(f, "rb").read() == res["0"][3]
     store.close()
+
+
+@pytest.mark.parametrize("container", ["plain", "gzip", "bgzf"])
+def test_device_written_gz_keeps_the_order_around_host_formatted_stretches(sdb, tmp_path, monkeypatch, container):
+    """Chunks gathered on the device wait there to be compressed together (gs_deflater_append); a stretch of the file that the device
+    refuses (a record with its sequence over two lines) is formatted on the host and written through the same file object.  The .gz
+    output must hold the records in input order -- what waits on the device goes out before any host-side write -- and equal the
+    plain output of the host formatter, for the accepted and for the dumped reads."""
+    from conftest import bgzf
+    keys = sdb.kmers[np.isin(sdb.value_idx, sdb.species_vi[:4])]
+    ob = orc.Bloom(orc.BLOOM_XOR, len(keys), 1e-8)
+    ob.put_many(keys)
+    gb = ga.DeviceBloomFilter(ga.BLOOM_XOR, ob.bits, ob.hash_factors, ob.words)
+    recs = [r for r in _fastq_bytes(sdb, 9000, seed=301) if len(r) > 20]
+    seq, off = synth.reads_host(sdb.genomes, 3, read_len=150, seed=5)
+    two_lines = [b"@ml%d\n%s\n%s\n+\n%s\n" % (i, seq[int(off[i]):int(off[i]) + 70].tobytes(), seq[int(off[i]) + 70:int(off[i + 1])].tobytes(), b"F" * 150) for i in range(3)]
+    data = b"".join(recs[:2500]) + two_lines[0] + b"".join(recs[2500:5200]) + two_lines[1] + two_lines[2] + b"".join(recs[5200:])
+    path = str(tmp_path / ("in.fastq" if container == "plain" else "in.fastq.gz"))
+    if container == "bgzf":
+        open(path, "wb").write(bgzf(data, block=30000, level=1))
+    elif container == "gzip":
+        open(path, "wb").write(gzip.compress(data, compresslevel=1, mtime=0))
+    else:
+        open(path, "wb").write(data)
+    monkeypatch.setenv("GS_HOST_BGZF_TEXT", "300000")
+    monkeypatch.setenv("GS_HOST_BLOCK_BYTES", "200000")
+    monkeypatch.setenv("GS_DEVICE_OUTPUT", "0")
+    a0, r0 = str(tmp_path / "acc0.fastq"), str(tmp_path / "rest0.fastq")
+    tot0 = host.filter_files(gb, 31, [path, path], filtered_path=a0, rest_path=r0)
+    monkeypatch.setenv("GS_DEVICE_OUTPUT", "1")
+    a1, r1 = str(tmp_path / "acc1.fastq.gz"), str(tmp_path / "rest1.fastq.gz")
+    tot1 = host.filter_files(gb, 31, [path, path], filtered_path=a1, rest_path=r1)
+    assert (tot1.reads, tot1.filtered_reads) == (tot0.reads, tot0.filtered_reads) and tot0.reads == 2 * (len(recs) + 3)
+    want_a, want_r = open(a0, "rb").read(), open(r0, "rb").read()
+    assert gzip.decompress(open(a1, "rb").read()) == want_a and gzip.decompress(open(r1, "rb").read()) == want_r
+    assert want_a.count(b"@ml") + want_r.count(b"@ml") == 6  # (the two-line records are in the outputs, rewritten in four lines)
+    gb.close()
