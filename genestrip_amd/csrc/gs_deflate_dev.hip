@@ -21,7 +21,7 @@
 //       - every token lane looks its Huffman code up in LDS (a length's code and extra bits as one precomputed word), a DPP
 //         prefix sum over the bit counts places the tokens, and the bits are ORed into a small LDS ring whose finished words
 //         leave as whole dwords.
-//     The Huffman code is SEMI-STATIC: a counting pass of the same tokenizer over a sample of the text (up to 512 ranges of 4 KB, spread
+//     The Huffman code is SEMI-STATIC: a counting pass of the same tokenizer over a sample of the text (up to 2 048 ranges of 1 KB, spread
 //     over it) gives the symbol frequencies, the host builds the length-limited code and the dynamic block header ONCE per call,
 //     and every member of the call carries that header: FASTQ is stationary, the loss against a code per member is under one
 //     per cent, and no tree is ever built on the device.  Every literal has a code; a piece that would grow is stored.
@@ -49,8 +49,8 @@ typedef unsigned long long u64;
 #define GD_RING 128u      // dwords of output under construction per wave
 #define GD_MAXLEN 258u
 #define GD_PREFIX_WORDS 128
-#define GD_SAMPLE 512          // ranges of the text the counting pass looks at ...
-#define GD_SAMPLE_BYTES 4032u  // ... of this many bytes each (a sixteenth of a piece): one wave per range, 0.15 ms instead of the 2.4 a whole piece takes
+#define GD_SAMPLE 2048         // ranges of the text the counting pass looks at ...
+#define GD_SAMPLE_BYTES 1008u  // ... of this many bytes each: one wave per range -- a chain of 16 steps (a whole piece: 1 000 steps, 2.4 ms; ranges of 4 032 bytes 0.15-0.57 ms)
 
 extern "C" int gs_crc_tiles_device(const uint8_t *d_text, int64_t n, uint32_t tile, uint32_t *d_crc, hipStream_t stream);
 extern "C" uint32_t gs_crc_init_term(uint64_t n);
