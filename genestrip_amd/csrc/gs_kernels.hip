@@ -1952,10 +1952,16 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_match_huge_finish_kernel(GsMatchP
         for (int i = lane; i < n_touch; i += 64) {  // (a node that is on the list twice is folded twice, to the same values)
             const int v = (int)touch[i];
             uint32_t total = 0, fmin = 0xffffffffu;
+            uint32_t cv[GS_HUGE_COPIES], fv[GS_HUGE_COPIES];  // (all loads on their way before the first is waited for)
+#pragma unroll
             for (int cp = 0; cp < GS_HUGE_COPIES; cp++) {
-                total += cnt_c[(size_t)cp * nv + v];
-                const uint32_t f = first_c[(size_t)cp * nv + v];
-                fmin = f < fmin ? f : fmin;
+                cv[cp] = cnt_c[(size_t)cp * nv + v];
+                fv[cp] = first_c[(size_t)cp * nv + v];
+            }
+#pragma unroll
+            for (int cp = 0; cp < GS_HUGE_COPIES; cp++) {
+                total += cv[cp];
+                fmin = fv[cp] < fmin ? fv[cp] : fmin;
             }
             cnt[v] = total;
             first[v] = fmin;
