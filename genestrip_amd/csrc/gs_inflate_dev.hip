@@ -62,14 +62,13 @@ struct __attribute__((aligned(16))) gs_u16x8 {
 #define GI_RING 2048               // bytes of recent text per wave in LDS (a power of two); with it a wave takes 8.6 KB: 16 waves per CU
 #endif
 #define GI_RING_SYM 1024           // symbols of recent text per wave of gi_segment_kernel (2 KB: with it five workgroups fit a CU)
+#define GI_LANE_SYMS 256u          // a group of at most this many symbols is written one lane per symbol (gi_decode_blocks)
 #define GI_PAR_MAX 16u             // matches of at most this length are copied one lane per match (gi_inflate_kernel)
 #define GI_ON(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
-#define GI_LDESC ((GI_LSIZE - 512) / 2)
-#define GI_DDESC ((GI_DSIZE - 256) / 2)
 
 // table entry (16 bits -- the tables of a wave take 4.7 KB of LDS, so that 32 waves fit a CU): bits 0-3 code bits to drop (in a
 // sub-table: the bits beyond the root), bits 4-6 kind, bits 7-15 value: the literal, the length / distance SYMBOL (base and extra
-// bits are arithmetic), or the number of the sub-table's descriptor (offset << 3 | index bits)
+// bits are arithmetic) -- or, kind GI_SUB, where the sub-table starts behind the root table, with its index bits in bits 0-3
 enum { GI_BAD = 0, GI_LIT = 1, GI_LEN = 2, GI_EOB = 3, GI_SUB = 4, GI_DIST = 5 };
 #define GI_ENTRY(bits, kind, value) ((uint16_t)((uint32_t)(bits) | ((uint32_t)(kind) << 4) | ((uint32_t)(value) << 7)))
 
@@ -85,10 +84,11 @@ struct GiWave {
     uint32_t cbuf[128];      // two 256-byte pieces of the compressed payload (piece j in half j & 1) for the token decoder
     uint16_t ltab[GI_LSIZE];
     uint16_t dtab[GI_DSIZE];
-    uint16_t ldesc[GI_LDESC], ddesc[GI_DDESC];
     uint16_t lwork[288], dwork[32];
     uint16_t lcount[16], dcount[16], offs[16];
     uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+    uint32_t lut[64];        // base | extra bits << 16 of the length symbols (0..28) and, from 32 on, of the distance symbols (0..29)
+    uint32_t slots[128];     // a group of at most 64 symbols: token descriptors by output index, and the symbols' states (gi_decode_blocks)
 };
 
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -213,7 +213,7 @@ struct GiBits {
 // type 0: literal / length codes (n = 288), 1: distance codes (n = 32), 2: code length codes (n = 19, root 7, no sub-tables).
 // All lanes run the same statements; only the replication of an entry over its copies is spread over the lanes.
 // Returns false for an over-subscribed or (where deflate forbids it) incomplete set of lengths.
-__device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab, uint16_t *desc, int n_desc, uint16_t *count, uint16_t *work,
+__device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab, uint16_t *count, uint16_t *work,
                          int root, int cap, int lane, bool *fast) {
     *fast = true;
     for (int i = lane; i < 16; i += 64) count[i] = 0;
@@ -284,16 +284,13 @@ __device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab,
                 sub_bits = curr;
                 sub_base = used;
                 used += 1 << curr;
-                if (used > cap || n_sub >= n_desc) {
+                if (used > cap) {
                     *fast = false;
                     gi_lds_sync();
                     return true;
                 }
                 for (int r = lane; r < (1 << curr); r += 64) tab[sub_base + r] = 0;
-                if (lane == 0) {
-                    desc[n_sub] = (uint16_t)(((uint32_t)sub_base << 3) | (uint32_t)sub_bits);
-                    tab[prefix] = GI_ENTRY(root, GI_SUB, n_sub);
-                }
+                if (lane == 0) tab[prefix] = GI_ENTRY(sub_bits, GI_SUB, sub_base - (1 << root));  // (at most 352 / 336 entries behind the root: nine bits)
                 n_sub++;
             }
             const uint16_t e = GI_ENTRY(len - root, kind, value);
@@ -315,12 +312,11 @@ __device__ bool gi_build(GiWave &w, int type, int n, int lens_at, uint16_t *tab,
 }
 
 // fast path: (kind << 16 | value << 4 | bits) of the next code; bits = 0: no such code
-__device__ __forceinline__ uint32_t gi_lookup(const uint16_t *tab, const uint16_t *desc, int root, const GiBits &b) {
+__device__ __forceinline__ uint32_t gi_lookup(const uint16_t *tab, int root, const GiBits &b) {
     uint32_t e = gi_uni(tab[b.peek(root)]);
     uint32_t bits = e & 15u;
     if (((e >> 4) & 7u) == GI_SUB) {
-        const uint32_t d = gi_uni(desc[e >> 7]);
-        e = gi_uni(tab[(d >> 3) + (((uint32_t)(b.bb >> root)) & ((1u << (d & 7u)) - 1u))]);
+        e = gi_uni(tab[(1u << root) + (e >> 7) + (((uint32_t)(b.bb >> root)) & ((1u << bits) - 1u))]);
         bits = (e & 15u) ? (e & 15u) + (uint32_t)root : 0u;
     }
     return (((e >> 4) & 7u) << 16) | ((e >> 7) << 4) | bits;
@@ -362,8 +358,7 @@ __device__ __forceinline__ void gi_token(const GiWave &w, uint32_t w0, uint32_t 
     uint32_t n = e & 15u;
     kind = (e >> 4) & 7u;
     if (kind == GI_SUB) {
-        const uint32_t d = w.ldesc[e >> 7];
-        e = w.ltab[(d >> 3) + ((w0 >> GI_LROOT) & ((1u << (d & 7u)) - 1u))];
+        e = w.ltab[(1u << GI_LROOT) + (e >> 7) + ((w0 >> GI_LROOT) & ((1u << n) - 1u))];
         n = (e & 15u) ? (e & 15u) + GI_LROOT : 0u;
         kind = (e >> 4) & 7u;
     }
@@ -374,19 +369,19 @@ __device__ __forceinline__ void gi_token(const GiWave &w, uint32_t w0, uint32_t 
     olen = kind == GI_LIT ? 1u : 0u;
     dist = 0;
     if (kind == GI_LEN) {
-        uint32_t lbase, lextra, dbase, dextra;
-        gi_len_sym(val & 31u, lbase, lextra);
+        const uint32_t lx = w.lut[val & 31u];
+        const uint32_t lbase = lx & 0xffffu, lextra = lx >> 16;
         olen = lbase + ((uint32_t)(bits >> n) & ((1u << lextra) - 1u));
         const uint32_t u = (uint32_t)(bits >> (n + lextra));  // (n + lextra <= 20: 44 bits are left, a distance takes at most 28)
         uint32_t de = w.dtab[u & ((1u << GI_DROOT) - 1u)];
         uint32_t dn = de & 15u, dk = (de >> 4) & 7u;
         if (dk == GI_SUB) {
-            const uint32_t d = w.ddesc[de >> 7];
-            de = w.dtab[(d >> 3) + ((u >> GI_DROOT) & ((1u << (d & 7u)) - 1u))];
+            de = w.dtab[(1u << GI_DROOT) + (de >> 7) + ((u >> GI_DROOT) & ((1u << dn) - 1u))];
             dn = (de & 15u) ? (de & 15u) + GI_DROOT : 0u;
             dk = (de >> 4) & 7u;
         }
-        gi_dist_sym((de >> 7) & 31u, dbase, dextra);
+        const uint32_t dx = w.lut[32u + ((de >> 7) & 31u)];
+        const uint32_t dbase = dx & 0xffffu, dextra = dx >> 16;
         dist = dbase + ((u >> dn) & ((1u << dextra) - 1u));
         t = n + lextra + dn + dextra;
         if (dk != GI_DIST || dn == 0) kind = GI_BAD;
@@ -401,6 +396,17 @@ __device__ __forceinline__ uint32_t gi_scan_incl(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// inclusive prefix maximum over the 64 lanes (the same six steps)
+__device__ __forceinline__ uint32_t gi_scan_max(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
     return x;
 }
 
@@ -451,7 +457,7 @@ __device__ int gi_dynamic_header(GiWave &w, GiBits &b, int lane, bool *lfast_out
     }
     gi_lds_sync();
     bool clfast = true;  // (19 codes of at most 7 bits under a 7-bit root: no sub-tables, always fast)
-    if (!gi_build(w, 2, 19, 0, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
+    if (!gi_build(w, 2, 19, 0, w.dtab, w.dcount, w.dwork, 7, GI_DSIZE, lane, &clfast)) {  // (in dtab for a moment)
         return GI_E_TABLE;
     }
     int at = 0, prev = 0;
@@ -459,7 +465,7 @@ __device__ int gi_dynamic_header(GiWave &w, GiBits &b, int lane, bool *lfast_out
     // the lengths are decoded into lens[19 ..] (behind the code length code's own lengths) and moved down afterwards
     while (at < total) {
         b.refill(lane);
-        const uint32_t e = gi_lookup(w.dtab, w.ddesc, 7, b);
+        const uint32_t e = gi_lookup(w.dtab, 7, b);
         if ((e >> 16) != GI_LIT || (e & 15u) == 0) {
             return GI_E_CODE;
         }
@@ -504,8 +510,8 @@ __device__ int gi_dynamic_header(GiWave &w, GiBits &b, int lane, bool *lfast_out
     if (w.lens[256] == 0) {  // a block without an end-of-block code never ends
         return GI_E_TABLE;
     }
-    if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
-        !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
+    if (!gi_build(w, 0, 288, 0, w.ltab, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+        !gi_build(w, 1, 32, 288, w.dtab, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
         return GI_E_TABLE;
     }
     *lfast_out = lfast;
@@ -543,6 +549,15 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
     uint32_t visible = 0;      // every byte below this offset is known to have reached memory
     int err = GI_OK;
     bool last = false, lfast = true, dfast = true;
+    {   // the token decoder's table of bases and extra bits (RFC 1951 3.2.5)
+        uint32_t base = 0, extra = 0;
+        if (lane < 29)
+            gi_len_sym((uint32_t)lane, base, extra);
+        else if (lane >= 32 && lane < 62)
+            gi_dist_sym((uint32_t)lane - 32u, base, extra);
+        w.lut[lane] = base | (extra << 16);
+        gi_lds_sync();
+    }
     auto flush = [&]() {
         if (npend) {
             const uint32_t at = pos - npend + (uint32_t)lane;
@@ -595,8 +610,8 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
             for (int s = lane; s < 288; s += 64) w.lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
             for (int s = lane; s < 32; s += 64) w.lens[288 + s] = 5;
             gi_lds_sync();
-            if (!gi_build(w, 0, 288, 0, w.ltab, w.ldesc, GI_LDESC, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
-                !gi_build(w, 1, 32, 288, w.dtab, w.ddesc, GI_DDESC, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
+            if (!gi_build(w, 0, 288, 0, w.ltab, w.lcount, w.lwork, GI_LROOT, GI_LSIZE, lane, &lfast) ||
+                !gi_build(w, 1, 32, 288, w.dtab, w.dcount, w.dwork, GI_DROOT, GI_DSIZE, lane, &dfast)) {
                 err = GI_E_TABLE;
                 break;
             }
@@ -670,8 +685,69 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                     err = GI_E_DIST;
                     break;
                 }
-                // A group of at most RING / 4 symbols is put together in the ring and stored from there in whole lines (below); a
-                // larger one (long matches) is stored piece by piece as it is produced.
+                if (total <= GI_LANE_SYMS) {
+                    // ---- a group of at most 256 symbols (all but runs and maximal matches): ONE LANE PER SYMBOL OF TEXT, 64 symbols
+                    // at a time.  Every token leaves a descriptor (its lane, literal byte or distance) at the index of its first
+                    // symbol, a prefix maximum hands it to the symbols behind it (the lane number in the top bits grows with the
+                    // index), and symbol j is the literal, or -- out[j] = out[j - dist], which holds for overlapping copies too --
+                    // the symbol `dist` in front of it: in front of these 64 (the ring; the text when the distance is larger than
+                    // the ring), or among them, and then lane j - dist knows it, now or after a few rounds of pointer jumping (a
+                    // chain of copies inside the 64; a run of n symbols takes log2 n rounds).  All reads of the ring come before
+                    // the writes of the same 64 symbols.
+                    uint32_t *const sa = w.slots, *const sb = w.slots + 64;
+                    const uint32_t rel = mpos - pos;
+                    const uint32_t desc = ((uint32_t)lane << 26) | (1u << 25) | (kind == GI_LIT ? (1u << 24) | lit : dist);
+                    uint32_t carry = 0;
+                    for (uint32_t base = 0; base < total; base += 64u) {
+                        sa[lane] = 0;
+                        gi_lds_sync();
+                        if (ol != 0u && rel - base < 64u) sa[rel - base] = desc;
+                        gi_lds_sync();
+                        const uint32_t d = max(gi_scan_max(sa[lane]), carry);
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)d, 63);
+                        const uint32_t at0 = pos + base;  // the first of these 64 symbols
+                        const bool act = base + (uint32_t)lane < total;
+                        const bool islit = ((d >> 24) & 1u) != 0;
+                        const uint32_t dd = d & 0xffffu;
+                        int32_t p = (int32_t)lane - (int32_t)dd;  // (of a match) index of the source among the 64, or negative
+                        const uint32_t ab = at0 + (uint32_t)p;    // its offset in the text
+                        uint32_t val = ring[ab & RM];
+                        const bool far = act && !islit && dd > RING;
+                        if (__ballot(far) != 0) {
+                            if (__ballot(far && (int32_t)ab >= (int32_t)visible) != 0) {  // the source reaches into symbols this wave stored since its last wait
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                visible = pos;
+                            }
+                            if (far) val = dst[(int32_t)ab];
+                        }
+                        if (islit) val = dd;
+                        bool pend = act && !islit && p >= 0;
+                        while (__ballot(pend) != 0) {
+                            sb[lane] = pend ? (uint32_t)p : (0x80000000u | val);
+                            gi_lds_sync();
+                            const uint32_t s = sb[pend ? p : lane];
+                            gi_lds_sync();
+                            if (pend) {
+                                if (s & 0x80000000u) {
+                                    val = s & 0xffffu;
+                                    pend = false;
+                                } else
+                                    p = (int32_t)s;
+                            }
+                        }
+                        if (act) {
+                            ring[(at0 + (uint32_t)lane) & RM] = (OutT)val;
+                            dst[at0 + (uint32_t)lane] = (OutT)val;
+                        }
+                        gi_lds_sync();
+                    }
+                    pos += total;
+                    P += adv;
+                    continue;
+                }
+                // A larger group (long matches) of at most RING / 4 symbols is put together in the ring and stored from there in whole
+                // lines (below); one beyond that is stored piece by piece as it is produced.
                 const bool big = total > RING / 4u;
                 if (on && kind == GI_LIT) {
                     if (big) dst[mpos] = (OutT)lit;
@@ -769,7 +845,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                     break;
                 }
             }
-            const uint32_t e = lfast ? gi_lookup(w.ltab, w.ldesc, GI_LROOT, b) : gi_slow(w.lcount, w.lwork, 0, b);
+            const uint32_t e = lfast ? gi_lookup(w.ltab, GI_LROOT, b) : gi_slow(w.lcount, w.lwork, 0, b);
             const uint32_t kind = e >> 16;
             if ((e & 15u) == 0) {
                 err = GI_E_CODE;
@@ -798,7 +874,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
             gi_len_sym((e >> 4) & 31u, lbase, lextra);
             const uint32_t len = lbase + b.get((int)lextra);
             b.refill(lane);
-            const uint32_t d = dfast ? gi_lookup(w.dtab, w.ddesc, GI_DROOT, b) : gi_slow(w.dcount, w.dwork, 1, b);
+            const uint32_t d = dfast ? gi_lookup(w.dtab, GI_DROOT, b) : gi_slow(w.dcount, w.dwork, 1, b);
             if ((d >> 16) != GI_DIST || (d & 15u) == 0) {
                 err = GI_E_CODE;
                 break;
