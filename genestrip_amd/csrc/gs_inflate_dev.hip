@@ -81,14 +81,18 @@ struct GiCode {            // what the canonical decoder needs (and the table bu
 };
 
 struct GiWave {
-    uint32_t cbuf[128];      // two 256-byte pieces of the compressed payload (piece j in half j & 1) for the token decoder
+    uint32_t cbuf[132];      // two 256-byte pieces of the compressed payload (piece j in half j & 1) for the token decoder; [128 ..] = [0 .. 3] again
     uint16_t ltab[GI_LSIZE];
     uint16_t dtab[GI_DSIZE];
-    uint16_t lwork[288], dwork[32];
+    union {
+        uint16_t lwork[288];  // (the table builder and the canonical decoder)
+        uint32_t slots[128];  // 64 symbols of a group: token descriptors by output index, and the symbols' states (gi_decode_blocks; only
+                              // while a block's symbols are decoded through the tables -- the canonical decoder never runs next to it)
+    };
+    uint16_t dwork[32];
     uint16_t lcount[16], dcount[16], offs[16];
     uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
     uint32_t lut[64];        // base | extra bits << 16 of the length symbols (0..28) and, from 32 on, of the distance symbols (0..29)
-    uint32_t slots[128];     // a group of at most 64 symbols: token descriptors by output index, and the symbols' states (gi_decode_blocks)
 };
 
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -630,25 +634,26 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                 const uint32_t p0 = b.load_piece(k * 256u, lane), p1 = b.load_piece((k + 1u) * 256u, lane);
                 w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = p0;
                 w.cbuf[((k + 1u) & 1u) * 64u + (uint32_t)lane] = p1;
+                if (lane < 4) w.cbuf[128 + lane] = (k & 1u) ? p1 : p0;  // (a lane's 96 bits are read without wrapping the index)
             }
             uint32_t ahead = b.load_piece((k + 2u) * 256u, lane);
             gi_lds_sync();
             bool eob = false;
-            uint32_t guard = 0;
             while (!eob) {
-                if (P > plimit || (u64)++guard > plimit + 64u) {  // (every group takes at least one bit: the second test cannot fire)
+                if (P > plimit) {  // (every group takes at least one bit, so the loop ends)
                     err = GI_E_INPUT;
                     break;
                 }
                 if ((uint32_t)(P >> 11) != k) {  // one piece further: piece k + 2 takes the place of piece k
                     w.cbuf[(k & 1u) * 64u + (uint32_t)lane] = ahead;
+                    if ((k & 1u) == 0u && lane < 4) w.cbuf[128 + lane] = ahead;
                     k++;
                     ahead = b.load_piece((k + 2u) * 256u, lane);
                     gi_lds_sync();
                 }
                 const uint32_t q = (uint32_t)(P & 4095u) + (uint32_t)lane;  // this lane's bit offset inside the 512 staged bytes
                 const uint32_t d0 = q >> 5, sh = q & 31u;
-                const uint32_t x0 = w.cbuf[d0 & 127u], x1 = w.cbuf[(d0 + 1u) & 127u], x2 = w.cbuf[(d0 + 2u) & 127u];
+                const uint32_t x0 = w.cbuf[d0], x1 = w.cbuf[d0 + 1u], x2 = w.cbuf[d0 + 2u];  // (d0 <= 129)
                 uint32_t kind, t, olen, dist, lit;
                 gi_token(w, __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), kind, t, olen, dist, lit);
                 // which lanes are token starts: lane 0 is one, and every token names the next
@@ -681,7 +686,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                 }
                 const bool is_match = on && kind == GI_LEN;
                 const u64 mm = __ballot(is_match);
-                if (mm != 0 && __ballot(is_match && dist > mpos + BACK) != 0) {
+                if (!MARK && mm != 0 && __ballot(is_match && dist > mpos + BACK) != 0) {  // (a segment's window takes every distance deflate can state)
                     err = GI_E_DIST;
                     break;
                 }
@@ -940,7 +945,7 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
     return err;
 }
 
-__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void gi_inflate_kernel(const uint8_t *comp, const GiBlock *blocks, int64_t n_blocks, uint8_t *out,
                                                                     int32_t *status, int force_slow, unsigned long long *next_member) {
     __shared__ GiWave s_w[GI_WAVES];
     __shared__ uint8_t s_ring[GI_WAVES][GI_RING];  // text byte p of a wave's member at [p % GI_RING]
@@ -1615,8 +1620,8 @@ static int gi_fail(int code, const std::string &m) {
         if (e_ != hipSuccess) return gi_fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a CU holds four: tables + ring of 16 waves)
-    int v = 4;
+static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a CU holds five of 31.4 KB -- it is handed out in pieces of 1 280 bytes --, 96 VGPRs)
+    int v = 5;
     if (const char *e = getenv("GS_INFLATE_WGS")) v = std::max(1, std::min(8, atoi(e)));
     return v;
 }
