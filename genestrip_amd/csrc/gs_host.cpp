@@ -852,6 +852,13 @@ inline int64_t gunzip_first_span() {
     return (int64_t)64 << 20;
 }
 
+// ... and when nobody waits for it but the match kernel (GS_HOST_GUNZIP_FIRST_MATCH; 0: a full batch): the first batch is the only one
+// that waits for its compressed bytes to cross PCIe
+inline int64_t gunzip_first_span_match() {
+    if (const char *e = getenv("GS_HOST_GUNZIP_FIRST_MATCH")) return std::max<int64_t>(0, atoll(e));
+    return 0;
+}
+
 inline GunzipperPool &gunzipper_pool() {
     static GunzipperPool *p = new GunzipperPool();  // (never destroyed, as the inflaters)
     return *p;
@@ -1049,7 +1056,7 @@ struct TextJob {
                 const double tg = now_s();
                 int grc = gunzipper_pool().open(&gzr_, device, tr.map, (int64_t)tr.map_len);
                 // (writers behind this job: a small first batch, so that they start after 10 ms and not after the 27 a full batch takes)
-                if (grc == GS_OK && (c.filtered.active() || c.kraken.active())) grc = gs_gunzipper_first_span(gzr_, gunzip_first_span());
+                if (grc == GS_OK) grc = gs_gunzipper_first_span(gzr_, (c.filtered.active() || c.kraken.active()) ? gunzip_first_span() : gunzip_first_span_match());
                 if (grc == GS_OK) grc = gs_gunzipper_next(gzr_, 0, &gz_text_, &gz_n_, &gz_last_);  // (the first batch now: a stream this path does not take shows here)
                 if (trace) fprintf(stderr, "gunzip on the device: rc %d, first batch %lld bytes of text, %.2f ms%s%s\n", grc, (long long)gz_n_, (now_s() - tg) * 1e3, grc ? ": " : "", grc ? gs_inflate_last_error() : "");
                 if (grc == GS_OK) {

@@ -91,8 +91,11 @@ struct GiWave {
     };
     uint16_t dwork[32];
     uint16_t lcount[16], dcount[16], offs[16];
-    uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
-    uint32_t lut[64];        // base | extra bits << 16 of the length symbols (0..28) and, from 32 on, of the distance symbols (0..29)
+    union {
+        uint8_t lens[320 + 32];  // (the lengths of a dynamic block are decoded at an offset of 24 and moved into place)
+        uint32_t lut[64];        // while a block's symbols are decoded (the lengths have become tables by then): base | extra bits << 16
+                                 // of the length symbols (0..28) and, from 32 on, of the distance symbols (0..29)
+    };
 };
 
 __constant__ uint8_t gi_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -553,15 +556,6 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
     uint32_t visible = 0;      // every byte below this offset is known to have reached memory
     int err = GI_OK;
     bool last = false, lfast = true, dfast = true;
-    {   // the token decoder's table of bases and extra bits (RFC 1951 3.2.5)
-        uint32_t base = 0, extra = 0;
-        if (lane < 29)
-            gi_len_sym((uint32_t)lane, base, extra);
-        else if (lane >= 32 && lane < 62)
-            gi_dist_sym((uint32_t)lane - 32u, base, extra);
-        w.lut[lane] = base | (extra << 16);
-        gi_lds_sync();
-    }
     auto flush = [&]() {
         if (npend) {
             const uint32_t at = pos - npend + (uint32_t)lane;
@@ -627,6 +621,14 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
         if (lfast && dfast) {
             // ---- the symbols of the block, 64 bit offsets at a time (see the head of the file)
             flush();
+            {   // the token decoder's table of bases and extra bits (RFC 1951 3.2.5), where the block's code lengths were
+                uint32_t base = 0, extra = 0;
+                if (lane < 29)
+                    gi_len_sym((uint32_t)lane, base, extra);
+                else if (lane >= 32 && lane < 62)
+                    gi_dist_sym((uint32_t)lane - 32u, base, extra);
+                w.lut[lane] = base | (extra << 16);
+            }
             u64 P = b.consumed();                         // the reader's position, bits from the start of the payload
             const u64 plimit = (u64)in_len * 8u;      // a token that starts behind it: the stream has run off its payload
             uint32_t k = (uint32_t)(P >> 11);             // pieces k and k + 1 are in w.cbuf, piece k + 2 is on its way
@@ -1286,8 +1288,9 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
     }
 }
 
-// (96 VGPRs and 7.2 KB of LDS per wave: five waves per SIMD, 20 per CU)
-__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
+// (80 VGPRs and 6.6 KB of LDS per wave: six waves per SIMD, 24 per CU -- the LDS of a CU is handed out in pieces of 1 280 bytes:
+// a workgroup of 32 064 bytes fits four times, not five, which cost a third of the kernel's speed before it was noticed)
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void gi_segment_kernel(const uint8_t *in, uint32_t in_len, const GiSeg *segs, int64_t n_segs,
                                                                                                            uint16_t *sym, int32_t *status, uint32_t *out_len,
                                                                                                            u64 *end_bit, unsigned long long *next_seg) {
     __shared__ GiWave s_w[GI_WAVES];
@@ -1626,8 +1629,8 @@ static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a C
     return v;
 }
 
-static int gi_seg_wgs_per_cu() {  // ... of gi_segment_kernel: five (2 KB of ring per wave, 96 VGPRs)
-    int v = 5;
+static int gi_seg_wgs_per_cu() {  // ... of gi_segment_kernel: six (26.3 KB of LDS per workgroup in pieces of 1 280 bytes, 80 VGPRs)
+    int v = 6;
     if (const char *e = getenv("GS_GUNZIP_WGS")) v = std::max(1, std::min(8, atoi(e)));
     return v;
 }
