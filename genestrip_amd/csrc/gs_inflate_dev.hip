@@ -1135,8 +1135,10 @@ __device__ bool gi_header_plausible(const uint8_t *in, uint32_t in_len, u64 o, u
 // GI_FIND_MAX of them, in stream order; in the stream's last MiB the final block as well), through three sieves of falling width and
 // rising cost --
 //   1. every offset: the type bits and the two code counts (one offset in nine passes).  The chunk goes through registers in pieces
-//      of 512 bytes (lane i holds dwords i and 64 + i, the next piece is on its way); a group of 64 offsets takes its three dwords
-//      with v_readlane, so a group is ~25 instructions and no memory latency.  The survivors' offsets are queued in LDS;
+//      of 512 bytes (lane i holds dwords i and 64 + i, the next piece is on its way); a lane tests the 32 offsets that start in its
+//      dword AT ONCE -- the three type bits and "HLIT, HDIST are not 30 or 31" are ~25 bit operations on the dword pair shifted by
+//      the fields' places (the first version tested one offset per lane: 22 instructions per 64 offsets instead of per 2 048) --
+//      and hands its survivors to a queue in LDS, one per trip;
 //   2. 64 queued offsets at a time: the code length code is complete (Kraft sum exactly one: one in 250 of those);
 //   3. 64 of those at a time, one per lane: gi_header_plausible (above);
 // and what is left -- real block starts, and a mirage per 100 MB -- through gi_dynamic_header by the whole wave.
@@ -1166,8 +1168,6 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
     GiWave &w = s_w[wib];
     uint32_t *const q1 = s_q1[wib], *const q2 = s_q2[wib];
     typedef uint32_t __attribute__((aligned(1))) u32_any;
-    const bool low_half = lane < 32;
-    const uint32_t sh = (uint32_t)lane & 31u;
     for (;;) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long take = 0;
@@ -1179,18 +1179,18 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
         // as its longest segment.  (A search of its own: twice the candidates in one chunk would make that wave the kernel's last.)
         const bool fin = ci >= n_real;
         const u64 lo_byte = (u64)(fin ? fin_first + (ci - n_real) : ci) * chunk_bytes;
-        const uint32_t type_bits = fin ? 5u : 4u;
         const u64 lo = lo_byte * 8u;
         const u64 hi_byte = lo_byte + chunk_bytes < (u64)in_len ? lo_byte + chunk_bytes : (u64)in_len;
         const uint32_t n_bits = (uint32_t)(hi_byte - lo_byte) * 8u;  // (offsets are kept relative to `lo`: a chunk is less than 512 MiB)
         uint32_t n1 = 0, h1 = 0, n2 = 0, n_found = 0, grp = 0;      // (wave-uniform; grp: groups of 64 offsets searched so far)
+        uint32_t pend = 0, pend_base = 0;  // sieve 1's survivors among this lane's 32 offsets from pend_base + 32 * lane on, not yet queued
         const uint8_t *const p0 = in + lo_byte + 4u * (uint32_t)lane;
         // the piece being searched: dwords 0 .. 63, 64 .. 127 and 128 of it; the one behind it (the buffer is zero for 1 KiB behind the stream)
         uint32_t r0 = 0, r1 = 0, r2 = 0;
         uint32_t x0 = *reinterpret_cast<const u32_any *>(p0), x1 = *reinterpret_cast<const u32_any *>(p0 + 256);
         uint32_t x2 = *reinterpret_cast<const u32_any *>(in + lo_byte + 512);
         for (;;) {
-            const bool scanned = grp * 64u >= n_bits;
+            const bool scanned = grp * 64u >= n_bits && __ballot(pend != 0u) == 0;
             if (n2 >= 64u || (scanned && n1 == 0u && n2 > 0u)) {
                 // sieve 3, one candidate per lane; then the whole header for what is left, in offset order
                 gi_lds_sync();
@@ -1251,8 +1251,20 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 n1 -= cnt;
                 continue;
             }
+            if (__ballot(pend != 0u) != 0) {
+                // sieve 1's survivors to the queue, one per lane and trip (a lane's 32 offsets hold three or four of them; at most 64
+                // a trip, and the queue is drained above before it holds 64: 63 + 64 of its 256 places)
+                const bool has = pend != 0u;
+                const u64 m = __ballot(has);
+                const uint32_t rel = pend_base + 32u * (uint32_t)lane + (uint32_t)__builtin_ctz(has ? pend : 1u);
+                if (has) q1[(h1 + n1 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 255u] = rel;
+                pend &= pend - 1u;
+                n1 += (uint32_t)__builtin_popcountll(m);
+                continue;
+            }
             if (scanned) break;
-            // sieve 1 over the next eight groups of 64 offsets: not final, dynamic, at most 286 / 30 codes
+            // sieve 1 over the next 2 048 offsets, 32 to a lane and all of them at once: not final, dynamic, at most 286 / 30 codes
+            // as bit operations on (x >> s) for the shifts the header's fields sit at
             if ((grp & 63u) == 0u) {
                 r0 = x0;
                 r1 = x1;
@@ -1265,24 +1277,24 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 }
             }
             {
-                const uint32_t oct = (grp >> 3) & 7u;
-                const uint32_t cur = oct < 4u ? r0 : r1, nxt = oct < 4u ? r1 : r2;
-                const uint32_t d = 16u * (oct & 3u);
-                const uint32_t rel0 = grp * 64u + (uint32_t)lane;
-#pragma unroll
-                for (uint32_t j = 0; j < 8u; j++) {
-                    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d + 2u * j));
-                    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(d + 2u * j + 1u));
-                    const uint32_t s2 = (j == 7u && d == 48u) ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0)
-                                                              : (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)((d + 2u * j + 2u) & 63u));
-                    const uint32_t w0 = __builtin_amdgcn_alignbit(low_half ? s1 : s2, low_half ? s0 : s1, sh);
-                    const uint32_t rel = rel0 + 64u * j;
-                    const bool ok = rel < n_bits && (w0 & 7u) == type_bits && ((w0 >> 3) & 31u) <= 29u && ((w0 >> 8) & 31u) <= 29u;
-                    const u64 m = __ballot(ok);
-                    if (ok) q1[(h1 + n1 + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 255u] = rel;
-                    n1 += (uint32_t)__builtin_popcountll(m);  // (the type bits 0 0 1 -- 1 0 1 -- fit every third offset at most: 22 per group, 63 + 176 in the ring)
-                }
-                grp += 8u;
+                const bool second = (grp & 32u) != 0u;
+                const uint32_t cur = second ? r1 : r0;                                                 // this lane's 32 offsets start in its dword
+                const uint32_t edge = (uint32_t)__builtin_amdgcn_readlane((int)(second ? r2 : r1), 0);  // the dword behind lane 63's
+                uint32_t nxt = (uint32_t)__shfl_down((int)cur, 1);
+                if (lane == 63) nxt = edge;
+#define GI_SH(sft) __builtin_amdgcn_alignbit(nxt, cur, sft)
+                uint32_t m = (fin ? cur : ~cur) & ~GI_SH(1) & GI_SH(2);      // type bits 1 0 1 (final) / 0 0 1, lowest first
+                m &= ~(GI_SH(4) & GI_SH(5) & GI_SH(6) & GI_SH(7));          // HLIT <= 29: not 1111x
+                m &= ~(GI_SH(9) & GI_SH(10) & GI_SH(11) & GI_SH(12));       // HDIST <= 29
+#undef GI_SH
+                pend_base = grp * 64u;
+                const uint32_t mine = pend_base + 32u * (uint32_t)lane;  // offsets at and beyond n_bits are not the chunk's
+                if (mine >= n_bits)
+                    m = 0;
+                else if (n_bits - mine < 32u)
+                    m &= (1u << (n_bits - mine)) - 1u;
+                pend = m;
+                grp += 32u;
             }
         }
     }
@@ -2392,10 +2404,9 @@ extern "C" int gs_gunzipper_next(gs_gunzipper *g, int64_t keep_tail, const uint8
             if (v == ~0ULL) break;
             if (v > rel0) (v < batch_bits ? cands : beyond).push_back(v);
         }
-    if (n_search > n_fchunks) {  // (the final block's place among the others)
-        std::sort(cands.begin(), cands.end());
-        std::sort(beyond.begin(), beyond.end());
-    }
+    // (in stream order: the final block's place among the others; and the finder queues the candidates of 2 048 offsets lane by lane)
+    std::sort(cands.begin(), cands.end());
+    std::sort(beyond.begin(), beyond.end());
     // One segment per wave slot and ONE ROUND of segments per batch: a segment is a wave's work from beginning to end, so the batch
     // takes as long as its longest segment whatever the others do -- blocks of the stream (50 KB of gzip -1 .. -6 FASTQ, 300 KB of
     // text, ~12 ms) are dealt out whole, m = floor(blocks / slots) to a segment, and what is left over when the blocks are not a
