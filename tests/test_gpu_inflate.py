@@ -131,6 +131,59 @@ def test_a_literal_behind_more_run_than_the_ring_holds():
             assert got.tobytes() == want, (run, level)
 
 
+def test_chains_of_copies_inside_one_group():
+    """The text of a group of up to 256 symbols is written one lane per symbol: a symbol whose source lies among the same 64 takes it from
+    that lane, after as many rounds of pointer jumping as the chain of copies is deep.  Texts made of periods of 1 .. 70 bytes (overlapping
+    copies, runs), of copies of copies a few bytes back, of groups of 65 .. 256 symbols with a long match in the middle, and of far
+    sources (text, not ring) next to near ones -- as BGZF members (byte ring of 2 KiB) and as single-member streams (symbol ring of 1 Ki,
+    markers in front of every segment)."""
+    rng = np.random.default_rng(2024)
+    texts = []
+    t = bytearray()
+    for period in list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 70]:  # a b a b a b ...: one literal period, then a copy that overlaps itself
+        unit = bytes(rng.integers(65, 91, period, dtype=np.uint8))
+        for reps in (2, 3, 5, 17, 40):
+            t += unit * reps + bytes(rng.integers(97, 123, int(rng.integers(1, 4)), dtype=np.uint8))
+    texts.append(bytes(t))
+    t = bytearray(rng.integers(65, 69, 40, dtype=np.uint8).tobytes())
+    while len(t) < 60000:  # every piece a copy of something 3 .. 60 bytes back, itself a copy: chains of three, four, five inside 64 symbols
+        d = int(rng.integers(3, 61))
+        ln = int(rng.integers(3, 10))
+        src = len(t) - d
+        for i in range(ln):
+            t.append(t[src + i])
+        if rng.integers(0, 5) == 0:
+            t += bytes(rng.integers(65, 69, 1, dtype=np.uint8))
+    texts.append(bytes(t))
+    base = bytes(rng.integers(65, 69, 5000, dtype=np.uint8))
+    t = bytearray(base)
+    while len(t) < 62000:  # short near copies, a long copy (70 .. 250 symbols: two to four rounds of 64), far copies beyond both rings
+        kind = int(rng.integers(0, 4))
+        d = (int(rng.integers(3, 40)), int(rng.integers(900, 1200)), int(rng.integers(1900, 2300)), int(rng.integers(3000, 4900)))[kind]
+        ln = int(rng.integers(70, 251)) if rng.integers(0, 6) == 0 else int(rng.integers(3, 9))
+        src = len(t) - d
+        for i in range(ln):
+            t.append(t[src + i])
+        t += bytes(rng.integers(65, 69, int(rng.integers(0, 3)), dtype=np.uint8))
+    texts.append(bytes(t))
+    parts, want = [], b""
+    for text in texts:
+        for level in (1, 6, 9):
+            data = text[:65000]
+            parts.append(_member(data, level=level))
+            want += data
+    _roundtrip(b"".join(parts), want)
+    for level in (1, 6, 9):
+        whole = b"".join(texts) * 6
+        for chunk in ("8192", "1048576"):
+            os.environ["GS_GUNZIP_CHUNK"] = chunk
+            try:
+                got, _ = ga.gunzip_device(gzip.compress(whole, compresslevel=level, mtime=0), len(whole))
+            finally:
+                del os.environ["GS_GUNZIP_CHUNK"]
+            assert got.tobytes() == whole, (level, chunk)
+
+
 def test_damaged_members_are_reported():
     text = (b"@r1\nACGTACGTAGCTAGCTAGCATCGATCGATCAGCTAGCTAGCTAGCTACGATCGATCGATCGATCGATCAGC\n+\n" + b"I" * 70 + b"\n") * 300
     good = _member(text)
