@@ -1635,6 +1635,13 @@ static int gi_fail(int code, const std::string &m) {
         if (e_ != hipSuccess) return gi_fail(e_ == hipErrorOutOfMemory ? GS_E_NOMEM : GS_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// The occupancy the two decoders are launched for is an LDS budget: a CU's 160 KB are handed out in pieces of 1 280 bytes, so a workgroup
+// that grows by a few bytes across a multiple of that loses a whole workgroup per CU (gi_segment_kernel 10.3 -> 15.5 ms when it did).
+constexpr size_t GI_LDS_PIECE = 1280, GI_LDS_CU = 160 * 1024;
+constexpr size_t gi_lds_pieces(size_t bytes) { return (bytes + GI_LDS_PIECE - 1) / GI_LDS_PIECE * GI_LDS_PIECE; }
+static_assert(6 * gi_lds_pieces(GI_WAVES * (sizeof(GiWave) + GI_RING_SYM * sizeof(uint16_t))) <= GI_LDS_CU, "gi_segment_kernel: six workgroups no longer fit a CU's LDS");
+static_assert(5 * gi_lds_pieces(GI_WAVES * (sizeof(GiWave) + GI_RING) + 4 * 256 * sizeof(uint32_t)) <= GI_LDS_CU, "gi_inflate_kernel: five workgroups no longer fit a CU's LDS");
+
 static int gi_wgs_per_cu() {  // workgroups of four waves per CU (the LDS of a CU holds five of 31.4 KB -- it is handed out in pieces of 1 280 bytes --, 96 VGPRs)
     int v = 5;
     if (const char *e = getenv("GS_INFLATE_WGS")) v = std::max(1, std::min(8, atoi(e)));
