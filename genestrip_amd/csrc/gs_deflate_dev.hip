@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * GD_WAVES) void gd_count_kernel(const uint8_t *
 }
 
 // one wave per piece (pieces drawn in order: blockIdx * GD_WAVES + wave, striding over the grid)
-__global__ __launch_bounds__(64 * GD_WAVES) void gd_deflate_kernel(const uint8_t *text, int64_t n, int64_t n_pieces, uint32_t piece_bytes, const GdTables *tables,
+__global__ __launch_bounds__(64 * GD_WAVES) __attribute__((amdgpu_waves_per_eu(7, 7))) void gd_deflate_kernel(const uint8_t *text, int64_t n, int64_t n_pieces, uint32_t piece_bytes, const GdTables *tables,
                                                                    const uint32_t *crc_raw, uint32_t init_full, uint32_t init_last, uint8_t *slots, uint32_t *sizes) {
     __shared__ GdTables T;
     __shared__ GdWaveLds W[GD_WAVES];
@@ -1014,7 +1014,7 @@ extern "C" int gs_deflater_pack(gs_deflater *d, const uint8_t *d_text, int64_t n
     GD_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(GdTables), hipMemcpyHostToDevice, d->stream));
     // 3. one wave per piece
     const int64_t last_len = n - (n_pieces - 1) * (int64_t)piece;
-    static const int blocks_per_cu = getenv("GS_DEFLATE_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("GS_DEFLATE_BLOCKS_PER_CU"))) : 5;  // (95 VGPRs: five waves per SIMD; 14.2 -> 12.3 ms per 630 MB against four)
+    static const int blocks_per_cu = getenv("GS_DEFLATE_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("GS_DEFLATE_BLOCKS_PER_CU"))) : 7;  // (seven waves per SIMD: 65 VGPRs when the compiler is told to, 21.3 KB of LDS per block; 4 / 5 / 6 / 7 blocks: 26.8 / 24.1 / 23.2 / 21.4 ms per 1.26 GB)
     const int grid = (int)std::min<int64_t>((n_pieces + GD_WAVES - 1) / GD_WAVES, (int64_t)d->n_cu * blocks_per_cu);
     hipLaunchKernelGGL((gd_deflate_kernel), dim3((unsigned)grid), dim3(64 * GD_WAVES), 0, d->stream, d_text, n, n_pieces, piece, d->d_tables, d->d_crc, gs_crc_init_term(piece),
                        gs_crc_init_term((uint64_t)last_len), d->d_slots, d->d_sizes);
