@@ -28,7 +28,7 @@ BLOOM_XOR, BLOOM_MURMUR, BLOOM_BLOCKED = 0, 1, 2
 
 # every symbol include/gsgpu.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = (
-    "gs_last_error", "gs_strerror", "gs_abi_version", "gs_device_count",
+    "gs_last_error", "gs_strerror", "gs_device_cache_trim", "gs_abi_version", "gs_device_count",
     "gs_match_merge", "gs_match_max_contig_reads", "gs_db_create", "gs_db_get_info", "gs_db_destroy", "gs_db_save", "gs_db_load",
     "gs_match_begin", "gs_match_submit", "gs_match_submit_async", "gs_match_wait", "gs_match_sync", "gs_match_finish", "gs_match_reset", "gs_match_destroy",
     "gs_match_device_state", "gs_match_or_bitmap", "gs_match_kernel_time", "gs_match_segments",
@@ -107,7 +107,7 @@ def lib():
     L = C.CDLL(path)
     vp, i32, i64, dbl, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_int
     sig = {
-        "gs_last_error": (C.c_char_p, []), "gs_strerror": (C.c_char_p, [ci]), "gs_abi_version": (ci, []),
+        "gs_last_error": (C.c_char_p, []), "gs_strerror": (C.c_char_p, [ci]), "gs_device_cache_trim": (ci, []), "gs_abi_version": (ci, []),
         "gs_device_count": (ci, [vp]),
         "gs_db_create": (ci, [vp, ci, ci, i64, vp, vp, i32, vp]), "gs_db_get_info": (ci, [vp, vp]),
         "gs_db_destroy": (ci, [vp]), "gs_db_save": (ci, [vp, C.c_char_p]), "gs_db_load": (ci, [vp, ci, C.c_char_p]),

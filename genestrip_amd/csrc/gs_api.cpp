@@ -23,6 +23,128 @@
 
 typedef unsigned long long u64;
 
+// ---------------------------------------------------------------------------------------------------
+// Device blocks between calls.  A file-level call (gs_host_match_files: begin, a few submits, finish, destroy) allocates some twenty
+// buffers -- text banks, queues, result arrays -- and frees them 30 ms later; hipMalloc and hipFree of those cost 5.5 of the 30 ms
+// (GS_HOST_TRACE: the first submit 2.9 ms against 0.09 for the next ones, destroy 2.6).  Every hipMalloc / hipFree of THIS file goes
+// through a small cache instead: a freed block waits (per device, by exact size) for the next request of its size.  hipFree's
+// contract is kept -- the device is idle when it returns --, only the unmapping is saved.  At most GS_DEVICE_CACHE_MB (default 4096)
+// wait, the oldest go first; a block of more than a quarter of that (a big store) is never kept; when an allocation fails everything
+// that waits is freed and the allocation tried again; gs_device_cache_trim() frees it all (gs_host_release_pools calls it).
+// ---------------------------------------------------------------------------------------------------
+#include <deque>
+#include <mutex>
+#include <unordered_map>
+namespace gs_cache {
+struct Block {
+    void *p;
+    size_t n;
+    int dev;
+};
+struct State {
+    std::mutex mu;
+    std::unordered_map<void *, std::pair<size_t, int>> live;  // blocks handed out: size, device
+    std::deque<Block> idle;                                    // blocks that wait, oldest first
+    size_t idle_bytes = 0;
+};
+static State &state() {
+    static State *s = new State();  // (never destroyed: blocks may be freed from static destructors)
+    return *s;
+}
+static size_t cap_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("GS_DEVICE_CACHE_MB");
+        return (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20;
+    }();
+    return v;
+}
+static void drop_idle_locked(State &st, size_t keep_bytes) {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    while (!st.idle.empty() && st.idle_bytes > keep_bytes) {
+        const Block b = st.idle.front();
+        st.idle.pop_front();
+        st.idle_bytes -= b.n;
+        hipSetDevice(b.dev);
+        hipFree(b.p);
+    }
+    if (have) hipSetDevice(cur);
+}
+static hipError_t alloc(void **p, size_t n) {
+    State &st = state();
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        for (auto it = st.idle.begin(); it != st.idle.end(); ++it)
+            if (it->n == n && it->dev == dev) {
+                *p = it->p;
+                st.idle_bytes -= n;
+                st.idle.erase(it);
+                st.live[*p] = {n, dev};
+                return hipSuccess;
+            }
+    }
+    static const bool trace = getenv("GS_CACHE_TRACE") != nullptr;  // (developer: which requests the cache could not serve)
+    if (trace) fprintf(stderr, "device cache: %zu bytes allocated\n", n);
+    e = hipMalloc(p, n);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(st.mu);
+            drop_idle_locked(st, 0);
+        }
+        e = hipMalloc(p, n);
+    }
+    if (e == hipSuccess && n != 0 && n <= cap_bytes() / 4) {
+        std::lock_guard<std::mutex> lk(st.mu);
+        st.live[*p] = {n, dev};
+    }
+    return e;
+}
+static hipError_t release(void *p) {
+    if (!p) return hipSuccess;
+    State &st = state();
+    std::unique_lock<std::mutex> lk(st.mu);
+    const auto it = st.live.find(p);
+    if (it == st.live.end()) {
+        lk.unlock();
+        return hipFree(p);
+    }
+    const Block b{p, it->second.first, it->second.second};
+    st.live.erase(it);
+    lk.unlock();
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (have && cur != b.dev) hipSetDevice(b.dev);
+    const hipError_t e = hipDeviceSynchronize();  // (what hipFree guarantees: nothing on the device uses the block any more)
+    if (have && cur != b.dev) hipSetDevice(cur);
+    lk.lock();
+    st.idle.push_back(b);
+    st.idle_bytes += b.n;
+    drop_idle_locked(st, cap_bytes());
+    return e;
+}
+static void trim() {
+    State &st = state();
+    std::lock_guard<std::mutex> lk(st.mu);
+    drop_idle_locked(st, 0);
+}
+}  // namespace gs_cache
+template <typename T>
+static inline hipError_t gs_cached_malloc(T **p, size_t n) {
+    return gs_cache::alloc(reinterpret_cast<void **>(p), n);
+}
+static inline hipError_t gs_cached_free(void *p) { return gs_cache::release(p); }
+#define hipMalloc gs_cached_malloc
+#define hipFree gs_cached_free
+
+extern "C" int gs_device_cache_trim(void) {
+    gs_cache::trim();
+    return GS_OK;
+}
+
 extern "C" hipError_t gs_launch_match(const GsMatchParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_huge(const GsMatchParams *P, int grid, hipStream_t stream);
 extern "C" hipError_t gs_launch_match_wide(const GsMatchParams *P, int ns, int n_cu, hipStream_t stream);

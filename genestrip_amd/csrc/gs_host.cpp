@@ -2785,6 +2785,7 @@ void release_pools_impl() {
 
 extern "C" int gs_host_release_pools(void) try {
     release_pools_impl();
+    gs_device_cache_trim();  // (the pools' device memory went through the C ABI library's block cache)
     return GS_OK;
 } catch (const std::exception &e) {  // (nothing may leave through the C ABI)
     return hfail(GS_E_INVALID, std::string("unexpected exception: ") + e.what());

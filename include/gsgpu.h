@@ -46,6 +46,11 @@ enum { GS_MEM_HOST = 0, GS_MEM_DEVICE = 1, GS_MEM_DEVICE_TEXT = 2 /* gs_match_su
 
 const char *gs_last_error(void);
 const char *gs_strerror(int code);
+
+/* The library keeps the device buffers of finished runs (text banks, queues, result arrays: up to GS_DEVICE_CACHE_MB, default
+ * 4096) for the next run of the same shape -- allocating and unmapping them is a fifth of a 30 ms file-level call.  This frees
+ * what waits (it is also freed, by itself, when an allocation fails).  The reference has no counterpart: its buffers are JVM heap. */
+int gs_device_cache_trim(void);
 int gs_abi_version(void);
 int gs_device_count(int *n);
 
