@@ -22,6 +22,11 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.gs_strerror(-6).decode() == "no usable gfx950 device"
 
 
+def test_device_cache_trim_needs_no_device():
+    """gs_device_cache_trim frees the device blocks that wait for the next run; with nothing waiting (no GPU here) it just returns"""
+    assert ga.lib().gs_device_cache_trim() == 0
+
+
 def test_host_layer_exports_every_declared_symbol():
     from genestrip_amd import host
     L = host.lib()

@@ -201,6 +201,32 @@ def test_match_files_empty_file(sdb, tmp_path):
     store.close()
 
 
+def test_device_blocks_kept_between_calls_and_trimmed(sdb, tmp_path, monkeypatch):
+    """The C ABI library keeps the device buffers of a finished run for the next one (gs_api.cpp's block cache): calls of the same and
+    of other shapes one after the other, with the cache trimmed in between (gs_host_release_pools -> gs_device_cache_trim) and with a
+    cache of no bytes, give the tables of the first call -- a block is handed out again only when the device is idle and is never zeroed,
+    so a run that counted on fresh memory would show here."""
+    seq, off = synth.reads_host(sdb.genomes, 6000, read_len=150, seed=23)
+    big, small = str(tmp_path / "big.fastq"), str(tmp_path / "small.fastq.gz")
+    _write_fastq(big, seq, off, gz=False)
+    _write_fastq(small, seq[:int(off[700])], off[:701], gz=True)
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)
+    want_big = host.match_files(store, [big])[0]
+    want_small = host.match_files(store, [small])[0]
+    assert want_big[:, :9].any() and want_small[:, :9].any() and not np.array_equal(want_big, want_small)
+    for rnd in range(3):
+        assert np.array_equal(host.match_files(store, [big])[0], want_big)
+        assert np.array_equal(host.match_files(store, [small], kraken_out_path=str(tmp_path / "k.out"), taxids=sdb.taxids)[0], want_small)
+        assert np.array_equal(host.match_files(store, [big], batch_reads=900)[0], want_big)
+        if rnd == 1:
+            host.release_pools()
+            assert ga.lib().gs_device_cache_trim() == 0
+    store.close()
+    store = ga.DeviceKMerStore(31, sdb.kmers, sdb.value_idx, sdb.n_values, sdb.parent_vi)  # (its buffers may be the old store's)
+    assert np.array_equal(host.match_files(store, [big])[0], want_big)
+    store.close()
+
+
 @pytest.mark.parametrize("block", [0, 100, 5000])
 @pytest.mark.parametrize("shape", ["plain", "crlf", "no final newline", "multi-line record", "nul"])
 def test_filter_files_text_path_equals_reference_parser(sdb, tmp_path, monkeypatch, block, shape):
