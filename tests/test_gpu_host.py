@@ -203,9 +203,9 @@ def test_match_files_empty_file(sdb, tmp_path):
 
 def test_device_blocks_kept_between_calls_and_trimmed(sdb, tmp_path, monkeypatch):
     """The C ABI library keeps the device buffers of a finished run for the next one (gs_api.cpp's block cache): calls of the same and
-    of other shapes one after the other, with the cache trimmed in between (gs_host_release_pools -> gs_device_cache_trim) and with a
-    cache of no bytes, give the tables of the first call -- a block is handed out again only when the device is idle and is never zeroed,
-    so a run that counted on fresh memory would show here."""
+    of other shapes one after the other, with the cache trimmed in between (gs_host_release_pools -> gs_device_cache_trim), give the
+    tables of the first call -- a block is handed out again only when the device is idle and is never zeroed, so a run that counted on
+    fresh memory would show here."""
     seq, off = synth.reads_host(sdb.genomes, 6000, read_len=150, seed=23)
     big, small = str(tmp_path / "big.fastq"), str(tmp_path / "small.fastq.gz")
     _write_fastq(big, seq, off, gz=False)
