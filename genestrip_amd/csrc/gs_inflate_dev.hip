@@ -1147,13 +1147,12 @@ __device__ bool gi_header_plausible(const uint8_t *in, uint32_t in_len, u64 o, u
 // per chunk, up to the chunk's first block start only: 5.9 ms for 4 096 chunks of 58 KB.  This one reads the whole stream.)
 #define GI_FIND_MAX 16
 #define GI_FIND_LAUNCHES 64  // finder launches per batch at most (each has a work counter of its own; what is left when they are used up goes into the last one)
-__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
+__global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(5, 5))) void gi_find_kernel(const uint8_t *in, uint32_t in_len, uint32_t chunk_bytes,
                                                                                                         int64_t first, int64_t n_chunks, u64 *start_bit, unsigned long long *next_chunk,
                                                                                                         int text_only, int64_t n_real, int64_t fin_first) {
     __shared__ GiWave s_w[GI_WAVES];
     __shared__ uint32_t s_q1[GI_WAVES][256];  // sieve 1's survivors (a ring; bit offsets from the chunk's first bit)
     __shared__ uint32_t s_q2[GI_WAVES][128];  // sieve 2's survivors
-    __shared__ uint8_t s_sorted[GI_WAVES][64 * 20];
     __shared__ uint8_t s_kraft[4096];  // four code lengths of 3 bits -> their Kraft sum in 1 / 128 (255: more than one)
     for (uint32_t i = threadIdx.x; i < 4096u; i += 64 * GI_WAVES) {
         uint32_t sum = 0;
@@ -1199,7 +1198,9 @@ __global__ __launch_bounds__(64 * GI_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 const bool act = (uint32_t)lane < cnt;
                 const uint32_t rel = q2[act ? lane : 0];
                 const uint32_t rest = q2[64u + (uint32_t)lane < n2 ? 64u + (uint32_t)lane : 0u];
-                const bool good = act && gi_header_plausible(in, in_len, lo + rel, &s_sorted[wib][20 * lane], text_only != 0);
+                // (a lane's 20 bytes of symbols in canonical order lie in the wave's literal table, which gi_dynamic_header builds anew
+                // below: five workgroups of 28.4 KB fit a CU, with 96 VGPRs five waves a SIMD)
+                const bool good = act && gi_header_plausible(in, in_len, lo + rel, reinterpret_cast<uint8_t *>(w.ltab) + 20 * lane, text_only != 0);
                 for (u64 cand = __ballot(good); cand != 0; cand &= cand - 1) {
                     const u64 oc = lo + (u64)(uint32_t)__builtin_amdgcn_readlane((int)rel, __builtin_ctzll(cand));
                     GiBits b;
