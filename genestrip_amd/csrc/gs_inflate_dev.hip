@@ -622,6 +622,20 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
         if (lfast && dfast) {
             // ---- the symbols of the block, 64 bit offsets at a time (see the head of the file)
             flush();
+            // Is this block's text mostly literals of two or three bits (bases under a code of their own: what this library's writer makes
+            // of FASTQ; quality strings of few symbols)?  Then 64 bits hold 25 tokens and more, and the scalar walk over them -- six
+            // dependent instructions and a taken branch per token -- is what a group waits for: such a block takes the walk four tokens
+            // at a time (below).  Decided once per block from the code lengths: half the code space in literals of at most three bits.
+            bool dense;
+            {
+                uint32_t mass = 0;  // in eighths of the code space
+                for (int sidx = lane; sidx < 256; sidx += 64) {
+                    const uint32_t l = w.lens[sidx];
+                    mass += (l >= 1u && l <= 3u) ? (8u >> l) : 0u;
+                }
+                dense = (uint32_t)__builtin_amdgcn_readlane((int)gi_scan_incl(mass), 63) >= 4u;
+                gi_lds_sync();
+            }
             {   // the token decoder's table of bases and extra bits (RFC 1951 3.2.5), where the block's code lengths were
                 uint32_t base = 0, extra = 0;
                 if (lane < 29)
@@ -663,12 +677,44 @@ __device__ int gi_decode_blocks(GiWave &w, typename GiOut<MARK>::T *ring, GiBits
                 const bool stop = kind == GI_EOB || kind == GI_BAD;
                 const uint32_t step = stop ? 64u : t;  // (an end marker ends the walk)
                 u64 chain = 0;
-                uint32_t at = 0;
-                do {  // (a token has at least one bit: at most 64 trips)
-                    chain |= 1ULL << at;
-                    at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
-                } while (at < 64u);
-                uint32_t adv = at;  // bits of this group
+                uint32_t adv;  // bits of this group
+                if (dense) {
+                    // The lanes follow the links first -- where the second, third and fourth token behind every offset starts (three
+                    // cross-lane reads) --, the scalar walk takes every FOURTH token, and the three behind each of those are marked
+                    // through LDS.
+                    const uint32_t j1 = min((uint32_t)lane + step, 64u);
+                    auto hop = [&](uint32_t from, uint32_t table) {  // table[from], or 64 behind the end
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((from & 63u) << 2), (int)table);
+                        return from < 64u ? v : 64u;
+                    };
+                    const uint32_t j2 = hop(j1, j1), j3 = hop(j2, j1), j4 = hop(j2, j2);
+                    u64 fourth = 0;
+                    uint32_t at = 0;
+                    do {
+                        fourth |= 1ULL << at;
+                        at = (uint32_t)__builtin_amdgcn_readlane((int)j4, (int)at);
+                    } while (at < 64u);
+                    uint32_t *const fl = w.slots;
+                    fl[lane] = 0u;
+                    gi_lds_sync();
+                    if (GI_ON(fourth)) {
+                        if (j1 < 64u) fl[j1] = 1u;
+                        if (j2 < 64u) fl[j2] = 1u;
+                        if (j3 < 64u) fl[j3] = 1u;
+                    }
+                    gi_lds_sync();
+                    chain = fourth | __ballot(fl[lane] != 0u);
+                    gi_lds_sync();
+                    const int el = 63 - __builtin_clzll(chain);
+                    adv = (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)step, el);
+                } else {
+                    uint32_t at = 0;
+                    do {  // (a token has at least one bit: at most 64 trips)
+                        chain |= 1ULL << at;
+                        at += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)at);
+                    } while (at < 64u);
+                    adv = at;
+                }
                 if ((__ballot(stop) & chain) != 0) {  // the chain's last token is an end marker
                     const int el = 63 - __builtin_clzll(chain);
                     if ((uint32_t)__builtin_amdgcn_readlane((int)kind, el) == GI_BAD) {
