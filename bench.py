@@ -303,7 +303,9 @@ def _resources(cnt, kern_ms, n_reads, ceil, footprint_key, src):
                              "own_mix_ceiling_G_winst_per_s": round(ceil["valu_mix"] / 1e9, 1),
                              "note": "wave64 VALU instructions over the measured rate of full-rate 32-bit VALU ops at 8 waves per SIMD (gs_calibrate, "
                                      "this run); frac_vs_own_instruction_mix prices the same count against a calibration kernel with the match kernel's "
-                                     "mix -- a ceiling defined by the kernel itself, not a hardware rate"}
+                                     "mix (27 of 64 instructions of the 2.3-cycle class -- and / or / xor / add / sub / lshr / mov on VGPRs and constants --, "
+                                     "37 of the 4.3-cycle class: every compare, select, three-operand, 64-bit and cross-lane instruction; per-opcode "
+                                     "rates: tools/valu_rates.hip, profiles/r04_valu_rates.txt): the share of the SIMDs' cycles the vector pipes are busy"}
         fr["valu_issue"] = out["valu_issue"]["frac"]
     if "SQ_INSTS_SALU" in cnt:
         s = cnt["SQ_INSTS_SALU"] + cnt.get("SQ_INSTS_SMEM", 0.0)

@@ -38,6 +38,27 @@ KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0\n")
 KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n")
 KERNEL(k_add_lit, "v_add_u32 %0, 0x12345678, %0\n")
 KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2\n")
+KERNEL(k_or, "v_or_b32 %0, %0, %1\n")
+KERNEL(k_xor, "v_xor_b32 %0, %0, %1\n")
+KERNEL(k_sub, "v_sub_u32 %0, %0, %1\n")
+KERNEL(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0\n")
+KERNEL(k_lshrrev_b32, "v_lshrrev_b32 %0, %1, %0\n")
+KERNEL(k_min_u32, "v_min_u32 %0, %0, %1\n")
+KERNEL(k_mov, "v_mov_b32 %0, %1\n")
+KERNEL(k_mul_u24, "v_mul_u32_u24 %0, %0, %1\n")
+KERNEL(k_add_e64, "v_add_u32_e64 %0, %0, %1\n")
+KERNEL(k_and_sgpr, "v_and_b32 %0, s40, %0\n")
+KERNEL(k_cmp_cnd, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\n")
+KERNEL(k_addc, "v_add_co_u32 %0, vcc, %0, %1\nv_addc_co_u32 %2, vcc, %2, %3, vcc\n")
+KERNEL(k_and_inline, "v_and_b32 %0, 15, %0\n")
+KERNEL(k_and_lit, "v_and_b32 %0, 0x7fff1234, %0\n")
+KERNEL(k_add_inline, "v_add_u32 %0, 7, %0\n")
+KERNEL(k_add_sgpr, "v_add_u32 %0, s40, %0\n")
+KERNEL(k_lshlrev_vgpr, "v_lshlrev_b32 %0, %1, %0\n")
+KERNEL(k_lshrrev_inline, "v_lshrrev_b32 %0, 3, %0\n")
+KERNEL(k_and_2chains, "v_and_b32 %0, %0, %1\nv_and_b32 %2, %2, %3\n")
+KERNEL(k_bfe_2chains, "v_bfe_u32 %0, %0, 4, 3\nv_bfe_u32 %2, %2, 4, 3\n")
+KERNEL(k_and_indep, "v_and_b32 %0, %1, %2\n")
 KERNEL(k_cmp_sgpr, "v_cmp_eq_u32 s[40:41], %0, %1\n")
 KERNEL(k_cndmask_sgpr, "v_cndmask_b32 %0, %0, %1, s[40:41]\n")
 
@@ -65,6 +86,6 @@ int main() {
     }
     RUN(k_add) RUN(k_and) RUN(k_cndmask) RUN(k_cmp32) RUN(k_cmp64) RUN(k_lshl_add_u64) RUN(k_lshlrev_b64) RUN(k_lshrrev_b64) RUN(k_mad_u64_u32)
     RUN(k_mul_lo) RUN(k_mul_hi) RUN(k_alignbit) RUN(k_bfe) RUN(k_perm) RUN(k_min3) RUN(k_add3) RUN(k_lshl_add_u32) RUN(k_bfrev) RUN(k_readlane)
-    RUN(k_mbcnt) RUN(k_mov_dpp) RUN(k_add_lit) RUN(k_and_or) RUN(k_cmp_sgpr) RUN(k_cndmask_sgpr)
+    RUN(k_mbcnt) RUN(k_mov_dpp) RUN(k_add_lit) RUN(k_and_or) RUN(k_or) RUN(k_xor) RUN(k_sub) RUN(k_lshlrev_b32) RUN(k_lshrrev_b32) RUN(k_min_u32) RUN(k_mov) RUN(k_mul_u24) RUN(k_add_e64) RUN(k_and_sgpr) RUN(k_cmp_cnd) RUN(k_addc) RUN(k_and_inline) RUN(k_and_lit) RUN(k_add_inline) RUN(k_add_sgpr) RUN(k_lshlrev_vgpr) RUN(k_lshrrev_inline) RUN(k_and_2chains) RUN(k_bfe_2chains) RUN(k_and_indep) RUN(k_cmp_sgpr) RUN(k_cndmask_sgpr)
     return 0;
 }
