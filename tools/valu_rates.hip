@@ -59,6 +59,18 @@ KERNEL(k_lshrrev_inline, "v_lshrrev_b32 %0, 3, %0\n")
 KERNEL(k_and_2chains, "v_and_b32 %0, %0, %1\nv_and_b32 %2, %2, %3\n")
 KERNEL(k_bfe_2chains, "v_bfe_u32 %0, %0, 4, 3\nv_bfe_u32 %2, %2, 4, 3\n")
 KERNEL(k_and_indep, "v_and_b32 %0, %1, %2\n")
+KERNEL(k_cmp_cnd3, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_cndmask_b32 %0, %0, %3, vcc\nv_cndmask_b32 %1, %1, %3, vcc\n")
+KERNEL(k_cnd_e64_vcc, "v_cndmask_b32_e64 %0, %0, %1, vcc\n")
+KERNEL(k_cnd_alt, "v_cndmask_b32 %0, %0, %1, vcc\nv_and_b32 %2, %2, %3\n")
+KERNEL(k_cnd2_and, "v_cndmask_b32 %0, %0, %1, vcc\nv_cndmask_b32 %2, %2, %3, vcc\nv_and_b32 %1, %1, %3\n")
+KERNEL(k_cnd64_cnd32, "v_cndmask_b32_e64 %0, %0, %1, vcc\nv_cndmask_b32 %2, %2, %3, vcc\n")
+KERNEL(k_cnd2_indep, "v_cndmask_b32 %0, %1, %3, vcc\nv_cndmask_b32 %2, %1, %3, vcc\n")
+KERNEL(k_cmp_cnd2, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_cndmask_b32 %0, %0, %3, vcc\n")
+KERNEL(k_cmp_cnd_and_cnd, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_and_b32 %1, %1, %3\nv_cndmask_b32 %0, %0, %3, vcc\n")
+KERNEL(k_cmp_cnd_nop_cnd, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\ns_nop 0\nv_cndmask_b32 %0, %0, %3, vcc\n")
+KERNEL(k_cmp64s_cnd64x2, "v_cmp_eq_u32 s[40:41], %0, %1\nv_cndmask_b32_e64 %2, %2, %3, s[40:41]\nv_cndmask_b32_e64 %0, %0, %3, s[40:41]\n")
+KERNEL(k_cmp_cnd64x2, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32_e64 %2, %2, %3, vcc\nv_cndmask_b32_e64 %0, %0, %3, vcc\n")
+KERNEL(k_cmp_cnd32_cnd64, "v_cmp_eq_u32 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_cndmask_b32_e64 %0, %0, %3, vcc\n")
 KERNEL(k_cmp_sgpr, "v_cmp_eq_u32 s[40:41], %0, %1\n")
 KERNEL(k_cndmask_sgpr, "v_cndmask_b32 %0, %0, %1, s[40:41]\n")
 
@@ -86,6 +98,6 @@ int main() {
     }
     RUN(k_add) RUN(k_and) RUN(k_cndmask) RUN(k_cmp32) RUN(k_cmp64) RUN(k_lshl_add_u64) RUN(k_lshlrev_b64) RUN(k_lshrrev_b64) RUN(k_mad_u64_u32)
     RUN(k_mul_lo) RUN(k_mul_hi) RUN(k_alignbit) RUN(k_bfe) RUN(k_perm) RUN(k_min3) RUN(k_add3) RUN(k_lshl_add_u32) RUN(k_bfrev) RUN(k_readlane)
-    RUN(k_mbcnt) RUN(k_mov_dpp) RUN(k_add_lit) RUN(k_and_or) RUN(k_or) RUN(k_xor) RUN(k_sub) RUN(k_lshlrev_b32) RUN(k_lshrrev_b32) RUN(k_min_u32) RUN(k_mov) RUN(k_mul_u24) RUN(k_add_e64) RUN(k_and_sgpr) RUN(k_cmp_cnd) RUN(k_addc) RUN(k_and_inline) RUN(k_and_lit) RUN(k_add_inline) RUN(k_add_sgpr) RUN(k_lshlrev_vgpr) RUN(k_lshrrev_inline) RUN(k_and_2chains) RUN(k_bfe_2chains) RUN(k_and_indep) RUN(k_cmp_sgpr) RUN(k_cndmask_sgpr)
+    RUN(k_mbcnt) RUN(k_mov_dpp) RUN(k_add_lit) RUN(k_and_or) RUN(k_or) RUN(k_xor) RUN(k_sub) RUN(k_lshlrev_b32) RUN(k_lshrrev_b32) RUN(k_min_u32) RUN(k_mov) RUN(k_mul_u24) RUN(k_add_e64) RUN(k_and_sgpr) RUN(k_cmp_cnd) RUN(k_addc) RUN(k_and_inline) RUN(k_and_lit) RUN(k_add_inline) RUN(k_add_sgpr) RUN(k_lshlrev_vgpr) RUN(k_lshrrev_inline) RUN(k_and_2chains) RUN(k_bfe_2chains) RUN(k_and_indep) RUN(k_cmp_cnd3) RUN(k_cnd_e64_vcc) RUN(k_cnd_alt) RUN(k_cnd2_and) RUN(k_cnd64_cnd32) RUN(k_cnd2_indep) RUN(k_cmp_cnd2) RUN(k_cmp_cnd_and_cnd) RUN(k_cmp_cnd_nop_cnd) RUN(k_cmp64s_cnd64x2) RUN(k_cmp_cnd64x2) RUN(k_cmp_cnd32_cnd64) RUN(k_cmp_sgpr) RUN(k_cndmask_sgpr)
     return 0;
 }
