@@ -63,10 +63,21 @@ __global__ __launch_bounds__(GS_TEXT_BLOCK) void gs_text_count_kernel(GsTextPara
 __global__ __launch_bounds__(1024) void gs_text_scan_kernel(GsTextParams P, int64_t n_tiles) {
     __shared__ u64 s_part[1024];
     const int t = threadIdx.x;
-    const int64_t per = (n_tiles + 1023) / 1024;
-    const int64_t a = (int64_t)t * per, b = a + per < n_tiles ? a + per : n_tiles;
+    // A thread's run of counts is a stream of cache lines of its own (1 024 such streams): with one dword per load every line was asked
+    // of L2 sixteen times (0.22 ms for the 131 072 tiles of a 512 MiB slice).  Runs of a multiple of 16 counts, read a line -- four
+    // 16-byte loads back to back -- at a time.
+    const int64_t per = ((n_tiles + 1023) / 1024 + 15) & ~(int64_t)15;
+    const int64_t a = (int64_t)t * per < n_tiles ? (int64_t)t * per : n_tiles, b = a + per < n_tiles ? a + per : n_tiles;
     u64 sum = 0;
-    for (int64_t i = a; i < b; i++) sum += P.tile_count[i];
+    int64_t i0 = a;
+    for (; i0 + 16 <= b; i0 += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const uint4 *>(P.tile_count + i0)[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum += (u64)v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    for (int64_t i = i0; i < b; i++) sum += P.tile_count[i];
     s_part[t] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -76,7 +87,24 @@ __global__ __launch_bounds__(1024) void gs_text_scan_kernel(GsTextParams P, int6
         __syncthreads();
     }
     u64 run = s_part[t] - sum;
-    for (int64_t i = a; i < b; i++) {
+    int64_t i1 = a;
+    for (; i1 + 16 <= b; i1 += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const uint4 *>(P.tile_count + i1)[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c0 = v[u].x, c1 = v[u].y, c2 = v[u].z, c3 = v[u].w;
+            v[u].x = (uint32_t)run;
+            v[u].y = (uint32_t)(run + c0);
+            v[u].z = (uint32_t)(run + c0 + c1);
+            v[u].w = (uint32_t)(run + c0 + c1 + c2);
+            run += (u64)c0 + c1 + c2 + c3;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) reinterpret_cast<uint4 *>(P.tile_count + i1)[u] = v[u];
+    }
+    for (int64_t i = i1; i < b; i++) {
         const uint32_t c = P.tile_count[i];
         P.tile_count[i] = (uint32_t)run;
         run += c;
