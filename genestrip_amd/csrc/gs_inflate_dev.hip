@@ -1645,10 +1645,18 @@ __global__ __launch_bounds__(1024) void gi_cut_kernel(const uint8_t *text, int64
     __shared__ u64 s_scan[1024];
     __shared__ u64 s_lo, s_before, s_tile;
     const int t = (int)threadIdx.x;
-    const int64_t per = (n_tiles + 1023) / 1024;
-    const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    const int64_t per = ((n_tiles + 1023) / 1024 + 15) & ~(int64_t)15;  // (a multiple of 16 counts: a thread's run is read a cache line at a time, as in gs_text_scan_kernel)
+    const int64_t lo = (int64_t)t * per < n_tiles ? (int64_t)t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
     u64 mine = 0;
-    for (int64_t i = lo; i < hi; i++) mine += tile_count[i];
+    int64_t i0 = lo;
+    for (; i0 + 16 <= hi; i0 += 16) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = reinterpret_cast<const uint4 *>(tile_count + i0)[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) mine += (u64)v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    for (int64_t i = i0; i < hi; i++) mine += tile_count[i];
     u64 total = 0;
     const u64 incl = gi_block_scan(mine, s_scan, t, &total);
     const u64 target = total & ~3ULL;  // the newline with this number (1-based) ends the last whole record
